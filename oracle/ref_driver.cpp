@@ -1,0 +1,213 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the shipped library.
+//
+// Thin C-ABI driver around the *unmodified* reference decoder
+// (/root/reference/DCSDecoder/DCSDecoder.cpp + DCSDecoderNative.cpp), compiled
+// from where the sources lie by oracle/Makefile into oracle/_ref/libdcsref.so.
+// This file is ours; it only #includes the reference headers.  It exists to
+// (1) pin oracle/dcs_oracle.c against the real reference and (2) generate the
+// golden vectors under tests/golden/ (tests/golden/make_golden.py).
+//
+// The drive recipe is the reference's own ROM-less one (DCSEncoder.cpp:522-571,
+// EncoderTester.cpp:85-137): MinHost + DCSDecoderNative + InitStandalone(os) +
+// SetDefaultVolume(v) + SoftBoot() + LoadAudioStream(ch, ROMPointer(0,bytes),
+// level) + 240 x GetNextSample() per frame.
+//
+// White-box probes (bit cursor, bandTypeBuf, mixing multiplier) read protected
+// members; the standard headers are included first so that the access hack
+// below only touches the reference's own class declarations.
+#include <cstdint>
+#include <cstring>
+#include <cstdlib>
+#include <cstdio>
+#include <memory>
+#include <list>
+#include <map>
+#include <string>
+#include <vector>
+#include <unordered_map>
+#include <unordered_set>
+#include <functional>
+#include <type_traits>
+#include <regex>
+#include <set>
+#include <algorithm>
+
+#define protected public
+#define private public
+#include "DCSDecoderNative.h"
+#undef protected
+#undef private
+
+extern "C" {
+
+// per-frame probe record, captured immediately BEFORE the MainLoop() that
+// produces the frame
+struct RefProbe
+{
+    int32_t active;          // stream still playing on channel 0?
+    int32_t bitOff;          // bits consumed from the start of the stream payload (after header)
+    uint16_t mixMul;         // channel[0].mixingMultiplier before MainLoop rescales it
+    uint16_t volMult;        // master volumeMultiplier
+    uint16_t bandType[16];   // carried band type codes before the frame
+};
+
+static DCSDecoder::OSVersion OsFromInt(int os)
+{
+    switch (os)
+    {
+    case 0: return DCSDecoder::OSVersion::OS93a;
+    case 1: return DCSDecoder::OSVersion::OS93b;
+    case 2: return DCSDecoder::OSVersion::OS94;
+    default: return DCSDecoder::OSVersion::OS95;
+    }
+}
+
+// Decode nch streams loaded on channels 0..nch-1 at tick 0, pulling
+// nFramesOut frames (240 samples each).  streams[i]/lens[i] are copied into
+// padded buffers (the reference bit reader looks ahead up to 4 bytes).
+// probes (optional) receives nFramesOut records for channel 0.
+int ref_decode(int os, int volume, int nch,
+    const uint8_t *const *streams, const size_t *lens, const int *levels,
+    int nFramesOut, int16_t *pcm, RefProbe *probes)
+{
+    if (nch < 1 || nch > 8)
+        return -1;
+
+    std::vector<std::vector<uint8_t>> bufs(nch);
+    for (int i = 0 ; i < nch ; ++i)
+    {
+        bufs[i].assign(streams[i], streams[i] + lens[i]);
+        bufs[i].resize(lens[i] + 64, 0);
+    }
+
+    DCSDecoder::MinHost host;
+    DCSDecoderNative dec(&host);
+    dec.InitStandalone(OsFromInt(os));
+    dec.SetDefaultVolume(volume);
+    dec.SoftBoot();
+    for (int i = 0 ; i < nch ; ++i)
+        dec.LoadAudioStream(i, DCSDecoder::ROMPointer(0, bufs[i].data()), levels[i]);
+
+    for (int f = 0 ; f < nFramesOut ; ++f)
+    {
+        if (probes != nullptr)
+        {
+            auto &ch = dec.channel[0];
+            auto &s = ch.audioStream;
+            RefProbe &pr = probes[f];
+            pr.active = s.playbackBitPtr.IsNull() ? 0 : 1;
+            pr.bitOff = pr.active
+                ? static_cast<int32_t>((s.playbackBitPtr.p.p - s.startPtr.p) * 8 - s.playbackBitPtr.nBits)
+                : -1;
+            pr.mixMul = ch.mixingMultiplier;
+            pr.volMult = dec.volumeMultiplier;
+            // note: at a stream (re)start the reference zeroes bandTypeBuf inside
+            // DecodeStream, after this probe; report what the frame will see
+            bool atStart = pr.active && (s.playbackBitPtr == s.startPtr);
+            for (int i = 0 ; i < 16 ; ++i)
+                pr.bandType[i] = atStart ? 0 : s.bandTypeBuf[i];
+        }
+        for (int i = 0 ; i < 240 ; ++i)
+            *pcm++ = dec.GetNextSample();
+    }
+    return dec.IsOK() ? 0 : -2;
+}
+
+// DCSDecoderNative::GetStreamInfo (DCSDecoderNative.cpp:1486-1537)
+int ref_stream_info(int os, const uint8_t *stream, size_t len,
+    int *nFrames, int *nBytes, int *formatType, int *formatSubType, uint8_t *header16)
+{
+    std::vector<uint8_t> buf(stream, stream + len);
+    buf.resize(len + 64, 0);
+
+    DCSDecoder::MinHost host;
+    DCSDecoderNative dec(&host);
+    dec.InitStandalone(OsFromInt(os));
+    dec.SoftBoot();
+    auto info = dec.GetStreamInfo(DCSDecoder::ROMPointer(0, buf.data()));
+    *nFrames = info.nFrames;
+    *nBytes = info.nBytes;
+    *formatType = info.formatType;
+    *formatSubType = info.formatSubType;
+    memcpy(header16, info.header, 16);
+    return 0;
+}
+
+// White-box frame-level entry: run DecompressFrame for one frame of one stream
+// into a zeroed 512-word frame buffer and return the frequency-domain words,
+// then TransformFrame(volShift) with a caller-given overlap tail.  Used to pin
+// the transform stages separately from the unpackers.
+int ref_transform(int os, uint16_t *frameBuf512, int volShift,
+    uint16_t *overlap16, int16_t *pcm240)
+{
+    DCSDecoder::MinHost host;
+    DCSDecoderNative dec(&host);
+    dec.InitStandalone(OsFromInt(os));
+    dec.SoftBoot();
+    memcpy(dec.frameBuffer, frameBuf512, sizeof(dec.frameBuffer));
+    memcpy(dec.overlapBuffer, overlap16, sizeof(dec.overlapBuffer));
+    dec.decoderImpl->TransformFrame(volShift);
+    memcpy(pcm240, dec.outputBuffer, 240 * sizeof(int16_t));
+    memcpy(overlap16, dec.overlapBuffer, sizeof(dec.overlapBuffer));
+    memcpy(frameBuf512, dec.frameBuffer, sizeof(dec.frameBuffer));
+    return 0;
+}
+
+// White-box: decompress `nFrames` consecutive frames of one stream with a given
+// mixing multiplier, each into a fresh zeroed frame buffer (no transform).
+// out = nFrames x 512 words.  Also returns the per-frame bit offsets.
+int ref_decompress(int os, const uint8_t *stream, size_t len, uint16_t mixMul,
+    int nFrames, uint16_t *out, int32_t *bitOffs, uint16_t *bandTypes /* nFrames x 16, after frame */,
+    int32_t *stopFlags)
+{
+    std::vector<uint8_t> buf(stream, stream + len);
+    buf.resize(len + 64, 0);
+
+    DCSDecoder::MinHost host;
+    DCSDecoderNative dec(&host);
+    dec.InitStandalone(OsFromInt(os));
+    dec.SoftBoot();
+
+    auto &ch = dec.channel[0];
+    dec.InitChannelStream(ch, DCSDecoder::ROMPointer(0, buf.data()));
+    dec.InitStreamPlayback(ch);
+    for (int f = 0 ; f < nFrames ; ++f)
+    {
+        auto &s = ch.audioStream;
+        bitOffs[f] = static_cast<int32_t>((s.playbackBitPtr.p.p - s.startPtr.p) * 8 - s.playbackBitPtr.nBits);
+        ch.mixingMultiplier = mixMul;
+        ch.stop = false;
+        uint16_t fb[0x200];
+        memset(fb, 0, sizeof(fb));
+        dec.decoderImpl->DecompressFrame(ch, fb);
+        memcpy(out + f * 0x200, fb, sizeof(fb));
+        memcpy(bandTypes + f * 16, s.bandTypeBuf, 16 * sizeof(uint16_t));
+        stopFlags[f] = ch.stop ? 1 : 0;
+    }
+    return 0;
+}
+
+// Volume / mixing parameter probes (DCSDecoderNative.cpp:3250-3282, :3042-3121)
+uint16_t ref_volume_multiplier(int volume)
+{
+    DCSDecoder::MinHost host;
+    DCSDecoderNative dec(&host);
+    dec.InitStandalone(DCSDecoder::OSVersion::OS94);
+    dec.SetDefaultVolume(volume);
+    dec.SoftBoot();
+    return dec.volumeMultiplier;
+}
+
+uint16_t ref_mixing_multiplier(int os, int levelSum, int channelVolume)
+{
+    DCSDecoder::MinHost host;
+    DCSDecoderNative dec(&host);
+    dec.InitStandalone(OsFromInt(os));
+    dec.SoftBoot();
+    dec.channel[0].channelVolume = static_cast<uint16_t>(channelVolume);
+    dec.channel[0].mixer[0].curLevel = levelSum;
+    dec.UpdateMixingLevels();
+    return dec.channel[0].mixingMultiplier;
+}
+
+}   // extern "C"
