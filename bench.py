@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the batched DCS frame decode on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dcs93_4096|dcs94_65536|mixed_16384]
+
+One "step" = one pass of the hot path (one kernel launch) over one resident batch of synthetic frames.
+Metric (BASELINE.json): bit-exact int16 PCM samples/s; value = samples of all ranks / max-over-ranks time.
+Multi-GPU: one process per GPU (torch.distributed.run), each rank decodes its own range of the stream
+corpus (weak scaling, no data-path collective: frames of different streams are independent).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(streams, budget_s=12.0):
+    """the CPU checker timed on this box's host cores on a bounded sample of the same workload:
+    the compiled reference (oracle/_ref) when it travelled with the repo, else the oracle port"""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.dcs_oracle import Oracle, Reference, reference_available
+    kind = "reference" if reference_available() else "port"
+    chk = Reference() if kind == "reference" else Oracle()
+    cores = max(1, min(os.cpu_count() or 1, 32))
+
+    def work(args):
+        os_, s, vol, lvl = args
+        nf = (s[0] << 8) | s[1]
+        chk.decode(os_, vol, [s], [lvl], nf)      # ctypes releases the GIL; both libraries are re-entrant
+        return nf
+
+    sample = streams[:max(cores, min(len(streams), 64))]
+    frames = 0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        while time.perf_counter() - t0 < budget_s:
+            frames += sum(ex.map(work, sample))
+    dt = time.perf_counter() - t0
+    return dict(value=frames * 240 / dt, unit="samples/s", cores=cores, kind=kind,
+                sample="%d streams of the workload decoded repeatedly for %.1f s (%d frames), %d threads, "
+                       "one decoder object per stream" % (len(sample), dt, frames, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="dcs93_4096")
+    ap.add_argument("--fpw", type=int, default=0, help="frames per wavefront override (8/16/32/64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import dcsexplorer_amd as D
+    from dcsexplorer_amd import workloads
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    # this rank's range of the corpus: same shape on every rank, different streams (seeds)
+    fn = workloads.WORKLOADS[args.workload]
+    if rank == 0:
+        streams = fn()
+    else:
+        import inspect
+        n_streams = inspect.signature(fn).parameters["n_streams"].default
+        streams = workloads.shifted(fn, rank * n_streams)
+    b = D.build_stream_batch(streams)
+    if args.workload == "mixed_16384":
+        b, _ = workloads.interleave(b)
+    n_frames = int(b["jobs"].size)
+
+    ctx = D.Context(local_rank)
+    if args.fpw:
+        ctx.set_frames_per_wave(args.fpw)
+    batch = ctx.batch(b["blob"], b["srcs"], b["jobs"])
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        batch.run(stream)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run(stream)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # kernel-only average duration by HIP events on the launch stream (roofline denominator)
+    kern_ms = batch.time(max(10, args.steps), stream)
+    algo_bytes = batch.algorithmic_bytes
+
+    # bit-exactness of what was just timed (rank 0, default corpus range): per-stream hashes vs the
+    # reference's committed hashes
+    bit_exact = None
+    if rank == 0:
+        from oracle.dcs_oracle import fnv1a64
+        pcm, err = batch.download()
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "dcs_golden_hashes.json")))["workloads"]
+        if args.workload in gold:
+            if args.workload == "mixed_16384":
+                _, perm = workloads.interleave(D.build_stream_batch(streams))
+                inv = np.empty_like(perm); inv[perm] = np.arange(perm.size)
+                pcm = pcm[inv]
+            first = D.build_stream_batch(streams)["first_job"] if args.workload == "mixed_16384" else b["first_job"]
+            got = ["%016x" % fnv1a64(pcm[first[k]:first[k + 1]].tobytes()) for k in range(len(first) - 1)]
+            bit_exact = bool(got == gold[args.workload]["stream_hashes"]) and not bool(err.any())
+
+    if rank == 0:
+        samples = n_frames * 240 * world * args.steps
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "bit_exact_int16_pcm_samples_per_sec",
+            "value": samples / dt,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int16 (1.15 fixed point, 32-bit integer intermediates)",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "frames_per_gpu_per_step": n_frames,
+                       "samples_per_frame": 240, "frames_per_wave": args.fpw or "auto",
+                       "partition": "range over streams, no collective"},
+            "bit_exact": bit_exact,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "dcsDecodeKernel", "kernel_avg_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(streams)
+        print(json.dumps(out))
+
+    batch.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

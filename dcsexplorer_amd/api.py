@@ -1,0 +1,358 @@
+"""ctypes binding of include/dcs_hip.h.  Fails loudly when the shared library is missing: there is
+no Python or CPU implementation of the decode path in this package."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+OS93A, OS93B, OS94, OS95 = 0, 1, 2, 3
+FMT_93_T0, FMT_93B_T1, FMT_93A_T1, FMT_94_T0, FMT_94_T1_S0, FMT_94_T1_S3 = range(6)
+FRAME_SAMPLES = 240
+FRAME_STOP, FRAME_FATAL = 1, 2
+PREV_NONE = 0xFFFFFFFF
+PREV_EXT = 0x80000000
+XFORM_93, XFORM_94 = 0, 1
+
+# numpy views of the ABI structs (layouts asserted against the library at load time)
+SRC_DTYPE = np.dtype([("streamOff", "<u8"), ("bitOff", "<u4"), ("nBits", "<u4"), ("mixMul", "<u2"),
+                      ("format", "u1"), ("hdrLen", "u1"), ("reserved", "<u4"), ("bandType", "<u2", (16,))])
+JOB_DTYPE = np.dtype([("firstSrc", "<u4"), ("nSrc", "u1"), ("volShift", "u1"), ("xform", "u1"), ("flags", "u1"),
+                      ("prev", "<u4"), ("reserved", "<u4")])
+INDEX_DTYPE = np.dtype([("bitOff", "<u4"), ("nBits", "<u4"), ("bandType", "<u2", (16,)), ("err", "<u4")])
+assert SRC_DTYPE.itemsize == 56 and JOB_DTYPE.itemsize == 16 and INDEX_DTYPE.itemsize == 44
+
+
+class StreamInfo(ctypes.Structure):
+    _fields_ = [("nFrames", ctypes.c_int32), ("nBytes", ctypes.c_int32), ("formatType", ctypes.c_int32),
+                ("formatSubType", ctypes.c_int32), ("header", ctypes.c_uint8 * 16), ("format", ctypes.c_int32),
+                ("hdrLen", ctypes.c_int32), ("nValidFrames", ctypes.c_int32), ("payloadBits", ctypes.c_uint32)]
+
+
+class SynthParams(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("format", ctypes.c_int32), ("nFrames", ctypes.c_int32),
+                ("nBands", ctypes.c_int32), ("strideFromBand", ctypes.c_int32), ("profile", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class DcsError(RuntimeError):
+    def __init__(self, status, msg=""):
+        super().__init__("libdcs_hip status %d %s" % (status, msg))
+        self.status = status
+
+
+_LIB = None
+
+EXPORTS = [
+    "dcs_abi_version", "dcs_index_stream", "dcs_volume_multiplier", "dcs_mixing_multiplier", "dcs_frame_scale",
+    "dcs_stream_params", "dcs_ctx_create", "dcs_ctx_destroy", "dcs_last_error", "dcs_device_count",
+    "dcs_ctx_set_frames_per_wave", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run",
+    "dcs_batch_time", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_device_pcm",
+    "dcs_batch_algorithmic_bytes", "dcs_batch_num_jobs", "dcs_decode_streams", "dcs_count_stream_frames",
+    "dcs_synth_stream", "dcs_plan_chunks",
+]
+
+
+def lib_path():
+    return os.path.join(HERE, "libdcs_hip.so")
+
+
+def load_library():
+    """Load libdcs_hip.so.  If torch is importable it is imported first so that the process uses a
+    single HIP runtime (torch bundles its own libamdhip64 with the same soname)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C dcsexplorer_amd/csrc` (there is no fallback implementation)" % path)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = ctypes.CDLL(path)
+    vp, u32, i32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_size_t
+    L.dcs_abi_version.restype = u32
+    L.dcs_index_stream.restype = i32
+    L.dcs_index_stream.argtypes = [i32, vp, sz, vp, u32, ctypes.POINTER(StreamInfo)]
+    L.dcs_volume_multiplier.restype = ctypes.c_uint16
+    L.dcs_volume_multiplier.argtypes = [ctypes.c_int]
+    L.dcs_mixing_multiplier.restype = ctypes.c_uint16
+    L.dcs_mixing_multiplier.argtypes = [i32, ctypes.c_int, ctypes.c_int]
+    L.dcs_frame_scale.restype = ctypes.c_int
+    L.dcs_frame_scale.argtypes = [ctypes.c_uint16, vp, vp, ctypes.c_int]
+    L.dcs_stream_params.restype = i32
+    L.dcs_stream_params.argtypes = [i32, ctypes.c_int, ctypes.c_int, ctypes.c_int, u32, vp, vp]
+    L.dcs_ctx_create.restype = i32
+    L.dcs_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.dcs_ctx_destroy.restype = None
+    L.dcs_ctx_destroy.argtypes = [vp]
+    L.dcs_last_error.restype = ctypes.c_char_p
+    L.dcs_last_error.argtypes = [vp]
+    L.dcs_device_count.restype = ctypes.c_int
+    L.dcs_ctx_set_frames_per_wave.restype = i32
+    L.dcs_ctx_set_frames_per_wave.argtypes = [vp, ctypes.c_int]
+    L.dcs_decode_batch.restype = i32
+    L.dcs_decode_batch.argtypes = [vp, vp, sz, vp, u32, vp, u32, vp, u32, vp, vp, vp]
+    L.dcs_batch_create.restype = i32
+    L.dcs_batch_create.argtypes = [vp, vp, sz, vp, u32, vp, u32, vp, u32, ctypes.POINTER(vp)]
+    L.dcs_batch_destroy.restype = None
+    L.dcs_batch_destroy.argtypes = [vp]
+    L.dcs_batch_run.restype = i32
+    L.dcs_batch_run.argtypes = [vp, vp]
+    L.dcs_batch_time.restype = i32
+    L.dcs_batch_time.argtypes = [vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    L.dcs_batch_sync.restype = i32
+    L.dcs_batch_sync.argtypes = [vp]
+    L.dcs_batch_download.restype = i32
+    L.dcs_batch_download.argtypes = [vp, vp, vp, vp]
+    L.dcs_batch_device_pcm.restype = vp
+    L.dcs_batch_device_pcm.argtypes = [vp]
+    L.dcs_batch_algorithmic_bytes.restype = ctypes.c_uint64
+    L.dcs_batch_algorithmic_bytes.argtypes = [vp]
+    L.dcs_batch_num_jobs.restype = u32
+    L.dcs_batch_num_jobs.argtypes = [vp]
+    L.dcs_decode_streams.restype = i32
+    L.dcs_count_stream_frames.restype = i32
+    L.dcs_synth_stream.restype = i32
+    L.dcs_synth_stream.argtypes = [ctypes.POINTER(SynthParams), vp, sz, ctypes.POINTER(sz)]
+    L.dcs_plan_chunks.restype = i32
+    L.dcs_plan_chunks.argtypes = [vp, u32, ctypes.c_int, vp, sz, ctypes.POINTER(u32)]
+    _LIB = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _check(st, ctx=None):
+    if st != 0:
+        msg = load_library().dcs_last_error(ctx)
+        raise DcsError(st, msg.decode() if msg else "")
+
+
+# ---------------------------------------------------------------------------------------------- host side
+def index_stream(os_, stream):
+    """dcs_index_stream: returns (index records as INDEX_DTYPE array, StreamInfo)"""
+    L = load_library()
+    buf = np.frombuffer(bytes(stream), dtype=np.uint8)
+    nframes = (int(buf[0]) << 8) | int(buf[1])
+    out = np.zeros(max(nframes, 1), dtype=INDEX_DTYPE)
+    info = StreamInfo()
+    st = L.dcs_index_stream(os_, _ptr(buf), buf.size, _ptr(out), nframes, ctypes.byref(info))
+    if st != 0:
+        raise DcsError(st)
+    return out[:info.nValidFrames], info
+
+
+def volume_multiplier(vol):
+    return load_library().dcs_volume_multiplier(vol)
+
+
+def mixing_multiplier(os_, level_sum, channel_volume=0xFF):
+    return load_library().dcs_mixing_multiplier(os_, level_sum, channel_volume)
+
+
+def frame_scale(vol_mult, mix_muls, active=None):
+    mm = np.ascontiguousarray(mix_muls, dtype=np.uint16).copy()
+    act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+    vs = load_library().dcs_frame_scale(vol_mult, _ptr(mm), _ptr(act), mm.size)
+    return vs, mm
+
+
+def stream_params(os_, volume, level, nframes, channel_volume=0xFF):
+    mm = np.zeros(nframes, dtype=np.uint16)
+    vs = np.zeros(nframes, dtype=np.uint8)
+    _check(load_library().dcs_stream_params(os_, volume, level, channel_volume, nframes, _ptr(mm), _ptr(vs)))
+    return mm, vs
+
+
+def synth_stream(fmt, nframes, seed, nbands=16, stride_from=16, profile=0):
+    L = load_library()
+    p = SynthParams(seed=seed, format=fmt, nFrames=nframes, nBands=nbands, strideFromBand=stride_from,
+                    profile=profile, reserved=0)
+    n = ctypes.c_size_t(0)
+    _check(L.dcs_synth_stream(ctypes.byref(p), None, 0, ctypes.byref(n)))
+    out = np.zeros(n.value, dtype=np.uint8)
+    _check(L.dcs_synth_stream(ctypes.byref(p), _ptr(out), out.size, ctypes.byref(n)))
+    return out.tobytes()
+
+
+def format_os(fmt, prefer_95=False, prefer_93a=False):
+    """an OS version whose decoder parses `fmt`"""
+    if fmt == FMT_93A_T1:
+        return OS93A
+    if fmt == FMT_93B_T1:
+        return OS93B
+    if fmt == FMT_93_T0:
+        return OS93A if prefer_93a else OS93B
+    return OS95 if prefer_95 else OS94
+
+
+def build_stream_batch(streams, extra_frames=0, pad=64):
+    """Host-side batch description for independent streams, each played alone from a fresh decoder
+    (LoadAudioStream(0, ptr, level), DCSDecoderNative.cpp:1387).
+
+    streams: iterable of (os, bytes, volume, level).  Returns dict(blob, srcs, jobs, first_job)."""
+    blob = bytearray()
+    srcs, jobs, first = [], [], []
+    njobs = 0
+    for os_, data, volume, level in streams:
+        idx, info = index_stream(os_, data)
+        nframes = info.nFrames
+        mm, vs = stream_params(os_, volume, level, nframes)
+        while len(blob) & 3:
+            blob.append(0)
+        off = len(blob)
+        blob += bytes(data)
+        blob += bytes(pad)
+        nvalid = info.nValidFrames
+        s = np.zeros(nvalid, dtype=SRC_DTYPE)
+        s["streamOff"] = off
+        s["bitOff"] = idx["bitOff"]
+        s["nBits"] = idx["nBits"]
+        s["mixMul"] = mm[:nvalid]
+        s["format"] = info.format
+        s["hdrLen"] = info.hdrLen
+        s["bandType"] = idx["bandType"]
+        total = nframes + extra_frames
+        j = np.zeros(total, dtype=JOB_DTYPE)
+        nsrc_before = sum(len(x) for x in srcs)
+        j["firstSrc"][:nvalid] = nsrc_before + np.arange(nvalid)
+        j["nSrc"][:nvalid] = 1
+        j["volShift"][:nvalid] = vs[:nvalid]
+        j["volShift"][nvalid:] = 8
+        j["xform"] = XFORM_93 if os_ in (OS93A, OS93B) else XFORM_94
+        j["prev"] = njobs + np.arange(total, dtype=np.int64) - 1
+        j["prev"][0] = PREV_NONE
+        srcs.append(s)
+        jobs.append(j)
+        first.append(njobs)
+        njobs += total
+    first.append(njobs)
+    return dict(blob=bytes(blob), srcs=np.concatenate(srcs) if srcs else np.zeros(0, SRC_DTYPE),
+                jobs=np.concatenate(jobs), first_job=np.array(first, dtype=np.int64))
+
+
+def plan_chunks(jobs, fpw):
+    """dcs_plan_chunks -> (slots [nChunks, fpw] of dict-like structured array, nChunks)"""
+    L = load_library()
+    jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+    n = ctypes.c_uint32(0)
+    _check(L.dcs_plan_chunks(_ptr(jobs), jobs.size, fpw, None, 0, ctypes.byref(n)))
+    raw = np.zeros(n.value * fpw, dtype=np.uint64)
+    _check(L.dcs_plan_chunks(_ptr(jobs), jobs.size, fpw, _ptr(raw), raw.size, ctypes.byref(n)))
+    out = np.zeros(raw.size, dtype=[("job", "<u4"), ("prevSlot", "u1"), ("flags", "u1")])
+    out["job"] = raw & 0xFFFFFFFF
+    out["prevSlot"] = (raw >> 32) & 0xFF
+    out["flags"] = (raw >> 40) & 0xFF
+    return out.reshape(n.value, fpw)
+
+
+def device_count():
+    return load_library().dcs_device_count()
+
+
+# ---------------------------------------------------------------------------------------------- device side
+class Context:
+    """DcsCtx: one GPU.  Raises DcsError(DCS_ERR_NO_DEVICE) when there is no gfx950 device."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = ctypes.c_void_p()
+        st = self.L.dcs_ctx_create(device, ctypes.byref(h))
+        if st != 0:
+            msg = self.L.dcs_last_error(None)
+            raise DcsError(st, msg.decode() if msg else "")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.dcs_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_frames_per_wave(self, fpw):
+        _check(self.L.dcs_ctx_set_frames_per_wave(self.h, fpw), self.h)
+
+    def decode_batch(self, blob, srcs, jobs, tails_in=None, want_tails=False):
+        blob_a = np.frombuffer(bytes(blob), dtype=np.uint8)
+        srcs = np.ascontiguousarray(srcs, dtype=SRC_DTYPE)
+        jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+        n = jobs.size
+        pcm = np.zeros((n, FRAME_SAMPLES), dtype=np.int16)
+        err = np.zeros(n, dtype=np.uint32)
+        tails = np.zeros((n, 16), dtype=np.int16) if want_tails else None
+        tin = None if tails_in is None else np.ascontiguousarray(tails_in, dtype=np.int16)
+        _check(self.L.dcs_decode_batch(self.h, _ptr(blob_a), blob_a.size, _ptr(srcs), srcs.size, _ptr(jobs), n,
+                                       _ptr(tin), 0 if tin is None else tin.shape[0], _ptr(pcm), _ptr(err),
+                                       _ptr(tails)), self.h)
+        return (pcm, err, tails) if want_tails else (pcm, err)
+
+    def decode_streams(self, streams, extra_frames=0):
+        """streams: iterable of (os, bytes, volume, level) -> (pcm [frames,240], err, first_job)"""
+        b = build_stream_batch(streams, extra_frames)
+        pcm, err = self.decode_batch(b["blob"], b["srcs"], b["jobs"])
+        return pcm, err, b["first_job"]
+
+    def batch(self, blob, srcs, jobs, tails_in=None):
+        return Batch(self, blob, srcs, jobs, tails_in)
+
+
+class Batch:
+    """DcsBatch: a job list resident in HBM"""
+
+    def __init__(self, ctx, blob, srcs, jobs, tails_in=None):
+        self.ctx = ctx
+        self.L = ctx.L
+        blob_a = np.frombuffer(bytes(blob), dtype=np.uint8)
+        srcs = np.ascontiguousarray(srcs, dtype=SRC_DTYPE)
+        jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+        tin = None if tails_in is None else np.ascontiguousarray(tails_in, dtype=np.int16)
+        h = ctypes.c_void_p()
+        _check(self.L.dcs_batch_create(ctx.h, _ptr(blob_a), blob_a.size, _ptr(srcs), srcs.size, _ptr(jobs), jobs.size,
+                                       _ptr(tin), 0 if tin is None else tin.shape[0], ctypes.byref(h)), ctx.h)
+        self.h = h
+        self.n_jobs = jobs.size
+
+    def run(self, stream=None):
+        _check(self.L.dcs_batch_run(self.h, ctypes.c_void_p(stream) if stream else None), self.ctx.h)
+
+    def time(self, iters, stream=None):
+        ms = ctypes.c_float(0)
+        _check(self.L.dcs_batch_time(self.h, ctypes.c_void_p(stream) if stream else None, iters, ctypes.byref(ms)),
+               self.ctx.h)
+        return ms.value
+
+    def sync(self):
+        _check(self.L.dcs_batch_sync(self.h), self.ctx.h)
+
+    def download(self, want_tails=False):
+        pcm = np.zeros((self.n_jobs, FRAME_SAMPLES), dtype=np.int16)
+        err = np.zeros(self.n_jobs, dtype=np.uint32)
+        tails = np.zeros((self.n_jobs, 16), dtype=np.int16) if want_tails else None
+        _check(self.L.dcs_batch_download(self.h, _ptr(pcm), _ptr(err), _ptr(tails)), self.ctx.h)
+        return (pcm, err, tails) if want_tails else (pcm, err)
+
+    @property
+    def algorithmic_bytes(self):
+        return int(self.L.dcs_batch_algorithmic_bytes(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.dcs_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,92 @@
+// dcs_common.h -- internal declarations shared by the host side and the HIP kernels of libdcs_hip.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/dcs_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// Decode tables as the kernels consume them.  Built once on the host from the canonical code lists
+// in dcs_tables.h (dcs_tables.cpp), uploaded at context creation, and staged into LDS by every
+// workgroup (the `lds` part) or read through L1/L2 (the rest).
+//
+// Variable-length codes are decoded with a 256-entry first-level table on the next 8 bits plus a
+// binary trie for the (rare) longer codes:
+//   fast[peek8]  : bit15 set  -> leaf:  bits 11..8 = code length (1..8), bits 7..0 = payload
+//                  bit15 clear -> index of the trie node reached after those 8 bits
+//   trie[n]      : bit15 set  -> leaf payload (bits 7..0); clear -> index of the '0' child, the
+//                  '1' child is the next entry
+// Payload for the 1994+ band-type deltas is delta+16 (0..30); for the 1993b band types it is the
+// raw 6-bit leaf value of the format (<0x1E: keep sub-type, value-0x0F; else toggle, value-0x2E).
+// ---------------------------------------------------------------------------------------------
+#define DCS_CB94_TOTAL   940            // 4+8+32+128+256+512 direct-lookup entries, codebooks 1..6
+#define DCS_TRIE94_MAX   64
+#define DCS_TRIE93_MAX   128
+
+struct DcsLdsTables
+{
+    uint16_t cb94[DCS_CB94_TOTAL];      // entry = nBits<<8 | val   (DCSDecoderNative.cpp:2046-2175 semantics)
+    uint16_t cbInfo[8];                 // per sample code 1..6: maxBits | (base offset into cb94)<<4
+    uint16_t fast94[256];
+    uint16_t trie94[DCS_TRIE94_MAX];
+    uint16_t fast93[256];
+    uint16_t trie93[DCS_TRIE93_MAX];
+    uint16_t xlat94[48];                // [band class 0..2][code] = typeCode | scalingAdj<<8 (:1926-1953)
+    uint8_t  preAdj94[32];              // [0..15] sub-type 0 map, [16..31] sub-type 1..3 map (:1744-1749)
+    uint16_t bandBits93a[64];           // bandBits (0xFF = end of frame) | prefixBits<<8 (:2878-2902)
+    uint16_t scaleCb93a[80];            // value (0xFF = escape) | nBits<<8 | subTable<<12 (:2938-2959)
+    uint8_t  inputs93a[24];             // inputs per band, 18 used (:2865)
+    uint16_t scaleMant[4];              // 0x8000, 0x9838, 0xB505, 0xD745 (:1978)
+    uint16_t pad[4];
+};
+
+struct DcsDevTables
+{
+    DcsLdsTables lds;                   // copied to LDS by each workgroup
+    uint16_t pair93a[2048];             // OS93a Type-1 sample pair table (:2698-2827); read via L1/L2
+    uint16_t fftCoef[256];              // sin block 0..0x7F, cos block 0x80..0xFF, bit-reversed order (:366)
+    uint16_t ovlCoef[16];               // overlap window (:314)
+};
+
+// host-side view (same structure; one process-wide immutable instance)
+const DcsDevTables &dcsTables();
+
+// ---------------------------------------------------------------------------------------------
+// Kernel work list.  The planner (dcs_plan.cpp) cuts the job list into chunks of at most FPW slots;
+// one wavefront decodes one chunk.  A slot is a job to decode; HALO slots are decoded only for the
+// 16-sample tail they hand to a later slot of the same chunk (the predecessor of the chunk's first
+// frame lives in another chunk).
+// ---------------------------------------------------------------------------------------------
+#define DCS_SLOT_HALO      0x01u        // do not write PCM / err for this slot
+#define DCS_SLOT_EXT_TAIL  0x02u        // overlap tail comes from tailsIn[job.prev & 0x7FFFFFFF]
+#define DCS_SLOT_EMPTY     0x80u        // padding
+#define DCS_NO_PREV_SLOT   0xFFu
+
+struct DcsSlot
+{
+    uint32_t job;
+    uint8_t  prevSlot;                  // slot index inside the chunk whose tail overlaps into this one
+    uint8_t  flags;
+    uint16_t reserved;
+};
+
+struct DcsKernelArgs
+{
+    const uint8_t      *blob;
+    uint64_t            blobLen;        // bytes that may be read (allocation is padded beyond this)
+    const DcsSrcDesc   *srcs;
+    const DcsFrameJob  *jobs;
+    const DcsSlot      *slots;          // nChunks x fpw
+    uint32_t            nChunks;
+    uint32_t            nJobs;
+    int16_t            *pcm;            // nJobs x 240
+    uint32_t           *err;            // nJobs
+    const int16_t      *tailsIn;        // k x 16 (may be null)
+    int16_t            *tailsOut;       // nJobs x 16 (may be null)
+    const DcsDevTables *tables;
+};
+
+// planner: returns the number of chunks; slots is resized to nChunks * fpw
+#ifdef __cplusplus
+#include <vector>
+uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw, std::vector<DcsSlot> &slots);
+#endif

@@ -1,0 +1,83 @@
+// dcs_plan.cpp -- cuts a job list into per-wavefront chunks.
+//
+// The only coupling between output frames is the 16-sample overlap tail a frame hands to its
+// successor (DCSDecoderNative.cpp:538-575, :789-812).  Inside a chunk the tail travels through LDS;
+// when a frame's predecessor falls in another chunk it is decoded a second time here as a HALO slot
+// (tail only, no PCM written), which costs 1/fpw extra work and needs no inter-workgroup
+// communication, no second kernel and no extra HBM traffic.
+#include "dcs_common.h"
+#include <vector>
+
+uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw, std::vector<DcsSlot> &slots)
+{
+    slots.clear();
+    if (nJobs == 0 || fpw < 2)
+        return 0;
+    slots.reserve(static_cast<size_t>(nJobs) + nJobs / static_cast<uint32_t>(fpw - 1) + static_cast<size_t>(fpw));
+
+    // slotOf[j] = position of job j inside the chunk being built (valid when stampOf[j] == chunk id)
+    std::vector<uint32_t> stampOf(nJobs, 0xFFFFFFFFu);
+    std::vector<uint8_t> slotOf(nJobs, 0);
+
+    uint32_t chunk = 0;
+    uint32_t used = 0;                  // slots filled in the current chunk
+    const DcsSlot empty{ 0xFFFFFFFFu, DCS_NO_PREV_SLOT, DCS_SLOT_EMPTY, 0 };
+    auto closeChunk = [&]() {
+        while (used < static_cast<uint32_t>(fpw)) { slots.push_back(empty); ++used; }
+        ++chunk;
+        used = 0;
+    };
+    auto inChunk = [&](uint32_t j) { return j < nJobs && stampOf[j] == chunk; };
+
+    for (uint32_t j = 0 ; j < nJobs ; ++j)
+    {
+        const uint32_t prev = jobs[j].prev;
+        const bool ext = prev != DCS_PREV_NONE && (prev & DCS_PREV_EXT) != 0;
+        const bool link = prev != DCS_PREV_NONE && !ext && prev < nJobs && prev != j;
+
+        uint32_t need = (link && !inChunk(prev)) ? 2u : 1u;
+        if (used + need > static_cast<uint32_t>(fpw))
+        {
+            closeChunk();
+            need = link ? 2u : 1u;      // nothing of the new chunk exists yet
+        }
+
+        uint8_t prevSlot = DCS_NO_PREV_SLOT;
+        if (link)
+        {
+            if (!inChunk(prev))
+            {
+                slots.push_back({ prev, DCS_NO_PREV_SLOT, DCS_SLOT_HALO, 0 });
+                stampOf[prev] = chunk;
+                slotOf[prev] = static_cast<uint8_t>(used++);
+            }
+            prevSlot = slotOf[prev];
+        }
+        slots.push_back({ j, prevSlot, static_cast<uint8_t>(ext ? DCS_SLOT_EXT_TAIL : 0), 0 });
+        stampOf[j] = chunk;
+        slotOf[j] = static_cast<uint8_t>(used++);
+        if (used == static_cast<uint32_t>(fpw))
+            closeChunk();
+    }
+    if (used != 0)
+        closeChunk();
+    return chunk;
+}
+
+extern "C" DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw,
+                                     uint64_t *slotsOut, size_t cap, uint32_t *nChunksOut)
+{
+    if (jobs == nullptr || nChunksOut == nullptr || fpw < 2 || fpw > 64)
+        return DCS_ERR_INVALID_ARG;
+    std::vector<DcsSlot> slots;
+    *nChunksOut = dcsPlanChunks(jobs, nJobs, fpw, slots);
+    if (slotsOut != nullptr)
+    {
+        if (cap < slots.size())
+            return DCS_ERR_CAPACITY;
+        for (size_t i = 0 ; i < slots.size() ; ++i)
+            slotsOut[i] = static_cast<uint64_t>(slots[i].job) | (static_cast<uint64_t>(slots[i].prevSlot) << 32)
+                        | (static_cast<uint64_t>(slots[i].flags) << 40);
+    }
+    return DCS_OK;
+}

@@ -1,0 +1,124 @@
+// dcs_streams.cpp -- whole-stream convenience on top of the batch ABI: the shape of the reference's
+// only batch decode, `DCSExplorer --extract-streams` (DCSExplorer.cpp:1628-1907): every stream is
+// played alone through LoadAudioStream(0, ptr, level) (DCSDecoderNative.cpp:1387) and pulled for
+// nFrames (+ taper) frames of 240 samples (ExtractToWAV, DCSExplorer.cpp:1670-1721).  Here each
+// stream starts from a freshly constructed decoder (zero overlap tail, first-frame multiplier 0x7FFF).
+#include "dcs_common.h"
+#include <string.h>
+#include <vector>
+
+namespace {
+
+struct Built
+{
+    std::vector<uint8_t> blob;
+    std::vector<DcsSrcDesc> srcs;
+    std::vector<DcsFrameJob> jobs;
+    std::vector<uint32_t> firstJob;     // per stream, plus a final total
+};
+
+DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, Built &B, bool countOnly)
+{
+    std::vector<DcsFrameIndex> idx;
+    std::vector<uint16_t> mm;
+    std::vector<uint8_t> vs;
+    uint64_t total = 0;
+    for (uint32_t k = 0 ; k < nStreams ; ++k)
+    {
+        const DcsStreamRef &sr = streams[k];
+        if (sr.data == nullptr || sr.len < 3 || sr.os < DCS_OS93A || sr.os > DCS_OS95)
+            return DCS_ERR_INVALID_ARG;
+        const DcsOsVersion os = static_cast<DcsOsVersion>(sr.os);
+        const uint32_t nFrames = (static_cast<uint32_t>(sr.data[0]) << 8) | sr.data[1];
+        if (nFrames == 0)
+            return DCS_ERR_BAD_STREAM;
+        B.firstJob.push_back(static_cast<uint32_t>(total));
+        total += nFrames + extraFrames;
+        if (countOnly)
+            continue;
+
+        idx.resize(nFrames);
+        DcsStreamInfo info;
+        DcsStatus st = dcs_index_stream(os, sr.data, sr.len, idx.data(), nFrames, &info);
+        if (st != DCS_OK)
+            return st;
+        mm.resize(nFrames); vs.resize(nFrames);
+        st = dcs_stream_params(os, sr.volume, sr.level, sr.channelVolume, nFrames, mm.data(), vs.data());
+        if (st != DCS_OK)
+            return st;
+
+        // streams are laid out back to back, each starting on a 4-byte boundary
+        while (B.blob.size() & 3)
+            B.blob.push_back(0);
+        const uint64_t streamOff = B.blob.size();
+        B.blob.insert(B.blob.end(), sr.data, sr.data + sr.len);
+
+        const uint8_t xform = (os == DCS_OS93A || os == DCS_OS93B) ? DCS_XFORM_93 : DCS_XFORM_94;
+        const uint32_t nValid = static_cast<uint32_t>(info.nValidFrames);
+        for (uint32_t f = 0 ; f < nFrames + extraFrames ; ++f)
+        {
+            DcsFrameJob jb;
+            memset(&jb, 0, sizeof(jb));
+            jb.xform = xform;
+            jb.prev = (f == 0) ? DCS_PREV_NONE : static_cast<uint32_t>(B.jobs.size() - 1);
+            if (f < nValid)
+            {
+                DcsSrcDesc sd;
+                memset(&sd, 0, sizeof(sd));
+                sd.streamOff = streamOff;
+                sd.bitOff = idx[f].bitOff;
+                sd.nBits = idx[f].nBits;
+                sd.mixMul = mm[f];
+                sd.format = static_cast<uint8_t>(info.format);
+                sd.hdrLen = static_cast<uint8_t>(info.hdrLen);
+                memcpy(sd.bandType, idx[f].bandType, sizeof(sd.bandType));
+                jb.firstSrc = static_cast<uint32_t>(B.srcs.size());
+                jb.nSrc = 1;
+                jb.volShift = vs[f];
+                B.srcs.push_back(sd);
+            }
+            else
+            {
+                // no active channel: zero spectrum, MainLoop's shift clamps to 8 (:253-260); the frame
+                // still carries the predecessor's overlap tail (the "taper" frame)
+                jb.nSrc = 0;
+                jb.volShift = 8;
+            }
+            B.jobs.push_back(jb);
+        }
+    }
+    B.firstJob.push_back(static_cast<uint32_t>(total));
+    return DCS_OK;
+}
+
+}   // namespace
+
+extern "C" DcsStatus dcs_count_stream_frames(const DcsStreamRef *streams, uint32_t nStreams,
+                                             uint32_t extraFrames, uint64_t *nFramesOut)
+{
+    if (streams == nullptr || nFramesOut == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    Built B;
+    DcsStatus st = buildStreams(streams, nStreams, extraFrames, B, true);
+    if (st == DCS_OK)
+        *nFramesOut = B.firstJob.back();
+    return st;
+}
+
+extern "C" DcsStatus dcs_decode_streams(DcsCtx *ctx, const DcsStreamRef *streams, uint32_t nStreams,
+                                        uint32_t extraFrames, int16_t *pcmOut, size_t pcmCapFrames,
+                                        uint32_t *frameOffsets, uint32_t *errOut)
+{
+    if (ctx == nullptr || streams == nullptr || nStreams == 0 || pcmOut == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    Built B;
+    DcsStatus st = buildStreams(streams, nStreams, extraFrames, B, false);
+    if (st != DCS_OK)
+        return st;
+    if (B.jobs.size() > pcmCapFrames)
+        return DCS_ERR_CAPACITY;
+    if (frameOffsets != nullptr)
+        memcpy(frameOffsets, B.firstJob.data(), sizeof(uint32_t) * B.firstJob.size());
+    return dcs_decode_batch(ctx, B.blob.data(), B.blob.size(), B.srcs.data(), static_cast<uint32_t>(B.srcs.size()),
+                            B.jobs.data(), static_cast<uint32_t>(B.jobs.size()), nullptr, 0, pcmOut, errOut, nullptr);
+}

@@ -1,0 +1,141 @@
+// dcs_tables.cpp -- expands the canonical code lists of dcs_tables.h into the lookup structures the
+// kernels (and the host index pass) use.  See dcs_common.h for the layouts.
+#include "dcs_common.h"
+#include "dcs_tables.h"
+#include <string.h>
+#include <vector>
+
+namespace {
+
+// Build fast[256] + trie[] for a prefix code.  payload(v) maps the list's value to the 8-bit payload.
+template <size_t N, typename F>
+void buildVlc(const DcsVlc (&codes)[N], uint16_t *fast, uint16_t *trie, size_t trieCap, F payload)
+{
+    // binary trie in a temporary pointer form
+    struct Node { int child[2]; int leaf; };
+    std::vector<Node> nodes;
+    nodes.push_back({{-1, -1}, -1});
+    for (const DcsVlc &c : codes)
+    {
+        int n = 0;
+        for (int b = c.len - 1 ; b >= 0 ; --b)
+        {
+            int bit = (c.code >> b) & 1;
+            if (nodes[n].child[bit] < 0)
+            {
+                nodes[n].child[bit] = static_cast<int>(nodes.size());
+                nodes.push_back({{-1, -1}, -1});
+            }
+            n = nodes[n].child[bit];
+        }
+        nodes[n].leaf = payload(c.val) & 0xFF;
+    }
+
+    // flatten: children of an interior node are stored adjacently; the root's children sit at 0,1
+    std::vector<uint16_t> flat;
+    std::vector<int> flatIndexOf(nodes.size(), -1);
+    struct Pending { int node; size_t slot; };
+    std::vector<Pending> work;
+    flat.resize(2);
+    work.push_back({nodes[0].child[0], 0});
+    work.push_back({nodes[0].child[1], 1});
+    for (size_t w = 0 ; w < work.size() ; ++w)
+    {
+        const Node &nd = nodes[work[w].node];
+        flatIndexOf[work[w].node] = static_cast<int>(work[w].slot);
+        if (nd.leaf >= 0)
+            flat[work[w].slot] = static_cast<uint16_t>(0x8000 | nd.leaf);
+        else
+        {
+            size_t base = flat.size();
+            flat.resize(base + 2);
+            flat[work[w].slot] = static_cast<uint16_t>(base);
+            work.push_back({nd.child[0], base});
+            work.push_back({nd.child[1], base + 1});
+        }
+    }
+    memset(trie, 0, trieCap * sizeof(uint16_t));
+    for (size_t i = 0 ; i < flat.size() && i < trieCap ; ++i)
+        trie[i] = flat[i];
+
+    // first-level table on 8 bits
+    for (int v = 0 ; v < 256 ; ++v)
+    {
+        int n = 0, used = 0;
+        while (used < 8 && nodes[n].leaf < 0)
+        {
+            n = nodes[n].child[(v >> (7 - used)) & 1];
+            ++used;
+        }
+        if (nodes[n].leaf >= 0)
+            fast[v] = static_cast<uint16_t>(0x8000 | (used << 8) | nodes[n].leaf);
+        else
+        {
+            // interior after 8 bits: continue from this node's child pair
+            uint16_t slotVal = flat[static_cast<size_t>(flatIndexOf[n])];
+            fast[v] = slotVal;      // = index of its '0' child (bit15 clear)
+        }
+    }
+}
+
+template <size_t N>
+void expandSampleBook(const DcsVlc (&codes)[N], int maxBits, uint16_t *out)
+{
+    for (const DcsVlc &c : codes)
+    {
+        int span = 1 << (maxBits - c.len);
+        for (int i = 0 ; i < span ; ++i)
+            out[(c.code << (maxBits - c.len)) + i] = static_cast<uint16_t>((c.len << 8) | (c.val & 0xFF));
+    }
+}
+
+DcsDevTables build()
+{
+    DcsDevTables t;
+    memset(&t, 0, sizeof(t));
+    static const int maxBits[7] = { 0, 2, 3, 5, 7, 8, 9 };      // DCSDecoderNative.cpp:2005
+    int base = 0;
+    uint16_t *cb = t.lds.cb94;
+    auto put = [&](int k, auto &codes) {
+        expandSampleBook(codes, maxBits[k], cb + base);
+        t.lds.cbInfo[k] = static_cast<uint16_t>((base << 4) | maxBits[k]);
+        base += 1 << maxBits[k];
+    };
+    put(1, kVlc94Sample1); put(2, kVlc94Sample2); put(3, kVlc94Sample3);
+    put(4, kVlc94Sample4); put(5, kVlc94Sample5); put(6, kVlc94Sample6);
+
+    buildVlc(kVlc94BandTypeDelta, t.lds.fast94, t.lds.trie94, DCS_TRIE94_MAX, [](int v) { return v + 16; });
+    buildVlc(kVlc93BandType, t.lds.fast93, t.lds.trie93, DCS_TRIE93_MAX, [](int v) { return v; });
+
+    for (int i = 0 ; i < 16 ; ++i)
+    {
+        t.lds.xlat94[i] = kXlatB02[i];
+        t.lds.xlat94[16 + i] = kXlatB35[i];
+        t.lds.xlat94[32 + i] = kXlatB6F[i];
+        t.lds.preAdj94[i] = kPreAdjSub0[i];
+        t.lds.preAdj94[16 + i] = kPreAdjSub3[i];
+    }
+    memcpy(t.lds.bandBits93a, kBandBits93a, sizeof(t.lds.bandBits93a));
+    memcpy(t.lds.scaleCb93a, kScaleCb93a, sizeof(t.lds.scaleCb93a));
+    for (int i = 0 ; i < 18 ; ++i)
+        t.lds.inputs93a[i] = kInputsPerBand93a[i];
+    memcpy(t.lds.scaleMant, kScaleMant, sizeof(t.lds.scaleMant));
+    memcpy(t.pair93a, kPair93a, sizeof(t.pair93a));
+    memcpy(t.fftCoef, kFftCoef, sizeof(t.fftCoef));
+    memcpy(t.ovlCoef, kOverlapCoef, sizeof(t.ovlCoef));
+    return t;
+}
+
+}   // namespace
+
+const DcsDevTables &dcsTables()
+{
+    static const DcsDevTables tables = build();
+    return tables;
+}
+
+static_assert(sizeof(DcsLdsTables) % 16 == 0, "LDS table block must be a multiple of 16 bytes");
+static_assert(sizeof(DcsSrcDesc) == 56, "DcsSrcDesc layout");
+static_assert(sizeof(DcsFrameJob) == 16, "DcsFrameJob layout");
+static_assert(sizeof(DcsFrameIndex) == 44, "DcsFrameIndex layout");
+static_assert(sizeof(DcsSlot) == 8, "DcsSlot layout");

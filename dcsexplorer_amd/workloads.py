@@ -1,0 +1,130 @@
+"""Seeded synthetic workloads: the BASELINE.json configurations restated on the library's own
+stream writer (the reference ships no audio).  Used by bench.py and by the parity tests; everything is
+derived from integer seeds so the GPU box regenerates byte-identical inputs.
+
+  dcs93_4096     configs[1]: 4096 DCS-93 frames = 64 streams x 64 frames, OS93 Type 0
+  dcs94_65536    configs[2]: 65536 1994+ ("DCS-95 format") frames = 256 streams x 256 frames,
+                 80 % Type 1 sub-type 3, 10 % Type 1 sub-type 0, 10 % Type 0
+  mixed_16384    configs[3]: 128 streams x 128 frames over all six unpack layouts, frames interleaved
+                 so that neighbouring frames of the batch alternate formats
+  corpus         configs[4] stand-in: `titles` synthetic titles of `streams_per_title` streams with
+                 U[20, max_frames] frames each (no ROM corpus exists in the reference tree)
+"""
+import numpy as np
+
+from . import api as D
+
+
+def _splitmix(seed):
+    x = seed & 0xFFFFFFFFFFFFFFFF
+    while True:
+        x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        yield z ^ (z >> 31)
+
+
+def streams_dcs93_4096(n_streams=64, n_frames=64):
+    out = []
+    for k in range(n_streams):
+        strided = (k % 10) == 9
+        s = D.synth_stream(D.FMT_93_T0, n_frames, seed=0x93020002 + k, nbands=12 if strided else 16,
+                           stride_from=6 if strided else 16, profile=0)
+        out.append((D.OS93A if (k & 1) else D.OS93B, s, 255, 0x64))
+    return out
+
+
+def streams_dcs94_65536(n_streams=256, n_frames=256):
+    out = []
+    for k in range(n_streams):
+        m = k % 10
+        fmt = D.FMT_94_T0 if m == 0 else D.FMT_94_T1_S0 if m == 1 else D.FMT_94_T1_S3
+        s = D.synth_stream(fmt, n_frames, seed=0x94000003 + k, nbands=16, stride_from=16 if (k % 7) else 12,
+                           profile=0)
+        out.append((D.OS95 if (k & 1) else D.OS94, s, 220, 0x64))
+    return out
+
+
+def streams_mixed_16384(n_streams=128, n_frames=128):
+    out = []
+    for k in range(n_streams):
+        fmt = k % 6
+        os_ = D.format_os(fmt, prefer_95=bool(k & 8), prefer_93a=bool(k & 8))
+        s = D.synth_stream(fmt, n_frames, seed=0x00040004 + k, nbands=18 if fmt == D.FMT_93A_T1 else 16,
+                           stride_from=16, profile=k % 3)
+        out.append((os_, s, 200 + (k % 56), 0x60 + (k % 16)))
+    return out
+
+
+def streams_corpus(titles=29, streams_per_title=600, max_frames=2000, seed=0x0005):
+    out = []
+    for t in range(titles):
+        g = _splitmix(seed * 1000003 + t)
+        era = t % 4                      # 0: OS93a, 1: OS93b, 2: OS94, 3: OS95
+        for k in range(streams_per_title):
+            r = next(g)
+            nf = 20 + r % (max_frames - 19)
+            if era == 0:
+                fmt = D.FMT_93A_T1 if (r >> 20) % 8 == 0 else D.FMT_93_T0
+            elif era == 1:
+                fmt = D.FMT_93B_T1 if (r >> 20) % 2 else D.FMT_93_T0
+            else:
+                m = (r >> 20) % 10
+                fmt = D.FMT_94_T0 if m == 0 else D.FMT_94_T1_S0 if m == 1 else D.FMT_94_T1_S3
+            s = D.synth_stream(fmt, int(nf), seed=(seed << 32) + t * 100000 + k,
+                               nbands=18 if fmt == D.FMT_93A_T1 else 16, stride_from=16, profile=0)
+            out.append((era, s, 255, 0x60 + (r >> 40) % 16))
+    return out
+
+
+def interleave(batch):
+    """re-order the jobs of a build_stream_batch() result round-robin over the streams, remapping the
+    overlap links; returns (new batch dict, perm) with new_jobs[i] = old_jobs[perm[i]]"""
+    first = batch["first_job"]
+    n_streams = len(first) - 1
+    lens = np.diff(first)
+    order = []
+    for f in range(int(lens.max())):
+        for s in range(n_streams):
+            if f < lens[s]:
+                order.append(first[s] + f)
+    perm = np.array(order, dtype=np.int64)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.size)
+    jobs = batch["jobs"][perm].copy()
+    prev = jobs["prev"].astype(np.int64)
+    link = (prev != D.PREV_NONE) & ((prev & D.PREV_EXT) == 0)
+    prev[link] = inv[prev[link]]
+    jobs["prev"] = prev.astype(np.uint32)
+    nb = dict(batch)
+    nb["jobs"] = jobs
+    return nb, perm
+
+
+def shifted(fn, stream_offset):
+    """the same workload shape over a different range of the (unbounded) seeded corpus: stream k of the
+    result is stream k + stream_offset of the corpus.  Used to give every rank its own range."""
+    import inspect
+    n = inspect.signature(fn).parameters["n_streams"].default
+    return fn(n_streams=n + stream_offset)[stream_offset:]
+
+
+WORKLOADS = {
+    "dcs93_4096": streams_dcs93_4096,
+    "dcs94_65536": streams_dcs94_65536,
+    "mixed_16384": streams_mixed_16384,
+}
+
+
+def build(name, **kw):
+    """returns dict(blob, srcs, jobs, first_job, streams)"""
+    streams = WORKLOADS[name](**kw)
+    b = D.build_stream_batch(streams)
+    b["streams"] = streams
+    if name == "mixed_16384":
+        nb, perm = interleave(b)
+        nb["streams"] = streams
+        nb["perm"] = perm
+        return nb
+    return b

@@ -1,0 +1,261 @@
+/* dcs_hip.h -- C ABI of libdcs_hip.so: batched DCS audio frame decode on AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE hot path of mjrgh/DCSExplorer: DCSDecoderNative's per-frame
+ * decode (bitstream unpack -> dequantise -> inverse transform -> overlap-add -> int16 PCM).  The
+ * reference has no process/device boundary on this path (everything is one C++ object), so the ABI
+ * below is new; every entry point names the reference interface it replaces.  `file:line` citations
+ * are relative to the reference tree (DCSDecoder/...).
+ *
+ *   reference                                              this library
+ *   ----------------------------------------------------   ----------------------------------------
+ *   DCSDecoderNative::GetStreamInfo   (Native.cpp:1486)     dcs_index_stream        (host scan)
+ *   SetMasterVolume + MainLoop scale + UpdateMixingLevels   dcs_volume_multiplier, dcs_mixing_multiplier,
+ *     (Native.cpp:3250, :227-269, :3072-3121)                dcs_frame_scale, dcs_stream_params
+ *   DecoderImpl{93,93a,94x}::DecompressFrame  (:1679-3032)  dcs_decode_batch / dcs_batch_run (HIP kernel,
+ *   DecoderImpl{93,94x}::TransformFrame       (:397-813)     phase 1 = unpack, phase 2 = transform+overlap)
+ *   DCSDecoder::GetNextSample pump  (DCSDecoder.cpp:1579)   DCSDecoderHIP (include/DCSDecoderHIP.h) on top
+ *
+ * Plain C types only; all memory is caller-owned unless a function says otherwise; every function
+ * returns a DcsStatus (0 = ok, negative = error) and never throws.  A DcsCtx is bound to one GPU and
+ * is not thread-safe (same rule as the reference decoder object, DCSDecoder.h:90-105); use one
+ * context per thread / per GPU.  There is NO CPU fallback: if no gfx950 device is usable,
+ * dcs_ctx_create fails with DCS_ERR_NO_DEVICE and nothing decodes.
+ */
+#ifndef DCS_HIP_H
+#define DCS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCS_ABI_VERSION 1
+#define DCS_FRAME_SAMPLES 240          /* PCM samples per frame (DCSDecoder.h:123: 7.68 ms at 31250 Hz) */
+#define DCS_MAX_CHANNELS 8             /* DCSDecoderNative.h:305 */
+
+typedef int32_t DcsStatus;
+enum
+{
+    DCS_OK = 0,
+    DCS_ERR_INVALID_ARG   = -1,
+    DCS_ERR_NO_DEVICE     = -2,        /* no usable gfx950 GPU / HIP runtime failure at init */
+    DCS_ERR_HIP           = -3,        /* a HIP call failed; see dcs_last_error() */
+    DCS_ERR_NO_MEMORY     = -4,
+    DCS_ERR_CAPACITY      = -5,        /* caller-provided output array too small */
+    DCS_ERR_BAD_STREAM    = -6         /* stream unusable (e.g. zero frames, truncated header) */
+};
+
+/* OS generation of the ROM the stream comes from (DCSDecoder.h:846-900).  OS94 and OS95 share one
+ * audio format; OS93a differs from OS93b in its Type-1 streams and its mixing base. */
+typedef enum DcsOsVersion { DCS_OS93A = 0, DCS_OS93B = 1, DCS_OS94 = 2, DCS_OS95 = 3 } DcsOsVersion;
+
+/* Unpack layout of a stream = (OS family, header type bit, 94x sub-type == 0?)
+ * (DCSDecoderNative.cpp:3147-3160, :1707-1712, :2308, :2841). */
+typedef enum DcsFormat
+{
+    DCS_FMT_93_T0     = 0,             /* OS93a/OS93b Type 0  (DecoderImpl93, fixed-width bands)        */
+    DCS_FMT_93B_T1    = 1,             /* OS93b Type 1        (Huffman band types, differential)        */
+    DCS_FMT_93A_T1    = 2,             /* OS93a Type 1        (1-byte header, pair-table VQ)            */
+    DCS_FMT_94_T0     = 3,             /* OS94/95 Type 0                                                 */
+    DCS_FMT_94_T1_S0  = 4,             /* OS94/95 Type 1, sub-type 0 pre-adjust map                      */
+    DCS_FMT_94_T1_S3  = 5              /* OS94/95 Type 1, sub-type 1..3 pre-adjust map                   */
+} DcsFormat;
+
+/* per-frame error bits (dcs_decode_batch errOut / DcsFrameIndex.err) */
+#define DCS_FRAME_STOP   1u            /* the reference's channel.stop: corrupt band, zeroed (:1989, :2216) */
+#define DCS_FRAME_FATAL  2u            /* malformed beyond what the reference defines (it has UB there):
+                                          decode of the frame stops at that point; STOP is raised too    */
+
+/* ------------------------------------------------------------------------------------------------
+ * Index pass: the carried state that makes a frame independently decodable.
+ * Replaces the serial walk of GetStreamInfo (DCSDecoderNative.cpp:1486-1537); there is no frame
+ * index or sync word in a DCS stream, a frame's bit offset is only known after decoding every
+ * earlier frame (:1715, :2260), and the 1994+/1993b-Type-1 formats delta-code band types (:1833, :2428).
+ */
+typedef struct DcsFrameIndex
+{
+    uint32_t bitOff;                   /* first bit of the frame, counted from the first payload byte   */
+    uint32_t nBits;                    /* bits the frame occupies                                       */
+    uint16_t bandType[16];             /* AudioStream::bandTypeBuf on entry to the frame                */
+    uint32_t err;                      /* DCS_FRAME_* raised while scanning this frame                  */
+} DcsFrameIndex;                       /* 44 bytes */
+
+typedef struct DcsStreamInfo           /* DCSDecoderNative::StreamInfo (DCSDecoderNative.h:106-122)     */
+{
+    int32_t  nFrames;                  /* frame count from the stream's U16 prefix                      */
+    int32_t  nBytes;                   /* bytes from the start of the stream to the bit reader's byte
+                                          pointer after the last frame, look-ahead included (:1509)      */
+    int32_t  formatType;               /* header[0] & 0x80                                              */
+    int32_t  formatSubType;            /* as GetStreamInfo computes it (:1517)                          */
+    uint8_t  header[16];
+    int32_t  format;                   /* DcsFormat                                                     */
+    int32_t  hdrLen;                   /* 16, or 1 for OS93a Type 1 (:1457)                             */
+    int32_t  nValidFrames;             /* frames indexed before a STOP/FATAL ended the stream (the frame
+                                          that raised it is included: the reference still plays it)      */
+    uint32_t payloadBits;              /* exact bit length of the nValidFrames frames                   */
+} DcsStreamInfo;
+
+/* Scan one stream on the host.  `stream` points at the U16 big-endian frame count.  Bytes past
+ * `len` read as zero.  Writes min(nValidFrames, cap) entries to `out` (may be NULL with cap 0 to
+ * only fill `info`).  Returns DCS_ERR_CAPACITY if cap was too small (info is still valid). */
+DcsStatus dcs_index_stream(DcsOsVersion os, const uint8_t *stream, size_t len,
+                           DcsFrameIndex *out, uint32_t cap, DcsStreamInfo *info);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-frame mixing parameters (host arithmetic; inputs to the hot path)
+ */
+/* SetMasterVolume (DCSDecoderNative.cpp:3250-3282): 0..255 -> 1.15 PCM multiplier */
+uint16_t dcs_volume_multiplier(int volume);
+/* UpdateMixingLevels multiplier (:3072-3121): sum of mixing levels (level byte << 6 each), channel
+ * volume 0..255 (ignored for OS93a, which starts from 0x7FFF) */
+uint16_t dcs_mixing_multiplier(DcsOsVersion os, int levelSum, int channelVolume);
+/* MainLoop's shared scale (:227-269): given the (unscaled) multipliers of the channels that are
+ * active this frame, computes volShift (0..8) and rescales each multiplier in place. */
+int dcs_frame_scale(uint16_t volMult, uint16_t *mixMul, const uint8_t *active, int nch);
+/* The sequence MainLoop produces for ONE stream loaded on channel 0 of a freshly constructed
+ * decoder with LoadAudioStream(0, ptr, level) (:1387): frame 0 uses the constructor's 0x7FFF
+ * (DCSDecoderNative.h:514), later frames the value UpdateMixingLevels left behind. */
+DcsStatus dcs_stream_params(DcsOsVersion os, int volume, int level, int channelVolume,
+                            uint32_t nFrames, uint16_t *mixMulScaled, uint8_t *volShift);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch description
+ */
+typedef struct DcsSrcDesc              /* one channel's contribution to one output frame; 56 bytes     */
+{
+    uint64_t streamOff;                /* byte offset in the blob of the stream's U16 frame count       */
+    uint32_t bitOff;                   /* DcsFrameIndex.bitOff                                          */
+    uint32_t nBits;                    /* DcsFrameIndex.nBits (staging hint; 0 = unknown)               */
+    uint16_t mixMul;                   /* Channel::mixingMultiplier after MainLoop's rescale (:264-269) */
+    uint8_t  format;                   /* DcsFormat                                                     */
+    uint8_t  hdrLen;                   /* 16 or 1                                                       */
+    uint32_t reserved;
+    uint16_t bandType[16];             /* DcsFrameIndex.bandType                                        */
+} DcsSrcDesc;
+
+#define DCS_PREV_NONE 0xFFFFFFFFu      /* overlap tail is all zero (fresh decoder / after silence)      */
+#define DCS_PREV_EXT  0x80000000u      /* | index into the tailsIn array given to the run call          */
+
+#define DCS_XFORM_93  0                /* DecoderImpl93::TransformFrame  (:614-813)                     */
+#define DCS_XFORM_94  1                /* DecoderImpl94x::TransformFrame (:397-576)                     */
+
+typedef struct DcsFrameJob             /* one output frame = one MainLoop pass; 16 bytes                */
+{
+    uint32_t firstSrc;                 /* first of nSrc consecutive DcsSrcDesc, mixed in that order     */
+    uint8_t  nSrc;                     /* 0..8; 0 = silent spectrum (taper frame after a stream ends)   */
+    uint8_t  volShift;                 /* 0..8 (:253-260)                                               */
+    uint8_t  xform;                    /* DCS_XFORM_*: a decoder object has ONE transform (:3147-3160)  */
+    uint8_t  flags;                    /* reserved, 0                                                   */
+    uint32_t prev;                     /* job whose last 16 samples overlap into this frame (:569-575,
+                                          :810-812), or DCS_PREV_NONE, or DCS_PREV_EXT | k              */
+    uint32_t reserved;
+} DcsFrameJob;
+
+/* ------------------------------------------------------------------------------------------------
+ * Context and execution
+ */
+typedef struct DcsCtx DcsCtx;
+
+DcsStatus dcs_ctx_create(int deviceId, DcsCtx **ctx);
+void      dcs_ctx_destroy(DcsCtx *ctx);
+const char *dcs_last_error(const DcsCtx *ctx);     /* ctx may be NULL: last error of ctx_create */
+int       dcs_device_count(void);                  /* does not initialise the GPU runtime further than counting */
+
+/* tuning: frames handled per wavefront in the kernel (8, 16, 32 or 64); 0 = choose from batch size */
+DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw);
+
+/* One-shot convenience: host buffers in, host buffers out (H2D, kernel, D2H on the context's
+ * stream, synchronous).  pcmOut = nJobs x 240 int16; errOut (optional) = nJobs x uint32 DCS_FRAME_*.
+ * tailsIn (optional) = 16-sample overlap tails referenced by DCS_PREV_EXT; tailsOut (optional) =
+ * nJobs x 16 samples, the tail each frame leaves for its successor. */
+DcsStatus dcs_decode_batch(DcsCtx *ctx,
+                           const uint8_t *blob, size_t blobLen,
+                           const DcsSrcDesc *srcs, uint32_t nSrcs,
+                           const DcsFrameJob *jobs, uint32_t nJobs,
+                           const int16_t *tailsIn, uint32_t nTailsIn,
+                           int16_t *pcmOut, uint32_t *errOut, int16_t *tailsOut);
+
+/* Resident batches: upload once, run many times, download when wanted.  This is the path bench.py
+ * times (inputs already in HBM when the clock starts). */
+typedef struct DcsBatch DcsBatch;
+
+DcsStatus dcs_batch_create(DcsCtx *ctx,
+                           const uint8_t *blob, size_t blobLen,
+                           const DcsSrcDesc *srcs, uint32_t nSrcs,
+                           const DcsFrameJob *jobs, uint32_t nJobs,
+                           const int16_t *tailsIn, uint32_t nTailsIn,
+                           DcsBatch **batch);
+void      dcs_batch_destroy(DcsBatch *batch);
+/* Enqueue the decode on `hipStream` (a hipStream_t passed as void*; NULL = the context's stream).
+ * Asynchronous: returns after the launch. */
+DcsStatus dcs_batch_run(DcsBatch *batch, void *hipStream);
+/* Run `iters` times bracketed by HIP events on the same stream and return the average kernel
+ * duration in milliseconds (what bench.py's roofline block divides by). */
+DcsStatus dcs_batch_time(DcsBatch *batch, void *hipStream, int iters, float *avgMs);
+DcsStatus dcs_batch_sync(DcsBatch *batch);
+DcsStatus dcs_batch_download(DcsBatch *batch, int16_t *pcmOut, uint32_t *errOut, int16_t *tailsOut);
+/* device pointers, for callers that keep the PCM on the GPU (int16 [nJobs][240]) */
+void     *dcs_batch_device_pcm(DcsBatch *batch);
+/* bytes the kernel reads + writes for this batch, by the definition of SURVEY section 8(d) */
+uint64_t  dcs_batch_algorithmic_bytes(const DcsBatch *batch);
+uint32_t  dcs_batch_num_jobs(const DcsBatch *batch);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-stream convenience (the reference's --extract-streams shape, DCSExplorer.cpp:1628-1907):
+ * index + parameters + decode of nStreams independent streams, each played alone from a fresh
+ * decoder at (volume, level); extraFrames taper frames are appended per stream (ExtractToWAV plays
+ * nFrames+2, :1670-1721).  pcmOut receives the streams back to back; frameOffsets (nStreams+1,
+ * optional) the first output frame of each stream.
+ */
+typedef struct DcsStreamRef
+{
+    const uint8_t *data;               /* U16 frame count, header, payload                              */
+    size_t         len;
+    int32_t        os;                 /* DcsOsVersion                                                  */
+    int32_t        volume;             /* master volume 0..255                                          */
+    int32_t        level;              /* mixing level byte (track opcodes 07-0C), e.g. 0x64            */
+    int32_t        channelVolume;      /* 0..255, normally 255                                          */
+} DcsStreamRef;
+
+DcsStatus dcs_decode_streams(DcsCtx *ctx, const DcsStreamRef *streams, uint32_t nStreams,
+                             uint32_t extraFrames, int16_t *pcmOut, size_t pcmCapFrames,
+                             uint32_t *frameOffsets, uint32_t *errOut);
+/* number of output frames dcs_decode_streams will produce (host-only; runs the index pass) */
+DcsStatus dcs_count_stream_frames(const DcsStreamRef *streams, uint32_t nStreams,
+                                  uint32_t extraFrames, uint64_t *nFramesOut);
+
+/* ------------------------------------------------------------------------------------------------
+ * Synthetic stream writer (seeded, integer-only).  Produces VALID streams
+ * of every unpack layout for tests and benchmarks -- the reference ships no audio (Tests/.gitignore).
+ */
+typedef struct DcsSynthParams
+{
+    uint64_t seed;
+    int32_t  format;                   /* DcsFormat                                                     */
+    int32_t  nFrames;                  /* 1..65535                                                      */
+    int32_t  nBands;                   /* populated header bands: 1..16 (93a Type 1: 1..18)             */
+    int32_t  strideFromBand;           /* first band carrying the half-density 0x40 bit; >= 16 = none   */
+    int32_t  profile;                  /* 0 = default mix, 1 = dense (wide codes), 2 = sparse (many zero
+                                          bands), 3 = adversarial edge cases (max widths, deep codes)   */
+    int32_t  reserved;
+} DcsSynthParams;
+
+/* Returns the stream length in bytes via *lenOut; writes at most cap bytes (DCS_ERR_CAPACITY if the
+ * stream did not fit; call with out = NULL, cap = 0 to size). */
+DcsStatus dcs_synth_stream(const DcsSynthParams *params, uint8_t *out, size_t cap, size_t *lenOut);
+
+/* Diagnostic: the chunk plan the kernel launch would use for `jobs` at `fpw` frames per wavefront.
+ * Each slot is returned as job | prevSlot<<32 | flags<<40 (flags: 1 = halo, 2 = external tail,
+ * 0x80 = padding).  One wavefront decodes one chunk of fpw slots; a frame whose overlap predecessor
+ * lies in another chunk gets that predecessor decoded again as a halo slot. */
+DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw,
+                          uint64_t *slotsOut, size_t cap, uint32_t *nChunksOut);
+
+uint32_t dcs_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCS_HIP_H */

@@ -14,6 +14,7 @@
 #include "dcs_oracle.h"
 #include "dcs_oracle_tables.h"
 #include <string.h>
+#include <stdlib.h>
 
 /* ------------------------------------------------------------------------
  * L0: ADSP-2105 arithmetic (DCSDecoderNative.h:822-906, .cpp:3447-3580)
@@ -903,13 +904,19 @@ int orc_decode(int os, int volume, int nch,
 {
     if (nch < 1 || nch > 8)
         return -1;
-    static Player pl;       /* ~3 KB; static to keep the stack small (not re-entrant: test code) */
+    Player *plp = (Player *)malloc(sizeof(Player));    /* heap: re-entrant, callable from several threads */
+    if (!plp)
+        return -4;
+#define pl (*plp)
     player_init(&pl, os, volume);
     for (int c = 0 ; c < nch ; ++c)
     {
         int r = player_load(&pl, c, streams[c], lens[c], levels[c]);
         if (r != 0)
+        {
+            free(plp);
             return r;
+        }
     }
     for (int f = 0 ; f < nFramesOut ; ++f)
     {
@@ -927,6 +934,8 @@ int orc_decode(int os, int volume, int nch,
         }
         player_tick(&pl, pcm + (size_t)f * 240, NULL);
     }
+#undef pl
+    free(plp);
     return 0;
 }
 
@@ -953,7 +962,7 @@ int orc_frame_params(int os, int volume, int level, int nFrames,
 int orc_stream_info(int os, const uint8_t *stream, size_t len,
     int *nFrames, int *nBytes, int *formatType, int *formatSubType, uint8_t *header16)
 {
-    static Stream s;
+    Stream s;
     stream_open(&s, os, stream, len);
     stream_start(&s);
     for (int i = 0 ; i < s.nFrames ; ++i)
@@ -982,7 +991,7 @@ int orc_transform(int os, uint16_t *frameBuf512, int volShift, uint16_t *overlap
 int orc_decompress(int os, const uint8_t *stream, size_t len, uint16_t mixMul,
     int nFrames, uint16_t *out, int32_t *bitOffs, uint16_t *bandTypes, int32_t *stopFlags)
 {
-    static Stream s;
+    Stream s;
     stream_open(&s, os, stream, len);
     stream_start(&s);
     for (int f = 0 ; f < nFrames ; ++f)

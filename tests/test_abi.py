@@ -1,0 +1,59 @@
+"""the C-ABI library loads and exports every symbol include/dcs_hip.h declares (no GPU needed)"""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "dcs_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dcs_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(dcs):
+    L = dcs.load_library()
+    names = declared_functions()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(L, n), "libdcs_hip.so does not export %s" % n
+    from dcsexplorer_amd.api import EXPORTS
+    assert set(EXPORTS) == set(names)
+
+
+def test_abi_version_and_struct_sizes(dcs):
+    assert dcs.load_library().dcs_abi_version() == 1
+    assert dcs.SRC_DTYPE.itemsize == 56
+    assert dcs.JOB_DTYPE.itemsize == 16
+    assert dcs.INDEX_DTYPE.itemsize == 44
+
+
+def test_no_gpu_means_loud_failure_not_fallback(dcs):
+    """without a gfx950 device the context constructor must raise; nothing decodes on the CPU"""
+    if dcs.device_count() > 0:
+        return
+    try:
+        dcs.Context(0)
+    except dcs.DcsError as e:
+        assert e.status == -2
+    else:
+        raise AssertionError("Context() succeeded without a GPU")
+
+
+def test_product_never_references_oracle():
+    """the shipped package must not import, include or link anything under oracle/"""
+    pkg = os.path.join(ROOT, "dcsexplorer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle/" not in text and "dcs_oracle" not in text and "libdcsref" not in text, \
+                    "%s references the oracle" % os.path.join(dirpath, f)
+    for hdr in os.listdir(os.path.join(ROOT, "include")):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        assert "dcs_oracle" not in text

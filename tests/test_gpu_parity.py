@@ -1,0 +1,159 @@
+"""HIP path vs the oracle, through the C ABI, on a real MI355X.  Bit-exact or fail."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import dcsexplorer_amd as D
+from dcsexplorer_amd import workloads
+from oracle.dcs_oracle import fnv1a64
+from util import ALL_FORMATS, FORMAT_NAMES, make_stream, os_for, corrupt
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def oracle_streams(oracle, streams, extra=0):
+    out = []
+    for os_, s, vol, lvl in streams:
+        nf = (s[0] << 8) | s[1]
+        out.append(oracle.decode(os_, vol, [s], [lvl], nf + extra))
+    return np.concatenate(out)
+
+
+def assert_same(got, want, what=""):
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        f, i = bad[0]
+        raise AssertionError("%s: %d samples differ in %d frames; first at frame %d sample %d: got %d want %d"
+                             % (what, len(bad), len(set(bad[:, 0])), f, i, got[f, i], want[f, i]))
+
+
+def test_native_library_is_what_runs(gpu_ctx):
+    assert os.path.exists(D.lib_path())
+    assert D.device_count() >= 1
+
+
+@pytest.mark.parametrize("fmt", ALL_FORMATS, ids=[FORMAT_NAMES[f] for f in ALL_FORMATS])
+@pytest.mark.parametrize("profile", [0, 1, 2, 3])
+def test_single_stream_every_layout(gpu_ctx, oracle, fmt, profile):
+    for k in range(2):
+        s = make_stream(fmt, 70, seed=11000 + fmt * 32 + profile * 4 + k, profile=profile,
+                        stride_from=16 if k == 0 else 7)
+        streams = [(os_for(fmt, k), s, [255, 220, 0x67, 255][profile], [0x64, 0x7F, 0x64, 0x20][profile])]
+        pcm, err, _ = gpu_ctx.decode_streams(streams, extra_frames=2)
+        assert_same(pcm, oracle_streams(oracle, streams, extra=2), FORMAT_NAMES[fmt])
+        assert not err.any()
+
+
+@pytest.mark.parametrize("fpw", [8, 16, 32, 64])
+def test_frames_per_wave_variants_and_halos(gpu_ctx, oracle, fpw):
+    """chunk boundaries fall inside streams: the overlap tail must come from the halo re-decode"""
+    streams = [(os_for(f, f), make_stream(f, 45 + 13 * f, seed=12000 + f, profile=f % 3), 240, 0x62 + f)
+               for f in ALL_FORMATS]
+    gpu_ctx.set_frames_per_wave(fpw)
+    try:
+        pcm, err, _ = gpu_ctx.decode_streams(streams, extra_frames=1)
+    finally:
+        gpu_ctx.set_frames_per_wave(0)
+    assert_same(pcm, oracle_streams(oracle, streams, extra=1), "fpw=%d" % fpw)
+
+
+def test_golden_vectors(gpu_ctx):
+    """committed reference PCM (tests/golden/make_golden.py), single-stream cases"""
+    meta = json.load(open(os.path.join(GOLD, "dcs_golden_hashes.json")))
+    arrays = np.load(os.path.join(GOLD, "dcs_golden.npz"))
+    n = 0
+    for case in meta["cases"]:
+        if case["streams"] != 1:
+            continue
+        s = arrays[case["name"] + "/stream"].tobytes()
+        nf = (s[0] << 8) | s[1]
+        pcm, err, _ = gpu_ctx.decode_streams([(case["os"], s, case["volume"], case["levels"][0])],
+                                             extra_frames=case["frames_out"] - nf)
+        assert_same(pcm, arrays[case["name"] + "/pcm"], case["name"])
+        n += 1
+    assert n >= 31
+
+
+def test_interleaved_mixed_format_batch(gpu_ctx, oracle):
+    """configs[3] shape at reduced size: neighbouring frames alternate among the six layouts"""
+    b = workloads.build("mixed_16384", n_streams=30, n_frames=50)
+    pcm, err = gpu_ctx.decode_batch(b["blob"], b["srcs"], b["jobs"])
+    want = oracle_streams(oracle, b["streams"])[b["perm"]]
+    assert_same(pcm, want, "interleaved")
+    assert not err.any()
+
+
+def test_corrupted_streams_match_oracle_error_semantics(gpu_ctx, oracle):
+    """bit-flipped payloads: zeroed bands, stop at the failing frame, silence afterwards"""
+    streams = []
+    for fmt in ALL_FORMATS:
+        for k in range(12):
+            s = corrupt(make_stream(fmt, 20, seed=13000 + fmt * 16 + k, profile=k % 4), seed=100 + k, nflips=3)
+            streams.append((os_for(fmt), s + bytes(1024), 255, 0x64))
+    pcm, err, first = gpu_ctx.decode_streams(streams, extra_frames=2)
+    want = oracle_streams(oracle, streams, extra=2)
+    assert_same(pcm, want, "corrupted")
+    assert err.any()
+
+
+def test_external_tails_and_tails_out(gpu_ctx, oracle):
+    """streaming use: decode a stream in two calls, carrying the 16-sample overlap tail by hand"""
+    for fmt in (D.FMT_93_T0, D.FMT_94_T1_S3):
+        s = make_stream(fmt, 40, seed=14000 + fmt)
+        os_ = os_for(fmt)
+        b = D.build_stream_batch([(os_, s, 255, 0x64)])
+        want = oracle_streams(oracle, [(os_, s, 255, 0x64)])
+        jobs_a = b["jobs"][:17].copy()
+        pcm_a, _, tails_a = gpu_ctx.decode_batch(b["blob"], b["srcs"], jobs_a, want_tails=True)
+        jobs_b = b["jobs"][17:].copy()
+        jobs_b["prev"] = np.arange(jobs_b.size, dtype=np.int64) - 1
+        jobs_b["prev"][0] = D.PREV_EXT | 0
+        pcm_b, _ = gpu_ctx.decode_batch(b["blob"], b["srcs"], jobs_b, tails_in=tails_a[16:17])
+        assert_same(np.concatenate([pcm_a, pcm_b]), want, "two-call streaming")
+
+
+def test_multichannel_mix(gpu_ctx, oracle):
+    """several sources mixed into one output frame (MainLoop's per-channel DecodeStream loop, :272-273)"""
+    meta = json.load(open(os.path.join(GOLD, "dcs_golden_hashes.json")))
+    arrays = np.load(os.path.join(GOLD, "dcs_golden.npz"))
+    from mixer_ref import build_mix_batch
+    for case in meta["cases"]:
+        if case["streams"] == 1:
+            continue
+        streams = [arrays["%s/stream%d" % (case["name"], c)].tobytes() for c in range(case["streams"])]
+        b = build_mix_batch(case["os"], case["volume"], streams, case["levels"], case["frames_out"])
+        pcm, err = gpu_ctx.decode_batch(b["blob"], b["srcs"], b["jobs"])
+        assert_same(pcm, arrays[case["name"] + "/pcm"], case["name"])
+
+
+@pytest.mark.parametrize("wl", ["dcs93_4096", "dcs94_65536", "mixed_16384"])
+def test_full_size_workloads_hash_and_sampled_oracle(gpu_ctx, oracle, wl):
+    """BASELINE.json sizes: per-stream FNV-1a of the HIP PCM == the reference's committed hashes, plus
+    a direct oracle comparison on a sample of streams"""
+    meta = json.load(open(os.path.join(GOLD, "dcs_golden_hashes.json")))["workloads"][wl]
+    b = workloads.build(wl)
+    pcm, err = gpu_ctx.decode_batch(b["blob"], b["srcs"], b["jobs"])
+    assert not err.any()
+    if "perm" in b:
+        inv = np.empty_like(b["perm"]); inv[b["perm"]] = np.arange(b["perm"].size)
+        pcm = pcm[inv]
+    first = b["first_job"]
+    got = ["%016x" % fnv1a64(pcm[first[k]:first[k + 1]].tobytes()) for k in range(len(first) - 1)]
+    assert got == meta["stream_hashes"]
+    for k in range(0, len(b["streams"]), max(1, len(b["streams"]) // 16)):
+        assert_same(pcm[first[k]:first[k + 1]], oracle_streams(oracle, [b["streams"][k]]), "%s stream %d" % (wl, k))
+
+
+def test_batch_is_idempotent_and_resident(gpu_ctx):
+    """a resident batch run twice gives identical PCM; timing entry returns a positive duration"""
+    b = workloads.build("dcs93_4096", n_streams=16, n_frames=32)
+    bt = gpu_ctx.batch(b["blob"], b["srcs"], b["jobs"])
+    bt.run(); p1, _ = bt.download()
+    ms = bt.time(3)
+    p2, _ = bt.download()
+    assert np.array_equal(p1, p2) and ms > 0
+    assert bt.algorithmic_bytes > 480 * 512
+    bt.close()

@@ -1,0 +1,115 @@
+"""host side of the library (no GPU): index pass, mixing parameters, chunk planner, stream writer"""
+import numpy as np
+import pytest
+
+import dcsexplorer_amd as D
+from dcsexplorer_amd import workloads
+from util import ALL_FORMATS, FORMAT_NAMES, make_stream, os_for, corrupt
+
+
+@pytest.mark.parametrize("fmt", ALL_FORMATS, ids=[FORMAT_NAMES[f] for f in ALL_FORMATS])
+def test_index_pass_matches_oracle_probes(oracle, fmt):
+    for k in range(4):
+        s = make_stream(fmt, 60, seed=4200 + fmt * 8 + k, profile=k, stride_from=16 if k < 2 else 8)
+        os_ = os_for(fmt, k)
+        idx, info = D.index_stream(os_, s)
+        _, probes = oracle.decode(os_, 255, [s], [0x64], 60, probes=True)
+        assert info.nFrames == 60 and info.nValidFrames == 60 and info.format == fmt
+        assert info.hdrLen == (1 if fmt == D.FMT_93A_T1 else 16)
+        for f in range(60):
+            assert idx[f]["bitOff"] == probes[f].bitOff
+            assert list(idx[f]["bandType"]) == list(probes[f].bandType)
+        assert np.all(np.diff(idx["bitOff"].astype(np.int64)) == idx["nBits"][:-1])
+        assert int(idx["err"].max()) == 0
+        oi = oracle.stream_info(os_, s)
+        assert (info.nBytes, info.formatType, info.formatSubType, bytes(info.header)) == \
+               (oi["nBytes"], oi["formatType"], oi["formatSubType"], oi["header"])
+
+
+def test_index_pass_error_semantics_match_oracle(oracle):
+    """corrupted payloads: the stream ends at the first frame that raises STOP/FATAL, like the
+    reference's channel.stop sweep (DCSDecoderNative.cpp:95-116)"""
+    hit = 0
+    for fmt in ALL_FORMATS:
+        for k in range(40):
+            s = corrupt(make_stream(fmt, 30, seed=5100 + fmt * 64 + k, profile=k % 4), seed=k, nflips=4)
+            os_ = os_for(fmt)
+            idx, info = D.index_stream(os_, s)
+            _, _, _, stops = oracle.decompress(os_, s, 0x7FFF, 30)
+            first_bad = next((f for f in range(30) if stops[f]), None)
+            if first_bad is None:
+                assert info.nValidFrames == 30
+            else:
+                hit += 1
+                assert info.nValidFrames == first_bad + 1
+                assert idx[first_bad]["err"] == stops[first_bad]
+    assert hit > 5      # the corruption does trigger the error paths
+
+
+def test_mixing_parameters_match_oracle(oracle):
+    for v in range(256):
+        assert D.volume_multiplier(v) == oracle.volume_multiplier(v)
+    for os_ in range(4):
+        for ls in list(range(-8300, 8300, 97)) + [8191, -8191, 0]:
+            for cv in (0, 0x7F, 0xFF):
+                assert D.mixing_multiplier(os_, ls, cv) == oracle.mixing_multiplier(os_, ls, cv)
+        for vol, lvl in [(255, 0x7F), (255, 0x64), (220, 0x64), (0x67, 0x64), (0, 0x64), (1, 0), (255, 0xFF), (37, -5)]:
+            mm, vs = D.stream_params(os_, vol, lvl, 6)
+            omm, ovs = oracle.frame_params(os_, vol, lvl, 6)
+            assert np.array_equal(mm, omm) and np.array_equal(vs, ovs)
+    # values measured on the reference by the survey
+    mm, vs = D.stream_params(D.OS94, 255, 0x7F, 3)
+    assert (mm[0], vs[0], mm[1], vs[1]) == (0x7FFD, 0, 0xFEFC, 0)
+    mm, vs = D.stream_params(D.OS94, 220, 0x64, 3)
+    assert (mm[1], vs[1]) == (0x7E26, 1)
+    mm, vs = D.stream_params(D.OS94, 0x67, 0x64, 3)
+    assert (mm[1], vs[1]) == (0x6D56, 4)
+
+
+def test_stream_writer_is_deterministic_and_seed_sensitive():
+    a = D.synth_stream(D.FMT_94_T1_S3, 50, seed=1)
+    assert a == D.synth_stream(D.FMT_94_T1_S3, 50, seed=1)
+    assert a != D.synth_stream(D.FMT_94_T1_S3, 50, seed=2)
+    assert (a[0] << 8 | a[1]) == 50 and (a[2] & 0x80) and ((a[3] | a[4]) & 0x80)
+    b = D.synth_stream(D.FMT_93A_T1, 9, seed=5, nbands=18)
+    assert (b[2] & 0x80) and (b[2] & 0x1F) == 18
+
+
+@pytest.mark.parametrize("fpw", [8, 16, 32, 64])
+def test_chunk_plan_properties(fpw):
+    b = workloads.build("mixed_16384", n_streams=24, n_frames=37)
+    jobs = b["jobs"]
+    plan = D.plan_chunks(jobs, fpw)
+    flat = plan.reshape(-1)
+    real = flat[(flat["flags"] & 0x81) == 0]
+    # every job exactly once as a real slot
+    assert np.array_equal(np.sort(real["job"]), np.arange(jobs.size))
+    for chunk in plan:
+        seen = {}
+        pad = False
+        for pos, sl in enumerate(chunk):
+            if sl["flags"] & 0x80:
+                pad = True
+                continue
+            assert not pad, "padding only at the end of a chunk"
+            j = int(sl["job"])
+            if not (sl["flags"] & 1):
+                prev = int(jobs[j]["prev"])
+                if prev == D.PREV_NONE:
+                    assert sl["prevSlot"] == 0xFF
+                else:
+                    assert sl["prevSlot"] < pos and int(chunk[sl["prevSlot"]]["job"]) == prev
+            seen[j] = pos
+    # stream-contiguous order needs one halo per chunk at most
+    b2 = workloads.build("dcs93_4096", n_streams=5, n_frames=100)
+    plan2 = D.plan_chunks(b2["jobs"], fpw)
+    halos = int(((plan2["flags"] & 1) != 0).sum())
+    assert halos <= plan2.shape[0]
+
+
+def test_workload_builders_shape():
+    b = workloads.build("dcs93_4096")
+    assert b["jobs"].size == 4096 and b["srcs"].size == 4096
+    assert set(np.unique(b["jobs"]["xform"])) == {D.XFORM_93}
+    payload = int(b["srcs"]["nBits"].sum()) // 8
+    assert 90 * 4096 < payload < 200 * 4096            # ~125 compressed bytes per frame

@@ -1,0 +1,63 @@
+"""oracle/dcs_oracle.c against the committed golden vectors (produced by the compiled reference,
+tests/golden/make_golden.py) -- this is what pins the oracle on the GPU box, where /root/reference
+does not exist."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from dcsexplorer_amd import workloads
+from oracle.dcs_oracle import fnv1a64
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    meta = json.load(open(os.path.join(GOLD, "dcs_golden_hashes.json")))
+    arrays = np.load(os.path.join(GOLD, "dcs_golden.npz"))
+    return meta, arrays
+
+
+def case_streams(case, arrays):
+    name = case["name"]
+    if case["streams"] == 1:
+        return [arrays[name + "/stream"].tobytes()]
+    return [arrays["%s/stream%d" % (name, c)].tobytes() for c in range(case["streams"])]
+
+
+def test_oracle_reproduces_every_golden_case(oracle, golden):
+    meta, arrays = golden
+    assert len(meta["cases"]) >= 35
+    for case in meta["cases"]:
+        pcm = oracle.decode(case["os"], case["volume"], case_streams(case, arrays), case["levels"], case["frames_out"])
+        assert np.array_equal(pcm, arrays[case["name"] + "/pcm"]), case["name"]
+
+
+def test_survey_appendix_d_sample_values(golden):
+    """the sample values printed in SURVEY.md Appendix D (measured by the surveyor on the reference)"""
+    meta, arrays = golden
+    kats = [c for c in meta["cases"] if c["name"].startswith("KAT-")]
+    assert len(kats) == 7
+    for c in kats:
+        pcm = arrays[c["name"] + "/pcm"]
+        assert list(pcm[0, :8]) == c["survey_head"]
+        assert list(pcm[0, 16:20]) == c["survey_mid"]
+        assert list(pcm[0, 236:240]) == c["survey_tail"]
+        assert not pcm[3].any()                     # frame 3 is silence
+        assert not pcm[2, 16:].any()                # frame 2 is the taper: only the 16 overlap samples
+
+
+@pytest.mark.parametrize("wl", ["dcs93_4096", "dcs94_65536", "mixed_16384"])
+def test_oracle_matches_reference_hashes_of_full_workloads(oracle, golden, wl):
+    """full-size seeded workloads: per-stream FNV-1a of the oracle's PCM == the reference's"""
+    meta, _ = golden
+    want = meta["workloads"][wl]
+    streams = workloads.WORKLOADS[wl]()
+    assert len(streams) == want["streams"]
+    got = []
+    for os_, s, vol, lvl in streams:
+        nf = (s[0] << 8) | s[1]
+        got.append("%016x" % fnv1a64(oracle.decode(os_, vol, [s], [lvl], nf).tobytes()))
+    assert got == want["stream_hashes"]
