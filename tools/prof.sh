@@ -1,0 +1,36 @@
+#!/bin/bash
+# tools/prof.sh <tag> <workload> [extra bench args]  -- run on the GPU box (via gpurun).
+# Writes rocprofv3 kernel-trace stats and PMC counter passes under gpurun_out/prof_<tag>/.
+set -u
+TAG=${1:-r1}; WL=${2:-dcs94_65536}; shift 2 || true
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python3 $PWD/bench.py --workload $WL --steps 50 --warmup 5 --no-cpu-baseline $*"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.log
+for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_THREAD_CYCLES_VALU"; do
+  name=$(echo $pass | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -- $BENCH > /dev/null 2> $OUT/pmc_$name.log
+done
+cd $OUT
+# compact summaries
+python3 - <<'PY'
+import csv, glob, collections, os
+out = open("summary.txt", "w")
+for f in glob.glob("trace/**/*kernel_stats.csv", recursive=True):
+    out.write("== %s\n" % f); out.write(open(f).read())
+for f in sorted(glob.glob("pmc_*/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for row in csv.DictReader(open(f)):
+        k = (row.get("Kernel_Name", "")[:60], row.get("Counter_Name", ""))
+        agg[k][0] += 1; agg[k][1] += float(row.get("Counter_Value", 0) or 0)
+    out.write("== %s\n" % f)
+    for (kn, cn), (n, v) in sorted(agg.items()):
+        if "dcsDecode" in kn:
+            out.write("%-60s %-28s dispatches=%d avg=%.1f\n" % (kn, cn, n, v / n))
+out.close()
+print(open("summary.txt").read())
+PY
