@@ -119,7 +119,7 @@ def load_library():
     L.dcs_synth_stream.restype = i32
     L.dcs_synth_stream.argtypes = [ctypes.POINTER(SynthParams), vp, sz, ctypes.POINTER(sz)]
     L.dcs_plan_chunks.restype = i32
-    L.dcs_plan_chunks.argtypes = [vp, u32, ctypes.c_int, vp, sz, ctypes.POINTER(u32)]
+    L.dcs_plan_chunks.argtypes = [vp, u32, vp, ctypes.c_int, vp, sz, ctypes.POINTER(u32)]
     _LIB = L
     return L
 
@@ -237,14 +237,15 @@ def build_stream_batch(streams, extra_frames=0, pad=64):
                 jobs=np.concatenate(jobs), first_job=np.array(first, dtype=np.int64))
 
 
-def plan_chunks(jobs, fpw):
+def plan_chunks(jobs, fpw, srcs=None):
     """dcs_plan_chunks -> (slots [nChunks, fpw] of dict-like structured array, nChunks)"""
     L = load_library()
     jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+    srcs = None if srcs is None else np.ascontiguousarray(srcs, dtype=SRC_DTYPE)
     n = ctypes.c_uint32(0)
-    _check(L.dcs_plan_chunks(_ptr(jobs), jobs.size, fpw, None, 0, ctypes.byref(n)))
+    _check(L.dcs_plan_chunks(_ptr(jobs), jobs.size, _ptr(srcs), fpw, None, 0, ctypes.byref(n)))
     raw = np.zeros(n.value * fpw, dtype=np.uint64)
-    _check(L.dcs_plan_chunks(_ptr(jobs), jobs.size, fpw, _ptr(raw), raw.size, ctypes.byref(n)))
+    _check(L.dcs_plan_chunks(_ptr(jobs), jobs.size, _ptr(srcs), fpw, _ptr(raw), raw.size, ctypes.byref(n)))
     out = np.zeros(raw.size, dtype=[("job", "<u4"), ("prevSlot", "u1"), ("flags", "u1")])
     out["job"] = raw & 0xFFFFFFFF
     out["prevSlot"] = (raw >> 32) & 0xFF

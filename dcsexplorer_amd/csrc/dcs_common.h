@@ -56,6 +56,26 @@ const DcsDevTables &dcsTables();
 // 16-sample tail they hand to a later slot of the same chunk (the predecessor of the chunk's first
 // frame lives in another chunk).
 // ---------------------------------------------------------------------------------------------
+// LDS bit pool: the compressed bytes of the frames one wavefront unpacks in one round are staged
+// there.  The planner closes a chunk before the pool would overflow; a frame of unknown length
+// (nBits == 0) is budgeted at the format's maximum.
+#define DCS_POOL_DW_PER_FRAME 56        // 224 bytes per frame slot on average (typical frame: ~125-150 bytes)
+#define DCS_MAX_FRAME_BITS    4480      // 16 band headers + 255 x 16-bit samples, rounded up
+
+#ifdef __cplusplus
+// dwords of pool one source occupies: whole dwords covering the frame + 2 dwords of window look-ahead
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+uint32_t dcsPoolDwords(uint64_t streamOff, uint32_t hdrLen, uint32_t bitOff, uint32_t nBits)
+{
+    const uint32_t inDword = static_cast<uint32_t>(((streamOff + 2 + hdrLen) * 8 + bitOff) & 31);
+    const uint32_t bits = nBits ? nBits : DCS_MAX_FRAME_BITS;
+    return (inDword + bits + 31) / 32 + 2;
+}
+#endif
+
 #define DCS_SLOT_HALO      0x01u        // do not write PCM / err for this slot
 #define DCS_SLOT_EXT_TAIL  0x02u        // overlap tail comes from tailsIn[job.prev & 0x7FFFFFFF]
 #define DCS_SLOT_EMPTY     0x80u        // padding
@@ -88,5 +108,5 @@ struct DcsKernelArgs
 // planner: returns the number of chunks; slots is resized to nChunks * fpw
 #ifdef __cplusplus
 #include <vector>
-uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw, std::vector<DcsSlot> &slots);
+uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots);
 #endif

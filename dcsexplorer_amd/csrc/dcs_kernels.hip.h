@@ -8,11 +8,11 @@
 //            frame); running FPW frames side by side is what keeps the SIMD lanes busy.
 //            [DecoderImpl94x/93/93a::DecompressFrame, DCSDecoderNative.cpp:1679-2261, :2293-2684,
 //             :2831-3032; ROMBitPointer, DCSDecoderNative.h:229-289]
-//   phase 2, wave-per-frame:  the 64 lanes walk the slots in order and run the fixed-point inverse
-//            transform of each row cooperatively (one radix-2 butterfly per lane per stage for the
-//            1994+ transform, two for the 1993 one), apply the volume shift, overlap-add with the
-//            predecessor's 16-sample tail (kept in LDS) and write 240 int16 PCM samples with
-//            coalesced stores.
+//            The compressed bytes of the chunk are first staged into an LDS pool with coalesced
+//            loads (byte-swapped to bit order), so the per-symbol critical path never waits on HBM/L2.
+//   phase 2, 8 or 16 lanes per frame:  register-resident fixed-point inverse transforms of 8 (1994+)
+//            or 4 (1993) rows per pass, volume shift, overlap-add with the predecessor's 16-sample
+//            tail (kept in LDS), 240 int16 PCM samples written per frame.
 //            [DecoderImpl94x::TransformFrame :397-576, DecoderImpl93::TransformFrame :614-813]
 //
 // All arithmetic is the ADSP-2105 fixed-point arithmetic of the reference restated in 32-bit integer
@@ -25,12 +25,15 @@
 namespace dcsk {
 
 constexpr int kRowBytes = 516;          // 256 words + one pad dword: lane-per-frame rows hit distinct LDS banks
-constexpr int kScratchBytes = 1040;     // 256 complex points (1993 transform) + pad, 16-byte multiple
+constexpr int kScratchBytes = 5376;     // transpose scratch of one transform pass (8 x 168 or 4 x 336 dwords)
+
+__host__ __device__ constexpr int poolDwords(int fpw) { return fpw * DCS_POOL_DW_PER_FRAME; }
 
 __host__ __device__ constexpr int ldsBytes(int fpw)
 {
-    // tables | tile rows | band types [16][fpw] u16 | header bytes [16][fpw] u8 | tails [fpw][16] i16 | scratch
-    return static_cast<int>(sizeof(DcsLdsTables)) + ((fpw * kRowBytes + 15) & ~15) + fpw * 32 + fpw * 16 + fpw * 32 + kScratchBytes;
+    // tables | tile rows | band types [16][fpw] u16 | header bytes [16][fpw] u8 | tails [fpw][16] i16 | scratch | bit pool
+    return static_cast<int>(sizeof(DcsLdsTables)) + ((fpw * kRowBytes + 15) & ~15) + fpw * 32 + fpw * 16 + fpw * 32 + kScratchBytes
+         + poolDwords(fpw) * 4;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -75,52 +78,50 @@ __device__ __forceinline__ int calcExp32(uint32_t x)
 }
 
 // ------------------------------------------------------------------------------------------------
-// MSB-first bit reader over the blob in global memory; one instance per lane.  64-bit window,
-// refilled a big-endian dword at a time, next dword prefetched.  Same VALUES as ROMBitPointer
+// MSB-first bit reader over the LDS bit pool; one instance per lane.  The pool holds the frame's
+// dwords already byte-swapped, so a dword's MSB is the next bit of the stream.  64-bit window kept as
+// two 32-bit registers (hi:lo), refilled a dword at a time.  Same VALUES as ROMBitPointer
 // (DCSDecoderNative.h:229-289); the reference's byte-granular look-ahead is not observable here.
 // ------------------------------------------------------------------------------------------------
 struct BitReader
 {
-    const uint32_t *words;
-    uint32_t nWords;
-    uint32_t idx;
-    uint32_t nxt;
-    uint64_t win;
-    int cnt;
+    const uint32_t *p;      // next pool dword
+    uint32_t hi, lo;        // valid bits are left-aligned in hi:lo, invalid bits are zero
+    int cnt;                // number of valid bits
 
-    __device__ __forceinline__ uint32_t fetch(uint32_t i) const
+    __device__ __forceinline__ void init(const uint32_t *pool, int bitInDword)
     {
-        return i < nWords ? __builtin_bswap32(words[i]) : 0u;
-    }
-    __device__ __forceinline__ void init(const uint8_t *blob, uint64_t blobLen, uint64_t bitPos)
-    {
-        words = reinterpret_cast<const uint32_t *>(blob);
-        nWords = static_cast<uint32_t>((blobLen + 3) >> 2);
-        idx = static_cast<uint32_t>(bitPos >> 5);
-        const int sh = static_cast<int>(bitPos & 31);
-        const uint64_t d0 = fetch(idx), d1 = fetch(idx + 1);
-        nxt = fetch(idx + 2);
-        idx += 3;
-        win = ((d0 << 32) | d1) << sh;
-        cnt = 64 - sh;
+        hi = pool[0];
+        lo = pool[1];
+        p = pool + 2;
+        cnt = 64;
+        if (bitInDword != 0)
+            skip(bitInDword);
     }
     __device__ __forceinline__ void refill()
     {
         if (cnt <= 32)
         {
-            win |= static_cast<uint64_t>(nxt) << (32 - cnt);
+            // lo is empty here; append the next dword right behind the cnt valid bits
+            const uint64_t add = (static_cast<uint64_t>(*p++) << 32) >> cnt;
+            hi |= static_cast<uint32_t>(add >> 32);
+            lo = static_cast<uint32_t>(add);
             cnt += 32;
-            nxt = fetch(idx++);
         }
     }
     // n in 1..24, after refill()
-    __device__ __forceinline__ uint32_t peek(int n) const { return static_cast<uint32_t>(win >> (64 - n)); }
-    __device__ __forceinline__ void skip(int n) { win <<= n; cnt -= n; }
+    __device__ __forceinline__ uint32_t peek(int n) const { return hi >> (32 - n); }
+    __device__ __forceinline__ void skip(int n)      // n in 1..31
+    {
+        hi = __builtin_amdgcn_alignbit(hi, lo, static_cast<uint32_t>(32 - n));
+        lo <<= n;
+        cnt -= n;
+    }
     __device__ __forceinline__ uint32_t get(int n) { refill(); const uint32_t v = peek(n); skip(n); return v; }
     __device__ __forceinline__ int getSigned(int n)
     {
         refill();
-        const int v = static_cast<int>(static_cast<int64_t>(win) >> (64 - n));
+        const int v = static_cast<int>(hi) >> (32 - n);
         skip(n);
         return v;
     }
@@ -159,23 +160,29 @@ struct Lds
     __device__ __forceinline__ uint16_t *bandTypes() const { return reinterpret_cast<uint16_t *>(base + kSide); }            // [16][FPW]
     __device__ __forceinline__ uint8_t *hdrBytes() const { return base + kSide + FPW * 32; }                                   // [16][FPW]
     __device__ __forceinline__ uint16_t *tails() const { return reinterpret_cast<uint16_t *>(base + kSide + FPW * 48); }     // [FPW][16]
-    __device__ __forceinline__ uint32_t *scratch() const { return reinterpret_cast<uint32_t *>(base + kSide + FPW * 80); }   // 260 dwords
+    __device__ __forceinline__ uint32_t *scratch() const { return reinterpret_cast<uint32_t *>(base + kSide + FPW * 80); }   // kScratchBytes
+    __device__ __forceinline__ uint32_t *pool() const { return reinterpret_cast<uint32_t *>(base + kSide + FPW * 80 + kScratchBytes); }
 };
 
-// the 32-bit "splice" multiply-accumulate of the mixer (.cpp:2244-2250, :2434-2443)
-__device__ __forceinline__ void mixAdd(uint16_t *row, int idx, int scaledProduct, uint32_t mixMul)
+// the 32-bit "splice" multiply-accumulate of the mixer (.cpp:2244-2250, :2434-2443): low word =
+// scaled sample, high word = accumulator, add (int16)scaled * (uint16)mixMul, keep the high word.
+// FIRST: the row is still zero at idx (first source of the frame; no index is written twice by one
+// source), so the read of the accumulator is skipped.
+template <bool FIRST>
+__device__ __forceinline__ void mixAdd(uint16_t *cell, int scaledProduct, uint32_t mixMul)
 {
     const uint32_t s = static_cast<uint32_t>(scaledProduct) & 0xFFFFu;
-    uint32_t acc = (static_cast<uint32_t>(row[idx]) << 16) | s;
-    acc += static_cast<uint32_t>(sx16(s) * static_cast<int>(mixMul));
-    row[idx] = static_cast<uint16_t>(acc >> 16);
+    uint32_t acc = s + static_cast<uint32_t>(__mul24(sx16(s), static_cast<int>(mixMul)));
+    if (!FIRST)
+        acc += static_cast<uint32_t>(*cell) << 16;
+    *cell = static_cast<uint16_t>(acc >> 16);
 }
 // the same contribution removed again (exact inverse: the MAC is additive modulo 2^16 in the high word)
-__device__ __forceinline__ void mixSub(uint16_t *row, int idx, int scaledProduct, uint32_t mixMul)
+__device__ __forceinline__ void mixSub(uint16_t *cell, int scaledProduct, uint32_t mixMul)
 {
     const uint32_t s = static_cast<uint32_t>(scaledProduct) & 0xFFFFu;
-    const uint32_t c = (s + static_cast<uint32_t>(sx16(s) * static_cast<int>(mixMul))) >> 16;
-    row[idx] = static_cast<uint16_t>(row[idx] - c);
+    const uint32_t c = (s + static_cast<uint32_t>(__mul24(sx16(s), static_cast<int>(mixMul)))) >> 16;
+    *cell = static_cast<uint16_t>(*cell - c);
 }
 
 __device__ __forceinline__ uint32_t scaleFactor(const DcsLdsTables *T, int code)
@@ -190,11 +197,17 @@ __device__ __forceinline__ void dcFixup(uint16_t *row, uint32_t saved1)
     row[1] = static_cast<uint16_t>(saved1);
 }
 
+constexpr int kDummyWord = 256;         // the pad word of a tile row: sink for predicated-off stores
+
 // ------------------------------------------------------------------------------------------------
 // a2: 1994+ frame (DecoderImpl94x::DecompressFrame, .cpp:1679-2261)
+//
+// Lane-per-frame.  The per-band set-up is ordinary divergent code (16 times per frame); the symbol
+// loop -- ~250 iterations per frame -- is written branch-free so that lanes with Huffman-coded
+// bands, raw bands and different codebooks all execute the same instruction stream.
 // ------------------------------------------------------------------------------------------------
-template <int FPW>
-__device__ uint32_t unpack94(const Lds<FPW> &L, int lane, BitReader &br, int format, uint32_t mixMul)
+template <int FPW, bool FIRST>
+__device__ uint32_t unpack94(const Lds<FPW> &L, int lane, BitReader &br, int format, uint32_t mixMul, bool has)
 {
     const DcsLdsTables *T = L.tables();
     uint16_t *row = L.row(lane);
@@ -203,24 +216,36 @@ __device__ uint32_t unpack94(const Lds<FPW> &L, int lane, BitReader &br, int for
     const bool type1 = format != DCS_FMT_94_T0;
     const uint32_t saved1 = row[1];
     uint32_t err = 0;
+    bool done = !has;                               // lanes without a 1994+ source ride along masked off
 
     // scale pre-adjust for bands 0..2 from the PREVIOUS frame's codes (:1744-1773)
     int preAdj0 = 0, preAdj1 = 0, preAdj2 = 0;
-    if (type1)
+    if (type1 && !done)
     {
         const uint8_t *map = T->preAdj94 + (format == DCS_FMT_94_T1_S0 ? 0 : 16);
         const uint32_t c0 = bt[0], c1 = bt[FPW], c2 = bt[2 * FPW];
         if ((c0 | c1 | c2) > 15)
-            return DCS_FRAME_FATAL | DCS_FRAME_STOP;
-        preAdj0 = map[c0]; preAdj1 = map[c1]; preAdj2 = map[c2];
+        {
+            err = DCS_FRAME_FATAL | DCS_FRAME_STOP;
+            done = true;
+        }
+        else
+        {
+            preAdj0 = map[c0]; preAdj1 = map[c1]; preAdj2 = map[c2];
+        }
     }
 
     // frame header: band-type deltas (:1780-1834)
-    for (int i = 0 ; i < 16 ; ++i)
     {
-        if ((hdr[i * FPW] & 0x7F) == 0x7F)
-            break;
-        bt[i * FPW] = static_cast<uint16_t>(bt[i * FPW] + readVlc(br, T->fast94, T->trie94) - 16);
+        bool more = !done;
+        for (int i = 0 ; i < 16 ; ++i)
+        {
+            more = more && (hdr[i * FPW] & 0x7F) != 0x7F;
+            if (!__any(more))
+                break;
+            if (more)
+                bt[i * FPW] = static_cast<uint16_t>(bt[i * FPW] + readVlc(br, T->fast94, T->trie94) - 16);
+        }
     }
 
     int outIdx = 1;
@@ -228,108 +253,123 @@ __device__ uint32_t unpack94(const Lds<FPW> &L, int lane, BitReader &br, int for
     for (int band = 0 ; band < 16 ; ++band)
     {
         int hb = hdr[band * FPW] & 0x7F;
-        if (hb == 0x7F)
+        done = done || hb == 0x7F;
+        if (__all(done))
             break;
-        int count = band == 0 ? 7 : band == 1 ? 8 : band == 15 ? 32 : 16;          // :1848-1850
+
+        // ---- per-band set-up -------------------------------------------------------------------------
+        int i = 0;                  // symbols still to decode in this band
         int inc = 1;
-        if (hb & 0x40) { inc = 2; count >>= 1; }
-
-        int code = bt[band * FPW];
-        if (code == 0)
+        int rawW = 0;               // > 0: fixed-width band of that many bits
+        int shPeek = 0;             // 32 - look-ahead width
+        int ref = 0, scale = 0;
+        const uint16_t *book = T->cb94;
+        if (!done)
         {
-            outIdx += count;                        // the halved count, not count*inc (:1886)
-            continue;
-        }
-        int scaleCode = hb;
-        if (type1)
-        {
-            if (code > 15) { err |= DCS_FRAME_FATAL | DCS_FRAME_STOP; break; }
-            const uint32_t x = T->xlat94[(band < 3 ? 0 : band < 6 ? 16 : 32) + code];
-            if (band < 3)
-                hb += band == 0 ? preAdj0 : band == 1 ? preAdj1 : preAdj2;
-            scaleCode = hb + static_cast<int>(x >> 8);
-            code = static_cast<int>(x & 0xFF);
-        }
-        const int scale = static_cast<int>(scaleFactor(T, scaleCode));
-
-        if (code == 0)
-        {
-            valid = false; err |= DCS_FRAME_STOP;   // :1985-1991
-            outIdx += count * inc;
-        }
-        else if (code <= 6)
-        {
-            const uint32_t info = T->cbInfo[code];
-            const int maxBits = static_cast<int>(info & 0xF);
-            const uint16_t *book = T->cb94 + (info >> 4);
-            const int ref = 1 << (code - 1);
-            const BitReader bandStart = br;
-            const int idxStart = outIdx;
-            bool bad = false;
-            for (int i = count ; i > 0 ; )
+            int count = band == 0 ? 7 : band == 1 ? 8 : band == 15 ? 32 : 16;      // :1848-1850
+            if (hb & 0x40) { inc = 2; count >>= 1; }
+            int code = bt[band * FPW];
+            if (code == 0)
+                outIdx += count;                    // the halved count, not count*inc (:1886)
+            else
             {
-                br.refill();
-                const uint32_t e = book[br.peek(maxBits)];
-                br.skip(static_cast<int>(e >> 8));
-                if (e & 0x80)
+                int scaleCode = hb;
+                bool fatal = false;
+                if (type1)
                 {
-                    if (i >= 2) { outIdx += 2 * inc; i -= 2; }
-                    else { bad = true; outIdx += inc; i = 0; }              // :2213-2218
+                    fatal = code > 15;
+                    const uint32_t x = T->xlat94[(band < 3 ? 0 : band < 6 ? 16 : 32) + (code & 15)];
+                    if (band < 3)
+                        hb += band == 0 ? preAdj0 : band == 1 ? preAdj1 : preAdj2;
+                    scaleCode = hb + static_cast<int>(x >> 8);
+                    code = static_cast<int>(x & 0xFF);
+                }
+                fatal = fatal || code > 16;
+                scale = static_cast<int>(scaleFactor(T, scaleCode));
+                if (fatal)
+                {
+                    err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;
+                    done = true;
+                }
+                else if (code == 0)
+                {
+                    valid = false; err |= DCS_FRAME_STOP;       // :1985-1991
+                    outIdx += count * inc;
                 }
                 else
                 {
-                    if (valid)
-                        mixAdd(row, outIdx, (static_cast<int>(e & 0xFF) - ref) * scale, mixMul);
-                    outIdx += inc; --i;
-                }
-            }
-            if (bad)
-            {
-                // the reference zeroes the WHOLE band buffer on this error (:2238-2239): take back
-                // what this band already contributed by replaying it
-                if (valid)
-                {
-                    BitReader r2 = bandStart;
-                    int k = idxStart;
-                    for (int i = count ; i > 1 ; )
+                    i = count;
+                    int maxBits = code;
+                    if (code <= 6)
                     {
-                        r2.refill();
-                        const uint32_t e = book[r2.peek(maxBits)];
-                        r2.skip(static_cast<int>(e >> 8));
-                        if (e & 0x80) { k += 2 * inc; i -= 2; }
-                        else { mixSub(row, k, (static_cast<int>(e & 0xFF) - ref) * scale, mixMul); k += inc; --i; }
+                        const uint32_t info = T->cbInfo[code];
+                        maxBits = static_cast<int>(info & 0xF);
+                        book = T->cb94 + (info >> 4);
+                        ref = 1 << (code - 1);
                     }
+                    else
+                        rawW = code;
+                    shPeek = 32 - maxBits;
                 }
-                valid = false; err |= DCS_FRAME_STOP;
             }
         }
-        else
+
+        // ---- symbol loop, branch-free ------------------------------------------------------------------
+        const BitReader bandStart = br;
+        const int idxStart = outIdx;
+        const int countStart = i;
+        bool bad = false;
+        while (i > 0)
         {
-            if (code > 16) { err |= DCS_FRAME_FATAL | DCS_FRAME_STOP; break; }
-            for (int i = 0 ; i < count ; ++i, outIdx += inc)
+            br.refill();
+            const uint32_t pk = br.hi >> shPeek;
+            const uint32_t e = book[rawW ? 0u : pk];
+            const int n = rawW ? rawW : static_cast<int>(e >> 8);
+            const int v = rawW ? (static_cast<int>(br.hi) >> shPeek) : (static_cast<int>(e & 0xFF) - ref);
+            const bool dz = !rawW && (e & 0x80) != 0;           // "two zeros" code (:2200-2212)
+            br.skip(n);
+            bad = bad || (dz && i == 1);                        // no room for the second zero (:2213-2218)
+            const int step = (dz && i >= 2) ? 2 : 1;
+            mixAdd<FIRST>(&row[(dz || !valid) ? kDummyWord : outIdx], __mul24(v, scale), mixMul);
+            outIdx += inc * step;
+            i -= step;
+        }
+        if (bad)
+        {
+            // the reference zeroes the WHOLE band buffer on this error (:2238-2239): take back what the
+            // band already contributed by replaying it
+            if (valid)
             {
-                const int v = br.getSigned(code);
-                if (valid)
-                    mixAdd(row, outIdx, static_cast<int16_t>(v) * scale, mixMul);
+                BitReader r2 = bandStart;
+                int k = idxStart;
+                for (int j = countStart ; j > 1 ; )
+                {
+                    r2.refill();
+                    const uint32_t e = book[r2.hi >> shPeek];
+                    r2.skip(static_cast<int>(e >> 8));
+                    if (e & 0x80) { k += 2 * inc; j -= 2; }
+                    else { mixSub(&row[k], __mul24(static_cast<int>(e & 0xFF) - ref, scale), mixMul); k += inc; --j; }
+                }
             }
+            valid = false; err |= DCS_FRAME_STOP;
         }
     }
 
-    dcFixup(row, saved1);
+    if (has)
+        dcFixup(row, saved1);
     return err;
 }
 
 // ------------------------------------------------------------------------------------------------
 // a3: 1993 frame, Type 0 and OS93b Type 1 (DecoderImpl93::DecompressFrame + ReadHuff93, .cpp:2293-2684)
+//
+// The three sample codings of a band (direct / delta / double delta, :2565-2599) are folded into one
+// branch-free update:  d = in + (st == 2 ? prvDelta : 0);  p = d + (st == 0 ? 0 : prv);
+// prvDelta' = st == 0 ? p - prv : d;  prv' = p.  A code-0 band of sub-type 2 (ramp, :2539-2545) is the
+// same update with in = 0, so it rides in the same loop without reading bits.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mixAdd93(uint16_t *row, int idx, int scaledProduct, uint32_t mixMul)
-{
-    if (idx < 256)          // words 256..511 of the reference's buffer never reach the output (:714-732 overwrites them)
-        mixAdd(row, idx, scaledProduct, mixMul);
-}
-
-template <int FPW>
-__device__ uint32_t unpack93(const Lds<FPW> &L, int lane, BitReader &br, int format, uint32_t mixMul)
+template <int FPW, bool FIRST>
+__device__ uint32_t unpack93(const Lds<FPW> &L, int lane, BitReader &br, int format, uint32_t mixMul, bool has)
 {
     const DcsLdsTables *T = L.tables();
     uint16_t *row = L.row(lane);
@@ -338,6 +378,7 @@ __device__ uint32_t unpack93(const Lds<FPW> &L, int lane, BitReader &br, int for
     const bool type1 = format == DCS_FMT_93B_T1;
     const uint32_t saved1 = row[1];
     uint32_t err = 0;
+    bool done = !has;
 
     int subType = type1 ? 0 : 2;
     bool first = true, reuse = false;
@@ -348,118 +389,140 @@ __device__ uint32_t unpack93(const Lds<FPW> &L, int lane, BitReader &br, int for
     for (int band = 0 ; band < 16 ; ++band)
     {
         const int hb = hdr[band * FPW] & 0x7F;
-        if (hb == 0x7F)
+        done = done || hb == 0x7F;
+        if (__all(done))
             break;
-        const int scale = static_cast<int>(scaleFactor(T, hb));
-        const bool strided = (hb >> 6) != 0;
 
-        int nSamples, inc, fixup, stride;
-        if (!type1)
+        int nS = 0;                 // samples this lane runs through the main loop
+        int width = 0;              // bits per input (0: ramp, no bits read)
+        int inc = 1, fixup = 0;
+        int scale = 0;
+        bool quirk = false;         // code 0, sub-type 1
+        int nQ = 0;
+        if (!done)
         {
-            nSamples = 16;
-            if (!strided) { inc = 1; fixup = 0; stride = 16; }
-            else { ++outIdx; inc = 2; fixup = -1; stride = 31; }
-        }
-        else
-        {
-            fixup = 0;
-            if (!strided) { inc = 1; nSamples = stride = first ? 15 : 16; }
-            else { inc = 2; nSamples = stride = 8; }
-        }
-
-        if (reuse)
-            reuse = br.get(1) != 0;
-        if (!reuse)
-        {
+            scale = static_cast<int>(scaleFactor(T, hb));
+            const bool strided = (hb >> 6) != 0;
+            int nSamples, stride;
             if (!type1)
             {
-                if (br.get(1))
-                    subType = br.get(1) ? (subType == 2 ? 0 : subType + 1) : (subType == 0 ? 2 : subType - 1);
-                code = static_cast<int>(br.get(4));
+                nSamples = 16;
+                if (!strided) { stride = 16; }
+                else { ++outIdx; inc = 2; fixup = -1; stride = 31; }
             }
             else
             {
-                int v = readVlc(br, T->fast93, T->trie93);
-                if (v < 0x1E)
-                    v -= 0x0F;
+                if (!strided) { nSamples = stride = first ? 15 : 16; }
+                else { inc = 2; nSamples = stride = 8; }
+            }
+
+            if (reuse)
+                reuse = br.get(1) != 0;
+            if (!reuse)
+            {
+                if (!type1)
+                {
+                    if (br.get(1))
+                        subType = br.get(1) ? (subType == 2 ? 0 : subType + 1) : (subType == 0 ? 2 : subType - 1);
+                    code = static_cast<int>(br.get(4));
+                }
                 else
                 {
-                    v -= 0x2E;
-                    subType = subType != 0 ? 0 : 1;
+                    int v = readVlc(br, T->fast93, T->trie93);
+                    if (v < 0x1E)
+                        v -= 0x0F;
+                    else
+                    {
+                        v -= 0x2E;
+                        subType = subType != 0 ? 0 : 1;
+                    }
+                    const uint32_t nc = (bt[band * FPW] + static_cast<uint32_t>(v)) & 0xFFFFu;
+                    bt[band * FPW] = static_cast<uint16_t>(nc);
+                    code = static_cast<int>(nc);
                 }
-                const uint32_t nc = (bt[band * FPW] + static_cast<uint32_t>(v)) & 0xFFFFu;
-                bt[band * FPW] = static_cast<uint16_t>(nc);
-                code = static_cast<int>(nc);
             }
+
+            if (code == 0)
+            {
+                reuse = true;
+                if (subType == 0)
+                {
+                    outIdx += stride;
+                    prv = 0; prvDelta = 0;
+                }
+                else if (subType == 1)
+                {
+                    quirk = true; nQ = nSamples;
+                }
+                else
+                    nS = nSamples;
+            }
+            else
+            {
+                width = code + (type1 ? 0 : 1);
+                if (width > 16)
+                {
+                    err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;
+                    done = true;
+                    width = 0;
+                }
+                else
+                    nS = nSamples;
+            }
+            first = false;
         }
 
-        if (code == 0)
+        // ---- main sample loop, branch-free -----------------------------------------------------------
+        const uint32_t m2 = subType == 2 ? 0xFFFFu : 0u;        // add the previous delta
+        const uint32_t m0 = subType == 0 ? 0u : 0xFFFFu;        // add the previous value
+        const int shW = 32 - width;
+        const bool ran = nS > 0 || quirk;
+        for (int i = 0 ; i < nS ; ++i)
         {
-            reuse = true;
-            if (subType == 0)
+            uint32_t in = 0;
+            if (width != 0)
             {
-                outIdx += stride;
-                prv = 0; prvDelta = 0;
+                br.refill();
+                in = static_cast<uint32_t>(static_cast<int>(br.hi) >> shW);
+                br.skip(width);
             }
-            else if (subType == 1)
+            const uint32_t d = in + (prvDelta & m2);
+            const uint32_t p = d + (prv & m0);
+            prvDelta = d - (prv & ~m0);
+            prv = p;
+            mixAdd<FIRST>(&row[outIdx < 256 ? outIdx : kDummyWord], __mul24(sx16(p), scale), mixMul);
+            outIdx += inc;
+        }
+        prv &= 0xFFFFu; prvDelta &= 0xFFFFu;
+
+        // ---- code 0 / sub-type 1: repeat the previous input; the product's low word is carried from
+        // sample to sample instead of being reloaded (:2513-2534) -------------------------------------------
+        if (__any(quirk))
+        {
+            if (quirk)
             {
-                // repeat the previous input; the product's low word is carried, not reloaded (:2513-2534)
-                uint32_t low = static_cast<uint32_t>(sx16(prv) * scale) & 0xFFFFu;
+                uint32_t low = static_cast<uint32_t>(__mul24(sx16(prv), scale)) & 0xFFFFu;
                 const int mulLow = sx16(low);
-                for (int i = 0 ; i < nSamples ; ++i, outIdx += inc)
+                for (int i = 0 ; i < nQ ; ++i, outIdx += inc)
                 {
                     if (outIdx < 256)
                     {
-                        uint32_t acc = (static_cast<uint32_t>(row[outIdx]) << 16) | low;
-                        acc += static_cast<uint32_t>(mulLow * static_cast<int>(mixMul));
+                        uint32_t acc = low + static_cast<uint32_t>(__mul24(mulLow, static_cast<int>(mixMul)));
+                        if (!FIRST)
+                            acc += static_cast<uint32_t>(row[outIdx]) << 16;
                         row[outIdx] = static_cast<uint16_t>(acc >> 16);
                         low = acc & 0xFFFFu;
                     }
                 }
                 prvDelta = 0;
-                outIdx += fixup;
-            }
-            else
-            {
-                for (int i = 0 ; i < nSamples ; ++i, outIdx += inc)
-                {
-                    prv = (prv + prvDelta) & 0xFFFFu;
-                    mixAdd93(row, outIdx, sx16(prv) * scale, mixMul);
-                }
-                outIdx += fixup;
             }
         }
-        else
-        {
-            const int width = code + (type1 ? 0 : 1);
-            if (width > 16) { err |= DCS_FRAME_FATAL | DCS_FRAME_STOP; break; }
-            uint32_t last = 0, last2 = 0;
-            for (int i = 0 ; i < nSamples ; ++i, outIdx += inc)
-            {
-                const uint32_t in = static_cast<uint32_t>(br.getSigned(width)) & 0xFFFFu;
-                if (subType == 0)
-                {
-                    mixAdd93(row, outIdx, sx16(in) * scale, mixMul);
-                    last2 = last; last = in;
-                }
-                else
-                {
-                    prvDelta = (subType == 1) ? in : ((prvDelta + in) & 0xFFFFu);
-                    prv = (prv + prvDelta) & 0xFFFFu;
-                    mixAdd93(row, outIdx, sx16(prv) * scale, mixMul);
-                }
-            }
-            if (subType == 0)
-            {
-                prv = last;
-                prvDelta = (last - last2) & 0xFFFFu;
-            }
+        if (ran)
             outIdx += fixup;
-        }
-        first = false;
     }
 
-    dcFixup(row, saved1);
+    if (has)
+        dcFixup(row, saved1);
     return err;
 }
 
@@ -587,13 +650,62 @@ __device__ void dcMagnitude93(uint16_t *row)
 }
 
 // ------------------------------------------------------------------------------------------------
-// phase 2 helpers: complex points are dwords, low half = real, high half = imaginary
+// phase 2: register-resident inverse transforms.
+//
+// A frame's complex points are spread over LPF lanes x 16 registers (a point is one dword, low half
+// real, high half imaginary): 8 lanes per frame for the 1994+ transform (128 points), 16 lanes per
+// frame for the 1993 one (256 points), so one wavefront transforms G = 8 (or 4) frames per pass.
+// In layout A a lane holds the points whose LOW index bits equal its lane number, so the first
+// radix-2 stages (partner distance >= 8 resp. 16 points) stay inside the lane; one transpose through
+// LDS gives layout B (16 CONSECUTIVE points per lane) for the remaining stages.  Twiddles of the
+// layout-A stages are the same for every lane (scalar loads); those of layout B are per-lane constants.
+// No cross-lane traffic other than the two LDS transposes, one wave-level sync each.
 // ------------------------------------------------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pkAddSat(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pkSubSat(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pkAdd(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, static_cast<u16x2>(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b))); }
+__device__ __forceinline__ uint32_t pkSub(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, static_cast<u16x2>(__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b))); }
+__device__ __forceinline__ uint32_t pkAshr(uint32_t a, uint32_t shiftPair)
+{ return __builtin_bit_cast(uint32_t, static_cast<s16x2>(__builtin_bit_cast(s16x2, a) >> __builtin_bit_cast(s16x2, shiftPair))); }
+
 __device__ __forceinline__ uint32_t packC(int re, int im) { return (static_cast<uint32_t>(re) & 0xFFFFu) | (static_cast<uint32_t>(im) << 16); }
 __device__ __forceinline__ int reC(uint32_t c) { return sx16(c); }
 __device__ __forceinline__ int imC(uint32_t c) { return static_cast<int>(c) >> 16; }
 
-__device__ __forceinline__ int bitrev6(int v) { return static_cast<int>(__brev(static_cast<uint32_t>(v)) >> 26); }
+// t = a * (c + i*s) with the reference's rounding (.cpp:500-506, :761-765), packed (re | im << 16)
+__device__ __forceinline__ uint32_t rotatePk(uint32_t A, int c, int s)
+{
+    const int are = reC(A), aim = imC(A);
+    const int p2 = __mul24(aim, s);
+    const int dR = __mul24(are, c) - p2;
+    const int q2 = __mul24(are, s);
+    const int dI = __mul24(aim, c) + q2;
+    uint32_t mrR = (static_cast<uint32_t>(dR) << 1) + 0x8000u;
+    uint32_t mrI = (static_cast<uint32_t>(dI) << 1) + 0x8000u;
+    if ((p2 & 0x7FFF) == 0x4000) mrR &= ~0x10000u;
+    if ((q2 & 0x7FFF) == 0x4000) mrI &= ~0x10000u;
+    return __builtin_amdgcn_perm(mrI, mrR, 0x07060302u);       // (mrR >> 16) | (mrI & 0xFFFF0000)
+}
+
+// radix-2 butterfly u' = u - t, a' = u + t (saturating for the 1994+ transform, wrapping for 1993)
+template <bool SAT>
+__device__ __forceinline__ void bfly(uint32_t &U, uint32_t &A, uint32_t tw)
+{
+    const uint32_t T = rotatePk(A, sx16(tw), static_cast<int>(tw) >> 16);
+    const uint32_t u = U;
+    if (SAT) { U = pkSubSat(u, T); A = pkAddSat(u, T); }
+    else     { U = pkSub(u, T);    A = pkAdd(u, T); }
+}
+
+__device__ __forceinline__ int bitrev9(int v) { return static_cast<int>(__brev(static_cast<uint32_t>(v)) >> 23); }
+__device__ __forceinline__ int bitrevN(int v, int bits) { return static_cast<int>(__brev(static_cast<uint32_t>(v)) >> (32 - bits)); }
 
 // overlap-add of one sample (.cpp:545-554, :797-801): both products signed x unsigned, sum, +0x8000, high word
 __device__ __forceinline__ int overlapMix(int x, uint32_t cx, int o, uint32_t co)
@@ -603,143 +715,257 @@ __device__ __forceinline__ int overlapMix(int x, uint32_t cx, int o, uint32_t co
     return static_cast<int>(a + b + 0x8000u) >> 16;
 }
 
+constexpr int kRowStride = 20;          // dwords per 16-point row in the transpose scratch (16 + 4 pad: conflict-free b128)
+constexpr int kGroupStrideA = 160;      // 94x first transpose: 8 rows
+constexpr int kGroupStrideB94 = 168;    // 94x second transpose
+constexpr int kGroupStrideB93 = 336;    // 93 transpose: 16 rows + 16
+constexpr int kXformScratchBytes = 5376;
+
 struct LaneConsts
 {
-    uint32_t tw94[6];       // per stage: cos | sin<<16 for this lane's butterfly
-    uint32_t twPre94;       // pre-twiddle pair c0 | c1<<16 (.cpp:428-429)
-    uint32_t tw93[7][2];    // two butterflies per lane per stage
-    uint32_t ovlA, ovlB;    // overlap window: co[2l] | co[2l+1]<<16, co[15-2l] | co[14-2l]<<16 (lanes 0..7)
+    uint32_t pre94[8];      // 94x pre-twiddle of pair i = l + 8j: c0 | c1 << 16 (.cpp:428-429)
+    uint32_t twB94[14];     // 94x layout-B stages: d=4 [0..1], d=2 [2..5], d=1 [6..13]; cos | sin << 16
+    uint32_t twB93[15];     // 93 layout-B stages: d=8 [0], d=4 [1..2], d=2 [3..6], d=1 [7..14]
+    uint32_t ovl94a, ovl94b;    // overlap window of pair m = bitrev3(l): co[2m] | co[2m+1]<<16 ; co[15-2m] | co[14-2m]<<16
+    uint32_t ovl93;             // overlap window of sample i = bitrev4(l): co[i] | co[15-i]<<16
 };
 
-__device__ __forceinline__ int bitrev9(int v) { return static_cast<int>(__brev(static_cast<uint32_t>(v)) >> 23); }
+__device__ __forceinline__ uint32_t twAt(const uint16_t *coef, int part)
+{
+    return static_cast<uint32_t>(coef[0x80 + part]) | (static_cast<uint32_t>(coef[part]) << 16);
+}
 
 __device__ void loadLaneConsts(const DcsDevTables *G, int lane, LaneConsts &C)
 {
     const uint16_t *coef = G->fftCoef;
-    for (int st = 0 ; st < 6 ; ++st)
+    const int l8 = lane & 7, l16 = lane & 15;
+#pragma unroll
+    for (int j = 0 ; j < 8 ; ++j)
     {
-        const int part = lane >> (5 - st);                      // butterfly lane of stage st lives in partition lane / (32 >> st)
-        C.tw94[st] = static_cast<uint32_t>(coef[0x80 + part]) | (static_cast<uint32_t>(coef[part]) << 16);
+        const int i = l8 + 8 * j;
+        C.pre94[j] = static_cast<uint32_t>(coef[bitrev9(2 + 4 * i)]) | (static_cast<uint32_t>(coef[bitrev9(4 * i)]) << 16);
     }
-    C.twPre94 = static_cast<uint32_t>(coef[bitrev9(2 + 4 * lane)]) | (static_cast<uint32_t>(coef[bitrev9(4 * lane)]) << 16);
-    for (int st = 0 ; st < 7 ; ++st)
-        for (int h = 0 ; h < 2 ; ++h)
-        {
-            const int part = (lane + 64 * h) >> (6 - st);
-            C.tw93[st][h] = static_cast<uint32_t>(coef[0x80 + part]) | (static_cast<uint32_t>(coef[part]) << 16);
-        }
-    const int l = lane & 7;
-    C.ovlA = static_cast<uint32_t>(G->ovlCoef[2 * l]) | (static_cast<uint32_t>(G->ovlCoef[2 * l + 1]) << 16);
-    C.ovlB = static_cast<uint32_t>(G->ovlCoef[15 - 2 * l]) | (static_cast<uint32_t>(G->ovlCoef[14 - 2 * l]) << 16);
+#pragma unroll
+    for (int k = 0 ; k < 2 ; ++k) C.twB94[k] = twAt(coef, 2 * l8 + k);
+#pragma unroll
+    for (int k = 0 ; k < 4 ; ++k) C.twB94[2 + k] = twAt(coef, 4 * l8 + k);
+#pragma unroll
+    for (int k = 0 ; k < 8 ; ++k) C.twB94[6 + k] = twAt(coef, 8 * l8 + k);
+    C.twB93[0] = twAt(coef, l16);
+#pragma unroll
+    for (int k = 0 ; k < 2 ; ++k) C.twB93[1 + k] = twAt(coef, 2 * l16 + k);
+#pragma unroll
+    for (int k = 0 ; k < 4 ; ++k) C.twB93[3 + k] = twAt(coef, 4 * l16 + k);
+#pragma unroll
+    for (int k = 0 ; k < 8 ; ++k) C.twB93[7 + k] = twAt(coef, 8 * l16 + k);
+    const int m = bitrevN(l8, 3);
+    C.ovl94a = static_cast<uint32_t>(G->ovlCoef[2 * m]) | (static_cast<uint32_t>(G->ovlCoef[2 * m + 1]) << 16);
+    C.ovl94b = static_cast<uint32_t>(G->ovlCoef[15 - 2 * m]) | (static_cast<uint32_t>(G->ovlCoef[14 - 2 * m]) << 16);
+    const int i = bitrevN(l16, 4);
+    C.ovl93 = static_cast<uint32_t>(G->ovlCoef[i]) | (static_cast<uint32_t>(G->ovlCoef[15 - i]) << 16);
 }
 
-// block of one wavefront: this is a fence for the compiler plus s_waitcnt; hipcc drops the s_barrier
-// itself when the workgroup is a single wave
+// wavefront-level ordering of LDS traffic between lanes.  The workgroup is one wavefront, so hipcc
+// lowers this to a compiler fence + s_waitcnt without an s_barrier.
 __device__ __forceinline__ void waveSync() { __syncthreads(); }
 
-// 1994+ transform of one row into 256 time samples held as S[0..127] (bit-reversed order) (.cpp:397-524)
-__device__ void transform94(const uint32_t *rowC, uint32_t *S, int lane, const LaneConsts &C)
+// per-lane description of the frame a lane works on in a transform pass
+struct PassLane
 {
-    // pre-pass 1 + 2 on the pair (point lane, point 128 - lane) (:403-456)
+    const uint32_t *rowC;   // the frame's spectrum row in the tile
+    uint32_t *S;            // this lane group's transpose scratch
+    int l;                  // lane inside the group
+    uint32_t shiftPair;     // volShift | volShift << 16
+    bool active;
+};
+
+__device__ __forceinline__ uint4 ldsRead4(const uint32_t *p) { return *reinterpret_cast<const uint4 *>(p); }
+__device__ __forceinline__ void ldsWrite4(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{ *reinterpret_cast<uint4 *>(p) = make_uint4(a, b, c, d); }
+
+// 1994+ transform of 8 frames, 8 lanes each (DecoderImpl94x::TransformFrame, .cpp:397-534).
+// On return x[r'] holds point 16*l + r' = output sample pair m = 8*bitrev4(r') + bitrev3(l), shifted.
+__device__ __forceinline__ void transform94x8(const PassLane &P, uint32_t *Sbase, int g, const uint16_t *coef,
+                                              const LaneConsts &C, uint32_t (&x)[16])
+{
+    const int l = P.l;
+    uint32_t *SA = Sbase + g * kGroupStrideA;
+    // ---- pre-passes 1 + 2 on the pairs (i, 128 - i), i = l + 8j (:403-456) ------------------------
+    uint32_t An[8], Bn[8];
+#pragma unroll
+    for (int j = 0 ; j < 8 ; ++j)
     {
-        const uint32_t X = rowC[lane];
-        const uint32_t Y = lane == 0 ? 0u : rowC[128 - lane];       // words 0x100/0x101 start at zero
-        const int x0 = reC(X), x1 = imC(X), y0 = reC(Y), y1 = imC(Y);
-        // MulSS(v, 0x8000) is a wrapping 16-bit negate
-        int a0 = sx16(static_cast<uint32_t>(-sat16(x0 + y0)));
-        int b0 = sx16(static_cast<uint32_t>(-sat16(x0 - y0)));
-        int a1 = sx16(static_cast<uint32_t>(-sat16(x1 - y1)));
-        int b1 = sx16(static_cast<uint32_t>(-sat16(x1 + y1)));
-        const int c0 = sx16(C.twPre94), c1 = static_cast<int>(C.twPre94) >> 16;
+        const int i = l + 8 * j;
+        const uint32_t X = P.rowC[i];
+        uint32_t Y = P.rowC[(128 - i) & 127];
+        if (i == 0) Y = 0;                                  // words 0x100/0x101 start at zero
+        // MulSS(v, 0x8000) = wrapping negate
+        const uint32_t Sm = pkAddSat(X, Y), Df = pkSubSat(X, Y);
+        const uint32_t a = pkSub(0u, __builtin_amdgcn_perm(Df, Sm, 0x07060100u));     // (-(x0+y0), -(x1-y1))
+        const uint32_t b = pkSub(0u, __builtin_amdgcn_perm(Sm, Df, 0x07060100u));     // (-(x0-y0), -(x1+y1))
+        const int b0 = reC(b), b1 = imC(b);
+        const int c0 = sx16(C.pre94[j]), c1 = static_cast<int>(C.pre94[j]) >> 16;
         // prod0 = b1*c1 - b0*c0 ; prod1 = b1*c0 + b0*c1
-        const int p1 = __mul24(b1, c1), p2 = __mul24(b0, c0);
-        const int prod0 = roundHi(static_cast<uint32_t>(p1 - p2) << 1, p2);
-        const int q1 = __mul24(b1, c0), q2 = __mul24(b0, c1);
-        const int prod1 = roundHi(static_cast<uint32_t>(q1 + q2) << 1, q2);
-        const uint32_t A = packC(sat16(prod1 + a0), sat16(prod0 + a1));
-        const uint32_t B = packC(sat16(a0 - prod1), sat16(prod0 - a1));
-        S[lane] = A;
-        if (lane != 0)
-            S[128 - lane] = B;
+        const int p2 = __mul24(b0, c0), q2 = __mul24(b0, c1);
+        uint32_t m0 = (static_cast<uint32_t>(__mul24(b1, c1) - p2) << 1) + 0x8000u;
+        uint32_t m1 = (static_cast<uint32_t>(__mul24(b1, c0) + q2) << 1) + 0x8000u;
+        if ((p2 & 0x7FFF) == 0x4000) m0 &= ~0x10000u;
+        if ((q2 & 0x7FFF) == 0x4000) m1 &= ~0x10000u;
+        const uint32_t Pr = __builtin_amdgcn_perm(m0, m1, 0x07060302u);   // (prod1, prod0)
+        An[j] = pkAddSat(Pr, a);                                        // (prod1 + a0, prod0 + a1)
+        const uint32_t t = pkSubSat(a, Pr);                             // (a0 - prod1, a1 - prod0)
+        const uint32_t t2 = pkSubSat(Pr, a);                            // (prod1 - a0, prod0 - a1)
+        Bn[j] = __builtin_amdgcn_perm(t2, t, 0x07060100u);              // (a0 - prod1, prod0 - a1)
+    }
+    // point 64: real part negated, imaginary part unchanged (:403-404); it is B of the pair i = 0... of lane 0, j = 0 has no
+    // partner, so lane 0 places it where B[0] would go
+    if (l == 0)
+    {
+        const uint32_t M = P.rowC[64];
+        Bn[0] = __builtin_amdgcn_perm(M, pkSub(0u, M), 0x07060100u);
+    }
+    // transpose into layout A: point p sits at row (p & 7), position (p >> 3).  A points of lane l fill
+    // positions 0..7 of row l; its B points (128 - i) fill positions 15 - j of row (8 - l) & 7, except
+    // lane 0 whose B points 128 - 8j sit at position 16 - j of row 0 (j = 0 holds point 64 -> position 8)
+    {
+        uint32_t *rowA = SA + l * kRowStride;
+        ldsWrite4(rowA, An[0], An[1], An[2], An[3]);
+        ldsWrite4(rowA + 4, An[4], An[5], An[6], An[7]);
+        uint32_t *rowB = SA + ((8 - l) & 7) * kRowStride;
+        if (l != 0)
+        {
+            ldsWrite4(rowB + 8, Bn[7], Bn[6], Bn[5], Bn[4]);
+            ldsWrite4(rowB + 12, Bn[3], Bn[2], Bn[1], Bn[0]);
+        }
         else
         {
-            // point 64: real part negated, imaginary part unchanged (:403-404)
-            const uint32_t M = rowC[64];
-            S[64] = packC(sx16(static_cast<uint32_t>(-reC(M))), imC(M));
+            ldsWrite4(rowB + 8, Bn[0], Bn[7], Bn[6], Bn[5]);
+            ldsWrite4(rowB + 12, Bn[4], Bn[3], Bn[2], Bn[1]);
         }
     }
     waveSync();
-
-    // pre-pass 3 (:458-471): saturating radix-2 across the two halves, then six stages (:480-524)
-    uint32_t U = S[lane], A = S[lane + 64];
     {
-        const int ur = reC(U), ui = imC(U), ar = reC(A), ai = imC(A);
-        U = packC(sat16(ur + ar), sat16(ui + ai));
-        A = packC(sat16(ur - ar), sat16(ui - ai));
-    }
-    S[lane] = U; S[lane + 64] = A;
-    waveSync();
-
+        const uint32_t *rowA = SA + l * kRowStride;
 #pragma unroll
-    for (int st = 0 ; st < 6 ; ++st)
-    {
-        const int d = 32 >> st;
-        const int u = ((lane >> (5 - st)) << (6 - st)) | (lane & (d - 1));
-        U = S[u]; A = S[u + d];
-        int tre, tim;
-        rotate(reC(A), imC(A), sx16(C.tw94[st]), static_cast<int>(C.tw94[st]) >> 16, tre, tim);
-        const int ur = reC(U), ui = imC(U);
-        S[u] = packC(sat16(ur - tre), sat16(ui - tim));
-        S[u + d] = packC(sat16(ur + tre), sat16(ui + tim));
-        waveSync();
+        for (int q = 0 ; q < 4 ; ++q)
+        {
+            const uint4 v = ldsRead4(rowA + 4 * q);
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
     }
+    waveSync();         // scratch is reused by the second transpose
+    // ---- layout A: point p = 8r + l.  pre-pass 3 (:458-471) then stages d = 32, 16, 8 (:480-524) -------
+#pragma unroll
+    for (int r = 0 ; r < 8 ; ++r)
+    {
+        const uint32_t u = x[r], a = x[r + 8];
+        x[r] = pkAddSat(u, a); x[r + 8] = pkSubSat(u, a);
+    }
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & 4)) bfly<true>(x[r], x[r + 4], twAt(coef, r >> 3));
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & 2)) bfly<true>(x[r], x[r + 2], twAt(coef, r >> 2));
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & 1)) bfly<true>(x[r], x[r + 1], twAt(coef, r >> 1));
+    // ---- transpose to layout B: point p = 16 l' + r' ------------------------------------------------------
+    {
+        uint32_t *SB = Sbase + g * kGroupStrideB94;
+#pragma unroll
+        for (int r = 0 ; r < 16 ; ++r)
+            SB[(r >> 1) * kRowStride + 8 * (r & 1) + l] = x[r];
+        waveSync();
+        const uint32_t *rowB = SB + l * kRowStride;
+#pragma unroll
+        for (int q = 0 ; q < 4 ; ++q)
+        {
+            const uint4 v = ldsRead4(rowB + 4 * q);
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+    }
+    // ---- stages d = 4, 2, 1 ------------------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & 4)) bfly<true>(x[r], x[r + 4], C.twB94[r >> 3]);
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & 2)) bfly<true>(x[r], x[r + 2], C.twB94[2 + (r >> 2)]);
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & 1)) bfly<true>(x[r], x[r + 1], C.twB94[6 + (r >> 1)]);
+    // volume shift (:532-534)
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        x[r] = pkAshr(x[r], P.shiftPair);
 }
 
-// 1993 transform of one row (DC step already applied) into S[0..255] (.cpp:714-778)
-__device__ void transform93(const uint32_t *rowC, uint32_t *S, int lane, const LaneConsts &C)
+// 1993 transform of 4 frames, 16 lanes each (DecoderImpl93::TransformFrame, .cpp:714-785; the DC
+// magnitude step ran in phase 1).  On return x[r'] holds point 16*l + r'; its real part is output
+// sample i = 16*bitrev4(r') + bitrev4(l), shifted.
+__device__ __forceinline__ void transform93x4(const PassLane &P, uint32_t *Sbase, int g, const uint16_t *coef,
+                                              const LaneConsts &C, uint32_t (&x)[16])
 {
-    // expand 128 -> 256 complex points with wrapping adds (:714-732)
+    const int l = P.l;
+    // ---- expand 128 -> 256 points (:714-732): S[p] = (A.re + B.re, A.im - B.im), S[128 + p] = (A.re - B.re, A.im + B.im)
+    // with A = row[p], B = row[128 - p]; layout A: point p = 16 r + l, so S[p] -> x[r], S[128 + p] -> x[r + 8]
+#pragma unroll
+    for (int r = 0 ; r < 8 ; ++r)
     {
-        const uint32_t X = rowC[1 + lane], Y = rowC[127 - lane];
-        const int xr = reC(X), xi = imC(X), yr = reC(Y), yi = imC(Y);
-        S[1 + lane]   = packC(xr + yr, xi - yi);
-        S[127 - lane] = packC(xr + yr, yi - xi);
-        S[129 + lane] = packC(xr - yr, xi + yi);
-        S[255 - lane] = packC(yr - xr, xi + yi);
-        if (lane == 0)
+        const int p = 16 * r + l;
+        const uint32_t A = P.rowC[p];
+        const uint32_t B = P.rowC[(128 - p) & 127];
+        const uint32_t Sm = pkAdd(A, B), Df = pkSub(A, B);
+        x[r] = __builtin_amdgcn_perm(Df, Sm, 0x07060100u);          // (sum.re, diff.im)
+        x[r + 8] = __builtin_amdgcn_perm(Sm, Df, 0x07060100u);      // (diff.re, sum.im)
+        if (p == 0)
         {
-            const uint32_t Z = rowC[0];         // (|DC|, 0) from dcMagnitude93
-            S[0] = Z; S[128] = Z;
+            x[0] = A; x[8] = A;                                     // (|DC|, 0) from dcMagnitude93 (:709-710)
         }
     }
-    waveSync();
-
+    // ---- stages d = 64, 32, 16 (wrapping) (:742-778) ------------------------------------------------------
 #pragma unroll
-    for (int st = 0 ; st < 7 ; ++st)
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & 4)) bfly<false>(x[r], x[r + 4], twAt(coef, r >> 3));
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & 2)) bfly<false>(x[r], x[r + 2], twAt(coef, r >> 2));
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & 1)) bfly<false>(x[r], x[r + 1], twAt(coef, r >> 1));
+    // ---- transpose: point 16 r + l  ->  lane r, register l -------------------------------------------------
     {
-        const int d = 64 >> st;
-        uint32_t o[2][2];
+        uint32_t *SB = Sbase + g * kGroupStrideB93;
 #pragma unroll
-        for (int h = 0 ; h < 2 ; ++h)
-        {
-            const int k = lane + 64 * h;
-            const int u = ((k >> (6 - st)) << (7 - st)) | (k & (d - 1));
-            const uint32_t U = S[u], A = S[u + d];
-            int tre, tim;
-            rotate(reC(A), imC(A), sx16(C.tw93[st][h]), static_cast<int>(C.tw93[st][h]) >> 16, tre, tim);
-            o[h][0] = packC(reC(U) - tre, imC(U) - tim);
-            o[h][1] = packC(tre + reC(U), tim + imC(U));
-        }
+        for (int r = 0 ; r < 16 ; ++r)
+            SB[r * kRowStride + l] = x[r];
         waveSync();
+        const uint32_t *rowB = SB + l * kRowStride;
 #pragma unroll
-        for (int h = 0 ; h < 2 ; ++h)
+        for (int q = 0 ; q < 4 ; ++q)
         {
-            const int k = lane + 64 * h;
-            const int u = ((k >> (6 - st)) << (7 - st)) | (k & (d - 1));
-            S[u] = o[h][0]; S[u + d] = o[h][1];
+            const uint4 v = ldsRead4(rowB + 4 * q);
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
         }
-        waveSync();
     }
+    // ---- stages d = 8, 4, 2, 1 -----------------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0 ; r < 8 ; ++r)
+        bfly<false>(x[r], x[r + 8], C.twB93[0]);
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & 4)) bfly<false>(x[r], x[r + 4], C.twB93[1 + (r >> 3)]);
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & 2)) bfly<false>(x[r], x[r + 2], C.twB93[3 + (r >> 2)]);
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & 1)) bfly<false>(x[r], x[r + 1], C.twB93[7 + (r >> 1)]);
+    // volume shift of the real parts (:782-785)
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        x[r] = pkAshr(x[r], P.shiftPair);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -778,113 +1004,204 @@ __global__ void __launch_bounds__(64) dcsDecodeKernel(const DcsKernelArgs a)
         job = a.jobs[slot.job];
     waveSync();
 
-    // ---- phase 1: lane-per-frame unpack ----------------------------------------------------------
+    // ---- phase 1: lane-per-frame unpack, one round per source index ------------------------------------
     uint32_t err = 0;
-    if (live)
     {
-        for (int s = 0 ; s < job.nSrc ; ++s)
+        uint32_t *pool = L.pool();
+        const uint32_t *blobW = reinterpret_cast<const uint32_t *>(a.blob);
+        const uint32_t blobWords = static_cast<uint32_t>((a.blobLen + 3) >> 2);
+        const int myNSrc = live ? job.nSrc : 0;
+        int maxSrc = myNSrc;
+#pragma unroll
+        for (int d = 32 ; d >= 1 ; d >>= 1)
+            maxSrc = max(maxSrc, __shfl_xor(maxSrc, d));
+
+        for (int r = 0 ; r < maxSrc ; ++r)
         {
-            const DcsSrcDesc *sd = &a.srcs[job.firstSrc + s];
-            const uint64_t streamOff = sd->streamOff;
-            const int format = sd->format;
-            const int hdrLen = sd->hdrLen;
-            const uint32_t mixMul = sd->mixMul;
-            // carried band types and the stream header into this lane's LDS columns
-            uint16_t *bt = L.bandTypes() + lane;
-            uint8_t *hb = L.hdrBytes() + lane;
-            for (int i = 0 ; i < 16 ; ++i)
+            const bool has = r < myNSrc;
+            const DcsSrcDesc *sd = &a.srcs[has ? job.firstSrc + r : 0];
+            uint64_t streamOff = 0;
+            uint32_t bitOff = 0, nBits = 0, mixMul = 0;
+            int format = 0, hdrLen = 16;
+            if (has)
             {
-                bt[i * FPW] = sd->bandType[i];
-                const uint64_t at = streamOff + 2 + static_cast<uint64_t>(i);
-                hb[i * FPW] = (i < hdrLen && at < a.blobLen) ? a.blob[at] : static_cast<uint8_t>(0);
+                streamOff = sd->streamOff; bitOff = sd->bitOff; nBits = sd->nBits;
+                mixMul = sd->mixMul; format = sd->format; hdrLen = sd->hdrLen;
             }
+            const uint64_t bitPos = (streamOff + 2 + static_cast<uint64_t>(hdrLen)) * 8 + bitOff;
+            const uint32_t startDw = static_cast<uint32_t>(bitPos >> 5);
+            const uint32_t nDw = has ? dcsPoolDwords(streamOff, static_cast<uint32_t>(hdrLen), bitOff, nBits) : 0u;
+
+            // exclusive prefix sum of the dword counts = each lane's offset in the pool
+            uint32_t incl = nDw;
+#pragma unroll
+            for (int d = 1 ; d < 64 ; d <<= 1)
+            {
+                const uint32_t up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            const uint32_t off = incl - nDw;
+            const bool fits = incl <= static_cast<uint32_t>(poolDwords(FPW));
+
+            // stage: one coalesced run of dwords per slot, byte-swapped so that bit 31 is the next stream bit
+            for (int s = 0 ; s < FPW ; ++s)
+            {
+                const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(nDw), s));
+                const uint32_t st = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(startDw), s));
+                const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(off), s));
+                if (o + n > static_cast<uint32_t>(poolDwords(FPW)))
+                    continue;
+                for (uint32_t i = static_cast<uint32_t>(lane) ; i < n ; i += 64)
+                {
+                    const uint32_t w = st + i;
+                    pool[o + i] = w < blobWords ? __builtin_bswap32(blobW[w]) : 0u;
+                }
+            }
+
+            if (has)
+            {
+                // carried band types and the stream header into this lane's LDS columns
+                uint16_t *bt = L.bandTypes() + lane;
+                uint8_t *hb = L.hdrBytes() + lane;
+#pragma unroll
+                for (int i = 0 ; i < 16 ; ++i)
+                {
+                    bt[i * FPW] = sd->bandType[i];
+                    const uint64_t at = streamOff + 2 + static_cast<uint64_t>(i);
+                    hb[i * FPW] = (i < hdrLen && at < a.blobLen) ? a.blob[at] : static_cast<uint8_t>(0);
+                }
+            }
+            waveSync();
+
+            // every lane enters the unpackers (their symbol loops are wave-convergent); lanes without a
+            // source of that family are masked off inside
+            if (has && !fits)
+                err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;            // cannot happen with the library's planner
+            const bool ok = has && fits;
             BitReader br;
-            br.init(a.blob, a.blobLen, (streamOff + 2 + static_cast<uint64_t>(hdrLen)) * 8 + sd->bitOff);
-            uint32_t e;
-            if (format >= DCS_FMT_94_T0)
-                e = unpack94<FPW>(L, lane, br, format, mixMul);
-            else if (format == DCS_FMT_93A_T1)
-                e = unpack93a<FPW>(L, lane, br, mixMul, a.tables->pair93a);
-            else
-                e = unpack93<FPW>(L, lane, br, format, mixMul);
-            err |= e;
+            br.init(pool + (ok ? off : 0u), static_cast<int>(bitPos & 31));
+            const bool is94 = ok && format >= DCS_FMT_94_T0;
+            const bool is93a = ok && format == DCS_FMT_93A_T1;
+            const bool is93 = ok && format < DCS_FMT_93A_T1;
+            if (__any(is94))
+                err |= (r == 0) ? unpack94<FPW, true>(L, lane, br, format, mixMul, is94)
+                                : unpack94<FPW, false>(L, lane, br, format, mixMul, is94);
+            if (__any(is93))
+                err |= (r == 0) ? unpack93<FPW, true>(L, lane, br, format, mixMul, is93)
+                                : unpack93<FPW, false>(L, lane, br, format, mixMul, is93);
+            if (is93a)
+                err |= unpack93a<FPW>(L, lane, br, mixMul, a.tables->pair93a);
+            waveSync();
         }
-        if (job.xform == DCS_XFORM_93)
-            dcMagnitude93(L.row(lane));
-        if (!(slot.flags & DCS_SLOT_HALO) && a.err != nullptr)
-            a.err[slot.job] = err;
+        if (live)
+        {
+            if (job.xform == DCS_XFORM_93)
+                dcMagnitude93(L.row(lane));
+            if (!(slot.flags & DCS_SLOT_HALO) && a.err != nullptr)
+                a.err[slot.job] = err;
+        }
     }
     waveSync();
 
-    // ---- phase 2: wave-per-frame transform, overlap, emit -----------------------------------------
+    // ---- phase 2: transform passes (8 frames x 8 lanes, or 4 frames x 16 lanes), overlap, emit ------------
     uint32_t *S = L.scratch();
-    uint16_t *tails = L.tails();
-    for (int s = 0 ; s < FPW ; ++s)
-    {
-        const uint32_t flags = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(slot.flags), s));
-        if (flags & DCS_SLOT_EMPTY)
-            break;
-        const uint32_t jobIdx = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(slot.job), s));
-        const int prevSlot = __builtin_amdgcn_readlane(static_cast<int>(slot.prevSlot), s);
-        const int volShift = __builtin_amdgcn_readlane(static_cast<int>(job.volShift), s);
-        const int xform = __builtin_amdgcn_readlane(static_cast<int>(job.xform), s);
-        const uint32_t prevJob = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(job.prev), s));
-        const uint32_t *rowC = reinterpret_cast<const uint32_t *>(L.row(s));
+    uint32_t *tails = reinterpret_cast<uint32_t *>(L.tails());         // [slot][8] dwords = 16 samples
+    const uint16_t *coef = a.tables->fftCoef;
+    const int nSlots = __popcll(__ballot(live));                        // padding slots are trailing
+    const int slotFlags = slot.flags, slotJob = static_cast<int>(slot.job), slotPrev = slot.prevSlot;
+    const int jobShift = job.volShift, jobXform = job.xform, jobPrev = static_cast<int>(job.prev);
 
-        // predecessor's tail pair for lanes 0..7
-        uint32_t tailPair = 0;
-        if (lane < 8)
+    for (int s0 = 0 ; s0 < nSlots ; )
+    {
+        const int xf = __builtin_amdgcn_readlane(jobXform, s0);
+        const int G = (xf == DCS_XFORM_94) ? 8 : 4;
+        int n = 1;
+        while (n < G && s0 + n < nSlots && __builtin_amdgcn_readlane(jobXform, s0 + n) == xf)
+            ++n;
+
+        const int lpfShift = (xf == DCS_XFORM_94) ? 3 : 4;
+        const int g = lane >> lpfShift;
+        const bool active = g < n;
+        const int mySlot = s0 + (active ? g : 0);
+        const int myFlags = __shfl(slotFlags, mySlot);
+        const uint32_t myJob = static_cast<uint32_t>(__shfl(slotJob, mySlot));
+        const int myPrevSlot = __shfl(slotPrev, mySlot);
+        const int myShift = __shfl(jobShift, mySlot);
+        const uint32_t myPrevJob = static_cast<uint32_t>(__shfl(jobPrev, mySlot));
+
+        PassLane P;
+        P.rowC = reinterpret_cast<const uint32_t *>(L.row(mySlot));
+        P.S = S;
+        P.l = lane & ((1 << lpfShift) - 1);
+        P.shiftPair = static_cast<uint32_t>(myShift) * 0x00010001u;
+        P.active = active;
+
+        uint32_t x[16];
+        if (xf == DCS_XFORM_94)
+            transform94x8(P, S, g, coef, C, x);
+        else
+            transform93x4(P, S, g, coef, C, x);
+
+        // tail for the successor = output samples 240..255 (:569-575, :805-812): register 15 of every lane
+        if (active)
         {
-            if (flags & DCS_SLOT_EXT_TAIL)
+            if (xf == DCS_XFORM_94)
+                tails[mySlot * 8 + bitrevN(P.l, 3)] = x[15];
+            else
+                reinterpret_cast<uint16_t *>(tails)[mySlot * 16 + bitrevN(P.l, 4)] = static_cast<uint16_t>(x[15]);
+        }
+        waveSync();
+
+        const bool emit = active && !(myFlags & DCS_SLOT_HALO);
+        if (xf == DCS_XFORM_94)
+        {
+            // overlap-add on sample pair m = bitrev3(l) (register 0) (:538-555)
+            const int m = bitrevN(P.l, 3);
+            uint32_t tailPair = 0;
+            if (myFlags & DCS_SLOT_EXT_TAIL)
             {
                 if (a.tailsIn != nullptr)
-                    tailPair = reinterpret_cast<const uint32_t *>(a.tailsIn)[static_cast<size_t>(prevJob & 0x7FFFFFFFu) * 8 + lane];
+                    tailPair = reinterpret_cast<const uint32_t *>(a.tailsIn)[static_cast<size_t>(myPrevJob & 0x7FFFFFFFu) * 8 + m];
             }
-            else if (prevSlot != DCS_NO_PREV_SLOT)
-                tailPair = reinterpret_cast<const uint32_t *>(tails)[prevSlot * 8 + lane];
-        }
-
-        uint32_t first, second;         // sample pairs (2l, 2l+1) and (2l+128, 2l+129)
-        if (xform == DCS_XFORM_94)
-        {
-            transform94(rowC, S, lane, C);
-            const int r = bitrev6(lane) * 2;
-            const uint32_t P0 = S[r], P1 = S[r + 1];
-            first  = packC(reC(P0) >> volShift, imC(P0) >> volShift);         // :532-534
-            second = packC(reC(P1) >> volShift, imC(P1) >> volShift);
+            else if (myPrevSlot != DCS_NO_PREV_SLOT)
+                tailPair = tails[myPrevSlot * 8 + m];
+            x[0] = packC(overlapMix(reC(x[0]), C.ovl94a & 0xFFFFu, reC(tailPair), C.ovl94b & 0xFFFFu),
+                         overlapMix(imC(x[0]), C.ovl94a >> 16, imC(tailPair), C.ovl94b >> 16));
+            if (emit)
+            {
+                uint32_t *out = reinterpret_cast<uint32_t *>(a.pcm) + static_cast<size_t>(myJob) * (DCS_FRAME_SAMPLES / 2);
+#pragma unroll
+                for (int r = 0 ; r < 15 ; ++r)
+                    out[8 * bitrevN(r, 4) + m] = x[r];                 // pair 8*bitrev4(r) + bitrev3(l)
+                if (a.tailsOut != nullptr)
+                    reinterpret_cast<uint32_t *>(a.tailsOut)[static_cast<size_t>(myJob) * 8 + m] = x[15];
+            }
         }
         else
         {
-            transform93(rowC, S, lane, C);
-            // sample i = Re(Q[bitrev8(i)]) >> volShift (:782-785); this lane takes samples 2l, 2l+1, 2l+128, 2l+129
-            const int r0 = bitrev6(lane) * 2;           // bitrev8(2l)   = bitrev6(l) << 1        (l < 64)
-            const uint32_t Q0 = S[r0], Q1 = S[r0 + 128], Q2 = S[r0 + 1], Q3 = S[r0 + 129];
-            first  = packC(reC(Q0) >> volShift, reC(Q1) >> volShift);         // bitrev8(2l+1)   = r0 + 128
-            second = packC(reC(Q2) >> volShift, reC(Q3) >> volShift);         // bitrev8(2l+128) = r0 + 1
-        }
-
-        if (lane < 8)
-        {
-            // overlap-add with the predecessor's last 16 samples (:538-555, :789-802)
-            const int s0 = overlapMix(reC(first), C.ovlA & 0xFFFFu, reC(tailPair), C.ovlB & 0xFFFFu);
-            const int s1 = overlapMix(imC(first), C.ovlA >> 16, imC(tailPair), C.ovlB >> 16);
-            first = packC(s0, s1);
-        }
-
-        // tail for the successor: samples 240..255 = `second` of lanes 56..63 (:569-575, :805-812)
-        if (lane >= 56)
-            reinterpret_cast<uint32_t *>(tails)[s * 8 + (lane - 56)] = second;
-
-        if (!(flags & DCS_SLOT_HALO))
-        {
-            uint32_t *out = reinterpret_cast<uint32_t *>(a.pcm) + static_cast<size_t>(jobIdx) * (DCS_FRAME_SAMPLES / 2);
-            out[lane] = first;
-            if (lane < 56)
-                out[64 + lane] = second;
-            else if (a.tailsOut != nullptr)
-                reinterpret_cast<uint32_t *>(a.tailsOut)[static_cast<size_t>(jobIdx) * 8 + (lane - 56)] = second;
+            // overlap-add on sample i = bitrev4(l) (register 0) (:789-802)
+            const int i = bitrevN(P.l, 4);
+            int tailSample = 0;
+            if (myFlags & DCS_SLOT_EXT_TAIL)
+            {
+                if (a.tailsIn != nullptr)
+                    tailSample = a.tailsIn[static_cast<size_t>(myPrevJob & 0x7FFFFFFFu) * 16 + i];
+            }
+            else if (myPrevSlot != DCS_NO_PREV_SLOT)
+                tailSample = static_cast<int16_t>(reinterpret_cast<const uint16_t *>(tails)[myPrevSlot * 16 + i]);
+            x[0] = static_cast<uint32_t>(overlapMix(reC(x[0]), C.ovl93 & 0xFFFFu, tailSample, C.ovl93 >> 16)) & 0xFFFFu;
+            if (emit)
+            {
+                int16_t *out = a.pcm + static_cast<size_t>(myJob) * DCS_FRAME_SAMPLES;
+#pragma unroll
+                for (int r = 0 ; r < 15 ; ++r)
+                    out[16 * bitrevN(r, 4) + i] = static_cast<int16_t>(x[r]);      // sample 16*bitrev4(r) + bitrev4(l)
+                if (a.tailsOut != nullptr)
+                    a.tailsOut[static_cast<size_t>(myJob) * 16 + i] = static_cast<int16_t>(x[15]);
+            }
         }
         waveSync();
+        s0 += n;
     }
 }
 

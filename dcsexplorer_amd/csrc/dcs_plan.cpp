@@ -8,7 +8,7 @@
 #include "dcs_common.h"
 #include <vector>
 
-uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw, std::vector<DcsSlot> &slots)
+uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots)
 {
     slots.clear();
     if (nJobs == 0 || fpw < 2)
@@ -19,6 +19,27 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw, std::ve
     std::vector<uint32_t> stampOf(nJobs, 0xFFFFFFFFu);
     std::vector<uint8_t> slotOf(nJobs, 0);
 
+    // LDS bit-pool budget: per unpack round r (the r-th source of every job in the chunk) the staged
+    // frames must fit fpw * DCS_POOL_DW_PER_FRAME dwords
+    const uint32_t poolCap = static_cast<uint32_t>(fpw) * DCS_POOL_DW_PER_FRAME;
+    uint32_t poolUse[DCS_MAX_CHANNELS] = { 0 };
+    auto poolNeed = [&](uint32_t j, uint32_t r) -> uint32_t {
+        if (srcs == nullptr || r >= jobs[j].nSrc)
+            return 0;
+        const DcsSrcDesc &sd = srcs[jobs[j].firstSrc + r];
+        return dcsPoolDwords(sd.streamOff, sd.hdrLen, sd.bitOff, sd.nBits);
+    };
+    auto poolFits = [&](uint32_t j, uint32_t halo, bool withHalo) {
+        for (uint32_t r = 0 ; r < DCS_MAX_CHANNELS ; ++r)
+            if (poolUse[r] + poolNeed(j, r) + (withHalo ? poolNeed(halo, r) : 0) > poolCap)
+                return false;
+        return true;
+    };
+    auto poolAdd = [&](uint32_t j) {
+        for (uint32_t r = 0 ; r < DCS_MAX_CHANNELS ; ++r)
+            poolUse[r] += poolNeed(j, r);
+    };
+
     uint32_t chunk = 0;
     uint32_t used = 0;                  // slots filled in the current chunk
     const DcsSlot empty{ 0xFFFFFFFFu, DCS_NO_PREV_SLOT, DCS_SLOT_EMPTY, 0 };
@@ -26,6 +47,7 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw, std::ve
         while (used < static_cast<uint32_t>(fpw)) { slots.push_back(empty); ++used; }
         ++chunk;
         used = 0;
+        for (uint32_t &u : poolUse) u = 0;
     };
     auto inChunk = [&](uint32_t j) { return j < nJobs && stampOf[j] == chunk; };
 
@@ -36,7 +58,7 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw, std::ve
         const bool link = prev != DCS_PREV_NONE && !ext && prev < nJobs && prev != j;
 
         uint32_t need = (link && !inChunk(prev)) ? 2u : 1u;
-        if (used + need > static_cast<uint32_t>(fpw))
+        if (used + need > static_cast<uint32_t>(fpw) || (used != 0 && !poolFits(j, prev, need == 2)))
         {
             closeChunk();
             need = link ? 2u : 1u;      // nothing of the new chunk exists yet
@@ -48,12 +70,14 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw, std::ve
             if (!inChunk(prev))
             {
                 slots.push_back({ prev, DCS_NO_PREV_SLOT, DCS_SLOT_HALO, 0 });
+                poolAdd(prev);
                 stampOf[prev] = chunk;
                 slotOf[prev] = static_cast<uint8_t>(used++);
             }
             prevSlot = slotOf[prev];
         }
         slots.push_back({ j, prevSlot, static_cast<uint8_t>(ext ? DCS_SLOT_EXT_TAIL : 0), 0 });
+        poolAdd(j);
         stampOf[j] = chunk;
         slotOf[j] = static_cast<uint8_t>(used++);
         if (used == static_cast<uint32_t>(fpw))
@@ -64,13 +88,13 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw, std::ve
     return chunk;
 }
 
-extern "C" DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw,
+extern "C" DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw,
                                      uint64_t *slotsOut, size_t cap, uint32_t *nChunksOut)
 {
-    if (jobs == nullptr || nChunksOut == nullptr || fpw < 2 || fpw > 64)
+    if (jobs == nullptr || nChunksOut == nullptr || fpw < 8 || fpw > 64)
         return DCS_ERR_INVALID_ARG;
     std::vector<DcsSlot> slots;
-    *nChunksOut = dcsPlanChunks(jobs, nJobs, fpw, slots);
+    *nChunksOut = dcsPlanChunks(jobs, nJobs, srcs, fpw, slots);
     if (slotsOut != nullptr)
     {
         if (cap < slots.size())

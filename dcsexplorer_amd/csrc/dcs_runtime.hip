@@ -217,7 +217,7 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
     b->fpw = chooseFpw(ctx, nJobs);
 
     std::vector<DcsSlot> slots;
-    b->nChunks = dcsPlanChunks(jobs, nJobs, b->fpw, slots);
+    b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots);
 
     // algorithmic bytes: compressed payload + descriptors read, PCM written
     b->algoBytes = (payloadBits + 7) / 8 + static_cast<uint64_t>(nSrcs) * sizeof(DcsSrcDesc)

@@ -249,8 +249,9 @@ DcsStatus dcs_synth_stream(const DcsSynthParams *params, uint8_t *out, size_t ca
 /* Diagnostic: the chunk plan the kernel launch would use for `jobs` at `fpw` frames per wavefront.
  * Each slot is returned as job | prevSlot<<32 | flags<<40 (flags: 1 = halo, 2 = external tail,
  * 0x80 = padding).  One wavefront decodes one chunk of fpw slots; a frame whose overlap predecessor
- * lies in another chunk gets that predecessor decoded again as a halo slot. */
-DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, int fpw,
+ * lies in another chunk gets that predecessor decoded again as a halo slot.  `srcs` (may be NULL)
+ * lets the planner also respect the kernel's LDS budget for staged compressed bytes. */
+DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw,
                           uint64_t *slotsOut, size_t cap, uint32_t *nChunksOut);
 
 uint32_t dcs_abi_version(void);
