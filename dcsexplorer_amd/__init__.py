@@ -8,7 +8,7 @@ from .api import (  # noqa: F401
     OS93A, OS93B, OS94, OS95,
     FMT_93_T0, FMT_93B_T1, FMT_93A_T1, FMT_94_T0, FMT_94_T1_S0, FMT_94_T1_S3,
     FRAME_SAMPLES, FRAME_STOP, FRAME_FATAL, PREV_NONE, PREV_EXT, XFORM_93, XFORM_94,
-    SRC_DTYPE, JOB_DTYPE, INDEX_DTYPE,
+    SRC_DTYPE, JOB_DTYPE, INDEX_DTYPE, IDX_SERIAL,
     DcsError, lib_path, load_library,
     index_stream, stream_params, volume_multiplier, mixing_multiplier, frame_scale,
     synth_stream, build_stream_batch, device_count, plan_chunks, format_os,

@@ -16,12 +16,15 @@ PREV_EXT = 0x80000000
 XFORM_93, XFORM_94 = 0, 1
 
 # numpy views of the ABI structs (layouts asserted against the library at load time)
-SRC_DTYPE = np.dtype([("streamOff", "<u8"), ("bitOff", "<u4"), ("nBits", "<u4"), ("mixMul", "<u2"),
-                      ("format", "u1"), ("hdrLen", "u1"), ("reserved", "<u4"), ("bandType", "<u2", (16,))])
+SPLIT_DTYPE = np.dtype([("bitDelta", "<u2"), ("prv", "<u2"), ("prvDelta", "<u2"), ("state", "<u2")])
+INDEX_DTYPE = np.dtype([("bitOff", "<u4"), ("nBits", "<u2"), ("hdrBits", "<u2"), ("bandType", "u1", (16,)),
+                        ("preAdj", "<u2"), ("nBands", "u1"), ("flags", "u1"), ("split", SPLIT_DTYPE, (3,))])
+SRC_DTYPE = np.dtype([("streamOff", "<u8"), ("mixMul", "<u2"), ("format", "u1"), ("hdrLen", "u1"),
+                      ("idx", INDEX_DTYPE)])
 JOB_DTYPE = np.dtype([("firstSrc", "<u4"), ("nSrc", "u1"), ("volShift", "u1"), ("xform", "u1"), ("flags", "u1"),
                       ("prev", "<u4"), ("reserved", "<u4")])
-INDEX_DTYPE = np.dtype([("bitOff", "<u4"), ("nBits", "<u4"), ("bandType", "<u2", (16,)), ("err", "<u4")])
-assert SRC_DTYPE.itemsize == 56 and JOB_DTYPE.itemsize == 16 and INDEX_DTYPE.itemsize == 44
+assert SRC_DTYPE.itemsize == 64 and JOB_DTYPE.itemsize == 16 and INDEX_DTYPE.itemsize == 52
+IDX_SERIAL = 1
 
 
 class StreamInfo(ctypes.Structure):
@@ -212,12 +215,10 @@ def build_stream_batch(streams, extra_frames=0, pad=64):
         nvalid = info.nValidFrames
         s = np.zeros(nvalid, dtype=SRC_DTYPE)
         s["streamOff"] = off
-        s["bitOff"] = idx["bitOff"]
-        s["nBits"] = idx["nBits"]
         s["mixMul"] = mm[:nvalid]
         s["format"] = info.format
         s["hdrLen"] = info.hdrLen
-        s["bandType"] = idx["bandType"]
+        s["idx"] = idx
         total = nframes + extra_frames
         j = np.zeros(total, dtype=JOB_DTYPE)
         nsrc_before = sum(len(x) for x in srcs)

@@ -57,8 +57,7 @@ const DcsDevTables &dcsTables();
 // frame lives in another chunk).
 // ---------------------------------------------------------------------------------------------
 // LDS bit pool: the compressed bytes of the frames one wavefront unpacks in one round are staged
-// there.  The planner closes a chunk before the pool would overflow; a frame of unknown length
-// (nBits == 0) is budgeted at the format's maximum.
+// there.  The planner closes a chunk before the pool would overflow.
 #define DCS_POOL_DW_PER_FRAME 56        // 224 bytes per frame slot on average (typical frame: ~125-150 bytes)
 #define DCS_MAX_FRAME_BITS    4480      // 16 band headers + 255 x 16-bit samples, rounded up
 
@@ -71,8 +70,7 @@ __host__ __device__
 uint32_t dcsPoolDwords(uint64_t streamOff, uint32_t hdrLen, uint32_t bitOff, uint32_t nBits)
 {
     const uint32_t inDword = static_cast<uint32_t>(((streamOff + 2 + hdrLen) * 8 + bitOff) & 31);
-    const uint32_t bits = nBits ? nBits : DCS_MAX_FRAME_BITS;
-    return (inDword + bits + 31) / 32 + 2;
+    return (inDword + nBits + 31) / 32 + 2;
 }
 #endif
 

@@ -58,43 +58,70 @@ struct Scan
     Bits b;
     uint8_t header[16];
     uint16_t bandType[16];
+    int nBands = 0;
     uint32_t err = 0;
 };
 
 inline void fatal(Scan &s) { s.err |= DCS_FRAME_FATAL | DCS_FRAME_STOP; }
 
+inline void putSplit(DcsFrameIndex &fi, int band, uint32_t frameStart, const Scan &s, int outIdx,
+                     uint32_t prv = 0, uint32_t prvDelta = 0, int subType = 0, bool reuse = false)
+{
+    if (band != 4 && band != 8 && band != 12)
+        return;
+    DcsSplit &sp = fi.split[band / 4 - 1];
+    sp.bitDelta = static_cast<uint16_t>(s.b.bitPos() - frameStart);
+    sp.prv = static_cast<uint16_t>(prv);
+    sp.prvDelta = static_cast<uint16_t>(prvDelta);
+    sp.state = static_cast<uint16_t>((outIdx & 0x1FF) | (subType << 9) | (reuse ? 0x800 : 0));
+}
+
 // --- 1994+ frame (:1679-2261) -----------------------------------------------------------------
-void scan94(Scan &s)
+void scan94(Scan &s, DcsFrameIndex &fi)
 {
     const DcsLdsTables &T = dcsTables().lds;
     const uint8_t *hdr = s.header;
     const bool type1 = (hdr[0] & 0x80) != 0;
+    const bool sub0 = ((hdr[1] | hdr[2]) & 0x80) == 0;
+    const uint32_t frameStart = s.b.bitPos();
 
-    // Type 1 indexes its pre-adjust map with the previous frame's codes of bands 0..2 (:1771-1773)
+    // Type 1 indexes its pre-adjust map with the previous frame's codes of bands 0..2 (:1744-1773)
     if (type1)
+    {
         for (int i = 0 ; i < 3 ; ++i)
             if (s.bandType[i] > 15) { fatal(s); return; }
+        const uint8_t *map = T.preAdj94 + (sub0 ? 0 : 16);
+        fi.preAdj = static_cast<uint16_t>(map[s.bandType[0]] | (map[s.bandType[1]] << 4) | (map[s.bandType[2]] << 8));
+    }
 
     // frame header: one delta code per populated band (:1780-1834)
-    for (int i = 0 ; i < 16 && (hdr[i] & 0x7F) != 0x7F ; ++i)
+    for (int i = 0 ; i < s.nBands ; ++i)
         s.bandType[i] = static_cast<uint16_t>(s.bandType[i] + readVlc(s.b, T.trie94) - 16);
+    fi.hdrBits = static_cast<uint16_t>(s.b.bitPos() - frameStart);
+    for (int i = 0 ; i < 16 ; ++i)
+        fi.bandType[i] = static_cast<uint8_t>(s.bandType[i] > 255 ? 255 : s.bandType[i]);
 
-    for (int band = 0 ; band < 16 ; ++band)
+    int outIdx = 1;
+    for (int band = 0 ; band < s.nBands ; ++band)
     {
+        putSplit(fi, band, frameStart, s, outIdx);
         const int hb = hdr[band] & 0x7F;
-        if (hb == 0x7F)
-            break;
         int count = band == 0 ? 7 : band == 1 ? 8 : band == 15 ? 32 : 16;      // :1848-1850
-        if (hb & 0x40)
-            count /= 2;
+        int inc = 1;
+        if (hb & 0x40) { count /= 2; inc = 2; }
         int code = s.bandType[band];
         if (code == 0)
+        {
+            outIdx += count;                            // the halved count (:1886)
             continue;
+        }
         if (type1)
         {
             if (code > 15) { fatal(s); return; }
             code = T.xlat94[(band < 3 ? 0 : band < 6 ? 16 : 32) + code] & 0xFF;
         }
+        if (code > 16) { fatal(s); return; }
+        outIdx += count * inc;
         if (code == 0)
         {
             s.err |= DCS_FRAME_STOP;                    // :1985-1991, consumes nothing
@@ -116,7 +143,6 @@ void scan94(Scan &s)
         }
         else
         {
-            if (code > 16) { fatal(s); return; }
             for (int i = 0 ; i < count ; ++i)
                 s.b.get(code);
         }
@@ -124,20 +150,37 @@ void scan94(Scan &s)
 }
 
 // --- 1993 frame, Type 0 and OS93b Type 1 (:2293-2615) --------------------------------------------
-void scan93(Scan &s)
+void scan93(Scan &s, DcsFrameIndex &fi)
 {
     const DcsLdsTables &T = dcsTables().lds;
     const bool type1 = (s.header[0] & 0x80) != 0;
+    const uint32_t frameStart = s.b.bitPos();
     bool first = true, reuse = false;
     int code = 0;
+    int subType = type1 ? 0 : 2;
+    uint32_t prv = 0, prvDelta = 0;
+    int outIdx = 1;
 
-    for (int band = 0 ; band < 16 ; ++band)
+    for (int i = 0 ; i < 16 ; ++i)
+        fi.bandType[i] = static_cast<uint8_t>(s.bandType[i] > 255 ? 255 : s.bandType[i]);
+
+    for (int band = 0 ; band < s.nBands ; ++band)
     {
+        putSplit(fi, band, frameStart, s, outIdx, prv, prvDelta, subType, reuse);
         const int hb = s.header[band] & 0x7F;
-        if (hb == 0x7F)
-            break;
         const bool strided = (hb >> 6) != 0;
-        const int nSamples = !type1 ? 16 : strided ? 8 : first ? 15 : 16;       // :2351-2383
+        int nSamples, inc = 1, fixup = 0, stride;
+        if (!type1)
+        {
+            nSamples = 16;
+            if (!strided) stride = 16;
+            else { ++outIdx; inc = 2; fixup = -1; stride = 31; }
+        }
+        else
+        {
+            if (!strided) nSamples = stride = first ? 15 : 16;
+            else { inc = 2; nSamples = stride = 8; }
+        }
 
         if (reuse)
             reuse = s.b.get(1) != 0;
@@ -146,26 +189,61 @@ void scan93(Scan &s)
             if (!type1)
             {
                 if (s.b.get(1))
-                    s.b.get(1);                                 // sub-type step direction (:2402-2414)
+                    subType = s.b.get(1) ? (subType + 1) % 3 : (subType + 2) % 3;   // :2402-2414
                 code = static_cast<int>(s.b.get(4));
             }
             else
             {
                 int v = readVlc(s.b, T.trie93);
-                v = v < 0x1E ? v - 0x0F : v - 0x2E;             // :2668-2681
+                if (v < 0x1E)
+                    v -= 0x0F;                                      // :2668-2681
+                else
+                {
+                    v -= 0x2E;
+                    subType = subType != 0 ? 0 : 1;
+                }
                 s.bandType[band] = static_cast<uint16_t>(s.bandType[band] + v);
                 code = s.bandType[band];
             }
         }
 
         if (code == 0)
-            reuse = true;                                       // :2455
+        {
+            reuse = true;                                           // :2455
+            if (subType == 0) { outIdx += stride; prv = 0; prvDelta = 0; }
+            else if (subType == 1) { prvDelta = 0; outIdx += nSamples * inc + fixup; }
+            else
+            {
+                for (int i = 0 ; i < nSamples ; ++i)
+                    prv = (prv + prvDelta) & 0xFFFF;
+                outIdx += nSamples * inc + fixup;
+            }
+        }
         else
         {
             const int width = code + (type1 ? 0 : 1);
             if (width > 16) { fatal(s); return; }
+            // the sample values are needed only for the carried (prv, prvDelta) pair (:2565-2599)
+            uint32_t last = 0, last2 = 0;
             for (int i = 0 ; i < nSamples ; ++i)
-                s.b.get(width);
+            {
+                uint32_t in = s.b.get(width);
+                if (in & (1u << (width - 1)))
+                    in |= 0xFFFFFFFFu << width;
+                in &= 0xFFFF;
+                if (subType == 0) { last2 = last; last = in; }
+                else
+                {
+                    prvDelta = subType == 1 ? in : ((prvDelta + in) & 0xFFFF);
+                    prv = (prv + prvDelta) & 0xFFFF;
+                }
+            }
+            if (subType == 0)
+            {
+                prv = last;
+                prvDelta = (last - last2) & 0xFFFF;
+            }
+            outIdx += nSamples * inc + fixup;
         }
         first = false;
     }
@@ -222,6 +300,11 @@ extern "C" DcsStatus dcs_index_stream(DcsOsVersion os, const uint8_t *stream, si
         s.header[i] = static_cast<uint8_t>(s.b.byteAt(2 + static_cast<size_t>(i)));
     memset(s.bandType, 0, sizeof(s.bandType));
     s.b.payOff = s.b.p = 2 + static_cast<size_t>(hdrLen);
+    if (os == DCS_OS93A && typeBit)
+        s.nBands = s.header[0] & 0x1F;
+    else
+        while (s.nBands < 16 && (s.header[s.nBands] & 0x7F) != 0x7F)
+            ++s.nBands;
 
     int format;
     if (os == DCS_OS93A)
@@ -248,18 +331,19 @@ extern "C" DcsStatus dcs_index_stream(DcsOsVersion os, const uint8_t *stream, si
     for (int f = 0 ; f < nFrames ; ++f)
     {
         DcsFrameIndex fi;
+        memset(&fi, 0, sizeof(fi));
         fi.bitOff = s.b.bitPos();
-        memcpy(fi.bandType, s.bandType, sizeof(fi.bandType));
+        fi.nBands = static_cast<uint8_t>(s.nBands);
         s.err = 0;
         switch (format)
         {
         case DCS_FMT_93_T0:
-        case DCS_FMT_93B_T1: scan93(s); break;
+        case DCS_FMT_93B_T1: scan93(s, fi); break;
         case DCS_FMT_93A_T1: scan93a(s); break;
-        default:             scan94(s); break;
+        default:             scan94(s, fi); break;
         }
-        fi.nBits = s.b.bitPos() - fi.bitOff;
-        fi.err = s.err;
+        fi.nBits = static_cast<uint16_t>(s.b.bitPos() - fi.bitOff);
+        fi.flags = static_cast<uint8_t>((s.err << 4) | ((s.err != 0 || format == DCS_FMT_93A_T1) ? DCS_IDX_SERIAL : 0));
         if (static_cast<uint32_t>(valid) < cap)
             out[valid] = fi;
         else if (out != nullptr || cap != 0)

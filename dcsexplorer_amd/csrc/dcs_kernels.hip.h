@@ -2,17 +2,19 @@
 //
 // One wavefront (= one 64-thread workgroup) decodes one CHUNK of up to FPW frames in two phases:
 //
-//   phase 1, lane-per-frame:  lane s unpacks the bitstream of slot s (Huffman / fixed-width fields),
-//            dequantises and mix-accumulates the <=255 frequency-domain words of the frame into row
-//            s of an LDS tile.  This is the serial entropy decode (~250 dependent symbol decodes per
-//            frame); running FPW frames side by side is what keeps the SIMD lanes busy.
+//   phase 1, unpack, SUB lanes per frame:  the index pass recorded the decoder state at the start of
+//            header bands 4, 8 and 12 of every frame (DcsSplit), so SUB = 4 lanes unpack one frame in
+//            parallel, four bands each: Huffman / fixed-width fields -> dequantise -> mix-accumulate the
+//            <=255 frequency-domain words into the frame's row of an LDS tile.  16 frames x 4 lanes
+//            keep all 64 lanes of the wavefront on the serial entropy decode (~64 dependent symbol
+//            decodes per lane instead of ~250 per frame).  The compressed bytes of the chunk are first
+//            staged into an LDS pool with coalesced loads (byte-swapped to bit order), so the
+//            per-symbol critical path never waits on HBM/L2.
 //            [DecoderImpl94x/93/93a::DecompressFrame, DCSDecoderNative.cpp:1679-2261, :2293-2684,
 //             :2831-3032; ROMBitPointer, DCSDecoderNative.h:229-289]
-//            The compressed bytes of the chunk are first staged into an LDS pool with coalesced
-//            loads (byte-swapped to bit order), so the per-symbol critical path never waits on HBM/L2.
-//   phase 2, 8 or 16 lanes per frame:  register-resident fixed-point inverse transforms of 8 (1994+)
-//            or 4 (1993) rows per pass, volume shift, overlap-add with the predecessor's 16-sample
-//            tail (kept in LDS), 240 int16 PCM samples written per frame.
+//   phase 2, transform, 8 or 16 lanes per frame:  register-resident fixed-point inverse transforms of
+//            8 (1994+) or 4 (1993) rows per pass, volume shift, overlap-add with the predecessor's
+//            16-sample tail (kept in LDS), 240 int16 PCM samples written per frame.
 //            [DecoderImpl94x::TransformFrame :397-576, DecoderImpl93::TransformFrame :614-813]
 //
 // All arithmetic is the ADSP-2105 fixed-point arithmetic of the reference restated in 32-bit integer
@@ -24,16 +26,22 @@
 
 namespace dcsk {
 
-constexpr int kRowBytes = 516;          // 256 words + one pad dword: lane-per-frame rows hit distinct LDS banks
+constexpr int kRowBytes = 516;          // 256 words + one pad dword: rows of different frames hit distinct LDS banks
 constexpr int kScratchBytes = 5376;     // transpose scratch of one transform pass (8 x 168 or 4 x 336 dwords)
 
 __host__ __device__ constexpr int poolDwords(int fpw) { return fpw * DCS_POOL_DW_PER_FRAME; }
+__host__ __device__ constexpr int subLanes(int fpw) { return fpw <= 16 ? 4 : fpw == 32 ? 2 : 1; }
+
+// the bit pool (phase 1) and the transpose scratch (phase 2) are never live together: one region
+__host__ __device__ constexpr int poolOrScratchBytes(int fpw)
+{
+    return poolDwords(fpw) * 4 > kScratchBytes ? poolDwords(fpw) * 4 : kScratchBytes;
+}
 
 __host__ __device__ constexpr int ldsBytes(int fpw)
 {
-    // tables | tile rows | band types [16][fpw] u16 | header bytes [16][fpw] u8 | tails [fpw][16] i16 | scratch | bit pool
-    return static_cast<int>(sizeof(DcsLdsTables)) + ((fpw * kRowBytes + 15) & ~15) + fpw * 32 + fpw * 16 + fpw * 32 + kScratchBytes
-         + poolDwords(fpw) * 4;
+    // tables | tile rows | tails [fpw][16] i16 | bit pool / transpose scratch
+    return static_cast<int>(sizeof(DcsLdsTables)) + ((fpw * kRowBytes + 15) & ~15) + fpw * 32 + poolOrScratchBytes(fpw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -157,12 +165,34 @@ struct Lds
     __device__ __forceinline__ uint16_t *row(int s) const
     { return reinterpret_cast<uint16_t *>(base + sizeof(DcsLdsTables) + s * kRowBytes); }
     static constexpr int kSide = static_cast<int>(sizeof(DcsLdsTables)) + ((FPW * kRowBytes + 15) & ~15);
-    __device__ __forceinline__ uint16_t *bandTypes() const { return reinterpret_cast<uint16_t *>(base + kSide); }            // [16][FPW]
-    __device__ __forceinline__ uint8_t *hdrBytes() const { return base + kSide + FPW * 32; }                                   // [16][FPW]
-    __device__ __forceinline__ uint16_t *tails() const { return reinterpret_cast<uint16_t *>(base + kSide + FPW * 48); }     // [FPW][16]
-    __device__ __forceinline__ uint32_t *scratch() const { return reinterpret_cast<uint32_t *>(base + kSide + FPW * 80); }   // kScratchBytes
-    __device__ __forceinline__ uint32_t *pool() const { return reinterpret_cast<uint32_t *>(base + kSide + FPW * 80 + kScratchBytes); }
+    __device__ __forceinline__ uint16_t *tails() const { return reinterpret_cast<uint16_t *>(base + kSide); }               // [FPW][16]
+    __device__ __forceinline__ uint32_t *scratch() const { return reinterpret_cast<uint32_t *>(base + kSide + FPW * 32); }  // phase 2
+    __device__ __forceinline__ uint32_t *pool() const { return scratch(); }                                                    // phase 1
 };
+
+// what one sub-lane knows about the frame quarter it unpacks
+struct Quarter
+{
+    uint32_t h0, h1, h2, h3;    // the stream header, 16 bytes (byte b = h[b >> 2] >> 8*(b & 3))
+    uint32_t t0, t1, t2, t3;    // DcsFrameIndex.bandType, same packing
+    int bandBase;           // first header band of this lane
+    int nb;                 // number of bands this lane unpacks (0: idle)
+    int outIdx;             // tile word index at the start of bandBase
+    uint32_t preAdj;        // 1994+ Type 1, bands 0..2 (4 bits each)
+    // 1993 formats: state carried into bandBase
+    uint32_t prv, prvDelta;
+    int subType;
+    bool reuse, first;
+};
+
+// byte b (0..15) of four registers; explicit selects so that nothing is indexed in memory
+__device__ __forceinline__ int byteOf(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int b)
+{
+    const int i = b >> 2;
+    const uint32_t lo = (i & 1) ? w1 : w0, hi = (i & 1) ? w3 : w2;
+    const uint32_t w = (i & 2) ? hi : lo;
+    return static_cast<int>((w >> (8 * (b & 3))) & 0xFFu);
+}
 
 // the 32-bit "splice" multiply-accumulate of the mixer (.cpp:2244-2250, :2434-2443): low word =
 // scaled sample, high word = accumulator, add (int16)scaled * (uint16)mixMul, keep the high word.
@@ -202,73 +232,45 @@ constexpr int kDummyWord = 256;         // the pad word of a tile row: sink for 
 // ------------------------------------------------------------------------------------------------
 // a2: 1994+ frame (DecoderImpl94x::DecompressFrame, .cpp:1679-2261)
 //
-// Lane-per-frame.  The per-band set-up is ordinary divergent code (16 times per frame); the symbol
-// loop -- ~250 iterations per frame -- is written branch-free so that lanes with Huffman-coded
-// bands, raw bands and different codebooks all execute the same instruction stream.
+// Each lane unpacks Q.nb consecutive header bands.  The frame header (band-type deltas, :1780-1834)
+// was already resolved by the index pass: Q.types holds this frame's codes, Q.preAdj the scale
+// pre-adjust that depends on the PREVIOUS frame (:1744-1773).  The per-band set-up is ordinary
+// divergent code; the symbol loop is branch-free so that lanes with Huffman-coded bands, raw bands
+// and different codebooks all execute the same instruction stream.
 // ------------------------------------------------------------------------------------------------
-template <int FPW, bool FIRST>
-__device__ uint32_t unpack94(const Lds<FPW> &L, int lane, BitReader &br, int format, uint32_t mixMul, bool has)
+template <bool FIRST>
+__device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br, const Quarter &Q,
+                             int format, uint32_t mixMul, bool has)
 {
-    const DcsLdsTables *T = L.tables();
-    uint16_t *row = L.row(lane);
-    uint16_t *bt = L.bandTypes() + lane;            // element b at bt[b * FPW]
-    const uint8_t *hdr = L.hdrBytes() + lane;       // element b at hdr[b * FPW]
     const bool type1 = format != DCS_FMT_94_T0;
-    const uint32_t saved1 = row[1];
     uint32_t err = 0;
-    bool done = !has;                               // lanes without a 1994+ source ride along masked off
-
-    // scale pre-adjust for bands 0..2 from the PREVIOUS frame's codes (:1744-1773)
-    int preAdj0 = 0, preAdj1 = 0, preAdj2 = 0;
-    if (type1 && !done)
-    {
-        const uint8_t *map = T->preAdj94 + (format == DCS_FMT_94_T1_S0 ? 0 : 16);
-        const uint32_t c0 = bt[0], c1 = bt[FPW], c2 = bt[2 * FPW];
-        if ((c0 | c1 | c2) > 15)
-        {
-            err = DCS_FRAME_FATAL | DCS_FRAME_STOP;
-            done = true;
-        }
-        else
-        {
-            preAdj0 = map[c0]; preAdj1 = map[c1]; preAdj2 = map[c2];
-        }
-    }
-
-    // frame header: band-type deltas (:1780-1834)
-    {
-        bool more = !done;
-        for (int i = 0 ; i < 16 ; ++i)
-        {
-            more = more && (hdr[i * FPW] & 0x7F) != 0x7F;
-            if (!__any(more))
-                break;
-            if (more)
-                bt[i * FPW] = static_cast<uint16_t>(bt[i * FPW] + readVlc(br, T->fast94, T->trie94) - 16);
-        }
-    }
-
-    int outIdx = 1;
+    int nb = has ? Q.nb : 0;
+    int outIdx = Q.outIdx;
     bool valid = true;
-    for (int band = 0 ; band < 16 ; ++band)
-    {
-        int hb = hdr[band * FPW] & 0x7F;
-        done = done || hb == 0x7F;
-        if (__all(done))
-            break;
+    const bool owner = has && Q.bandBase == 0;          // the lane that holds band 0 does the DC fix-up
+    const uint32_t saved1 = (owner && !FIRST) ? row[1] : 0u;
 
+    int maxNb = nb;
+#pragma unroll
+    for (int d = 32 ; d >= 1 ; d >>= 1)
+        maxNb = max(maxNb, __shfl_xor(maxNb, d));
+
+    for (int k = 0 ; k < maxNb ; ++k)
+    {
         // ---- per-band set-up -------------------------------------------------------------------------
+        const int band = Q.bandBase + k;
         int i = 0;                  // symbols still to decode in this band
         int inc = 1;
         int rawW = 0;               // > 0: fixed-width band of that many bits
         int shPeek = 0;             // 32 - look-ahead width
         int ref = 0, scale = 0;
         const uint16_t *book = T->cb94;
-        if (!done)
+        if (k < nb)
         {
+            int hb = byteOf(Q.h0, Q.h1, Q.h2, Q.h3, band) & 0x7F;
             int count = band == 0 ? 7 : band == 1 ? 8 : band == 15 ? 32 : 16;      // :1848-1850
             if (hb & 0x40) { inc = 2; count >>= 1; }
-            int code = bt[band * FPW];
+            int code = byteOf(Q.t0, Q.t1, Q.t2, Q.t3, band);
             if (code == 0)
                 outIdx += count;                    // the halved count, not count*inc (:1886)
             else
@@ -280,16 +282,17 @@ __device__ uint32_t unpack94(const Lds<FPW> &L, int lane, BitReader &br, int for
                     fatal = code > 15;
                     const uint32_t x = T->xlat94[(band < 3 ? 0 : band < 6 ? 16 : 32) + (code & 15)];
                     if (band < 3)
-                        hb += band == 0 ? preAdj0 : band == 1 ? preAdj1 : preAdj2;
+                        hb += static_cast<int>((Q.preAdj >> (4 * band)) & 15u);
                     scaleCode = hb + static_cast<int>(x >> 8);
-                    code = static_cast<int>(x & 0xFF);
+                    if (!fatal)
+                        code = static_cast<int>(x & 0xFF);
                 }
                 fatal = fatal || code > 16;
                 scale = static_cast<int>(scaleFactor(T, scaleCode));
                 if (fatal)
                 {
                     err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;
-                    done = true;
+                    nb = 0;                         // stop: later bands contribute nothing
                 }
                 else if (code == 0)
                 {
@@ -337,25 +340,25 @@ __device__ uint32_t unpack94(const Lds<FPW> &L, int lane, BitReader &br, int for
         if (bad)
         {
             // the reference zeroes the WHOLE band buffer on this error (:2238-2239): take back what the
-            // band already contributed by replaying it
+            // band already contributed by replaying it.  (Frames with errors are never split.)
             if (valid)
             {
                 BitReader r2 = bandStart;
-                int k = idxStart;
+                int kk = idxStart;
                 for (int j = countStart ; j > 1 ; )
                 {
                     r2.refill();
                     const uint32_t e = book[r2.hi >> shPeek];
                     r2.skip(static_cast<int>(e >> 8));
-                    if (e & 0x80) { k += 2 * inc; j -= 2; }
-                    else { mixSub(&row[k], __mul24(static_cast<int>(e & 0xFF) - ref, scale), mixMul); k += inc; --j; }
+                    if (e & 0x80) { kk += 2 * inc; j -= 2; }
+                    else { mixSub(&row[kk], __mul24(static_cast<int>(e & 0xFF) - ref, scale), mixMul); kk += inc; --j; }
                 }
             }
             valid = false; err |= DCS_FRAME_STOP;
         }
     }
 
-    if (has)
+    if (owner)
         dcFixup(row, saved1);
     return err;
 }
@@ -368,39 +371,39 @@ __device__ uint32_t unpack94(const Lds<FPW> &L, int lane, BitReader &br, int for
 // prvDelta' = st == 0 ? p - prv : d;  prv' = p.  A code-0 band of sub-type 2 (ramp, :2539-2545) is the
 // same update with in = 0, so it rides in the same loop without reading bits.
 // ------------------------------------------------------------------------------------------------
-template <int FPW, bool FIRST>
-__device__ uint32_t unpack93(const Lds<FPW> &L, int lane, BitReader &br, int format, uint32_t mixMul, bool has)
+template <bool FIRST>
+__device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br, const Quarter &Q,
+                             int format, uint32_t mixMul, bool has)
 {
-    const DcsLdsTables *T = L.tables();
-    uint16_t *row = L.row(lane);
-    uint16_t *bt = L.bandTypes() + lane;
-    const uint8_t *hdr = L.hdrBytes() + lane;
     const bool type1 = format == DCS_FMT_93B_T1;
-    const uint32_t saved1 = row[1];
     uint32_t err = 0;
-    bool done = !has;
+    int nb = has ? Q.nb : 0;
+    const bool owner = has && Q.bandBase == 0;
+    const uint32_t saved1 = (owner && !FIRST) ? row[1] : 0u;
 
-    int subType = type1 ? 0 : 2;
-    bool first = true, reuse = false;
-    uint32_t prv = 0, prvDelta = 0;         // uint16 semantics: masked on use
+    int subType = Q.subType;
+    bool first = Q.first, reuse = Q.reuse;
+    uint32_t prv = Q.prv, prvDelta = Q.prvDelta;        // uint16 semantics: masked on use
     int code = 0;
-    int outIdx = 1;
+    int outIdx = Q.outIdx;
 
-    for (int band = 0 ; band < 16 ; ++band)
+    int maxNb = nb;
+#pragma unroll
+    for (int d = 32 ; d >= 1 ; d >>= 1)
+        maxNb = max(maxNb, __shfl_xor(maxNb, d));
+
+    for (int k = 0 ; k < maxNb ; ++k)
     {
-        const int hb = hdr[band * FPW] & 0x7F;
-        done = done || hb == 0x7F;
-        if (__all(done))
-            break;
-
+        const int band = Q.bandBase + k;
         int nS = 0;                 // samples this lane runs through the main loop
         int width = 0;              // bits per input (0: ramp, no bits read)
         int inc = 1, fixup = 0;
         int scale = 0;
         bool quirk = false;         // code 0, sub-type 1
         int nQ = 0;
-        if (!done)
+        if (k < nb)
         {
+            const int hb = byteOf(Q.h0, Q.h1, Q.h2, Q.h3, band) & 0x7F;
             scale = static_cast<int>(scaleFactor(T, hb));
             const bool strided = (hb >> 6) != 0;
             int nSamples, stride;
@@ -436,9 +439,7 @@ __device__ uint32_t unpack93(const Lds<FPW> &L, int lane, BitReader &br, int for
                         v -= 0x2E;
                         subType = subType != 0 ? 0 : 1;
                     }
-                    const uint32_t nc = (bt[band * FPW] + static_cast<uint32_t>(v)) & 0xFFFFu;
-                    bt[band * FPW] = static_cast<uint16_t>(nc);
-                    code = static_cast<int>(nc);
+                    code = (byteOf(Q.t0, Q.t1, Q.t2, Q.t3, band) + v) & 0xFFFF;
                 }
             }
 
@@ -463,7 +464,7 @@ __device__ uint32_t unpack93(const Lds<FPW> &L, int lane, BitReader &br, int for
                 if (width > 16)
                 {
                     err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;
-                    done = true;
+                    nb = 0;
                     width = 0;
                 }
                 else
@@ -521,20 +522,17 @@ __device__ uint32_t unpack93(const Lds<FPW> &L, int lane, BitReader &br, int for
             outIdx += fixup;
     }
 
-    if (has)
+    if (owner)
         dcFixup(row, saved1);
     return err;
 }
 
 // ------------------------------------------------------------------------------------------------
-// a4: OS93a Type 1 frame (DecoderImpl93a::DecompressFrame, .cpp:2831-3032)
+// a4: OS93a Type 1 frame (DecoderImpl93a::DecompressFrame, .cpp:2831-3032).  Not split: one lane per frame.
 // ------------------------------------------------------------------------------------------------
-template <int FPW>
-__device__ uint32_t unpack93a(const Lds<FPW> &L, int lane, BitReader &br, uint32_t mixMul, const uint16_t *pairTable)
+__device__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *row, BitReader &br, int hb, uint32_t mixMul,
+                              const uint16_t *pairTable)
 {
-    const DcsLdsTables *T = L.tables();
-    uint16_t *row = L.row(lane);
-    const int hb = L.hdrBytes()[lane];
     const uint16_t *bbBook = &T->bandBits93a[(hb & 0x60) >> 1];
     const int numBands = hb & 0x1F;
     int prvScale = 0x1A;
@@ -978,6 +976,11 @@ __global__ void __launch_bounds__(64) dcsDecodeKernel(const DcsKernelArgs a)
     const Lds<FPW> L{ smem };
     const int lane = static_cast<int>(threadIdx.x);
     const uint32_t chunk = blockIdx.x;
+    constexpr int SUB = subLanes(FPW);              // lanes that unpack one frame together
+    constexpr int BPL = 16 / SUB;                   // header bands per sub-lane
+    const int s = lane % FPW;                       // slot of this lane
+    const int q = lane / FPW;                       // which part of the frame it unpacks
+    const bool unpacker = q < SUB;
 
     // ---- stage tables, clear the tile --------------------------------------------------------
     {
@@ -994,20 +997,20 @@ __global__ void __launch_bounds__(64) dcsDecodeKernel(const DcsKernelArgs a)
     LaneConsts C;
     loadLaneConsts(a.tables, lane, C);
 
-    // ---- slot and job of this lane -------------------------------------------------------------
-    DcsSlot slot{ 0xFFFFFFFFu, DCS_NO_PREV_SLOT, DCS_SLOT_EMPTY, 0 };
-    if (lane < FPW)
-        slot = a.slots[static_cast<size_t>(chunk) * FPW + lane];
+    // ---- slot and job of this lane (all sub-lanes of a slot hold the same copy) -----------------
+    DcsSlot slot = a.slots[static_cast<size_t>(chunk) * FPW + s];
     const bool live = !(slot.flags & DCS_SLOT_EMPTY);
     DcsFrameJob job{ 0, 0, 0, DCS_XFORM_94, 0, DCS_PREV_NONE, 0 };
     if (live)
         job = a.jobs[slot.job];
     waveSync();
 
-    // ---- phase 1: lane-per-frame unpack, one round per source index ------------------------------------
+    // ---- phase 1: unpack, one round per source index -------------------------------------------------
     uint32_t err = 0;
     {
         uint32_t *pool = L.pool();
+        const DcsLdsTables *T = L.tables();
+        uint16_t *row = L.row(s);
         const uint32_t *blobW = reinterpret_cast<const uint32_t *>(a.blob);
         const uint32_t blobWords = static_cast<uint32_t>((a.blobLen + 3) >> 2);
         const int myNSrc = live ? job.nSrc : 0;
@@ -1019,20 +1022,32 @@ __global__ void __launch_bounds__(64) dcsDecodeKernel(const DcsKernelArgs a)
         for (int r = 0 ; r < maxSrc ; ++r)
         {
             const bool has = r < myNSrc;
-            const DcsSrcDesc *sd = &a.srcs[has ? job.firstSrc + r : 0];
-            uint64_t streamOff = 0;
-            uint32_t bitOff = 0, nBits = 0, mixMul = 0;
-            int format = 0, hdrLen = 16;
-            if (has)
-            {
-                streamOff = sd->streamOff; bitOff = sd->bitOff; nBits = sd->nBits;
-                mixMul = sd->mixMul; format = sd->format; hdrLen = sd->hdrLen;
-            }
+            // the descriptor: four uint4 per lane, identical addresses within a slot's sub-lanes
+            const uint4 *sdp = reinterpret_cast<const uint4 *>(&a.srcs[has ? job.firstSrc + r : 0]);
+            uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0, d2 = d0, d3 = d0;
+            if (has) { d0 = sdp[0]; d1 = sdp[1]; d2 = sdp[2]; d3 = sdp[3]; }
+            // DcsSrcDesc: [0] streamOff lo, [1] streamOff hi, [2] mixMul | format<<16 | hdrLen<<24,
+            // idx at byte 12: [3] bitOff, [4] nBits | hdrBits<<16, [5..8] bandType, [9] preAdj | nBands<<16 | flags<<24,
+            // [10..15] split[3]
+            const uint64_t streamOff = static_cast<uint64_t>(d0.x) | (static_cast<uint64_t>(d0.y) << 32);
+            const uint32_t mixMul = d0.z & 0xFFFFu;
+            const int format = static_cast<int>((d0.z >> 16) & 0xFFu);
+            const int hdrLen = has ? static_cast<int>(d0.z >> 24) : 16;
+            const uint32_t bitOff = d0.w;
+            const uint32_t nBits = d1.x & 0xFFFFu, hdrBits = d1.x >> 16;
+            const int nBands = static_cast<int>((d2.y >> 16) & 0xFFu);
+            const uint32_t flags = d2.y >> 24;
+            const bool serial = (flags & DCS_IDX_SERIAL) != 0 || SUB == 1;
+
+            Quarter Q;
+            Q.t0 = d1.y; Q.t1 = d1.z; Q.t2 = d1.w; Q.t3 = d2.x;
+            Q.preAdj = d2.y & 0xFFFFu;
+
             const uint64_t bitPos = (streamOff + 2 + static_cast<uint64_t>(hdrLen)) * 8 + bitOff;
             const uint32_t startDw = static_cast<uint32_t>(bitPos >> 5);
-            const uint32_t nDw = has ? dcsPoolDwords(streamOff, static_cast<uint32_t>(hdrLen), bitOff, nBits) : 0u;
+            const uint32_t nDw = (has && q == 0) ? dcsPoolDwords(streamOff, static_cast<uint32_t>(hdrLen), bitOff, nBits) : 0u;
 
-            // exclusive prefix sum of the dword counts = each lane's offset in the pool
+            // exclusive prefix sum of the dword counts over the slots = each frame's offset in the pool
             uint32_t incl = nDw;
 #pragma unroll
             for (int d = 1 ; d < 64 ; d <<= 1)
@@ -1040,15 +1055,17 @@ __global__ void __launch_bounds__(64) dcsDecodeKernel(const DcsKernelArgs a)
                 const uint32_t up = __shfl_up(incl, d);
                 if (lane >= d) incl += up;
             }
-            const uint32_t off = incl - nDw;
-            const bool fits = incl <= static_cast<uint32_t>(poolDwords(FPW));
+            const uint32_t offMine = incl - nDw;
+            const uint32_t off = __shfl(offMine, s);                        // from the slot's q = 0 lane
+            const uint32_t nDwSlot = __shfl(nDw, s);
+            const bool fits = off + nDwSlot <= static_cast<uint32_t>(poolDwords(FPW));
 
             // stage: one coalesced run of dwords per slot, byte-swapped so that bit 31 is the next stream bit
-            for (int s = 0 ; s < FPW ; ++s)
+            for (int t = 0 ; t < FPW ; ++t)
             {
-                const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(nDw), s));
-                const uint32_t st = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(startDw), s));
-                const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(off), s));
+                const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(nDw), t));
+                const uint32_t st = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(startDw), t));
+                const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(offMine), t));
                 if (o + n > static_cast<uint32_t>(poolDwords(FPW)))
                     continue;
                 for (uint32_t i = static_cast<uint32_t>(lane) ; i < n ; i += 64)
@@ -1058,45 +1075,87 @@ __global__ void __launch_bounds__(64) dcsDecodeKernel(const DcsKernelArgs a)
                 }
             }
 
-            if (has)
+            // the stream header: 16 bytes at streamOff + 2, via aligned dwords
             {
-                // carried band types and the stream header into this lane's LDS columns
-                uint16_t *bt = L.bandTypes() + lane;
-                uint8_t *hb = L.hdrBytes() + lane;
+                const uint32_t hw = static_cast<uint32_t>((streamOff + 2) >> 2);
+                const uint32_t sh = static_cast<uint32_t>((streamOff + 2) & 3);
+                uint32_t w[5];
 #pragma unroll
-                for (int i = 0 ; i < 16 ; ++i)
+                for (int i = 0 ; i < 5 ; ++i)
+                    w[i] = (has && hw + i < blobWords) ? blobW[hw + i] : 0u;
+                Q.h0 = __builtin_amdgcn_alignbyte(w[1], w[0], sh);
+                Q.h1 = __builtin_amdgcn_alignbyte(w[2], w[1], sh);
+                Q.h2 = __builtin_amdgcn_alignbyte(w[3], w[2], sh);
+                Q.h3 = __builtin_amdgcn_alignbyte(w[4], w[3], sh);
+                if (hdrLen == 1)
                 {
-                    bt[i * FPW] = sd->bandType[i];
-                    const uint64_t at = streamOff + 2 + static_cast<uint64_t>(i);
-                    hb[i * FPW] = (i < hdrLen && at < a.blobLen) ? a.blob[at] : static_cast<uint8_t>(0);
+                    Q.h0 &= 0xFFu; Q.h1 = Q.h2 = Q.h3 = 0;
                 }
             }
             waveSync();
 
+            // ---- which part of the frame this lane unpacks, and from which decoder state ----------------
+            const bool ok = has && fits && unpacker;
+            if (has && !fits && q == 0)
+                err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;            // cannot happen with the library's planner
+            if (has && q == 0)
+                err |= flags >> 4;                                  // errors the index pass met before band 0 (:1771-1773)
+            uint32_t relBits = hdrBits;                             // band 0 starts behind the 1994+ frame header
+            Q.bandBase = 0;
+            Q.outIdx = 1;
+            Q.prv = 0; Q.prvDelta = 0;
+            Q.subType = (format == DCS_FMT_93B_T1) ? 0 : 2;
+            Q.reuse = false; Q.first = true;
+            if (serial)
+                Q.nb = (q == 0) ? nBands : 0;
+            else
+            {
+                Q.bandBase = q * BPL;
+                Q.nb = min(max(nBands - Q.bandBase, 0), BPL);
+                if (q != 0)
+                {
+                    // DcsSplit k = (bandBase / 4) - 1, 8 bytes each, starting at descriptor dword 10
+                    const int k = Q.bandBase / 4 - 1;
+                    const uint32_t sp0 = k == 0 ? d2.z : k == 1 ? d3.x : d3.z;
+                    const uint32_t sp1 = k == 0 ? d2.w : k == 1 ? d3.y : d3.w;
+                    relBits = sp0 & 0xFFFFu;
+                    Q.prv = sp0 >> 16;
+                    Q.prvDelta = sp1 & 0xFFFFu;
+                    const uint32_t st = sp1 >> 16;
+                    Q.outIdx = static_cast<int>(st & 0x1FFu);
+                    Q.subType = static_cast<int>((st >> 9) & 3u);
+                    Q.reuse = (st & 0x800u) != 0;
+                    Q.first = false;
+                }
+            }
+            const uint32_t inPool = static_cast<uint32_t>(bitPos & 31) + relBits;
+            BitReader br;
+            br.init(pool + (ok ? off + (inPool >> 5) : 0u), static_cast<int>(inPool & 31));
+
             // every lane enters the unpackers (their symbol loops are wave-convergent); lanes without a
             // source of that family are masked off inside
-            if (has && !fits)
-                err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;            // cannot happen with the library's planner
-            const bool ok = has && fits;
-            BitReader br;
-            br.init(pool + (ok ? off : 0u), static_cast<int>(bitPos & 31));
             const bool is94 = ok && format >= DCS_FMT_94_T0;
-            const bool is93a = ok && format == DCS_FMT_93A_T1;
+            const bool is93a = ok && format == DCS_FMT_93A_T1 && q == 0;
             const bool is93 = ok && format < DCS_FMT_93A_T1;
             if (__any(is94))
-                err |= (r == 0) ? unpack94<FPW, true>(L, lane, br, format, mixMul, is94)
-                                : unpack94<FPW, false>(L, lane, br, format, mixMul, is94);
+                err |= (r == 0) ? unpack94<true>(T, row, br, Q, format, mixMul, is94)
+                                : unpack94<false>(T, row, br, Q, format, mixMul, is94);
             if (__any(is93))
-                err |= (r == 0) ? unpack93<FPW, true>(L, lane, br, format, mixMul, is93)
-                                : unpack93<FPW, false>(L, lane, br, format, mixMul, is93);
+                err |= (r == 0) ? unpack93<true>(T, row, br, Q, format, mixMul, is93)
+                                : unpack93<false>(T, row, br, Q, format, mixMul, is93);
             if (is93a)
-                err |= unpack93a<FPW>(L, lane, br, mixMul, a.tables->pair93a);
+                err |= unpack93a(T, row, br, static_cast<int>(Q.h0 & 0xFFu), mixMul, a.tables->pair93a);
             waveSync();
         }
-        if (live)
+
+        // a frame's error bits = OR over its sub-lanes
+#pragma unroll
+        for (int k = 1 ; k < SUB ; ++k)
+            err |= __shfl(err, (lane + k * FPW) & 63);
+        if (live && q == 0)
         {
             if (job.xform == DCS_XFORM_93)
-                dcMagnitude93(L.row(lane));
+                dcMagnitude93(row);
             if (!(slot.flags & DCS_SLOT_HALO) && a.err != nullptr)
                 a.err[slot.job] = err;
         }
@@ -1107,7 +1166,7 @@ __global__ void __launch_bounds__(64) dcsDecodeKernel(const DcsKernelArgs a)
     uint32_t *S = L.scratch();
     uint32_t *tails = reinterpret_cast<uint32_t *>(L.tails());         // [slot][8] dwords = 16 samples
     const uint16_t *coef = a.tables->fftCoef;
-    const int nSlots = __popcll(__ballot(live));                        // padding slots are trailing
+    const int nSlots = __popcll(__ballot(live && lane < FPW));          // padding slots are trailing
     const int slotFlags = slot.flags, slotJob = static_cast<int>(slot.job), slotPrev = slot.prevSlot;
     const int jobShift = job.volShift, jobXform = job.xform, jobPrev = static_cast<int>(job.prev);
 

@@ -27,7 +27,7 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
         if (srcs == nullptr || r >= jobs[j].nSrc)
             return 0;
         const DcsSrcDesc &sd = srcs[jobs[j].firstSrc + r];
-        return dcsPoolDwords(sd.streamOff, sd.hdrLen, sd.bitOff, sd.nBits);
+        return dcsPoolDwords(sd.streamOff, sd.hdrLen, sd.idx.bitOff, sd.idx.nBits);
     };
     auto poolFits = [&](uint32_t j, uint32_t halo, bool withHalo) {
         for (uint32_t r = 0 ; r < DCS_MAX_CHANNELS ; ++r)

@@ -140,17 +140,14 @@ extern "C" DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw)
     return DCS_OK;
 }
 
-// frames per wavefront: large batches amortise the serial unpack over all 64 lanes; small batches
-// spread over more wavefronts so that every CU has work
+// frames per wavefront.  Four lanes unpack one frame, so 16 frames fill the 64 lanes; small batches
+// use 8 frames per wavefront so that more CUs get work (32 / 64 exist for comparison runs).
 static int chooseFpw(const DcsCtx *ctx, uint32_t nJobs)
 {
     if (ctx->fpwOverride != 0)
         return ctx->fpwOverride;
     const uint64_t simds = static_cast<uint64_t>(ctx->numCUs) * 4;
-    if (nJobs >= simds * 64 * 2) return 64;
-    if (nJobs >= simds * 32) return 32;
-    if (nJobs >= simds * 8) return 16;
-    return 8;
+    return nJobs >= simds * 16 ? 16 : 8;
 }
 
 extern "C" void dcs_batch_destroy(DcsBatch *b)
@@ -206,7 +203,7 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
             ctx->lastError = "source " + std::to_string(s) + ": bad format / header length / stream offset";
             return DCS_ERR_INVALID_ARG;
         }
-        payloadBits += sd.nBits;
+        payloadBits += sd.idx.nBits;
     }
 
     DcsBatch *b = new (std::nothrow) DcsBatch;

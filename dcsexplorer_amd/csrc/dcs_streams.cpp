@@ -66,12 +66,10 @@ DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t 
                 DcsSrcDesc sd;
                 memset(&sd, 0, sizeof(sd));
                 sd.streamOff = streamOff;
-                sd.bitOff = idx[f].bitOff;
-                sd.nBits = idx[f].nBits;
                 sd.mixMul = mm[f];
                 sd.format = static_cast<uint8_t>(info.format);
                 sd.hdrLen = static_cast<uint8_t>(info.hdrLen);
-                memcpy(sd.bandType, idx[f].bandType, sizeof(sd.bandType));
+                sd.idx = idx[f];
                 jb.firstSrc = static_cast<uint32_t>(B.srcs.size());
                 jb.nSrc = 1;
                 jb.volShift = vs[f];

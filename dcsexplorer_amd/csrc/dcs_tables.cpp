@@ -135,7 +135,8 @@ const DcsDevTables &dcsTables()
 }
 
 static_assert(sizeof(DcsLdsTables) % 16 == 0, "LDS table block must be a multiple of 16 bytes");
-static_assert(sizeof(DcsSrcDesc) == 56, "DcsSrcDesc layout");
+static_assert(sizeof(DcsSrcDesc) == 64, "DcsSrcDesc layout");
+static_assert(offsetof(DcsSrcDesc, idx) == 12, "DcsSrcDesc layout");
 static_assert(sizeof(DcsFrameJob) == 16, "DcsFrameJob layout");
-static_assert(sizeof(DcsFrameIndex) == 44, "DcsFrameIndex layout");
+static_assert(sizeof(DcsFrameIndex) == 52, "DcsFrameIndex layout");
 static_assert(sizeof(DcsSlot) == 8, "DcsSlot layout");

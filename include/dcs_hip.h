@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DCS_ABI_VERSION 1
+#define DCS_ABI_VERSION 2
 #define DCS_FRAME_SAMPLES 240          /* PCM samples per frame (DCSDecoder.h:123: 7.68 ms at 31250 Hz) */
 #define DCS_MAX_CHANNELS 8             /* DCSDecoderNative.h:305 */
 
@@ -63,7 +63,7 @@ typedef enum DcsFormat
     DCS_FMT_94_T1_S3  = 5              /* OS94/95 Type 1, sub-type 1..3 pre-adjust map                   */
 } DcsFormat;
 
-/* per-frame error bits (dcs_decode_batch errOut / DcsFrameIndex.err) */
+/* per-frame error bits (dcs_decode_batch errOut / DcsFrameIndex.flags >> 4) */
 #define DCS_FRAME_STOP   1u            /* the reference's channel.stop: corrupt band, zeroed (:1989, :2216) */
 #define DCS_FRAME_FATAL  2u            /* malformed beyond what the reference defines (it has UB there):
                                           decode of the frame stops at that point; STOP is raised too    */
@@ -74,13 +74,35 @@ typedef enum DcsFormat
  * index or sync word in a DCS stream, a frame's bit offset is only known after decoding every
  * earlier frame (:1715, :2260), and the 1994+/1993b-Type-1 formats delta-code band types (:1833, :2428).
  */
+/* Decoder state at the start of band 4(k+1), k = 0..2: lets four lanes unpack one frame in parallel,
+ * one quarter (four header bands) each. */
+typedef struct DcsSplit
+{
+    uint16_t bitDelta;                 /* bits from the frame's first bit to the band's first bit         */
+    uint16_t prv;                      /* 1993 formats: prvInput      (:2317)                             */
+    uint16_t prvDelta;                 /* 1993 formats: prvInputDelta (:2318)                             */
+    uint16_t state;                    /* output index (bits 0..8) | band sub-type << 9 (2 bits) |
+                                          "reuse type 0" flag << 11 (:2319, :2388)                         */
+} DcsSplit;
+
+#define DCS_IDX_SERIAL 1u              /* flags: do not split this frame (a band raised an error, or the
+                                          layout has no split points: OS93a Type 1)                        */
+
 typedef struct DcsFrameIndex
 {
     uint32_t bitOff;                   /* first bit of the frame, counted from the first payload byte   */
-    uint32_t nBits;                    /* bits the frame occupies                                       */
-    uint16_t bandType[16];             /* AudioStream::bandTypeBuf on entry to the frame                */
-    uint32_t err;                      /* DCS_FRAME_* raised while scanning this frame                  */
-} DcsFrameIndex;                       /* 44 bytes */
+    uint16_t nBits;                    /* bits the frame occupies                                       */
+    uint16_t hdrBits;                  /* 1994+: bits of the frame header (band-type deltas, :1780-1834);
+                                          band 0 starts at bitOff + hdrBits.  0 for the 1993 formats     */
+    uint8_t  bandType[16];             /* 1994+: band-type codes AFTER this frame's header deltas;
+                                          OS93b Type 1: codes carried INTO the frame (AudioStream::
+                                          bandTypeBuf); values above 255 are stored as 255               */
+    uint16_t preAdj;                   /* 1994+ Type 1: scale pre-adjust of bands 0..2 (4 bits each),
+                                          derived from the PREVIOUS frame's codes (:1771-1773)           */
+    uint8_t  nBands;                   /* populated header bands (stream constant)                       */
+    uint8_t  flags;                    /* DCS_IDX_SERIAL | DCS_FRAME_* error bits << 4                   */
+    DcsSplit split[3];
+} DcsFrameIndex;                       /* 52 bytes */
 
 typedef struct DcsStreamInfo           /* DCSDecoderNative::StreamInfo (DCSDecoderNative.h:106-122)     */
 {
@@ -123,16 +145,13 @@ DcsStatus dcs_stream_params(DcsOsVersion os, int volume, int level, int channelV
 /* ------------------------------------------------------------------------------------------------
  * Batch description
  */
-typedef struct DcsSrcDesc              /* one channel's contribution to one output frame; 56 bytes     */
+typedef struct DcsSrcDesc              /* one channel's contribution to one output frame; 64 bytes     */
 {
     uint64_t streamOff;                /* byte offset in the blob of the stream's U16 frame count       */
-    uint32_t bitOff;                   /* DcsFrameIndex.bitOff                                          */
-    uint32_t nBits;                    /* DcsFrameIndex.nBits (staging hint; 0 = unknown)               */
     uint16_t mixMul;                   /* Channel::mixingMultiplier after MainLoop's rescale (:264-269) */
     uint8_t  format;                   /* DcsFormat                                                     */
     uint8_t  hdrLen;                   /* 16 or 1                                                       */
-    uint32_t reserved;
-    uint16_t bandType[16];             /* DcsFrameIndex.bandType                                        */
+    DcsFrameIndex idx;                 /* the index pass's record of the frame                          */
 } DcsSrcDesc;
 
 #define DCS_PREV_NONE 0xFFFFFFFFu      /* overlap tail is all zero (fresh decoder / after silence)      */

@@ -35,9 +35,8 @@ def build_mix_batch(os_, volume, streams, levels, frames_out):
                 continue
             fi = idxs[c][pos[c]]
             sd = np.zeros(1, dtype=D.SRC_DTYPE)
-            sd["streamOff"] = offs[c]; sd["bitOff"] = fi["bitOff"]; sd["nBits"] = fi["nBits"]
+            sd["streamOff"] = offs[c]; sd["idx"] = fi
             sd["mixMul"] = scaled[c]; sd["format"] = infos[c].format; sd["hdrLen"] = infos[c].hdrLen
-            sd["bandType"] = fi["bandType"]
             srcs.append(sd)
             n += 1
             pos[c] += 1

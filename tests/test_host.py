@@ -16,11 +16,22 @@ def test_index_pass_matches_oracle_probes(oracle, fmt):
         _, probes = oracle.decode(os_, 255, [s], [0x64], 60, probes=True)
         assert info.nFrames == 60 and info.nValidFrames == 60 and info.format == fmt
         assert info.hdrLen == (1 if fmt == D.FMT_93A_T1 else 16)
+        _, probes2 = oracle.decode(os_, 255, [s + bytes(8)], [0x64], 61, probes=True)
         for f in range(60):
             assert idx[f]["bitOff"] == probes[f].bitOff
-            assert list(idx[f]["bandType"]) == list(probes[f].bandType)
+            if fmt >= D.FMT_94_T0:
+                # 1994+: the record holds the codes AFTER the frame's header deltas = what frame f+1 carries in
+                if f < 59:
+                    assert list(idx[f]["bandType"]) == list(probes[f + 1].bandType)
+            elif fmt == D.FMT_93B_T1:
+                assert list(idx[f]["bandType"]) == list(probes[f].bandType)
+            assert 1 <= idx[f]["nBands"] <= (18 if fmt == D.FMT_93A_T1 else 16)
+            for q in range(3):
+                sp = idx[f]["split"][q]
+                assert sp["bitDelta"] <= idx[f]["nBits"]
         assert np.all(np.diff(idx["bitOff"].astype(np.int64)) == idx["nBits"][:-1])
-        assert int(idx["err"].max()) == 0
+        assert int((idx["flags"] >> 4).max()) == 0
+        assert np.all((idx["flags"] & D.IDX_SERIAL) == (1 if fmt == D.FMT_93A_T1 else 0))
         oi = oracle.stream_info(os_, s)
         assert (info.nBytes, info.formatType, info.formatSubType, bytes(info.header)) == \
                (oi["nBytes"], oi["formatType"], oi["formatSubType"], oi["header"])
@@ -42,7 +53,8 @@ def test_index_pass_error_semantics_match_oracle(oracle):
             else:
                 hit += 1
                 assert info.nValidFrames == first_bad + 1
-                assert idx[first_bad]["err"] == stops[first_bad]
+                assert (idx[first_bad]["flags"] >> 4) == stops[first_bad]
+                assert idx[first_bad]["flags"] & D.IDX_SERIAL
     assert hit > 5      # the corruption does trigger the error paths
 
 
@@ -79,7 +91,7 @@ def test_stream_writer_is_deterministic_and_seed_sensitive():
 def test_chunk_plan_properties(fpw):
     b = workloads.build("mixed_16384", n_streams=24, n_frames=37)
     jobs = b["jobs"]
-    plan = D.plan_chunks(jobs, fpw)
+    plan = D.plan_chunks(jobs, fpw, b["srcs"])
     flat = plan.reshape(-1)
     real = flat[(flat["flags"] & 0x81) == 0]
     # every job exactly once as a real slot
@@ -102,7 +114,7 @@ def test_chunk_plan_properties(fpw):
             seen[j] = pos
     # stream-contiguous order needs one halo per chunk at most
     b2 = workloads.build("dcs93_4096", n_streams=5, n_frames=100)
-    plan2 = D.plan_chunks(b2["jobs"], fpw)
+    plan2 = D.plan_chunks(b2["jobs"], fpw, b2["srcs"])
     halos = int(((plan2["flags"] & 1) != 0).sum())
     assert halos <= plan2.shape[0]
 
@@ -111,5 +123,5 @@ def test_workload_builders_shape():
     b = workloads.build("dcs93_4096")
     assert b["jobs"].size == 4096 and b["srcs"].size == 4096
     assert set(np.unique(b["jobs"]["xform"])) == {D.XFORM_93}
-    payload = int(b["srcs"]["nBits"].sum()) // 8
+    payload = int(b["srcs"]["idx"]["nBits"].astype(np.int64).sum()) // 8
     assert 90 * 4096 < payload < 200 * 4096            # ~125 compressed bytes per frame
