@@ -26,8 +26,6 @@ struct DcsLdsTables
 {
     uint16_t cb94[DCS_CB94_TOTAL];      // entry = nBits<<8 | val   (DCSDecoderNative.cpp:2046-2175 semantics)
     uint16_t cbInfo[8];                 // per sample code 1..6: maxBits | (base offset into cb94)<<4
-    uint16_t fast94[256];
-    uint16_t trie94[DCS_TRIE94_MAX];
     uint16_t fast93[256];
     uint16_t trie93[DCS_TRIE93_MAX];
     uint16_t xlat94[48];                // [band class 0..2][code] = typeCode | scalingAdj<<8 (:1926-1953)
@@ -39,9 +37,24 @@ struct DcsLdsTables
     uint16_t pad[4];
 };
 
+// per-lane constants of the transform passes (dcs_kernels.hip.h): twiddles and overlap-window entries that
+// depend only on the lane number, precomputed on the host so that a wavefront fetches them with ten
+// 16-byte loads per lane instead of ~40 scattered table reads
+struct DcsLaneConsts
+{
+    uint32_t pre94[8];                  // 94x pre-twiddle of pair i = l + 8j: c0 | c1 << 16 (.cpp:428-429), l = lane & 7
+    uint32_t twB94[14];                 // 94x layout-B stages: d=4 [0..1], d=2 [2..5], d=1 [6..13]; cos | sin << 16
+    uint32_t twB93[15];                 // 93 layout-B stages: d=8 [0], d=4 [1..2], d=2 [3..6], d=1 [7..14], l = lane & 15
+    uint32_t ovl94a, ovl94b;            // overlap window of pair m = bitrev3(l): co[2m] | co[2m+1]<<16 ; co[15-2m] | co[14-2m]<<16
+    uint32_t ovl93;                     // overlap window of sample i = bitrev4(l): co[i] | co[15-i]<<16
+};
+
 struct DcsDevTables
 {
     DcsLdsTables lds;                   // copied to LDS by each workgroup
+    DcsLaneConsts lane[64];
+    uint16_t fast94[256];               // 1994+ band-type delta code: only the host index pass reads it
+    uint16_t trie94[DCS_TRIE94_MAX];
     uint16_t pair93a[2048];             // OS93a Type-1 sample pair table (:2698-2827); read via L1/L2
     uint16_t fftCoef[256];              // sin block 0..0x7F, cos block 0x80..0xFF, bit-reversed order (:366)
     uint16_t ovlCoef[16];               // overlap window (:314)

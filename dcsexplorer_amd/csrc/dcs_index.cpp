@@ -80,6 +80,7 @@ inline void putSplit(DcsFrameIndex &fi, int band, uint32_t frameStart, const Sca
 void scan94(Scan &s, DcsFrameIndex &fi)
 {
     const DcsLdsTables &T = dcsTables().lds;
+    const uint16_t *trie94 = dcsTables().trie94;
     const uint8_t *hdr = s.header;
     const bool type1 = (hdr[0] & 0x80) != 0;
     const bool sub0 = ((hdr[1] | hdr[2]) & 0x80) == 0;
@@ -96,7 +97,7 @@ void scan94(Scan &s, DcsFrameIndex &fi)
 
     // frame header: one delta code per populated band (:1780-1834)
     for (int i = 0 ; i < s.nBands ; ++i)
-        s.bandType[i] = static_cast<uint16_t>(s.bandType[i] + readVlc(s.b, T.trie94) - 16);
+        s.bandType[i] = static_cast<uint16_t>(s.bandType[i] + readVlc(s.b, trie94) - 16);
     fi.hdrBits = static_cast<uint16_t>(s.b.bitPos() - frameStart);
     for (int i = 0 ; i < 16 ; ++i)
         fi.bandType[i] = static_cast<uint8_t>(s.bandType[i] > 255 ? 255 : s.bandType[i]);

@@ -26,22 +26,18 @@
 
 namespace dcsk {
 
-constexpr int kRowBytes = 516;          // 256 words + one pad dword: rows of different frames hit distinct LDS banks
-constexpr int kScratchBytes = 5376;     // transpose scratch of one transform pass (8 x 168 or 4 x 336 dwords)
+constexpr int kWavesPerBlock = 4;       // wavefronts of a workgroup share one copy of the decode tables in LDS
+constexpr int kRowBytes = 528;          // 256 words + 16 bytes: 16-byte aligned rows (the transforms transpose through them
+                                        // with 128-bit accesses), rows of neighbouring frames land on different LDS banks
 
 __host__ __device__ constexpr int poolDwords(int fpw) { return fpw * DCS_POOL_DW_PER_FRAME; }
-__host__ __device__ constexpr int subLanes(int fpw) { return fpw <= 16 ? 4 : fpw == 32 ? 2 : 1; }
+__host__ __device__ constexpr int subLanes(int fpw) { return fpw <= 16 ? 4 : fpw == 32 ? 2 : 1; }   // 8 and 16 are built
 
-// the bit pool (phase 1) and the transpose scratch (phase 2) are never live together: one region
-__host__ __device__ constexpr int poolOrScratchBytes(int fpw)
-{
-    return poolDwords(fpw) * 4 > kScratchBytes ? poolDwords(fpw) * 4 : kScratchBytes;
-}
-
+// per wavefront: tile rows | tails [fpw][16] i16 | bit pool
+__host__ __device__ constexpr int waveLdsBytes(int fpw) { return fpw * kRowBytes + fpw * 32 + poolDwords(fpw) * 4; }
 __host__ __device__ constexpr int ldsBytes(int fpw)
 {
-    // tables | tile rows | tails [fpw][16] i16 | bit pool / transpose scratch
-    return static_cast<int>(sizeof(DcsLdsTables)) + ((fpw * kRowBytes + 15) & ~15) + fpw * 32 + poolOrScratchBytes(fpw);
+    return static_cast<int>(sizeof(DcsLdsTables)) + kWavesPerBlock * waveLdsBytes(fpw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -160,14 +156,12 @@ __device__ __forceinline__ int readVlc(BitReader &br, const uint16_t *fast, cons
 template <int FPW>
 struct Lds
 {
-    unsigned char *base;
-    __device__ __forceinline__ const DcsLdsTables *tables() const { return reinterpret_cast<const DcsLdsTables *>(base); }
-    __device__ __forceinline__ uint16_t *row(int s) const
-    { return reinterpret_cast<uint16_t *>(base + sizeof(DcsLdsTables) + s * kRowBytes); }
-    static constexpr int kSide = static_cast<int>(sizeof(DcsLdsTables)) + ((FPW * kRowBytes + 15) & ~15);
-    __device__ __forceinline__ uint16_t *tails() const { return reinterpret_cast<uint16_t *>(base + kSide); }               // [FPW][16]
-    __device__ __forceinline__ uint32_t *scratch() const { return reinterpret_cast<uint32_t *>(base + kSide + FPW * 32); }  // phase 2
-    __device__ __forceinline__ uint32_t *pool() const { return scratch(); }                                                    // phase 1
+    unsigned char *tab;         // workgroup-shared tables
+    unsigned char *base;        // this wavefront's region
+    __device__ __forceinline__ const DcsLdsTables *tables() const { return reinterpret_cast<const DcsLdsTables *>(tab); }
+    __device__ __forceinline__ uint16_t *row(int s) const { return reinterpret_cast<uint16_t *>(base + s * kRowBytes); }
+    __device__ __forceinline__ uint16_t *tails() const { return reinterpret_cast<uint16_t *>(base + FPW * kRowBytes); }      // [FPW][16]
+    __device__ __forceinline__ uint32_t *pool() const { return reinterpret_cast<uint32_t *>(base + FPW * (kRowBytes + 32)); }
 };
 
 // what one sub-lane knows about the frame quarter it unpacks
@@ -713,81 +707,58 @@ __device__ __forceinline__ int overlapMix(int x, uint32_t cx, int o, uint32_t co
     return static_cast<int>(a + b + 0x8000u) >> 16;
 }
 
-constexpr int kRowStride = 20;          // dwords per 16-point row in the transpose scratch (16 + 4 pad: conflict-free b128)
-constexpr int kGroupStrideA = 160;      // 94x first transpose: 8 rows
-constexpr int kGroupStrideB94 = 168;    // 94x second transpose
-constexpr int kGroupStrideB93 = 336;    // 93 transpose: 16 rows + 16
-constexpr int kXformScratchBytes = 5376;
-
-struct LaneConsts
-{
-    uint32_t pre94[8];      // 94x pre-twiddle of pair i = l + 8j: c0 | c1 << 16 (.cpp:428-429)
-    uint32_t twB94[14];     // 94x layout-B stages: d=4 [0..1], d=2 [2..5], d=1 [6..13]; cos | sin << 16
-    uint32_t twB93[15];     // 93 layout-B stages: d=8 [0], d=4 [1..2], d=2 [3..6], d=1 [7..14]
-    uint32_t ovl94a, ovl94b;    // overlap window of pair m = bitrev3(l): co[2m] | co[2m+1]<<16 ; co[15-2m] | co[14-2m]<<16
-    uint32_t ovl93;             // overlap window of sample i = bitrev4(l): co[i] | co[15-i]<<16
-};
+typedef DcsLaneConsts LaneConsts;
 
 __device__ __forceinline__ uint32_t twAt(const uint16_t *coef, int part)
 {
     return static_cast<uint32_t>(coef[0x80 + part]) | (static_cast<uint32_t>(coef[part]) << 16);
 }
 
-__device__ void loadLaneConsts(const DcsDevTables *G, int lane, LaneConsts &C)
+// ten 16-byte loads per lane from the host-built table
+__device__ __forceinline__ void loadLaneConsts(const DcsDevTables *G, int lane, LaneConsts &C)
 {
-    const uint16_t *coef = G->fftCoef;
-    const int l8 = lane & 7, l16 = lane & 15;
+    const uint4 *src = reinterpret_cast<const uint4 *>(&G->lane[lane]);
+    uint4 *dst = reinterpret_cast<uint4 *>(&C);
 #pragma unroll
-    for (int j = 0 ; j < 8 ; ++j)
-    {
-        const int i = l8 + 8 * j;
-        C.pre94[j] = static_cast<uint32_t>(coef[bitrev9(2 + 4 * i)]) | (static_cast<uint32_t>(coef[bitrev9(4 * i)]) << 16);
-    }
-#pragma unroll
-    for (int k = 0 ; k < 2 ; ++k) C.twB94[k] = twAt(coef, 2 * l8 + k);
-#pragma unroll
-    for (int k = 0 ; k < 4 ; ++k) C.twB94[2 + k] = twAt(coef, 4 * l8 + k);
-#pragma unroll
-    for (int k = 0 ; k < 8 ; ++k) C.twB94[6 + k] = twAt(coef, 8 * l8 + k);
-    C.twB93[0] = twAt(coef, l16);
-#pragma unroll
-    for (int k = 0 ; k < 2 ; ++k) C.twB93[1 + k] = twAt(coef, 2 * l16 + k);
-#pragma unroll
-    for (int k = 0 ; k < 4 ; ++k) C.twB93[3 + k] = twAt(coef, 4 * l16 + k);
-#pragma unroll
-    for (int k = 0 ; k < 8 ; ++k) C.twB93[7 + k] = twAt(coef, 8 * l16 + k);
-    const int m = bitrevN(l8, 3);
-    C.ovl94a = static_cast<uint32_t>(G->ovlCoef[2 * m]) | (static_cast<uint32_t>(G->ovlCoef[2 * m + 1]) << 16);
-    C.ovl94b = static_cast<uint32_t>(G->ovlCoef[15 - 2 * m]) | (static_cast<uint32_t>(G->ovlCoef[14 - 2 * m]) << 16);
-    const int i = bitrevN(l16, 4);
-    C.ovl93 = static_cast<uint32_t>(G->ovlCoef[i]) | (static_cast<uint32_t>(G->ovlCoef[15 - i]) << 16);
+    for (int i = 0 ; i < static_cast<int>(sizeof(LaneConsts) / 16) ; ++i)
+        dst[i] = src[i];
 }
 
-// wavefront-level ordering of LDS traffic between lanes.  The workgroup is one wavefront, so hipcc
-// lowers this to a compiler fence + s_waitcnt without an s_barrier.
-__device__ __forceinline__ void waveSync() { __syncthreads(); }
+// Ordering of LDS traffic between the lanes of ONE wavefront.  A wavefront's LDS instructions execute
+// in program order, so no hardware wait is needed; this only stops the compiler from moving LDS
+// accesses across the point.  (A workgroup barrier must not be used here: the four wavefronts of a
+// workgroup work on independent chunks with different trip counts.)
+__device__ __forceinline__ void waveSync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // per-lane description of the frame a lane works on in a transform pass
 struct PassLane
 {
-    const uint32_t *rowC;   // the frame's spectrum row in the tile
-    uint32_t *S;            // this lane group's transpose scratch
+    uint32_t *rowC;         // the frame's spectrum row in the tile; reused as transpose scratch once it is in registers
     int l;                  // lane inside the group
     uint32_t shiftPair;     // volShift | volShift << 16
-    bool active;
 };
 
 __device__ __forceinline__ uint4 ldsRead4(const uint32_t *p) { return *reinterpret_cast<const uint4 *>(p); }
 __device__ __forceinline__ void ldsWrite4(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 { *reinterpret_cast<uint4 *>(p) = make_uint4(a, b, c, d); }
 
+// The transposes go through the frame's own tile row viewed as 8 rows x 16 dwords.  The four quads of a
+// row are XOR-swizzled with the row number so that 128-bit accesses of the 8 lanes of a frame spread
+// over all banks: dword index of (row, pos) = row*16 + (((pos >> 2) ^ (row >> 1)) & 3)*4 + (pos & 3).
+__device__ __forceinline__ int swzQuad(int row, int quad) { return row * 16 + ((quad ^ (row >> 1)) & 3) * 4; }
+__device__ __forceinline__ int swzPos(int row, int pos) { return swzQuad(row, pos >> 2) + (pos & 3); }
+
 // 1994+ transform of 8 frames, 8 lanes each (DecoderImpl94x::TransformFrame, .cpp:397-534).
 // On return x[r'] holds point 16*l + r' = output sample pair m = 8*bitrev4(r') + bitrev3(l), shifted.
-__device__ __forceinline__ void transform94x8(const PassLane &P, uint32_t *Sbase, int g, const uint16_t *coef,
-                                              const LaneConsts &C, uint32_t (&x)[16])
+__device__ __forceinline__ void transform94x8(const PassLane &P, const uint16_t *coef, const LaneConsts &C, uint32_t (&x)[16])
 {
     const int l = P.l;
-    uint32_t *SA = Sbase + g * kGroupStrideA;
+    uint32_t *S = P.rowC;
     // ---- pre-passes 1 + 2 on the pairs (i, 128 - i), i = l + 8j (:403-456) ------------------------
     uint32_t An[8], Bn[8];
 #pragma unroll
@@ -815,43 +786,40 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, uint32_t *Sbase
         const uint32_t t2 = pkSubSat(Pr, a);                            // (prod1 - a0, prod0 - a1)
         Bn[j] = __builtin_amdgcn_perm(t2, t, 0x07060100u);              // (a0 - prod1, prod0 - a1)
     }
-    // point 64: real part negated, imaginary part unchanged (:403-404); it is B of the pair i = 0... of lane 0, j = 0 has no
+    // point 64: real part negated, imaginary part unchanged (:403-404); the pair i = 0 of lane 0 has no
     // partner, so lane 0 places it where B[0] would go
     if (l == 0)
     {
         const uint32_t M = P.rowC[64];
         Bn[0] = __builtin_amdgcn_perm(M, pkSub(0u, M), 0x07060100u);
     }
+    waveSync();         // every lane has read its part of the row: the row becomes scratch
     // transpose into layout A: point p sits at row (p & 7), position (p >> 3).  A points of lane l fill
     // positions 0..7 of row l; its B points (128 - i) fill positions 15 - j of row (8 - l) & 7, except
     // lane 0 whose B points 128 - 8j sit at position 16 - j of row 0 (j = 0 holds point 64 -> position 8)
     {
-        uint32_t *rowA = SA + l * kRowStride;
-        ldsWrite4(rowA, An[0], An[1], An[2], An[3]);
-        ldsWrite4(rowA + 4, An[4], An[5], An[6], An[7]);
-        uint32_t *rowB = SA + ((8 - l) & 7) * kRowStride;
+        ldsWrite4(S + swzQuad(l, 0), An[0], An[1], An[2], An[3]);
+        ldsWrite4(S + swzQuad(l, 1), An[4], An[5], An[6], An[7]);
+        const int rb = (8 - l) & 7;
         if (l != 0)
         {
-            ldsWrite4(rowB + 8, Bn[7], Bn[6], Bn[5], Bn[4]);
-            ldsWrite4(rowB + 12, Bn[3], Bn[2], Bn[1], Bn[0]);
+            ldsWrite4(S + swzQuad(rb, 2), Bn[7], Bn[6], Bn[5], Bn[4]);
+            ldsWrite4(S + swzQuad(rb, 3), Bn[3], Bn[2], Bn[1], Bn[0]);
         }
         else
         {
-            ldsWrite4(rowB + 8, Bn[0], Bn[7], Bn[6], Bn[5]);
-            ldsWrite4(rowB + 12, Bn[4], Bn[3], Bn[2], Bn[1]);
+            ldsWrite4(S + swzQuad(rb, 2), Bn[0], Bn[7], Bn[6], Bn[5]);
+            ldsWrite4(S + swzQuad(rb, 3), Bn[4], Bn[3], Bn[2], Bn[1]);
         }
     }
     waveSync();
-    {
-        const uint32_t *rowA = SA + l * kRowStride;
 #pragma unroll
-        for (int q = 0 ; q < 4 ; ++q)
-        {
-            const uint4 v = ldsRead4(rowA + 4 * q);
-            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-        }
+    for (int c = 0 ; c < 4 ; ++c)
+    {
+        const uint4 v = ldsRead4(S + swzQuad(l, c));
+        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
     }
-    waveSync();         // scratch is reused by the second transpose
+    waveSync();         // the row is reused by the second transpose
     // ---- layout A: point p = 8r + l.  pre-pass 3 (:458-471) then stages d = 32, 16, 8 (:480-524) -------
 #pragma unroll
     for (int r = 0 ; r < 8 ; ++r)
@@ -868,20 +836,16 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, uint32_t *Sbase
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
         if (!(r & 1)) bfly<true>(x[r], x[r + 1], twAt(coef, r >> 1));
-    // ---- transpose to layout B: point p = 16 l' + r' ------------------------------------------------------
+    // ---- transpose to layout B: point p = 16 l' + r' lives in row (p >> 4), position (p & 15) ---------------
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        S[swzPos(r >> 1, 8 * (r & 1) + l)] = x[r];
+    waveSync();
+#pragma unroll
+    for (int c = 0 ; c < 4 ; ++c)
     {
-        uint32_t *SB = Sbase + g * kGroupStrideB94;
-#pragma unroll
-        for (int r = 0 ; r < 16 ; ++r)
-            SB[(r >> 1) * kRowStride + 8 * (r & 1) + l] = x[r];
-        waveSync();
-        const uint32_t *rowB = SB + l * kRowStride;
-#pragma unroll
-        for (int q = 0 ; q < 4 ; ++q)
-        {
-            const uint4 v = ldsRead4(rowB + 4 * q);
-            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-        }
+        const uint4 v = ldsRead4(S + swzQuad(l, c));
+        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
     }
     // ---- stages d = 4, 2, 1 ------------------------------------------------------------------------------
 #pragma unroll
@@ -902,10 +866,10 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, uint32_t *Sbase
 // 1993 transform of 4 frames, 16 lanes each (DecoderImpl93::TransformFrame, .cpp:714-785; the DC
 // magnitude step ran in phase 1).  On return x[r'] holds point 16*l + r'; its real part is output
 // sample i = 16*bitrev4(r') + bitrev4(l), shifted.
-__device__ __forceinline__ void transform93x4(const PassLane &P, uint32_t *Sbase, int g, const uint16_t *coef,
-                                              const LaneConsts &C, uint32_t (&x)[16])
+__device__ __forceinline__ void transform93x4(const PassLane &P, const uint16_t *coef, const LaneConsts &C, uint32_t (&x)[16])
 {
     const int l = P.l;
+    uint32_t *S = P.rowC;
     // ---- expand 128 -> 256 points (:714-732): S[p] = (A.re + B.re, A.im - B.im), S[128 + p] = (A.re - B.re, A.im + B.im)
     // with A = row[p], B = row[128 - p]; layout A: point p = 16 r + l, so S[p] -> x[r], S[128 + p] -> x[r + 8]
 #pragma unroll
@@ -932,21 +896,31 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, uint32_t *Sbase
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
         if (!(r & 1)) bfly<false>(x[r], x[r + 1], twAt(coef, r >> 1));
-    // ---- transpose: point 16 r + l  ->  lane r, register l -------------------------------------------------
+    // ---- transpose: point 16 r + l  ->  lane r, register l.  The row holds 8 x 16 dwords, so two rounds:
+    // registers 0..7 feed lanes 0..7, registers 8..15 feed lanes 8..15 ---------------------------------------------
+    waveSync();         // every lane has read its part of the row: the row becomes scratch
+    uint32_t y[16];
+#pragma unroll
+    for (int h = 0 ; h < 2 ; ++h)
     {
-        uint32_t *SB = Sbase + g * kGroupStrideB93;
 #pragma unroll
-        for (int r = 0 ; r < 16 ; ++r)
-            SB[r * kRowStride + l] = x[r];
+        for (int r = 0 ; r < 8 ; ++r)
+            S[swzPos(r, l)] = x[8 * h + r];
         waveSync();
-        const uint32_t *rowB = SB + l * kRowStride;
-#pragma unroll
-        for (int q = 0 ; q < 4 ; ++q)
+        if ((l >> 3) == h)
         {
-            const uint4 v = ldsRead4(rowB + 4 * q);
-            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+#pragma unroll
+            for (int c = 0 ; c < 4 ; ++c)
+            {
+                const uint4 v = ldsRead4(S + swzQuad(l & 7, c));
+                y[4 * c] = v.x; y[4 * c + 1] = v.y; y[4 * c + 2] = v.z; y[4 * c + 3] = v.w;
+            }
         }
+        waveSync();
     }
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        x[r] = y[r];
     // ---- stages d = 8, 4, 2, 1 -----------------------------------------------------------------------------
 #pragma unroll
     for (int r = 0 ; r < 8 ; ++r)
@@ -970,29 +944,32 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, uint32_t *Sbase
 // the kernel
 // ------------------------------------------------------------------------------------------------
 template <int FPW>
-__global__ void __launch_bounds__(64) dcsDecodeKernel(const DcsKernelArgs a)
+__global__ void __launch_bounds__(64 * kWavesPerBlock) dcsDecodeKernel(const DcsKernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Lds<FPW> L{ smem };
-    const int lane = static_cast<int>(threadIdx.x);
-    const uint32_t chunk = blockIdx.x;
+    const int wave = static_cast<int>(threadIdx.x) >> 6;
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    const Lds<FPW> L{ smem, smem + sizeof(DcsLdsTables) + wave * waveLdsBytes(FPW) };
+    const uint32_t chunk = blockIdx.x * kWavesPerBlock + static_cast<uint32_t>(wave);
     constexpr int SUB = subLanes(FPW);              // lanes that unpack one frame together
     constexpr int BPL = 16 / SUB;                   // header bands per sub-lane
     const int s = lane % FPW;                       // slot of this lane
     const int q = lane / FPW;                       // which part of the frame it unpacks
     const bool unpacker = q < SUB;
 
-    // ---- stage tables, clear the tile --------------------------------------------------------
+    // ---- stage the shared tables (whole workgroup), clear this wavefront's tile ------------------------
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(&a.tables->lds);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (int i = lane ; i < static_cast<int>(sizeof(DcsLdsTables) / 16) ; i += 64)
+        for (int i = static_cast<int>(threadIdx.x) ; i < static_cast<int>(sizeof(DcsLdsTables) / 16) ; i += 64 * kWavesPerBlock)
             dst[i] = src[i];
-        uint4 *tile = reinterpret_cast<uint4 *>(smem + sizeof(DcsLdsTables));
-        constexpr int kTile16 = ((FPW * kRowBytes + 15) & ~15) / 16;
-        for (int i = lane ; i < kTile16 ; i += 64)
+        uint4 *tile = reinterpret_cast<uint4 *>(L.base);
+        for (int i = lane ; i < FPW * kRowBytes / 16 ; i += 64)
             tile[i] = make_uint4(0, 0, 0, 0);
     }
+    __syncthreads();                                // the only workgroup barrier: tables are in place
+    if (chunk >= a.nChunks)
+        return;                                     // padding wavefront of the last workgroup
 
     LaneConsts C;
     loadLaneConsts(a.tables, lane, C);
@@ -1003,7 +980,6 @@ __global__ void __launch_bounds__(64) dcsDecodeKernel(const DcsKernelArgs a)
     DcsFrameJob job{ 0, 0, 0, DCS_XFORM_94, 0, DCS_PREV_NONE, 0 };
     if (live)
         job = a.jobs[slot.job];
-    waveSync();
 
     // ---- phase 1: unpack, one round per source index -------------------------------------------------
     uint32_t err = 0;
@@ -1163,7 +1139,6 @@ __global__ void __launch_bounds__(64) dcsDecodeKernel(const DcsKernelArgs a)
     waveSync();
 
     // ---- phase 2: transform passes (8 frames x 8 lanes, or 4 frames x 16 lanes), overlap, emit ------------
-    uint32_t *S = L.scratch();
     uint32_t *tails = reinterpret_cast<uint32_t *>(L.tails());         // [slot][8] dwords = 16 samples
     const uint16_t *coef = a.tables->fftCoef;
     const int nSlots = __popcll(__ballot(live && lane < FPW));          // padding slots are trailing
@@ -1188,18 +1163,18 @@ __global__ void __launch_bounds__(64) dcsDecodeKernel(const DcsKernelArgs a)
         const int myShift = __shfl(jobShift, mySlot);
         const uint32_t myPrevJob = static_cast<uint32_t>(__shfl(jobPrev, mySlot));
 
+        // lane groups beyond the pass's frames run the same instruction stream on a dummy row (the bit
+        // pool is dead in phase 2) and store nothing
         PassLane P;
-        P.rowC = reinterpret_cast<const uint32_t *>(L.row(mySlot));
-        P.S = S;
+        P.rowC = active ? reinterpret_cast<uint32_t *>(L.row(mySlot)) : L.pool();
         P.l = lane & ((1 << lpfShift) - 1);
         P.shiftPair = static_cast<uint32_t>(myShift) * 0x00010001u;
-        P.active = active;
 
         uint32_t x[16];
         if (xf == DCS_XFORM_94)
-            transform94x8(P, S, g, coef, C, x);
+            transform94x8(P, coef, C, x);
         else
-            transform93x4(P, S, g, coef, C, x);
+            transform93x4(P, coef, C, x);
 
         // tail for the successor = output samples 240..255 (:569-575, :805-812): register 15 of every lane
         if (active)

@@ -3,6 +3,7 @@
 // dcs_ctx_create fails and nothing below can run.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -108,8 +109,8 @@ extern "C" DcsStatus dcs_ctx_create(int deviceId, DcsCtx **out)
         HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dTables), sizeof(DcsDevTables)));
         HIPCHK(ctx, hipMemcpy(ctx->dTables, &dcsTables(), sizeof(DcsDevTables), hipMemcpyHostToDevice));
         // opt in to the LDS the largest configuration needs
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dcsk::dcsDecodeKernel<64>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, dcsk::ldsBytes(64)));
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dcsk::dcsDecodeKernel<16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, dcsk::ldsBytes(16)));
         return DCS_OK;
     }();
     if (st != DCS_OK)
@@ -134,14 +135,14 @@ extern "C" void dcs_ctx_destroy(DcsCtx *ctx)
 
 extern "C" DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw)
 {
-    if (ctx == nullptr || !(fpw == 0 || fpw == 8 || fpw == 16 || fpw == 32 || fpw == 64))
+    if (ctx == nullptr || !(fpw == 0 || fpw == 8 || fpw == 16))
         return DCS_ERR_INVALID_ARG;
     ctx->fpwOverride = fpw;
     return DCS_OK;
 }
 
 // frames per wavefront.  Four lanes unpack one frame, so 16 frames fill the 64 lanes; small batches
-// use 8 frames per wavefront so that more CUs get work (32 / 64 exist for comparison runs).
+// use 8 frames per wavefront so that more CUs get work.
 static int chooseFpw(const DcsCtx *ctx, uint32_t nJobs)
 {
     if (ctx->fpwOverride != 0)
@@ -262,7 +263,10 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
 template <int FPW>
 static hipError_t launch(const DcsKernelArgs &args, hipStream_t stream)
 {
-    dcsk::dcsDecodeKernel<FPW><<<dim3(args.nChunks), dim3(64), dcsk::ldsBytes(FPW), stream>>>(args);
+    // DCS_EXTRA_LDS (bytes): experiment knob, lowers occupancy by requesting unused LDS
+    static const int extraLds = getenv("DCS_EXTRA_LDS") ? atoi(getenv("DCS_EXTRA_LDS")) : 0;
+    const uint32_t blocks = (args.nChunks + dcsk::kWavesPerBlock - 1) / dcsk::kWavesPerBlock;
+    dcsk::dcsDecodeKernel<FPW><<<dim3(blocks), dim3(64 * dcsk::kWavesPerBlock), dcsk::ldsBytes(FPW) + extraLds, stream>>>(args);
     return hipGetLastError();
 }
 
@@ -286,13 +290,7 @@ extern "C" DcsStatus dcs_batch_run(DcsBatch *b, void *hipStream)
     args.tailsOut = b->dTailsOut;
     args.tables = ctx->dTables;
     hipError_t e;
-    switch (b->fpw)
-    {
-    case 64: e = launch<64>(args, stream); break;
-    case 32: e = launch<32>(args, stream); break;
-    case 16: e = launch<16>(args, stream); break;
-    default: e = launch<8>(args, stream); break;
-    }
+    e = (b->fpw == 16) ? launch<16>(args, stream) : launch<8>(args, stream);
     if (e != hipSuccess)
     {
         ctx->lastError = std::string("kernel launch failed: ") + hipGetErrorString(e);

@@ -104,7 +104,7 @@ DcsDevTables build()
     put(1, kVlc94Sample1); put(2, kVlc94Sample2); put(3, kVlc94Sample3);
     put(4, kVlc94Sample4); put(5, kVlc94Sample5); put(6, kVlc94Sample6);
 
-    buildVlc(kVlc94BandTypeDelta, t.lds.fast94, t.lds.trie94, DCS_TRIE94_MAX, [](int v) { return v + 16; });
+    buildVlc(kVlc94BandTypeDelta, t.fast94, t.trie94, DCS_TRIE94_MAX, [](int v) { return v + 16; });
     buildVlc(kVlc93BandType, t.lds.fast93, t.lds.trie93, DCS_TRIE93_MAX, [](int v) { return v; });
 
     for (int i = 0 ; i < 16 ; ++i)
@@ -123,6 +123,32 @@ DcsDevTables build()
     memcpy(t.pair93a, kPair93a, sizeof(t.pair93a));
     memcpy(t.fftCoef, kFftCoef, sizeof(t.fftCoef));
     memcpy(t.ovlCoef, kOverlapCoef, sizeof(t.ovlCoef));
+
+    // per-lane transform constants (see DcsLaneConsts)
+    auto rev = [](int v, int bits) { int r = 0; for (int i = 0 ; i < bits ; ++i) r |= ((v >> i) & 1) << (bits - 1 - i); return r; };
+    auto tw = [&](int part) { return static_cast<uint32_t>(kFftCoef[0x80 + part]) | (static_cast<uint32_t>(kFftCoef[part]) << 16); };
+    for (int lane = 0 ; lane < 64 ; ++lane)
+    {
+        DcsLaneConsts &c = t.lane[lane];
+        const int l8 = lane & 7, l16 = lane & 15;
+        for (int j = 0 ; j < 8 ; ++j)
+        {
+            const int i = l8 + 8 * j;
+            c.pre94[j] = static_cast<uint32_t>(kFftCoef[rev(2 + 4 * i, 9)]) | (static_cast<uint32_t>(kFftCoef[rev(4 * i, 9)]) << 16);
+        }
+        for (int k = 0 ; k < 2 ; ++k) c.twB94[k] = tw(2 * l8 + k);
+        for (int k = 0 ; k < 4 ; ++k) c.twB94[2 + k] = tw(4 * l8 + k);
+        for (int k = 0 ; k < 8 ; ++k) c.twB94[6 + k] = tw(8 * l8 + k);
+        c.twB93[0] = tw(l16);
+        for (int k = 0 ; k < 2 ; ++k) c.twB93[1 + k] = tw(2 * l16 + k);
+        for (int k = 0 ; k < 4 ; ++k) c.twB93[3 + k] = tw(4 * l16 + k);
+        for (int k = 0 ; k < 8 ; ++k) c.twB93[7 + k] = tw(8 * l16 + k);
+        const int m = rev(l8, 3);
+        c.ovl94a = static_cast<uint32_t>(kOverlapCoef[2 * m]) | (static_cast<uint32_t>(kOverlapCoef[2 * m + 1]) << 16);
+        c.ovl94b = static_cast<uint32_t>(kOverlapCoef[15 - 2 * m]) | (static_cast<uint32_t>(kOverlapCoef[14 - 2 * m]) << 16);
+        const int i = rev(l16, 4);
+        c.ovl93 = static_cast<uint32_t>(kOverlapCoef[i]) | (static_cast<uint32_t>(kOverlapCoef[15 - i]) << 16);
+    }
     return t;
 }
 
@@ -135,6 +161,7 @@ const DcsDevTables &dcsTables()
 }
 
 static_assert(sizeof(DcsLdsTables) % 16 == 0, "LDS table block must be a multiple of 16 bytes");
+static_assert(sizeof(DcsLaneConsts) == 160 && offsetof(DcsDevTables, lane) % 16 == 0, "lane constants are fetched as uint4");
 static_assert(sizeof(DcsSrcDesc) == 64, "DcsSrcDesc layout");
 static_assert(offsetof(DcsSrcDesc, idx) == 12, "DcsSrcDesc layout");
 static_assert(sizeof(DcsFrameJob) == 16, "DcsFrameJob layout");
