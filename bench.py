@@ -22,31 +22,27 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def cpu_baseline(streams, budget_s=12.0):
-    """the CPU checker timed on this box's host cores on a bounded sample of the same workload:
-    the compiled reference (oracle/_ref) when it travelled with the repo, else the oracle port"""
-    import numpy as np
-    from concurrent.futures import ThreadPoolExecutor
+    """the CPU checker timed on this box's host cores on a bounded sample of the same workload: the
+    compiled reference (oracle/_ref) when it travelled with the repo, else the oracle port.  The
+    threads live inside the C library (no Python in the timed loop); each thread plays its share of the
+    streams through one decoder object, LoadAudioStream + 240 x GetNextSample per frame, the way the
+    reference's own batch decode (--extract-streams) drives the path."""
     from oracle.dcs_oracle import Oracle, Reference, reference_available
     kind = "reference" if reference_available() else "port"
     chk = Reference() if kind == "reference" else Oracle()
-    cores = max(1, min(os.cpu_count() or 1, 32))
-
-    def work(args):
-        os_, s, vol, lvl = args
-        nf = (s[0] << 8) | s[1]
-        chk.decode(os_, vol, [s], [lvl], nf)      # ctypes releases the GIL; both libraries are re-entrant
-        return nf
-
-    sample = streams[:max(cores, min(len(streams), 64))]
-    frames = 0
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    frames_per_pass = sum((s[1][0] << 8) | s[1][1] for s in streams)
+    # calibrate one pass, then size the repeat count for the budget
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        while time.perf_counter() - t0 < budget_s:
-            frames += sum(ex.map(work, sample))
+    chk.decode_many(streams, 1, cores)
+    one = max(time.perf_counter() - t0, 1e-4)
+    repeat = max(1, int(budget_s / one))
+    t0 = time.perf_counter()
+    frames = chk.decode_many(streams, repeat, cores)
     dt = time.perf_counter() - t0
     return dict(value=frames * 240 / dt, unit="samples/s", cores=cores, kind=kind,
-                sample="%d streams of the workload decoded repeatedly for %.1f s (%d frames), %d threads, "
-                       "one decoder object per stream" % (len(sample), dt, frames, cores))
+                sample="the %d streams (%d frames) of the workload decoded %d times in %.1f s on %d threads, "
+                       "one decoder object per thread" % (len(streams), frames_per_pass, repeat, dt, cores))
 
 
 def main():
@@ -140,6 +136,15 @@ def main():
     if rank == 0:
         samples = n_frames * 240 * world * args.steps
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        # HBM traffic per launch: FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes of this same command
+        # (tools/prof.sh), committed under profiles/; null when no profile of this workload exists
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tpath):
+            t = json.load(open(tpath))
+            traffic = t["traffic_bytes_fetch_raw"]
+            traffic_note = ("FETCH_SIZE+WRITE_SIZE from %s; FETCH_SIZE raw (x2 per the gfx950 wide-read correction "
+                            "would give %d)" % (os.path.relpath(tpath, ROOT), t["traffic_bytes_fetch_x2"]))
         out = {
             "metric": "bit_exact_int16_pcm_samples_per_sec",
             "value": samples / dt,
@@ -158,7 +163,7 @@ def main():
                        "partition": "range over streams, no collective"},
             "bit_exact": bit_exact,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "dcsDecodeKernel", "kernel_avg_ms": kern_ms,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }

@@ -15,6 +15,7 @@
 #include "dcs_oracle_tables.h"
 #include <string.h>
 #include <stdlib.h>
+#include <pthread.h>
 
 /* ------------------------------------------------------------------------
  * L0: ADSP-2105 arithmetic (DCSDecoderNative.h:822-906, .cpp:3447-3580)
@@ -1005,6 +1006,59 @@ int orc_decompress(int os, const uint8_t *stream, size_t len, uint16_t mixMul,
         stopFlags[f] = s.stop | (s.fatal << 1);
     }
     return 0;
+}
+
+/* CPU-baseline helper, same contract as ref_decode_many in ref_driver.cpp */
+typedef struct
+{
+    const int *os, *volume, *level;
+    const uint8_t *const *streams;
+    const size_t *lens;
+    int n, repeat, nThreads, tid;
+    long long frames;
+} ManyArg;
+
+static void *many_worker(void *p)
+{
+    ManyArg *a = (ManyArg *)p;
+    int16_t *pcm = NULL;
+    size_t cap = 0;
+    for (int rep = 0 ; rep < a->repeat ; ++rep)
+        for (int i = a->tid ; i < a->n ; i += a->nThreads)
+        {
+            const int nf = (a->streams[i][0] << 8) | a->streams[i][1];
+            if ((size_t)nf * 240 > cap)
+            {
+                cap = (size_t)nf * 240;
+                pcm = (int16_t *)realloc(pcm, cap * sizeof(int16_t));
+            }
+            const uint8_t *sp = a->streams[i];
+            orc_decode(a->os[i], a->volume[i], 1, &sp, &a->lens[i], &a->level[i], nf, pcm, NULL);
+            a->frames += nf;
+        }
+    free(pcm);
+    return NULL;
+}
+
+long long orc_decode_many(const int *os, const int *volume, const int *level,
+    const uint8_t *const *streams, const size_t *lens, int n, int repeat, int nThreads)
+{
+    if (nThreads < 1) nThreads = 1;
+    if (nThreads > 256) nThreads = 256;
+    pthread_t th[256];
+    ManyArg args[256];
+    for (int t = 0 ; t < nThreads ; ++t)
+    {
+        args[t] = (ManyArg){ os, volume, level, streams, lens, n, repeat, nThreads, t, 0 };
+        pthread_create(&th[t], NULL, many_worker, &args[t]);
+    }
+    long long total = 0;
+    for (int t = 0 ; t < nThreads ; ++t)
+    {
+        pthread_join(th[t], NULL);
+        total += args[t].frames;
+    }
+    return total;
 }
 
 uint64_t orc_fnv1a64(const void *data, size_t n)

@@ -75,6 +75,11 @@ uint16_t orc_mixing_multiplier(int os, int levelSum, int channelVolume);
 int orc_frame_params(int os, int volume, int level, int nFrames,
     uint16_t *mixMulScaled, uint8_t *volShift);
 
+/* CPU-baseline helper: n single-channel streams, each from a fresh decoder, `repeat` times on nThreads
+ * threads (range partition).  Returns frames decoded.  Same contract as ref_decode_many. */
+long long orc_decode_many(const int *os, const int *volume, const int *level,
+    const uint8_t *const *streams, const size_t *lens, int n, int repeat, int nThreads);
+
 /* FNV-1a 64 over bytes (offset 0xcbf29ce484222325, prime 0x100000001b3) */
 uint64_t orc_fnv1a64(const void *data, size_t n);
 

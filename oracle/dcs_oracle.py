@@ -98,6 +98,21 @@ class _Checker:
                                stops.ctypes.data_as(ctypes.c_void_p))
         return out, bit_offs, band_types, stops
 
+    def decode_many(self, streams, repeat, nthreads):
+        """streams: list of (os, bytes, volume, level); decodes each from a fresh decoder `repeat` times on
+        `nthreads` host threads inside the C library; returns frames decoded"""
+        n = len(streams)
+        keep = [_u8buf(s[1]) for s in streams]
+        ptrs = (ctypes.POINTER(ctypes.c_uint8) * n)(
+            *[ctypes.cast(a, ctypes.POINTER(ctypes.c_uint8)) for a, _ in keep])
+        lens = (ctypes.c_size_t * n)(*[l for _, l in keep])
+        os_ = (ctypes.c_int * n)(*[s[0] for s in streams])
+        vol = (ctypes.c_int * n)(*[s[2] for s in streams])
+        lvl = (ctypes.c_int * n)(*[s[3] for s in streams])
+        f = self._fn("decode_many")
+        f.restype = ctypes.c_longlong
+        return int(f(os_, vol, lvl, ptrs, lens, ctypes.c_int(n), ctypes.c_int(repeat), ctypes.c_int(nthreads)))
+
     def volume_multiplier(self, vol):
         return self._fn("volume_multiplier")(vol)
 

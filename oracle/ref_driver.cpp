@@ -31,6 +31,7 @@
 #include <regex>
 #include <set>
 #include <algorithm>
+#include <thread>
 
 #define protected public
 #define private public
@@ -208,6 +209,57 @@ uint16_t ref_mixing_multiplier(int os, int levelSum, int channelVolume)
     dec.channel[0].mixer[0].curLevel = levelSum;
     dec.UpdateMixingLevels();
     return dec.channel[0].mixingMultiplier;
+}
+
+// CPU-baseline helper: decode n single-channel streams `repeat` times on `nThreads` host threads
+// (streams range-partitioned over the threads).  Each thread owns ONE decoder object per OS version and
+// plays its streams through it one after the other -- LoadAudioStream(0, ptr, level), then
+// nFrames x 240 GetNextSample() -- which is how the reference's own batch decode drives the path
+// (DCSExplorer --extract-streams, DCSExplorer.cpp:1628-1907).  Timing only: the PCM is discarded.
+// Returns the number of frames decoded.
+long long ref_decode_many(const int *os, const int *volume, const int *level,
+    const uint8_t *const *streams, const size_t *lens, int n, int repeat, int nThreads)
+{
+    // padded copies: the reference bit reader looks a few bytes ahead
+    std::vector<std::vector<uint8_t>> bufs(n);
+    for (int i = 0 ; i < n ; ++i)
+    {
+        bufs[i].assign(streams[i], streams[i] + lens[i]);
+        bufs[i].resize(lens[i] + 64, 0);
+    }
+    std::vector<long long> frames(nThreads, 0);
+    std::vector<std::thread> pool;
+    for (int t = 0 ; t < nThreads ; ++t)
+        pool.emplace_back([&, t]() {
+            DCSDecoder::MinHost host;
+            std::unique_ptr<DCSDecoderNative> dec[4];
+            volatile int16_t sink = 0;
+            for (int rep = 0 ; rep < repeat ; ++rep)
+                for (int i = t ; i < n ; i += nThreads)
+                {
+                    auto &d = dec[os[i] & 3];
+                    if (!d)
+                    {
+                        d.reset(new DCSDecoderNative(&host));
+                        d->InitStandalone(OsFromInt(os[i]));
+                        d->SetDefaultVolume(volume[i]);
+                        d->SoftBoot();
+                    }
+                    d->SetMasterVolume(volume[i]);
+                    const int nf = (bufs[i][0] << 8) | bufs[i][1];
+                    d->LoadAudioStream(0, DCSDecoder::ROMPointer(0, bufs[i].data()), level[i]);
+                    int16_t acc = 0;
+                    for (int k = 0 ; k < nf * 240 ; ++k)
+                        acc ^= d->GetNextSample();
+                    sink = acc;
+                    frames[t] += nf;
+                }
+            (void)sink;
+        });
+    for (auto &th : pool) th.join();
+    long long total = 0;
+    for (long long f : frames) total += f;
+    return total;
 }
 
 }   // extern "C"
