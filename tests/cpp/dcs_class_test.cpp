@@ -1,0 +1,99 @@
+// dcs_class_test -- a C++ client written the way the reference's callers drive DCSDecoderNative
+// (DCSEncoder.cpp:522-571, EncoderTester.cpp:85-137): MinHost + decoder + InitStandalone + SetDefaultVolume
+// + SoftBoot + LoadAudioStream + 240 x GetNextSample per frame.  tests/test_gpu_class.py compares the PCM it
+// writes with the oracle.
+//
+//   dcs_class_test live  <os> <volume> <lookahead> <out.pcm> <nFramesOut> <level0> <stream0.bin> [<level1> <stream1.bin> ...]
+//   dcs_class_test batch <os> <volume> <extraFrames> <out.pcm> <level> <stream0.bin> [<stream1.bin> ...]
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/DCSDecoderHIP.h"
+
+using namespace dcship;
+
+static std::vector<uint8_t> readFile(const char *path)
+{
+    std::vector<uint8_t> v;
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+    uint8_t buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0)
+        v.insert(v.end(), buf, buf + n);
+    fclose(f);
+    return v;
+}
+
+static DCSDecoder::OSVersion osOf(int os)
+{
+    switch (os)
+    {
+    case 0: return DCSDecoder::OSVersion::OS93a;
+    case 1: return DCSDecoder::OSVersion::OS93b;
+    case 2: return DCSDecoder::OSVersion::OS94;
+    default: return DCSDecoder::OSVersion::OS95;
+    }
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 7)
+    {
+        fprintf(stderr, "usage: see the comment at the top of dcs_class_test.cpp\n");
+        return 2;
+    }
+    const std::string mode = argv[1];
+    const int os = atoi(argv[2]), volume = atoi(argv[3]);
+    DCSDecoder::MinHost host;
+
+    // the decoder is created through the same registration map DCSExplorer's --decoder=<name> uses
+    auto &reg = DCSDecoder::GetRegistrationMap();
+    auto it = reg.find("hip");
+    if (it == reg.end()) { fprintf(stderr, "decoder 'hip' is not registered\n"); return 3; }
+    DCSDecoderHIP *dec = static_cast<DCSDecoderHIP *>(it->second.factory(&host));
+    dec->InitStandalone(osOf(os));
+    dec->SetDefaultVolume(volume);
+    dec->SoftBoot();
+    if (!dec->IsOK()) { fprintf(stderr, "decoder not OK: %s\n", dec->GetErrorMessage().c_str()); return 4; }
+
+    std::vector<int16_t> pcm;
+    if (mode == "live")
+    {
+        dec->SetLookahead(atoi(argv[4]));
+        const int nFramesOut = atoi(argv[6]);
+        std::vector<std::vector<uint8_t>> keep;
+        int ch = 0;
+        for (int i = 7 ; i + 1 < argc ; i += 2, ++ch)
+        {
+            keep.push_back(readFile(argv[i + 1]));
+            dec->LoadAudioStream(ch, DCSDecoder::ROMPointer(0, keep.back().data()), atoi(argv[i]), keep.back().size());
+        }
+        auto info = dec->GetStreamInfo(DCSDecoder::ROMPointer(0, keep[0].data()), keep[0].size());
+        fprintf(stderr, "stream 0: %d frames, %d bytes, type %d/%d\n", info.nFrames, info.nBytes, info.formatType, info.formatSubType);
+        for (int f = 0 ; f < nFramesOut ; ++f)
+            for (int i = 0 ; i < 240 ; ++i)
+                pcm.push_back(dec->GetNextSample());
+        if (!dec->IsOK()) { fprintf(stderr, "decoder failed: %s\n", dec->GetErrorMessage().c_str()); return 5; }
+    }
+    else
+    {
+        const unsigned extra = static_cast<unsigned>(atoi(argv[4]));
+        const int level = atoi(argv[6]);
+        std::vector<std::vector<uint8_t>> keep;
+        std::vector<DCSDecoderHIP::BatchStream> streams;
+        for (int i = 7 ; i < argc ; ++i)
+        {
+            keep.push_back(readFile(argv[i]));
+            streams.push_back({ keep.back().data(), keep.back().size(), volume, level });
+        }
+        if (!dec->DecodeStreamsBatch(streams, extra, pcm)) { fprintf(stderr, "batch decode failed\n"); return 6; }
+    }
+    FILE *out = fopen(argv[5], "wb");
+    fwrite(pcm.data(), sizeof(int16_t), pcm.size(), out);
+    fclose(out);
+    delete dec;
+    return 0;
+}

@@ -1,0 +1,75 @@
+"""DCSDecoderHIP (include/DCSDecoderHIP.h): the reference's decoder class surface on top of the C ABI,
+driven by a C++ client written like the reference's own callers (tests/cpp/dcs_class_test.cpp)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import dcsexplorer_amd as D
+from util import make_stream, os_for
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "dcsexplorer_amd", "dcs_class_test")
+
+
+def run(args, tmp_path):
+    out = str(tmp_path / "out.pcm")
+    full = [EXE] + [a if a != "OUT" else out for a in args]
+    p = subprocess.run(full, capture_output=True, text=True, timeout=300)
+    return p, out
+
+
+def write_stream(tmp_path, name, data):
+    path = str(tmp_path / name)
+    open(path, "wb").write(data)
+    return path
+
+
+def test_class_fails_loudly_without_gpu(tmp_path):
+    """no device: SoftBoot ends in InitializationError, IsOK() is false, nothing is decoded on the CPU"""
+    assert os.path.exists(EXE), "build with make -C dcsexplorer_amd/csrc"
+    if D.device_count() > 0:
+        pytest.skip("a GPU is present")
+    s = write_stream(tmp_path, "s.bin", make_stream(D.FMT_94_T1_S3, 4, seed=1))
+    p, _ = run(["live", "3", "255", "1", "OUT", "4", "100", s], tmp_path)
+    assert p.returncode == 4 and "HIP decoder unavailable" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lookahead", [1, 7])
+def test_live_playback_matches_oracle(tmp_path, oracle, lookahead):
+    for fmt in (D.FMT_94_T1_S3, D.FMT_93_T0, D.FMT_93A_T1):
+        data = make_stream(fmt, 23, seed=21000 + fmt)
+        os_ = os_for(fmt)
+        s = write_stream(tmp_path, "s%d.bin" % fmt, data)
+        p, out = run(["live", str(os_), "230", str(lookahead), "OUT", "26", str(0x66), s], tmp_path)
+        assert p.returncode == 0, p.stderr
+        got = np.fromfile(out, dtype=np.int16).reshape(26, 240)
+        want = oracle.decode(os_, 230, [data], [0x66], 26)
+        assert np.array_equal(got, want), "fmt %d" % fmt
+
+
+@pytest.mark.gpu
+def test_live_multichannel_matches_oracle(tmp_path, oracle):
+    datas = [make_stream(f, 9 + 6 * i, seed=22000 + i, profile=i % 3) for i, f in
+             enumerate((D.FMT_94_T0, D.FMT_94_T1_S0, D.FMT_94_T1_S3, D.FMT_94_T1_S3))]
+    levels = [0x68, 0x60, 0x64, 0x5C]
+    args = ["live", "2", "255", "5", "OUT", "40"]
+    for i, d in enumerate(datas):
+        args += [str(levels[i]), write_stream(tmp_path, "m%d.bin" % i, d)]
+    p, out = run(args, tmp_path)
+    assert p.returncode == 0, p.stderr
+    got = np.fromfile(out, dtype=np.int16).reshape(40, 240)
+    assert np.array_equal(got, oracle.decode(2, 255, datas, levels, 40))
+
+
+@pytest.mark.gpu
+def test_batch_submit_matches_oracle(tmp_path, oracle):
+    datas = [make_stream(D.FMT_93B_T1, 12 + 3 * i, seed=23000 + i) for i in range(5)]
+    args = ["batch", "1", "240", "2", "OUT", str(0x64)] + [write_stream(tmp_path, "b%d.bin" % i, d) for i, d in enumerate(datas)]
+    p, out = run(args, tmp_path)
+    assert p.returncode == 0, p.stderr
+    got = np.fromfile(out, dtype=np.int16).reshape(-1, 240)
+    want = np.concatenate([oracle.decode(1, 240, [d], [0x64], ((d[0] << 8) | d[1]) + 2) for d in datas])
+    assert np.array_equal(got, want)
