@@ -55,15 +55,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-
     import numpy as np
     import torch
     import torch.distributed as dist
     import dcsexplorer_amd as D
-    from dcsexplorer_amd import workloads
+    from dcsexplorer_amd import sharding, workloads
+
+    rank, local_rank, world = sharding.rank_info()
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -73,13 +71,7 @@ def main():
         torch.cuda.set_device(local_rank)
 
     # this rank's range of the corpus: same shape on every rank, different streams (seeds)
-    fn = workloads.WORKLOADS[args.workload]
-    if rank == 0:
-        streams = fn()
-    else:
-        import inspect
-        n_streams = inspect.signature(fn).parameters["n_streams"].default
-        streams = workloads.shifted(fn, rank * n_streams)
+    streams = sharding.rank_streams(args.workload, rank)
     b = D.build_stream_batch(streams)
     if args.workload == "mixed_16384":
         b, _ = workloads.interleave(b)
@@ -108,10 +100,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = sharding.max_over_ranks(dt, device="cuda")
 
     # kernel-only average duration by HIP events on the launch stream (roofline denominator)
     kern_ms = batch.time(max(10, args.steps), stream)
