@@ -72,10 +72,11 @@ const DcsDevTables &dcsTables();
 // LDS bit pool: the compressed bytes of the frames one wavefront unpacks in one round are staged
 // there.  The planner closes a chunk before the pool would overflow.
 #define DCS_POOL_DW_PER_FRAME 56        // 224 bytes per frame slot on average (typical frame: ~125-150 bytes)
+#define DCS_POOL_DW_MIN       320       // but never less than two maximal frames (a halo and its successor)
 #define DCS_MAX_FRAME_BITS    4480      // 16 band headers + 255 x 16-bit samples, rounded up
 
 #ifdef __cplusplus
-// dwords of pool one source occupies: whole dwords covering the frame + 2 dwords of window look-ahead
+// dwords of pool one source occupies: whole dwords covering the frame + 3 dwords of window look-ahead
 static inline
 #ifdef __HIPCC__
 __host__ __device__
@@ -83,7 +84,18 @@ __host__ __device__
 uint32_t dcsPoolDwords(uint64_t streamOff, uint32_t hdrLen, uint32_t bitOff, uint32_t nBits)
 {
     const uint32_t inDword = static_cast<uint32_t>(((streamOff + 2 + hdrLen) * 8 + bitOff) & 31);
-    return (inDword + nBits + 31) / 32 + 2;
+    return (inDword + nBits + 31) / 32 + 3;
+}
+#endif
+
+#ifdef __cplusplus
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr uint32_t dcsPoolCapacity(int fpw)
+{
+    return static_cast<uint32_t>(fpw * DCS_POOL_DW_PER_FRAME > DCS_POOL_DW_MIN ? fpw * DCS_POOL_DW_PER_FRAME : DCS_POOL_DW_MIN);
 }
 #endif
 
@@ -92,12 +104,15 @@ uint32_t dcsPoolDwords(uint64_t streamOff, uint32_t hdrLen, uint32_t bitOff, uin
 #define DCS_SLOT_EMPTY     0x80u        // padding
 #define DCS_NO_PREV_SLOT   0xFFu
 
-struct DcsSlot
-{
-    uint32_t job;
+struct DcsSlot                          // 16 bytes: everything the kernel needs to know about a job, so
+{                                       // that the job list itself is never read on the device
+    uint32_t job;                       // output index (PCM row, err entry)
     uint8_t  prevSlot;                  // slot index inside the chunk whose tail overlaps into this one
     uint8_t  flags;
-    uint16_t reserved;
+    uint8_t  nSrc;
+    uint8_t  shiftXform;                // volShift | xform << 4
+    uint32_t firstSrc;
+    uint32_t prevJob;                   // DcsFrameJob.prev (external-tail index when DCS_SLOT_EXT_TAIL)
 };
 
 struct DcsKernelArgs
@@ -105,7 +120,6 @@ struct DcsKernelArgs
     const uint8_t      *blob;
     uint64_t            blobLen;        // bytes that may be read (allocation is padded beyond this)
     const DcsSrcDesc   *srcs;
-    const DcsFrameJob  *jobs;
     const DcsSlot      *slots;          // nChunks x fpw
     uint32_t            nChunks;
     uint32_t            nJobs;
@@ -114,6 +128,7 @@ struct DcsKernelArgs
     const int16_t      *tailsIn;        // k x 16 (may be null)
     int16_t            *tailsOut;       // nJobs x 16 (may be null)
     const DcsDevTables *tables;
+    unsigned long long *debug;          // diagnostic builds only (DCS_STAMPS); null otherwise
 };
 
 // planner: returns the number of chunks; slots is resized to nChunks * fpw

@@ -26,11 +26,19 @@
 
 namespace dcsk {
 
+// diagnostic build only (-DDCS_STAMPS): per-chunk cycle stamps at the phase boundaries, written to a debug
+// buffer no other code reads (args.debug); never enabled in the shipped library
+#ifdef DCS_STAMPS
+#define DCS_STAMP(k) do { if (lane == 0 && a.debug != nullptr) a.debug[static_cast<size_t>(chunk) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DCS_STAMP(k) do { } while (0)
+#endif
+
 constexpr int kWavesPerBlock = 4;       // wavefronts of a workgroup share one copy of the decode tables in LDS
 constexpr int kRowBytes = 528;          // 256 words + 16 bytes: 16-byte aligned rows (the transforms transpose through them
                                         // with 128-bit accesses), rows of neighbouring frames land on different LDS banks
 
-__host__ __device__ constexpr int poolDwords(int fpw) { return fpw * DCS_POOL_DW_PER_FRAME; }
+__host__ __device__ constexpr int poolDwords(int fpw) { return static_cast<int>(dcsPoolCapacity(fpw)); }
 __host__ __device__ constexpr int subLanes(int fpw) { return fpw <= 16 ? 4 : fpw == 32 ? 2 : 1; }   // 8 and 16 are built
 
 // per wavefront: tile rows | tails [fpw][16] i16 | bit pool
@@ -89,15 +97,18 @@ __device__ __forceinline__ int calcExp32(uint32_t x)
 // ------------------------------------------------------------------------------------------------
 struct BitReader
 {
-    const uint32_t *p;      // next pool dword
+    const uint32_t *p;      // pool dword after `nxt`
     uint32_t hi, lo;        // valid bits are left-aligned in hi:lo, invalid bits are zero
+    uint32_t nxt;           // the next pool dword, fetched one refill ahead so that its LDS latency is off the
+                            // per-symbol critical path
     int cnt;                // number of valid bits
 
     __device__ __forceinline__ void init(const uint32_t *pool, int bitInDword)
     {
         hi = pool[0];
         lo = pool[1];
-        p = pool + 2;
+        nxt = pool[2];
+        p = pool + 3;
         cnt = 64;
         if (bitInDword != 0)
             skip(bitInDword);
@@ -106,11 +117,12 @@ struct BitReader
     {
         if (cnt <= 32)
         {
-            // lo is empty here; append the next dword right behind the cnt valid bits
-            const uint64_t add = (static_cast<uint64_t>(*p++) << 32) >> cnt;
+            // lo is empty here; append the prefetched dword right behind the cnt valid bits
+            const uint64_t add = (static_cast<uint64_t>(nxt) << 32) >> cnt;
             hi |= static_cast<uint32_t>(add >> 32);
             lo = static_cast<uint32_t>(add);
             cnt += 32;
+            nxt = *p++;
         }
     }
     // n in 1..24, after refill()
@@ -944,13 +956,14 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const uint16_t 
 // the kernel
 // ------------------------------------------------------------------------------------------------
 template <int FPW>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) dcsDecodeKernel(const DcsKernelArgs a)
+__global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const DcsKernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = static_cast<int>(threadIdx.x) >> 6;
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const Lds<FPW> L{ smem, smem + sizeof(DcsLdsTables) + wave * waveLdsBytes(FPW) };
     const uint32_t chunk = blockIdx.x * kWavesPerBlock + static_cast<uint32_t>(wave);
+    if (chunk < a.nChunks) DCS_STAMP(0);
     constexpr int SUB = subLanes(FPW);              // lanes that unpack one frame together
     constexpr int BPL = 16 / SUB;                   // header bands per sub-lane
     const int s = lane % FPW;                       // slot of this lane
@@ -971,15 +984,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dcsDecodeKernel(const Dcs
     if (chunk >= a.nChunks)
         return;                                     // padding wavefront of the last workgroup
 
-    LaneConsts C;
-    loadLaneConsts(a.tables, lane, C);
+    DCS_STAMP(1);
 
     // ---- slot and job of this lane (all sub-lanes of a slot hold the same copy) -----------------
-    DcsSlot slot = a.slots[static_cast<size_t>(chunk) * FPW + s];
+    const DcsSlot slot = a.slots[static_cast<size_t>(chunk) * FPW + s];
     const bool live = !(slot.flags & DCS_SLOT_EMPTY);
-    DcsFrameJob job{ 0, 0, 0, DCS_XFORM_94, 0, DCS_PREV_NONE, 0 };
-    if (live)
-        job = a.jobs[slot.job];
+    struct { uint32_t firstSrc; int nSrc; int volShift; int xform; uint32_t prev; } job;
+    job.firstSrc = slot.firstSrc; job.nSrc = slot.nSrc; job.volShift = slot.shiftXform & 15;
+    job.xform = slot.shiftXform >> 4; job.prev = slot.prevJob;
 
     // ---- phase 1: unpack, one round per source index -------------------------------------------------
     uint32_t err = 0;
@@ -995,6 +1007,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dcsDecodeKernel(const Dcs
         for (int d = 32 ; d >= 1 ; d >>= 1)
             maxSrc = max(maxSrc, __shfl_xor(maxSrc, d));
 
+#ifdef DCS_EXP_NO_PHASE1
+        if (maxSrc > 1000)
+#endif
         for (int r = 0 ; r < maxSrc ; ++r)
         {
             const bool has = r < myNSrc;
@@ -1036,21 +1051,50 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dcsDecodeKernel(const Dcs
             const uint32_t nDwSlot = __shfl(nDw, s);
             const bool fits = off + nDwSlot <= static_cast<uint32_t>(poolDwords(FPW));
 
-            // stage: one coalesced run of dwords per slot, byte-swapped so that bit 31 is the next stream bit
-            for (int t = 0 ; t < FPW ; ++t)
+            // stage: one coalesced run of dwords per slot, byte-swapped so that bit 31 is the next stream bit.
+            // All loads of a group of slots are issued before the first store, so their latencies overlap.
+            constexpr int kStageUnroll = FPW < 8 ? FPW : 8;
+            for (int t0 = 0 ; t0 < FPW ; t0 += kStageUnroll)
             {
-                const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(nDw), t));
-                const uint32_t st = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(startDw), t));
-                const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(offMine), t));
-                if (o + n > static_cast<uint32_t>(poolDwords(FPW)))
-                    continue;
-                for (uint32_t i = static_cast<uint32_t>(lane) ; i < n ; i += 64)
+                uint32_t v[kStageUnroll], dst[kStageUnroll];
+                bool any64 = false;
+#pragma unroll
+                for (int u = 0 ; u < kStageUnroll ; ++u)
                 {
-                    const uint32_t w = st + i;
-                    pool[o + i] = w < blobWords ? __builtin_bswap32(blobW[w]) : 0u;
+                    const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(nDw), t0 + u));
+                    const uint32_t st = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(startDw), t0 + u));
+                    const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(offMine), t0 + u));
+                    const bool room = o + n <= static_cast<uint32_t>(poolDwords(FPW));
+                    const uint32_t w = st + static_cast<uint32_t>(lane);
+                    const bool mine = room && static_cast<uint32_t>(lane) < n;
+                    v[u] = (mine && w < blobWords) ? blobW[w] : 0u;
+                    dst[u] = mine ? o + static_cast<uint32_t>(lane) : 0xFFFFFFFFu;
+                    any64 = any64 || (room && n > 64);
+                }
+#pragma unroll
+                for (int u = 0 ; u < kStageUnroll ; ++u)
+                    if (dst[u] != 0xFFFFFFFFu)
+                        pool[dst[u]] = __builtin_bswap32(v[u]);
+                if (any64)
+                {
+                    // frames longer than 256 bytes: the rest, slot by slot
+                    for (int u = 0 ; u < kStageUnroll ; ++u)
+                    {
+                        const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(nDw), t0 + u));
+                        const uint32_t st = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(startDw), t0 + u));
+                        const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(offMine), t0 + u));
+                        if (o + n > static_cast<uint32_t>(poolDwords(FPW)))
+                            continue;
+                        for (uint32_t i = static_cast<uint32_t>(lane) + 64 ; i < n ; i += 64)
+                        {
+                            const uint32_t w = st + i;
+                            pool[o + i] = w < blobWords ? __builtin_bswap32(blobW[w]) : 0u;
+                        }
+                    }
                 }
             }
 
+            if (r == 0) DCS_STAMP(2);
             // the stream header: 16 bytes at streamOff + 2, via aligned dwords
             {
                 const uint32_t hw = static_cast<uint32_t>((streamOff + 2) >> 2);
@@ -1070,6 +1114,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dcsDecodeKernel(const Dcs
             }
             waveSync();
 
+            if (r == 0) DCS_STAMP(3);
             // ---- which part of the frame this lane unpacks, and from which decoder state ----------------
             const bool ok = has && fits && unpacker;
             if (has && !fits && q == 0)
@@ -1124,6 +1169,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dcsDecodeKernel(const Dcs
             waveSync();
         }
 
+        DCS_STAMP(4);
         // a frame's error bits = OR over its sub-lanes
 #pragma unroll
         for (int k = 1 ; k < SUB ; ++k)
@@ -1138,6 +1184,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dcsDecodeKernel(const Dcs
     }
     waveSync();
 
+    DCS_STAMP(5);
+    LaneConsts C;                                   // fetched here so that they are not live during phase 1
+    loadLaneConsts(a.tables, lane, C);
     // ---- phase 2: transform passes (8 frames x 8 lanes, or 4 frames x 16 lanes), overlap, emit ------------
     uint32_t *tails = reinterpret_cast<uint32_t *>(L.tails());         // [slot][8] dwords = 16 samples
     const uint16_t *coef = a.tables->fftCoef;
@@ -1145,6 +1194,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dcsDecodeKernel(const Dcs
     const int slotFlags = slot.flags, slotJob = static_cast<int>(slot.job), slotPrev = slot.prevSlot;
     const int jobShift = job.volShift, jobXform = job.xform, jobPrev = static_cast<int>(job.prev);
 
+#ifdef DCS_EXP_NO_PHASE2
+    if (nSlots > 1000)
+#endif
     for (int s0 = 0 ; s0 < nSlots ; )
     {
         const int xf = __builtin_amdgcn_readlane(jobXform, s0);
@@ -1237,6 +1289,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dcsDecodeKernel(const Dcs
         waveSync();
         s0 += n;
     }
+    DCS_STAMP(6);
 }
 
 }   // namespace dcsk

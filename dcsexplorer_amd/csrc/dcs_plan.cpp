@@ -8,6 +8,11 @@
 #include "dcs_common.h"
 #include <vector>
 
+static DcsSlot makeSlot(const DcsFrameJob &jb, uint32_t job, uint8_t prevSlot, uint8_t flags)
+{
+    return DcsSlot{ job, prevSlot, flags, jb.nSrc, static_cast<uint8_t>(jb.volShift | (jb.xform << 4)), jb.firstSrc, jb.prev };
+}
+
 uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots)
 {
     slots.clear();
@@ -21,7 +26,7 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
 
     // LDS bit-pool budget: per unpack round r (the r-th source of every job in the chunk) the staged
     // frames must fit fpw * DCS_POOL_DW_PER_FRAME dwords
-    const uint32_t poolCap = static_cast<uint32_t>(fpw) * DCS_POOL_DW_PER_FRAME;
+    const uint32_t poolCap = dcsPoolCapacity(fpw);
     uint32_t poolUse[DCS_MAX_CHANNELS] = { 0 };
     auto poolNeed = [&](uint32_t j, uint32_t r) -> uint32_t {
         if (srcs == nullptr || r >= jobs[j].nSrc)
@@ -42,7 +47,7 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
 
     uint32_t chunk = 0;
     uint32_t used = 0;                  // slots filled in the current chunk
-    const DcsSlot empty{ 0xFFFFFFFFu, DCS_NO_PREV_SLOT, DCS_SLOT_EMPTY, 0 };
+    const DcsSlot empty{ 0xFFFFFFFFu, DCS_NO_PREV_SLOT, DCS_SLOT_EMPTY, 0, 0, 0, DCS_PREV_NONE };
     auto closeChunk = [&]() {
         while (used < static_cast<uint32_t>(fpw)) { slots.push_back(empty); ++used; }
         ++chunk;
@@ -69,14 +74,14 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
         {
             if (!inChunk(prev))
             {
-                slots.push_back({ prev, DCS_NO_PREV_SLOT, DCS_SLOT_HALO, 0 });
+                slots.push_back(makeSlot(jobs[prev], prev, DCS_NO_PREV_SLOT, DCS_SLOT_HALO));
                 poolAdd(prev);
                 stampOf[prev] = chunk;
                 slotOf[prev] = static_cast<uint8_t>(used++);
             }
             prevSlot = slotOf[prev];
         }
-        slots.push_back({ j, prevSlot, static_cast<uint8_t>(ext ? DCS_SLOT_EXT_TAIL : 0), 0 });
+        slots.push_back(makeSlot(jobs[j], j, prevSlot, static_cast<uint8_t>(ext ? DCS_SLOT_EXT_TAIL : 0)));
         poolAdd(j);
         stampOf[j] = chunk;
         slotOf[j] = static_cast<uint8_t>(used++);
@@ -91,7 +96,7 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
 extern "C" DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw,
                                      uint64_t *slotsOut, size_t cap, uint32_t *nChunksOut)
 {
-    if (jobs == nullptr || nChunksOut == nullptr || fpw < 8 || fpw > 64)
+    if (jobs == nullptr || nChunksOut == nullptr || fpw < 4 || fpw > 64)
         return DCS_ERR_INVALID_ARG;
     std::vector<DcsSlot> slots;
     *nChunksOut = dcsPlanChunks(jobs, nJobs, srcs, fpw, slots);

@@ -32,12 +32,12 @@ struct DcsBatch
     // device buffers
     uint8_t *dBlob = nullptr;
     DcsSrcDesc *dSrcs = nullptr;
-    DcsFrameJob *dJobs = nullptr;
     DcsSlot *dSlots = nullptr;
     int16_t *dTailsIn = nullptr;
     int16_t *dPcm = nullptr;
     uint32_t *dErr = nullptr;
     int16_t *dTailsOut = nullptr;
+    unsigned long long *dDebug = nullptr;   // DCS_STAMPS builds only
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -135,20 +135,20 @@ extern "C" void dcs_ctx_destroy(DcsCtx *ctx)
 
 extern "C" DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw)
 {
-    if (ctx == nullptr || !(fpw == 0 || fpw == 8 || fpw == 16))
+    if (ctx == nullptr || !(fpw == 0 || fpw == 4 || fpw == 8 || fpw == 16))
         return DCS_ERR_INVALID_ARG;
     ctx->fpwOverride = fpw;
     return DCS_OK;
 }
 
 // frames per wavefront.  Four lanes unpack one frame, so 16 frames fill the 64 lanes; small batches
-// use 8 frames per wavefront so that more CUs get work.
+// use 8 or 4 frames per wavefront: more wavefronts, and a shorter serial path in each.
 static int chooseFpw(const DcsCtx *ctx, uint32_t nJobs)
 {
     if (ctx->fpwOverride != 0)
         return ctx->fpwOverride;
     const uint64_t simds = static_cast<uint64_t>(ctx->numCUs) * 4;
-    return nJobs >= simds * 16 ? 16 : 8;
+    return nJobs >= simds * 16 ? 16 : nJobs >= simds * 6 ? 8 : 4;
 }
 
 extern "C" void dcs_batch_destroy(DcsBatch *b)
@@ -156,7 +156,7 @@ extern "C" void dcs_batch_destroy(DcsBatch *b)
     if (b == nullptr)
         return;
     (void)hipSetDevice(b->ctx->device);
-    void *ptrs[] = { b->dBlob, b->dSrcs, b->dJobs, b->dSlots, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut };
+    void *ptrs[] = { b->dBlob, b->dSrcs, b->dSlots, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -217,7 +217,8 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
     std::vector<DcsSlot> slots;
     b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots);
 
-    // algorithmic bytes: compressed payload + descriptors read, PCM written
+    // algorithmic bytes: compressed payload + descriptors read (one DcsSrcDesc per source, one
+    // 16-byte job record per frame -- the device reads it in its DcsSlot form), PCM written
     b->algoBytes = (payloadBits + 7) / 8 + static_cast<uint64_t>(nSrcs) * sizeof(DcsSrcDesc)
                  + static_cast<uint64_t>(nJobs) * sizeof(DcsFrameJob) + static_cast<uint64_t>(nJobs) * DCS_FRAME_SAMPLES * 2;
 
@@ -233,8 +234,6 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
             HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dSrcs), sizeof(DcsSrcDesc) * nSrcs));
             HIPCHK(ctx, hipMemcpyAsync(b->dSrcs, srcs, sizeof(DcsSrcDesc) * nSrcs, hipMemcpyHostToDevice, ctx->stream));
         }
-        HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dJobs), sizeof(DcsFrameJob) * nJobs));
-        HIPCHK(ctx, hipMemcpyAsync(b->dJobs, jobs, sizeof(DcsFrameJob) * nJobs, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dSlots), sizeof(DcsSlot) * slots.size()));
         HIPCHK(ctx, hipMemcpyAsync(b->dSlots, slots.data(), sizeof(DcsSlot) * slots.size(), hipMemcpyHostToDevice, ctx->stream));
         if (nTailsIn)
@@ -246,6 +245,10 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
         HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dErr), sizeof(uint32_t) * nJobs));
         HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dTailsOut), sizeof(int16_t) * 16 * nJobs));
         HIPCHK(ctx, hipMemsetAsync(b->dErr, 0, sizeof(uint32_t) * nJobs, ctx->stream));
+#ifdef DCS_STAMPS
+        HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dDebug), sizeof(unsigned long long) * 8 * (b->nChunks + 4)));
+        HIPCHK(ctx, hipMemsetAsync(b->dDebug, 0, sizeof(unsigned long long) * 8 * (b->nChunks + 4), ctx->stream));
+#endif
         HIPCHK(ctx, hipEventCreate(&b->ev0));
         HIPCHK(ctx, hipEventCreate(&b->ev1));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -280,7 +283,6 @@ extern "C" DcsStatus dcs_batch_run(DcsBatch *b, void *hipStream)
     args.blob = b->dBlob;
     args.blobLen = b->blobLen;
     args.srcs = b->dSrcs;
-    args.jobs = b->dJobs;
     args.slots = b->dSlots;
     args.nChunks = b->nChunks;
     args.nJobs = b->nJobs;
@@ -289,8 +291,9 @@ extern "C" DcsStatus dcs_batch_run(DcsBatch *b, void *hipStream)
     args.tailsIn = b->dTailsIn;
     args.tailsOut = b->dTailsOut;
     args.tables = ctx->dTables;
+    args.debug = b->dDebug;
     hipError_t e;
-    e = (b->fpw == 16) ? launch<16>(args, stream) : launch<8>(args, stream);
+    e = (b->fpw == 16) ? launch<16>(args, stream) : (b->fpw == 8) ? launch<8>(args, stream) : launch<4>(args, stream);
     if (e != hipSuccess)
     {
         ctx->lastError = std::string("kernel launch failed: ") + hipGetErrorString(e);
@@ -344,6 +347,18 @@ extern "C" DcsStatus dcs_batch_download(DcsBatch *b, int16_t *pcmOut, uint32_t *
 }
 
 extern "C" void *dcs_batch_device_pcm(DcsBatch *b) { return b ? b->dPcm : nullptr; }
+
+#ifdef DCS_STAMPS
+// diagnostic builds only: copy the per-chunk phase stamps (8 x uint64 per chunk) to the host
+extern "C" int dcs_debug_stamps(DcsBatch *b, unsigned long long *out, uint32_t capChunks)
+{
+    if (b == nullptr || b->dDebug == nullptr) return -1;
+    (void)hipStreamSynchronize(b->ctx->stream);
+    const uint32_t n = b->nChunks < capChunks ? b->nChunks : capChunks;
+    (void)hipMemcpy(out, b->dDebug, sizeof(unsigned long long) * 8 * n, hipMemcpyDeviceToHost);
+    return static_cast<int>(n);
+}
+#endif
 extern "C" uint64_t dcs_batch_algorithmic_bytes(const DcsBatch *b) { return b ? b->algoBytes : 0; }
 extern "C" uint32_t dcs_batch_num_jobs(const DcsBatch *b) { return b ? b->nJobs : 0; }
 

@@ -166,4 +166,4 @@ static_assert(sizeof(DcsSrcDesc) == 64, "DcsSrcDesc layout");
 static_assert(offsetof(DcsSrcDesc, idx) == 12, "DcsSrcDesc layout");
 static_assert(sizeof(DcsFrameJob) == 16, "DcsFrameJob layout");
 static_assert(sizeof(DcsFrameIndex) == 52, "DcsFrameIndex layout");
-static_assert(sizeof(DcsSlot) == 8, "DcsSlot layout");
+static_assert(sizeof(DcsSlot) == 16, "DcsSlot layout");

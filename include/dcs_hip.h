@@ -182,7 +182,7 @@ void      dcs_ctx_destroy(DcsCtx *ctx);
 const char *dcs_last_error(const DcsCtx *ctx);     /* ctx may be NULL: last error of ctx_create */
 int       dcs_device_count(void);                  /* does not initialise the GPU runtime further than counting */
 
-/* tuning: frames handled per wavefront in the kernel (8 or 16); 0 = choose from batch size */
+/* tuning: frames handled per wavefront in the kernel (4, 8 or 16); 0 = choose from batch size */
 DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw);
 
 /* One-shot convenience: host buffers in, host buffers out (H2D, kernel, D2H on the context's

@@ -47,7 +47,7 @@ def test_single_stream_every_layout(gpu_ctx, oracle, fmt, profile):
         assert not err.any()
 
 
-@pytest.mark.parametrize("fpw", [8, 16])
+@pytest.mark.parametrize("fpw", [4, 8, 16])
 def test_frames_per_wave_variants_and_halos(gpu_ctx, oracle, fpw):
     """chunk boundaries fall inside streams: the overlap tail must come from the halo re-decode"""
     streams = [(os_for(f, f), make_stream(f, 45 + 13 * f, seed=12000 + f, profile=f % 3), 240, 0x62 + f)

@@ -87,7 +87,7 @@ def test_stream_writer_is_deterministic_and_seed_sensitive():
     assert (b[2] & 0x80) and (b[2] & 0x1F) == 18
 
 
-@pytest.mark.parametrize("fpw", [8, 16])
+@pytest.mark.parametrize("fpw", [4, 8, 16])
 def test_chunk_plan_properties(fpw):
     b = workloads.build("mixed_16384", n_streams=24, n_frames=37)
     jobs = b["jobs"]

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Where a wavefront spends its cycles: runs a workload on the DIAGNOSTIC library (make stamps) and prints
+the median cycle count of each phase.  Shares only, not absolute times (the stamps serialise)."""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dcsexplorer_amd.api as api
+api.lib_path = lambda: os.path.join(ROOT, "dcsexplorer_amd", "libdcs_hip_stamps.so")
+import dcsexplorer_amd as D
+from dcsexplorer_amd import workloads
+wl = sys.argv[1] if len(sys.argv) > 1 else "dcs93_4096"
+fpw = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+ctx = D.Context(0)
+if fpw: ctx.set_frames_per_wave(fpw)
+b = workloads.build(wl)
+bt = ctx.batch(b["blob"], b["srcs"], b["jobs"])
+for _ in range(3): bt.run()
+bt.sync()
+L = D.load_library()
+cap = 1 << 16
+out = np.zeros((cap, 8), dtype=np.uint64)
+L.dcs_debug_stamps.restype = ctypes.c_int
+n = L.dcs_debug_stamps(bt.h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(cap))
+st = out[:n].astype(np.int64)
+names = ["tables+zero+barrier", "lane consts + slot/desc + prefix + stage loads", "header loads", "unpack", "err/dc", "(sync)", "transform+emit"]
+tot = st[:, 6] - st[:, 0]
+print(wl, "fpw", fpw or "auto", "chunks", n, "median total cycles", int(np.median(tot)), "min", int(tot.min()), "max", int(tot.max()))
+for k in range(6):
+    d = st[:, k + 1] - st[:, k]
+    print("  %-48s median %7d  (%.1f%%)" % (names[k] if k < 5 else names[6], int(np.median(d)), 100 * np.median(d) / np.median(tot)))
+span = st[:, 6].max() - st[:, 0].min()
+print("  first start -> last end: %d cycles (s_memtime ticks at 100 MHz? see guide) " % span)
