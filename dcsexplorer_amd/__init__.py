@@ -10,7 +10,7 @@ from .api import (  # noqa: F401
     FRAME_SAMPLES, FRAME_STOP, FRAME_FATAL, PREV_NONE, PREV_EXT, XFORM_93, XFORM_94,
     SRC_DTYPE, JOB_DTYPE, INDEX_DTYPE, IDX_SERIAL,
     DcsError, lib_path, load_library,
-    index_stream, stream_params, volume_multiplier, mixing_multiplier, frame_scale,
+    index_stream, index_streams, pack_streams, stream_params, volume_multiplier, mixing_multiplier, frame_scale,
     synth_stream, build_stream_batch, device_count, plan_chunks, format_os,
     Context, Batch,
 )

@@ -8,6 +8,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 OS93A, OS93B, OS94, OS95 = 0, 1, 2, 3
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NO_MEMORY, ERR_CAPACITY, ERR_BAD_STREAM = -1, -2, -3, -4, -5, -6
 FMT_93_T0, FMT_93B_T1, FMT_93A_T1, FMT_94_T0, FMT_94_T1_S0, FMT_94_T1_S3 = range(6)
 FRAME_SAMPLES = 240
 FRAME_STOP, FRAME_FATAL = 1, 2
@@ -33,6 +34,17 @@ class StreamInfo(ctypes.Structure):
                 ("hdrLen", ctypes.c_int32), ("nValidFrames", ctypes.c_int32), ("payloadBits", ctypes.c_uint32)]
 
 
+class StreamRef(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("len", ctypes.c_size_t), ("os", ctypes.c_int32),
+                ("volume", ctypes.c_int32), ("level", ctypes.c_int32), ("channelVolume", ctypes.c_int32)]
+
+
+LOC_DTYPE = np.dtype([("off", "<u8"), ("len", "<u4"), ("os", "<i4"), ("firstRecord", "<u8")])
+INFO_DTYPE = np.dtype([("nFrames", "<i4"), ("nBytes", "<i4"), ("formatType", "<i4"), ("formatSubType", "<i4"),
+                       ("header", "u1", (16,)), ("format", "<i4"), ("hdrLen", "<i4"), ("nValidFrames", "<i4"),
+                       ("payloadBits", "<u4")])
+
+
 class SynthParams(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("format", ctypes.c_int32), ("nFrames", ctypes.c_int32),
                 ("nBands", ctypes.c_int32), ("strideFromBand", ctypes.c_int32), ("profile", ctypes.c_int32),
@@ -53,7 +65,8 @@ EXPORTS = [
     "dcs_ctx_set_frames_per_wave", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run",
     "dcs_batch_time", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_device_pcm",
     "dcs_batch_algorithmic_bytes", "dcs_batch_num_jobs", "dcs_decode_streams", "dcs_count_stream_frames",
-    "dcs_synth_stream", "dcs_plan_chunks",
+    "dcs_synth_stream", "dcs_plan_chunks", "dcs_index_streams", "dcs_index_streams_gpu",
+    "dcs_index_streams_gpu_time",
 ]
 
 
@@ -123,6 +136,12 @@ def load_library():
     L.dcs_synth_stream.argtypes = [ctypes.POINTER(SynthParams), vp, sz, ctypes.POINTER(sz)]
     L.dcs_plan_chunks.restype = i32
     L.dcs_plan_chunks.argtypes = [vp, u32, vp, ctypes.c_int, vp, sz, ctypes.POINTER(u32)]
+    L.dcs_index_streams.restype = i32
+    L.dcs_index_streams.argtypes = [vp, u32, ctypes.c_int, vp, vp, vp]
+    L.dcs_index_streams_gpu.restype = i32
+    L.dcs_index_streams_gpu.argtypes = [vp, vp, sz, vp, u32, vp, ctypes.c_uint64, vp]
+    L.dcs_index_streams_gpu_time.restype = i32
+    L.dcs_index_streams_gpu_time.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
     _LIB = L
     return L
 
@@ -149,6 +168,60 @@ def index_stream(os_, stream):
     if st != 0:
         raise DcsError(st)
     return out[:info.nValidFrames], info
+
+
+def _info_from_record(r):
+    info = StreamInfo()
+    ctypes.memmove(ctypes.byref(info), r.tobytes(), ctypes.sizeof(info))
+    return info
+
+
+def _frame_counts(streams):
+    return np.array([(s[1][0] << 8) | s[1][1] for s in streams], dtype=np.uint64)
+
+
+def _split_records(out, infos, first):
+    return [(out[int(first[k]):int(first[k]) + int(infos[k]["nValidFrames"])], _info_from_record(infos[k]))
+            for k in range(len(infos))]
+
+
+def index_streams(streams, threads=0):
+    """dcs_index_streams: index many (os, bytes, ...) streams on `threads` host threads (0 = all).
+    Returns a list of (records, StreamInfo), one per stream, identical to index_stream on each."""
+    L = load_library()
+    streams = list(streams)
+    if not streams:
+        return []
+    counts = _frame_counts(streams)
+    first = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    keep = [np.frombuffer(bytes(s[1]), dtype=np.uint8) for s in streams]
+    refs = (StreamRef * len(streams))()
+    for k, s in enumerate(streams):
+        refs[k].data = keep[k].ctypes.data
+        refs[k].len = keep[k].size
+        refs[k].os = s[0]
+    out = np.zeros(max(int(first[-1]), 1), dtype=INDEX_DTYPE)
+    infos = np.zeros(len(streams), dtype=INFO_DTYPE)
+    st = L.dcs_index_streams(refs, len(streams), threads, _ptr(out), _ptr(first), _ptr(infos))
+    if st != 0:
+        raise DcsError(st)
+    return _split_records(out, infos, first)
+
+
+def pack_streams(streams, pad=64):
+    """Lay (os, bytes, ...) streams out in one dword-aligned blob: -> (blob bytes, LOC_DTYPE array)"""
+    blob = bytearray()
+    locs = np.zeros(len(streams), dtype=LOC_DTYPE)
+    rec = 0
+    for k, s in enumerate(streams):
+        while len(blob) & 3:
+            blob.append(0)
+        data = bytes(s[1])
+        locs[k] = (len(blob), len(data), s[0], rec)
+        rec += (data[0] << 8) | data[1]
+        blob += data
+        blob += bytes(pad)
+    return bytes(blob), locs
 
 
 def volume_multiplier(vol):
@@ -195,16 +268,20 @@ def format_os(fmt, prefer_95=False, prefer_93a=False):
     return OS95 if prefer_95 else OS94
 
 
-def build_stream_batch(streams, extra_frames=0, pad=64):
+def build_stream_batch(streams, extra_frames=0, pad=64, indexer=None):
     """Host-side batch description for independent streams, each played alone from a fresh decoder
     (LoadAudioStream(0, ptr, level), DCSDecoderNative.cpp:1387).
 
-    streams: iterable of (os, bytes, volume, level).  Returns dict(blob, srcs, jobs, first_job)."""
+    streams: iterable of (os, bytes, volume, level).  indexer: None (dcs_index_stream per stream), or a
+    callable streams -> [(records, StreamInfo)] such as index_streams or Context.index_streams_gpu.
+    Returns dict(blob, srcs, jobs, first_job)."""
     blob = bytearray()
     srcs, jobs, first = [], [], []
     njobs = 0
-    for os_, data, volume, level in streams:
-        idx, info = index_stream(os_, data)
+    streams = list(streams)
+    indexed = indexer(streams) if indexer is not None else None
+    for k, (os_, data, volume, level) in enumerate(streams):
+        idx, info = indexed[k] if indexed is not None else index_stream(os_, data)
         nframes = info.nFrames
         mm, vs = stream_params(os_, volume, level, nframes)
         while len(blob) & 3:
@@ -307,6 +384,27 @@ class Context:
 
     def batch(self, blob, srcs, jobs, tails_in=None):
         return Batch(self, blob, srcs, jobs, tails_in)
+
+    def index_streams_gpu(self, streams):
+        """dcs_index_streams_gpu: the index pass on the GPU, one lane per stream.  Same result as
+        index_streams / index_stream."""
+        streams = list(streams)
+        if not streams:
+            return []
+        blob, locs = pack_streams(streams)
+        counts = _frame_counts(streams)
+        cap = int(counts.sum())
+        out = np.zeros(max(cap, 1), dtype=INDEX_DTYPE)
+        infos = np.zeros(len(streams), dtype=INFO_DTYPE)
+        b = np.frombuffer(blob, dtype=np.uint8)
+        _check(self.L.dcs_index_streams_gpu(self.h, _ptr(b), b.size, _ptr(locs), len(streams), _ptr(out), cap,
+                                            _ptr(infos)), self.h)
+        return _split_records(out, infos, locs["firstRecord"])
+
+    def index_gpu_time(self, iters=10):
+        ms = ctypes.c_float()
+        _check(self.L.dcs_index_streams_gpu_time(self.h, iters, ctypes.byref(ms)), self.h)
+        return ms.value
 
 
 class Batch:

@@ -1,284 +1,33 @@
-// dcs_index.cpp -- host index pass: walks a DCS stream and records, for every frame, the carried
-// state that makes it independently decodable (bit offset, band-type codes).
-//
-// Replaces DCSDecoderNative::GetStreamInfo (DCSDecoderNative.cpp:1486-1537), which finds the end of
-// a stream the same way: by running the frame decompressor over every frame.  This walker follows
-// only the LENGTHS of the coded fields (it never reconstructs a sample, so it cannot serve as a CPU
-// decode path); the layouts it parses are those of DecoderImpl94x/93/93a::DecompressFrame
-// (:1679-2261, :2293-2684, :2831-3032) and the container of InitChannelStream (:1433-1463).
-#include "dcs_common.h"
-#include <string.h>
+// dcs_index.cpp -- host entry points of the index pass (the walker itself is dcs_scan.h, shared with
+// the device index kernel).
+#include "dcs_scan.h"
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 namespace {
 
-// MSB-first reader with the reference's look-ahead policy (ROMBitPointer, DCSDecoderNative.h:229-289):
-// Peek(n) pulls whole bytes while nBits <= n.  The policy matters only for StreamInfo.nBytes, which
-// the reference computes from the reader's BYTE pointer (:1509).
-struct Bits
+struct HostFetch
 {
-    const uint8_t *data = nullptr;
-    size_t len = 0;
-    size_t payOff = 0;
-    size_t p = 0;
-    uint32_t buf = 0;
-    int nBits = 0;
-
-    uint32_t byteAt(size_t i) const { return i < len ? data[i] : 0u; }
-    uint32_t peek(int n)
-    {
-        while (nBits <= n)
-        {
-            buf |= byteAt(p++) << (24 - nBits);
-            nBits += 8;
-        }
-        return buf >> (32 - n);
-    }
-    uint32_t get(int n)
-    {
-        uint32_t r = peek(n);
-        nBits -= n;
-        buf <<= n;
-        return r;
-    }
-    uint32_t bitPos() const { return static_cast<uint32_t>((p - payOff) * 8 - static_cast<size_t>(nBits)); }
+    const uint8_t *data;
+    size_t len;
+    uint32_t operator()(size_t i) const { return i < len ? data[i] : 0u; }
 };
 
-// one prefix code through the trie of dcs_common.h, bit-serial like the reference's tree walks
-// (:1819-1828, :2653-2661) so the reader's look-ahead -- and therefore nBytes -- is the same
-inline int readVlc(Bits &b, const uint16_t *trie)
+struct ArraySink
 {
-    uint32_t e = trie[b.get(1)];
-    while (!(e & 0x8000))
-        e = trie[e + b.get(1)];
-    return static_cast<int>(e & 0xFF);
-}
-
-struct Scan
-{
-    Bits b;
-    uint8_t header[16];
-    uint16_t bandType[16];
-    int nBands = 0;
-    uint32_t err = 0;
+    DcsFrameIndex *out;
+    uint32_t cap;
+    uint32_t written = 0;
+    bool overflow = false;
+    void operator()(uint32_t f, const DcsFrameIndex &fi)
+    {
+        if (f < cap) { out[f] = fi; written = f + 1; }
+        else overflow = true;
+    }
 };
-
-inline void fatal(Scan &s) { s.err |= DCS_FRAME_FATAL | DCS_FRAME_STOP; }
-
-inline void putSplit(DcsFrameIndex &fi, int band, uint32_t frameStart, const Scan &s, int outIdx,
-                     uint32_t prv = 0, uint32_t prvDelta = 0, int subType = 0, bool reuse = false)
-{
-    if (band != 4 && band != 8 && band != 12)
-        return;
-    DcsSplit &sp = fi.split[band / 4 - 1];
-    sp.bitDelta = static_cast<uint16_t>(s.b.bitPos() - frameStart);
-    sp.prv = static_cast<uint16_t>(prv);
-    sp.prvDelta = static_cast<uint16_t>(prvDelta);
-    sp.state = static_cast<uint16_t>((outIdx & 0x1FF) | (subType << 9) | (reuse ? 0x800 : 0));
-}
-
-// --- 1994+ frame (:1679-2261) -----------------------------------------------------------------
-void scan94(Scan &s, DcsFrameIndex &fi)
-{
-    const DcsLdsTables &T = dcsTables().lds;
-    const uint16_t *trie94 = dcsTables().trie94;
-    const uint8_t *hdr = s.header;
-    const bool type1 = (hdr[0] & 0x80) != 0;
-    const bool sub0 = ((hdr[1] | hdr[2]) & 0x80) == 0;
-    const uint32_t frameStart = s.b.bitPos();
-
-    // Type 1 indexes its pre-adjust map with the previous frame's codes of bands 0..2 (:1744-1773)
-    if (type1)
-    {
-        for (int i = 0 ; i < 3 ; ++i)
-            if (s.bandType[i] > 15) { fatal(s); return; }
-        const uint8_t *map = T.preAdj94 + (sub0 ? 0 : 16);
-        fi.preAdj = static_cast<uint16_t>(map[s.bandType[0]] | (map[s.bandType[1]] << 4) | (map[s.bandType[2]] << 8));
-    }
-
-    // frame header: one delta code per populated band (:1780-1834)
-    for (int i = 0 ; i < s.nBands ; ++i)
-        s.bandType[i] = static_cast<uint16_t>(s.bandType[i] + readVlc(s.b, trie94) - 16);
-    fi.hdrBits = static_cast<uint16_t>(s.b.bitPos() - frameStart);
-    for (int i = 0 ; i < 16 ; ++i)
-        fi.bandType[i] = static_cast<uint8_t>(s.bandType[i] > 255 ? 255 : s.bandType[i]);
-
-    int outIdx = 1;
-    for (int band = 0 ; band < s.nBands ; ++band)
-    {
-        putSplit(fi, band, frameStart, s, outIdx);
-        const int hb = hdr[band] & 0x7F;
-        int count = band == 0 ? 7 : band == 1 ? 8 : band == 15 ? 32 : 16;      // :1848-1850
-        int inc = 1;
-        if (hb & 0x40) { count /= 2; inc = 2; }
-        int code = s.bandType[band];
-        if (code == 0)
-        {
-            outIdx += count;                            // the halved count (:1886)
-            continue;
-        }
-        if (type1)
-        {
-            if (code > 15) { fatal(s); return; }
-            code = T.xlat94[(band < 3 ? 0 : band < 6 ? 16 : 32) + code] & 0xFF;
-        }
-        if (code > 16) { fatal(s); return; }
-        outIdx += count * inc;
-        if (code == 0)
-        {
-            s.err |= DCS_FRAME_STOP;                    // :1985-1991, consumes nothing
-        }
-        else if (code <= 6)
-        {
-            const int maxBits = T.cbInfo[code] & 0xF;
-            const uint16_t *book = T.cb94 + (T.cbInfo[code] >> 4);
-            for (int i = count ; i != 0 ; --i)
-            {
-                const uint32_t e = book[s.b.peek(maxBits)];
-                s.b.get(static_cast<int>(e >> 8));
-                if (e & 0x80)
-                {
-                    if (i >= 2) --i;
-                    else { s.err |= DCS_FRAME_STOP; i = 1; }        // :2213-2218
-                }
-            }
-        }
-        else
-        {
-            for (int i = 0 ; i < count ; ++i)
-                s.b.get(code);
-        }
-    }
-}
-
-// --- 1993 frame, Type 0 and OS93b Type 1 (:2293-2615) --------------------------------------------
-void scan93(Scan &s, DcsFrameIndex &fi)
-{
-    const DcsLdsTables &T = dcsTables().lds;
-    const bool type1 = (s.header[0] & 0x80) != 0;
-    const uint32_t frameStart = s.b.bitPos();
-    bool first = true, reuse = false;
-    int code = 0;
-    int subType = type1 ? 0 : 2;
-    uint32_t prv = 0, prvDelta = 0;
-    int outIdx = 1;
-
-    for (int i = 0 ; i < 16 ; ++i)
-        fi.bandType[i] = static_cast<uint8_t>(s.bandType[i] > 255 ? 255 : s.bandType[i]);
-
-    for (int band = 0 ; band < s.nBands ; ++band)
-    {
-        putSplit(fi, band, frameStart, s, outIdx, prv, prvDelta, subType, reuse);
-        const int hb = s.header[band] & 0x7F;
-        const bool strided = (hb >> 6) != 0;
-        int nSamples, inc = 1, fixup = 0, stride;
-        if (!type1)
-        {
-            nSamples = 16;
-            if (!strided) stride = 16;
-            else { ++outIdx; inc = 2; fixup = -1; stride = 31; }
-        }
-        else
-        {
-            if (!strided) nSamples = stride = first ? 15 : 16;
-            else { inc = 2; nSamples = stride = 8; }
-        }
-
-        if (reuse)
-            reuse = s.b.get(1) != 0;
-        if (!reuse)
-        {
-            if (!type1)
-            {
-                if (s.b.get(1))
-                    subType = s.b.get(1) ? (subType + 1) % 3 : (subType + 2) % 3;   // :2402-2414
-                code = static_cast<int>(s.b.get(4));
-            }
-            else
-            {
-                int v = readVlc(s.b, T.trie93);
-                if (v < 0x1E)
-                    v -= 0x0F;                                      // :2668-2681
-                else
-                {
-                    v -= 0x2E;
-                    subType = subType != 0 ? 0 : 1;
-                }
-                s.bandType[band] = static_cast<uint16_t>(s.bandType[band] + v);
-                code = s.bandType[band];
-            }
-        }
-
-        if (code == 0)
-        {
-            reuse = true;                                           // :2455
-            if (subType == 0) { outIdx += stride; prv = 0; prvDelta = 0; }
-            else if (subType == 1) { prvDelta = 0; outIdx += nSamples * inc + fixup; }
-            else
-            {
-                for (int i = 0 ; i < nSamples ; ++i)
-                    prv = (prv + prvDelta) & 0xFFFF;
-                outIdx += nSamples * inc + fixup;
-            }
-        }
-        else
-        {
-            const int width = code + (type1 ? 0 : 1);
-            if (width > 16) { fatal(s); return; }
-            // the sample values are needed only for the carried (prv, prvDelta) pair (:2565-2599)
-            uint32_t last = 0, last2 = 0;
-            for (int i = 0 ; i < nSamples ; ++i)
-            {
-                uint32_t in = s.b.get(width);
-                if (in & (1u << (width - 1)))
-                    in |= 0xFFFFFFFFu << width;
-                in &= 0xFFFF;
-                if (subType == 0) { last2 = last; last = in; }
-                else
-                {
-                    prvDelta = subType == 1 ? in : ((prvDelta + in) & 0xFFFF);
-                    prv = (prv + prvDelta) & 0xFFFF;
-                }
-            }
-            if (subType == 0)
-            {
-                prv = last;
-                prvDelta = (last - last2) & 0xFFFF;
-            }
-            outIdx += nSamples * inc + fixup;
-        }
-        first = false;
-    }
-}
-
-// --- OS93a Type 1 frame (:2831-3032) ---------------------------------------------------------------
-void scan93a(Scan &s)
-{
-    const DcsLdsTables &T = dcsTables().lds;
-    const int hb = s.header[0];
-    const uint16_t *bbBook = &T.bandBits93a[(hb & 0x60) >> 1];
-    const int numBands = hb & 0x1F;
-
-    for (int band = 0 ; band < numBands ; ++band)
-    {
-        if (band >= 18) { fatal(s); return; }
-        const uint32_t e = bbBook[s.b.peek(4)];
-        s.b.get(static_cast<int>(e >> 8));
-        const int bandBits = static_cast<int>(e & 0xFF);
-        if (bandBits == 0xFF)
-            break;
-        if (bandBits == 0)
-            continue;
-        uint32_t sc = T.scaleCb93a[s.b.peek(4)];
-        s.b.get(static_cast<int>((sc >> 8) & 0xF));
-        if ((sc & 0xFF) == 0xFF)
-        {
-            sc = T.scaleCb93a[((sc >> 12) << 4) + s.b.peek(4)];
-            s.b.get(static_cast<int>((sc >> 8) & 0xF) - 4);
-        }
-        for (int i = 0 ; i < T.inputs93a[band] ; ++i)
-            s.b.get(bandBits);
-    }
-}
 
 }   // namespace
 
@@ -287,80 +36,148 @@ extern "C" DcsStatus dcs_index_stream(DcsOsVersion os, const uint8_t *stream, si
 {
     if (stream == nullptr || len < 3 || os < DCS_OS93A || os > DCS_OS95 || (out == nullptr && cap != 0))
         return DCS_ERR_INVALID_ARG;
-
-    Scan s;
-    s.b.data = stream;
-    s.b.len = len;
-
-    // container (InitChannelStream :1433-1463, InitStreamPlayback :1595-1641)
-    const int nFrames = (stream[0] << 8) | stream[1];
-    const bool typeBit = (stream[2] & 0x80) != 0;
-    const int hdrLen = (os == DCS_OS93A && typeBit) ? 1 : 16;
-    memset(s.header, 0, sizeof(s.header));
-    for (int i = 0 ; i < hdrLen ; ++i)
-        s.header[i] = static_cast<uint8_t>(s.b.byteAt(2 + static_cast<size_t>(i)));
-    memset(s.bandType, 0, sizeof(s.bandType));
-    s.b.payOff = s.b.p = 2 + static_cast<size_t>(hdrLen);
-    if (os == DCS_OS93A && typeBit)
-        s.nBands = s.header[0] & 0x1F;
-    else
-        while (s.nBands < 16 && (s.header[s.nBands] & 0x7F) != 0x7F)
-            ++s.nBands;
-
-    int format;
-    if (os == DCS_OS93A)
-        format = typeBit ? DCS_FMT_93A_T1 : DCS_FMT_93_T0;
-    else if (os == DCS_OS93B)
-        format = typeBit ? DCS_FMT_93B_T1 : DCS_FMT_93_T0;
-    else if (!typeBit)
-        format = DCS_FMT_94_T0;
-    else
-        format = (((s.header[1] | s.header[2]) & 0x80) == 0) ? DCS_FMT_94_T1_S0 : DCS_FMT_94_T1_S3;
-
-    DcsStreamInfo si;
-    memset(&si, 0, sizeof(si));
-    si.nFrames = nFrames;
-    si.formatType = typeBit ? 1 : 0;
-    if (os == DCS_OS94 || os == DCS_OS95)       // sic: GetStreamInfo tests header[1] twice (:1517)
-        si.formatSubType = ((s.header[1] & 0x80) >> 6) | ((s.header[1] & 0x80) >> 7);
-    memcpy(si.header, s.header, 16);
-    si.format = format;
-    si.hdrLen = hdrLen;
-
-    DcsStatus status = DCS_OK;
-    int valid = 0;
-    for (int f = 0 ; f < nFrames ; ++f)
-    {
-        DcsFrameIndex fi;
-        memset(&fi, 0, sizeof(fi));
-        fi.bitOff = s.b.bitPos();
-        fi.nBands = static_cast<uint8_t>(s.nBands);
-        s.err = 0;
-        switch (format)
-        {
-        case DCS_FMT_93_T0:
-        case DCS_FMT_93B_T1: scan93(s, fi); break;
-        case DCS_FMT_93A_T1: scan93a(s); break;
-        default:             scan94(s, fi); break;
-        }
-        fi.nBits = static_cast<uint16_t>(s.b.bitPos() - fi.bitOff);
-        fi.flags = static_cast<uint8_t>((s.err << 4) | ((s.err != 0 || format == DCS_FMT_93A_T1) ? DCS_IDX_SERIAL : 0));
-        if (static_cast<uint32_t>(valid) < cap)
-            out[valid] = fi;
-        else if (out != nullptr || cap != 0)
-            status = DCS_ERR_CAPACITY;
-        ++valid;
-        si.payloadBits = s.b.bitPos();
-        if (s.err != 0)
-            break;                  // the reference stops the channel on the next tick (:95-116)
-    }
-    si.nValidFrames = valid;
-    si.nBytes = static_cast<int32_t>(s.b.p);
-    if (out == nullptr && cap == 0)
-        status = DCS_OK;
+    DcsBits<HostFetch> reader{ HostFetch{ stream, len } };
+    const DcsScanTables tabs{ &dcsTables().lds, dcsTables().trie94 };
+    ArraySink sink{ out, cap };
+    DcsScanMem mem;
+    const DcsStreamInfo si = dcsScanStream(static_cast<int>(os), reader, tabs, &mem, sink);
     if (info != nullptr)
         *info = si;
-    if (nFrames == 0)
+    if (si.nFrames == 0)
         return DCS_ERR_BAD_STREAM;
-    return status;
+    if (out == nullptr && cap == 0)
+        return DCS_OK;
+    return sink.overflow ? DCS_ERR_CAPACITY : DCS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Many streams at once.  The worker threads are created on first use and kept (spawning a thread costs
+// about as much as indexing a short stream); the pool object is deliberately never destroyed, so nothing
+// joins or tears down at process exit.  Streams are handed out through an atomic counter.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+class IndexPool
+{
+public:
+    static IndexPool &get()
+    {
+        static IndexPool *pool = new IndexPool;
+        return *pool;
+    }
+
+    // run fn(k) for k in [0, n) on up to `threads` threads (the caller is one of them)
+    void run(uint32_t n, int threads, const std::function<void(uint32_t)> &fn)
+    {
+        std::lock_guard<std::mutex> serial(runMutex);           // one parallel region at a time
+        const int helpers = threads - 1;
+        grow(helpers);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = &fn;
+            total = n;
+            next.store(0);
+            wanted = helpers;
+            running = helpers;
+            ++generation;
+        }
+        cv.notify_all();
+        drain(fn, n);
+        std::unique_lock<std::mutex> lk(m);
+        done.wait(lk, [&] { return running == 0; });
+        job = nullptr;
+    }
+
+private:
+    void drain(const std::function<void(uint32_t)> &fn, uint32_t n)
+    {
+        for (uint32_t k = next.fetch_add(1) ; k < n ; k = next.fetch_add(1))
+            fn(k);
+    }
+    void grow(int helpers)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        while (static_cast<int>(nWorkers) < helpers)
+        {
+            const int id = static_cast<int>(nWorkers++);
+            std::thread([this, id] { worker(id); }).detach();
+        }
+    }
+    void worker(int id)
+    {
+        uint64_t seen = 0;
+        for (;;)
+        {
+            const std::function<void(uint32_t)> *fn;
+            uint32_t n;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return generation != seen; });
+                seen = generation;
+                if (id >= wanted)
+                    continue;               // this region uses fewer threads
+                fn = job;
+                n = total;
+            }
+            drain(*fn, n);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (--running == 0)
+                    done.notify_one();
+            }
+        }
+    }
+
+    std::mutex runMutex, m;
+    std::condition_variable cv, done;
+    const std::function<void(uint32_t)> *job = nullptr;
+    std::atomic<uint32_t> next{ 0 };
+    uint32_t total = 0;
+    uint64_t generation = 0;
+    int wanted = 0, running = 0;
+    size_t nWorkers = 0;
+};
+
+}   // namespace
+
+// Stream k's records go to out + firstRecord[k]; it writes at most nFrames(k) of them (the U16 prefix
+// of the stream).  nThreads 0 = the hardware threads, at most 64 and at most one per stream.
+extern "C" DcsStatus dcs_index_streams(const DcsStreamRef *streams, uint32_t nStreams, int nThreads,
+                                       DcsFrameIndex *out, const uint64_t *firstRecord, DcsStreamInfo *infos)
+{
+    if (streams == nullptr || out == nullptr || firstRecord == nullptr || infos == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    if (nStreams == 0)
+        return DCS_OK;
+    if (nThreads <= 0)
+    {
+        nThreads = static_cast<int>(std::thread::hardware_concurrency());
+        if (nThreads > 64) nThreads = 64;
+    }
+    if (nThreads < 1) nThreads = 1;
+    if (nThreads > 256) nThreads = 256;
+    if (static_cast<uint32_t>(nThreads) > nStreams) nThreads = static_cast<int>(nStreams);
+    std::atomic<int> firstError{ DCS_OK };
+    const std::function<void(uint32_t)> one = [&](uint32_t k) {
+        const DcsStreamRef &sr = streams[k];
+        DcsStatus st = DCS_ERR_INVALID_ARG;
+        if (sr.data != nullptr && sr.len >= 3)
+        {
+            const uint32_t nf = (static_cast<uint32_t>(sr.data[0]) << 8) | sr.data[1];
+            st = dcs_index_stream(static_cast<DcsOsVersion>(sr.os), sr.data, sr.len, out + firstRecord[k], nf, &infos[k]);
+            if (st == DCS_ERR_BAD_STREAM)
+                st = DCS_OK;                // reported through infos[k].nFrames == 0
+        }
+        if (st != DCS_OK)
+        {
+            int expected = DCS_OK;
+            firstError.compare_exchange_strong(expected, st);
+        }
+    };
+    if (nThreads == 1)
+        for (uint32_t k = 0 ; k < nStreams ; ++k)
+            one(k);
+    else
+        IndexPool::get().run(nStreams, nThreads, one);
+    return static_cast<DcsStatus>(firstError.load());
 }

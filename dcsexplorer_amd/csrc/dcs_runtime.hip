@@ -10,6 +10,7 @@
 #include <new>
 #include "dcs_common.h"
 #include "dcs_kernels.hip.h"
+#include "dcs_scan.h"
 
 struct DcsCtx
 {
@@ -19,6 +20,15 @@ struct DcsCtx
     int fpwOverride = 0;
     int numCUs = 256;
     std::string lastError;
+    // inputs of the last dcs_index_streams_gpu call, resident for dcs_index_streams_gpu_time
+    uint32_t *dIdxBlob = nullptr;
+    DcsStreamLoc *dIdxLocs = nullptr;
+    DcsFrameIndex *dIdxOut = nullptr;
+    DcsStreamInfo *dIdxInfos = nullptr;
+    size_t idxBlobLen = 0, idxBlobDw = 0;
+    uint32_t idxStreams = 0;
+    uint64_t idxCap = 0;
+    int idxLanes = 1;
 };
 
 struct DcsBatch
@@ -129,6 +139,10 @@ extern "C" void dcs_ctx_destroy(DcsCtx *ctx)
         return;
     (void)hipSetDevice(ctx->device);
     if (ctx->dTables) (void)hipFree(ctx->dTables);
+    if (ctx->dIdxBlob) (void)hipFree(ctx->dIdxBlob);
+    if (ctx->dIdxLocs) (void)hipFree(ctx->dIdxLocs);
+    if (ctx->dIdxOut) (void)hipFree(ctx->dIdxOut);
+    if (ctx->dIdxInfos) (void)hipFree(ctx->dIdxInfos);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -378,4 +392,224 @@ extern "C" DcsStatus dcs_decode_batch(DcsCtx *ctx,
         st = dcs_batch_download(b, pcmOut, errOut, tailsOut);
     dcs_batch_destroy(b);
     return st;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Index kernel: the walker of dcs_scan.h with one lane per stream.  The walk is serial inside a stream
+// (each frame starts where the last one ended), so the parallelism is across streams only; `lanes`
+// active lanes per wavefront spread few streams over many CUs instead of packing them into divergent
+// waves.  Stream bytes are fetched a dword at a time; the small code tables sit in LDS.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+// Device-side reader of the walker: a 64-bit MSB-first window refilled a dword at a time, the next
+// dwords prefetched.  The reference reader's byte pointer (what StreamInfo.nBytes reports, see DcsBits in
+// dcs_scan.h) is not emulated byte by byte but computed: Peek(n) at bit position B leaves the pointer
+// at floor((B + n) / 8) + 1 bytes into the payload at least, so the pointer after the walk is the
+// maximum of that over every read.
+struct DevBits
+{
+    const uint32_t *blobDw;
+    size_t nDw;                 // dwords allocated behind blobDw
+    size_t base;                // byte offset of the stream in the blob
+    size_t len;                 // stream bytes; bytes past it read as zero
+    size_t payOff = 0;
+    uint64_t win = 0;           // unread bits, MSB first
+    int have = 0;               // valid bits in win
+    uint32_t pos = 0;           // payload bits consumed
+    uint32_t hi = 0;            // max over reads of (pos + n)
+    bool any = false;
+    size_t nextDw = 0;          // dword index of q0
+    uint32_t q0 = 0, q1 = 0;    // prefetched raw dwords
+
+    __device__ uint32_t rawAt(size_t w) const { return w < nDw ? blobDw[w] : 0u; }
+    __device__ uint32_t byteAt(size_t i) const
+    {
+        if (i >= len)
+            return 0;
+        const size_t a = base + i;
+        return (rawAt(a >> 2) >> ((a & 3) * 8)) & 0xFF;
+    }
+    // dword w of the blob as 32 MSB-first stream bits, bytes outside [base, base+len) zeroed
+    __device__ uint32_t streamBits(size_t w, uint32_t raw) const
+    {
+        const size_t lo = w * 4;
+        if (lo + 4 > base + len)
+        {
+            const size_t end = base + len;
+            const uint32_t keep = lo >= end ? 0u : static_cast<uint32_t>(end - lo);     // 0..3 bytes
+            raw &= keep == 0 ? 0u : (0xFFFFFFFFu >> (32 - 8 * keep));
+        }
+        return __builtin_bswap32(raw);
+    }
+    __device__ void setPayload(size_t off)
+    {
+        payOff = off;
+        const size_t a = base + off;
+        const size_t w = a >> 2;
+        const uint32_t skip = static_cast<uint32_t>(a & 3) * 8;
+        win = static_cast<uint64_t>(streamBits(w, rawAt(w))) << (32 + skip);
+        have = 32 - static_cast<int>(skip);
+        nextDw = w + 1;
+        q0 = rawAt(nextDw);
+        q1 = rawAt(nextDw + 1);
+        pos = 0; hi = 0; any = false;
+    }
+    __device__ uint32_t peek(int n)
+    {
+        any = true;
+        const uint32_t reach = pos + static_cast<uint32_t>(n);
+        hi = reach > hi ? reach : hi;
+        if (have < n)
+        {
+            win |= static_cast<uint64_t>(streamBits(nextDw, q0)) << (32 - have);
+            have += 32;
+            ++nextDw;
+            q0 = q1;
+            q1 = rawAt(nextDw + 1);
+        }
+        return n == 0 ? 0u : static_cast<uint32_t>(win >> (64 - n));
+    }
+    __device__ uint32_t get(int n)
+    {
+        const uint32_t r = peek(n);
+        win <<= n;
+        have -= n;
+        pos += static_cast<uint32_t>(n);
+        return r;
+    }
+    __device__ uint32_t bitPos() const { return pos; }
+    __device__ size_t bytesFetched() const { return any ? payOff + (hi >> 3) + 1 : payOff; }
+};
+
+struct DevSink
+{
+    DcsFrameIndex *out;
+    uint32_t cap;
+    __device__ void operator()(uint32_t f, const DcsFrameIndex &fi)
+    {
+        if (f < cap)
+            out[f] = fi;
+    }
+};
+
+__global__ __launch_bounds__(64) void dcsIndexKernel(const uint32_t *blobDw, size_t nDw, const DcsStreamLoc *locs,
+                                                      uint32_t nStreams, int lanes, const DcsDevTables *tables,
+                                                      DcsFrameIndex *out, DcsStreamInfo *infos)
+{
+    __shared__ DcsLdsTables T;
+    __shared__ DcsScanMem mem[64];
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tables->lds);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&T);
+        for (uint32_t i = threadIdx.x ; i < sizeof(DcsLdsTables) / 4 ; i += blockDim.x)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) >= lanes)
+        return;
+    const uint32_t k = blockIdx.x * static_cast<uint32_t>(lanes) + threadIdx.x;
+    if (k >= nStreams)
+        return;
+    const DcsStreamLoc loc = locs[k];
+    DevBits reader{ blobDw, nDw, static_cast<size_t>(loc.off), static_cast<size_t>(loc.len) };
+    const uint32_t nf = (reader.byteAt(0) << 8) | reader.byteAt(1);
+    DevSink sink{ out + loc.firstRecord, nf };
+    const DcsScanTables tabs{ &T, tables->trie94 };
+    infos[k] = dcsScanStream(loc.os, reader, tabs, &mem[threadIdx.x], sink);
+}
+
+}   // namespace
+
+static hipError_t launchIndex(DcsCtx *ctx)
+{
+    const uint32_t lanes = static_cast<uint32_t>(ctx->idxLanes);
+    const uint32_t blocks = (ctx->idxStreams + lanes - 1) / lanes;
+    hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), 0, ctx->stream, ctx->dIdxBlob, ctx->idxBlobDw, ctx->dIdxLocs,
+                       ctx->idxStreams, ctx->idxLanes, ctx->dTables, ctx->dIdxOut, ctx->dIdxInfos);
+    return hipGetLastError();
+}
+
+extern "C" DcsStatus dcs_index_streams_gpu(DcsCtx *ctx, const uint8_t *blob, size_t blobLen,
+                                           const DcsStreamLoc *streams, uint32_t nStreams,
+                                           DcsFrameIndex *out, uint64_t outCap, DcsStreamInfo *infos)
+{
+    if (ctx == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    if (blob == nullptr || streams == nullptr || nStreams == 0 || out == nullptr || infos == nullptr)
+    {
+        ctx->lastError = "dcs_index_streams_gpu: null argument or no streams";
+        return DCS_ERR_INVALID_ARG;
+    }
+    // every stream must lie in the blob and its records (at most its U16 frame count) in `out`
+    for (uint32_t k = 0 ; k < nStreams ; ++k)
+    {
+        const DcsStreamLoc &l = streams[k];
+        if (l.len < 3 || l.off > blobLen || l.len > blobLen - l.off || l.os < DCS_OS93A || l.os > DCS_OS95)
+        {
+            ctx->lastError = "dcs_index_streams_gpu: stream " + std::to_string(k) + " outside the blob or bad OS version";
+            return DCS_ERR_INVALID_ARG;
+        }
+        const uint64_t nf = (static_cast<uint64_t>(blob[l.off]) << 8) | blob[l.off + 1];
+        if (l.firstRecord > outCap || nf > outCap - l.firstRecord)
+        {
+            ctx->lastError = "dcs_index_streams_gpu: records of stream " + std::to_string(k) + " do not fit in out";
+            return DCS_ERR_CAPACITY;
+        }
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (void *p : { static_cast<void *>(ctx->dIdxBlob), static_cast<void *>(ctx->dIdxLocs),
+                     static_cast<void *>(ctx->dIdxOut), static_cast<void *>(ctx->dIdxInfos) })
+        if (p) (void)hipFree(p);
+    ctx->dIdxBlob = nullptr; ctx->dIdxLocs = nullptr; ctx->dIdxOut = nullptr; ctx->dIdxInfos = nullptr;
+    ctx->idxStreams = 0;
+    const size_t blobAlloc = (blobLen + 3 + 4) & ~size_t(3);
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dIdxBlob), blobAlloc));
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dIdxLocs), sizeof(DcsStreamLoc) * nStreams));
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dIdxOut), sizeof(DcsFrameIndex) * (outCap ? outCap : 1)));
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dIdxInfos), sizeof(DcsStreamInfo) * nStreams));
+    HIPCHK(ctx, hipMemsetAsync(reinterpret_cast<uint8_t *>(ctx->dIdxBlob) + (blobAlloc - 8), 0, 8, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dIdxBlob, blob, blobLen, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dIdxLocs, streams, sizeof(DcsStreamLoc) * nStreams, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->dIdxOut, 0, sizeof(DcsFrameIndex) * (outCap ? outCap : 1), ctx->stream));
+    ctx->idxBlobLen = blobLen;
+    ctx->idxBlobDw = blobAlloc / 4;
+    ctx->idxStreams = nStreams;
+    ctx->idxCap = outCap;
+    // few streams: one lane per wave on as many CUs as possible; many: fill the waves
+    const uint32_t wavesWanted = static_cast<uint32_t>(ctx->numCUs) * 8;
+    uint32_t lanes = (nStreams + wavesWanted - 1) / wavesWanted;
+    ctx->idxLanes = static_cast<int>(lanes < 1 ? 1 : lanes > 64 ? 64 : lanes);
+    HIPCHK(ctx, launchIndex(ctx));
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->dIdxOut, sizeof(DcsFrameIndex) * outCap, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(infos, ctx->dIdxInfos, sizeof(DcsStreamInfo) * nStreams, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_index_streams_gpu_time(DcsCtx *ctx, int iters, float *avgMs)
+{
+    if (ctx == nullptr || avgMs == nullptr || iters < 1)
+        return DCS_ERR_INVALID_ARG;
+    if (ctx->idxStreams == 0)
+    {
+        ctx->lastError = "dcs_index_streams_gpu_time: no resident index inputs";
+        return DCS_ERR_INVALID_ARG;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    for (int i = 0 ; i < iters ; ++i)
+        HIPCHK(ctx, launchIndex(ctx));
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avgMs = ms / static_cast<float>(iters);
+    return DCS_OK;
 }

@@ -19,29 +19,43 @@ struct Built
 
 DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, Built &B, bool countOnly)
 {
-    std::vector<DcsFrameIndex> idx;
     std::vector<uint16_t> mm;
     std::vector<uint8_t> vs;
-    uint64_t total = 0;
+    uint64_t total = 0, totalSrc = 0;
+    std::vector<uint64_t> firstRecord(nStreams);
     for (uint32_t k = 0 ; k < nStreams ; ++k)
     {
         const DcsStreamRef &sr = streams[k];
         if (sr.data == nullptr || sr.len < 3 || sr.os < DCS_OS93A || sr.os > DCS_OS95)
             return DCS_ERR_INVALID_ARG;
-        const DcsOsVersion os = static_cast<DcsOsVersion>(sr.os);
         const uint32_t nFrames = (static_cast<uint32_t>(sr.data[0]) << 8) | sr.data[1];
         if (nFrames == 0)
             return DCS_ERR_BAD_STREAM;
         B.firstJob.push_back(static_cast<uint32_t>(total));
+        firstRecord[k] = totalSrc;
         total += nFrames + extraFrames;
-        if (countOnly)
-            continue;
+        totalSrc += nFrames;
+    }
+    B.firstJob.push_back(static_cast<uint32_t>(total));
+    if (countOnly)
+        return DCS_OK;
 
-        idx.resize(nFrames);
-        DcsStreamInfo info;
-        DcsStatus st = dcs_index_stream(os, sr.data, sr.len, idx.data(), nFrames, &info);
-        if (st != DCS_OK)
-            return st;
+    // the index pass over all streams, on the host worker pool (dcs_index.cpp)
+    std::vector<DcsFrameIndex> allIdx(totalSrc);
+    std::vector<DcsStreamInfo> infos(nStreams);
+    DcsStatus st = dcs_index_streams(streams, nStreams, 0, allIdx.data(), firstRecord.data(), infos.data());
+    if (st != DCS_OK)
+        return st;
+    B.jobs.reserve(total);
+    B.srcs.reserve(totalSrc);
+
+    for (uint32_t k = 0 ; k < nStreams ; ++k)
+    {
+        const DcsStreamRef &sr = streams[k];
+        const DcsOsVersion os = static_cast<DcsOsVersion>(sr.os);
+        const uint32_t nFrames = (static_cast<uint32_t>(sr.data[0]) << 8) | sr.data[1];
+        const DcsFrameIndex *idx = allIdx.data() + firstRecord[k];
+        const DcsStreamInfo &info = infos[k];
         mm.resize(nFrames); vs.resize(nFrames);
         st = dcs_stream_params(os, sr.volume, sr.level, sr.channelVolume, nFrames, mm.data(), vs.data());
         if (st != DCS_OK)
@@ -85,7 +99,6 @@ DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t 
             B.jobs.push_back(jb);
         }
     }
-    B.firstJob.push_back(static_cast<uint32_t>(total));
     return DCS_OK;
 }
 

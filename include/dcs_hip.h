@@ -246,6 +246,33 @@ DcsStatus dcs_count_stream_frames(const DcsStreamRef *streams, uint32_t nStreams
                                   uint32_t extraFrames, uint64_t *nFramesOut);
 
 /* ------------------------------------------------------------------------------------------------
+ * Index many streams at once: on `nThreads` host threads (0 = all hardware threads), or on the GPU with
+ * one lane per stream (dcs_index_streams_gpu; the streams are given as offsets into one blob, which is
+ * uploaded, walked by the index kernel and the records downloaded).  Stream k's records go to
+ * out + firstRecord(k), at most nFrames(k) of them (nFrames = the stream's U16 prefix); infos[k] receives
+ * its summary.  Both run the same walker (csrc/dcs_scan.h) and return identical records; they replace
+ * the serial GetStreamInfo walk (DCSDecoderNative.cpp:1486-1537) in front of the decode kernel.
+ */
+DcsStatus dcs_index_streams(const DcsStreamRef *streams, uint32_t nStreams, int nThreads,
+                            DcsFrameIndex *out, const uint64_t *firstRecord, DcsStreamInfo *infos);
+
+typedef struct DcsStreamLoc
+{
+    uint64_t off;                      /* byte offset of the stream (its U16 frame count) in the blob     */
+    uint32_t len;                      /* bytes that belong to the stream (bytes past it read as zero)    */
+    int32_t  os;                       /* DcsOsVersion                                                  */
+    uint64_t firstRecord;              /* where the stream's records go in `out`                        */
+} DcsStreamLoc;
+
+DcsStatus dcs_index_streams_gpu(DcsCtx *ctx, const uint8_t *blob, size_t blobLen,
+                                const DcsStreamLoc *streams, uint32_t nStreams,
+                                DcsFrameIndex *out, uint64_t outCap, DcsStreamInfo *infos);
+/* average milliseconds of the index kernel alone over `iters` launches of the last
+ * dcs_index_streams_gpu call's inputs (kept resident in the context until the next call) */
+DcsStatus dcs_index_streams_gpu_time(DcsCtx *ctx, int iters, float *avgMs);
+
+
+/* ------------------------------------------------------------------------------------------------
  * Synthetic stream writer (seeded, integer-only).  Produces VALID streams
  * of every unpack layout for tests and benchmarks -- the reference ships no audio (Tests/.gitignore).
  */

@@ -157,3 +157,50 @@ def test_batch_is_idempotent_and_resident(gpu_ctx):
     assert np.array_equal(p1, p2) and ms > 0
     assert bt.algorithmic_bytes > 480 * 512
     bt.close()
+
+
+@pytest.mark.gpu
+def test_gpu_index_pass_equals_host_index_pass(gpu_ctx, oracle):
+    """dcs_index_streams_gpu (one lane per stream) must return the host walker's records bit for bit --
+    valid streams of every layout, corrupted streams, ragged lengths -- and decode to the oracle's PCM."""
+    streams = []
+    for i, fmt in enumerate(ALL_FORMATS * 4):
+        s = make_stream(fmt, 3 + 11 * i, seed=4000 + i, profile=i % 4)
+        if i % 6 == 5:
+            s = corrupt(s, seed=i)
+        streams.append((os_for(fmt, i), s, 0xE0, 0x64))
+    got = gpu_ctx.index_streams_gpu(streams)
+    for (os_, data, _, _), (idx, info) in zip(streams, got):
+        want_idx, want_info = D.index_stream(os_, data)
+        assert idx.tobytes() == want_idx.tobytes()
+        assert bytes(info) == bytes(want_info)
+    b = D.build_stream_batch(streams, extra_frames=2, indexer=gpu_ctx.index_streams_gpu)
+    pcm, err = gpu_ctx.decode_batch(b["blob"], b["srcs"], b["jobs"])
+    assert_same(pcm, oracle_streams(oracle, streams, extra=2), "gpu-indexed batch")
+
+
+@pytest.mark.gpu
+def test_gpu_index_pass_many_streams_fills_waves(gpu_ctx):
+    """more streams than one-lane-per-wave placement covers: the lanes-per-wave > 1 path"""
+    streams = []
+    for i in range(5000):
+        fmt = ALL_FORMATS[i % len(ALL_FORMATS)]
+        streams.append((os_for(fmt, i), make_stream(fmt, 1 + i % 3, seed=70000 + i, profile=i % 4), 0xFF, 0x64))
+    got = gpu_ctx.index_streams_gpu(streams)
+    want = D.api.index_streams(streams)
+    for (gi, ginfo), (wi, winfo) in zip(got, want):
+        assert gi.tobytes() == wi.tobytes()
+        assert bytes(ginfo) == bytes(winfo)
+
+
+@pytest.mark.gpu
+def test_gpu_index_pass_rejects_bad_shapes(gpu_ctx):
+    s = make_stream(ALL_FORMATS[0], 4, seed=1)
+    blob, locs = D.api.pack_streams([(os_for(ALL_FORMATS[0]), s, 0xFF, 0x64)])
+    b = np.frombuffer(blob, dtype=np.uint8)
+    out = np.zeros(4, dtype=D.api.INDEX_DTYPE)
+    infos = np.zeros(1, dtype=D.api.INFO_DTYPE)
+    L = gpu_ctx.L
+    bad = locs.copy(); bad["len"] = b.size + 100
+    assert L.dcs_index_streams_gpu(gpu_ctx.h, b.ctypes.data, b.size, bad.ctypes.data, 1, out.ctypes.data, 4, infos.ctypes.data) == D.api.ERR_INVALID_ARG
+    assert L.dcs_index_streams_gpu(gpu_ctx.h, b.ctypes.data, b.size, locs.ctypes.data, 1, out.ctypes.data, 3, infos.ctypes.data) == D.api.ERR_CAPACITY

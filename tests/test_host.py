@@ -125,3 +125,33 @@ def test_workload_builders_shape():
     assert set(np.unique(b["jobs"]["xform"])) == {D.XFORM_93}
     payload = int(b["srcs"]["idx"]["nBits"].astype(np.int64).sum()) // 8
     assert 90 * 4096 < payload < 200 * 4096            # ~125 compressed bytes per frame
+
+
+def _mixed_stream_set():
+    streams = []
+    for i, fmt in enumerate(ALL_FORMATS * 3):
+        s = make_stream(fmt, 5 + 7 * i, seed=900 + i, profile=i % 4)
+        if i % 5 == 4:
+            s = corrupt(s, seed=i)
+        streams.append((os_for(fmt, i), s, 0xFF, 0x64))
+    return streams
+
+
+@pytest.mark.parametrize("threads", [1, 3, 0])
+def test_threaded_indexer_equals_single_stream_indexer(threads):
+    streams = _mixed_stream_set()
+    many = D.api.index_streams(streams, threads=threads)
+    assert len(many) == len(streams)
+    for (os_, data, _, _), (idx, info) in zip(streams, many):
+        want_idx, want_info = D.index_stream(os_, data)
+        assert idx.tobytes() == want_idx.tobytes()
+        assert bytes(info) == bytes(want_info)
+
+
+def test_batch_built_from_threaded_indexer_is_identical():
+    streams = _mixed_stream_set()
+    a = D.build_stream_batch(streams, extra_frames=2)
+    b = D.build_stream_batch(streams, extra_frames=2, indexer=D.api.index_streams)
+    assert a["blob"] == b["blob"]
+    assert a["srcs"].tobytes() == b["srcs"].tobytes()
+    assert a["jobs"].tobytes() == b["jobs"].tobytes()
