@@ -24,7 +24,8 @@
 
 struct DcsLdsTables
 {
-    uint16_t cb94[DCS_CB94_TOTAL];      // entry = nBits<<8 | val   (DCSDecoderNative.cpp:2046-2175 semantics)
+    uint16_t cb94[DCS_CB94_TOTAL];      // entry = sample (signed byte, 0 for the two-zeros code) | nBits<<8 | step<<13
+                                        // (step = samples the code stands for: 1, or 2 for two zeros; .cpp:2046-2175)
     uint16_t cbInfo[8];                 // per sample code 1..6: maxBits | (base offset into cb94)<<4
     uint16_t fast93[256];
     uint16_t trie93[DCS_TRIE93_MAX];
@@ -34,7 +35,7 @@ struct DcsLdsTables
     uint16_t scaleCb93a[80];            // value (0xFF = escape) | nBits<<8 | subTable<<12 (:2938-2959)
     uint8_t  inputs93a[24];             // inputs per band, 18 used (:2865)
     uint16_t scaleMant[4];              // 0x8000, 0x9838, 0xB505, 0xD745 (:1978)
-    uint16_t pad[4];
+    uint16_t raw94[20];                 // two-entry "codebooks" of the fixed-width sample codes 7..16: width<<8 | 1<<13
 };
 
 // per-lane constants of the transform passes (dcs_kernels.hip.h): twiddles and overlap-window entries that

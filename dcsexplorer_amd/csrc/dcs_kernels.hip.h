@@ -98,55 +98,40 @@ __device__ __forceinline__ int calcExp32(uint32_t x)
 struct BitReader
 {
     const uint32_t *p;      // pool dword after `nxt`
-    uint32_t hi, lo;        // valid bits are left-aligned in hi:lo, invalid bits are zero
-    uint32_t nxt;           // the next pool dword, fetched one refill ahead so that its LDS latency is off the
-                            // per-symbol critical path
-    int cnt;                // number of valid bits
+    uint32_t hi, lo;        // the window: the next 32 bits of the stream are ({hi,lo} >> negpos) & 0xFFFFFFFF
+    uint32_t nxt;           // the pool dword after lo, fetched one refill ahead so that its LDS latency is off
+                            // the per-symbol critical path
+    int negpos;             // 0..31: unread bits of the window that lie below the next 32
 
     __device__ __forceinline__ void init(const uint32_t *pool, int bitInDword)
     {
-        hi = pool[0];
-        lo = pool[1];
-        nxt = pool[2];
-        p = pool + 3;
-        cnt = 64;
-        if (bitInDword != 0)
-            skip(bitInDword);
+        hi = 0;
+        lo = pool[0];
+        nxt = pool[1];
+        p = pool + 2;
+        negpos = 0;
+        skip(bitInDword);
     }
-    __device__ __forceinline__ void refill()
+    // the next 32 bits, MSB first
+    __device__ __forceinline__ uint32_t cur() const { return __builtin_amdgcn_alignbit(hi, lo, static_cast<uint32_t>(negpos)); }
+    __device__ __forceinline__ uint32_t peek(int n) const { return cur() >> (32 - n); }     // n in 1..32
+    __device__ __forceinline__ void skip(int n)                                             // n in 0..32
     {
-        if (cnt <= 32)
+        negpos -= n;
+        if (negpos < 0)
         {
-            // lo is empty here; append the prefetched dword right behind the cnt valid bits
-            const uint64_t add = (static_cast<uint64_t>(nxt) << 32) >> cnt;
-            hi |= static_cast<uint32_t>(add >> 32);
-            lo = static_cast<uint32_t>(add);
-            cnt += 32;
+            hi = lo;
+            lo = nxt;
             nxt = *p++;
+            negpos += 32;
         }
     }
-    // n in 1..24, after refill()
-    __device__ __forceinline__ uint32_t peek(int n) const { return hi >> (32 - n); }
-    __device__ __forceinline__ void skip(int n)      // n in 1..31
-    {
-        hi = __builtin_amdgcn_alignbit(hi, lo, static_cast<uint32_t>(32 - n));
-        lo <<= n;
-        cnt -= n;
-    }
-    __device__ __forceinline__ uint32_t get(int n) { refill(); const uint32_t v = peek(n); skip(n); return v; }
-    __device__ __forceinline__ int getSigned(int n)
-    {
-        refill();
-        const int v = static_cast<int>(hi) >> (32 - n);
-        skip(n);
-        return v;
-    }
+    __device__ __forceinline__ uint32_t get(int n) { const uint32_t v = peek(n); skip(n); return v; }
 };
 
 // prefix code via first-level table + trie (dcs_common.h)
 __device__ __forceinline__ int readVlc(BitReader &br, const uint16_t *fast, const uint16_t *trie)
 {
-    br.refill();
     uint32_t e = fast[br.peek(8)];
     if (e & 0x8000)
     {
@@ -198,6 +183,14 @@ __device__ __forceinline__ int byteOf(uint32_t w0, uint32_t w1, uint32_t w2, uin
     const uint32_t lo = (i & 1) ? w1 : w0, hi = (i & 1) ? w3 : w2;
     const uint32_t w = (i & 2) ? hi : lo;
     return static_cast<int>((w >> (8 * (b & 3))) & 0xFFu);
+}
+
+// 24 x 24 -> low 32 bits, always the full-rate instruction
+__device__ __forceinline__ int mul24(int a, int b)
+{
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // the 32-bit "splice" multiply-accumulate of the mixer (.cpp:2244-2250, :2434-2443): low word =
@@ -267,9 +260,10 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
         const int band = Q.bandBase + k;
         int i = 0;                  // symbols still to decode in this band
         int inc = 1;
-        int rawW = 0;               // > 0: fixed-width band of that many bits
-        int shPeek = 0;             // 32 - look-ahead width
-        int ref = 0, scale = 0;
+        bool isRaw = false;         // fixed-width band (sample codes 7..16)
+        int shPeek = 0;             // 32 - look-ahead width (raw: 32 - sample width)
+        int shIdx = 0;              // shift that turns the next 32 bits into the codebook index
+        int scale = 0;
         const uint16_t *book = T->cb94;
         if (k < nb)
         {
@@ -308,56 +302,70 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
                 else
                 {
                     i = count;
-                    int maxBits = code;
                     if (code <= 6)
                     {
                         const uint32_t info = T->cbInfo[code];
-                        maxBits = static_cast<int>(info & 0xF);
+                        shPeek = 32 - static_cast<int>(info & 0xF);
+                        shIdx = shPeek;
                         book = T->cb94 + (info >> 4);
-                        ref = 1 << (code - 1);
                     }
                     else
-                        rawW = code;
-                    shPeek = 32 - maxBits;
+                    {
+                        // fixed-width code: the value is the top `code` bits; its two-entry "codebook"
+                        // (indexed with one bit) supplies the width and the step like a real one
+                        isRaw = true;
+                        shPeek = 32 - code;
+                        shIdx = 31;
+                        book = T->raw94 + 2 * (code - 7);
+                    }
                 }
             }
         }
+        if (!valid)
+            scale = 0;              // after a STOP the band is still parsed, its samples contribute nothing
 
         // ---- symbol loop, branch-free ------------------------------------------------------------------
+        // One codebook entry drives everything: value, code length and how many samples it stands for
+        // (the "two zeros" code, :2200-2212, has value 0 and step 2, so it needs no special store: adding a
+        // zero product leaves the accumulator as it was).  A two-zeros code with one sample left (:2213-2218)
+        // drives i to -1, which is how the error is seen after the loop.
         const BitReader bandStart = br;
-        const int idxStart = outIdx;
+        uint16_t *cell = row + outIdx;
+        uint16_t *const cellStart = cell;
         const int countStart = i;
-        bool bad = false;
+        const int inc2 = inc;
+        const int incBytes = inc * 2;
         while (i > 0)
         {
-            br.refill();
-            const uint32_t pk = br.hi >> shPeek;
-            const uint32_t e = book[rawW ? 0u : pk];
-            const int n = rawW ? rawW : static_cast<int>(e >> 8);
-            const int v = rawW ? (static_cast<int>(br.hi) >> shPeek) : (static_cast<int>(e & 0xFF) - ref);
-            const bool dz = !rawW && (e & 0x80) != 0;           // "two zeros" code (:2200-2212)
-            br.skip(n);
-            bad = bad || (dz && i == 1);                        // no room for the second zero (:2213-2218)
-            const int step = (dz && i >= 2) ? 2 : 1;
-            mixAdd<FIRST>(&row[(dz || !valid) ? kDummyWord : outIdx], __mul24(v, scale), mixMul);
-            outIdx += inc * step;
+            const uint32_t w = br.cur();
+            const uint32_t e = book[w >> shIdx];
+            const int vr = static_cast<int>(w) >> shPeek;
+            const int vh = static_cast<int>(static_cast<int8_t>(e & 0xFF));
+            const int step = static_cast<int>(e >> 13);
+            br.skip(static_cast<int>((e >> 8) & 0x1F));
+            mixAdd<FIRST>(cell, mul24(isRaw ? vr : vh, scale), mixMul);
+            cell = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(cell) + incBytes * step);
             i -= step;
         }
-        if (bad)
+        outIdx += static_cast<int>(cell - cellStart);
+        if (i < 0)
         {
             // the reference zeroes the WHOLE band buffer on this error (:2238-2239): take back what the
             // band already contributed by replaying it.  (Frames with errors are never split.)
+            outIdx -= inc2;                 // the second zero had no room: the band ends where it should
             if (valid)
             {
                 BitReader r2 = bandStart;
-                int kk = idxStart;
+                uint16_t *c2 = cellStart;
                 for (int j = countStart ; j > 1 ; )
                 {
-                    r2.refill();
-                    const uint32_t e = book[r2.hi >> shPeek];
-                    r2.skip(static_cast<int>(e >> 8));
-                    if (e & 0x80) { kk += 2 * inc; j -= 2; }
-                    else { mixSub(&row[kk], __mul24(static_cast<int>(e & 0xFF) - ref, scale), mixMul); kk += inc; --j; }
+                    const uint32_t e = book[r2.cur() >> shIdx];
+                    r2.skip(static_cast<int>((e >> 8) & 0x1F));
+                    const int step = static_cast<int>(e >> 13);
+                    if (step == 1)
+                        mixSub(c2, mul24(static_cast<int>(static_cast<int8_t>(e & 0xFF)), scale), mixMul);
+                    c2 += inc2 * step;
+                    j -= step;
                 }
             }
             valid = false; err |= DCS_FRAME_STOP;
@@ -489,8 +497,7 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
             uint32_t in = 0;
             if (width != 0)
             {
-                br.refill();
-                in = static_cast<uint32_t>(static_cast<int>(br.hi) >> shW);
+                in = static_cast<uint32_t>(static_cast<int>(br.cur()) >> shW);
                 br.skip(width);
             }
             const uint32_t d = in + (prvDelta & m2);
@@ -550,7 +557,6 @@ __device__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *row, BitReader &b
         if (band >= 18) { err |= DCS_FRAME_FATAL | DCS_FRAME_STOP; break; }
         const int numInputs = T->inputs93a[band];
 
-        br.refill();
         const uint32_t e = bbBook[br.peek(4)];
         br.skip(static_cast<int>(e >> 8));
         const int bandBits = static_cast<int>(e & 0xFF);
@@ -562,12 +568,10 @@ __device__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *row, BitReader &b
             continue;
         }
 
-        br.refill();
         uint32_t sc = T->scaleCb93a[br.peek(4)];
         br.skip(static_cast<int>((sc >> 8) & 0xF));
         if ((sc & 0xFF) == 0xFF)
         {
-            br.refill();
             sc = T->scaleCb93a[((sc >> 12) << 4) + br.peek(4)];
             br.skip(static_cast<int>((sc >> 8) & 0xF) - 4);
         }
@@ -965,7 +969,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
     const uint32_t chunk = blockIdx.x * kWavesPerBlock + static_cast<uint32_t>(wave);
     if (chunk < a.nChunks) DCS_STAMP(0);
     constexpr int SUB = subLanes(FPW);              // lanes that unpack one frame together
-    constexpr int BPL = 16 / SUB;                   // header bands per sub-lane
+    static_assert(SUB == 4, "the index pass records three split points per frame");
     const int s = lane % FPW;                       // slot of this lane
     const int q = lane / FPW;                       // which part of the frame it unpacks
     const bool unpacker = q < SUB;
@@ -1131,12 +1135,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
                 Q.nb = (q == 0) ? nBands : 0;
             else
             {
-                Q.bandBase = q * BPL;
-                Q.nb = min(max(nBands - Q.bandBase, 0), BPL);
+                // lane q takes bands [q * bpl, (q + 1) * bpl), bpl = ceil(nBands / 4) (dcsBandsPerLane, dcs_scan.h)
+                const int bpl = nBands <= 4 ? 1 : (nBands + 3) >> 2;
+                Q.bandBase = q * bpl;
+                Q.nb = min(max(nBands - Q.bandBase, 0), bpl);
                 if (q != 0)
                 {
-                    // DcsSplit k = (bandBase / 4) - 1, 8 bytes each, starting at descriptor dword 10
-                    const int k = Q.bandBase / 4 - 1;
+                    // DcsSplit k = q - 1, 8 bytes each, starting at descriptor dword 10
+                    const int k = q - 1;
                     const uint32_t sp0 = k == 0 ? d2.z : k == 1 ? d3.x : d3.z;
                     const uint32_t sp1 = k == 0 ? d2.w : k == 1 ? d3.y : d3.w;
                     relBits = sp0 & 0xFFFFu;

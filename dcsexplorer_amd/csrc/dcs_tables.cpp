@@ -79,13 +79,19 @@ void buildVlc(const DcsVlc (&codes)[N], uint16_t *fast, uint16_t *trie, size_t t
 }
 
 template <size_t N>
-void expandSampleBook(const DcsVlc (&codes)[N], int maxBits, uint16_t *out)
+void expandSampleBook(const DcsVlc (&codes)[N], int maxBits, int ref, uint16_t *out)
 {
+    // every slot consumes at least one sample, so that a kernel loop over a band always terminates
+    for (int i = 0 ; i < (1 << maxBits) ; ++i)
+        out[i] = static_cast<uint16_t>(1 << 13);
     for (const DcsVlc &c : codes)
     {
+        const bool twoZeros = (c.val & 0x80) != 0;
+        const int sample = twoZeros ? 0 : c.val - ref;
+        const uint16_t e = static_cast<uint16_t>((sample & 0xFF) | (c.len << 8) | ((twoZeros ? 2 : 1) << 13));
         int span = 1 << (maxBits - c.len);
         for (int i = 0 ; i < span ; ++i)
-            out[(c.code << (maxBits - c.len)) + i] = static_cast<uint16_t>((c.len << 8) | (c.val & 0xFF));
+            out[(c.code << (maxBits - c.len)) + i] = e;
     }
 }
 
@@ -97,12 +103,14 @@ DcsDevTables build()
     int base = 0;
     uint16_t *cb = t.lds.cb94;
     auto put = [&](int k, auto &codes) {
-        expandSampleBook(codes, maxBits[k], cb + base);
+        expandSampleBook(codes, maxBits[k], 1 << (k - 1), cb + base);
         t.lds.cbInfo[k] = static_cast<uint16_t>((base << 4) | maxBits[k]);
         base += 1 << maxBits[k];
     };
     put(1, kVlc94Sample1); put(2, kVlc94Sample2); put(3, kVlc94Sample3);
     put(4, kVlc94Sample4); put(5, kVlc94Sample5); put(6, kVlc94Sample6);
+    for (int w = 7 ; w <= 16 ; ++w)
+        t.lds.raw94[2 * (w - 7)] = t.lds.raw94[2 * (w - 7) + 1] = static_cast<uint16_t>((w << 8) | (1 << 13));
 
     buildVlc(kVlc94BandTypeDelta, t.fast94, t.trie94, DCS_TRIE94_MAX, [](int v) { return v + 16; });
     buildVlc(kVlc93BandType, t.lds.fast93, t.lds.trie93, DCS_TRIE93_MAX, [](int v) { return v; });

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DCS_ABI_VERSION 2
+#define DCS_ABI_VERSION 3
 #define DCS_FRAME_SAMPLES 240          /* PCM samples per frame (DCSDecoder.h:123: 7.68 ms at 31250 Hz) */
 #define DCS_MAX_CHANNELS 8             /* DCSDecoderNative.h:305 */
 
@@ -74,8 +74,9 @@ typedef enum DcsFormat
  * index or sync word in a DCS stream, a frame's bit offset is only known after decoding every
  * earlier frame (:1715, :2260), and the 1994+/1993b-Type-1 formats delta-code band types (:1833, :2428).
  */
-/* Decoder state at the start of band 4(k+1), k = 0..2: lets four lanes unpack one frame in parallel,
- * one quarter (four header bands) each. */
+/* Decoder state at the start of band (k+1) * bpl, k = 0..2, where bpl = ceil(nBands / 4) (1 when
+ * nBands <= 4): lets four lanes unpack one frame in parallel, bpl header bands each, and keeps all four
+ * busy for streams that populate fewer than 16 bands. */
 typedef struct DcsSplit
 {
     uint16_t bitDelta;                 /* bits from the frame's first bit to the band's first bit         */
