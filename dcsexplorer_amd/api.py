@@ -19,12 +19,12 @@ XFORM_93, XFORM_94 = 0, 1
 # numpy views of the ABI structs (layouts asserted against the library at load time)
 SPLIT_DTYPE = np.dtype([("bitDelta", "<u2"), ("prv", "<u2"), ("prvDelta", "<u2"), ("state", "<u2")])
 INDEX_DTYPE = np.dtype([("bitOff", "<u4"), ("nBits", "<u2"), ("hdrBits", "<u2"), ("bandType", "u1", (16,)),
-                        ("preAdj", "<u2"), ("nBands", "u1"), ("flags", "u1"), ("split", SPLIT_DTYPE, (3,))])
+                        ("preAdj", "<u2"), ("nBands", "u1"), ("flags", "u1"), ("split", SPLIT_DTYPE, (15,))])
 SRC_DTYPE = np.dtype([("streamOff", "<u8"), ("mixMul", "<u2"), ("format", "u1"), ("hdrLen", "u1"),
                       ("idx", INDEX_DTYPE)])
 JOB_DTYPE = np.dtype([("firstSrc", "<u4"), ("nSrc", "u1"), ("volShift", "u1"), ("xform", "u1"), ("flags", "u1"),
                       ("prev", "<u4"), ("reserved", "<u4")])
-assert SRC_DTYPE.itemsize == 64 and JOB_DTYPE.itemsize == 16 and INDEX_DTYPE.itemsize == 52
+assert SRC_DTYPE.itemsize == 160 and JOB_DTYPE.itemsize == 16 and INDEX_DTYPE.itemsize == 148
 IDX_SERIAL = 1
 
 

@@ -39,7 +39,7 @@ constexpr int kRowBytes = 528;          // 256 words + 16 bytes: 16-byte aligned
                                         // with 128-bit accesses), rows of neighbouring frames land on different LDS banks
 
 __host__ __device__ constexpr int poolDwords(int fpw) { return static_cast<int>(dcsPoolCapacity(fpw)); }
-__host__ __device__ constexpr int subLanes(int fpw) { return fpw <= 16 ? 4 : fpw == 32 ? 2 : 1; }   // 8 and 16 are built
+__host__ __device__ constexpr int subLanes(int fpw) { return 64 / fpw; }     // 16, 8 and 4 lanes per frame for fpw 4, 8, 16
 
 // per wavefront: tile rows | tails [fpw][16] i16 | bit pool
 __host__ __device__ constexpr int waveLdsBytes(int fpw) { return fpw * kRowBytes + fpw * 32 + poolDwords(fpw) * 4; }
@@ -490,21 +490,19 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         // ---- main sample loop, branch-free -----------------------------------------------------------
         const uint32_t m2 = subType == 2 ? 0xFFFFu : 0u;        // add the previous delta
         const uint32_t m0 = subType == 0 ? 0u : 0xFFFFu;        // add the previous value
-        const int shW = 32 - width;
+        // width 0 (a ramp: no bits read) rides along with an all-zero mask instead of a branch
+        const int shW = (32 - width) & 31;
+        const uint32_t wMask = width != 0 ? 0xFFFFFFFFu : 0u;
         const bool ran = nS > 0 || quirk;
         for (int i = 0 ; i < nS ; ++i)
         {
-            uint32_t in = 0;
-            if (width != 0)
-            {
-                in = static_cast<uint32_t>(static_cast<int>(br.cur()) >> shW);
-                br.skip(width);
-            }
+            const uint32_t in = static_cast<uint32_t>(static_cast<int>(br.cur() & wMask) >> shW);
+            br.skip(width);
             const uint32_t d = in + (prvDelta & m2);
             const uint32_t p = d + (prv & m0);
             prvDelta = d - (prv & ~m0);
             prv = p;
-            mixAdd<FIRST>(&row[outIdx < 256 ? outIdx : kDummyWord], __mul24(sx16(p), scale), mixMul);
+            mixAdd<FIRST>(&row[outIdx < 256 ? outIdx : kDummyWord], mul24(sx16(p), scale), mixMul);
             outIdx += inc;
         }
         prv &= 0xFFFFu; prvDelta &= 0xFFFFu;
@@ -515,7 +513,7 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         {
             if (quirk)
             {
-                uint32_t low = static_cast<uint32_t>(__mul24(sx16(prv), scale)) & 0xFFFFu;
+                uint32_t low = static_cast<uint32_t>(mul24(sx16(prv), scale)) & 0xFFFFu;
                 const int mulLow = sx16(low);
                 for (int i = 0 ; i < nQ ; ++i, outIdx += inc)
                 {
@@ -969,7 +967,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
     const uint32_t chunk = blockIdx.x * kWavesPerBlock + static_cast<uint32_t>(wave);
     if (chunk < a.nChunks) DCS_STAMP(0);
     constexpr int SUB = subLanes(FPW);              // lanes that unpack one frame together
-    static_assert(SUB == 4, "the index pass records three split points per frame");
+    static_assert(SUB * FPW == 64 && SUB <= 16, "every lane unpacks; a frame has at most 16 split lanes");
     const int s = lane % FPW;                       // slot of this lane
     const int q = lane / FPW;                       // which part of the frame it unpacks
     const bool unpacker = q < SUB;
@@ -1019,11 +1017,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             const bool has = r < myNSrc;
             // the descriptor: four uint4 per lane, identical addresses within a slot's sub-lanes
             const uint4 *sdp = reinterpret_cast<const uint4 *>(&a.srcs[has ? job.firstSrc + r : 0]);
-            uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0, d2 = d0, d3 = d0;
-            if (has) { d0 = sdp[0]; d1 = sdp[1]; d2 = sdp[2]; d3 = sdp[3]; }
+            uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0;
+            uint2 d2 = make_uint2(0, 0);
+            if (has) { d0 = sdp[0]; d1 = sdp[1]; d2 = *reinterpret_cast<const uint2 *>(sdp + 2); }
             // DcsSrcDesc: [0] streamOff lo, [1] streamOff hi, [2] mixMul | format<<16 | hdrLen<<24,
             // idx at byte 12: [3] bitOff, [4] nBits | hdrBits<<16, [5..8] bandType, [9] preAdj | nBands<<16 | flags<<24,
-            // [10..15] split[3]
+            // [10..39] split[15], two dwords each
             const uint64_t streamOff = static_cast<uint64_t>(d0.x) | (static_cast<uint64_t>(d0.y) << 32);
             const uint32_t mixMul = d0.z & 0xFFFFu;
             const int format = static_cast<int>((d0.z >> 16) & 0xFFu);
@@ -1135,16 +1134,16 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
                 Q.nb = (q == 0) ? nBands : 0;
             else
             {
-                // lane q takes bands [q * bpl, (q + 1) * bpl), bpl = ceil(nBands / 4) (dcsBandsPerLane, dcs_scan.h)
-                const int bpl = nBands <= 4 ? 1 : (nBands + 3) >> 2;
+                // lane q takes bands [q * bpl, (q + 1) * bpl), bpl = ceil(nBands / SUB)
+                const int nb16 = min(nBands, 16);
+                const int bpl = max((nb16 + SUB - 1) / SUB, 1);
                 Q.bandBase = q * bpl;
-                Q.nb = min(max(nBands - Q.bandBase, 0), bpl);
-                if (q != 0)
+                Q.nb = min(max(nb16 - Q.bandBase, 0), bpl);
+                if (q != 0 && Q.nb != 0)
                 {
-                    // DcsSplit k = q - 1, 8 bytes each, starting at descriptor dword 10
-                    const int k = q - 1;
-                    const uint32_t sp0 = k == 0 ? d2.z : k == 1 ? d3.x : d3.z;
-                    const uint32_t sp1 = k == 0 ? d2.w : k == 1 ? d3.y : d3.w;
+                    // DcsSplit of band bandBase = split[bandBase - 1], 8 bytes each from descriptor dword 10
+                    const uint2 sp = reinterpret_cast<const uint2 *>(sdp)[5 + Q.bandBase - 1];
+                    const uint32_t sp0 = sp.x, sp1 = sp.y;
                     relBits = sp0 & 0xFFFFu;
                     Q.prv = sp0 >> 16;
                     Q.prvDelta = sp1 & 0xFFFFu;

@@ -93,20 +93,14 @@ DCS_HD inline int dcsReadVlc(R &b, const uint16_t *trie)
 template <class R>
 DCS_HD inline void dcsFatal(DcsScan<R> &s) { s.err |= DCS_FRAME_FATAL | DCS_FRAME_STOP; }
 
-// The split points of a frame: lane q of the four that unpack it together takes header bands
-// [q * bpl, (q + 1) * bpl) with bpl = ceil(nBands / 4), so that streams with fewer than 16 populated bands
-// still keep all four lanes busy.  split[q - 1] is the decoder state at the start of lane q's first band.
-DCS_HD inline int dcsBandsPerLane(int nBands) { return nBands <= 4 ? 1 : (nBands + 3) >> 2; }
-
+// split[band - 1] = the decoder state at the start of `band` (1..15)
 template <class R>
 DCS_HD inline void dcsPutSplit(DcsFrameIndex &fi, int band, uint32_t frameStart, const DcsScan<R> &s, int outIdx,
                                uint32_t prv = 0, uint32_t prvDelta = 0, int subType = 0, bool reuse = false)
 {
-    const int bpl = dcsBandsPerLane(s.nBands);
-    const int q = band / bpl;
-    if (band == 0 || q > 3 || q * bpl != band)
+    if (band < 1 || band > 15)
         return;
-    DcsSplit &sp = fi.split[q - 1];
+    DcsSplit &sp = fi.split[band - 1];
     sp.bitDelta = static_cast<uint16_t>(s.b.bitPos() - frameStart);
     sp.prv = static_cast<uint16_t>(prv);
     sp.prvDelta = static_cast<uint16_t>(prvDelta);

@@ -170,8 +170,8 @@ const DcsDevTables &dcsTables()
 
 static_assert(sizeof(DcsLdsTables) % 16 == 0, "LDS table block must be a multiple of 16 bytes");
 static_assert(sizeof(DcsLaneConsts) == 160 && offsetof(DcsDevTables, lane) % 16 == 0, "lane constants are fetched as uint4");
-static_assert(sizeof(DcsSrcDesc) == 64, "DcsSrcDesc layout");
+static_assert(sizeof(DcsSrcDesc) == 160, "DcsSrcDesc layout");
 static_assert(offsetof(DcsSrcDesc, idx) == 12, "DcsSrcDesc layout");
 static_assert(sizeof(DcsFrameJob) == 16, "DcsFrameJob layout");
-static_assert(sizeof(DcsFrameIndex) == 52, "DcsFrameIndex layout");
+static_assert(sizeof(DcsFrameIndex) == 148 && offsetof(DcsFrameIndex, split) == 28, "DcsFrameIndex layout");
 static_assert(sizeof(DcsSlot) == 16, "DcsSlot layout");

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DCS_ABI_VERSION 3
+#define DCS_ABI_VERSION 4
 #define DCS_FRAME_SAMPLES 240          /* PCM samples per frame (DCSDecoder.h:123: 7.68 ms at 31250 Hz) */
 #define DCS_MAX_CHANNELS 8             /* DCSDecoderNative.h:305 */
 
@@ -74,9 +74,9 @@ typedef enum DcsFormat
  * index or sync word in a DCS stream, a frame's bit offset is only known after decoding every
  * earlier frame (:1715, :2260), and the 1994+/1993b-Type-1 formats delta-code band types (:1833, :2428).
  */
-/* Decoder state at the start of band (k+1) * bpl, k = 0..2, where bpl = ceil(nBands / 4) (1 when
- * nBands <= 4): lets four lanes unpack one frame in parallel, bpl header bands each, and keeps all four
- * busy for streams that populate fewer than 16 bands. */
+/* Decoder state at the start of header band k+1, k = 0..14: lets up to 16 lanes unpack one frame in
+ * parallel.  The kernel gives a frame 4, 8 or 16 lanes (64 / frames-per-wavefront); lane q takes bands
+ * [q * bpl, (q + 1) * bpl) with bpl = ceil(nBands / lanes) and starts from split[q * bpl - 1]. */
 typedef struct DcsSplit
 {
     uint16_t bitDelta;                 /* bits from the frame's first bit to the band's first bit         */
@@ -102,8 +102,8 @@ typedef struct DcsFrameIndex
                                           derived from the PREVIOUS frame's codes (:1771-1773)           */
     uint8_t  nBands;                   /* populated header bands (stream constant)                       */
     uint8_t  flags;                    /* DCS_IDX_SERIAL | DCS_FRAME_* error bits << 4                   */
-    DcsSplit split[3];
-} DcsFrameIndex;                       /* 52 bytes */
+    DcsSplit split[15];
+} DcsFrameIndex;                       /* 148 bytes */
 
 typedef struct DcsStreamInfo           /* DCSDecoderNative::StreamInfo (DCSDecoderNative.h:106-122)     */
 {

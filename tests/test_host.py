@@ -26,7 +26,7 @@ def test_index_pass_matches_oracle_probes(oracle, fmt):
             elif fmt == D.FMT_93B_T1:
                 assert list(idx[f]["bandType"]) == list(probes[f].bandType)
             assert 1 <= idx[f]["nBands"] <= (18 if fmt == D.FMT_93A_T1 else 16)
-            for q in range(3):
+            for q in range(min(int(idx[f]["nBands"]), 16) - 1):
                 sp = idx[f]["split"][q]
                 assert sp["bitDelta"] <= idx[f]["nBits"]
         assert np.all(np.diff(idx["bitOff"].astype(np.int64)) == idx["nBits"][:-1])
