@@ -539,18 +539,17 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
 }
 
 // ------------------------------------------------------------------------------------------------
-// a4: OS93a Type 1 frame (DecoderImpl93a::DecompressFrame, .cpp:2831-3032).  Not split: one lane per frame.
+// a4: OS93a Type 1 frame (DecoderImpl93a::DecompressFrame, .cpp:2831-3032).  A lane takes the bands
+// [bandBase, bandEnd); what it needs from the bands before it -- the previous scale code and whether the
+// frame already ended -- comes from the split record.
 // ------------------------------------------------------------------------------------------------
 __device__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *row, BitReader &br, int hb, uint32_t mixMul,
-                              const uint16_t *pairTable)
+                              const uint16_t *pairTable, int bandBase, int bandEnd, int prvScale, int outIdx)
 {
     const uint16_t *bbBook = &T->bandBits93a[(hb & 0x60) >> 1];
-    const int numBands = hb & 0x1F;
-    int prvScale = 0x1A;
-    int outIdx = 0;
     uint32_t err = 0;
 
-    for (int band = 0 ; band < numBands ; ++band)
+    for (int band = bandBase ; band < bandEnd ; ++band)
     {
         if (band >= 18) { err |= DCS_FRAME_FATAL | DCS_FRAME_STOP; break; }
         const int numInputs = T->inputs93a[band];
@@ -592,7 +591,7 @@ __device__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *row, BitReader &b
             const uint16_t *pair = pairBase + 2 * br.get(bandBits);
             for (int k = 0 ; k < 2 ; ++k, ++outIdx)
             {
-                const int p = __mul24(sx16(pair[k]), sfs);
+                const int p = mul24(sx16(pair[k]), sfs);
                 row[outIdx] = static_cast<uint16_t>(roundHi((static_cast<uint32_t>(row[outIdx]) << 16) + (static_cast<uint32_t>(p) << 1), p));
             }
         }
@@ -1161,7 +1160,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             // every lane enters the unpackers (their symbol loops are wave-convergent); lanes without a
             // source of that family are masked off inside
             const bool is94 = ok && format >= DCS_FMT_94_T0;
-            const bool is93a = ok && format == DCS_FMT_93A_T1 && q == 0;
+            // OS93a Type 1: up to 18 bands, the lane that holds band 15 also takes 16 and 17; a lane whose split
+            // record says the frame ended earlier has nothing to do
+            const bool is93a = ok && format == DCS_FMT_93A_T1 && Q.nb != 0 && !(Q.bandBase != 0 && Q.reuse);
             const bool is93 = ok && format < DCS_FMT_93A_T1;
             if (__any(is94))
                 err |= (r == 0) ? unpack94<true>(T, row, br, Q, format, mixMul, is94)
@@ -1170,7 +1171,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
                 err |= (r == 0) ? unpack93<true>(T, row, br, Q, format, mixMul, is93)
                                 : unpack93<false>(T, row, br, Q, format, mixMul, is93);
             if (is93a)
-                err |= unpack93a(T, row, br, static_cast<int>(Q.h0 & 0xFFu), mixMul, a.tables->pair93a);
+            {
+                const int end = Q.bandBase + Q.nb;
+                err |= unpack93a(T, row, br, static_cast<int>(Q.h0 & 0xFFu), mixMul, a.tables->pair93a, Q.bandBase,
+                                 (end >= 16 && nBands > 16) ? nBands : end,
+                                 Q.bandBase == 0 ? 0x1A : sx16(Q.prv), Q.bandBase == 0 ? 0 : Q.outIdx);
+            }
             waveSync();
         }
 

@@ -5,6 +5,11 @@
 // when a frame's predecessor falls in another chunk it is decoded a second time here as a HALO slot
 // (tail only, no PCM written), which costs 1/fpw extra work and needs no inter-workgroup
 // communication, no second kernel and no extra HBM traffic.
+//
+// Jobs are visited chain by chain (a chain = frames linked through `prev`, i.e. one decoder playing), not
+// in job order: a batch whose job list interleaves many streams frame by frame would otherwise need a
+// halo for every single frame.  Where a frame lands in the plan does not matter, its PCM goes to its job
+// index.
 #include "dcs_common.h"
 #include <vector>
 
@@ -56,7 +61,38 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
     };
     auto inChunk = [&](uint32_t j) { return j < nJobs && stampOf[j] == chunk; };
 
+    // chain order: a job is followed by its first successor; everything else starts a new chain
+    auto linked = [&](uint32_t j) {
+        const uint32_t prev = jobs[j].prev;
+        return prev != DCS_PREV_NONE && (prev & DCS_PREV_EXT) == 0 && prev < nJobs && prev != j;
+    };
+    std::vector<uint32_t> succ(nJobs, 0xFFFFFFFFu);
+    std::vector<uint8_t> follows(nJobs, 0);
     for (uint32_t j = 0 ; j < nJobs ; ++j)
+        if (linked(j) && succ[jobs[j].prev] == 0xFFFFFFFFu)
+        {
+            succ[jobs[j].prev] = j;
+            follows[j] = 1;
+        }
+    std::vector<uint32_t> order;
+    order.reserve(nJobs);
+    for (uint32_t head = 0 ; head < nJobs ; ++head)
+    {
+        if (follows[head])
+            continue;
+        for (uint32_t j = head ; j != 0xFFFFFFFFu ; j = succ[j])
+            order.push_back(j);
+    }
+    // (a cycle of prev links has no head: append whatever was not reached, in job order)
+    if (order.size() != nJobs)
+    {
+        std::vector<uint8_t> seen(nJobs, 0);
+        for (uint32_t j : order) seen[j] = 1;
+        for (uint32_t j = 0 ; j < nJobs ; ++j)
+            if (!seen[j]) order.push_back(j);
+    }
+
+    for (uint32_t j : order)
     {
         const uint32_t prev = jobs[j].prev;
         const bool ext = prev != DCS_PREV_NONE && (prev & DCS_PREV_EXT) != 0;

@@ -162,7 +162,9 @@ static int chooseFpw(const DcsCtx *ctx, uint32_t nJobs)
     if (ctx->fpwOverride != 0)
         return ctx->fpwOverride;
     const uint64_t simds = static_cast<uint64_t>(ctx->numCUs) * 4;
-    return nJobs >= simds * 16 ? 16 : nJobs >= simds * 6 ? 8 : 4;
+    // measured (tools/fpw_sweep.py): while every wavefront of the batch fits on the chip at once (3 per SIMD),
+    // fewer frames per wavefront = more lanes per frame = shorter chains; past that, fewer, fuller wavefronts win
+    return nJobs >= simds * 40 ? 16 : nJobs >= simds * 10 ? 8 : 4;
 }
 
 extern "C" void dcs_batch_destroy(DcsBatch *b)

@@ -284,22 +284,37 @@ DCS_HD void dcsScan93(DcsScan<R> &s, const DcsScanTables &tabs, DcsFrameIndex &f
 }
 
 // --- OS93a Type 1 frame (:2831-3032) ---------------------------------------------------------------
+// Carried from band to band: the bit position and the previous band's scale code (:2962-2975).  A split
+// record holds them in (bitDelta, prv); its "reuse" bit says the frame already ended before this band
+// (the 0xFF band-bits code, :2905-2912).
 template <class R>
-DCS_HD void dcsScan93a(DcsScan<R> &s, const DcsScanTables &tabs)
+DCS_HD void dcsScan93a(DcsScan<R> &s, const DcsScanTables &tabs, DcsFrameIndex &fi)
 {
     const DcsLdsTables &T = *tabs.lds;
     const int hb = s.header[0];
     const uint16_t *bbBook = &T.bandBits93a[(hb & 0x60) >> 1];
     const int numBands = hb & 0x1F;
+    const uint32_t frameStart = s.b.bitPos();
+    int prvScale = 0x1A;
+    int outIdx = 0;
+    bool ended = false;
 
     for (int band = 0 ; band < numBands ; ++band)
     {
+        dcsPutSplit(fi, band, frameStart, s, outIdx, static_cast<uint32_t>(prvScale), 0, 0, ended);
+        if (ended)
+            continue;
         if (band >= 18) { dcsFatal(s); return; }
+        const int numInputs = T.inputs93a[band];
         const uint32_t e = bbBook[s.b.peek(4)];
         s.b.get(static_cast<int>(e >> 8));
         const int bandBits = static_cast<int>(e & 0xFF);
         if (bandBits == 0xFF)
-            break;
+        {
+            ended = true;
+            continue;
+        }
+        outIdx += numInputs * 2;
         if (bandBits == 0)
             continue;
         uint32_t sc = T.scaleCb93a[s.b.peek(4)];
@@ -309,7 +324,11 @@ DCS_HD void dcsScan93a(DcsScan<R> &s, const DcsScanTables &tabs)
             sc = T.scaleCb93a[((sc >> 12) << 4) + s.b.peek(4)];
             s.b.get(static_cast<int>((sc >> 8) & 0xF) - 4);
         }
-        for (int i = 0 ; i < T.inputs93a[band] ; ++i)
+        int scaleCode = prvScale + static_cast<int>(sc & 0xFF) - 1 + bandBits * 2;
+        if (scaleCode > 0x39)
+            scaleCode -= 0x36;
+        prvScale = scaleCode - bandBits * 2;
+        for (int i = 0 ; i < numInputs ; ++i)
             s.b.get(bandBits);
     }
 }
@@ -371,11 +390,11 @@ DCS_HD DcsStreamInfo dcsScanStream(int os, R reader, const DcsScanTables &tabs, 
         {
         case DCS_FMT_93_T0:
         case DCS_FMT_93B_T1: dcsScan93(s, tabs, fi); break;
-        case DCS_FMT_93A_T1: dcsScan93a(s, tabs); break;
+        case DCS_FMT_93A_T1: dcsScan93a(s, tabs, fi); break;
         default:             dcsScan94(s, tabs, fi); break;
         }
         fi.nBits = static_cast<uint16_t>(s.b.bitPos() - frameBit);
-        fi.flags = static_cast<uint8_t>((s.err << 4) | ((s.err != 0 || format == DCS_FMT_93A_T1) ? DCS_IDX_SERIAL : 0));
+        fi.flags = static_cast<uint8_t>((s.err << 4) | (s.err != 0 ? DCS_IDX_SERIAL : 0));
         sink(static_cast<uint32_t>(valid), fi);
         ++valid;
         si.payloadBits = s.b.bitPos();
