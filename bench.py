@@ -127,13 +127,23 @@ def main():
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
         # HBM traffic per launch: FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes of this same command
         # (tools/prof.sh), committed under profiles/; null when no profile of this workload exists
-        traffic, traffic_note = None, None
+        traffic, traffic_note, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if os.path.exists(tpath):
             t = json.load(open(tpath))
             traffic = t["traffic_bytes_fetch_raw"]
             traffic_note = ("FETCH_SIZE+WRITE_SIZE from %s; FETCH_SIZE raw (x2 per the gfx950 wide-read correction "
                             "would give %d)" % (os.path.relpath(tpath, ROOT), t["traffic_bytes_fetch_x2"]))
+            if "SQ_INSTS_VALU" in t and "GRBM_GUI_ACTIVE" in t:
+                # what actually bounds this integer kernel: wave64 VALU issue, 4 cycles per instruction per SIMD.
+                # Counters are from the committed profile of this workload; the cycle count is GRBM_GUI_ACTIVE
+                # (summed over the 8 XCDs) of the same profile.
+                simds = 256 * 4
+                cycles = t["GRBM_GUI_ACTIVE"] / 8.0
+                valu = {"valu_insts_per_launch": t["SQ_INSTS_VALU"], "simds": simds, "issue_cycles_per_inst": 4,
+                        "kernel_cycles": cycles, "frac_of_valu_issue_peak": t["SQ_INSTS_VALU"] * 4 / (simds * cycles),
+                        "lds_bank_conflict_cycles": t.get("SQ_LDS_BANK_CONFLICT"),
+                        "source": os.path.relpath(tpath, ROOT)}
         out = {
             "metric": "bit_exact_int16_pcm_samples_per_sec",
             "value": samples / dt,
@@ -145,16 +155,17 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int16 (1.15 fixed point, 32-bit integer intermediates)",
+            "dtype": "int16",
             "data": "synthetic",
             "config": {"workload": args.workload, "frames_per_gpu_per_step": n_frames,
                        "samples_per_frame": 240, "frames_per_wave": args.fpw or "auto",
+                       "arithmetic": "ADSP-2105 1.15 fixed point, 32-bit integer intermediates",
                        "partition": "range over streams, no collective"},
             "bit_exact": bit_exact,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "dcsDecodeKernel", "kernel_avg_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "algorithmic_bytes_per_launch": algo_bytes, "valu_issue": valu},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(streams)

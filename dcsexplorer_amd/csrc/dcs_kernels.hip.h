@@ -1,15 +1,16 @@
 // dcs_kernels.hip.h -- CDNA4 (gfx950) kernels for batched DCS frame decode.
 //
-// One wavefront (= one 64-thread workgroup) decodes one CHUNK of up to FPW frames in two phases:
+// One wavefront decodes one CHUNK of up to FPW frames in two phases (four wavefronts form a workgroup and
+// share the LDS copy of the tables):
 //
-//   phase 1, unpack, SUB lanes per frame:  the index pass recorded the decoder state at the start of
-//            header bands 4, 8 and 12 of every frame (DcsSplit), so SUB = 4 lanes unpack one frame in
-//            parallel, four bands each: Huffman / fixed-width fields -> dequantise -> mix-accumulate the
-//            <=255 frequency-domain words into the frame's row of an LDS tile.  16 frames x 4 lanes
-//            keep all 64 lanes of the wavefront on the serial entropy decode (~64 dependent symbol
-//            decodes per lane instead of ~250 per frame).  The compressed bytes of the chunk are first
-//            staged into an LDS pool with coalesced loads (byte-swapped to bit order), so the
-//            per-symbol critical path never waits on HBM/L2.
+//   phase 1, unpack, SUB = 64 / FPW lanes per frame:  the index pass recorded the decoder state at the
+//            start of every header band (DcsSplit), so 4, 8 or 16 lanes unpack one frame in parallel, a
+//            few bands each: Huffman / fixed-width fields -> dequantise -> mix-accumulate the <=255
+//            frequency-domain words into the frame's row of an LDS tile.  All 64 lanes of the wavefront
+//            work on the serial entropy decode (16..80 dependent symbol decodes per lane instead of
+//            ~250 per frame).  The compressed bytes of the chunk are first staged into an LDS pool with
+//            coalesced loads (byte-swapped to bit order), so the per-symbol critical path never waits
+//            on HBM/L2.
 //            [DecoderImpl94x/93/93a::DecompressFrame, DCSDecoderNative.cpp:1679-2261, :2293-2684,
 //             :2831-3032; ROMBitPointer, DCSDecoderNative.h:229-289]
 //   phase 2, transform, 8 or 16 lanes per frame:  register-resident fixed-point inverse transforms of

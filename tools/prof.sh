@@ -38,12 +38,23 @@ print(open("summary.txt").read())
 import json, re
 vals = {}
 for line in open("summary.txt"):
-    m = re.search(r"dcsDecodeKernel<(\d+)>.*\s(FETCH_SIZE|WRITE_SIZE)\s+dispatches=(\d+) avg=([0-9.]+)", line)
+    m = re.search(r"dcsDecodeKernel<(\d+)>.*\s([A-Z_]+)\s+dispatches=(\d+) avg=([0-9.]+)", line)
     if m:
         vals[m.group(2)] = float(m.group(4)); vals["fpw"] = int(m.group(1))
+    m = re.match(r'"void dcsk::dcsDecodeKernel<\d+>\(DcsKernelArgs\)",(\d+),(\d+),([0-9.]+)', line)
+    if m:
+        vals["trace_calls"] = int(m.group(1)); vals["trace_avg_ns"] = float(m.group(3))
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-    json.dump({"fetch_kb_raw": vals["FETCH_SIZE"], "write_kb": vals["WRITE_SIZE"], "fpw": vals["fpw"],
-               "traffic_bytes_fetch_raw": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
-               "traffic_bytes_fetch_x2": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024},
-              open("traffic.json", "w"))
+    d = {"fetch_kb_raw": vals["FETCH_SIZE"], "write_kb": vals["WRITE_SIZE"], "fpw": vals["fpw"],
+         "traffic_bytes_fetch_raw": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
+         "traffic_bytes_fetch_x2": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024}
+    # issue-side counters of the same kernel (per launch), so that the HBM fraction can be read next to what
+    # actually bounds the kernel: VALU instruction issue (4 cycles per wave64 instruction per SIMD)
+    for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+              "SQ_ACTIVE_INST_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"):
+        if k in vals:
+            d[k] = vals[k]
+    if "trace_avg_ns" in vals:
+        d["trace_avg_ns"] = vals["trace_avg_ns"]; d["trace_calls"] = vals["trace_calls"]
+    json.dump(d, open("traffic.json", "w"))
 PY
