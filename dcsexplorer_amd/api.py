@@ -66,7 +66,8 @@ EXPORTS = [
     "dcs_batch_time", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_device_pcm",
     "dcs_batch_algorithmic_bytes", "dcs_batch_num_jobs", "dcs_decode_streams", "dcs_count_stream_frames",
     "dcs_synth_stream", "dcs_plan_chunks", "dcs_index_streams", "dcs_index_streams_gpu",
-    "dcs_index_streams_gpu_time",
+    "dcs_index_streams_gpu_time", "dcs_stream_params_from", "dcs_decode_stream_sequence", "dcs_wav_header",
+    "dcs_dcsa_header", "dcs_dcsa_parse", "dcs_write_wav", "dcs_write_dcsa", "dcs_frame_diff",
 ]
 
 
@@ -136,6 +137,22 @@ def load_library():
     L.dcs_synth_stream.argtypes = [ctypes.POINTER(SynthParams), vp, sz, ctypes.POINTER(sz)]
     L.dcs_plan_chunks.restype = i32
     L.dcs_plan_chunks.argtypes = [vp, u32, vp, ctypes.c_int, vp, sz, ctypes.POINTER(u32)]
+    L.dcs_stream_params_from.restype = i32
+    L.dcs_stream_params_from.argtypes = [i32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint16, u32, vp, vp]
+    L.dcs_decode_stream_sequence.restype = i32
+    L.dcs_decode_stream_sequence.argtypes = [vp, vp, u32, u32, vp, sz, vp, vp]
+    L.dcs_wav_header.restype = None
+    L.dcs_wav_header.argtypes = [u32, vp]
+    L.dcs_dcsa_header.restype = i32
+    L.dcs_dcsa_header.argtypes = [i32, u32, vp]
+    L.dcs_dcsa_parse.restype = i32
+    L.dcs_dcsa_parse.argtypes = [vp, sz, ctypes.POINTER(i32), ctypes.POINTER(vp), ctypes.POINTER(u32)]
+    L.dcs_write_wav.restype = i32
+    L.dcs_write_wav.argtypes = [ctypes.c_char_p, vp, u32]
+    L.dcs_write_dcsa.restype = i32
+    L.dcs_write_dcsa.argtypes = [ctypes.c_char_p, i32, vp, u32]
+    L.dcs_frame_diff.restype = ctypes.c_int
+    L.dcs_frame_diff.argtypes = [ctypes.c_uint64, vp, vp, ctypes.c_char_p, sz, ctypes.POINTER(sz)]
     L.dcs_index_streams.restype = i32
     L.dcs_index_streams.argtypes = [vp, u32, ctypes.c_int, vp, vp, vp]
     L.dcs_index_streams_gpu.restype = i32
@@ -246,6 +263,42 @@ def stream_params(os_, volume, level, nframes, channel_volume=0xFF):
     return mm, vs
 
 
+def wav_header(nframes):
+    out = np.zeros(44, dtype=np.uint8)
+    load_library().dcs_wav_header(nframes, _ptr(out))
+    return out.tobytes()
+
+
+def dcsa_header(os_, nbytes):
+    out = np.zeros(36, dtype=np.uint8)
+    st = load_library().dcs_dcsa_header(os_, nbytes, _ptr(out))
+    if st != 0:
+        raise DcsError(st)
+    return out.tobytes()
+
+
+def dcsa_parse(data):
+    """-> (os, stream bytes) of a "DCSa" container; raises DcsError(ERR_BAD_STREAM) if it is not one"""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+    os_, ptr, n = ctypes.c_int32(), ctypes.c_void_p(), ctypes.c_uint32()
+    st = load_library().dcs_dcsa_parse(_ptr(buf), len(data), ctypes.byref(os_), ctypes.byref(ptr), ctypes.byref(n))
+    if st != 0:
+        raise DcsError(st)
+    off = ptr.value - buf.ctypes.data
+    return os_.value, bytes(data)[off:off + n.value]
+
+
+def frame_diff(frame_no, mine, theirs):
+    """-> (number of differing samples, the block the reference's --validate log would hold)"""
+    a = np.ascontiguousarray(mine, dtype=np.int16)
+    b = np.ascontiguousarray(theirs, dtype=np.int16)
+    assert a.size == FRAME_SAMPLES and b.size == FRAME_SAMPLES
+    text = ctypes.create_string_buffer(8192)
+    n = ctypes.c_size_t()
+    d = load_library().dcs_frame_diff(frame_no, _ptr(a), _ptr(b), text, len(text), ctypes.byref(n))
+    return d, text.raw[:n.value].decode()
+
+
 def synth_stream(fmt, nframes, seed, nbands=16, stride_from=16, profile=0):
     L = load_library()
     p = SynthParams(seed=seed, format=fmt, nFrames=nframes, nBands=nbands, strideFromBand=stride_from,
@@ -288,7 +341,7 @@ def build_stream_batch(streams, extra_frames=0, pad=64, indexer=None):
             blob.append(0)
         off = len(blob)
         blob += bytes(data)
-        blob += bytes(pad)
+        blob += bytes(max(pad, info.nBytes - len(data) + 8))     # bytes past a (damaged) stream's end read as zero
         nvalid = info.nValidFrames
         s = np.zeros(nvalid, dtype=SRC_DTYPE)
         s["streamOff"] = off
@@ -384,6 +437,27 @@ class Context:
 
     def batch(self, blob, srcs, jobs, tails_in=None):
         return Batch(self, blob, srcs, jobs, tails_in)
+
+    def decode_stream_sequence(self, os_, volume, streams, levels, extra_frames=2):
+        """dcs_decode_stream_sequence: the --extract-streams loop on one decoder object.
+        streams: list of bytes; -> (pcm [frames, 240], err, first frame of each stream)"""
+        keep = [np.frombuffer(bytes(s), dtype=np.uint8) for s in streams]
+        refs = (StreamRef * len(streams))()
+        total = 0
+        for k, s in enumerate(keep):
+            refs[k].data = s.ctypes.data
+            refs[k].len = s.size
+            refs[k].os = os_
+            refs[k].volume = volume
+            refs[k].level = levels[k]
+            refs[k].channelVolume = 0xFF
+            total += ((int(s[0]) << 8) | int(s[1])) + extra_frames
+        pcm = np.zeros((total, FRAME_SAMPLES), dtype=np.int16)
+        err = np.zeros(total, dtype=np.uint32)
+        first = np.zeros(len(streams) + 1, dtype=np.uint32)
+        _check(self.L.dcs_decode_stream_sequence(self.h, refs, len(streams), extra_frames, _ptr(pcm), total,
+                                                 _ptr(first), _ptr(err)), self.h)
+        return pcm, err, first
 
     def index_streams_gpu(self, streams):
         """dcs_index_streams_gpu: the index pass on the GPU, one lane per stream.  Same result as

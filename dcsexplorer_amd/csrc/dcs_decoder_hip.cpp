@@ -114,6 +114,8 @@ void DCSDecoderHIP::LoadAudioStream(int ch, const ROMPointer &p, int mixingLevel
     Channel &c = channel[ch];
     const uint32_t nFrames = (static_cast<uint32_t>(p.p[0]) << 8) | p.p[1];
     c.active = false;
+    c.stopPending = false;
+    c.level = mixingLevel << 6;                                 // :1404
     if (nFrames == 0)
         return;                                                 // nothing to play (:1414)
     c.index.resize(nFrames);
@@ -125,9 +127,8 @@ void DCSDecoderHIP::LoadAudioStream(int ch, const ROMPointer &p, int mixingLevel
     if (used > maxLen)
         used = maxLen;
     c.bytes.assign(p.p, p.p + used);
-    c.bytes.resize(used + 16, 0);
+    c.bytes.resize((used > static_cast<size_t>(c.info.nBytes) ? used : static_cast<size_t>(c.info.nBytes)) + 16, 0);
     c.pos = 0;
-    c.level = mixingLevel << 6;                                 // :1404
     c.active = !c.index.empty();
 }
 
@@ -154,6 +155,8 @@ void DCSDecoderHIP::Invalidate()
         channel[i].pos = rewind.pos[i];
         channel[i].active = rewind.active[i];
         channel[i].mixMul = rewind.mixMul[i];
+        channel[i].level = rewind.level[i];
+        channel[i].stopPending = rewind.stopPending[i];
     }
     memcpy(tail, rewind.tail, sizeof(tail));
     ready.clear();
@@ -185,6 +188,8 @@ void DCSDecoderHIP::PlanAndDecode()
         rewind.pos[i] = channel[i].pos;
         rewind.active[i] = channel[i].active;
         rewind.mixMul[i] = channel[i].mixMul;
+        rewind.level[i] = channel[i].level;
+        rewind.stopPending[i] = channel[i].stopPending;
     }
     memcpy(rewind.tail, tail, sizeof(tail));
 
@@ -207,6 +212,15 @@ void DCSDecoderHIP::PlanAndDecode()
     std::vector<Snapshot> snaps;
     for (int t = 0 ; t < lookahead ; ++t)
     {
+        // forced-stop sweep (:95-116): a stream that raised an error on the previous tick is gone now, and
+        // its mixer level with it
+        for (Channel &c : channel)
+            if (c.stopPending)
+            {
+                c.stopPending = false;
+                c.level = 0;
+            }
+
         // MainLoop's shared scale over the active channels (:227-269)
         uint16_t mm[DCS_MAX_CHANNELS];
         uint8_t act[DCS_MAX_CHANNELS];
@@ -238,8 +252,11 @@ void DCSDecoderHIP::PlanAndDecode()
             srcs.push_back(sd);
             ++jb.nSrc;
             if (++c.pos >= c.index.size())
+            {
                 c.active = false;                               // end of stream, loop count 1 (:1565-1588); an
                                                                 // error frame also ends it (:95-116)
+                c.stopPending = c.index.size() < static_cast<size_t>(c.info.nFrames);
+            }
         }
         jobs.push_back(jb);
 
@@ -251,6 +268,8 @@ void DCSDecoderHIP::PlanAndDecode()
             sn.pos[i] = channel[i].pos;
             sn.active[i] = channel[i].active;
             sn.mixMul[i] = channel[i].mixMul;
+            sn.level[i] = channel[i].level;
+            sn.stopPending[i] = channel[i].stopPending;
         }
         snaps.push_back(sn);
     }

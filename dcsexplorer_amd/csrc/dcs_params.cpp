@@ -82,11 +82,19 @@ extern "C" int dcs_frame_scale(uint16_t volMult, uint16_t *mixMul, const uint8_t
 extern "C" DcsStatus dcs_stream_params(DcsOsVersion os, int volume, int level, int channelVolume,
                                        uint32_t nFrames, uint16_t *mixMulScaled, uint8_t *volShift)
 {
+    // a fresh decoder: Channel::mixingMultiplier initialiser (DCSDecoderNative.h:514)
+    return dcs_stream_params_from(os, volume, level, channelVolume, 0x7FFF, nFrames, mixMulScaled, volShift);
+}
+
+extern "C" DcsStatus dcs_stream_params_from(DcsOsVersion os, int volume, int level, int channelVolume,
+                                            uint16_t firstMixMul, uint32_t nFrames,
+                                            uint16_t *mixMulScaled, uint8_t *volShift)
+{
     if (mixMulScaled == nullptr || volShift == nullptr)
         return DCS_ERR_INVALID_ARG;
     const uint16_t volMult = dcs_volume_multiplier(volume);
     const uint16_t steady = dcs_mixing_multiplier(os, level << 6, channelVolume);
-    uint16_t mm = 0x7FFF;           // Channel::mixingMultiplier initialiser (DCSDecoderNative.h:514)
+    uint16_t mm = firstMixMul;      // what the previous tick's UpdateMixingLevels left in the channel
     for (uint32_t f = 0 ; f < nFrames ; ++f)
     {
         uint16_t scaled = mm;

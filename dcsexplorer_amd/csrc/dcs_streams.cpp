@@ -17,7 +17,9 @@ struct Built
     std::vector<uint32_t> firstJob;     // per stream, plus a final total
 };
 
-DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, Built &B, bool countOnly)
+// sequence: the streams are played one after the other by ONE decoder (dcs_decode_stream_sequence)
+DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, Built &B, bool countOnly,
+                       bool sequence = false)
 {
     std::vector<uint16_t> mm;
     std::vector<uint8_t> vs;
@@ -57,7 +59,18 @@ DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t 
         const DcsFrameIndex *idx = allIdx.data() + firstRecord[k];
         const DcsStreamInfo &info = infos[k];
         mm.resize(nFrames); vs.resize(nFrames);
-        st = dcs_stream_params(os, sr.volume, sr.level, sr.channelVolume, nFrames, mm.data(), vs.data());
+        uint16_t firstMul = 0x7FFF;
+        if (sequence && k != 0)
+        {
+            // what UpdateMixingLevels left behind after the previous stream's last tick: its level, or 0 when
+            // the forced-stop sweep reset the mixer after an error (:95-116)
+            const DcsStreamRef &pr = streams[k - 1];
+            const DcsStreamInfo &pi = infos[k - 1];
+            const bool stopped = pi.nValidFrames < pi.nFrames;      // cut short; an error in the very last frame
+                                                                    // finds the channel already idle (:100-113)
+            firstMul = dcs_mixing_multiplier(os, stopped ? 0 : pr.level << 6, pr.channelVolume);
+        }
+        st = dcs_stream_params_from(os, sr.volume, sr.level, sr.channelVolume, firstMul, nFrames, mm.data(), vs.data());
         if (st != DCS_OK)
             return st;
 
@@ -66,6 +79,10 @@ DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t 
             B.blob.push_back(0);
         const uint64_t streamOff = B.blob.size();
         B.blob.insert(B.blob.end(), sr.data, sr.data + sr.len);
+        // a damaged or truncated stream may run past its buffer: bytes past the end read as zero (that is what
+        // the index pass assumed), not as the start of the next stream
+        if (static_cast<size_t>(info.nBytes) > sr.len)
+            B.blob.insert(B.blob.end(), static_cast<size_t>(info.nBytes) - sr.len, 0);
 
         const uint8_t xform = (os == DCS_OS93A || os == DCS_OS93B) ? DCS_XFORM_93 : DCS_XFORM_94;
         const uint32_t nValid = static_cast<uint32_t>(info.nValidFrames);
@@ -74,7 +91,7 @@ DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t 
             DcsFrameJob jb;
             memset(&jb, 0, sizeof(jb));
             jb.xform = xform;
-            jb.prev = (f == 0) ? DCS_PREV_NONE : static_cast<uint32_t>(B.jobs.size() - 1);
+            jb.prev = (f == 0 && !(sequence && k != 0)) ? DCS_PREV_NONE : static_cast<uint32_t>(B.jobs.size() - 1);
             if (f < nValid)
             {
                 DcsSrcDesc sd;
@@ -124,6 +141,28 @@ extern "C" DcsStatus dcs_decode_streams(DcsCtx *ctx, const DcsStreamRef *streams
         return DCS_ERR_INVALID_ARG;
     Built B;
     DcsStatus st = buildStreams(streams, nStreams, extraFrames, B, false);
+    if (st != DCS_OK)
+        return st;
+    if (B.jobs.size() > pcmCapFrames)
+        return DCS_ERR_CAPACITY;
+    if (frameOffsets != nullptr)
+        memcpy(frameOffsets, B.firstJob.data(), sizeof(uint32_t) * B.firstJob.size());
+    return dcs_decode_batch(ctx, B.blob.data(), B.blob.size(), B.srcs.data(), static_cast<uint32_t>(B.srcs.size()),
+                            B.jobs.data(), static_cast<uint32_t>(B.jobs.size()), nullptr, 0, pcmOut, errOut, nullptr);
+}
+
+extern "C" DcsStatus dcs_decode_stream_sequence(DcsCtx *ctx, const DcsStreamRef *streams, uint32_t nStreams,
+                                                uint32_t extraFrames, int16_t *pcmOut, size_t pcmCapFrames,
+                                                uint32_t *frameOffsets, uint32_t *errOut)
+{
+    if (ctx == nullptr || streams == nullptr || nStreams == 0 || pcmOut == nullptr || extraFrames < 2)
+        return DCS_ERR_INVALID_ARG;
+    for (uint32_t k = 1 ; k < nStreams ; ++k)
+        if (streams[k].os != streams[0].os || streams[k].volume != streams[0].volume
+            || streams[k].channelVolume != streams[0].channelVolume)
+            return DCS_ERR_INVALID_ARG;
+    Built B;
+    DcsStatus st = buildStreams(streams, nStreams, extraFrames, B, false, true);
     if (st != DCS_OK)
         return st;
     if (B.jobs.size() > pcmCapFrames)

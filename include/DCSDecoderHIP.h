@@ -167,6 +167,7 @@ private:
         uint32_t pos = 0;                       // next frame
         int level = 0;                          // mixer[ch].curLevel (level byte << 6)
         uint16_t mixMul = 0x7FFF;               // Channel::mixingMultiplier (DCSDecoderNative.h:514)
+        bool stopPending = false;               // AudioStream::stop: the next tick resets the mixer level (:95-116)
     };
     void PlanAndDecode();
     void Invalidate();
@@ -179,7 +180,11 @@ private:
     Channel channel[DCS_MAX_CHANNELS];
     int lookahead = 1;
     std::deque<std::vector<int16_t>> ready;     // frames decoded ahead
-    struct Snapshot { uint32_t pos[DCS_MAX_CHANNELS]; bool active[DCS_MAX_CHANNELS]; uint16_t mixMul[DCS_MAX_CHANNELS]; int16_t tail[16]; };
+    struct Snapshot
+    {
+        uint32_t pos[DCS_MAX_CHANNELS]; bool active[DCS_MAX_CHANNELS]; uint16_t mixMul[DCS_MAX_CHANNELS];
+        int level[DCS_MAX_CHANNELS]; bool stopPending[DCS_MAX_CHANNELS]; int16_t tail[16];
+    };
     std::deque<Snapshot> after;                 // decoder state after each ready frame
     Snapshot rewind{};                          // decoder state after the last frame handed out
     int16_t tail[16] = { 0 };                   // overlapBuffer (DCSDecoderNative.h:149)

@@ -142,6 +142,12 @@ int dcs_frame_scale(uint16_t volMult, uint16_t *mixMul, const uint8_t *active, i
  * (DCSDecoderNative.h:514), later frames the value UpdateMixingLevels left behind. */
 DcsStatus dcs_stream_params(DcsOsVersion os, int volume, int level, int channelVolume,
                             uint32_t nFrames, uint16_t *mixMulScaled, uint8_t *volShift);
+/* The same for a decoder that has played before: frame 0 is mixed with `firstMixMul`, the multiplier the
+ * previous tick left in the channel (MainLoop uses it at :240/:267 before UpdateMixingLevels recomputes it
+ * at :281); 0x7FFF for a freshly constructed decoder (DCSDecoderNative.h:514). */
+DcsStatus dcs_stream_params_from(DcsOsVersion os, int volume, int level, int channelVolume,
+                                 uint16_t firstMixMul, uint32_t nFrames,
+                                 uint16_t *mixMulScaled, uint8_t *volShift);
 
 /* ------------------------------------------------------------------------------------------------
  * Batch description
@@ -246,6 +252,18 @@ DcsStatus dcs_decode_streams(DcsCtx *ctx, const DcsStreamRef *streams, uint32_t 
 DcsStatus dcs_count_stream_frames(const DcsStreamRef *streams, uint32_t nStreams,
                                   uint32_t extraFrames, uint64_t *nFramesOut);
 
+/* The stream loop of `DCSExplorer --extract-streams` exactly (DCSExplorer.cpp:1628-1907): ONE decoder
+ * object plays the streams one after the other -- LoadAudioStream(0, ptr, level), nFrames + extraFrames
+ * frames, ClearTracks() during the last two (ExtractToWAV :1670-1721) -- so frame 0 of every stream but the
+ * first is mixed with the multiplier the previous stream's level left behind (level 0 if that stream was
+ * stopped by an error, :95-116), and only the very first stream sees the constructor's 0x7FFF.  All streams
+ * must name the same os / volume / channelVolume (they are properties of the one decoder); extraFrames
+ * must be at least 2, as it is there, so that every stream starts from a silent decoder.  Output layout as
+ * dcs_decode_streams.  Still one kernel launch for everything. */
+DcsStatus dcs_decode_stream_sequence(DcsCtx *ctx, const DcsStreamRef *streams, uint32_t nStreams,
+                                     uint32_t extraFrames, int16_t *pcmOut, size_t pcmCapFrames,
+                                     uint32_t *frameOffsets, uint32_t *errOut);
+
 /* ------------------------------------------------------------------------------------------------
  * Index many streams at once: on `nThreads` host threads (0 = all hardware threads), or on the GPU with
  * one lane per stream (dcs_index_streams_gpu; the streams are given as offsets into one blob, which is
@@ -272,6 +290,24 @@ DcsStatus dcs_index_streams_gpu(DcsCtx *ctx, const uint8_t *blob, size_t blobLen
  * dcs_index_streams_gpu call's inputs (kept resident in the context until the next call) */
 DcsStatus dcs_index_streams_gpu_time(DcsCtx *ctx, int iters, float *avgMs);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Output formats of the reference's extraction and validation modes.
+ */
+/* the 44-byte WAV header of ExtractToWAV (DCSExplorer.cpp:1686-1699): mono, 16 bit, 31 250 Hz, nFrames x 240 samples */
+void      dcs_wav_header(uint32_t nFrames, uint8_t out[44]);
+/* the 36-byte "DCSa" raw-stream container header (DCSExplorer.cpp:1831-1866; README.md:274-289); the data section
+ * that follows is the stream's first GetStreamInfo().nBytes bytes */
+DcsStatus dcs_dcsa_header(DcsOsVersion os, uint32_t nBytes, uint8_t out[36]);
+/* its reader, with the acceptance test of DCSEncoder::IsDCSFile (DCSEncoder.cpp:358-400) */
+DcsStatus dcs_dcsa_parse(const uint8_t *file, size_t len, DcsOsVersion *osOut,
+                         const uint8_t **streamOut, uint32_t *nBytesOut);
+DcsStatus dcs_write_wav(const char *path, const int16_t *pcm, uint32_t nFrames);
+DcsStatus dcs_write_dcsa(const char *path, DcsOsVersion os, const uint8_t *stream, uint32_t nBytes);
+/* one frame of the --validate log (DCSExplorer.cpp:1358-1447): returns the number of differing samples and
+ * formats the reference's log block into `text` (optional) */
+int       dcs_frame_diff(uint64_t frameNo, const int16_t *mine, const int16_t *theirs,
+                         char *text, size_t textCap, size_t *textLen);
 
 /* ------------------------------------------------------------------------------------------------
  * Synthetic stream writer (seeded, integer-only).  Produces VALID streams

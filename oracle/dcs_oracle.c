@@ -940,6 +940,37 @@ int orc_decode(int os, int volume, int nch,
     return 0;
 }
 
+/* The stream loop of DCSExplorer --extract-streams (DCSExplorer.cpp:1628-1907) on one decoder: same contract as
+ * ref_decode_sequence in ref_driver.cpp.  ClearTracks (:1466-1473) clears every channel's audio stream. */
+int orc_decode_sequence(int os, int volume, int n, const uint8_t *const *streams, const size_t *lens,
+    const int *levels, int extraFrames, int16_t *pcm)
+{
+    Player *pl = (Player *)malloc(sizeof(Player));
+    if (!pl)
+        return -4;
+    player_init(pl, os, volume);
+    for (int i = 0 ; i < n ; ++i)
+    {
+        int r = player_load(pl, 0, streams[i], lens[i], levels[i]);
+        if (r != 0)
+        {
+            free(pl);
+            return r;
+        }
+        const int nFrames = (int)pl->ch[0].st.nFrames + extraFrames;
+        for (int frame = 0 ; frame < nFrames ; ++frame)
+        {
+            player_tick(pl, pcm, NULL);
+            pcm += 240;
+            if (frame + 2 >= nFrames)
+                for (int c = 0 ; c < 8 ; ++c)
+                    pl->ch[c].active = 0;
+        }
+    }
+    free(pl);
+    return 0;
+}
+
 int orc_frame_params(int os, int volume, int level, int nFrames,
     uint16_t *mixMulScaled, uint8_t *volShiftOut)
 {

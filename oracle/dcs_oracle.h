@@ -53,6 +53,12 @@ int orc_decode(int os, int volume, int nch,
     const uint8_t *const *streams, const size_t *lens, const int *levels,
     int nFramesOut, int16_t *pcm, OrcProbe *probes);
 
+/* The --extract-streams loop on ONE decoder object (DCSExplorer.cpp:1628-1907): per stream
+ * LoadAudioStream(0, ptr, level), nFrames + extraFrames frames, ClearTracks after each of the last two.
+ * pcm = all frames back to back. */
+int orc_decode_sequence(int os, int volume, int n, const uint8_t *const *streams, const size_t *lens,
+    const int *levels, int extraFrames, int16_t *pcm);
+
 /* DCSDecoderNative::GetStreamInfo (:1486-1537) */
 int orc_stream_info(int os, const uint8_t *stream, size_t len,
     int *nFrames, int *nBytes, int *formatType, int *formatSubType, uint8_t *header16);

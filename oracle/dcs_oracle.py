@@ -67,6 +67,25 @@ class _Checker:
             raise RuntimeError("%sdecode failed: %d" % (self.prefix, r))
         return (pcm, pr) if probes else pcm
 
+    def decode_sequence(self, os_, volume, streams, levels, extra_frames=2):
+        """streams played one after the other through ONE decoder (the --extract-streams loop);
+        returns int16 [sum(nFrames + extra), 240]"""
+        n = len(streams)
+        keep = [_u8buf(s) for s in streams]
+        ptrs = (ctypes.POINTER(ctypes.c_uint8) * n)(
+            *[ctypes.cast(a, ctypes.POINTER(ctypes.c_uint8)) for a, _ in keep])
+        lens = (ctypes.c_size_t * n)(*[l for _, l in keep])
+        lv = (ctypes.c_int * n)(*levels)
+        total = sum(((bytes(s)[0] << 8) | bytes(s)[1]) + extra_frames for s in streams)
+        pcm = np.zeros((total, 240), dtype=np.int16)
+        f = self._fn("decode_sequence")
+        f.restype = ctypes.c_int
+        r = f(ctypes.c_int(os_), ctypes.c_int(volume), ctypes.c_int(n), ptrs, lens, lv, ctypes.c_int(extra_frames),
+              pcm.ctypes.data_as(ctypes.c_void_p))
+        if r != 0:
+            raise RuntimeError("%sdecode_sequence failed: %d" % (self.prefix, r))
+        return pcm
+
     def stream_info(self, os_, stream):
         a, n = _u8buf(stream)
         nf, nb, ft, fs = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int())

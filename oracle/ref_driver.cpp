@@ -262,4 +262,39 @@ long long ref_decode_many(const int *os, const int *volume, const int *level,
     return total;
 }
 
+// The stream loop of DCSExplorer --extract-streams (DCSExplorer.cpp:1628-1907) on ONE decoder object: for every
+// stream LoadAudioStream(0, ptr, level), then nFrames + extraFrames frames of 240 GetNextSample() with
+// ClearTracks() after each of the last two (ExtractToWAV, :1670-1721).  Decoder state (mixing multiplier,
+// overlap tail) carries from one stream to the next exactly as it does there.  pcm receives the frames of
+// all streams back to back.
+int ref_decode_sequence(int os, int volume, int n, const uint8_t *const *streams, const size_t *lens,
+    const int *levels, int extraFrames, int16_t *pcm)
+{
+    std::vector<std::vector<uint8_t>> bufs(n);
+    for (int i = 0 ; i < n ; ++i)
+    {
+        bufs[i].assign(streams[i], streams[i] + lens[i]);
+        bufs[i].resize(lens[i] + 64, 0);
+    }
+    DCSDecoder::MinHost host;
+    DCSDecoderNative dec(&host);
+    dec.InitStandalone(OsFromInt(os));
+    dec.SetDefaultVolume(volume);
+    dec.SoftBoot();
+    dec.SetMasterVolume(volume);
+    for (int i = 0 ; i < n ; ++i)
+    {
+        dec.LoadAudioStream(0, DCSDecoder::ROMPointer(0, bufs[i].data()), levels[i]);
+        const int nFrames = ((bufs[i][0] << 8) | bufs[i][1]) + extraFrames;
+        for (int frame = 0 ; frame < nFrames ; ++frame)
+        {
+            for (int k = 0 ; k < 240 ; ++k)
+                *pcm++ = dec.GetNextSample();
+            if (frame + 2 >= nFrames)
+                dec.ClearTracks();
+        }
+    }
+    return 0;
+}
+
 }   // extern "C"

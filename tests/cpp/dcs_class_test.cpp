@@ -78,6 +78,33 @@ int main(int argc, char **argv)
                 pcm.push_back(dec->GetNextSample());
         if (!dec->IsOK()) { fprintf(stderr, "decoder failed: %s\n", dec->GetErrorMessage().c_str()); return 5; }
     }
+    else if (mode == "extract")
+    {
+        // the stream loop of DCSExplorer --extract-streams, written the way it is there (DCSExplorer.cpp:1670-1721,
+        // :1900-1907): one decoder object, stream after stream; each stream also goes to <OUT>.<k>.wav
+        dec->SetLookahead(atoi(argv[4]));
+        dec->SetMasterVolume(volume);
+        std::vector<std::vector<uint8_t>> keep;
+        int k = 0;
+        for (int i = 7 ; i + 1 < argc ; i += 2, ++k)
+        {
+            keep.push_back(readFile(argv[i + 1]));
+            const std::vector<uint8_t> &data = keep.back();
+            dec->LoadAudioStream(0, DCSDecoder::ROMPointer(0, data.data()), atoi(argv[i]), data.size());
+            const int nFrames = ((data[0] << 8) | data[1]) + 2;
+            const size_t first = pcm.size();
+            for (int frame = 0 ; frame < nFrames ; ++frame)
+            {
+                for (int si = 0 ; si < 240 ; ++si)
+                    pcm.push_back(dec->GetNextSample());
+                if (frame + 2 >= nFrames)
+                    dec->ClearTracks();
+            }
+            const std::string wav = std::string(argv[5]) + "." + std::to_string(k) + ".wav";
+            if (dcs_write_wav(wav.c_str(), pcm.data() + first, static_cast<uint32_t>(nFrames)) != DCS_OK) return 7;
+        }
+        if (!dec->IsOK()) { fprintf(stderr, "decoder failed: %s\n", dec->GetErrorMessage().c_str()); return 5; }
+    }
     else
     {
         const unsigned extra = static_cast<unsigned>(atoi(argv[4]));

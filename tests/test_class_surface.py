@@ -73,3 +73,31 @@ def test_batch_submit_matches_oracle(tmp_path, oracle):
     got = np.fromfile(out, dtype=np.int16).reshape(-1, 240)
     want = np.concatenate([oracle.decode(1, 240, [d], [0x64], ((d[0] << 8) | d[1]) + 2) for d in datas])
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lookahead", [1, 16])
+def test_extract_streams_loop_matches_oracle(tmp_path, oracle, lookahead):
+    """the --extract-streams loop on ONE DCSDecoderHIP object: decoder state carries over between streams
+    (incl. a stream stopped by an error, whose mixer level is reset), WAV files as ExtractToWAV writes them"""
+    from util import corrupt
+    datas, levels = [], [0x64, 0x7F, 0x30, 0x64, 0x55]
+    for i in range(5):
+        d = make_stream(D.FMT_94_T1_S3 if i % 2 else D.FMT_94_T0, 6 + 4 * i, seed=24000 + i, profile=i % 4)
+        if i == 2:
+            d = corrupt(d, seed=5)
+        datas.append(d)
+    args = ["extract", "3", "255", str(lookahead), "OUT", "0"]
+    for i, d in enumerate(datas):
+        args += [str(levels[i]), write_stream(tmp_path, "e%d.bin" % i, d)]
+    p, out = run(args, tmp_path)
+    assert p.returncode == 0, p.stderr
+    got = np.fromfile(out, dtype=np.int16).reshape(-1, 240)
+    want = oracle.decode_sequence(3, 255, datas, levels, 2)
+    assert np.array_equal(got, want)
+    pos = 0
+    for k, d in enumerate(datas):
+        n = ((d[0] << 8) | d[1]) + 2
+        raw = open("%s.%d.wav" % (out, k), "rb").read()
+        assert raw[:44] == D.wav_header(n) and raw[44:] == want[pos:pos + n].tobytes()
+        pos += n

@@ -204,3 +204,19 @@ def test_gpu_index_pass_rejects_bad_shapes(gpu_ctx):
     bad = locs.copy(); bad["len"] = b.size + 100
     assert L.dcs_index_streams_gpu(gpu_ctx.h, b.ctypes.data, b.size, bad.ctypes.data, 1, out.ctypes.data, 4, infos.ctypes.data) == D.api.ERR_INVALID_ARG
     assert L.dcs_index_streams_gpu(gpu_ctx.h, b.ctypes.data, b.size, locs.ctypes.data, 1, out.ctypes.data, 3, infos.ctypes.data) == D.api.ERR_CAPACITY
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("os_", [0, 1, 2, 3])
+def test_stream_sequence_on_one_decoder(gpu_ctx, oracle, os_):
+    """dcs_decode_stream_sequence = the --extract-streams loop in one launch: frame 0 of each stream is mixed
+    with what the previous stream's level left behind (a stream cut short by an error leaves level 0)"""
+    from test_oracle_vs_ref import _sequence_case
+    for with_error in (False, True):
+        streams, levels = _sequence_case(os_, 6100 + 10 * os_, with_error)
+        for vol, extra in ((255, 2), (190, 4)):
+            pcm, err, first = gpu_ctx.decode_stream_sequence(os_, vol, streams, levels, extra)
+            assert_same(pcm, oracle.decode_sequence(os_, vol, streams, levels, extra), "sequence os %d" % os_)
+            assert first[-1] == pcm.shape[0]
+    L = gpu_ctx.L
+    assert L.dcs_decode_stream_sequence(gpu_ctx.h, None, 0, 2, None, 0, None, None) == D.api.ERR_INVALID_ARG

@@ -85,3 +85,34 @@ def test_looping_is_not_used_but_short_streams_work(oracle, reference):
         s = make_stream(fmt, 1, seed=77 + fmt)
         assert np.array_equal(oracle.decode(os_for(fmt), 255, [s], [0x64], 4),
                               reference.decode(os_for(fmt), 255, [s], [0x64], 4))
+
+
+def _sequence_case(os_, seed, with_error=False):
+    """streams of the layouts one OS version plays, ragged lengths, different levels"""
+    from util import corrupt
+    fmts = [f for f in ALL_FORMATS if os_for(f) == os_ or os_for(f, 1) == os_]
+    streams, levels = [], []
+    for i in range(6):
+        fmt = fmts[i % len(fmts)]
+        s = make_stream(fmt, 3 + 5 * i, seed=seed + i, profile=i % 4)
+        if with_error and i in (1, 4):
+            s = corrupt(s, seed=seed + i)
+        streams.append(s)
+        levels.append([0x64, 0x7F, 0x20, 0x64, 0x50, 0x7F][i])
+    return streams, levels
+
+
+@pytest.mark.parametrize("os_", [0, 1, 2, 3])
+@pytest.mark.parametrize("with_error", [False, True])
+def test_extract_streams_sequence_on_one_decoder(oracle, reference, os_, with_error):
+    """the --extract-streams loop: decoder state carries from stream to stream"""
+    streams, levels = _sequence_case(os_, 5100 + 10 * os_, with_error)
+    for vol, extra in ((255, 2), (200, 3)):
+        a = oracle.decode_sequence(os_, vol, streams, levels, extra)
+        b = reference.decode_sequence(os_, vol, streams, levels, extra)
+        assert np.array_equal(a, b)
+    # the carry-over is observable: frame 0 of the second stream differs from a fresh decoder's
+    a = oracle.decode_sequence(os_, 255, streams[:2], levels[:2], 2)
+    n0 = ((streams[0][0] << 8) | streams[0][1]) + 2
+    fresh = oracle.decode(os_, 255, [streams[1]], [levels[1]], 1)
+    assert not np.array_equal(a[n0], fresh[0]) or not a[n0].any()
