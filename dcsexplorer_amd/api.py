@@ -45,6 +45,23 @@ INFO_DTYPE = np.dtype([("nFrames", "<i4"), ("nBytes", "<i4"), ("formatType", "<i
                        ("payloadBits", "<u4")])
 
 
+class RomCheck(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("hw", ctypes.c_int32), ("os", ctypes.c_int32),
+                ("nominalVersion", ctypes.c_uint32), ("catalogOffset", ctypes.c_uint32), ("nTracks", ctypes.c_uint32),
+                ("signature", ctypes.c_char * 128)]
+
+
+class TrackInfo(ctypes.Structure):
+    _fields_ = [("address", ctypes.c_uint32), ("channel", ctypes.c_int32), ("type", ctypes.c_int32),
+                ("deferCode", ctypes.c_int32), ("time", ctypes.c_uint32), ("looping", ctypes.c_int32)]
+
+
+TRACKOP_DTYPE = np.dtype([("offset", "<i4"), ("nestingLevel", "<i4"), ("loopParent", "<i4"), ("delayCount", "<u2"),
+                          ("opcode", "u1"), ("nOperandBytes", "u1"), ("operandBytes", "u1", (8,))])
+EXTRACT_DTYPE = np.dtype([("track", "<u4"), ("streamNum", "<u4"), ("address", "<u4"), ("level", "<i4")])
+HW_DCS93, HW_DCS95 = 2, 3
+
+
 class SynthParams(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("format", ctypes.c_int32), ("nFrames", ctypes.c_int32),
                 ("nBands", ctypes.c_int32), ("strideFromBand", ctypes.c_int32), ("profile", ctypes.c_int32),
@@ -68,6 +85,10 @@ EXPORTS = [
     "dcs_synth_stream", "dcs_plan_chunks", "dcs_index_streams", "dcs_index_streams_gpu",
     "dcs_index_streams_gpu_time", "dcs_stream_params_from", "dcs_decode_stream_sequence", "dcs_wav_header",
     "dcs_dcsa_header", "dcs_dcsa_parse", "dcs_write_wav", "dcs_write_dcsa", "dcs_frame_diff",
+    "dcs_romset_create", "dcs_romset_destroy", "dcs_romset_last_error", "dcs_romset_add_rom", "dcs_romset_load_zip",
+    "dcs_romset_load_zip_memory", "dcs_romset_check", "dcs_romset_set_version", "dcs_romset_num_tracks",
+    "dcs_romset_pointer", "dcs_romset_track_info", "dcs_romset_decompile", "dcs_romset_list_streams",
+    "dcs_romset_extract_plan", "dcs_romset_stream_refs",
 ]
 
 
@@ -153,6 +174,36 @@ def load_library():
     L.dcs_write_dcsa.argtypes = [ctypes.c_char_p, i32, vp, u32]
     L.dcs_frame_diff.restype = ctypes.c_int
     L.dcs_frame_diff.argtypes = [ctypes.c_uint64, vp, vp, ctypes.c_char_p, sz, ctypes.POINTER(sz)]
+    L.dcs_romset_create.restype = vp
+    L.dcs_romset_create.argtypes = []
+    L.dcs_romset_destroy.restype = None
+    L.dcs_romset_destroy.argtypes = [vp]
+    L.dcs_romset_last_error.restype = ctypes.c_char_p
+    L.dcs_romset_last_error.argtypes = [vp]
+    L.dcs_romset_add_rom.restype = i32
+    L.dcs_romset_add_rom.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, sz]
+    L.dcs_romset_load_zip.restype = i32
+    L.dcs_romset_load_zip.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
+    L.dcs_romset_load_zip_memory.restype = i32
+    L.dcs_romset_load_zip_memory.argtypes = [vp, ctypes.c_char_p, sz, ctypes.c_char_p, ctypes.c_char_p]
+    L.dcs_romset_check.restype = i32
+    L.dcs_romset_check.argtypes = [vp, ctypes.POINTER(RomCheck)]
+    L.dcs_romset_set_version.restype = i32
+    L.dcs_romset_set_version.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.dcs_romset_num_tracks.restype = u32
+    L.dcs_romset_num_tracks.argtypes = [vp]
+    L.dcs_romset_pointer.restype = i32
+    L.dcs_romset_pointer.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_int)]
+    L.dcs_romset_track_info.restype = i32
+    L.dcs_romset_track_info.argtypes = [vp, u32, ctypes.POINTER(TrackInfo)]
+    L.dcs_romset_decompile.restype = i32
+    L.dcs_romset_decompile.argtypes = [vp, u32, vp, u32, ctypes.POINTER(u32)]
+    L.dcs_romset_list_streams.restype = i32
+    L.dcs_romset_list_streams.argtypes = [vp, vp, u32, ctypes.POINTER(u32)]
+    L.dcs_romset_extract_plan.restype = i32
+    L.dcs_romset_extract_plan.argtypes = [vp, vp, u32, ctypes.POINTER(u32)]
+    L.dcs_romset_stream_refs.restype = i32
+    L.dcs_romset_stream_refs.argtypes = [vp, vp, u32, ctypes.c_int, vp]
     L.dcs_index_streams.restype = i32
     L.dcs_index_streams.argtypes = [vp, u32, ctypes.c_int, vp, vp, vp]
     L.dcs_index_streams_gpu.restype = i32
@@ -438,6 +489,21 @@ class Context:
     def batch(self, blob, srcs, jobs, tails_in=None):
         return Batch(self, blob, srcs, jobs, tails_in)
 
+    def extract_streams(self, romset, volume=255, extra_frames=2):
+        """the whole `--extract-streams` pipeline: ROM set -> plan -> one launch -> PCM per stream.
+        -> (plan items, pcm [frames, 240], first frame of each stream)"""
+        items = romset.extract_plan()
+        refs = romset.stream_refs(items, volume)
+        total = ctypes.c_uint64()
+        st = self.L.dcs_count_stream_frames(refs, len(items), extra_frames, ctypes.byref(total))
+        if st != 0:
+            raise DcsError(st)
+        pcm = np.zeros((total.value, FRAME_SAMPLES), dtype=np.int16)
+        first = np.zeros(len(items) + 1, dtype=np.uint32)
+        _check(self.L.dcs_decode_stream_sequence(self.h, refs, len(items), extra_frames, _ptr(pcm), total.value,
+                                                 _ptr(first), None), self.h)
+        return items, pcm, first
+
     def decode_stream_sequence(self, os_, volume, streams, levels, extra_frames=2):
         """dcs_decode_stream_sequence: the --extract-streams loop on one decoder object.
         streams: list of bytes; -> (pcm [frames, 240], err, first frame of each stream)"""
@@ -530,3 +596,128 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+class RomSet:
+    """DcsRomSet: sound ROM images -> catalog, track programs, streams (include/dcs_hip.h, csrc/dcs_rom.cpp)"""
+
+    def __init__(self, images=None, zip_path=None, zip_bytes=None, zip_name="roms.zip", explicit_u2=None):
+        self.L = load_library()
+        self.h = ctypes.c_void_p(self.L.dcs_romset_create())
+        st = 0
+        if images:
+            for chip, data in images.items():
+                st = st or self.L.dcs_romset_add_rom(self.h, chip, bytes(data), len(data))
+        elif zip_path is not None:
+            st = self.L.dcs_romset_load_zip(self.h, str(zip_path).encode(), explicit_u2.encode() if explicit_u2 else None)
+        elif zip_bytes is not None:
+            st = self.L.dcs_romset_load_zip_memory(self.h, zip_bytes, len(zip_bytes), zip_name.encode(),
+                                                   explicit_u2.encode() if explicit_u2 else None)
+        if st != 0:
+            msg = self.L.dcs_romset_last_error(self.h).decode()
+            self.close()
+            raise DcsError(st, msg)
+
+    def close(self):
+        if self.h:
+            self.L.dcs_romset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self):
+        c = RomCheck()
+        _rs_check(self.L.dcs_romset_check(self.h, ctypes.byref(c)), self)
+        return c
+
+    def set_version(self, hw, os_):
+        _rs_check(self.L.dcs_romset_set_version(self.h, hw, os_), self)
+
+    @property
+    def num_tracks(self):
+        return self.L.dcs_romset_num_tracks(self.h)
+
+    def track_info(self, track):
+        ti = TrackInfo()
+        return ti if self.L.dcs_romset_track_info(self.h, track, ctypes.byref(ti)) == 0 else None
+
+    def decompile(self, track):
+        n = ctypes.c_uint32()
+        _rs_check(self.L.dcs_romset_decompile(self.h, track, None, 0, ctypes.byref(n)), self)
+        ops = np.zeros(max(n.value, 1), dtype=TRACKOP_DTYPE)
+        _rs_check(self.L.dcs_romset_decompile(self.h, track, _ptr(ops), n.value, ctypes.byref(n)), self)
+        return ops[:n.value]
+
+    def list_streams(self):
+        n = ctypes.c_uint32()
+        _rs_check(self.L.dcs_romset_list_streams(self.h, None, 0, ctypes.byref(n)), self)
+        a = np.zeros(max(n.value, 1), dtype=np.uint32)
+        _rs_check(self.L.dcs_romset_list_streams(self.h, _ptr(a), n.value, ctypes.byref(n)), self)
+        return a[:n.value]
+
+    def pointer(self, linear):
+        """-> (chip number 2..9, offset in that chip's image, bytes available from there, address)"""
+        p, avail, chip = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_int()
+        _rs_check(self.L.dcs_romset_pointer(self.h, linear, ctypes.byref(p), ctypes.byref(avail), ctypes.byref(chip)), self)
+        return chip.value, p.value, avail.value
+
+    def stream_bytes(self, linear):
+        _, p, avail = self.pointer(linear)
+        return ctypes.string_at(p, avail)
+
+    def extract_plan(self):
+        n = ctypes.c_uint32()
+        _rs_check(self.L.dcs_romset_extract_plan(self.h, None, 0, ctypes.byref(n)), self)
+        a = np.zeros(max(n.value, 1), dtype=EXTRACT_DTYPE)
+        _rs_check(self.L.dcs_romset_extract_plan(self.h, _ptr(a), n.value, ctypes.byref(n)), self)
+        return a[:n.value]
+
+    def stream_refs(self, items, volume):
+        refs = (StreamRef * max(len(items), 1))()
+        items = np.ascontiguousarray(items, dtype=EXTRACT_DTYPE)
+        _rs_check(self.L.dcs_romset_stream_refs(self.h, _ptr(items), len(items), volume, refs), self)
+        return refs
+
+    def dump(self, force_hw=-1, force_os=-1):
+        """everything derived from the images as text, one item per line (the tests compare it with the same dump
+        made from the reference's answers)"""
+        c = self.check()
+        out = ["check status=%d hw=%d os=%d nominal=%04x catalog=%x ntracks=%u sig=%s" % (
+            c.status, c.hw, c.os, c.nominalVersion, c.catalogOffset, c.nTracks, c.signature.decode())]
+        if force_hw >= 0 or force_os >= 0:
+            self.set_version(force_hw if force_hw >= 0 else c.hw, force_os if force_os >= 0 else c.os)
+        for t in range(self.num_tracks):
+            ti = self.track_info(t)
+            if ti is None:
+                continue
+            out.append("track %u addr=%06x ch=%d type=%d defer=%04x time=%u loop=%d" % (
+                t, ti.address, ti.channel, ti.type, ti.deferCode & 0xFFFF, ti.time, ti.looping))
+            if ti.type != 1:
+                continue
+            for op in self.decompile(t):
+                out.append(" op off=%d nest=%d parent=%d delay=%04x opc=%02x n=%d bytes=%s" % (
+                    op["offset"], op["nestingLevel"], op["loopParent"], op["delayCount"], op["opcode"], op["nOperandBytes"],
+                    bytes(op["operandBytes"][:min(int(op["nOperandBytes"]), 8)]).hex()))
+        base = {}
+        for a in self.list_streams():
+            chip, p, avail = self.pointer(int(a))
+            if chip not in base:
+                base[chip] = self.pointer((chip - 2) << (21 if self.check_hw() == HW_DCS95 else 20))[1]
+            out.append("stream %06x chip=%d off=%x" % (a, chip, p - base[chip]))
+        for it in self.extract_plan():
+            out.append("extract track=%u num=%d addr=%06x level=%d" % (it["track"], it["streamNum"], it["address"], it["level"]))
+        return "\n".join(out) + "\n"
+
+    def check_hw(self):
+        # the version in effect (after a possible override) shows in how a pointer is split
+        chip, _, _ = self.pointer(1 << 20)
+        return HW_DCS93 if chip == 3 else HW_DCS95
+
+
+def _rs_check(st, rs):
+    if st != 0:
+        raise DcsError(st, rs.L.dcs_romset_last_error(rs.h).decode())

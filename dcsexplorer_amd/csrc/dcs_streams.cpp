@@ -78,9 +78,11 @@ DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t 
         while (B.blob.size() & 3)
             B.blob.push_back(0);
         const uint64_t streamOff = B.blob.size();
-        B.blob.insert(B.blob.end(), sr.data, sr.data + sr.len);
-        // a damaged or truncated stream may run past its buffer: bytes past the end read as zero (that is what
-        // the index pass assumed), not as the start of the next stream
+        // only the bytes the stream uses (the caller's buffer may be the whole rest of a ROM image) ...
+        const size_t used = static_cast<size_t>(info.nBytes) < sr.len ? static_cast<size_t>(info.nBytes) : sr.len;
+        B.blob.insert(B.blob.end(), sr.data, sr.data + used);
+        // ... and a damaged or truncated stream may run past its buffer: bytes past the end read as zero (that
+        // is what the index pass assumed), not as the start of the next stream
         if (static_cast<size_t>(info.nBytes) > sr.len)
             B.blob.insert(B.blob.end(), static_cast<size_t>(info.nBytes) - sr.len, 0);
 

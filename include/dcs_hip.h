@@ -292,6 +292,77 @@ DcsStatus dcs_index_streams_gpu_time(DcsCtx *ctx, int iters, float *avgMs);
 
 
 /* ------------------------------------------------------------------------------------------------
+ * ROM ingestion: from sound ROM images (U2..U9, or a PinMame .zip of them) to the streams the decoder is
+ * fed with.  Same results as the reference's DCSDecoder::AddROM / CheckROMs / MakeROMPointer /
+ * GetTrackInfo / DecompileTrackProgram / ListStreams (DCSDecoder.cpp:26-76, :207-495, :672-1293) and
+ * LoadROMFromZipFile (DCSDecoderZipLoader.cpp:60-207) on the same images; every read is bounds-checked
+ * (a pointer that leaves its image reads 0xFF, like unpopulated ROM space on the board).
+ */
+typedef struct DcsRomSet DcsRomSet;
+
+enum { DCS_HW_UNKNOWN = 0, DCS_HW_INVALID = 1, DCS_HW_DCS93 = 2, DCS_HW_DCS95 = 3 };    /* DCSDecoder.h:816-822 */
+
+typedef struct DcsRomCheck
+{
+    int32_t  status;                   /* CheckROMs: 1 = all good, else the Ux number of the first bad ROM   */
+    int32_t  hw;                       /* DCS_HW_*                                                          */
+    int32_t  os;                       /* DcsOsVersion, -1 = not detected                                   */
+    uint32_t nominalVersion;           /* 0x0103.. when the software carries one, else 0                    */
+    uint32_t catalogOffset;            /* 0x3000 / 0x4000 / 0x6000, 0 = none                                */
+    uint32_t nTracks;
+    char     signature[128];           /* U2 signature text, empty if U2 does not look like one             */
+} DcsRomCheck;
+
+typedef struct DcsTrackInfo            /* DCSDecoder::TrackInfo (DCSDecoder.h:375-430)                      */
+{
+    uint32_t address;                  /* 24-bit linear ROM address of the track                            */
+    int32_t  channel;
+    int32_t  type;                     /* 1 byte-code program, 2 deferred, 3 deferred indirect              */
+    int32_t  deferCode;
+    uint32_t time;                     /* running time in frames                                            */
+    int32_t  looping;
+} DcsTrackInfo;
+
+typedef struct DcsTrackOp              /* DCSDecoder::Opcode without the text (DCSDecoder.h:432-478)        */
+{
+    int32_t  offset;                   /* byte offset of the step in the program                            */
+    int32_t  nestingLevel;
+    int32_t  loopParent;               /* -1 at top level                                                   */
+    uint16_t delayCount;
+    uint8_t  opcode;
+    uint8_t  nOperandBytes;
+    uint8_t  operandBytes[8];
+} DcsTrackOp;
+
+typedef struct DcsExtractItem          /* one stream of the --extract-streams loop                          */
+{
+    uint32_t track;                    /* track whose program plays it first                                */
+    uint32_t streamNum;                /* 1-based count within that track (the file name's _%02X_)          */
+    uint32_t address;                  /* linear ROM address of the stream                                  */
+    int32_t  level;                    /* mixing level the loop plays it at                                 */
+} DcsExtractItem;
+
+DcsRomSet  *dcs_romset_create(void);
+void        dcs_romset_destroy(DcsRomSet *rs);
+const char *dcs_romset_last_error(const DcsRomSet *rs);
+DcsStatus   dcs_romset_add_rom(DcsRomSet *rs, int chip /* 2..9 */, const uint8_t *data, size_t size);   /* copies */
+DcsStatus   dcs_romset_load_zip(DcsRomSet *rs, const char *path, const char *explicitU2 /* may be NULL */);
+DcsStatus   dcs_romset_load_zip_memory(DcsRomSet *rs, const uint8_t *zip, size_t len, const char *zipBaseName,
+                                       const char *explicitU2);
+DcsStatus   dcs_romset_check(DcsRomSet *rs, DcsRomCheck *out);           /* also adopts the detected versions    */
+DcsStatus   dcs_romset_set_version(DcsRomSet *rs, int hw, int os);       /* explicit override (no ADSP code in U2) */
+uint32_t    dcs_romset_num_tracks(const DcsRomSet *rs);
+DcsStatus   dcs_romset_pointer(const DcsRomSet *rs, uint32_t linear, const uint8_t **p, size_t *avail, int *chip);
+DcsStatus   dcs_romset_track_info(const DcsRomSet *rs, uint32_t track, DcsTrackInfo *ti);   /* BAD_STREAM: no such track */
+DcsStatus   dcs_romset_decompile(const DcsRomSet *rs, uint32_t track, DcsTrackOp *ops, uint32_t cap, uint32_t *nOut);
+DcsStatus   dcs_romset_list_streams(const DcsRomSet *rs, uint32_t *addrs, uint32_t cap, uint32_t *nOut);
+/* which streams `DCSExplorer --extract-streams` extracts, in its order and at its mixing levels
+ * (DCSExplorer.cpp:1742-1810), and the same as input for dcs_decode_stream_sequence */
+DcsStatus   dcs_romset_extract_plan(const DcsRomSet *rs, DcsExtractItem *items, uint32_t cap, uint32_t *nOut);
+DcsStatus   dcs_romset_stream_refs(const DcsRomSet *rs, const DcsExtractItem *items, uint32_t n, int volume,
+                                   DcsStreamRef *refs);
+
+/* ------------------------------------------------------------------------------------------------
  * Output formats of the reference's extraction and validation modes.
  */
 /* the 44-byte WAV header of ExtractToWAV (DCSExplorer.cpp:1686-1699): mono, 16 bit, 31 250 Hz, nFrames x 240 samples */

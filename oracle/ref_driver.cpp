@@ -297,4 +297,87 @@ int ref_decode_sequence(int os, int volume, int n, const uint8_t *const *streams
     return 0;
 }
 
+// ROM ingestion: everything the reference derives from a set of ROM images, as text, one item
+// per line -- CheckROMs, the catalog, every track's TrackInfo and decompiled program, ListStreams with
+// MakeROMPointer, and the stream list of the --extract-streams loop (the loop itself lives in the Windows
+// program DCSExplorer.cpp:1742-1810; its 20 lines of level tracking are restated here on top of the
+// reference's DecompileTrackProgram).  forceHw/forceOs >= 0 override what CheckROMs detected (synthetic
+// images carry no ADSP code to detect the OS version from).  Returns the text length.
+size_t ref_rom_dump(const uint8_t *const *roms, const size_t *sizes, int forceHw, int forceOs, char *out, size_t cap)
+{
+    DCSDecoder::MinHost host;
+    DCSDecoderNative dec(&host);
+    for (int i = 0 ; i < 8 ; ++i)
+        if (roms[i] != nullptr && sizes[i] != 0)
+            dec.AddROM(i + 2, roms[i], sizes[i]);
+    std::string t;
+    char line[512];
+    const int status = dec.CheckROMs();
+    auto hwNum = [](DCSDecoder::HWVersion h) { return h == DCSDecoder::HWVersion::DCS93 ? 2 : h == DCSDecoder::HWVersion::DCS95 ? 3 : h == DCSDecoder::HWVersion::Invalid ? 1 : 0; };
+    auto osNum = [](DCSDecoder::OSVersion o) { return o == DCSDecoder::OSVersion::OS93a ? 0 : o == DCSDecoder::OSVersion::OS93b ? 1 : o == DCSDecoder::OSVersion::OS94 ? 2 : o == DCSDecoder::OSVersion::OS95 ? 3 : -1; };
+    snprintf(line, sizeof(line), "check status=%d hw=%d os=%d nominal=%04x catalog=%x ntracks=%u sig=%s\n", status,
+             hwNum(dec.hwVersion), osNum(dec.osVersion), dec.nominalVersion, dec.GetCatalogOffset(),
+             static_cast<unsigned>(dec.catalog.nTracks), dec.GetSignature().c_str());
+    t += line;
+    if (forceHw >= 0)
+        dec.hwVersion = forceHw == 3 ? DCSDecoder::HWVersion::DCS95 : DCSDecoder::HWVersion::DCS93;
+    if (forceOs >= 0)
+        dec.osVersion = OsFromInt(forceOs);
+    std::unordered_set<uint32_t> seen;
+    std::string plan;
+    for (unsigned trackNum = 0 ; trackNum < dec.catalog.nTracks ; ++trackNum)
+    {
+        DCSDecoder::TrackInfo ti;
+        if (!dec.GetTrackInfo(static_cast<uint16_t>(trackNum), ti))
+            continue;
+        snprintf(line, sizeof(line), "track %u addr=%06x ch=%d type=%d defer=%04x time=%u loop=%d\n", trackNum, ti.address,
+                 ti.channel, ti.type, ti.deferCode & 0xFFFF, ti.time, ti.looping ? 1 : 0);
+        t += line;
+        if (ti.type != 1)
+            continue;
+        int mixerLevel[8] = { 0x64, 0x64, 0x64, 0x64, 0x64, 0x64, 0x64, 0x64 };
+        int streamNum = 0;
+        for (auto &op : dec.DecompileTrackProgram(static_cast<uint16_t>(trackNum)))
+        {
+            snprintf(line, sizeof(line), " op off=%d nest=%d parent=%d delay=%04x opc=%02x n=%d bytes=", op.offset, op.nestingLevel,
+                     op.loopParent, op.delayCount, op.opcode, op.nOperandBytes);
+            t += line;
+            for (int i = 0 ; i < op.nOperandBytes && i < 8 ; ++i)
+            {
+                snprintf(line, sizeof(line), "%02x", op.operandBytes[i]);
+                t += line;
+            }
+            t += "\n";
+            const int ch = op.operandBytes[0] & 7;
+            if (op.opcode == 0x07 || op.opcode == 0x0A) mixerLevel[ch] = op.operandBytes[1];
+            else if (op.opcode == 0x08 || op.opcode == 0x0B) mixerLevel[ch] += op.operandBytes[1];
+            else if (op.opcode == 0x09 || op.opcode == 0x0A) mixerLevel[ch] -= op.operandBytes[1];
+            else if (op.opcode == 0x01)
+            {
+                const uint32_t addr = (op.operandBytes[1] << 16) | (op.operandBytes[2] << 8) | op.operandBytes[3];
+                if (seen.insert(addr).second)
+                {
+                    snprintf(line, sizeof(line), "extract track=%u num=%d addr=%06x level=%d\n", trackNum, ++streamNum, addr, mixerLevel[ch]);
+                    plan += line;
+                }
+            }
+        }
+    }
+    for (uint32_t addr : dec.ListStreams())
+    {
+        auto rp = dec.MakeROMPointer(addr);
+        const auto &rom = dec.ROM[rp.chipSelect];
+        snprintf(line, sizeof(line), "stream %06x chip=%d off=%zx\n", addr, rp.NominalChipNumber(), static_cast<size_t>(rp.p - rom.data));
+        t += line;
+    }
+    t += plan;
+    if (out != nullptr && cap != 0)
+    {
+        const size_t n = t.size() < cap - 1 ? t.size() : cap - 1;
+        memcpy(out, t.data(), n);
+        out[n] = 0;
+    }
+    return t.size();
+}
+
 }   // extern "C"
