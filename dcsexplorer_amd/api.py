@@ -89,6 +89,9 @@ EXPORTS = [
     "dcs_romset_load_zip_memory", "dcs_romset_check", "dcs_romset_set_version", "dcs_romset_num_tracks",
     "dcs_romset_pointer", "dcs_romset_track_info", "dcs_romset_decompile", "dcs_romset_list_streams",
     "dcs_romset_extract_plan", "dcs_romset_stream_refs",
+    "dcs_seq_create", "dcs_seq_destroy", "dcs_seq_last_error", "dcs_seq_set_master_volume", "dcs_seq_set_reported_version",
+    "dcs_seq_write_data_port", "dcs_seq_add_track_command", "dcs_seq_clear_tracks", "dcs_seq_load_audio_stream",
+    "dcs_seq_plan", "dcs_seq_pending_ticks", "dcs_seq_is_fatal", "dcs_seq_host_bytes", "dcs_seq_decode",
 ]
 
 
@@ -204,6 +207,24 @@ def load_library():
     L.dcs_romset_extract_plan.argtypes = [vp, vp, u32, ctypes.POINTER(u32)]
     L.dcs_romset_stream_refs.restype = i32
     L.dcs_romset_stream_refs.argtypes = [vp, vp, u32, ctypes.c_int, vp]
+    L.dcs_seq_create.restype = vp
+    L.dcs_seq_create.argtypes = [vp]
+    L.dcs_seq_destroy.restype = None
+    L.dcs_seq_destroy.argtypes = [vp]
+    L.dcs_seq_last_error.restype = ctypes.c_char_p
+    L.dcs_seq_last_error.argtypes = [vp]
+    for name, args in (("dcs_seq_set_master_volume", [vp, ctypes.c_int]), ("dcs_seq_set_reported_version", [vp, ctypes.c_uint16]),
+                       ("dcs_seq_write_data_port", [vp, ctypes.c_uint8]), ("dcs_seq_add_track_command", [vp, ctypes.c_uint16]),
+                       ("dcs_seq_clear_tracks", [vp]), ("dcs_seq_load_audio_stream", [vp, ctypes.c_int, u32, ctypes.c_int]),
+                       ("dcs_seq_plan", [vp, u32]), ("dcs_seq_decode", [vp, vp, vp, sz, vp])):
+        getattr(L, name).restype = i32
+        getattr(L, name).argtypes = args
+    L.dcs_seq_pending_ticks.restype = u32
+    L.dcs_seq_pending_ticks.argtypes = [vp]
+    L.dcs_seq_is_fatal.restype = ctypes.c_int
+    L.dcs_seq_is_fatal.argtypes = [vp]
+    L.dcs_seq_host_bytes.restype = u32
+    L.dcs_seq_host_bytes.argtypes = [vp, vp, u32]
     L.dcs_index_streams.restype = i32
     L.dcs_index_streams.argtypes = [vp, u32, ctypes.c_int, vp, vp, vp]
     L.dcs_index_streams_gpu.restype = i32
@@ -721,3 +742,66 @@ class RomSet:
 def _rs_check(st, rs):
     if st != 0:
         raise DcsError(st, rs.L.dcs_romset_last_error(rs.h).decode())
+
+
+class Sequencer:
+    """DcsSequencer: the track-program VM in front of the frame decode (csrc/dcs_sequencer.cpp)"""
+
+    def __init__(self, romset, volume=255):
+        self.L = load_library()
+        self.rs = romset                        # keep the ROM set alive
+        self.h = ctypes.c_void_p(self.L.dcs_seq_create(romset.h))
+        if not self.h:
+            raise DcsError(ERR_INVALID_ARG, "dcs_seq_create: ROM set without U2 or without versions")
+        self.L.dcs_seq_set_master_volume(self.h, volume)
+
+    def close(self):
+        if self.h:
+            self.L.dcs_seq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def event(self, kind, value):
+        """kind 0 data-port byte, 1 track command, 2 master volume, 3 ClearTracks"""
+        if kind == 0: self.L.dcs_seq_write_data_port(self.h, value)
+        elif kind == 1: self.L.dcs_seq_add_track_command(self.h, value)
+        elif kind == 2: self.L.dcs_seq_set_master_volume(self.h, value)
+        elif kind == 3: self.L.dcs_seq_clear_tracks(self.h)
+
+    def run_script(self, n_ticks, events):
+        """plan n_ticks ticks, applying the (tick, kind, value) events before their tick"""
+        e = 0
+        events = sorted(events, key=lambda x: x[0])
+        for t in range(n_ticks):
+            while e < len(events) and events[e][0] <= t:
+                self.event(events[e][1], events[e][2])
+                e += 1
+            st = self.L.dcs_seq_plan(self.h, 1)
+            if st != 0:
+                raise DcsError(st, self.L.dcs_seq_last_error(self.h).decode())
+
+    @property
+    def pending_ticks(self):
+        return self.L.dcs_seq_pending_ticks(self.h)
+
+    @property
+    def fatal(self):
+        return bool(self.L.dcs_seq_is_fatal(self.h))
+
+    def host_bytes(self):
+        n = self.L.dcs_seq_host_bytes(self.h, None, 0)
+        a = np.zeros((max(n, 1), 2), dtype=np.uint32)
+        self.L.dcs_seq_host_bytes(self.h, _ptr(a), n)
+        return [(int(t), int(b)) for t, b in a[:n]]
+
+    def decode(self, ctx):
+        n = self.pending_ticks
+        pcm = np.zeros((n, FRAME_SAMPLES), dtype=np.int16)
+        err = np.zeros(max(n, 1), dtype=np.uint32)
+        _check(self.L.dcs_seq_decode(ctx.h, self.h, _ptr(pcm), n, _ptr(err)), ctx.h)
+        return pcm, err[:n]

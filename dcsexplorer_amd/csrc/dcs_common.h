@@ -64,6 +64,9 @@ struct DcsDevTables
 // host-side view (same structure; one process-wide immutable instance)
 const DcsDevTables &dcsTables();
 
+// MainLoop's shared fixed-point scale with a per-channel master multiplier (dcs_params.cpp)
+int dcsFrameScaleV(const uint16_t *vol, uint16_t *mixMul, const uint8_t *counted, int nch);
+
 // ---------------------------------------------------------------------------------------------
 // Kernel work list.  The planner (dcs_plan.cpp) cuts the job list into chunks of at most FPW slots;
 // one wavefront decodes one chunk.  A slot is a job to decode; HALO slots are decoded only for the

@@ -60,23 +60,36 @@ extern "C" uint16_t dcs_mixing_multiplier(DcsOsVersion os, int levelSum, int cha
     return static_cast<uint16_t>(acc << 1);
 }
 
-extern "C" int dcs_frame_scale(uint16_t volMult, uint16_t *mixMul, const uint8_t *active, int nch)
+// The scale block of MainLoop (:227-269) in its general form: channel i counts towards the sum when
+// counted[i] is set and is multiplied by vol[i] (the master multiplier, or 0x7FFE for a channel with the
+// "maximum mixing level" override, :232-236, :262-266).
+int dcsFrameScaleV(const uint16_t *vol, uint16_t *mixMul, const uint8_t *counted, int nch)
 {
     // sum of (mixing multiplier x master multiplier) over the channels with a stream, in 4.28 after
     // the >>2; its exponent picks the shift that keeps the mixed spectrum inside 1.15 (:227-260)
     uint64_t sum = 0;
     for (int i = 0 ; i < nch ; ++i)
-        if (active == nullptr || active[i])
-            sum += static_cast<uint64_t>(mixMul[i]) * volMult;
+        if (counted == nullptr || counted[i])
+            sum += static_cast<uint64_t>(mixMul[i]) * vol[i];
     sum >>= 2;
     int shift = -(expOf(static_cast<uint32_t>(sum)) + 3);
     shift = shift < 0 ? 0 : shift > 8 ? 8 : shift;
     for (int i = 0 ; i < nch ; ++i)
     {
-        const uint64_t m = (static_cast<uint64_t>(mixMul[i]) * volMult) << 1;      // :264-269
+        const uint64_t m = (static_cast<uint64_t>(mixMul[i]) * vol[i]) << 1;       // :264-269
         mixMul[i] = static_cast<uint16_t>((m << shift) >> 16);
     }
     return shift;
+}
+
+extern "C" int dcs_frame_scale(uint16_t volMult, uint16_t *mixMul, const uint8_t *active, int nch)
+{
+    uint16_t vol[DCS_MAX_CHANNELS];
+    if (nch < 0 || nch > DCS_MAX_CHANNELS)
+        return 0;
+    for (int i = 0 ; i < nch ; ++i)
+        vol[i] = volMult;
+    return dcsFrameScaleV(vol, mixMul, active, nch);
 }
 
 extern "C" DcsStatus dcs_stream_params(DcsOsVersion os, int volume, int level, int channelVolume,

@@ -20,51 +20,7 @@
 #include <string>
 #include <vector>
 
-namespace {
-
-struct RomImage
-{
-    std::vector<uint8_t> data;
-    bool present = false;
-};
-
-// a position inside one ROM image; reads past the image give 0xFF
-struct Cursor
-{
-    const std::vector<uint8_t> *rom = nullptr;
-    size_t pos = 0;
-    uint32_t u8() { const uint32_t v = (rom != nullptr && pos < rom->size()) ? (*rom)[pos] : 0xFFu; ++pos; return v; }
-    uint32_t u16() { const uint32_t h = u8(); return (h << 8) | u8(); }
-    uint32_t u24() { const uint32_t h = u16(); return (h << 8) | u8(); }
-    void skip(size_t n) { pos += n; }
-};
-
-}   // namespace
-
-struct DcsRomSet
-{
-    RomImage rom[8];                    // U2..U9
-    std::vector<uint8_t> missing;       // stand-in for unpopulated chips: 8 KB of 0xFF (:262-281)
-    uint32_t catalogOfs = 0;
-    uint32_t trackIndex = 0;            // offset in U2 of the 3-byte-per-track index
-    uint32_t nTracks = 0;
-    int hw = DCS_HW_UNKNOWN;
-    int os = -1;                        // DcsOsVersion, -1 = not known
-    uint32_t nominalVersion = 0;
-    std::string lastError;
-
-    const std::vector<uint8_t> &image(int chipSelect) const
-    {
-        return rom[chipSelect & 7].present ? rom[chipSelect & 7].data : missing;
-    }
-    // MakeROMPointer (:68-76): chip select from bits 21.. (DCS-95) or 20.. (DCS-93), offset masked to the ROM size
-    Cursor at(uint32_t linear) const
-    {
-        const int cs = static_cast<int>((linear >> (hw == DCS_HW_DCS95 ? 21 : 20)) & 7);
-        const std::vector<uint8_t> &img = image(cs);
-        return Cursor{ &img, static_cast<size_t>(linear & static_cast<uint32_t>(img.size() - 1)) };
-    }
-};
+#include "dcs_rom.h"
 
 namespace {
 
@@ -188,16 +144,17 @@ extern "C" DcsStatus dcs_romset_add_rom(DcsRomSet *rs, int chip, const uint8_t *
         rs->lastError = "ROM size is not a power of two";      // MakeROMPointer masks offsets with size - 1
         return DCS_ERR_INVALID_ARG;
     }
-    RomImage &r = rs->rom[chip - 2];
+    DcsRomImage &r = rs->rom[chip - 2];
     r.data.assign(data, data + size);
     r.present = true;
     if (chip == 2)
     {
         rs->catalogOfs = findCatalog(r.data);
-        rs->trackIndex = 0; rs->nTracks = 0;
+        rs->trackIndex = 0; rs->indirectIndex = 0; rs->nTracks = 0;
         if (rs->catalogOfs != 0)
         {
             rs->trackIndex = be24(r.data, rs->catalogOfs + 0x40);
+            rs->indirectIndex = be24(r.data, rs->catalogOfs + 0x43);
             rs->nTracks = be16(r.data, rs->catalogOfs + 0x46);
         }
     }
@@ -306,7 +263,7 @@ extern "C" DcsStatus dcs_romset_pointer(const DcsRomSet *rs, uint32_t linear, co
 {
     if (rs == nullptr || p == nullptr || avail == nullptr)
         return DCS_ERR_INVALID_ARG;
-    const Cursor c = rs->at(linear);
+    const DcsRomCursor c = rs->at(linear);
     *p = c.rom->data() + c.pos;
     *avail = c.rom->size() - c.pos;
     if (chip != nullptr)
@@ -327,7 +284,7 @@ extern "C" DcsStatus dcs_romset_track_info(const DcsRomSet *rs, uint32_t track, 
     const uint32_t addr = be24(rs->rom[0].data, rs->trackIndex + static_cast<size_t>(track) * 3);
     if ((addr & 0x00FF0000u) == 0x00FF0000u)
         return DCS_ERR_BAD_STREAM;                  // not populated
-    Cursor p = rs->at(addr);
+    DcsRomCursor p = rs->at(addr);
     const uint32_t type = p.u8(), ch = p.u8();
     if (ch > 7)
         return DCS_ERR_BAD_STREAM;
@@ -360,7 +317,7 @@ extern "C" DcsStatus dcs_romset_track_info(const DcsRomSet *rs, uint32_t track, 
         case 0x01:
             {
                 p.u8();
-                Cursor stream = rs->at(p.u24());
+                DcsRomCursor stream = rs->at(p.u24());
                 const uint32_t repeat = p.u8();
                 const uint32_t streamTime = stream.u16();
                 stack.back().loopingStreamTime = repeat == 0 ? streamTime : 0;
@@ -415,7 +372,7 @@ static DcsStatus decompile(const DcsRomSet *rs, uint32_t track, std::vector<DcsT
     DcsTrackInfo ti;
     if (dcs_romset_track_info(rs, track, &ti) != DCS_OK || ti.type != 1)
         return DCS_OK;                              // no byte-code program: empty list, as the reference
-    Cursor p = rs->at(ti.address);
+    DcsRomCursor p = rs->at(ti.address);
     const size_t start = p.pos;
     p.skip(2);
     std::vector<int> loops;
@@ -531,7 +488,7 @@ extern "C" DcsStatus dcs_romset_stream_refs(const DcsRomSet *rs, const DcsExtrac
         return DCS_ERR_INVALID_ARG;
     for (uint32_t i = 0 ; i < n ; ++i)
     {
-        const Cursor c = rs->at(items[i].address);
+        const DcsRomCursor c = rs->at(items[i].address);
         refs[i].data = c.rom->data() + c.pos;
         refs[i].len = c.rom->size() - c.pos;
         refs[i].os = rs->os;

@@ -1,0 +1,708 @@
+// dcs_sequencer.cpp -- the track-program sequencer in front of the frame decode: everything
+// DCSDecoderNative::MainLoop does in a 7.68 ms tick EXCEPT decompress and transform, run on the host for
+// any number of ticks ahead, producing the batch (which frame of which stream on which channel, at which
+// mixing multiplier, with which shared scale) that one kernel launch then decodes.
+//
+// Mirrors, with the same audible result and the same bytes sent to the host:
+//   MainLoop: forced-stop sweep, command queue, ExecTrack per channel, shared scale   DCSDecoderNative.cpp:89-306
+//   LoadTrack / ExecTrack (opcodes 00-12), loop stack, MixingLevelOp                  :826-1371
+//   LoadAudioStream / InitChannelStream / DecodeStream (looping, end of stream)       :1387-1463, :1546-1589
+//   UpdateMixingLevels (fades, multiplier, track counters, host event timers)         :3042-3135
+//   IRQ2Handler (data-port protocol: track commands, volume, version query)           :3297-3437
+//   the sample pump's ResetException retry                                            DCSDecoder.cpp:1579-1690
+// Opcodes 10-12 only feed state no audio depends on (DCSDecoderNative.h:645); they are parsed and ignored.
+// Defined where the reference is not: a channel operand >= 8 or a track whose type byte is > 3 takes the
+// reference's ResetException path; a zero-frame stream is not played.
+#include "dcs_rom.h"
+#include <string.h>
+#include <deque>
+#include <map>
+#include <memory>
+#include <vector>
+
+namespace {
+
+struct ResetException { };
+
+struct StreamEntry
+{
+    std::vector<DcsFrameIndex> index;
+    DcsStreamInfo info;
+    uint64_t blobOff = 0;
+};
+
+struct Mixer
+{
+    int cur = 0, target = 0, delta = 0, steps = 0;
+    void reset() { cur = 0; target = 0; steps = 0; }           // (the delta survives, :489)
+};
+
+struct LoopPos { uint32_t counter; DcsRomCursor pos; };
+
+struct Chan
+{
+    bool stop = false;
+    DcsRomCursor track;                     // null = no program
+    uint32_t trackCounter = 0;              // uint16 in the reference
+    struct { uint8_t data = 0; uint16_t interval = 0, counter = 0; } timer;
+    std::vector<LoopPos> loops;
+    uint8_t nextTrackType = 0;
+    uint16_t nextTrackLink = 0;
+    Mixer mixer[DCS_MAX_CHANNELS];
+    int sourceChannel = -1;
+    uint16_t channelVolume = 0xFF;
+    bool maxOverride = false;
+    uint16_t mixMul = 0x7FFF;               // Channel::mixingMultiplier (DCSDecoderNative.h:514)
+    // audio stream
+    const StreamEntry *st = nullptr;        // null = nothing playing
+    uint32_t frameCounter = 0, loopCounter = 0, pos = 0;
+};
+
+}   // namespace
+
+struct DcsSequencer
+{
+    const DcsRomSet *rs = nullptr;
+    int os = DCS_OS94;
+    bool totan = false;                     // GameID::TOTAN quirk of the data-port handler (:3345-3351)
+    uint16_t volumeMultiplier = 0x0391;     // DCSDecoderNative.h:161
+    uint16_t reportedVersion = 0x0106;
+    Chan ch[DCS_MAX_CHANNELS];
+    std::deque<uint16_t> commandQueue;
+    std::deque<uint8_t> dataPortQueue;
+    uint8_t lastDataPortByte = 0;
+    int nDataPortBytes = 0;
+    uint16_t dataPortWord = 0, dataPortExt = 0;
+    int dataPortTimeout = 0;
+    uint8_t variables[256] = { 0 };
+    bool fatal = false;
+    uint64_t tick = 0;
+
+    // the batch planned so far
+    std::map<std::pair<const void *, size_t>, std::unique_ptr<StreamEntry>> streams;
+    std::vector<uint8_t> blob;
+    std::vector<DcsSrcDesc> srcs;
+    std::vector<DcsFrameJob> jobs;
+    std::vector<DcsHostByte> hostBytes;
+    int16_t tail[16] = { 0 };
+    std::string lastError;
+
+    void toHost(uint8_t b) { hostBytes.push_back(DcsHostByte{ static_cast<uint32_t>(tick), static_cast<uint32_t>(b) }); }
+    Chan &chan(uint32_t c)
+    {
+        if (c >= DCS_MAX_CHANNELS)
+            throw ResetException();
+        return ch[c];
+    }
+    void resetMixingLevels(int c)           // :3233-3239: channel c's contribution to every channel's mix
+    {
+        for (Chan &x : ch)
+            x.mixer[c].reset();
+    }
+
+    const StreamEntry *streamAt(DcsRomCursor p);
+    void loadAudioStream(uint32_t streamChannel, int sourceChannel, uint32_t loopCounter, DcsRomCursor p);
+    void loadTrack(uint32_t c, DcsRomCursor p);
+    void execTrack(int c);
+    void mixingLevelOp(int cur, DcsRomCursor &p, int mode, bool fade);
+    void irq2(uint8_t data);
+    void mainLoop();
+};
+
+// the stream at a ROM position: indexed once, its bytes copied once into the batch's blob
+const StreamEntry *DcsSequencer::streamAt(DcsRomCursor p)
+{
+    const auto key = std::make_pair(static_cast<const void *>(p.rom), p.pos);
+    auto it = streams.find(key);
+    if (it != streams.end())
+        return it->second.get();
+    std::unique_ptr<StreamEntry> e(new StreamEntry);
+    const uint8_t *data = p.rom->data() + p.pos;
+    const size_t avail = p.rom->size() - p.pos;
+    const uint32_t nFrames = avail >= 2 ? (static_cast<uint32_t>(data[0]) << 8) | data[1] : 0;
+    if (nFrames != 0 && avail >= 3)
+    {
+        e->index.resize(nFrames);
+        if (dcs_index_stream(static_cast<DcsOsVersion>(os), data, avail, e->index.data(), nFrames, &e->info) != DCS_OK)
+            e->index.clear();
+        else
+            e->index.resize(static_cast<size_t>(e->info.nValidFrames));
+    }
+    if (!e->index.empty())
+    {
+        while (blob.size() & 3)
+            blob.push_back(0);
+        e->blobOff = blob.size();
+        const size_t used = static_cast<size_t>(e->info.nBytes) < avail ? static_cast<size_t>(e->info.nBytes) : avail;
+        blob.insert(blob.end(), data, data + used);
+        blob.insert(blob.end(), static_cast<size_t>(e->info.nBytes) - used + 16, 0);
+    }
+    const StreamEntry *r = e.get();
+    streams[key] = std::move(e);
+    return r;
+}
+
+// LoadAudioStream (:1408-1431) + InitChannelStream (:1433-1463)
+void DcsSequencer::loadAudioStream(uint32_t streamChannel, int source, uint32_t loopCounter, DcsRomCursor p)
+{
+    Chan &c = chan(streamChannel);
+    const StreamEntry *e = streamAt(p);
+    if (e->index.empty())
+    {
+        c.st = nullptr;                     // zero frames (or unusable): nothing to play
+        return;
+    }
+    c.st = e;
+    c.frameCounter = static_cast<uint32_t>(e->info.nFrames);
+    c.pos = 0;
+    c.loopCounter = loopCounter;
+    if (c.sourceChannel >= 0 && c.sourceChannel != source)
+        c.mixer[c.sourceChannel].reset();
+    c.sourceChannel = source;
+}
+
+void DcsSequencer::loadTrack(uint32_t cn, DcsRomCursor p)       // :826-836
+{
+    Chan &c = chan(cn);
+    c.track = p;
+    c.st = nullptr;
+    c.trackCounter = 0;
+    c.timer.interval = c.timer.counter = 0;
+    c.loops.clear();
+    resetMixingLevels(static_cast<int>(cn));
+}
+
+void DcsSequencer::mixingLevelOp(int cur, DcsRomCursor &p, int mode, bool fade)     // :1316-1371
+{
+    const uint32_t target = p.u8();
+    const int param = static_cast<int>(static_cast<int8_t>(p.u8())) << 6;
+    const int steps = fade ? static_cast<int>(p.u16()) : 0;
+    Mixer &m = chan(target).mixer[cur];
+    m.steps = steps;
+    const int oldLevel = m.cur;
+    int newLevel = mode == 0 ? param : mode == 1 ? oldLevel + param : oldLevel - param;
+    const int delta = newLevel - oldLevel;
+    newLevel = newLevel > 8191 ? 8191 : newLevel < -8191 ? -8191 : newLevel;
+    m.target = newLevel;
+    if (steps != 0)
+        m.delta = delta / steps;
+    else
+        m.cur = newLevel;
+}
+
+void DcsSequencer::execTrack(int cur)       // :838-1290
+{
+    Chan &me = ch[cur];
+    DcsRomCursor p = me.track;
+    if (p.isNull())
+        return;
+    for (;;)
+    {
+        const uint32_t countPrefix = p.u16();
+        if (countPrefix == 0xFFFF || (me.trackCounter & 0xFFFF) != countPrefix)
+        {
+            p.skip(-2);
+            me.track = p;
+            return;
+        }
+        me.trackCounter = 0;
+        const uint32_t opcode = p.u8();
+        switch (opcode)
+        {
+        case 0x00:
+            me.track.clear();
+            me.st = nullptr;
+            me.loops.clear();
+            me.timer.interval = me.timer.counter = 0;
+            resetMixingLevels(cur);
+            return;
+
+        case 0x01:
+            {
+                const uint32_t streamChannel = p.u8();
+                if (streamChannel == 5)
+                    ch[5].maxOverride = false;
+                const DcsRomCursor stream = rs->at(p.u24());
+                const uint32_t loopCounter = p.u8();
+                loadAudioStream(streamChannel, cur, loopCounter, stream);
+            }
+            break;
+
+        case 0x02:
+            {
+                Chan &t = chan(p.u8());
+                if (t.st != nullptr)
+                {
+                    t.st = nullptr;
+                    resetMixingLevels(static_cast<int>(&t - ch));
+                }
+                t.track.clear();
+                t.timer.interval = t.timer.counter = 0;
+                if (me.track.isNull())
+                    return;
+            }
+            break;
+
+        case 0x03:
+            commandQueue.push_back(static_cast<uint16_t>(p.u16()));
+            break;
+
+        case 0x04:
+            if (os == DCS_OS93A)
+            {
+                const uint8_t cmdByte = static_cast<uint8_t>(p.u8());
+                const uint16_t counter = static_cast<uint16_t>(p.u16());
+                if (cmdByte == 0)
+                    me.timer.interval = me.timer.counter = 0;
+                else
+                {
+                    toHost(cmdByte);
+                    me.timer.data = cmdByte;
+                    me.timer.interval = me.timer.counter = counter;         // 0 = cleared
+                }
+            }
+            else
+            {
+                const uint8_t b = static_cast<uint8_t>(p.u8());
+                toHost(b);
+                if (rs->nominalVersion == 0x0105)
+                {
+                    if (b == 0x69) ch[5].maxOverride = true;
+                    else if (b == 0x6A) ch[5].maxOverride = false;
+                }
+            }
+            break;
+
+        case 0x05:
+            {
+                Chan &t = chan(p.u8());
+                const uint8_t type = t.nextTrackType;
+                if (type == 0)
+                    break;
+                t.nextTrackType = 0;
+                if (type == 2)
+                    commandQueue.push_back(t.nextTrackLink);
+                else if (type == 3)
+                {
+                    const uint32_t lo = t.nextTrackLink & 0xFF, hi = (t.nextTrackLink >> 8) & 0xFF;
+                    DcsRomCursor table = rs->at(rs->u2U24(rs->indirectIndex + lo * 3));
+                    table.skip(static_cast<long>(variables[hi]) * 2);
+                    commandQueue.push_back(static_cast<uint16_t>(table.u16()));
+                }
+            }
+            break;
+
+        case 0x06:
+            if (os != DCS_OS93A && os != DCS_OS93B)     // (the 1993 software reads no operands here, :1092-1100)
+            {
+                const uint32_t var = p.u8();
+                variables[var] = static_cast<uint8_t>(p.u8());
+            }
+            break;
+
+        case 0x07: case 0x08: case 0x09:
+            mixingLevelOp(cur, p, static_cast<int>(opcode) - 0x07, false);
+            break;
+        case 0x0A: case 0x0B: case 0x0C:
+            mixingLevelOp(cur, p, static_cast<int>(opcode) - 0x0A, true);
+            break;
+
+        case 0x0D:
+            break;
+
+        case 0x0E:
+            {
+                const uint32_t counter = p.u8();
+                me.loops.push_back(LoopPos{ counter, p });
+            }
+            break;
+
+        case 0x0F:
+            if (!me.loops.empty())
+            {
+                LoopPos &top = me.loops.back();
+                if (top.counter == 0)
+                    p = top.pos;
+                else if (top.counter == 1)
+                    me.loops.pop_back();
+                else
+                {
+                    --top.counter;
+                    p = top.pos;
+                }
+            }
+            break;
+
+        case 0x10:
+            p.skip(2);
+            break;
+        case 0x11: case 0x12:
+            p.skip(4);
+            break;
+
+        default:
+            throw ResetException();
+        }
+    }
+}
+
+void DcsSequencer::irq2(uint8_t data)       // :3297-3437
+{
+    if (dataPortTimeout >= 13)
+        nDataPortBytes = 0;
+    switch (nDataPortBytes)
+    {
+    case 0:
+        dataPortWord = static_cast<uint16_t>(data << 8);
+        nDataPortBytes = 1;
+        break;
+    case 1:
+        dataPortWord |= data;
+        nDataPortBytes = 0;
+        if ((dataPortWord >= 0x55AA && dataPortWord <= 0x55B2) || (dataPortWord >= 0x55BA && dataPortWord <= 0x55C1))
+        {
+            dataPortExt = dataPortWord;
+            nDataPortBytes = 2;
+        }
+        else if (dataPortWord > 0x55B2 && dataPortWord < 0x55BA)
+            ;
+        else if (dataPortWord == 0x55C2 || dataPortWord == 0x55C3)
+            toHost(static_cast<uint8_t>((dataPortWord == 0x55C2 ? reportedVersion >> 8 : reportedVersion) & 0xFF));
+        else if (dataPortWord & 0x8000)
+            ;
+        else if (dataPortWord == 0x03E7 && totan)
+            toHost(0x11);
+        else
+            commandQueue.push_back(dataPortWord);
+        break;
+    case 2:
+        dataPortWord = data;
+        nDataPortBytes = 3;
+        break;
+    case 3:
+        if (dataPortWord == static_cast<uint16_t>(data ^ 0xFF))
+        {
+            if (dataPortExt == 0x55AA)
+                volumeMultiplier = dcs_volume_multiplier(static_cast<uint8_t>(dataPortWord));
+            else if (dataPortExt <= 0x55B2)
+            {
+                const int c = dataPortExt - 0x55AB;
+                if (c >= 0 && c < DCS_MAX_CHANNELS)
+                    ch[c].channelVolume = static_cast<uint8_t>(dataPortWord);
+            }
+        }
+        nDataPortBytes = 0;
+        break;
+    }
+    dataPortTimeout = 0;
+}
+
+// one MainLoop pass minus decompress/transform: appends one job (and its sources) to the plan
+void DcsSequencer::mainLoop()
+{
+    // forced-stop sweep (:95-116)
+    for (int c = 0 ; c < DCS_MAX_CHANNELS ; ++c)
+        if (ch[c].stop)
+        {
+            ch[c].stop = false;
+            if (ch[c].st != nullptr)
+            {
+                ch[c].st = nullptr;
+                resetMixingLevels(c);
+            }
+            ch[c].timer.interval = ch[c].timer.counter = 0;
+            ch[c].track.clear();
+        }
+
+    // pending commands = track numbers (:129-171)
+    while (!commandQueue.empty())
+    {
+        const uint16_t cmd = commandQueue.front();
+        commandQueue.pop_front();
+        if (cmd >= rs->nTracks)
+            continue;
+        const uint32_t trackOfs = rs->u2U24(rs->trackIndex + static_cast<size_t>(cmd) * 3);
+        if ((trackOfs & 0xFF0000u) == 0xFF0000u)
+            continue;
+        DcsRomCursor p = rs->at(trackOfs);
+        const uint32_t type = p.u8(), c = p.u8();
+        if (type == 1)
+            loadTrack(c, p);
+        else if (type <= 3)
+        {
+            Chan &t = chan(c);
+            t.nextTrackType = static_cast<uint8_t>(type);
+            t.nextTrackLink = static_cast<uint16_t>(p.u16());
+        }
+        else
+            throw ResetException();
+    }
+
+    // the track programs, channel by channel (:184-197)
+    for (int c = 0 ; c < DCS_MAX_CHANNELS ; ++c)
+        execTrack(c);
+
+    // shared scale (:227-269)
+    uint16_t vol[DCS_MAX_CHANNELS], mm[DCS_MAX_CHANNELS];
+    uint8_t counted[DCS_MAX_CHANNELS];
+    for (int c = 0 ; c < DCS_MAX_CHANNELS ; ++c)
+    {
+        vol[c] = ch[c].maxOverride ? 0x7FFE : volumeMultiplier;
+        counted[c] = (ch[c].maxOverride || ch[c].st != nullptr) ? 1 : 0;
+        mm[c] = ch[c].mixMul;
+    }
+    const int volShift = dcsFrameScaleV(vol, mm, counted, DCS_MAX_CHANNELS);
+
+    // DecodeStream per channel (:1546-1589): which frame of which stream, then the stream's own bookkeeping
+    DcsFrameJob jb;
+    memset(&jb, 0, sizeof(jb));
+    jb.firstSrc = static_cast<uint32_t>(srcs.size());
+    jb.volShift = static_cast<uint8_t>(volShift);
+    jb.xform = (os == DCS_OS93A || os == DCS_OS93B) ? DCS_XFORM_93 : DCS_XFORM_94;
+    jb.prev = jobs.empty() ? (DCS_PREV_EXT | 0u) : static_cast<uint32_t>(jobs.size() - 1);
+    for (int c = 0 ; c < DCS_MAX_CHANNELS ; ++c)
+    {
+        Chan &x = ch[c];
+        if (x.st == nullptr)
+            continue;
+        if (x.pos < x.st->index.size())
+        {
+            DcsSrcDesc sd;
+            memset(&sd, 0, sizeof(sd));
+            sd.streamOff = x.st->blobOff;
+            sd.mixMul = mm[c];
+            sd.format = static_cast<uint8_t>(x.st->info.format);
+            sd.hdrLen = static_cast<uint8_t>(x.st->info.hdrLen);
+            sd.idx = x.st->index[x.pos];
+            srcs.push_back(sd);
+            ++jb.nSrc;
+            if ((sd.idx.flags >> 4) != 0)
+                x.stop = true;              // the frame decoder raises the channel's stop flag (:1989, :2216)
+        }
+        ++x.pos;
+        if (--x.frameCounter != 0)
+            continue;
+        x.frameCounter = static_cast<uint32_t>(x.st->info.nFrames);
+        x.pos = 0;
+        if (x.loopCounter == 0)
+            continue;
+        if (--x.loopCounter != 0)
+            continue;
+        x.st = nullptr;
+        x.sourceChannel = -1;
+    }
+    jobs.push_back(jb);
+
+    // UpdateMixingLevels (:3042-3135): fades, next tick's multipliers, track counters, host event timers
+    for (Chan &x : ch)
+        for (Mixer &m : x.mixer)
+        {
+            if (m.steps == 1)
+            {
+                m.steps = 0;
+                m.cur = m.target;
+            }
+            else if (m.steps > 1)
+            {
+                --m.steps;
+                m.cur += m.delta;
+                m.cur = m.cur > 8191 ? 8191 : m.cur < -8191 ? -8191 : m.cur;
+            }
+        }
+    for (Chan &x : ch)
+    {
+        int sum = 0;
+        for (const Mixer &m : x.mixer)
+            sum += m.cur;
+        x.mixMul = x.maxOverride ? dcs_mixing_multiplier(DCS_OS95, sum, 0xFF)
+                                 : dcs_mixing_multiplier(static_cast<DcsOsVersion>(os), sum, x.channelVolume);
+    }
+    for (Chan &x : ch)
+    {
+        ++x.trackCounter;
+        if (x.timer.interval != 0 && --x.timer.counter == 0)
+        {
+            x.timer.counter = x.timer.interval;
+            toHost(x.timer.data);
+        }
+    }
+    if (++dataPortTimeout > 13)
+        dataPortTimeout = 13;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" DcsSequencer *dcs_seq_create(const DcsRomSet *rs)
+{
+    if (rs == nullptr || rs->os < 0 || !rs->rom[0].present)
+        return nullptr;
+    DcsSequencer *s = new (std::nothrow) DcsSequencer;
+    if (s == nullptr)
+        return nullptr;
+    s->rs = rs;
+    s->os = rs->os;
+    // the U2 signature names the game; one title has a data-port quirk (DCSDecoder.cpp:147, DCSDecoderNative.cpp:3345)
+    const std::vector<uint8_t> &u2 = rs->rom[0].data;
+    static const char key[] = "arabian nights";
+    for (size_t i = 4 ; i + sizeof(key) - 1 <= 128 && i + sizeof(key) - 1 <= u2.size() && u2[i] != 0 ; ++i)
+    {
+        size_t k = 0;
+        while (k < sizeof(key) - 1 && (u2[i + k] | 0x20) == key[k]) ++k;
+        if (k == sizeof(key) - 1) { s->totan = true; break; }
+    }
+    return s;
+}
+
+extern "C" void dcs_seq_destroy(DcsSequencer *s) { delete s; }
+extern "C" const char *dcs_seq_last_error(const DcsSequencer *s) { return s != nullptr ? s->lastError.c_str() : ""; }
+
+extern "C" DcsStatus dcs_seq_set_master_volume(DcsSequencer *s, int vol)
+{
+    if (s == nullptr) return DCS_ERR_INVALID_ARG;
+    s->volumeMultiplier = dcs_volume_multiplier(vol);
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_seq_set_reported_version(DcsSequencer *s, uint16_t v)
+{
+    if (s == nullptr) return DCS_ERR_INVALID_ARG;
+    s->reportedVersion = v;
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_seq_write_data_port(DcsSequencer *s, uint8_t byte)
+{
+    if (s == nullptr) return DCS_ERR_INVALID_ARG;
+    s->dataPortQueue.push_back(byte);
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_seq_add_track_command(DcsSequencer *s, uint16_t track)
+{
+    if (s == nullptr) return DCS_ERR_INVALID_ARG;
+    s->commandQueue.push_back(track);
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_seq_clear_tracks(DcsSequencer *s)       // :1466-1473
+{
+    if (s == nullptr) return DCS_ERR_INVALID_ARG;
+    for (Chan &c : s->ch)
+    {
+        c.track.clear();
+        c.st = nullptr;
+    }
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_seq_load_audio_stream(DcsSequencer *s, int channel, uint32_t linearAddress, int mixingLevel)     // :1387-1406
+{
+    if (s == nullptr || channel < 0 || channel >= DCS_MAX_CHANNELS) return DCS_ERR_INVALID_ARG;
+    Chan &c = s->ch[channel];
+    c.track.clear();
+    s->loadAudioStream(static_cast<uint32_t>(channel), channel, 1, s->rs->at(linearAddress));
+    Mixer &m = c.mixer[channel];
+    m.reset();
+    m.cur = m.target = mixingLevel << 6;
+    return DCS_OK;
+}
+
+// Run the sequencer `nTicks` ticks further; every tick appends one frame job to the pending plan.  Bytes
+// written to the data port since the last tick are handled first, as the sample pump does (DCSDecoder.cpp:1617).
+extern "C" DcsStatus dcs_seq_plan(DcsSequencer *s, uint32_t nTicks)
+{
+    if (s == nullptr) return DCS_ERR_INVALID_ARG;
+    for (uint32_t t = 0 ; t < nTicks ; ++t)
+    {
+        if (s->fatal)
+        {
+            // DecoderFatalError: silence from here on (DCSDecoder.cpp:1672-1675)
+            DcsFrameJob jb;
+            memset(&jb, 0, sizeof(jb));
+            jb.volShift = 8;
+            jb.xform = (s->os == DCS_OS93A || s->os == DCS_OS93B) ? DCS_XFORM_93 : DCS_XFORM_94;
+            jb.prev = DCS_PREV_NONE;
+            jb.flags = 0;
+            s->jobs.push_back(jb);
+            ++s->tick;
+            continue;
+        }
+        while (!s->dataPortQueue.empty())
+        {
+            s->lastDataPortByte = s->dataPortQueue.front();
+            s->dataPortQueue.pop_front();
+            s->irq2(s->lastDataPortByte);
+        }
+        const size_t jobsBefore = s->jobs.size(), srcsBefore = s->srcs.size();
+        for (int retries = 0 ; ; )
+        {
+            try
+            {
+                s->mainLoop();
+                break;
+            }
+            catch (const ResetException &)
+            {
+                // MainLoop is simply entered again, state as the failed pass left it (DCSDecoder.cpp:1624-1648)
+                s->jobs.resize(jobsBefore);
+                s->srcs.resize(srcsBefore);
+                if (++retries > 3)
+                {
+                    s->fatal = true;
+                    s->lastError = "the decoder reset itself after repeated fatal errors in the track data";
+                    break;
+                }
+            }
+        }
+        if (s->fatal)
+        {
+            --t;                            // this tick is produced by the fatal branch above
+            continue;
+        }
+        ++s->tick;
+    }
+    return DCS_OK;
+}
+
+extern "C" uint32_t dcs_seq_pending_ticks(const DcsSequencer *s) { return s != nullptr ? static_cast<uint32_t>(s->jobs.size()) : 0; }
+extern "C" int dcs_seq_is_fatal(const DcsSequencer *s) { return s != nullptr && s->fatal ? 1 : 0; }
+
+extern "C" uint32_t dcs_seq_host_bytes(DcsSequencer *s, DcsHostByte *out, uint32_t cap)
+{
+    if (s == nullptr) return 0;
+    const uint32_t n = static_cast<uint32_t>(s->hostBytes.size());
+    if (out != nullptr && cap >= n)
+    {
+        if (n != 0)
+            memcpy(out, s->hostBytes.data(), sizeof(DcsHostByte) * n);
+        s->hostBytes.clear();
+    }
+    return n;
+}
+
+// Decode everything planned since the last call in ONE launch; the overlap tail carries over to the next call.
+extern "C" DcsStatus dcs_seq_decode(DcsCtx *ctx, DcsSequencer *s, int16_t *pcmOut, size_t pcmCapFrames, uint32_t *errOut)
+{
+    if (ctx == nullptr || s == nullptr || pcmOut == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    const size_t n = s->jobs.size();
+    if (n == 0)
+        return DCS_OK;
+    if (n > pcmCapFrames)
+        return DCS_ERR_CAPACITY;
+    if (s->blob.empty())
+        s->blob.assign(16, 0);
+    std::vector<int16_t> tails(n * 16);
+    const DcsStatus st = dcs_decode_batch(ctx, s->blob.data(), s->blob.size(), s->srcs.empty() ? nullptr : s->srcs.data(),
+                                          static_cast<uint32_t>(s->srcs.size()), s->jobs.data(), static_cast<uint32_t>(n),
+                                          s->tail, 1, pcmOut, errOut, tails.data());
+    if (st != DCS_OK)
+    {
+        s->lastError = dcs_last_error(ctx);
+        return st;
+    }
+    memcpy(s->tail, &tails[(n - 1) * 16], sizeof(s->tail));
+    s->jobs.clear();
+    s->srcs.clear();
+    // the blob and the stream cache stay: streams already copied are reused by later plans
+    return DCS_OK;
+}

@@ -363,6 +363,38 @@ DcsStatus   dcs_romset_stream_refs(const DcsRomSet *rs, const DcsExtractItem *it
                                    DcsStreamRef *refs);
 
 /* ------------------------------------------------------------------------------------------------
+ * Track-program sequencer: everything DCSDecoderNative::MainLoop does per 7.68 ms tick except decompress
+ * and transform (command queue, ExecTrack opcodes 00-12, loops, deferred tracks, mixing levels and fades,
+ * looping streams, host event timers, the data-port protocol; DCSDecoderNative.cpp:89-306, :826-1371,
+ * :1387-1463, :1546-1589, :3042-3135, :3297-3437), run on the host for any number of ticks ahead.  Each
+ * tick appends one frame job to a pending plan; dcs_seq_decode turns the whole plan into PCM with ONE
+ * kernel launch.  This is what `--extract-tracks` / `--validate --autoplay` style callers need: up to 8
+ * channels mixed in the frequency domain before one transform, with the per-frame multipliers and shared
+ * scale the sequencer derives.  The ROM set must outlive the sequencer and have its versions set
+ * (dcs_romset_check or dcs_romset_set_version).
+ */
+typedef struct DcsSequencer DcsSequencer;
+typedef struct DcsHostByte { uint32_t tick; uint32_t byte; } DcsHostByte;      /* a byte the decoder sent to the host */
+
+DcsSequencer *dcs_seq_create(const DcsRomSet *rs);                   /* NULL: no U2 / versions unknown          */
+void        dcs_seq_destroy(DcsSequencer *seq);
+const char *dcs_seq_last_error(const DcsSequencer *seq);
+DcsStatus   dcs_seq_set_master_volume(DcsSequencer *seq, int volume);             /* SetMasterVolume           */
+DcsStatus   dcs_seq_set_reported_version(DcsSequencer *seq, uint16_t version);    /* answer to 55C2/55C3       */
+DcsStatus   dcs_seq_write_data_port(DcsSequencer *seq, uint8_t byte);             /* WriteDataPort             */
+DcsStatus   dcs_seq_add_track_command(DcsSequencer *seq, uint16_t track);         /* AddTrackCommand (:1475)   */
+DcsStatus   dcs_seq_clear_tracks(DcsSequencer *seq);                              /* ClearTracks (:1466)       */
+DcsStatus   dcs_seq_load_audio_stream(DcsSequencer *seq, int channel, uint32_t linearAddress, int mixingLevel);
+DcsStatus   dcs_seq_plan(DcsSequencer *seq, uint32_t nTicks);        /* run nTicks ticks, extend the pending plan  */
+uint32_t    dcs_seq_pending_ticks(const DcsSequencer *seq);
+int         dcs_seq_is_fatal(const DcsSequencer *seq);               /* DecoderFatalError after 4 failed passes    */
+/* bytes sent to the host since the last successful call; returns their number (call with out = NULL to size) */
+uint32_t    dcs_seq_host_bytes(DcsSequencer *seq, DcsHostByte *out, uint32_t cap);
+/* decode the pending plan (pcmOut = pending ticks x 240 samples) in one launch and clear it; the overlap
+ * tail carries into the next plan */
+DcsStatus   dcs_seq_decode(DcsCtx *ctx, DcsSequencer *seq, int16_t *pcmOut, size_t pcmCapFrames, uint32_t *errOut);
+
+/* ------------------------------------------------------------------------------------------------
  * Output formats of the reference's extraction and validation modes.
  */
 /* the 44-byte WAV header of ExtractToWAV (DCSExplorer.cpp:1686-1699): mono, 16 bit, 31 250 Hz, nFrames x 240 samples */

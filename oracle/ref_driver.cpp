@@ -380,4 +380,59 @@ size_t ref_rom_dump(const uint8_t *const *roms, const size_t *sizes, int forceHw
     return t.size();
 }
 
+// Track-program sequencer: the real decoder with ROMs, driven tick by tick.  events = triples
+// (tick, kind, value): kind 0 WriteDataPort(value), 1 AddTrackCommand(value), 2 SetMasterVolume(value),
+// 3 ClearTracks(); applied before the tick's first sample.  pcm = nTicks x 240; host bytes the decoder sent
+// are returned as (tick, byte) pairs.  forceNominal >= 0 overrides the detected nominal version.
+struct RefCapHost : public DCSDecoder::Host
+{
+    std::vector<uint32_t> *log; uint32_t *tick;
+    void ReceiveDataPort(uint8_t data) override { log->push_back(*tick); log->push_back(data); }
+    void ClearDataPort() override { }
+    void BootTimerControl(bool) override { }
+};
+
+int ref_seq_run(const uint8_t *const *roms, const size_t *sizes, int forceHw, int forceOs, int forceNominal, int volume,
+    const uint32_t *events, int nEvents, int nTicks, int16_t *pcm, uint32_t *hostBytes, int hostCap, int *nHost, int *fatal)
+{
+    std::vector<uint32_t> log;
+    uint32_t tick = 0;
+    RefCapHost host;
+    host.log = &log; host.tick = &tick;
+    DCSDecoderNative dec(&host);
+    for (int i = 0 ; i < 8 ; ++i)
+        if (roms[i] != nullptr && sizes[i] != 0)
+            dec.AddROM(i + 2, roms[i], sizes[i]);
+    dec.CheckROMs();
+    if (forceHw >= 0) dec.hwVersion = forceHw == 3 ? DCSDecoder::HWVersion::DCS95 : DCSDecoder::HWVersion::DCS93;
+    if (forceOs >= 0) dec.osVersion = OsFromInt(forceOs);
+    if (forceNominal >= 0) dec.nominalVersion = static_cast<uint16_t>(forceNominal);
+    dec.SetDefaultVolume(volume);
+    dec.SoftBoot();
+    dec.SetMasterVolume(volume);
+    int e = 0;
+    for (tick = 0 ; tick < static_cast<uint32_t>(nTicks) ; ++tick)
+    {
+        for ( ; e < nEvents && events[3 * e] <= tick ; ++e)
+        {
+            const uint32_t kind = events[3 * e + 1], value = events[3 * e + 2];
+            if (kind == 0) dec.WriteDataPort(static_cast<uint8_t>(value));
+            else if (kind == 1) dec.AddTrackCommand(static_cast<uint16_t>(value));
+            else if (kind == 2) dec.SetMasterVolume(static_cast<int>(value));
+            else if (kind == 3) dec.ClearTracks();
+        }
+        for (int k = 0 ; k < 240 ; ++k)
+            *pcm++ = dec.GetNextSample();
+    }
+    const int n = static_cast<int>(log.size() / 2);
+    if (nHost != nullptr) *nHost = n;
+    for (int i = 0 ; i < n && i < hostCap ; ++i)
+    {
+        hostBytes[2 * i] = log[2 * i];
+        hostBytes[2 * i + 1] = log[2 * i + 1];
+    }
+    if (fatal != nullptr) *fatal = dec.IsOK() ? 0 : 1;
+    return 0;
+}
+
 }   // extern "C"

@@ -22,7 +22,7 @@ def checksum(img):
 
 
 class RomSet:
-    def __init__(self, hw, os_, catalog_ofs, seed, n_streams=9, frames=6, version_code=True, signature="Synthetic Pinball (c) 1994 test"):
+    def __init__(self, hw, os_, catalog_ofs, seed, n_streams=9, frames=6, version_code=True, signature="Synthetic Pinball (c) 1994 test", nominal=0x0104):
         self.hw, self.os, self.catalog_ofs = hw, os_, catalog_ofs
         g = splitmix(seed)
         sizes = {2: 0x80000, 3: 0x100000, 4: 0x80000}
@@ -39,7 +39,8 @@ class RomSet:
                 for k, w in enumerate(words):
                     u2[ofs + 4 * k: ofs + 4 * k + 3] = struct.pack(">I", w)[1:]
             if hw == HW95:
-                ops(0x2000 + 0x320 * 4, [0x40104E, 0x0F16F8, 0x93300E, 0x18123F, 0x40104E, 0x0F1608, 0x0F16F8, 0x93300E, 0x18456F])
+                v = 0x400000 | (nominal << 4) | 0xE                     # SR0 = <major:minor>
+                ops(0x2000 + 0x320 * 4, [v, 0x0F16F8, 0x93300E, 0x18123F, v, 0x0F1608, 0x0F16F8, 0x93300E, 0x18456F])
             elif os_ in (D.OS93A, D.OS93B):
                 ops(0x1000 + 0x140 * 4, [0x380026, 0x3C1005, 0x0C00C0])
                 if os_ == D.OS93A:
@@ -161,3 +162,89 @@ def damage(rs, seed):
         imgs[2][0x7FFFF] = (-(ck & 0xFF)) & 0xFF
     out.images = {c: bytes(b) for c, b in imgs.items()}
     return out
+
+
+class SeqRomSet(RomSet):
+    """a ROM set whose track programs exercise the sequencer: looping and repeated streams, fades, nested and
+    endless loops, queued / deferred / deferred-indirect tracks, variables, data-port bytes and host event
+    timers, a program that plays on another channel, a stop of the own channel, an invalid opcode and an
+    invalid track type"""
+
+    def __init__(self, hw, os_, catalog_ofs, seed, version_code=True, nominal=0x0104):
+        RomSet.__init__(self, hw, os_, catalog_ofs, seed, n_streams=12, frames=5, version_code=version_code, nominal=nominal)
+        imgs = {c: bytearray(b) for c, b in self.images.items()}
+        u2 = imgs[2]
+        A = list(self.streams)
+
+        def step(delay, opcode, operands=b""):
+            return _u16(delay) + bytes([opcode]) + operands
+        def play(ch, addr, rep=1): return bytes([ch]) + _u24(addr) + bytes([rep])
+        setvar = (lambda v, x: b"") if os_ in (D.OS93A, D.OS93B) else (lambda v, x: bytes([v, x]))
+        def port(b, cnt=0): return bytes([b, cnt >> 8, cnt & 0xFF]) if os_ == D.OS93A else bytes([b])
+        end = step(0, 0x00)
+        T = []
+        T.append(bytes([1, 0]) + b"".join(step(0, 0x02, bytes([c])) for c in range(1, 6)) + step(0, 0x02, b"\0"))     # 0: stops all, itself last
+        T.append(bytes([1, 0]) + step(0, 0x07, bytes([0, 0x70])) + step(0, 0x01, play(0, A[0], 0)) + step(0xFFFF, 0x0D))   # 1
+        T.append(bytes([1, 1]) + step(0, 0x0A, bytes([1, 0x60, 0, 8])) + step(0, 0x01, play(1, A[1], 2)) + step(5, 0x08, bytes([1, 6]))
+                 + step(0, 0x0E, bytes([3])) + step(4, 0x09, bytes([1, 2])) + step(0, 0x01, play(1, A[2])) + step(0, 0x0F)
+                 + step(2, 0x03, _u16(7)) + end)                                                                       # 2
+        T.append(bytes([2, 2]) + _u16(8))                                                                              # 3: deferred -> track 8
+        T.append(bytes([3, 3]) + bytes([7, 1]))                                                                        # 4: deferred indirect: table 1 [var 7]
+        T.append(bytes([1, 2]) + step(0, 0x06, setvar(7, 2)) + step(1, 0x05, bytes([2])) + step(0, 0x05, bytes([3]))
+                 + step(0, 0x05, bytes([4])) + step(0, 0x07, bytes([2, 0x58])) + step(0, 0x01, play(2, A[3])) + step(9, 0x0D) + end)   # 5
+        T.append(bytes([1, 4]) + step(0, 0x04, port(0x69, 3)) + step(0, 0x07, bytes([4, 0x64])) + step(0, 0x01, play(4, A[4], 0))
+                 + step(6, 0x0C, bytes([4, 0x20, 0, 5])) + step(12, 0x04, port(0x6A)) + step(0xFFFF, 0x00))             # 6
+        T.append(bytes([1, 5]) + step(0, 0x07, bytes([5, 0x50])) + step(0, 0x01, play(5, A[5], 3)) + step(2, 0x0B, bytes([5, 0x10, 0, 6]))
+                 + step(0, 0x10, bytes([5, 9])) + step(0, 0x11, bytes([5, 3, 0, 4])) + step(0, 0x12, bytes([5, 1, 0, 0])) + step(14, 0x0D) + end)  # 7
+        T.append(bytes([1, 2]) + step(0, 0x07, bytes([2, 0x68])) + step(0, 0x01, play(2, A[6])) + step(0xFFFF, 0x0D))  # 8
+        for k in range(3):                                                                                            # 9, 10, 11
+            T.append(bytes([1, 3]) + step(0, 0x07, bytes([3, 0x48 + 8 * k])) + step(0, 0x01, play(3, A[7 + k])) + step(0xFFFF, 0x0D))
+        T.append(bytes([1, 1]) + step(0, 0x07, bytes([0, 0x30])) + step(0, 0x01, play(0, A[10])) + step(3, 0x07, bytes([1, 0x66]))
+                 + step(0, 0x01, play(1, A[11])) + step(0xFFFF, 0x0D))                                                 # 12: plays on channel 0 from channel 1
+        T.append(bytes([1, 6]) + step(0, 0x07, bytes([6, 0x64])) + step(0, 0x33, b"\1\2"))                              # 13: invalid opcode, no delay: fatal
+        T.append(bytes([4, 0]) + _u16(0))                                                                              # 14: invalid track type
+        T.append(bytes([1, 6]) + step(0, 0x0E, bytes([2])) + step(1, 0x07, bytes([6, 0x40])) + step(0, 0x0E, bytes([0]))
+                 + step(2, 0x01, play(6, A[2])) + step(0, 0x0F) + step(0, 0x0F) + end)                                  # 15: endless inner loop
+        T.append(bytes([1, 7]) + step(0, 0x07, bytes([7, 0x5C])) + step(0, 0x01, play(7, A[3], 2)) + step(0xFFFF, 0x0D))  # 16
+        T.append(bytes([1, 0]) + step(2, 0x02, b"\0") + step(0, 0x01, play(0, A[4])) + end)                             # 17: stops itself
+        T.append(bytes([1, 6]) + step(0, 0x07, bytes([6, 0x64])) + step(0, 0x01, play(6, A[5], 0)) + step(1, 0x33, b"\1\2"))   # 18: invalid opcode behind a delay: a reset per tick, never fatal
+        self.n_tracks = len(T)
+        index = bytearray()
+        p2 = 0x8000
+        u2[0x8000:0x9000] = b"\xFF" * 0x1000
+        for t in T:
+            u2[p2:p2 + len(t)] = t
+            index += _u24(p2 if hw != HW95 else p2)          # U2: chip select 0, linear address = offset
+            p2 += len(t) + 2
+        u2[0x7000:0x7000 + len(index)] = index
+        # deferred-indirect table index at catalog + 0x43 -> table 1 = tracks 9, 10, 11
+        di_index, table1 = 0x7800, 0x7900
+        u2[catalog_ofs + 0x43:catalog_ofs + 0x46] = _u24(di_index)
+        u2[di_index:di_index + 6] = _u24(0x7A00) + _u24(table1)
+        u2[table1:table1 + 6] = _u16(9) + _u16(10) + _u16(11)
+        u2[catalog_ofs + 0x46:catalog_ofs + 0x48] = _u16(len(T))
+        u2[0x7FFFE] = u2[0x7FFFF] = 0
+        ck = checksum(u2)
+        u2[0x7FFFE] = (-(ck >> 8)) & 0xFF
+        u2[0x7FFFF] = (-(ck & 0xFF)) & 0xFF
+        self.images = {c: bytes(b) for c, b in imgs.items()}
+
+
+# event scripts for the sequencer tests: (tick, kind, value); kind 0 data-port byte, 1 track command,
+# 2 master volume, 3 ClearTracks
+def port_cmd(tick, track):
+    return [(tick, 0, track >> 8), (tick, 0, track & 0xFF)]
+
+
+SCRIPTS = {
+    "main": (150, [(0, 1, 1)] + port_cmd(3, 2) + [(10, 1, 3), (10, 1, 4)] + port_cmd(12, 5) + [(30, 1, 6), (40, 1, 7)]
+             + [(50, 0, 0x7F)] + port_cmd(70, 12)                                # a lone first byte times out after 13 ticks
+             + [(80, 0, 0x55), (80, 0, 0xAA), (80, 0, 0xB0), (80, 0, 0x4F)]      # master volume 0xB0 through the data port
+             + [(84, 0, 0x55), (84, 0, 0xAC), (84, 0, 0x90), (84, 0, 0x6F)]      # channel 1 volume 0x90
+             + [(90, 0, 0x55), (90, 0, 0xC2), (91, 0, 0x55), (91, 0, 0xC3)]      # version query
+             + [(95, 1, 16), (100, 1, 15), (110, 1, 17), (120, 1, 0), (125, 1, 9999), (126, 0, 0x81), (126, 0, 0x00), (130, 1, 1), (140, 3, 0)]),
+    "fatal-opcode": (24, [(0, 1, 1), (5, 1, 13)]),
+    "reset-every-tick": (24, [(0, 1, 1), (5, 1, 18), (15, 1, 2)]),
+    "invalid-track-type": (12, [(0, 1, 2), (4, 1, 14)]),
+    "volume-and-clear": (40, [(0, 2, 0x40), (0, 1, 2), (8, 2, 0xFF), (15, 3, 0), (20, 1, 12), (30, 2, 0)]),
+}

@@ -1,0 +1,80 @@
+"""The track-program sequencer (csrc/dcs_sequencer.cpp) against the UNMODIFIED reference decoder
+driven tick by tick with ROMs (oracle/ref_driver.cpp:ref_seq_run): same bytes to the host at the same ticks,
+same fatal-error outcome, and -- on the GPU -- the same PCM for whole event scripts decoded in ONE launch.
+Expected values are committed (tests/golden/seq_golden.json) and also compared live where oracle/_ref exists."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import dcsexplorer_amd as D
+import romkit
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_seq_golden as G                     # noqa: E402
+
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "seq_golden.json")))
+PAIRS = [(c, s) for c in G.CASES for s in romkit.SCRIPTS]
+IDS = ["%s/%s" % (c[0], s) for c, s in PAIRS]
+
+
+def make_sequencer(case):
+    rs = D.RomSet(images=G.build(case).images)
+    c = rs.check()
+    assert c.status == 1 and c.os == case[2] and c.nominalVersion == case[5]
+    return rs, D.Sequencer(rs, G.VOLUME)
+
+
+@pytest.mark.parametrize("case,script", PAIRS, ids=IDS)
+def test_host_bytes_and_fatal_state_equal_reference_golden(case, script):
+    n, ev = romkit.SCRIPTS[script]
+    rs, seq = make_sequencer(case)
+    seq.run_script(n, ev)
+    gold = GOLD["%s/%s" % (case[0], script)]
+    assert seq.pending_ticks == n
+    assert [list(x) for x in seq.host_bytes()] == gold["host_bytes"]
+    assert seq.fatal == gold["fatal"]
+
+
+@pytest.mark.parametrize("case,script", PAIRS, ids=IDS)
+def test_host_bytes_equal_reference_live(case, script, reference):
+    n, ev = romkit.SCRIPTS[script]
+    _, hb, fatal = G.ref_run(reference, G.build(case), G.VOLUME, n, ev)
+    rs, seq = make_sequencer(case)
+    seq.run_script(n, ev)
+    assert [list(x) for x in seq.host_bytes()] == hb and seq.fatal == fatal
+
+
+def test_sequencer_needs_versions_and_u2():
+    rs = D.RomSet(images=G.build(G.CASES[2]).images)
+    with pytest.raises(D.DcsError):
+        D.Sequencer(rs)                         # versions not detected / set yet
+    rs.check()
+    D.Sequencer(rs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,script", PAIRS, ids=IDS)
+def test_script_pcm_equals_reference(gpu_ctx, case, script):
+    """a whole event script -- up to 8 channels, fades, loops, deferred tracks -- planned on the host and decoded in
+    one launch: PCM hash == the reference's, and PCM == the live reference where its build travelled along"""
+    from oracle.dcs_oracle import Reference, reference_available, fnv1a64
+    n, ev = romkit.SCRIPTS[script]
+    rs, seq = make_sequencer(case)
+    # decode in two launches to exercise the tail carry between plans
+    half = n // 2
+    seq.run_script(half, [e for e in ev if e[0] < half])
+    pcm_a, _ = seq.decode(gpu_ctx)
+    rest = [(t - half, k, v) for t, k, v in ev if t >= half]
+    seq.run_script(n - half, rest)
+    pcm_b, _ = seq.decode(gpu_ctx)
+    pcm = np.concatenate([pcm_a, pcm_b])
+    gold = GOLD["%s/%s" % (case[0], script)]
+    if reference_available():
+        want, _, _ = G.ref_run(Reference(), G.build(case), G.VOLUME, n, ev)
+        bad = np.nonzero((pcm != want).any(axis=1))[0]
+        assert bad.size == 0, "first differing ticks: %s" % bad[:8]
+    assert "%016x" % fnv1a64(pcm.tobytes()) == gold["pcm_fnv1a64"]
