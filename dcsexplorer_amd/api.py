@@ -92,6 +92,8 @@ EXPORTS = [
     "dcs_seq_create", "dcs_seq_destroy", "dcs_seq_last_error", "dcs_seq_set_master_volume", "dcs_seq_set_reported_version",
     "dcs_seq_write_data_port", "dcs_seq_add_track_command", "dcs_seq_clear_tracks", "dcs_seq_load_audio_stream",
     "dcs_seq_plan", "dcs_seq_pending_ticks", "dcs_seq_is_fatal", "dcs_seq_host_bytes", "dcs_seq_decode",
+    "dcs_seq_create_standalone", "dcs_seq_load_audio_stream_mem", "dcs_seq_rewind", "dcs_seq_set_rewindable",
+    "dcs_seq_tick", "dcs_seq_fatal_tick", "dcs_seq_stream_playing",
 ]
 
 
@@ -219,6 +221,14 @@ def load_library():
                        ("dcs_seq_plan", [vp, u32]), ("dcs_seq_decode", [vp, vp, vp, sz, vp])):
         getattr(L, name).restype = i32
         getattr(L, name).argtypes = args
+    L.dcs_seq_create_standalone.restype = vp
+    L.dcs_seq_create_standalone.argtypes = [i32]
+    L.dcs_seq_load_audio_stream_mem.restype = i32
+    L.dcs_seq_load_audio_stream_mem.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, sz, ctypes.c_int]
+    L.dcs_seq_rewind.restype = i32
+    L.dcs_seq_rewind.argtypes = [vp, u32]
+    L.dcs_seq_set_rewindable.restype = i32
+    L.dcs_seq_set_rewindable.argtypes = [vp, ctypes.c_int]
     L.dcs_seq_pending_ticks.restype = u32
     L.dcs_seq_pending_ticks.argtypes = [vp]
     L.dcs_seq_is_fatal.restype = ctypes.c_int
@@ -772,6 +782,16 @@ class Sequencer:
         elif kind == 1: self.L.dcs_seq_add_track_command(self.h, value)
         elif kind == 2: self.L.dcs_seq_set_master_volume(self.h, value)
         elif kind == 3: self.L.dcs_seq_clear_tracks(self.h)
+
+    def set_rewindable(self, on=True):
+        st = self.L.dcs_seq_set_rewindable(self.h, 1 if on else 0)
+        if st != 0:
+            raise DcsError(st)
+
+    def rewind(self, keep_ticks):
+        st = self.L.dcs_seq_rewind(self.h, keep_ticks)
+        if st != 0:
+            raise DcsError(st)
 
     def run_script(self, n_ticks, events):
         """plan n_ticks ticks, applying the (tick, kind, value) events before their tick"""

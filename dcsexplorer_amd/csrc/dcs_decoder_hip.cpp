@@ -52,8 +52,9 @@ DCSDecoderHIP::DCSDecoderHIP(Host *host, int deviceId) : DCSDecoder(host), devic
 
 DCSDecoderHIP::~DCSDecoderHIP()
 {
-    if (ctx != nullptr)
-        dcs_ctx_destroy(ctx);
+    if (seq != nullptr) dcs_seq_destroy(seq);
+    if (roms != nullptr) dcs_romset_destroy(roms);
+    if (ctx != nullptr) dcs_ctx_destroy(ctx);
 }
 
 void DCSDecoderHIP::InitStandalone(OSVersion v) { osVersion = v; }
@@ -69,6 +70,111 @@ DcsOsVersion DCSDecoderHIP::AbiOs() const
     }
 }
 
+// ---- ROMs ----------------------------------------------------------------------------------------------------
+bool DCSDecoderHIP::EnsureRoms()
+{
+    if (roms == nullptr)
+        roms = dcs_romset_create();
+    return roms != nullptr;
+}
+
+void DCSDecoderHIP::AddROM(int n, const uint8_t *data, size_t size)
+{
+    if (EnsureRoms())
+        dcs_romset_add_rom(roms, n, data, size);
+}
+
+bool DCSDecoderHIP::LoadROMFromZipFile(const char *zipFileName, const char *explicitU2, std::string *errorDetails)
+{
+    if (!EnsureRoms())
+        return false;
+    const DcsStatus st = dcs_romset_load_zip(roms, zipFileName, explicitU2);
+    if (st != DCS_OK && errorDetails != nullptr)
+        *errorDetails = dcs_romset_last_error(roms);
+    return st == DCS_OK;
+}
+
+uint8_t DCSDecoderHIP::CheckROMs()
+{
+    hwVersion = HWVersion::Invalid;
+    osVersion = OSVersion::Invalid;
+    nominalVersion = 0;
+    DcsRomCheck c;
+    if (roms == nullptr || dcs_romset_check(roms, &c) != DCS_OK)
+        return 2;
+    hwVersion = c.hw == DCS_HW_DCS93 ? HWVersion::DCS93 : c.hw == DCS_HW_DCS95 ? HWVersion::DCS95 : HWVersion::Invalid;
+    osVersion = c.os == DCS_OS93A ? OSVersion::OS93a : c.os == DCS_OS93B ? OSVersion::OS93b : c.os == DCS_OS94 ? OSVersion::OS94
+              : c.os == DCS_OS95 ? OSVersion::OS95 : OSVersion::Invalid;
+    nominalVersion = c.nominalVersion;
+    return static_cast<uint8_t>(c.status);
+}
+
+void DCSDecoderHIP::SetVersions(HWVersion hw, OSVersion os)
+{
+    hwVersion = hw;
+    osVersion = os;
+    if (EnsureRoms())
+        dcs_romset_set_version(roms, hw == HWVersion::DCS95 ? DCS_HW_DCS95 : DCS_HW_DCS93, AbiOs());
+}
+
+int DCSDecoderHIP::GetVersionNumber() const
+{
+    return nominalVersion != 0 ? static_cast<int>(nominalVersion)
+         : (osVersion == OSVersion::OS93a || osVersion == OSVersion::OS93b) ? 0x0100
+         : osVersion == OSVersion::OS94 ? 0x0101 : 0x0000;
+}
+
+uint16_t DCSDecoderHIP::GetMaxTrackNumber() const
+{
+    return static_cast<uint16_t>((roms != nullptr ? dcs_romset_num_tracks(roms) : 0) - 1);      // (sic) DCSDecoder.h:360
+}
+
+bool DCSDecoderHIP::GetTrackInfo(uint16_t trackNumber, TrackInfo &ti)
+{
+    ti = TrackInfo();
+    DcsTrackInfo t;
+    if (roms == nullptr || dcs_romset_track_info(roms, trackNumber, &t) != DCS_OK)
+        return false;
+    ti.address = t.address; ti.channel = t.channel; ti.type = t.type; ti.deferCode = t.deferCode;
+    ti.time = t.time; ti.looping = t.looping != 0;
+    return true;
+}
+
+std::vector<DcsTrackOp> DCSDecoderHIP::DecompileTrackProgram(uint16_t trackNumber)
+{
+    std::vector<DcsTrackOp> v;
+    uint32_t n = 0;
+    if (roms != nullptr && dcs_romset_decompile(roms, trackNumber, nullptr, 0, &n) == DCS_OK && n != 0)
+    {
+        v.resize(n);
+        dcs_romset_decompile(roms, trackNumber, v.data(), n, &n);
+    }
+    return v;
+}
+
+std::vector<uint32_t> DCSDecoderHIP::ListStreams()
+{
+    std::vector<uint32_t> v;
+    uint32_t n = 0;
+    if (roms != nullptr && dcs_romset_list_streams(roms, nullptr, 0, &n) == DCS_OK && n != 0)
+    {
+        v.resize(n);
+        dcs_romset_list_streams(roms, v.data(), n, &n);
+    }
+    return v;
+}
+
+DCSDecoder::ROMPointer DCSDecoderHIP::MakeROMPointer(uint32_t linearAddress) const
+{
+    const uint8_t *p = nullptr;
+    size_t avail = 0;
+    int chip = 2;
+    if (roms == nullptr || dcs_romset_pointer(roms, linearAddress, &p, &avail, &chip) != DCS_OK)
+        return ROMPointer();
+    return ROMPointer(chip - 2, p);
+}
+
+// ---- playing ---------------------------------------------------------------------------------------------------
 bool DCSDecoderHIP::Initialize()
 {
     if (ctx == nullptr)
@@ -80,14 +186,101 @@ bool DCSDecoderHIP::Initialize()
             return false;                                       // InitializationError: GetNextSample returns silence, IsOK() is false
         }
     }
-    SetMasterVolume(defaultVolume);                             // DCSDecoderNative.cpp:3206
+    if (seq != nullptr)
+    {
+        dcs_seq_destroy(seq);
+        seq = nullptr;
+    }
+    ready.clear(); hostBytes.clear(); handedOut = 0; nextTick = 0;
+    const bool haveRoms = roms != nullptr && dcs_romset_num_tracks(roms) != 0;
+    if (haveRoms)
+    {
+        if (hwVersion == HWVersion::Unknown)                    // SoftBoot does this (DCSDecoder.cpp:1522-1523)
+            CheckROMs();
+        if (hwVersion == HWVersion::Invalid || osVersion == OSVersion::Invalid || osVersion == OSVersion::Unknown)
+        {
+            errorMessage = "the ROM images could not be identified (CheckROMs); use SetVersions for images without decoder code";
+            return false;
+        }
+        seq = dcs_seq_create(roms);
+    }
+    else
+        seq = dcs_seq_create_standalone(AbiOs());
+    if (seq == nullptr)
+    {
+        errorMessage = "could not create the track sequencer";
+        return false;
+    }
+    dcs_seq_set_rewindable(seq, 1);
+    dcs_seq_set_reported_version(seq, reportedVersion);
+    dcs_seq_set_master_volume(seq, defaultVolume);              // DCSDecoderNative.cpp:3206
+    if (masterVolume >= 0)
+        dcs_seq_set_master_volume(seq, masterVolume);
     return true;
+}
+
+// Back to the decoder state after the last frame handed out: drops the frames decoded ahead and what the
+// sequencer did for them.
+void DCSDecoderHIP::Sync()
+{
+    if (seq == nullptr || ready.empty())
+        return;
+    dcs_seq_rewind(seq, handedOut);
+    ready.clear();
+    while (!hostBytes.empty() && hostBytes.back().tick >= nextTick)
+        hostBytes.pop_back();
 }
 
 void DCSDecoderHIP::SetMasterVolume(int vol)
 {
-    volumeMultiplier = dcs_volume_multiplier(vol);
-    Invalidate();
+    masterVolume = vol;
+    if (seq != nullptr)
+    {
+        Sync();
+        dcs_seq_set_master_volume(seq, vol);
+    }
+}
+
+void DCSDecoderHIP::SetReportedVersionNumber(uint16_t vsn)
+{
+    reportedVersion = vsn;
+    if (seq != nullptr)
+    {
+        Sync();
+        dcs_seq_set_reported_version(seq, vsn);
+    }
+}
+
+void DCSDecoderHIP::WriteDataPort(uint8_t data)
+{
+    if (state == State::HardBoot)
+    {
+        SoftBoot();                                             // the first byte only wakes the board (DCSDecoder.cpp:1531-1538)
+        return;
+    }
+    if (seq != nullptr)
+    {
+        Sync();
+        dcs_seq_write_data_port(seq, data);
+    }
+}
+
+void DCSDecoderHIP::AddTrackCommand(uint16_t trackNum)
+{
+    if (seq != nullptr)
+    {
+        Sync();
+        dcs_seq_add_track_command(seq, trackNum);
+    }
+}
+
+void DCSDecoderHIP::ClearTracks()
+{
+    if (seq != nullptr)
+    {
+        Sync();
+        dcs_seq_clear_tracks(seq);
+    }
 }
 
 DCSDecoderHIP::StreamInfo DCSDecoderHIP::GetStreamInfo(const ROMPointer &p, size_t maxLen)
@@ -108,192 +301,68 @@ DCSDecoderHIP::StreamInfo DCSDecoderHIP::GetStreamInfo(const ROMPointer &p, size
 
 void DCSDecoderHIP::LoadAudioStream(int ch, const ROMPointer &p, int mixingLevel, size_t maxLen)
 {
-    if (ch < 0 || ch >= DCS_MAX_CHANNELS || p.IsNull())         // :1390
+    if (seq == nullptr || ch < 0 || ch >= DCS_MAX_CHANNELS || p.IsNull())       // :1390
         return;
-    Invalidate();
-    Channel &c = channel[ch];
-    const uint32_t nFrames = (static_cast<uint32_t>(p.p[0]) << 8) | p.p[1];
-    c.active = false;
-    c.stopPending = false;
-    c.level = mixingLevel << 6;                                 // :1404
-    if (nFrames == 0)
-        return;                                                 // nothing to play (:1414)
-    c.index.resize(nFrames);
-    if (dcs_index_stream(AbiOs(), p.p, maxLen, c.index.data(), nFrames, &c.info) != DCS_OK)
-        return;
-    c.index.resize(static_cast<size_t>(c.info.nValidFrames));
-    // private copy of exactly the bytes the stream uses (+ the bit reader's look-ahead)
-    size_t used = static_cast<size_t>(c.info.nBytes) + 8;
-    if (used > maxLen)
-        used = maxLen;
-    c.bytes.assign(p.p, p.p + used);
-    c.bytes.resize((used > static_cast<size_t>(c.info.nBytes) ? used : static_cast<size_t>(c.info.nBytes)) + 16, 0);
-    c.pos = 0;
-    c.active = !c.index.empty();
+    Sync();
+    dcs_seq_load_audio_stream_mem(seq, ch, p.p, maxLen, mixingLevel);
 }
 
 bool DCSDecoderHIP::IsStreamPlaying(int ch)
 {
-    return ch >= 0 && ch < DCS_MAX_CHANNELS && channel[ch].active;
-}
-
-void DCSDecoderHIP::ClearTracks()
-{
-    Invalidate();
-    for (Channel &c : channel)
-        c.active = false;
-}
-
-// drop the frames decoded ahead and rewind to the state after the last frame handed out
-void DCSDecoderHIP::Invalidate()
-{
-    if (ready.empty())
-        return;
-    // `rewind` is the decoder state after the last frame that was handed out
-    for (int i = 0 ; i < DCS_MAX_CHANNELS ; ++i)
-    {
-        channel[i].pos = rewind.pos[i];
-        channel[i].active = rewind.active[i];
-        channel[i].mixMul = rewind.mixMul[i];
-        channel[i].level = rewind.level[i];
-        channel[i].stopPending = rewind.stopPending[i];
-    }
-    memcpy(tail, rewind.tail, sizeof(tail));
-    ready.clear();
-    after.clear();
+    if (seq == nullptr)
+        return false;
+    Sync();
+    return dcs_seq_stream_playing(seq, ch) != 0;
 }
 
 void DCSDecoderHIP::MainLoop()
 {
-    if (ready.empty())
-        PlanAndDecode();
-    if (ready.empty())
+    if (seq == nullptr)
     {
         state = State::DecoderFatalError;
-        errorMessage = std::string("HIP decode failed: ") + (ctx ? dcs_last_error(ctx) : "no context");
+        errorMessage = "decoder not initialised";
+        return;
+    }
+    if (ready.empty())
+    {
+        // run the sequencer `lookahead` ticks ahead and decode them in one launch
+        handedOut = 0;
+        std::vector<int16_t> pcm(static_cast<size_t>(lookahead) * DCS_FRAME_SAMPLES);
+        if (dcs_seq_plan(seq, static_cast<uint32_t>(lookahead)) != DCS_OK
+            || dcs_seq_decode(ctx, seq, pcm.data(), static_cast<size_t>(lookahead), nullptr) != DCS_OK)
+        {
+            state = State::DecoderFatalError;
+            errorMessage = std::string("HIP decode failed: ") + dcs_last_error(ctx);
+            return;
+        }
+        for (int t = 0 ; t < lookahead ; ++t)
+            ready.emplace_back(pcm.begin() + static_cast<size_t>(t) * DCS_FRAME_SAMPLES,
+                               pcm.begin() + static_cast<size_t>(t + 1) * DCS_FRAME_SAMPLES);
+        const uint32_t nb = dcs_seq_host_bytes(seq, nullptr, 0);
+        if (nb != 0)
+        {
+            std::vector<DcsHostByte> b(nb);
+            dcs_seq_host_bytes(seq, b.data(), nb);
+            hostBytes.insert(hostBytes.end(), b.begin(), b.end());
+        }
+    }
+    // this tick's bytes go to the host now, its frame to the output buffer
+    while (!hostBytes.empty() && hostBytes.front().tick <= nextTick)
+    {
+        host->ReceiveDataPort(static_cast<uint8_t>(hostBytes.front().byte));
+        hostBytes.pop_front();
+    }
+    if (dcs_seq_fatal_tick(seq) <= nextTick)
+    {
+        // the reference gives up after four failed passes in a row (DCSDecoder.cpp:1637-1645)
+        state = State::DecoderFatalError;
+        errorMessage = "The decoder performed a self-reset after encountering multiple fatal errors decoding track data.";
         return;
     }
     memcpy(outputBuffer, ready.front().data(), sizeof(outputBuffer));
-    rewind = after.front();                                     // committed: this frame has been handed out
     ready.pop_front();
-    after.pop_front();
-}
-
-// Plan `lookahead` MainLoop ticks from the current channel state and decode them in one launch.
-void DCSDecoderHIP::PlanAndDecode()
-{
-    // state before the first planned tick (for Invalidate)
-    for (int i = 0 ; i < DCS_MAX_CHANNELS ; ++i)
-    {
-        rewind.pos[i] = channel[i].pos;
-        rewind.active[i] = channel[i].active;
-        rewind.mixMul[i] = channel[i].mixMul;
-        rewind.level[i] = channel[i].level;
-        rewind.stopPending[i] = channel[i].stopPending;
-    }
-    memcpy(rewind.tail, tail, sizeof(tail));
-
-    // blob: the loaded streams back to back
-    std::vector<uint8_t> blob;
-    uint64_t off[DCS_MAX_CHANNELS] = { 0 };
-    for (int i = 0 ; i < DCS_MAX_CHANNELS ; ++i)
-    {
-        if (!channel[i].active)
-            continue;
-        while (blob.size() & 3) blob.push_back(0);
-        off[i] = blob.size();
-        blob.insert(blob.end(), channel[i].bytes.begin(), channel[i].bytes.end());
-    }
-
-    const DcsOsVersion os = AbiOs();
-    const uint8_t xform = (os == DCS_OS93A || os == DCS_OS93B) ? DCS_XFORM_93 : DCS_XFORM_94;
-    std::vector<DcsSrcDesc> srcs;
-    std::vector<DcsFrameJob> jobs;
-    std::vector<Snapshot> snaps;
-    for (int t = 0 ; t < lookahead ; ++t)
-    {
-        // forced-stop sweep (:95-116): a stream that raised an error on the previous tick is gone now, and
-        // its mixer level with it
-        for (Channel &c : channel)
-            if (c.stopPending)
-            {
-                c.stopPending = false;
-                c.level = 0;
-            }
-
-        // MainLoop's shared scale over the active channels (:227-269)
-        uint16_t mm[DCS_MAX_CHANNELS];
-        uint8_t act[DCS_MAX_CHANNELS];
-        for (int i = 0 ; i < DCS_MAX_CHANNELS ; ++i)
-        {
-            mm[i] = channel[i].mixMul;
-            act[i] = channel[i].active ? 1 : 0;
-        }
-        const int volShift = dcs_frame_scale(volumeMultiplier, mm, act, DCS_MAX_CHANNELS);
-
-        DcsFrameJob jb;
-        memset(&jb, 0, sizeof(jb));
-        jb.firstSrc = static_cast<uint32_t>(srcs.size());
-        jb.volShift = static_cast<uint8_t>(volShift);
-        jb.xform = xform;
-        jb.prev = (t == 0) ? (DCS_PREV_EXT | 0u) : static_cast<uint32_t>(jobs.size() - 1);
-        for (int i = 0 ; i < DCS_MAX_CHANNELS ; ++i)           // DecodeStream per channel, in channel order (:272-273)
-        {
-            Channel &c = channel[i];
-            if (!c.active)
-                continue;
-            DcsSrcDesc sd;
-            memset(&sd, 0, sizeof(sd));
-            sd.streamOff = off[i];
-            sd.mixMul = mm[i];
-            sd.format = static_cast<uint8_t>(c.info.format);
-            sd.hdrLen = static_cast<uint8_t>(c.info.hdrLen);
-            sd.idx = c.index[c.pos];
-            srcs.push_back(sd);
-            ++jb.nSrc;
-            if (++c.pos >= c.index.size())
-            {
-                c.active = false;                               // end of stream, loop count 1 (:1565-1588); an
-                                                                // error frame also ends it (:95-116)
-                c.stopPending = c.index.size() < static_cast<size_t>(c.info.nFrames);
-            }
-        }
-        jobs.push_back(jb);
-
-        // UpdateMixingLevels: next tick's multiplier from the channel's level (:3072-3121)
-        Snapshot sn;
-        for (int i = 0 ; i < DCS_MAX_CHANNELS ; ++i)
-        {
-            channel[i].mixMul = dcs_mixing_multiplier(os, channel[i].level, 0xFF);
-            sn.pos[i] = channel[i].pos;
-            sn.active[i] = channel[i].active;
-            sn.mixMul[i] = channel[i].mixMul;
-            sn.level[i] = channel[i].level;
-            sn.stopPending[i] = channel[i].stopPending;
-        }
-        snaps.push_back(sn);
-    }
-
-    std::vector<int16_t> pcm(static_cast<size_t>(lookahead) * DCS_FRAME_SAMPLES);
-    std::vector<int16_t> tailsOut(static_cast<size_t>(lookahead) * 16);
-    if (blob.empty())
-        blob.assign(16, 0);
-    DcsStatus st = dcs_decode_batch(ctx, blob.data(), blob.size(), srcs.empty() ? nullptr : srcs.data(),
-                                    static_cast<uint32_t>(srcs.size()), jobs.data(), static_cast<uint32_t>(jobs.size()),
-                                    tail, 1, pcm.data(), nullptr, tailsOut.data());
-    if (st != DCS_OK)
-    {
-        Invalidate();
-        return;
-    }
-    for (int t = 0 ; t < lookahead ; ++t)
-    {
-        ready.emplace_back(pcm.begin() + static_cast<size_t>(t) * DCS_FRAME_SAMPLES,
-                           pcm.begin() + static_cast<size_t>(t + 1) * DCS_FRAME_SAMPLES);
-        memcpy(snaps[static_cast<size_t>(t)].tail, &tailsOut[static_cast<size_t>(t) * 16], sizeof(tail));
-        after.push_back(snaps[static_cast<size_t>(t)]);
-    }
-    memcpy(tail, &tailsOut[static_cast<size_t>(lookahead - 1) * 16], sizeof(tail));
+    ++handedOut;
+    ++nextTick;
 }
 
 bool DCSDecoderHIP::DecodeStreamsBatch(const std::vector<BatchStream> &streams, unsigned extraFrames,

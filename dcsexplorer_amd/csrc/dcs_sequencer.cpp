@@ -58,15 +58,11 @@ struct Chan
     uint32_t frameCounter = 0, loopCounter = 0, pos = 0;
 };
 
-}   // namespace
-
-struct DcsSequencer
+// what a snapshot holds: the decoder state proper.  Copyable: stream entries are referenced by pointer and live
+// as long as the sequencer.
+struct VmState
 {
-    const DcsRomSet *rs = nullptr;
-    int os = DCS_OS94;
-    bool totan = false;                     // GameID::TOTAN quirk of the data-port handler (:3345-3351)
     uint16_t volumeMultiplier = 0x0391;     // DCSDecoderNative.h:161
-    uint16_t reportedVersion = 0x0106;
     Chan ch[DCS_MAX_CHANNELS];
     std::deque<uint16_t> commandQueue;
     std::deque<uint8_t> dataPortQueue;
@@ -76,14 +72,33 @@ struct DcsSequencer
     int dataPortTimeout = 0;
     uint8_t variables[256] = { 0 };
     bool fatal = false;
+    uint64_t fatalTick = 0;                 // the first tick that produced silence because of it
     uint64_t tick = 0;
+};
 
-    // the batch planned so far
+}   // namespace
+
+struct DcsSequencer : VmState
+{
+    const DcsRomSet *rs = nullptr;
+    DcsRomSet emptyRoms;                    // stand-alone mode: no ROMs, streams come from caller memory
+    int os = DCS_OS94;
+    bool totan = false;                     // GameID::TOTAN quirk of the data-port handler (:3345-3351)
+    uint16_t reportedVersion = 0x0106;
+
+    // the batch planned so far, and what is needed to go back inside it
     std::map<std::pair<const void *, size_t>, std::unique_ptr<StreamEntry>> streams;
+    std::vector<std::unique_ptr<StreamEntry>> uncached;                   // streams loaded from caller memory
     std::vector<uint8_t> blob;
     std::vector<DcsSrcDesc> srcs;
     std::vector<DcsFrameJob> jobs;
     std::vector<DcsHostByte> hostBytes;
+    std::vector<VmState> history;           // history[k] = state after k ticks of the current batch ([0] = before it)
+    std::vector<size_t> srcsAfter;          // srcs.size() after each tick of the current batch
+    std::vector<int16_t> batchTails;        // after a decode: the 16-sample tail each tick of the batch left
+    int16_t batchTail0[16] = { 0 };         // ... and the tail the batch started from
+    bool batchDecoded = false;
+    bool keepHistory = false;               // dcs_seq_set_rewindable: a snapshot per tick (about 2 KB each)
     int16_t tail[16] = { 0 };
     std::string lastError;
 
@@ -101,7 +116,10 @@ struct DcsSequencer
     }
 
     const StreamEntry *streamAt(DcsRomCursor p);
+    const StreamEntry *addStream(const uint8_t *data, size_t avail, std::pair<const void *, size_t> key, bool cache);
+    void compact();
     void loadAudioStream(uint32_t streamChannel, int sourceChannel, uint32_t loopCounter, DcsRomCursor p);
+    void loadStreamEntry(uint32_t streamChannel, int sourceChannel, uint32_t loopCounter, const StreamEntry *e);
     void loadTrack(uint32_t c, DcsRomCursor p);
     void execTrack(int c);
     void mixingLevelOp(int cur, DcsRomCursor &p, int mode, bool fade);
@@ -116,9 +134,12 @@ const StreamEntry *DcsSequencer::streamAt(DcsRomCursor p)
     auto it = streams.find(key);
     if (it != streams.end())
         return it->second.get();
+    return addStream(p.rom->data() + p.pos, p.rom->size() - p.pos, key, true);
+}
+
+const StreamEntry *DcsSequencer::addStream(const uint8_t *data, size_t avail, std::pair<const void *, size_t> key, bool cache)
+{
     std::unique_ptr<StreamEntry> e(new StreamEntry);
-    const uint8_t *data = p.rom->data() + p.pos;
-    const size_t avail = p.rom->size() - p.pos;
     const uint32_t nFrames = avail >= 2 ? (static_cast<uint32_t>(data[0]) << 8) | data[1] : 0;
     if (nFrames != 0 && avail >= 3)
     {
@@ -137,16 +158,54 @@ const StreamEntry *DcsSequencer::streamAt(DcsRomCursor p)
         blob.insert(blob.end(), data, data + used);
         blob.insert(blob.end(), static_cast<size_t>(e->info.nBytes) - used + 16, 0);
     }
-    const StreamEntry *r = e.get();
-    streams[key] = std::move(e);
+    StreamEntry *r = e.get();
+    if (cache)
+        streams[key] = std::move(e);
+    else
+        uncached.push_back(std::move(e));
     return r;
+}
+
+// Between batches: when the blob has grown large (a long-running decoder keeps loading streams), keep only the
+// streams a channel is still playing.
+void DcsSequencer::compact()
+{
+    if (blob.size() < (32u << 20))
+        return;
+    std::vector<uint8_t> fresh;
+    auto keep = [&](StreamEntry *e) {
+        const size_t n = static_cast<size_t>(e->info.nBytes) + 16;
+        while (fresh.size() & 3)
+            fresh.push_back(0);
+        const uint64_t off = fresh.size();
+        fresh.insert(fresh.end(), blob.begin() + static_cast<long>(e->blobOff), blob.begin() + static_cast<long>(e->blobOff + n));
+        e->blobOff = off;
+    };
+    auto playing = [&](const StreamEntry *e) {
+        for (const Chan &c : ch)
+            if (c.st == e)
+                return true;
+        return false;
+    };
+    for (auto it = streams.begin() ; it != streams.end() ; )
+        if (playing(it->second.get())) { keep(it->second.get()); ++it; }
+        else it = streams.erase(it);
+    for (auto it = uncached.begin() ; it != uncached.end() ; )
+        if (playing(it->get())) { keep(it->get()); ++it; }
+        else it = uncached.erase(it);
+    blob.swap(fresh);
 }
 
 // LoadAudioStream (:1408-1431) + InitChannelStream (:1433-1463)
 void DcsSequencer::loadAudioStream(uint32_t streamChannel, int source, uint32_t loopCounter, DcsRomCursor p)
 {
+    chan(streamChannel);                    // validate before touching the stream cache
+    loadStreamEntry(streamChannel, source, loopCounter, streamAt(p));
+}
+
+void DcsSequencer::loadStreamEntry(uint32_t streamChannel, int source, uint32_t loopCounter, const StreamEntry *e)
+{
     Chan &c = chan(streamChannel);
-    const StreamEntry *e = streamAt(p);
     if (e->index.empty())
     {
         c.st = nullptr;                     // zero frames (or unusable): nothing to play
@@ -531,6 +590,21 @@ void DcsSequencer::mainLoop()
 }
 
 // ---------------------------------------------------------------------------------------------------------
+extern "C" DcsSequencer *dcs_seq_create_standalone(DcsOsVersion os)
+{
+    if (os < DCS_OS93A || os > DCS_OS95)
+        return nullptr;
+    DcsSequencer *s = new (std::nothrow) DcsSequencer;
+    if (s == nullptr)
+        return nullptr;
+    s->emptyRoms.missing.assign(0x2000, 0xFF);
+    s->emptyRoms.os = os;
+    s->rs = &s->emptyRoms;
+    s->os = os;
+    s->history.push_back(*s);
+    return s;
+}
+
 extern "C" DcsSequencer *dcs_seq_create(const DcsRomSet *rs)
 {
     if (rs == nullptr || rs->os < 0 || !rs->rom[0].present)
@@ -549,6 +623,7 @@ extern "C" DcsSequencer *dcs_seq_create(const DcsRomSet *rs)
         while (k < sizeof(key) - 1 && (u2[i + k] | 0x20) == key[k]) ++k;
         if (k == sizeof(key) - 1) { s->totan = true; break; }
     }
+    s->history.push_back(*s);
     return s;
 }
 
@@ -606,11 +681,74 @@ extern "C" DcsStatus dcs_seq_load_audio_stream(DcsSequencer *s, int channel, uin
     return DCS_OK;
 }
 
+// LoadAudioStream for a stream that lives in caller memory rather than in a ROM image (the ROM-less recipe of
+// DCSEncoder.cpp:522-571); the bytes the stream uses are copied now, the buffer is not referenced later.  Bytes
+// past `len` read as zero.
+extern "C" DcsStatus dcs_seq_load_audio_stream_mem(DcsSequencer *s, int channel, const uint8_t *data, size_t len, int mixingLevel)
+{
+    if (s == nullptr || data == nullptr || len < 3 || channel < 0 || channel >= DCS_MAX_CHANNELS) return DCS_ERR_INVALID_ARG;
+    Chan &c = s->ch[channel];
+    c.track.clear();
+    s->loadStreamEntry(static_cast<uint32_t>(channel), channel, 1, s->addStream(data, len, std::make_pair(static_cast<const void *>(data), size_t(0)), false));
+    Mixer &m = c.mixer[channel];
+    m.reset();
+    m.cur = m.target = mixingLevel << 6;
+    return DCS_OK;
+}
+
+// Go back inside the current batch (the ticks planned since the last decode, or -- right after a decode -- the
+// ticks just decoded): the decoder state, the overlap tail and the host bytes become what they were after the
+// batch's first `keepTicks` ticks; later ticks are dropped.  This is how a caller that decodes ahead of time
+// stays exact when a command arrives: rewind to the last frame it handed out, apply the command, plan again.
+extern "C" DcsStatus dcs_seq_set_rewindable(DcsSequencer *s, int on)
+{
+    if (s == nullptr || !s->jobs.empty())
+        return DCS_ERR_INVALID_ARG;             // only between batches
+    s->keepHistory = on != 0;
+    s->batchDecoded = false;
+    s->history.assign(1, static_cast<const VmState &>(*s));
+    s->srcsAfter.clear();
+    s->batchTails.clear();
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_seq_rewind(DcsSequencer *s, uint32_t keepTicks)
+{
+    if (s == nullptr || !s->keepHistory || keepTicks + 1 > s->history.size())
+        return DCS_ERR_INVALID_ARG;
+    const uint64_t firstTick = s->history[0].tick;
+    static_cast<VmState &>(*s) = s->history[keepTicks];
+    s->history.resize(keepTicks + 1);
+    while (!s->hostBytes.empty() && s->hostBytes.back().tick >= firstTick + keepTicks)
+        s->hostBytes.pop_back();
+    if (s->batchDecoded)
+    {
+        memcpy(s->tail, keepTicks == 0 ? s->batchTail0 : &s->batchTails[(keepTicks - 1) * 16], sizeof(s->tail));
+        s->batchTails.resize(static_cast<size_t>(keepTicks) * 16);
+    }
+    else
+    {
+        s->jobs.resize(keepTicks);
+        s->srcs.resize(keepTicks == 0 ? 0 : s->srcsAfter[keepTicks - 1]);
+        s->srcsAfter.resize(keepTicks);
+    }
+    return DCS_OK;
+}
+
 // Run the sequencer `nTicks` ticks further; every tick appends one frame job to the pending plan.  Bytes
 // written to the data port since the last tick are handled first, as the sample pump does (DCSDecoder.cpp:1617).
 extern "C" DcsStatus dcs_seq_plan(DcsSequencer *s, uint32_t nTicks)
 {
     if (s == nullptr) return DCS_ERR_INVALID_ARG;
+    if (s->batchDecoded)
+    {
+        // a new batch starts: the previous one can no longer be rewound into
+        s->batchDecoded = false;
+        s->history.assign(1, static_cast<const VmState &>(*s));
+        s->srcsAfter.clear();
+        s->batchTails.clear();
+        s->compact();
+    }
     for (uint32_t t = 0 ; t < nTicks ; ++t)
     {
         if (s->fatal)
@@ -624,6 +762,7 @@ extern "C" DcsStatus dcs_seq_plan(DcsSequencer *s, uint32_t nTicks)
             jb.flags = 0;
             s->jobs.push_back(jb);
             ++s->tick;
+            if (s->keepHistory) { s->srcsAfter.push_back(s->srcs.size()); s->history.push_back(*s); }
             continue;
         }
         while (!s->dataPortQueue.empty())
@@ -648,6 +787,7 @@ extern "C" DcsStatus dcs_seq_plan(DcsSequencer *s, uint32_t nTicks)
                 if (++retries > 3)
                 {
                     s->fatal = true;
+                    s->fatalTick = s->tick;
                     s->lastError = "the decoder reset itself after repeated fatal errors in the track data";
                     break;
                 }
@@ -659,12 +799,19 @@ extern "C" DcsStatus dcs_seq_plan(DcsSequencer *s, uint32_t nTicks)
             continue;
         }
         ++s->tick;
+        if (s->keepHistory) { s->srcsAfter.push_back(s->srcs.size()); s->history.push_back(*s); }
     }
     return DCS_OK;
 }
 
 extern "C" uint32_t dcs_seq_pending_ticks(const DcsSequencer *s) { return s != nullptr ? static_cast<uint32_t>(s->jobs.size()) : 0; }
 extern "C" int dcs_seq_is_fatal(const DcsSequencer *s) { return s != nullptr && s->fatal ? 1 : 0; }
+extern "C" uint64_t dcs_seq_tick(const DcsSequencer *s) { return s != nullptr ? s->tick : 0; }
+extern "C" uint64_t dcs_seq_fatal_tick(const DcsSequencer *s) { return s != nullptr && s->fatal ? s->fatalTick : ~uint64_t(0); }
+extern "C" int dcs_seq_stream_playing(const DcsSequencer *s, int channel)
+{
+    return s != nullptr && channel >= 0 && channel < DCS_MAX_CHANNELS && s->ch[channel].st != nullptr ? 1 : 0;
+}
 
 extern "C" uint32_t dcs_seq_host_bytes(DcsSequencer *s, DcsHostByte *out, uint32_t cap)
 {
@@ -700,9 +847,13 @@ extern "C" DcsStatus dcs_seq_decode(DcsCtx *ctx, DcsSequencer *s, int16_t *pcmOu
         s->lastError = dcs_last_error(ctx);
         return st;
     }
+    memcpy(s->batchTail0, s->tail, sizeof(s->tail));
     memcpy(s->tail, &tails[(n - 1) * 16], sizeof(s->tail));
+    s->batchTails.swap(tails);
+    s->batchDecoded = true;
     s->jobs.clear();
     s->srcs.clear();
+    s->srcsAfter.clear();
     // the blob and the stream cache stay: streams already copied are reused by later plans
     return DCS_OK;
 }

@@ -101,7 +101,8 @@ protected:
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// Mirror of class DCSDecoderNative's public surface (DCSDecoderNative.h:11-129), frame decode on the GPU
+// Mirror of class DCSDecoderNative's public surface (DCSDecoderNative.h:11-129) plus the ROM-facing part of
+// DCSDecoder's (DCSDecoder.h:230-500); the sequencer runs on the host, the frame decode on the GPU
 // ---------------------------------------------------------------------------------------------------------
 class DCSDecoderHIP : public DCSDecoder
 {
@@ -111,10 +112,30 @@ public:
 
     const char *Name() const override { return "MI355X HIP batch decoder"; }
 
+    // ---- ROMs (DCSDecoder.h:230-360) ------------------------------------------------------------------------
+    enum class HWVersion { Unknown, Invalid, DCS93, DCS95 };                    // DCSDecoder.h:816-822
+    void AddROM(int n, const uint8_t *data, size_t size);                       // DCSDecoder.cpp:26-66 (the image is copied)
+    bool LoadROMFromZipFile(const char *zipFileName, const char *explicitU2 = nullptr, std::string *errorDetails = nullptr);
+    uint8_t CheckROMs();                                                        // DCSDecoder.cpp:236-495: 1 = good, else Ux
+    void SetVersions(HWVersion hw, OSVersion os);                               // explicit override (images without ADSP code)
+    HWVersion GetHWVersion() const { return hwVersion; }
+    OSVersion GetOSVersion() const { return osVersion; }
+    int GetVersionNumber() const;                                               // DCSDecoder.cpp:497-503
+    uint16_t GetMaxTrackNumber() const;                                         // DCSDecoder.h:360
+    struct TrackInfo { uint32_t address = 0; int channel = 0; int type = 0; int deferCode = 0; uint32_t time = 0; bool looping = false; };
+    bool GetTrackInfo(uint16_t trackNumber, TrackInfo &ti);                     // DCSDecoder.cpp:672-905
+    std::vector<DcsTrackOp> DecompileTrackProgram(uint16_t trackNumber);        // DCSDecoder.cpp:907-1160 (no text)
+    std::vector<uint32_t> ListStreams();                                        // DCSDecoder.cpp:1248-1293
+    ROMPointer MakeROMPointer(uint32_t linearAddress) const;                    // DCSDecoder.cpp:68-76
+
+    // ---- playing (DCSDecoder.h:540-620, DCSDecoderNative.h:34-129) -------------------------------------------
     // DCSDecoderNative.h:34 -- no ROMs: streams come from the caller, the OS version is given
     void InitStandalone(OSVersion osVersion);
     void SetMasterVolume(int vol) override;                     // DCSDecoderNative.h:47
-    void SetReportedVersionNumber(uint16_t vsn) { reportedVersion = vsn; }
+    void SetReportedVersionNumber(uint16_t vsn);
+    void WriteDataPort(uint8_t data);                           // DCSDecoder.cpp:1529-1543: the WPC board's commands
+    void AddTrackCommand(uint16_t trackNum);                    // DCSDecoderNative.cpp:1475
+    void ClearTracks();                                         // DCSDecoderNative.h:126
 
     // DCSDecoderNative.h:98.  The reference takes a bare pointer and trusts the stream to end; pass
     // maxLen when the size of the buffer behind streamPtr is known (bytes past it read as zero).
@@ -131,11 +152,6 @@ public:
     };
     StreamInfo GetStreamInfo(const ROMPointer &streamPtr, size_t maxLen = size_t(1) << 26);
 
-    void ClearTracks();                                         // DCSDecoderNative.h:126
-    // Track programs live in the ROM catalog, which is outside this path;
-    // the command is recorded and ignored.
-    void AddTrackCommand(uint16_t trackNum) { ignoredCommands.push_back(trackNum); }
-
     // ---- the batch-submit path (new): decode whole streams, each played alone from a fresh decoder at
     // (volume, mixingLevel), extraFrames taper frames appended per stream; one kernel launch for all.
     struct BatchStream
@@ -148,8 +164,10 @@ public:
     bool DecodeStreamsBatch(const std::vector<BatchStream> &streams, unsigned extraFrames,
                             std::vector<int16_t> &pcm, std::vector<uint32_t> *firstFrameOfStream = nullptr);
 
-    // Live playback decodes `frames` MainLoop ticks per kernel launch (default 1 = tick by tick).  Any
-    // LoadAudioStream / SetMasterVolume / ClearTracks discards ticks decoded ahead and replans.
+    // Live playback decodes `frames` MainLoop ticks per kernel launch (default 1 = tick by tick).  The
+    // sequencer simply runs that far ahead; anything that can change what it does -- WriteDataPort,
+    // AddTrackCommand, LoadAudioStream, SetMasterVolume, ClearTracks -- first takes it back to the last
+    // frame handed out, so the result does not depend on the look-ahead.
     void SetLookahead(int frames) { lookahead = frames < 1 ? 1 : frames > 4096 ? 4096 : frames; }
 
 protected:
@@ -158,37 +176,24 @@ protected:
     void MainLoop() override;
 
 private:
-    struct Channel
-    {
-        bool active = false;
-        std::vector<uint8_t> bytes;             // private copy: the stream must outlive the lookahead
-        std::vector<DcsFrameIndex> index;
-        DcsStreamInfo info{};
-        uint32_t pos = 0;                       // next frame
-        int level = 0;                          // mixer[ch].curLevel (level byte << 6)
-        uint16_t mixMul = 0x7FFF;               // Channel::mixingMultiplier (DCSDecoderNative.h:514)
-        bool stopPending = false;               // AudioStream::stop: the next tick resets the mixer level (:95-116)
-    };
-    void PlanAndDecode();
-    void Invalidate();
+    void Sync();                                // back to the state after the last frame handed out
     DcsOsVersion AbiOs() const;
+    bool EnsureRoms();
 
     DcsCtx *ctx = nullptr;
+    DcsRomSet *roms = nullptr;
+    DcsSequencer *seq = nullptr;
     int deviceId;
+    HWVersion hwVersion = HWVersion::Unknown;
+    uint32_t nominalVersion = 0;
     uint16_t reportedVersion = 0x0106;
-    uint16_t volumeMultiplier = 0x0391;         // DCSDecoderNative.h:161
-    Channel channel[DCS_MAX_CHANNELS];
+    int masterVolume = -1;                      // last SetMasterVolume before the sequencer existed
     int lookahead = 1;
     std::deque<std::vector<int16_t>> ready;     // frames decoded ahead
-    struct Snapshot
-    {
-        uint32_t pos[DCS_MAX_CHANNELS]; bool active[DCS_MAX_CHANNELS]; uint16_t mixMul[DCS_MAX_CHANNELS];
-        int level[DCS_MAX_CHANNELS]; bool stopPending[DCS_MAX_CHANNELS]; int16_t tail[16];
-    };
-    std::deque<Snapshot> after;                 // decoder state after each ready frame
-    Snapshot rewind{};                          // decoder state after the last frame handed out
-    int16_t tail[16] = { 0 };                   // overlapBuffer (DCSDecoderNative.h:149)
-    std::vector<uint16_t> ignoredCommands;
+    uint32_t handedOut = 0;                     // frames of the current batch already handed out
+    std::deque<DcsHostByte> hostBytes;          // bytes for the host, by tick, not delivered yet
+    uint64_t nextTick = 0;                      // tick of the next frame to hand out
+    std::string zipError;
 };
 
 }   // namespace dcship

@@ -377,6 +377,7 @@ typedef struct DcsSequencer DcsSequencer;
 typedef struct DcsHostByte { uint32_t tick; uint32_t byte; } DcsHostByte;      /* a byte the decoder sent to the host */
 
 DcsSequencer *dcs_seq_create(const DcsRomSet *rs);                   /* NULL: no U2 / versions unknown          */
+DcsSequencer *dcs_seq_create_standalone(DcsOsVersion os);            /* no ROMs: streams from caller memory     */
 void        dcs_seq_destroy(DcsSequencer *seq);
 const char *dcs_seq_last_error(const DcsSequencer *seq);
 DcsStatus   dcs_seq_set_master_volume(DcsSequencer *seq, int volume);             /* SetMasterVolume           */
@@ -385,9 +386,18 @@ DcsStatus   dcs_seq_write_data_port(DcsSequencer *seq, uint8_t byte);           
 DcsStatus   dcs_seq_add_track_command(DcsSequencer *seq, uint16_t track);         /* AddTrackCommand (:1475)   */
 DcsStatus   dcs_seq_clear_tracks(DcsSequencer *seq);                              /* ClearTracks (:1466)       */
 DcsStatus   dcs_seq_load_audio_stream(DcsSequencer *seq, int channel, uint32_t linearAddress, int mixingLevel);
+/* LoadAudioStream for a stream in caller memory (copied), the ROM-less recipe of DCSEncoder.cpp:522-571 */
+DcsStatus   dcs_seq_load_audio_stream_mem(DcsSequencer *seq, int channel, const uint8_t *data, size_t len, int mixingLevel);
 DcsStatus   dcs_seq_plan(DcsSequencer *seq, uint32_t nTicks);        /* run nTicks ticks, extend the pending plan  */
+/* go back inside the current batch (pending, or just decoded): state, overlap tail and host bytes as they were
+ * after its first keepTicks ticks; how a caller that decodes ahead stays exact when a command arrives */
+DcsStatus   dcs_seq_rewind(DcsSequencer *seq, uint32_t keepTicks);
+DcsStatus   dcs_seq_set_rewindable(DcsSequencer *seq, int on);      /* keep a snapshot per tick (off by default)  */
 uint32_t    dcs_seq_pending_ticks(const DcsSequencer *seq);
 int         dcs_seq_is_fatal(const DcsSequencer *seq);               /* DecoderFatalError after 4 failed passes    */
+uint64_t    dcs_seq_tick(const DcsSequencer *seq);                   /* ticks run so far                           */
+uint64_t    dcs_seq_fatal_tick(const DcsSequencer *seq);             /* first silent tick of a fatal error, or ~0  */
+int         dcs_seq_stream_playing(const DcsSequencer *seq, int channel);   /* IsStreamPlaying (:101)              */
 /* bytes sent to the host since the last successful call; returns their number (call with out = NULL to size) */
 uint32_t    dcs_seq_host_bytes(DcsSequencer *seq, DcsHostByte *out, uint32_t cap);
 /* decode the pending plan (pcmOut = pending ticks x 240 samples) in one launch and clear it; the overlap

@@ -78,6 +78,66 @@ int main(int argc, char **argv)
                 pcm.push_back(dec->GetNextSample());
         if (!dec->IsOK()) { fprintf(stderr, "decoder failed: %s\n", dec->GetErrorMessage().c_str()); return 5; }
     }
+    else if (mode == "script")
+    {
+        // ROM mode, the way DCSExplorer drives a decoder: AddROM per chip, CheckROMs, SoftBoot, then data-port
+        // bytes / track commands while pulling samples.  argv: script os volume lookahead OUT nTicks <script file>
+        // <u2> <u3> <u4>; script lines "tick kind value" (kind 0 WriteDataPort, 1 AddTrackCommand, 2 SetMasterVolume,
+        // 3 ClearTracks); host bytes go to <OUT>.host as "tick byte" lines
+        struct Cap : public DCSDecoder::Host
+        {
+            std::vector<std::pair<unsigned, unsigned>> log; unsigned tick = 0;
+            void ReceiveDataPort(uint8_t d) override { log.emplace_back(tick, d); }
+            void ClearDataPort() override { }
+            void BootTimerControl(bool) override { }
+        } cap;
+        delete dec;
+        dec = new DCSDecoderHIP(&cap);
+        std::vector<std::vector<uint8_t>> images;
+        for (int i = 8, chip = 2 ; i < argc ; ++i, ++chip)
+        {
+            images.push_back(readFile(argv[i]));
+            dec->AddROM(chip, images.back().data(), images.back().size());
+        }
+        const uint8_t status = dec->CheckROMs();
+        fprintf(stderr, "CheckROMs %d, version %04x, %d tracks, %zu streams\n", status, dec->GetVersionNumber(),
+                dec->GetMaxTrackNumber() + 1, dec->ListStreams().size());
+        dec->SetDefaultVolume(volume);
+        dec->SoftBoot();
+        dec->SetMasterVolume(volume);
+        dec->SetLookahead(atoi(argv[4]));
+        if (!dec->IsOK()) { fprintf(stderr, "decoder not OK: %s\n", dec->GetErrorMessage().c_str()); return 4; }
+        std::vector<unsigned> ev;
+        {
+            FILE *f = fopen(argv[7], "r");
+            unsigned a, b, c;
+            while (f != nullptr && fscanf(f, "%u %u %u", &a, &b, &c) == 3) { ev.push_back(a); ev.push_back(b); ev.push_back(c); }
+            if (f != nullptr) fclose(f);
+        }
+        const unsigned nTicks = static_cast<unsigned>(atoi(argv[6]));
+        size_t e = 0;
+        for (cap.tick = 0 ; cap.tick < nTicks ; ++cap.tick)
+        {
+            for ( ; e < ev.size() && ev[e] <= cap.tick ; e += 3)
+            {
+                if (ev[e + 1] == 0) dec->WriteDataPort(static_cast<uint8_t>(ev[e + 2]));
+                else if (ev[e + 1] == 1) dec->AddTrackCommand(static_cast<uint16_t>(ev[e + 2]));
+                else if (ev[e + 1] == 2) dec->SetMasterVolume(static_cast<int>(ev[e + 2]));
+                else if (ev[e + 1] == 3) dec->ClearTracks();
+            }
+            for (int si = 0 ; si < 240 ; ++si)
+                pcm.push_back(dec->GetNextSample());
+        }
+        FILE *hf = fopen((std::string(argv[5]) + ".host").c_str(), "w");
+        for (auto &hb : cap.log) fprintf(hf, "%u %u\n", hb.first, hb.second);
+        fprintf(hf, "fatal %d\n", dec->IsOK() ? 0 : 1);
+        fclose(hf);
+        FILE *out = fopen(argv[5], "wb");
+        fwrite(pcm.data(), sizeof(int16_t), pcm.size(), out);
+        fclose(out);
+        delete dec;
+        return 0;
+    }
     else if (mode == "extract")
     {
         // the stream loop of DCSExplorer --extract-streams, written the way it is there (DCSExplorer.cpp:1670-1721,

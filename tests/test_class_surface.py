@@ -101,3 +101,33 @@ def test_extract_streams_loop_matches_oracle(tmp_path, oracle, lookahead):
         raw = open("%s.%d.wav" % (out, k), "rb").read()
         assert raw[:44] == D.wav_header(n) and raw[44:] == want[pos:pos + n].tobytes()
         pos += n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lookahead", [1, 9])
+@pytest.mark.parametrize("script", ["main", "fatal-opcode", "volume-and-clear"])
+def test_rom_mode_script_through_the_class(tmp_path, lookahead, script):
+    """DCSDecoderHIP driven like DCSExplorer drives a decoder: AddROM, CheckROMs, SoftBoot, WriteDataPort /
+    AddTrackCommand while pulling samples.  PCM, the bytes sent to the host (with their tick) and the fatal
+    state equal the reference decoder's, whatever the look-ahead."""
+    import json, sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_seq_golden as G
+    import romkit
+    from oracle.dcs_oracle import fnv1a64
+    case = G.CASES[3]                                   # DCS-95 board, OS95
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "seq_golden.json")))["%s/%s" % (case[0], script)]
+    rs = G.build(case)
+    n, ev = romkit.SCRIPTS[script]
+    sf = tmp_path / "script.txt"
+    sf.write_text("".join("%d %d %d\n" % e for e in sorted(ev, key=lambda x: x[0])))
+    roms = [write_stream(tmp_path, "u%d.rom" % c, rs.images[c]) for c in (2, 3, 4)]
+    p, out = run(["script", "3", str(G.VOLUME), str(lookahead), "OUT", str(n), str(sf)] + roms, tmp_path)
+    assert p.returncode == 0, p.stderr
+    assert "CheckROMs 1, version 0104" in p.stderr
+    pcm = np.fromfile(out, dtype=np.int16)
+    lines = open(out + ".host").read().split("\n")
+    host = [[int(x) for x in l.split()] for l in lines if l and not l.startswith("fatal")]
+    assert host == gold["host_bytes"]
+    assert ("fatal 1" in lines) == gold["fatal"]
+    assert "%016x" % fnv1a64(pcm.tobytes()) == gold["pcm_fnv1a64"]
