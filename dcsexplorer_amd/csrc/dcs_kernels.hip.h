@@ -44,6 +44,8 @@ __host__ __device__ constexpr int subLanes(int fpw) { return 64 / fpw; }     // 
 
 // per wavefront: tile rows | tails [fpw][16] i16 | bit pool
 __host__ __device__ constexpr int waveLdsBytes(int fpw) { return fpw * kRowBytes + fpw * 32 + poolDwords(fpw) * 4; }
+// workgroup layout: tables | the four wavefronts' bit pools | the four wavefronts' (tile rows, tails).  The pools
+// come first on purpose, see BitReader.
 __host__ __device__ constexpr int ldsBytes(int fpw)
 {
     return static_cast<int>(sizeof(DcsLdsTables)) + kWavesPerBlock * waveLdsBytes(fpw);
@@ -104,6 +106,10 @@ struct BitReader
                             // the per-symbol critical path
     int negpos;             // 0..31: unread bits of the window that lie below the next 32
 
+    // A reader never runs more than about 1 KB past where it started (16 bands x 32 symbols x 16 bits), and in
+    // the workgroup's LDS layout every bit pool is followed by at least 8 KB of other data (more pools, then the
+    // tile rows), so even a reader driven by a record that does not match the bytes (only a caller-made one can
+    // be) stays inside the allocation without a bound check.
     __device__ __forceinline__ void init(const uint32_t *pool, int bitInDword)
     {
         hi = 0;
@@ -155,11 +161,12 @@ template <int FPW>
 struct Lds
 {
     unsigned char *tab;         // workgroup-shared tables
-    unsigned char *base;        // this wavefront's region
+    unsigned char *base;        // this wavefront's tile rows and tails
+    unsigned char *poolBase;    // this wavefront's bit pool
     __device__ __forceinline__ const DcsLdsTables *tables() const { return reinterpret_cast<const DcsLdsTables *>(tab); }
     __device__ __forceinline__ uint16_t *row(int s) const { return reinterpret_cast<uint16_t *>(base + s * kRowBytes); }
     __device__ __forceinline__ uint16_t *tails() const { return reinterpret_cast<uint16_t *>(base + FPW * kRowBytes); }      // [FPW][16]
-    __device__ __forceinline__ uint32_t *pool() const { return reinterpret_cast<uint32_t *>(base + FPW * (kRowBytes + 32)); }
+    __device__ __forceinline__ uint32_t *pool() const { return reinterpret_cast<uint32_t *>(poolBase); }
 };
 
 // what one sub-lane knows about the frame quarter it unpacks
@@ -245,7 +252,13 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
     const bool type1 = format != DCS_FMT_94_T0;
     uint32_t err = 0;
     int nb = has ? Q.nb : 0;
-    int outIdx = Q.outIdx;
+    // the most this lane's bands can advance the output index (samples per band, :1848-1850): with the index
+    // pass's own records start + advance <= 256 always holds, so the clamp only bites on a caller-made record
+    // that does not belong to the stream and keeps such a lane inside its frame's row
+    const int b1 = Q.bandBase + nb;
+    const int before = Q.bandBase <= 0 ? 0 : Q.bandBase == 1 ? 7 : 15 + 16 * (Q.bandBase - 2);
+    const int upTo = b1 <= 0 ? 0 : b1 == 1 ? 7 : b1 >= 16 ? 255 : 15 + 16 * (b1 - 2);
+    int outIdx = min(Q.outIdx, 256 - (upTo - before));
     bool valid = true;
     const bool owner = has && Q.bandBase == 0;          // the lane that holds band 0 does the DC fix-up
     const uint32_t saved1 = (owner && !FIRST) ? row[1] : 0u;
@@ -593,7 +606,8 @@ __device__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *row, BitReader &b
             for (int k = 0 ; k < 2 ; ++k, ++outIdx)
             {
                 const int p = mul24(sx16(pair[k]), sfs);
-                row[outIdx] = static_cast<uint16_t>(roundHi((static_cast<uint32_t>(row[outIdx]) << 16) + (static_cast<uint32_t>(p) << 1), p));
+                uint16_t *cell = &row[outIdx < 256 ? outIdx : kDummyWord];      // (254 words at most with a matching record)
+                *cell = static_cast<uint16_t>(roundHi((static_cast<uint32_t>(*cell) << 16) + (static_cast<uint32_t>(p) << 1), p));
             }
         }
     }
@@ -963,7 +977,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = static_cast<int>(threadIdx.x) >> 6;
     const int lane = static_cast<int>(threadIdx.x) & 63;
-    const Lds<FPW> L{ smem, smem + sizeof(DcsLdsTables) + wave * waveLdsBytes(FPW) };
+    constexpr int kPoolBytes = poolDwords(FPW) * 4, kTileBytes = FPW * (kRowBytes + 32);
+    static_assert(kPoolBytes % 16 == 0 && kWavesPerBlock * kTileBytes >= 8192, "LDS layout");
+    const Lds<FPW> L{ smem, smem + sizeof(DcsLdsTables) + kWavesPerBlock * kPoolBytes + wave * kTileBytes,
+                      smem + sizeof(DcsLdsTables) + wave * kPoolBytes };
     const uint32_t chunk = blockIdx.x * kWavesPerBlock + static_cast<uint32_t>(wave);
     if (chunk < a.nChunks) DCS_STAMP(0);
     constexpr int SUB = subLanes(FPW);              // lanes that unpack one frame together

@@ -220,6 +220,16 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
             ctx->lastError = "source " + std::to_string(s) + ": bad format / header length / stream offset";
             return DCS_ERR_INVALID_ARG;
         }
+        // the index record steers where lanes start reading and writing inside LDS: it must be self-consistent
+        const DcsFrameIndex &ix = sd.idx;
+        bool ok = ix.hdrBits <= ix.nBits && ix.nBands <= (sd.format == DCS_FMT_93A_T1 ? 31 : 16);
+        for (int k = 0 ; k < 15 && ok ; ++k)
+            ok = ix.split[k].bitDelta <= ix.nBits && (ix.split[k].state & 0x1FFu) <= 256u;
+        if (!ok)
+        {
+            ctx->lastError = "source " + std::to_string(s) + ": inconsistent frame index record";
+            return DCS_ERR_INVALID_ARG;
+        }
         payloadBits += sd.idx.nBits;
     }
 

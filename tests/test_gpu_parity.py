@@ -220,3 +220,34 @@ def test_stream_sequence_on_one_decoder(gpu_ctx, oracle, os_):
             assert first[-1] == pcm.shape[0]
     L = gpu_ctx.L
     assert L.dcs_decode_stream_sequence(gpu_ctx.h, None, 0, 2, None, 0, None, None) == D.api.ERR_INVALID_ARG
+
+
+@pytest.mark.gpu
+def test_caller_made_index_records_cannot_break_the_launch(gpu_ctx):
+    """the batch ABI takes index records from the caller: inconsistent ones are refused before anything is
+    launched, and consistent ones that do not belong to the bytes (records of another stream) decode to
+    garbage but stay inside the kernel's LDS (bounded readers, bounded accumulator indices)"""
+    a = make_stream(D.FMT_94_T1_S3, 40, seed=91001, profile=0)
+    b_ = make_stream(D.FMT_94_T1_S3, 40, seed=91002, profile=3)
+    os_ = os_for(D.FMT_94_T1_S3)
+    batch = D.build_stream_batch([(os_, a, 255, 0x64), (os_, b_, 255, 0x64)])
+    srcs = batch["srcs"].copy()
+    bad = srcs.copy()
+    bad["idx"]["split"][3]["bitDelta"][5] = 60000                # beyond the frame
+    with pytest.raises(D.DcsError):
+        gpu_ctx.decode_batch(batch["blob"], bad, batch["jobs"])
+    bad = srcs.copy()
+    bad["idx"]["split"][3]["state"][2] = 0x1FF                  # output index outside the row
+    with pytest.raises(D.DcsError):
+        gpu_ctx.decode_batch(batch["blob"], bad, batch["jobs"])
+    # swap the records of the two streams (stream offsets stay): self-consistent, but not these bytes' records
+    n = 40
+    swapped = srcs.copy()
+    swapped["idx"][:n], swapped["idx"][n:] = srcs["idx"][n:].copy(), srcs["idx"][:n].copy()
+    for fpw in (4, 8, 16):
+        gpu_ctx.set_frames_per_wave(fpw)
+        pcm, err = gpu_ctx.decode_batch(batch["blob"], swapped, batch["jobs"])
+        assert pcm.shape == (80, 240)
+    gpu_ctx.set_frames_per_wave(0)
+    good, _ = gpu_ctx.decode_batch(batch["blob"], srcs, batch["jobs"])
+    assert good.any()
