@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--workload", default="dcs93_4096")
     ap.add_argument("--fpw", type=int, default=0, help="frames per wavefront override (8/16/32/64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scale", type=int, default=1, help="decode SCALE times the workload's streams per step (further "
+                    "seeds of the same recipe): the large-batch rate; not a BASELINE config")
     args = ap.parse_args()
 
     import numpy as np
@@ -72,6 +74,11 @@ def main():
 
     # this rank's range of the corpus: same shape on every rank, different streams (seeds)
     streams = sharding.rank_streams(args.workload, rank)
+    if args.scale > 1:
+        import inspect
+        fn = workloads.WORKLOADS[args.workload]
+        n = inspect.signature(fn).parameters["n_streams"].default
+        streams = fn(n_streams=n * args.scale * world)[rank * n * args.scale:(rank + 1) * n * args.scale]
     b = D.build_stream_batch(streams)
     if args.workload == "mixed_16384":
         b, _ = workloads.interleave(b)
@@ -113,7 +120,7 @@ def main():
         from oracle.dcs_oracle import fnv1a64
         pcm, err = batch.download()
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "dcs_golden_hashes.json")))["workloads"]
-        if args.workload in gold:
+        if args.workload in gold and args.scale == 1:
             if args.workload == "mixed_16384":
                 _, perm = workloads.interleave(D.build_stream_batch(streams))
                 inv = np.empty_like(perm); inv[perm] = np.arange(perm.size)
@@ -160,7 +167,7 @@ def main():
             "config": {"workload": args.workload, "frames_per_gpu_per_step": n_frames,
                        "samples_per_frame": 240, "frames_per_wave": args.fpw or "auto",
                        "arithmetic": "ADSP-2105 1.15 fixed point, 32-bit integer intermediates",
-                       "partition": "range over streams, no collective"},
+                       "partition": "range over streams, no collective", "scale": args.scale},
             "bit_exact": bit_exact,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,

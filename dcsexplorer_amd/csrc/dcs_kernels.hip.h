@@ -724,6 +724,35 @@ __device__ __forceinline__ void bfly(uint32_t &U, uint32_t &A, uint32_t tw)
     else     { U = pkSub(u, T);    A = pkAdd(u, T); }
 }
 
+__device__ __forceinline__ uint32_t twAt(const uint16_t *coef, int part)
+{
+    return static_cast<uint32_t>(coef[0x80 + part]) | (static_cast<uint32_t>(coef[part]) << 16);
+}
+
+// The first two entries of the twiddle table are exact: entry 0 = (cos, sin) = (-1.0, 0), entry 1 = (0, -1.0)
+// (0x8000 is -1.0 in 1.15; dcs_tables.cpp asserts the values).  Multiplying by them needs no multiplier and
+// never triggers the rounding quirk (the last product is 0 or a multiple of 0x8000), so the reference's result
+// reduces to  t = (-a.re, -a.im)  resp.  t = (a.im, -a.re)  with 16-bit wrap-around (-(-32768) = -32768), which
+// is what rotatePk returns for them.  The layout-A stages know their twiddle index at compile time.
+template <bool SAT>
+__device__ __forceinline__ void bflyIdx(uint32_t &U, uint32_t &A, const uint16_t *coef, int idx)
+{
+    uint32_t T;
+    if (idx == 0)
+        T = pkSub(0u, A);
+    else if (idx == 1)
+        T = __builtin_bit_cast(uint32_t, static_cast<u16x2>(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbit(A, A, 16))
+                                                              * __builtin_bit_cast(u16x2, 0xFFFF0001u)));
+    else
+    {
+        bfly<SAT>(U, A, twAt(coef, idx));
+        return;
+    }
+    const uint32_t u = U;
+    if (SAT) { U = pkSubSat(u, T); A = pkAddSat(u, T); }
+    else     { U = pkSub(u, T);    A = pkAdd(u, T); }
+}
+
 __device__ __forceinline__ int bitrev9(int v) { return static_cast<int>(__brev(static_cast<uint32_t>(v)) >> 23); }
 __device__ __forceinline__ int bitrevN(int v, int bits) { return static_cast<int>(__brev(static_cast<uint32_t>(v)) >> (32 - bits)); }
 
@@ -737,10 +766,6 @@ __device__ __forceinline__ int overlapMix(int x, uint32_t cx, int o, uint32_t co
 
 typedef DcsLaneConsts LaneConsts;
 
-__device__ __forceinline__ uint32_t twAt(const uint16_t *coef, int part)
-{
-    return static_cast<uint32_t>(coef[0x80 + part]) | (static_cast<uint32_t>(coef[part]) << 16);
-}
 
 // ten 16-byte loads per lane from the host-built table
 __device__ __forceinline__ void loadLaneConsts(const DcsDevTables *G, int lane, LaneConsts &C)
@@ -857,13 +882,13 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const uint16_t 
     }
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 4)) bfly<true>(x[r], x[r + 4], twAt(coef, r >> 3));
+        if (!(r & 4)) bflyIdx<true>(x[r], x[r + 4], coef, r >> 3);
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 2)) bfly<true>(x[r], x[r + 2], twAt(coef, r >> 2));
+        if (!(r & 2)) bflyIdx<true>(x[r], x[r + 2], coef, r >> 2);
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 1)) bfly<true>(x[r], x[r + 1], twAt(coef, r >> 1));
+        if (!(r & 1)) bflyIdx<true>(x[r], x[r + 1], coef, r >> 1);
     // ---- transpose to layout B: point p = 16 l' + r' lives in row (p >> 4), position (p & 15) ---------------
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
@@ -917,13 +942,13 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const uint16_t 
     // ---- stages d = 64, 32, 16 (wrapping) (:742-778) ------------------------------------------------------
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 4)) bfly<false>(x[r], x[r + 4], twAt(coef, r >> 3));
+        if (!(r & 4)) bflyIdx<false>(x[r], x[r + 4], coef, r >> 3);
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 2)) bfly<false>(x[r], x[r + 2], twAt(coef, r >> 2));
+        if (!(r & 2)) bflyIdx<false>(x[r], x[r + 2], coef, r >> 2);
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 1)) bfly<false>(x[r], x[r + 1], twAt(coef, r >> 1));
+        if (!(r & 1)) bflyIdx<false>(x[r], x[r + 1], coef, r >> 1);
     // ---- transpose: point 16 r + l  ->  lane r, register l.  The row holds 8 x 16 dwords, so two rounds:
     // registers 0..7 feed lanes 0..7, registers 8..15 feed lanes 8..15 ---------------------------------------------
     waveSync();         // every lane has read its part of the row: the row becomes scratch

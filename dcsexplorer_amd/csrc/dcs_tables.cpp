@@ -2,6 +2,7 @@
 // kernels (and the host index pass) use.  See dcs_common.h for the layouts.
 #include "dcs_common.h"
 #include "dcs_tables.h"
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -130,6 +131,9 @@ DcsDevTables build()
     memcpy(t.lds.scaleMant, kScaleMant, sizeof(t.lds.scaleMant));
     memcpy(t.pair93a, kPair93a, sizeof(t.pair93a));
     memcpy(t.fftCoef, kFftCoef, sizeof(t.fftCoef));
+    // the kernel's multiplier-free butterflies (bflyIdx) rely on these exact twiddles: (-1.0, 0) and (0, -1.0)
+    if (kFftCoef[0x80] != 0x8000 || kFftCoef[0] != 0x0000 || kFftCoef[0x81] != 0x0000 || kFftCoef[1] != 0x8000)
+        abort();
     memcpy(t.ovlCoef, kOverlapCoef, sizeof(t.ovlCoef));
 
     // per-lane transform constants (see DcsLaneConsts)
