@@ -80,7 +80,7 @@ EXPORTS = [
     "dcs_abi_version", "dcs_index_stream", "dcs_volume_multiplier", "dcs_mixing_multiplier", "dcs_frame_scale",
     "dcs_stream_params", "dcs_ctx_create", "dcs_ctx_destroy", "dcs_last_error", "dcs_device_count",
     "dcs_ctx_set_frames_per_wave", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run",
-    "dcs_batch_time", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_device_pcm",
+    "dcs_batch_time", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_download_view", "dcs_batch_device_pcm",
     "dcs_batch_algorithmic_bytes", "dcs_batch_num_jobs", "dcs_decode_streams", "dcs_count_stream_frames",
     "dcs_synth_stream", "dcs_plan_chunks", "dcs_index_streams", "dcs_index_streams_gpu",
     "dcs_index_streams_gpu_time", "dcs_stream_params_from", "dcs_decode_stream_sequence", "dcs_wav_header",
@@ -151,6 +151,8 @@ def load_library():
     L.dcs_batch_sync.argtypes = [vp]
     L.dcs_batch_download.restype = i32
     L.dcs_batch_download.argtypes = [vp, vp, vp, vp]
+    L.dcs_batch_download_view.restype = i32
+    L.dcs_batch_download_view.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.dcs_batch_device_pcm.restype = vp
     L.dcs_batch_device_pcm.argtypes = [vp]
     L.dcs_batch_algorithmic_bytes.restype = ctypes.c_uint64
@@ -612,6 +614,15 @@ class Batch:
         tails = np.zeros((self.n_jobs, 16), dtype=np.int16) if want_tails else None
         _check(self.L.dcs_batch_download(self.h, _ptr(pcm), _ptr(err), _ptr(tails)), self.ctx.h)
         return (pcm, err, tails) if want_tails else (pcm, err)
+
+    def download_view(self):
+        """PCM and error words as numpy views of the batch's pinned host memory (no copy into Python memory);
+        valid until the batch is run again or closed"""
+        p, e = ctypes.c_void_p(), ctypes.c_void_p()
+        _check(self.L.dcs_batch_download_view(self.h, ctypes.byref(p), ctypes.byref(e)), self.ctx.h)
+        pcm = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_int16)), shape=(self.n_jobs, FRAME_SAMPLES))
+        err = np.ctypeslib.as_array(ctypes.cast(e, ctypes.POINTER(ctypes.c_uint32)), shape=(self.n_jobs,))
+        return pcm, err
 
     @property
     def algorithmic_bytes(self):

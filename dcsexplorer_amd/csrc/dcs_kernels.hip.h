@@ -1014,6 +1014,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
     const int q = lane / FPW;                       // which part of the frame it unpacks
     const bool unpacker = q < SUB;
 
+    // this lane's slot record: requested first, so that the load is in flight while the tables are staged
+    // (all sub-lanes of a slot hold the same copy; padding wavefronts of the last workgroup read slot 0)
+    const DcsSlot slot = a.slots[chunk < a.nChunks ? static_cast<size_t>(chunk) * FPW + s : 0];
+
     // ---- stage the shared tables (whole workgroup), clear this wavefront's tile ------------------------
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(&a.tables->lds);
@@ -1030,8 +1034,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
 
     DCS_STAMP(1);
 
-    // ---- slot and job of this lane (all sub-lanes of a slot hold the same copy) -----------------
-    const DcsSlot slot = a.slots[static_cast<size_t>(chunk) * FPW + s];
+    // ---- job of this lane's slot ---------------------------------------------------------------------------
     const bool live = !(slot.flags & DCS_SLOT_EMPTY);
     struct { uint32_t firstSrc; int nSrc; int volShift; int xform; uint32_t prev; } job;
     job.firstSrc = slot.firstSrc; job.nSrc = slot.nSrc; job.volShift = slot.shiftXform & 15;

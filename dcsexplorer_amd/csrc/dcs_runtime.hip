@@ -29,7 +29,44 @@ struct DcsCtx
     uint32_t idxStreams = 0;
     uint64_t idxCap = 0;
     int idxLanes = 1;
+    // device and pinned-host buffers of destroyed batches, kept for the next batch (hipMalloc / hipFree cost
+    // about as much as decoding a few thousand frames)
+    struct Cached { void *p; size_t cap; };
+    std::vector<Cached> devCache, pinCache;
+    size_t cachedBytes = 0;
 };
+
+static const size_t kCacheLimit = size_t(4) << 30;     // bytes kept per context, device + pinned
+
+static hipError_t cacheAlloc(DcsCtx *ctx, bool pinned, void **out, size_t bytes)
+{
+    std::vector<DcsCtx::Cached> &c = pinned ? ctx->pinCache : ctx->devCache;
+    size_t best = c.size();
+    for (size_t i = 0 ; i < c.size() ; ++i)
+        if (c[i].cap >= bytes && c[i].cap <= bytes * 2 + 4096 && (best == c.size() || c[i].cap < c[best].cap))
+            best = i;
+    if (best != c.size())
+    {
+        *out = c[best].p;
+        ctx->cachedBytes -= c[best].cap;
+        c.erase(c.begin() + static_cast<long>(best));
+        return hipSuccess;
+    }
+    return pinned ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+}
+
+static void cacheFree(DcsCtx *ctx, bool pinned, void *p, size_t cap)
+{
+    if (p == nullptr)
+        return;
+    if (ctx->cachedBytes + cap > kCacheLimit)
+    {
+        if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
+        return;
+    }
+    (pinned ? ctx->pinCache : ctx->devCache).push_back(DcsCtx::Cached{ p, cap });
+    ctx->cachedBytes += cap;
+}
 
 struct DcsBatch
 {
@@ -48,6 +85,11 @@ struct DcsBatch
     uint32_t *dErr = nullptr;
     int16_t *dTailsOut = nullptr;
     unsigned long long *dDebug = nullptr;   // DCS_STAMPS builds only
+    size_t cap[8] = { 0 };                  // allocated bytes of the buffers above, in that order
+    // pinned host mirror of (pcm, err), filled by dcs_batch_download_view
+    int16_t *hPcm = nullptr;
+    uint32_t *hErr = nullptr;
+    size_t hCap[2] = { 0 };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -143,6 +185,8 @@ extern "C" void dcs_ctx_destroy(DcsCtx *ctx)
     if (ctx->dIdxLocs) (void)hipFree(ctx->dIdxLocs);
     if (ctx->dIdxOut) (void)hipFree(ctx->dIdxOut);
     if (ctx->dIdxInfos) (void)hipFree(ctx->dIdxInfos);
+    for (const DcsCtx::Cached &c : ctx->devCache) (void)hipFree(c.p);
+    for (const DcsCtx::Cached &c : ctx->pinCache) (void)hipHostFree(c.p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -172,9 +216,12 @@ extern "C" void dcs_batch_destroy(DcsBatch *b)
     if (b == nullptr)
         return;
     (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);         // nothing of this batch is in flight when its buffers are recycled
     void *ptrs[] = { b->dBlob, b->dSrcs, b->dSlots, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug };
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+    for (int i = 0 ; i < 8 ; ++i)
+        cacheFree(b->ctx, false, ptrs[i], b->cap[i]);
+    cacheFree(b->ctx, true, b->hPcm, b->hCap[0]);
+    cacheFree(b->ctx, true, b->hErr, b->hCap[1]);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     delete b;
@@ -251,28 +298,28 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
     DcsStatus st = [&]() -> DcsStatus {
         HIPCHK(ctx, hipSetDevice(ctx->device));
         const size_t blobAlloc = ((blobLen + 3) & ~size_t(3)) + 64;         // zero tail: the bit reader prefetches past the end
-        HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dBlob), blobAlloc));
+        b->cap[0] = blobAlloc; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dBlob), b->cap[0]));
         HIPCHK(ctx, hipMemsetAsync(b->dBlob, 0, blobAlloc, ctx->stream));
         if (blobLen)
             HIPCHK(ctx, hipMemcpyAsync(b->dBlob, blob, blobLen, hipMemcpyHostToDevice, ctx->stream));
         if (nSrcs)
         {
-            HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dSrcs), sizeof(DcsSrcDesc) * nSrcs));
+            b->cap[1] = sizeof(DcsSrcDesc) * nSrcs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dSrcs), b->cap[1]));
             HIPCHK(ctx, hipMemcpyAsync(b->dSrcs, srcs, sizeof(DcsSrcDesc) * nSrcs, hipMemcpyHostToDevice, ctx->stream));
         }
-        HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dSlots), sizeof(DcsSlot) * slots.size()));
+        b->cap[2] = sizeof(DcsSlot) * slots.size(); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dSlots), b->cap[2]));
         HIPCHK(ctx, hipMemcpyAsync(b->dSlots, slots.data(), sizeof(DcsSlot) * slots.size(), hipMemcpyHostToDevice, ctx->stream));
         if (nTailsIn)
         {
-            HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dTailsIn), sizeof(int16_t) * 16 * nTailsIn));
+            b->cap[3] = sizeof(int16_t) * 16 * nTailsIn; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsIn), b->cap[3]));
             HIPCHK(ctx, hipMemcpyAsync(b->dTailsIn, tailsIn, sizeof(int16_t) * 16 * nTailsIn, hipMemcpyHostToDevice, ctx->stream));
         }
-        HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dPcm), sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs));
-        HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dErr), sizeof(uint32_t) * nJobs));
-        HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dTailsOut), sizeof(int16_t) * 16 * nJobs));
+        b->cap[4] = sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPcm), b->cap[4]));
+        b->cap[5] = sizeof(uint32_t) * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dErr), b->cap[5]));
+        b->cap[6] = sizeof(int16_t) * 16 * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsOut), b->cap[6]));
         HIPCHK(ctx, hipMemsetAsync(b->dErr, 0, sizeof(uint32_t) * nJobs, ctx->stream));
 #ifdef DCS_STAMPS
-        HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&b->dDebug), sizeof(unsigned long long) * 8 * (b->nChunks + 4)));
+        b->cap[7] = sizeof(unsigned long long) * 8 * (b->nChunks + 4); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dDebug), b->cap[7]));
         HIPCHK(ctx, hipMemsetAsync(b->dDebug, 0, sizeof(unsigned long long) * 8 * (b->nChunks + 4), ctx->stream));
 #endif
         HIPCHK(ctx, hipEventCreate(&b->ev0));
@@ -369,6 +416,35 @@ extern "C" DcsStatus dcs_batch_download(DcsBatch *b, int16_t *pcmOut, uint32_t *
         HIPCHK(ctx, hipMemcpy(errOut, b->dErr, sizeof(uint32_t) * b->nJobs, hipMemcpyDeviceToHost));
     if (tailsOut)
         HIPCHK(ctx, hipMemcpy(tailsOut, b->dTailsOut, sizeof(int16_t) * 16 * b->nJobs, hipMemcpyDeviceToHost));
+    return DCS_OK;
+}
+
+// PCM and error words in PINNED host memory owned by the batch (valid until it is destroyed or run again):
+// the device-to-host copy runs at link speed and the caller reads the result in place.
+extern "C" DcsStatus dcs_batch_download_view(DcsBatch *b, const int16_t **pcmOut, const uint32_t **errOut)
+{
+    if (b == nullptr || pcmOut == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    DcsCtx *ctx = b->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t pcmBytes = sizeof(int16_t) * DCS_FRAME_SAMPLES * b->nJobs, errBytes = sizeof(uint32_t) * b->nJobs;
+    if (b->hPcm == nullptr)
+    {
+        b->hCap[0] = pcmBytes;
+        HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&b->hPcm), pcmBytes));
+    }
+    if (b->hErr == nullptr && errOut != nullptr)
+    {
+        b->hCap[1] = errBytes;
+        HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&b->hErr), errBytes));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(b->hPcm, b->dPcm, pcmBytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (errOut != nullptr)
+        HIPCHK(ctx, hipMemcpyAsync(b->hErr, b->dErr, errBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *pcmOut = b->hPcm;
+    if (errOut != nullptr)
+        *errOut = b->hErr;
     return DCS_OK;
 }
 

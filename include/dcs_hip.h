@@ -222,6 +222,9 @@ DcsStatus dcs_batch_run(DcsBatch *batch, void *hipStream);
 DcsStatus dcs_batch_time(DcsBatch *batch, void *hipStream, int iters, float *avgMs);
 DcsStatus dcs_batch_sync(DcsBatch *batch);
 DcsStatus dcs_batch_download(DcsBatch *batch, int16_t *pcmOut, uint32_t *errOut, int16_t *tailsOut);
+/* the same without the copy into caller memory: PCM (and error words) in pinned host memory owned by the batch,
+ * valid until the batch is run again or destroyed; the device-to-host copy then runs at link speed */
+DcsStatus dcs_batch_download_view(DcsBatch *b, const int16_t **pcmOut, const uint32_t **errOut);
 /* device pointers, for callers that keep the PCM on the GPU (int16 [nJobs][240]) */
 void     *dcs_batch_device_pcm(DcsBatch *batch);
 /* bytes the kernel reads + writes for this batch, by the definition of SURVEY section 8(d) */

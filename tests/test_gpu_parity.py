@@ -147,6 +147,22 @@ def test_full_size_workloads_hash_and_sampled_oracle(gpu_ctx, oracle, wl):
         assert_same(pcm[first[k]:first[k + 1]], oracle_streams(oracle, [b["streams"][k]]), "%s stream %d" % (wl, k))
 
 
+def test_pinned_download_view_and_buffer_reuse(gpu_ctx):
+    """dcs_batch_download_view hands out the result in pinned memory; buffers of closed batches are reused"""
+    b = workloads.build("dcs93_4096", n_streams=6, n_frames=20)
+    want = None
+    for _ in range(3):                                  # the 2nd and 3rd batch run on recycled buffers
+        bt = gpu_ctx.batch(b["blob"], b["srcs"], b["jobs"])
+        bt.run(); bt.sync()
+        pcm, err = bt.download()
+        pv, ev = bt.download_view()
+        assert np.array_equal(pv, pcm) and np.array_equal(ev, err)
+        want = pcm if want is None else want
+        assert np.array_equal(pcm, want)
+        bt.close()
+
+
+@pytest.mark.gpu
 def test_batch_is_idempotent_and_resident(gpu_ctx):
     """a resident batch run twice gives identical PCM; timing entry returns a positive duration"""
     b = workloads.build("dcs93_4096", n_streams=16, n_frames=32)
