@@ -108,7 +108,7 @@ constexpr uint32_t dcsPoolCapacity(int fpw)
 #define DCS_SLOT_EMPTY     0x80u        // padding
 #define DCS_NO_PREV_SLOT   0xFFu
 
-struct DcsSlot                          // 16 bytes: everything the kernel needs to know about a job, so
+struct DcsSlot                          // 32 bytes: everything the kernel needs to know about a job, so
 {                                       // that the job list itself is never read on the device
     uint32_t job;                       // output index (PCM row, err entry)
     uint8_t  prevSlot;                  // slot index inside the chunk whose tail overlaps into this one
@@ -117,6 +117,12 @@ struct DcsSlot                          // 16 bytes: everything the kernel needs
     uint8_t  shiftXform;                // volShift | xform << 4
     uint32_t firstSrc;
     uint32_t prevJob;                   // DcsFrameJob.prev (external-tail index when DCS_SLOT_EXT_TAIL)
+    // where the compressed bytes of the job's FIRST source lie and where they go in the chunk's bit pool,
+    // worked out by the planner so that the staging loads need not wait for the descriptor
+    uint32_t startDw;                   // first blob dword of the frame
+    uint16_t nDw;                       // dwords to stage (dcsPoolDwords), 0 = no source
+    uint16_t poolOff;                   // dword offset of the frame in the wavefront's pool
+    uint32_t reserved[2];
 };
 
 struct DcsKernelArgs

@@ -1083,18 +1083,25 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             Q.preAdj = d2.y & 0xFFFFu;
 
             const uint64_t bitPos = (streamOff + 2 + static_cast<uint64_t>(hdrLen)) * 8 + bitOff;
-            const uint32_t startDw = static_cast<uint32_t>(bitPos >> 5);
-            const uint32_t nDw = (has && q == 0) ? dcsPoolDwords(streamOff, static_cast<uint32_t>(hdrLen), bitOff, nBits) : 0u;
-
-            // exclusive prefix sum of the dword counts over the slots = each frame's offset in the pool
-            uint32_t incl = nDw;
-#pragma unroll
-            for (int d = 1 ; d < 64 ; d <<= 1)
+            // which blob dwords to stage and where in the pool.  For a job's first source the planner has put this
+            // into the slot record, so the staging loads below do not wait for the descriptor; for further
+            // sources (multi-channel mixes) it follows from the descriptors and a prefix sum over the slots.
+            uint32_t startDw = slot.startDw;
+            uint32_t nDw = (has && q == 0) ? static_cast<uint32_t>(slot.nDw) : 0u;
+            uint32_t offMine = slot.poolOff;
+            if (r != 0)
             {
-                const uint32_t up = __shfl_up(incl, d);
-                if (lane >= d) incl += up;
+                startDw = static_cast<uint32_t>(bitPos >> 5);
+                nDw = (has && q == 0) ? dcsPoolDwords(streamOff, static_cast<uint32_t>(hdrLen), bitOff, nBits) : 0u;
+                uint32_t incl = nDw;
+#pragma unroll
+                for (int d = 1 ; d < 64 ; d <<= 1)
+                {
+                    const uint32_t up = __shfl_up(incl, d);
+                    if (lane >= d) incl += up;
+                }
+                offMine = incl - nDw;
             }
-            const uint32_t offMine = incl - nDw;
             const uint32_t off = __shfl(offMine, s);                        // from the slot's q = 0 lane
             const uint32_t nDwSlot = __shfl(nDw, s);
             const bool fits = off + nDwSlot <= static_cast<uint32_t>(poolDwords(FPW));

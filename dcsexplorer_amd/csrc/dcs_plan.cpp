@@ -13,9 +13,19 @@
 #include "dcs_common.h"
 #include <vector>
 
-static DcsSlot makeSlot(const DcsFrameJob &jb, uint32_t job, uint8_t prevSlot, uint8_t flags)
+// poolOff = dwords the chunk's earlier slots already take in unpack round 0
+static DcsSlot makeSlot(const DcsFrameJob &jb, uint32_t job, uint8_t prevSlot, uint8_t flags, const DcsSrcDesc *srcs, uint32_t poolOff)
 {
-    return DcsSlot{ job, prevSlot, flags, jb.nSrc, static_cast<uint8_t>(jb.volShift | (jb.xform << 4)), jb.firstSrc, jb.prev };
+    DcsSlot sl{ job, prevSlot, flags, jb.nSrc, static_cast<uint8_t>(jb.volShift | (jb.xform << 4)), jb.firstSrc, jb.prev, 0, 0, 0, { 0, 0 } };
+    if (srcs != nullptr && jb.nSrc != 0)
+    {
+        const DcsSrcDesc &sd = srcs[jb.firstSrc];
+        const uint64_t bitPos = (sd.streamOff + 2 + sd.hdrLen) * 8 + sd.idx.bitOff;
+        sl.startDw = static_cast<uint32_t>(bitPos >> 5);
+        sl.nDw = static_cast<uint16_t>(dcsPoolDwords(sd.streamOff, sd.hdrLen, sd.idx.bitOff, sd.idx.nBits));
+        sl.poolOff = static_cast<uint16_t>(poolOff < 0xFFFFu ? poolOff : 0xFFFFu);
+    }
+    return sl;
 }
 
 uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots)
@@ -52,7 +62,7 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
 
     uint32_t chunk = 0;
     uint32_t used = 0;                  // slots filled in the current chunk
-    const DcsSlot empty{ 0xFFFFFFFFu, DCS_NO_PREV_SLOT, DCS_SLOT_EMPTY, 0, 0, 0, DCS_PREV_NONE };
+    const DcsSlot empty{ 0xFFFFFFFFu, DCS_NO_PREV_SLOT, DCS_SLOT_EMPTY, 0, 0, 0, DCS_PREV_NONE, 0, 0, 0, { 0, 0 } };
     auto closeChunk = [&]() {
         while (used < static_cast<uint32_t>(fpw)) { slots.push_back(empty); ++used; }
         ++chunk;
@@ -110,14 +120,14 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
         {
             if (!inChunk(prev))
             {
-                slots.push_back(makeSlot(jobs[prev], prev, DCS_NO_PREV_SLOT, DCS_SLOT_HALO));
+                slots.push_back(makeSlot(jobs[prev], prev, DCS_NO_PREV_SLOT, DCS_SLOT_HALO, srcs, poolUse[0]));
                 poolAdd(prev);
                 stampOf[prev] = chunk;
                 slotOf[prev] = static_cast<uint8_t>(used++);
             }
             prevSlot = slotOf[prev];
         }
-        slots.push_back(makeSlot(jobs[j], j, prevSlot, static_cast<uint8_t>(ext ? DCS_SLOT_EXT_TAIL : 0)));
+        slots.push_back(makeSlot(jobs[j], j, prevSlot, static_cast<uint8_t>(ext ? DCS_SLOT_EXT_TAIL : 0), srcs, poolUse[0]));
         poolAdd(j);
         stampOf[j] = chunk;
         slotOf[j] = static_cast<uint8_t>(used++);

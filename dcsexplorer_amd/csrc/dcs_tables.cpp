@@ -178,4 +178,4 @@ static_assert(sizeof(DcsSrcDesc) == 160, "DcsSrcDesc layout");
 static_assert(offsetof(DcsSrcDesc, idx) == 12, "DcsSrcDesc layout");
 static_assert(sizeof(DcsFrameJob) == 16, "DcsFrameJob layout");
 static_assert(sizeof(DcsFrameIndex) == 148 && offsetof(DcsFrameIndex, split) == 28, "DcsFrameIndex layout");
-static_assert(sizeof(DcsSlot) == 16, "DcsSlot layout");
+static_assert(sizeof(DcsSlot) == 32, "DcsSlot layout");
