@@ -117,12 +117,20 @@ struct DcsSlot                          // 32 bytes: everything the kernel needs
     uint8_t  shiftXform;                // volShift | xform << 4
     uint32_t firstSrc;
     uint32_t prevJob;                   // DcsFrameJob.prev (external-tail index when DCS_SLOT_EXT_TAIL)
-    // where the compressed bytes of the job's FIRST source lie and where they go in the chunk's bit pool,
-    // worked out by the planner so that the staging loads need not wait for the descriptor
-    uint32_t startDw;                   // first blob dword of the frame
-    uint16_t nDw;                       // dwords to stage (dcsPoolDwords), 0 = no source
-    uint16_t poolOff;                   // dword offset of the frame in the wavefront's pool
-    uint32_t reserved[2];
+    // Unpack round 0 (the FIRST source of every job), worked out by the planner so that nothing of it waits for
+    // the descriptor.  The compressed bytes of a chunk's frames mostly lie back to back in the blob (consecutive
+    // frames of one stream), so they are staged as RUNS of dwords, 16 bytes per lane: slot k of a chunk carries
+    // run k (runNDw == 0: no further run), which has nothing to do with slot k's own frame.
+    uint32_t runStartDw;                // first blob dword of run k
+    uint16_t runNDw;                    // its length in dwords (whole frames + 3 dwords of window look-ahead)
+    uint16_t poolOff;                   // THIS slot's frame: pool dword that holds its first bit
+    // likewise for the first source's stream header and split records: with these the header bytes and the lane's
+    // split record are requested together with the descriptor instead of one memory round trip after it
+    uint32_t hdrDw;                     // blob dword that holds the first header byte (streamOff + 2)
+    uint8_t  hdrSh;                     // byte position of that byte in the dword
+    uint8_t  bpl;                       // header bands per unpack lane, ceil(min(nBands, 16) / (64 / fpw)); 0: one lane
+                                        // unpacks the whole frame (DCS_IDX_SERIAL)
+    uint16_t runPoolOff;                // pool dword where run k goes (a multiple of 4)
 };
 
 struct DcsKernelArgs

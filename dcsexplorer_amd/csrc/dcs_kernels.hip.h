@@ -23,6 +23,8 @@
 // DCSDecoderNative.h:822-906, .cpp:3447-3580.  No MFMA: this is integer small-transform work.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include <cstddef>
 #include "dcs_common.h"
 
 namespace dcsk {
@@ -263,12 +265,8 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
     const bool owner = has && Q.bandBase == 0;          // the lane that holds band 0 does the DC fix-up
     const uint32_t saved1 = (owner && !FIRST) ? row[1] : 0u;
 
-    int maxNb = nb;
-#pragma unroll
-    for (int d = 32 ; d >= 1 ; d >>= 1)
-        maxNb = max(maxNb, __shfl_xor(maxNb, d));
-
-    for (int k = 0 ; k < maxNb ; ++k)
+    // (the trip count is the largest nb of the wavefront: one ballot per band instead of a reduction up front)
+    for (int k = 0 ; __any(k < nb) ; ++k)
     {
         // ---- per-band set-up -------------------------------------------------------------------------
         const int band = Q.bandBase + k;
@@ -415,12 +413,7 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
     int code = 0;
     int outIdx = Q.outIdx;
 
-    int maxNb = nb;
-#pragma unroll
-    for (int d = 32 ; d >= 1 ; d >>= 1)
-        maxNb = max(maxNb, __shfl_xor(maxNb, d));
-
-    for (int k = 0 ; k < maxNb ; ++k)
+    for (int k = 0 ; __any(k < nb) ; ++k)
     {
         const int band = Q.bandBase + k;
         int nS = 0;                 // samples this lane runs through the main loop
@@ -765,6 +758,7 @@ __device__ __forceinline__ int overlapMix(int x, uint32_t cx, int o, uint32_t co
 }
 
 typedef DcsLaneConsts LaneConsts;
+typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));      // 16 bytes at any dword address
 
 
 // ten 16-byte loads per lane from the host-built table
@@ -1016,7 +1010,18 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
 
     // this lane's slot record: requested first, so that the load is in flight while the tables are staged
     // (all sub-lanes of a slot hold the same copy; padding wavefronts of the last workgroup read slot 0)
-    const DcsSlot slot = a.slots[chunk < a.nChunks ? static_cast<size_t>(chunk) * FPW + s : 0];
+    struct { uint32_t job; uint32_t prevSlot, flags, nSrc, shiftXform; uint32_t firstSrc, prevJob, runStartDw, runNDw, poolOff, hdrDw, hdrSh, bpl, runPoolOff; } slot;
+    {
+        // two 16-byte loads (DcsSlot is 32 bytes and the array 32-byte aligned), fields picked apart in registers
+        static_assert(sizeof(DcsSlot) == 32 && offsetof(DcsSlot, runStartDw) == 16 && offsetof(DcsSlot, hdrDw) == 24, "DcsSlot layout");
+        const uint4 *sp4 = reinterpret_cast<const uint4 *>(a.slots + (chunk < a.nChunks ? static_cast<size_t>(chunk) * FPW + s : 0));
+        const uint4 s0 = sp4[0], s1 = sp4[1];
+        slot.job = s0.x;
+        slot.prevSlot = s0.y & 0xFFu; slot.flags = (s0.y >> 8) & 0xFFu; slot.nSrc = (s0.y >> 16) & 0xFFu; slot.shiftXform = s0.y >> 24;
+        slot.firstSrc = s0.z; slot.prevJob = s0.w;
+        slot.runStartDw = s1.x; slot.runNDw = s1.y & 0xFFFFu; slot.poolOff = s1.y >> 16;
+        slot.hdrDw = s1.z; slot.hdrSh = s1.w & 0xFFu; slot.bpl = (s1.w >> 8) & 0xFFu; slot.runPoolOff = s1.w >> 16;
+    }
 
     // ---- stage the shared tables (whole workgroup), clear this wavefront's tile ------------------------
     {
@@ -1049,22 +1054,35 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
         const uint32_t *blobW = reinterpret_cast<const uint32_t *>(a.blob);
         const uint32_t blobWords = static_cast<uint32_t>((a.blobLen + 3) >> 2);
         const int myNSrc = live ? job.nSrc : 0;
-        int maxSrc = myNSrc;
-#pragma unroll
-        for (int d = 32 ; d >= 1 ; d >>= 1)
-            maxSrc = max(maxSrc, __shfl_xor(maxSrc, d));
 
-#ifdef DCS_EXP_NO_PHASE1
-        if (maxSrc > 1000)
-#endif
-        for (int r = 0 ; r < maxSrc ; ++r)
+        // one unpack round = the r-th source of every frame of the chunk.  R0 (the first source, in most batches the
+        // only one): the planner has put into the slot record where the compressed bytes, the stream header and
+        // the lane's split record lie, so all of it is requested in ONE memory round trip together with the
+        // descriptor; for further sources (multi-channel mixes) the addresses follow from the descriptor.
+        auto unpackRound = [&](auto r0tag, const int r)
         {
+            constexpr bool R0 = decltype(r0tag)::value;
             const bool has = r < myNSrc;
-            // the descriptor: four uint4 per lane, identical addresses within a slot's sub-lanes
+            // the descriptor: identical addresses within a slot's sub-lanes
             const uint4 *sdp = reinterpret_cast<const uint4 *>(&a.srcs[has ? job.firstSrc + r : 0]);
             uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0;
             uint2 d2 = make_uint2(0, 0);
             if (has) { d0 = sdp[0]; d1 = sdp[1]; d2 = *reinterpret_cast<const uint2 *>(sdp + 2); }
+            uint32_t hdrW[5] = { 0, 0, 0, 0, 0 };
+            uint2 sp = make_uint2(0, 0);
+            const int bplSlot = slot.bpl;
+            if (R0)
+            {
+                if (has && slot.hdrDw <= blobWords)             // (18 header bytes lie inside the blob: validated on the host)
+                {
+                    const u32x4a4 h = *reinterpret_cast<const u32x4a4 *>(blobW + slot.hdrDw);
+                    hdrW[0] = h.x; hdrW[1] = h.y; hdrW[2] = h.z; hdrW[3] = h.w;
+                    hdrW[4] = blobW[slot.hdrDw + 4];
+                }
+                // DcsSplit of band q * bpl = split[q * bpl - 1], 8 bytes each from descriptor dword 10
+                if (has && q != 0 && bplSlot != 0 && q * bplSlot < 16)
+                    sp = reinterpret_cast<const uint2 *>(sdp)[5 + q * bplSlot - 1];
+            }
             // DcsSrcDesc: [0] streamOff lo, [1] streamOff hi, [2] mixMul | format<<16 | hdrLen<<24,
             // idx at byte 12: [3] bitOff, [4] nBits | hdrBits<<16, [5..8] bandType, [9] preAdj | nBands<<16 | flags<<24,
             // [10..39] split[15], two dwords each
@@ -1076,23 +1094,60 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             const uint32_t nBits = d1.x & 0xFFFFu, hdrBits = d1.x >> 16;
             const int nBands = static_cast<int>((d2.y >> 16) & 0xFFu);
             const uint32_t flags = d2.y >> 24;
-            const bool serial = (flags & DCS_IDX_SERIAL) != 0 || SUB == 1;
+            const bool serial = R0 ? bplSlot == 0 : ((flags & DCS_IDX_SERIAL) != 0 || SUB == 1);
 
             Quarter Q;
             Q.t0 = d1.y; Q.t1 = d1.z; Q.t2 = d1.w; Q.t3 = d2.x;
             Q.preAdj = d2.y & 0xFFFFu;
 
             const uint64_t bitPos = (streamOff + 2 + static_cast<uint64_t>(hdrLen)) * 8 + bitOff;
-            // which blob dwords to stage and where in the pool.  For a job's first source the planner has put this
-            // into the slot record, so the staging loads below do not wait for the descriptor; for further
-            // sources (multi-channel mixes) it follows from the descriptors and a prefix sum over the slots.
-            uint32_t startDw = slot.startDw;
-            uint32_t nDw = (has && q == 0) ? static_cast<uint32_t>(slot.nDw) : 0u;
-            uint32_t offMine = slot.poolOff;
-            if (r != 0)
+            // ---- stage the compressed bytes into the bit pool, byte-swapped so that bit 31 of a dword is the next
+            // stream bit.  All loads are issued before the first store, so their latencies overlap.
+            uint32_t off;                                                   // pool dword of this lane's frame
+            bool fits;
+            if (R0)
             {
-                startDw = static_cast<uint32_t>(bitPos >> 5);
-                nDw = (has && q == 0) ? dcsPoolDwords(streamOff, static_cast<uint32_t>(hdrLen), bitOff, nBits) : 0u;
+                // the planner's runs (DcsSlot): 16 bytes per lane and instruction.  The blob allocation is
+                // zero-padded by 64 bytes, which covers the window look-ahead behind the last frame.
+                constexpr int kPieces = (poolDwords(FPW) + 255) / 256;
+                off = min(static_cast<uint32_t>(slot.poolOff), static_cast<uint32_t>(poolDwords(FPW) - 1));
+                fits = true;
+                const uint32_t runN = (q == 0) ? static_cast<uint32_t>(slot.runNDw) : 0u;
+#pragma unroll 1
+                for (int k = 0 ; k < FPW ; ++k)
+                {
+                    const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(runN), k));
+                    if (n == 0)
+                        break;
+                    const uint32_t st = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(slot.runStartDw), k));
+                    const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(slot.runPoolOff), k));
+                    if ((o & 3u) != 0 || o + n > static_cast<uint32_t>(poolDwords(FPW)))
+                        continue;                                           // cannot happen with the library's planner
+                    u32x4a4 v[kPieces];
+#pragma unroll
+                    for (int t = 0 ; t < kPieces ; ++t)
+                    {
+                        const uint32_t i = static_cast<uint32_t>(lane) * 4 + 256u * t;
+                        const uint32_t w = st + i;
+                        v[t] = u32x4a4{ 0, 0, 0, 0 };
+                        if (i < n && w + 4 <= blobWords + 16 && w + 4 > w)
+                            v[t] = *reinterpret_cast<const u32x4a4 *>(blobW + w);
+                    }
+#pragma unroll
+                    for (int t = 0 ; t < kPieces ; ++t)
+                    {
+                        const uint32_t i = static_cast<uint32_t>(lane) * 4 + 256u * t;
+                        if (i < n)
+                            ldsWrite4(pool + o + i, __builtin_bswap32(v[t].x), __builtin_bswap32(v[t].y),
+                                      __builtin_bswap32(v[t].z), __builtin_bswap32(v[t].w));
+                    }
+                }
+            }
+            else
+            {
+                // further sources: one coalesced run of dwords per slot, positions from a prefix sum over the slots
+                const uint32_t startDw = static_cast<uint32_t>(bitPos >> 5);
+                const uint32_t nDw = (has && q == 0) ? dcsPoolDwords(streamOff, static_cast<uint32_t>(hdrLen), bitOff, nBits) : 0u;
                 uint32_t incl = nDw;
 #pragma unroll
                 for (int d = 1 ; d < 64 ; d <<= 1)
@@ -1100,68 +1155,68 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
                     const uint32_t up = __shfl_up(incl, d);
                     if (lane >= d) incl += up;
                 }
-                offMine = incl - nDw;
-            }
-            const uint32_t off = __shfl(offMine, s);                        // from the slot's q = 0 lane
-            const uint32_t nDwSlot = __shfl(nDw, s);
-            const bool fits = off + nDwSlot <= static_cast<uint32_t>(poolDwords(FPW));
-
-            // stage: one coalesced run of dwords per slot, byte-swapped so that bit 31 is the next stream bit.
-            // All loads of a group of slots are issued before the first store, so their latencies overlap.
-            constexpr int kStageUnroll = FPW < 8 ? FPW : 8;
-            for (int t0 = 0 ; t0 < FPW ; t0 += kStageUnroll)
-            {
-                uint32_t v[kStageUnroll], dst[kStageUnroll];
-                bool any64 = false;
-#pragma unroll
-                for (int u = 0 ; u < kStageUnroll ; ++u)
+                const uint32_t offMine = incl - nDw;
+                off = __shfl(offMine, s);                                   // from the slot's q = 0 lane
+                const uint32_t nDwSlot = __shfl(nDw, s);
+                fits = off + nDwSlot <= static_cast<uint32_t>(poolDwords(FPW));
+                constexpr int kStageUnroll = FPW < 8 ? FPW : 8;
+                for (int t0 = 0 ; t0 < FPW ; t0 += kStageUnroll)
                 {
-                    const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(nDw), t0 + u));
-                    const uint32_t st = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(startDw), t0 + u));
-                    const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(offMine), t0 + u));
-                    const bool room = o + n <= static_cast<uint32_t>(poolDwords(FPW));
-                    const uint32_t w = st + static_cast<uint32_t>(lane);
-                    const bool mine = room && static_cast<uint32_t>(lane) < n;
-                    v[u] = (mine && w < blobWords) ? blobW[w] : 0u;
-                    dst[u] = mine ? o + static_cast<uint32_t>(lane) : 0xFFFFFFFFu;
-                    any64 = any64 || (room && n > 64);
-                }
+                    uint32_t v[kStageUnroll], dst[kStageUnroll];
+                    bool any64 = false;
 #pragma unroll
-                for (int u = 0 ; u < kStageUnroll ; ++u)
-                    if (dst[u] != 0xFFFFFFFFu)
-                        pool[dst[u]] = __builtin_bswap32(v[u]);
-                if (any64)
-                {
-                    // frames longer than 256 bytes: the rest, slot by slot
                     for (int u = 0 ; u < kStageUnroll ; ++u)
                     {
                         const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(nDw), t0 + u));
                         const uint32_t st = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(startDw), t0 + u));
                         const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(offMine), t0 + u));
-                        if (o + n > static_cast<uint32_t>(poolDwords(FPW)))
-                            continue;
-                        for (uint32_t i = static_cast<uint32_t>(lane) + 64 ; i < n ; i += 64)
+                        const bool room = o + n <= static_cast<uint32_t>(poolDwords(FPW));
+                        const uint32_t w = st + static_cast<uint32_t>(lane);
+                        const bool mine = room && static_cast<uint32_t>(lane) < n;
+                        v[u] = (mine && w < blobWords) ? blobW[w] : 0u;
+                        dst[u] = mine ? o + static_cast<uint32_t>(lane) : 0xFFFFFFFFu;
+                        any64 = any64 || (room && n > 64);
+                    }
+#pragma unroll
+                    for (int u = 0 ; u < kStageUnroll ; ++u)
+                        if (dst[u] != 0xFFFFFFFFu)
+                            pool[dst[u]] = __builtin_bswap32(v[u]);
+                    if (any64)
+                    {
+                        // frames longer than 256 bytes: the rest, slot by slot
+                        for (int u = 0 ; u < kStageUnroll ; ++u)
                         {
-                            const uint32_t w = st + i;
-                            pool[o + i] = w < blobWords ? __builtin_bswap32(blobW[w]) : 0u;
+                            const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(nDw), t0 + u));
+                            const uint32_t st = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(startDw), t0 + u));
+                            const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(offMine), t0 + u));
+                            if (o + n > static_cast<uint32_t>(poolDwords(FPW)))
+                                continue;
+                            for (uint32_t i = static_cast<uint32_t>(lane) + 64 ; i < n ; i += 64)
+                            {
+                                const uint32_t w = st + i;
+                                pool[o + i] = w < blobWords ? __builtin_bswap32(blobW[w]) : 0u;
+                            }
                         }
                     }
                 }
             }
 
-            if (r == 0) DCS_STAMP(2);
+            if (R0) DCS_STAMP(2);
             // the stream header: 16 bytes at streamOff + 2, via aligned dwords
             {
-                const uint32_t hw = static_cast<uint32_t>((streamOff + 2) >> 2);
-                const uint32_t sh = static_cast<uint32_t>((streamOff + 2) & 3);
-                uint32_t w[5];
+                uint32_t sh = slot.hdrSh;
+                if (!R0)
+                {
+                    const uint32_t hw = static_cast<uint32_t>((streamOff + 2) >> 2);
+                    sh = static_cast<uint32_t>((streamOff + 2) & 3);
 #pragma unroll
-                for (int i = 0 ; i < 5 ; ++i)
-                    w[i] = (has && hw + i < blobWords) ? blobW[hw + i] : 0u;
-                Q.h0 = __builtin_amdgcn_alignbyte(w[1], w[0], sh);
-                Q.h1 = __builtin_amdgcn_alignbyte(w[2], w[1], sh);
-                Q.h2 = __builtin_amdgcn_alignbyte(w[3], w[2], sh);
-                Q.h3 = __builtin_amdgcn_alignbyte(w[4], w[3], sh);
+                    for (int i = 0 ; i < 5 ; ++i)
+                        hdrW[i] = (has && hw + i < blobWords) ? blobW[hw + i] : 0u;
+                }
+                Q.h0 = __builtin_amdgcn_alignbyte(hdrW[1], hdrW[0], sh);
+                Q.h1 = __builtin_amdgcn_alignbyte(hdrW[2], hdrW[1], sh);
+                Q.h2 = __builtin_amdgcn_alignbyte(hdrW[3], hdrW[2], sh);
+                Q.h3 = __builtin_amdgcn_alignbyte(hdrW[4], hdrW[3], sh);
                 if (hdrLen == 1)
                 {
                     Q.h0 &= 0xFFu; Q.h1 = Q.h2 = Q.h3 = 0;
@@ -1169,7 +1224,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             }
             waveSync();
 
-            if (r == 0) DCS_STAMP(3);
+            if (R0) DCS_STAMP(3);
             // ---- which part of the frame this lane unpacks, and from which decoder state ----------------
             const bool ok = has && fits && unpacker;
             if (has && !fits && q == 0)
@@ -1188,13 +1243,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             {
                 // lane q takes bands [q * bpl, (q + 1) * bpl), bpl = ceil(nBands / SUB)
                 const int nb16 = min(nBands, 16);
-                const int bpl = max((nb16 + SUB - 1) / SUB, 1);
+                const int bpl = R0 ? bplSlot : max((nb16 + SUB - 1) / SUB, 1);
                 Q.bandBase = q * bpl;
                 Q.nb = min(max(nb16 - Q.bandBase, 0), bpl);
                 if (q != 0 && Q.nb != 0)
                 {
-                    // DcsSplit of band bandBase = split[bandBase - 1], 8 bytes each from descriptor dword 10
-                    const uint2 sp = reinterpret_cast<const uint2 *>(sdp)[5 + Q.bandBase - 1];
+                    if (!R0)
+                        sp = reinterpret_cast<const uint2 *>(sdp)[5 + Q.bandBase - 1];
                     const uint32_t sp0 = sp.x, sp1 = sp.y;
                     relBits = sp0 & 0xFFFFu;
                     Q.prv = sp0 >> 16;
@@ -1218,11 +1273,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             const bool is93a = ok && format == DCS_FMT_93A_T1 && Q.nb != 0 && !(Q.bandBase != 0 && Q.reuse);
             const bool is93 = ok && format < DCS_FMT_93A_T1;
             if (__any(is94))
-                err |= (r == 0) ? unpack94<true>(T, row, br, Q, format, mixMul, is94)
-                                : unpack94<false>(T, row, br, Q, format, mixMul, is94);
+                err |= unpack94<R0>(T, row, br, Q, format, mixMul, is94);
             if (__any(is93))
-                err |= (r == 0) ? unpack93<true>(T, row, br, Q, format, mixMul, is93)
-                                : unpack93<false>(T, row, br, Q, format, mixMul, is93);
+                err |= unpack93<R0>(T, row, br, Q, format, mixMul, is93);
             if (is93a)
             {
                 const int end = Q.bandBase + Q.nb;
@@ -1231,13 +1284,23 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
                                  Q.bandBase == 0 ? 0x1A : sx16(Q.prv), Q.bandBase == 0 ? 0 : Q.outIdx);
             }
             waveSync();
+        };
+
+#ifdef DCS_EXP_NO_PHASE1
+        if (a.nChunks > 0x7FFFFFF0u)
+#endif
+        {
+            if (__any(myNSrc > 0))
+                unpackRound(std::true_type{}, 0);
+            for (int r = 1 ; __any(r < myNSrc) ; ++r)
+                unpackRound(std::false_type{}, r);
         }
 
         DCS_STAMP(4);
         // a frame's error bits = OR over its sub-lanes
 #pragma unroll
-        for (int k = 1 ; k < SUB ; ++k)
-            err |= __shfl(err, (lane + k * FPW) & 63);
+        for (int m = FPW ; m < 64 ; m <<= 1)
+            err |= __shfl_xor(err, m);
         if (live && q == 0)
         {
             if (job.xform == DCS_XFORM_93)

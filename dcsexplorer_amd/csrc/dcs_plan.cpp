@@ -13,17 +13,19 @@
 #include "dcs_common.h"
 #include <vector>
 
-// poolOff = dwords the chunk's earlier slots already take in unpack round 0
-static DcsSlot makeSlot(const DcsFrameJob &jb, uint32_t job, uint8_t prevSlot, uint8_t flags, const DcsSrcDesc *srcs, uint32_t poolOff)
+// the slot of one job; where its first source's bytes go in the pool is filled in by placeFrame
+static DcsSlot makeSlot(const DcsFrameJob &jb, uint32_t job, uint8_t prevSlot, uint8_t flags, const DcsSrcDesc *srcs, int fpw)
 {
-    DcsSlot sl{ job, prevSlot, flags, jb.nSrc, static_cast<uint8_t>(jb.volShift | (jb.xform << 4)), jb.firstSrc, jb.prev, 0, 0, 0, { 0, 0 } };
+    DcsSlot sl{ job, prevSlot, flags, jb.nSrc, static_cast<uint8_t>(jb.volShift | (jb.xform << 4)), jb.firstSrc, jb.prev, 0, 0, 0, 0, 0, 0, 0 };
     if (srcs != nullptr && jb.nSrc != 0)
     {
         const DcsSrcDesc &sd = srcs[jb.firstSrc];
-        const uint64_t bitPos = (sd.streamOff + 2 + sd.hdrLen) * 8 + sd.idx.bitOff;
-        sl.startDw = static_cast<uint32_t>(bitPos >> 5);
-        sl.nDw = static_cast<uint16_t>(dcsPoolDwords(sd.streamOff, sd.hdrLen, sd.idx.bitOff, sd.idx.nBits));
-        sl.poolOff = static_cast<uint16_t>(poolOff < 0xFFFFu ? poolOff : 0xFFFFu);
+        sl.hdrDw = static_cast<uint32_t>((sd.streamOff + 2) >> 2);
+        sl.hdrSh = static_cast<uint8_t>((sd.streamOff + 2) & 3);
+        const int sub = 64 / fpw;
+        const int nb16 = sd.idx.nBands < 16 ? sd.idx.nBands : 16;
+        const int bpl = (nb16 + sub - 1) / sub;
+        sl.bpl = (sd.idx.flags & DCS_IDX_SERIAL) ? 0 : static_cast<uint8_t>(bpl < 1 ? 1 : bpl);
     }
     return sl;
 }
@@ -47,7 +49,8 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
         if (srcs == nullptr || r >= jobs[j].nSrc)
             return 0;
         const DcsSrcDesc &sd = srcs[jobs[j].firstSrc + r];
-        return dcsPoolDwords(sd.streamOff, sd.hdrLen, sd.idx.bitOff, sd.idx.nBits);
+        // (rounded up to the 16-byte granule of the run staging)
+        return (dcsPoolDwords(sd.streamOff, sd.hdrLen, sd.idx.bitOff, sd.idx.nBits) + 3) & ~3u;
     };
     auto poolFits = [&](uint32_t j, uint32_t halo, bool withHalo) {
         for (uint32_t r = 0 ; r < DCS_MAX_CHANNELS ; ++r)
@@ -62,9 +65,45 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
 
     uint32_t chunk = 0;
     uint32_t used = 0;                  // slots filled in the current chunk
-    const DcsSlot empty{ 0xFFFFFFFFu, DCS_NO_PREV_SLOT, DCS_SLOT_EMPTY, 0, 0, 0, DCS_PREV_NONE, 0, 0, 0, { 0, 0 } };
+    // unpack round 0 is staged as runs of blob dwords (DcsSlot): a frame that starts inside or right behind the
+    // chunk's last run extends it, anything else opens a new run at the next 16-byte boundary of the pool
+    struct Run { uint32_t start, n, poolOff; };
+    std::vector<Run> runs;
+    uint32_t runUse = 0;                // pool dwords the runs take (<= poolUse[0], which counts every frame in full)
+    auto placeFrame = [&](DcsSlot &sl, const DcsFrameJob &jb) {
+        if (srcs == nullptr || jb.nSrc == 0)
+            return;
+        const DcsSrcDesc &sd = srcs[jb.firstSrc];
+        const uint64_t bitPos = (sd.streamOff + 2 + sd.hdrLen) * 8 + sd.idx.bitOff;
+        const uint32_t st = static_cast<uint32_t>(bitPos >> 5);
+        const uint32_t n = dcsPoolDwords(sd.streamOff, sd.hdrLen, sd.idx.bitOff, sd.idx.nBits);
+        if (!runs.empty() && st >= runs.back().start && st <= runs.back().start + runs.back().n)
+        {
+            Run &r = runs.back();
+            if (st + n > r.start + r.n)
+                r.n = st + n - r.start;
+            runUse = r.poolOff + ((r.n + 3) & ~3u);
+        }
+        else
+        {
+            runs.push_back(Run{ st, n, runUse });
+            runUse += (n + 3) & ~3u;
+        }
+        sl.poolOff = static_cast<uint16_t>(runs.back().poolOff + (st - runs.back().start));
+    };
+    const DcsSlot empty{ 0xFFFFFFFFu, DCS_NO_PREV_SLOT, DCS_SLOT_EMPTY, 0, 0, 0, DCS_PREV_NONE, 0, 0, 0, 0, 0, 0, 0 };
     auto closeChunk = [&]() {
         while (used < static_cast<uint32_t>(fpw)) { slots.push_back(empty); ++used; }
+        // run k rides in slot k of the chunk (there are never more runs than frames)
+        DcsSlot *cs = &slots[slots.size() - static_cast<size_t>(fpw)];
+        for (size_t k = 0 ; k < runs.size() && k < static_cast<size_t>(fpw) ; ++k)
+        {
+            cs[k].runStartDw = runs[k].start;
+            cs[k].runNDw = static_cast<uint16_t>(runs[k].n);
+            cs[k].runPoolOff = static_cast<uint16_t>(runs[k].poolOff);
+        }
+        runs.clear();
+        runUse = 0;
         ++chunk;
         used = 0;
         for (uint32_t &u : poolUse) u = 0;
@@ -120,14 +159,16 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
         {
             if (!inChunk(prev))
             {
-                slots.push_back(makeSlot(jobs[prev], prev, DCS_NO_PREV_SLOT, DCS_SLOT_HALO, srcs, poolUse[0]));
+                slots.push_back(makeSlot(jobs[prev], prev, DCS_NO_PREV_SLOT, DCS_SLOT_HALO, srcs, fpw));
+                placeFrame(slots.back(), jobs[prev]);
                 poolAdd(prev);
                 stampOf[prev] = chunk;
                 slotOf[prev] = static_cast<uint8_t>(used++);
             }
             prevSlot = slotOf[prev];
         }
-        slots.push_back(makeSlot(jobs[j], j, prevSlot, static_cast<uint8_t>(ext ? DCS_SLOT_EXT_TAIL : 0), srcs, poolUse[0]));
+        slots.push_back(makeSlot(jobs[j], j, prevSlot, static_cast<uint8_t>(ext ? DCS_SLOT_EXT_TAIL : 0), srcs, fpw));
+        placeFrame(slots.back(), jobs[j]);
         poolAdd(j);
         stampOf[j] = chunk;
         slotOf[j] = static_cast<uint8_t>(used++);
