@@ -79,7 +79,7 @@ _LIB = None
 EXPORTS = [
     "dcs_abi_version", "dcs_index_stream", "dcs_volume_multiplier", "dcs_mixing_multiplier", "dcs_frame_scale",
     "dcs_stream_params", "dcs_ctx_create", "dcs_ctx_destroy", "dcs_last_error", "dcs_device_count",
-    "dcs_ctx_set_frames_per_wave", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run",
+    "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run",
     "dcs_batch_time", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_download_view", "dcs_batch_device_pcm",
     "dcs_batch_algorithmic_bytes", "dcs_batch_num_jobs", "dcs_decode_streams", "dcs_count_stream_frames",
     "dcs_synth_stream", "dcs_plan_chunks", "dcs_index_streams", "dcs_index_streams_gpu",
@@ -137,6 +137,10 @@ def load_library():
     L.dcs_device_count.restype = ctypes.c_int
     L.dcs_ctx_set_frames_per_wave.restype = i32
     L.dcs_ctx_set_frames_per_wave.argtypes = [vp, ctypes.c_int]
+    L.dcs_ctx_set_tail_handoff.restype = i32
+    L.dcs_ctx_set_tail_handoff.argtypes = [vp, ctypes.c_int]
+    L.dcs_plan_chunks2.restype = i32
+    L.dcs_plan_chunks2.argtypes = [vp, u32, vp, ctypes.c_int, ctypes.c_int, vp, sz, ctypes.POINTER(u32)]
     L.dcs_decode_batch.restype = i32
     L.dcs_decode_batch.argtypes = [vp, vp, sz, vp, u32, vp, u32, vp, u32, vp, vp, vp]
     L.dcs_batch_create.restype = i32
@@ -452,15 +456,15 @@ def build_stream_batch(streams, extra_frames=0, pad=64, indexer=None):
                 jobs=np.concatenate(jobs), first_job=np.array(first, dtype=np.int64))
 
 
-def plan_chunks(jobs, fpw, srcs=None):
-    """dcs_plan_chunks -> (slots [nChunks, fpw] of dict-like structured array, nChunks)"""
+def plan_chunks(jobs, fpw, srcs=None, handoff=True):
+    """dcs_plan_chunks2 -> slots [nChunks, fpw] as a structured array (job, prevSlot, flags)"""
     L = load_library()
     jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
     srcs = None if srcs is None else np.ascontiguousarray(srcs, dtype=SRC_DTYPE)
     n = ctypes.c_uint32(0)
-    _check(L.dcs_plan_chunks(_ptr(jobs), jobs.size, _ptr(srcs), fpw, None, 0, ctypes.byref(n)))
+    _check(L.dcs_plan_chunks2(_ptr(jobs), jobs.size, _ptr(srcs), fpw, int(handoff), None, 0, ctypes.byref(n)))
     raw = np.zeros(n.value * fpw, dtype=np.uint64)
-    _check(L.dcs_plan_chunks(_ptr(jobs), jobs.size, _ptr(srcs), fpw, _ptr(raw), raw.size, ctypes.byref(n)))
+    _check(L.dcs_plan_chunks2(_ptr(jobs), jobs.size, _ptr(srcs), fpw, int(handoff), _ptr(raw), raw.size, ctypes.byref(n)))
     out = np.zeros(raw.size, dtype=[("job", "<u4"), ("prevSlot", "u1"), ("flags", "u1")])
     out["job"] = raw & 0xFFFFFFFF
     out["prevSlot"] = (raw >> 32) & 0xFF
@@ -498,6 +502,9 @@ class Context:
 
     def set_frames_per_wave(self, fpw):
         _check(self.L.dcs_ctx_set_frames_per_wave(self.h, fpw), self.h)
+
+    def set_tail_handoff(self, enable):
+        _check(self.L.dcs_ctx_set_tail_handoff(self.h, int(bool(enable))), self.h)
 
     def decode_batch(self, blob, srcs, jobs, tails_in=None, want_tails=False):
         blob_a = np.frombuffer(bytes(blob), dtype=np.uint8)

@@ -105,6 +105,8 @@ constexpr uint32_t dcsPoolCapacity(int fpw)
 
 #define DCS_SLOT_HALO      0x01u        // do not write PCM / err for this slot
 #define DCS_SLOT_EXT_TAIL  0x02u        // overlap tail comes from tailsIn[job.prev & 0x7FFFFFFF]
+#define DCS_SLOT_EXPORT    0x04u        // publish this frame's tail in handoff[chunk] for a frame of a later chunk
+#define DCS_SLOT_IMPORT    0x08u        // overlap tail comes from handoff[prevJob] (prevJob = the publishing chunk)
 #define DCS_SLOT_EMPTY     0x80u        // padding
 #define DCS_NO_PREV_SLOT   0xFFu
 
@@ -147,10 +149,14 @@ struct DcsKernelArgs
     int16_t            *tailsOut;       // nJobs x 16 (may be null)
     const DcsDevTables *tables;
     unsigned long long *debug;          // diagnostic builds only (DCS_STAMPS); null otherwise
+    // tail hand-off between chunks: nChunks x 16 words of (epoch << 32 | payload); a word is valid for this launch
+    // when its epoch equals `epoch` (the batch's launch counter, never 0), so the buffer is never cleared
+    unsigned long long *handoff;
+    uint32_t            epoch;
 };
 
 // planner: returns the number of chunks; slots is resized to nChunks * fpw
 #ifdef __cplusplus
 #include <vector>
-uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots);
+uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true);
 #endif

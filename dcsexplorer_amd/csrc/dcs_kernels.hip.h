@@ -31,12 +31,18 @@ namespace dcsk {
 
 // diagnostic build only (-DDCS_STAMPS): per-chunk cycle stamps at the phase boundaries, written to a debug
 // buffer no other code reads (args.debug); never enabled in the shipped library
+struct Stamper
+{
 #ifdef DCS_STAMPS
-#define DCS_STAMP(k) do { if (lane == 0 && a.debug != nullptr) a.debug[static_cast<size_t>(chunk) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    unsigned long long *p;          // this chunk's 16 stamps; null on every lane but lane 0
+    __device__ __forceinline__ void operator()(int k) const { if (p != nullptr) p[k] = __builtin_amdgcn_s_memtime(); }
 #else
-#define DCS_STAMP(k) do { } while (0)
+    __device__ __forceinline__ void operator()(int) const { }
 #endif
+};
+#define DCS_STAMP(k) stamp(k)
 
+constexpr int kHandoffSpins = 1 << 18;  // bound of the wait for a tail from an earlier chunk (about a second)
 constexpr int kWavesPerBlock = 4;       // wavefronts of a workgroup share one copy of the decode tables in LDS
 constexpr int kRowBytes = 528;          // 256 words + 16 bytes: 16-byte aligned rows (the transforms transpose through them
                                         // with 128-bit accesses), rows of neighbouring frames land on different LDS banks
@@ -124,17 +130,21 @@ struct BitReader
     // the next 32 bits, MSB first
     __device__ __forceinline__ uint32_t cur() const { return __builtin_amdgcn_alignbit(hi, lo, static_cast<uint32_t>(negpos)); }
     __device__ __forceinline__ uint32_t peek(int n) const { return cur() >> (32 - n); }     // n in 1..32
-    __device__ __forceinline__ void skip(int n)                                             // n in 0..32
+    // Branch-free advance, n in 0..32.  The pool dword a refill would pull in is read every time (an LDS read costs no
+    // VALU issue and its result is only needed when the window actually moves, 32 bits later); symbol loops
+    // request it at the top of the iteration with prefetch() so that nothing ever waits for it.
+    __device__ __forceinline__ uint32_t prefetch() const { return *p; }
+    __device__ __forceinline__ void skip(int n, uint32_t ahead)
     {
         negpos -= n;
-        if (negpos < 0)
-        {
-            hi = lo;
-            lo = nxt;
-            nxt = *p++;
-            negpos += 32;
-        }
+        const bool refill = negpos < 0;
+        hi = refill ? lo : hi;
+        lo = refill ? nxt : lo;
+        nxt = refill ? ahead : nxt;
+        p += refill ? 1 : 0;
+        negpos &= 31;
     }
+    __device__ __forceinline__ void skip(int n) { skip(n, prefetch()); }
     __device__ __forceinline__ uint32_t get(int n) { const uint32_t v = peek(n); skip(n); return v; }
 };
 
@@ -249,7 +259,7 @@ constexpr int kDummyWord = 256;         // the pad word of a tile row: sink for 
 // ------------------------------------------------------------------------------------------------
 template <bool FIRST>
 __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br, const Quarter &Q,
-                             int format, uint32_t mixMul, bool has)
+                             int format, uint32_t mixMul, bool has, const Stamper &stamp)
 {
     const bool type1 = format != DCS_FMT_94_T0;
     uint32_t err = 0;
@@ -265,6 +275,7 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
     const bool owner = has && Q.bandBase == 0;          // the lane that holds band 0 does the DC fix-up
     const uint32_t saved1 = (owner && !FIRST) ? row[1] : 0u;
 
+    stamp(8);
     // (the trip count is the largest nb of the wavefront: one ballot per band instead of a reduction up front)
     for (int k = 0 ; __any(k < nb) ; ++k)
     {
@@ -341,6 +352,7 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
         // (the "two zeros" code, :2200-2212, has value 0 and step 2, so it needs no special store: adding a
         // zero product leaves the accumulator as it was).  A two-zeros code with one sample left (:2213-2218)
         // drives i to -1, which is how the error is seen after the loop.
+        if (k == 0) stamp(9);
         const BitReader bandStart = br;
         uint16_t *cell = row + outIdx;
         uint16_t *const cellStart = cell;
@@ -349,17 +361,19 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
         const int incBytes = inc * 2;
         while (i > 0)
         {
+            const uint32_t ahead = br.prefetch();
             const uint32_t w = br.cur();
             const uint32_t e = book[w >> shIdx];
             const int vr = static_cast<int>(w) >> shPeek;
             const int vh = static_cast<int>(static_cast<int8_t>(e & 0xFF));
             const int step = static_cast<int>(e >> 13);
-            br.skip(static_cast<int>((e >> 8) & 0x1F));
+            br.skip(static_cast<int>((e >> 8) & 0x1F), ahead);
             mixAdd<FIRST>(cell, mul24(isRaw ? vr : vh, scale), mixMul);
             cell = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(cell) + incBytes * step);
             i -= step;
         }
         outIdx += static_cast<int>(cell - cellStart);
+        if (k == 0) stamp(10);
         if (i < 0)
         {
             // the reference zeroes the WHOLE band buffer on this error (:2238-2239): take back what the
@@ -399,7 +413,7 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
 // ------------------------------------------------------------------------------------------------
 template <bool FIRST>
 __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br, const Quarter &Q,
-                             int format, uint32_t mixMul, bool has)
+                             int format, uint32_t mixMul, bool has, const Stamper &stamp)
 {
     const bool type1 = format == DCS_FMT_93B_T1;
     uint32_t err = 0;
@@ -413,6 +427,7 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
     int code = 0;
     int outIdx = Q.outIdx;
 
+    stamp(8);
     for (int k = 0 ; __any(k < nb) ; ++k)
     {
         const int band = Q.bandBase + k;
@@ -440,17 +455,30 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
                 else { inc = 2; nSamples = stride = 8; }
             }
 
+            // the band-type field (:2388-2419): [reuse bit, if the previous band was code 0] then, Type 0:
+            // [change sub-type] [direction, if changing] [4-bit code].  Parsed from ONE window read with one advance.
+            const uint32_t bw = br.cur();
+            int used = 0;
             if (reuse)
-                reuse = br.get(1) != 0;
+            {
+                reuse = (bw >> 31) != 0;
+                used = 1;
+            }
+            if (!reuse && !type1)
+            {
+                const uint32_t b = bw << used;
+                const bool change = (b >> 31) != 0;
+                const bool up = ((b >> 30) & 1u) != 0;
+                if (change)
+                    subType = up ? (subType == 2 ? 0 : subType + 1) : (subType == 0 ? 2 : subType - 1);
+                const int fixedBits = change ? 2 : 1;
+                code = static_cast<int>((b << fixedBits) >> 28);
+                used += fixedBits + 4;
+            }
+            br.skip(used);
             if (!reuse)
             {
-                if (!type1)
-                {
-                    if (br.get(1))
-                        subType = br.get(1) ? (subType == 2 ? 0 : subType + 1) : (subType == 0 ? 2 : subType - 1);
-                    code = static_cast<int>(br.get(4));
-                }
-                else
+                if (type1)
                 {
                     int v = readVlc(br, T->fast93, T->trie93);
                     if (v < 0x1E)
@@ -501,10 +529,12 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         const int shW = (32 - width) & 31;
         const uint32_t wMask = width != 0 ? 0xFFFFFFFFu : 0u;
         const bool ran = nS > 0 || quirk;
+        if (k == 0) stamp(9);
         for (int i = 0 ; i < nS ; ++i)
         {
+            const uint32_t ahead = br.prefetch();
             const uint32_t in = static_cast<uint32_t>(static_cast<int>(br.cur() & wMask) >> shW);
-            br.skip(width);
+            br.skip(width, ahead);
             const uint32_t d = in + (prvDelta & m2);
             const uint32_t p = d + (prv & m0);
             prvDelta = d - (prv & ~m0);
@@ -513,6 +543,7 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
             outIdx += inc;
         }
         prv &= 0xFFFFu; prvDelta &= 0xFFFFu;
+        if (k == 0) stamp(10);
 
         // ---- code 0 / sub-type 1: repeat the previous input; the product's low word is carried from
         // sample to sample instead of being reloaded (:2513-2534) -------------------------------------------
@@ -539,6 +570,7 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         if (ran)
             outIdx += fixup;
     }
+    stamp(11);
 
     if (owner)
         dcFixup(row, saved1);
@@ -1001,7 +1033,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
     const Lds<FPW> L{ smem, smem + sizeof(DcsLdsTables) + kWavesPerBlock * kPoolBytes + wave * kTileBytes,
                       smem + sizeof(DcsLdsTables) + wave * kPoolBytes };
     const uint32_t chunk = blockIdx.x * kWavesPerBlock + static_cast<uint32_t>(wave);
-    if (chunk < a.nChunks) DCS_STAMP(0);
+#ifdef DCS_STAMPS
+    const Stamper stamp{ (lane == 0 && a.debug != nullptr && chunk < a.nChunks) ? a.debug + static_cast<size_t>(chunk) * 16 : nullptr };
+#else
+    const Stamper stamp{};
+#endif
+    DCS_STAMP(0);
     constexpr int SUB = subLanes(FPW);              // lanes that unpack one frame together
     static_assert(SUB * FPW == 64 && SUB <= 16, "every lane unpacks; a frame has at most 16 split lanes");
     const int s = lane % FPW;                       // slot of this lane
@@ -1265,6 +1302,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             BitReader br;
             br.init(pool + (ok ? off + (inPool >> 5) : 0u), static_cast<int>(inPool & 31));
 
+            if (R0) DCS_STAMP(12);
             // every lane enters the unpackers (their symbol loops are wave-convergent); lanes without a
             // source of that family are masked off inside
             const bool is94 = ok && format >= DCS_FMT_94_T0;
@@ -1273,9 +1311,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             const bool is93a = ok && format == DCS_FMT_93A_T1 && Q.nb != 0 && !(Q.bandBase != 0 && Q.reuse);
             const bool is93 = ok && format < DCS_FMT_93A_T1;
             if (__any(is94))
-                err |= unpack94<R0>(T, row, br, Q, format, mixMul, is94);
+                err |= unpack94<R0>(T, row, br, Q, format, mixMul, is94, stamp);
             if (__any(is93))
-                err |= unpack93<R0>(T, row, br, Q, format, mixMul, is93);
+                err |= unpack93<R0>(T, row, br, Q, format, mixMul, is93, stamp);
             if (is93a)
             {
                 const int end = Q.bandBase + Q.nb;
@@ -1363,9 +1401,23 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             else
                 reinterpret_cast<uint16_t *>(tails)[mySlot * 16 + bitrevN(P.l, 4)] = static_cast<uint16_t>(x[15]);
         }
+        // ... and, for the last frame of a chunk whose successor lies in a later chunk, in the hand-off buffer: the
+        // payload travels inside the same 64-bit word as the launch's epoch, so no fence or flag is needed
+        if (active && (myFlags & DCS_SLOT_EXPORT))
+        {
+            const int k = (xf == DCS_XFORM_94) ? bitrevN(P.l, 3) : bitrevN(P.l, 4);
+            const uint32_t payload = (xf == DCS_XFORM_94) ? x[15] : (x[15] & 0xFFFFu);
+            __hip_atomic_store(a.handoff + static_cast<size_t>(chunk) * 16 + k,
+                               (static_cast<unsigned long long>(a.epoch) << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         waveSync();
 
         const bool emit = active && !(myFlags & DCS_SLOT_HALO);
+        // A frame whose tail comes from an earlier chunk (DCS_SLOT_IMPORT) is finished after the last pass: its first
+        // 16 output samples, not yet overlapped, wait in its tile row (dead after the transform).  Waiting here
+        // instead would chain the chunks of a stream one behind the other (this chunk's LAST frame, which the next
+        // chunk waits for, is transformed in a later pass).
+        const bool deferred = active && (myFlags & DCS_SLOT_IMPORT) != 0;
         if (xf == DCS_XFORM_94)
         {
             // overlap-add on sample pair m = bitrev3(l) (register 0) (:538-555)
@@ -1378,13 +1430,17 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             }
             else if (myPrevSlot != DCS_NO_PREV_SLOT)
                 tailPair = tails[myPrevSlot * 8 + m];
+            if (deferred)
+                P.rowC[m] = x[0];
             x[0] = packC(overlapMix(reC(x[0]), C.ovl94a & 0xFFFFu, reC(tailPair), C.ovl94b & 0xFFFFu),
                          overlapMix(imC(x[0]), C.ovl94a >> 16, imC(tailPair), C.ovl94b >> 16));
             if (emit)
             {
                 uint32_t *out = reinterpret_cast<uint32_t *>(a.pcm) + static_cast<size_t>(myJob) * (DCS_FRAME_SAMPLES / 2);
+                if (!deferred)
+                    out[m] = x[0];
 #pragma unroll
-                for (int r = 0 ; r < 15 ; ++r)
+                for (int r = 1 ; r < 15 ; ++r)
                     out[8 * bitrevN(r, 4) + m] = x[r];                 // pair 8*bitrev4(r) + bitrev3(l)
                 if (a.tailsOut != nullptr)
                     reinterpret_cast<uint32_t *>(a.tailsOut)[static_cast<size_t>(myJob) * 8 + m] = x[15];
@@ -1402,12 +1458,16 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             }
             else if (myPrevSlot != DCS_NO_PREV_SLOT)
                 tailSample = static_cast<int16_t>(reinterpret_cast<const uint16_t *>(tails)[myPrevSlot * 16 + i]);
+            if (deferred)
+                P.rowC[i] = x[0];
             x[0] = static_cast<uint32_t>(overlapMix(reC(x[0]), C.ovl93 & 0xFFFFu, tailSample, C.ovl93 >> 16)) & 0xFFFFu;
             if (emit)
             {
                 int16_t *out = a.pcm + static_cast<size_t>(myJob) * DCS_FRAME_SAMPLES;
+                if (!deferred)
+                    out[i] = static_cast<int16_t>(x[0]);
 #pragma unroll
-                for (int r = 0 ; r < 15 ; ++r)
+                for (int r = 1 ; r < 15 ; ++r)
                     out[16 * bitrevN(r, 4) + i] = static_cast<int16_t>(x[r]);      // sample 16*bitrev4(r) + bitrev4(l)
                 if (a.tailsOut != nullptr)
                     a.tailsOut[static_cast<size_t>(myJob) * 16 + i] = static_cast<int16_t>(x[15]);
@@ -1415,6 +1475,45 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
         }
         waveSync();
         s0 += n;
+    }
+
+    // ---- frames that take their tail from an earlier chunk: every tail this chunk publishes is out by now, so
+    // waiting cannot hold anybody up.  The producer was dispatched before this chunk and waits for nothing before it
+    // publishes, so the wait is short; it is bounded all the same (a word that never arrives costs the frame an
+    // error flag, not the launch).  Lane l of the first lane group finishes sample (pair) bitrev(l), for which it
+    // holds the overlap window in its constants.
+    DCS_STAMP(13);
+    for (unsigned long long pending = __ballot(live && lane < FPW && (slotFlags & DCS_SLOT_IMPORT) != 0) ; pending != 0 ; pending &= pending - 1)
+    {
+        const int sI = __builtin_ctzll(pending);
+        const int xf = __builtin_amdgcn_readlane(jobXform, sI);
+        const uint32_t jobI = static_cast<uint32_t>(__builtin_amdgcn_readlane(slotJob, sI));
+        const uint32_t fromChunk = static_cast<uint32_t>(__builtin_amdgcn_readlane(jobPrev, sI));
+        const int lpf = (xf == DCS_XFORM_94) ? 8 : 16;
+        if (lane < lpf)
+        {
+            const int k = (xf == DCS_XFORM_94) ? bitrevN(lane, 3) : bitrevN(lane, 4);
+            const unsigned long long *src = a.handoff + static_cast<size_t>(fromChunk) * 16 + k;
+            unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int spin = 0 ; static_cast<uint32_t>(w >> 32) != a.epoch && spin < kHandoffSpins ; ++spin)
+            {
+                __builtin_amdgcn_s_sleep(2);
+                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            uint32_t tail = 0;
+            if (static_cast<uint32_t>(w >> 32) == a.epoch)
+                tail = static_cast<uint32_t>(w);
+            else if (a.err != nullptr)
+                atomicOr(&a.err[jobI], DCS_FRAME_FATAL);
+            const uint32_t x0 = reinterpret_cast<const uint32_t *>(L.row(sI))[k];
+            if (xf == DCS_XFORM_94)
+                reinterpret_cast<uint32_t *>(a.pcm)[static_cast<size_t>(jobI) * (DCS_FRAME_SAMPLES / 2) + k] =
+                    packC(overlapMix(reC(x0), C.ovl94a & 0xFFFFu, reC(tail), C.ovl94b & 0xFFFFu),
+                          overlapMix(imC(x0), C.ovl94a >> 16, imC(tail), C.ovl94b >> 16));
+            else
+                a.pcm[static_cast<size_t>(jobI) * DCS_FRAME_SAMPLES + k] =
+                    static_cast<int16_t>(overlapMix(reC(x0), C.ovl93 & 0xFFFFu, sx16(tail), C.ovl93 >> 16));
+        }
     }
     DCS_STAMP(6);
 }

@@ -30,7 +30,7 @@ static DcsSlot makeSlot(const DcsFrameJob &jb, uint32_t job, uint8_t prevSlot, u
     return sl;
 }
 
-uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots)
+uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff)
 {
     slots.clear();
     if (nJobs == 0 || fpw < 2)
@@ -40,6 +40,10 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
     // slotOf[j] = position of job j inside the chunk being built (valid when stampOf[j] == chunk id)
     std::vector<uint32_t> stampOf(nJobs, 0xFFFFFFFFu);
     std::vector<uint8_t> slotOf(nJobs, 0);
+    // tail hand-off between chunks: where a job's own (non-halo) slot went, and the last live slot of every closed chunk
+    std::vector<uint32_t> homeChunk(nJobs, 0xFFFFFFFFu);
+    std::vector<size_t> homePos(nJobs, 0);
+    std::vector<size_t> lastLive;
 
     // LDS bit-pool budget: per unpack round r (the r-th source of every job in the chunk) the staged
     // frames must fit fpw * DCS_POOL_DW_PER_FRAME dwords
@@ -93,6 +97,7 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
     };
     const DcsSlot empty{ 0xFFFFFFFFu, DCS_NO_PREV_SLOT, DCS_SLOT_EMPTY, 0, 0, 0, DCS_PREV_NONE, 0, 0, 0, 0, 0, 0, 0 };
     auto closeChunk = [&]() {
+        lastLive.push_back(slots.size() - 1);
         while (used < static_cast<uint32_t>(fpw)) { slots.push_back(empty); ++used; }
         // run k rides in slot k of the chunk (there are never more runs than frames)
         DcsSlot *cs = &slots[slots.size() - static_cast<size_t>(fpw)];
@@ -147,31 +152,53 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
         const bool ext = prev != DCS_PREV_NONE && (prev & DCS_PREV_EXT) != 0;
         const bool link = prev != DCS_PREV_NONE && !ext && prev < nJobs && prev != j;
 
-        uint32_t need = (link && !inChunk(prev)) ? 2u : 1u;
+        // The predecessor's tail reaches this frame (a) through LDS when both are in one chunk, (b) through the
+        // hand-off buffer when the predecessor is the LAST frame of an EARLIER chunk (the usual case along a chain:
+        // that wavefront publishes the tail, this one picks it up after its own transform; chunks are dispatched in
+        // index order, so the producer is never behind the consumer), (c) otherwise by decoding the predecessor a
+        // second time in this chunk as a halo slot.
+        auto canImport = [&](uint32_t p) {
+            return handoff && homeChunk[p] != 0xFFFFFFFFu && homeChunk[p] < chunk && lastLive[homeChunk[p]] == homePos[p];
+        };
+        uint32_t need = (link && !inChunk(prev) && !canImport(prev)) ? 2u : 1u;
         if (used + need > static_cast<uint32_t>(fpw) || (used != 0 && !poolFits(j, prev, need == 2)))
         {
             closeChunk();
-            need = link ? 2u : 1u;      // nothing of the new chunk exists yet
+            need = (link && !canImport(prev)) ? 2u : 1u;      // nothing of the new chunk exists yet
         }
 
         uint8_t prevSlot = DCS_NO_PREV_SLOT;
+        uint8_t flags = static_cast<uint8_t>(ext ? DCS_SLOT_EXT_TAIL : 0);
+        uint32_t importFrom = 0;
         if (link)
         {
-            if (!inChunk(prev))
+            if (inChunk(prev))
+                prevSlot = slotOf[prev];
+            else if (canImport(prev))
+            {
+                slots[homePos[prev]].flags |= DCS_SLOT_EXPORT;
+                flags |= DCS_SLOT_IMPORT;
+                importFrom = homeChunk[prev];
+            }
+            else
             {
                 slots.push_back(makeSlot(jobs[prev], prev, DCS_NO_PREV_SLOT, DCS_SLOT_HALO, srcs, fpw));
                 placeFrame(slots.back(), jobs[prev]);
                 poolAdd(prev);
                 stampOf[prev] = chunk;
                 slotOf[prev] = static_cast<uint8_t>(used++);
+                prevSlot = slotOf[prev];
             }
-            prevSlot = slotOf[prev];
         }
-        slots.push_back(makeSlot(jobs[j], j, prevSlot, static_cast<uint8_t>(ext ? DCS_SLOT_EXT_TAIL : 0), srcs, fpw));
+        slots.push_back(makeSlot(jobs[j], j, prevSlot, flags, srcs, fpw));
+        if (flags & DCS_SLOT_IMPORT)
+            slots.back().prevJob = importFrom;          // the chunk whose last frame publishes the tail
         placeFrame(slots.back(), jobs[j]);
         poolAdd(j);
         stampOf[j] = chunk;
         slotOf[j] = static_cast<uint8_t>(used++);
+        homeChunk[j] = chunk;
+        homePos[j] = slots.size() - 1;
         if (used == static_cast<uint32_t>(fpw))
             closeChunk();
     }
@@ -180,13 +207,13 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
     return chunk;
 }
 
-extern "C" DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw,
-                                     uint64_t *slotsOut, size_t cap, uint32_t *nChunksOut)
+extern "C" DcsStatus dcs_plan_chunks2(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, int handoff,
+                                      uint64_t *slotsOut, size_t cap, uint32_t *nChunksOut)
 {
     if (jobs == nullptr || nChunksOut == nullptr || fpw < 4 || fpw > 64)
         return DCS_ERR_INVALID_ARG;
     std::vector<DcsSlot> slots;
-    *nChunksOut = dcsPlanChunks(jobs, nJobs, srcs, fpw, slots);
+    *nChunksOut = dcsPlanChunks(jobs, nJobs, srcs, fpw, slots, handoff != 0);
     if (slotsOut != nullptr)
     {
         if (cap < slots.size())
@@ -196,4 +223,10 @@ extern "C" DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, co
                         | (static_cast<uint64_t>(slots[i].flags) << 40);
     }
     return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw,
+                                     uint64_t *slotsOut, size_t cap, uint32_t *nChunksOut)
+{
+    return dcs_plan_chunks2(jobs, nJobs, srcs, fpw, 1, slotsOut, cap, nChunksOut);
 }

@@ -18,6 +18,7 @@ struct DcsCtx
     hipStream_t stream = nullptr;
     DcsDevTables *dTables = nullptr;
     int fpwOverride = 0;
+    bool handoff = true;                // tails cross chunk boundaries through the hand-off buffer (else: halo re-decode)
     int numCUs = 256;
     std::string lastError;
     // inputs of the last dcs_index_streams_gpu call, resident for dcs_index_streams_gpu_time
@@ -85,7 +86,9 @@ struct DcsBatch
     uint32_t *dErr = nullptr;
     int16_t *dTailsOut = nullptr;
     unsigned long long *dDebug = nullptr;   // DCS_STAMPS builds only
-    size_t cap[8] = { 0 };                  // allocated bytes of the buffers above, in that order
+    unsigned long long *dHandoff = nullptr; // nChunks x 16 words (DcsKernelArgs.handoff)
+    uint32_t epoch = 0;                     // launches of this batch so far
+    size_t cap[9] = { 0 };                  // allocated bytes of the buffers above, in that order
     // pinned host mirror of (pcm, err), filled by dcs_batch_download_view
     int16_t *hPcm = nullptr;
     uint32_t *hErr = nullptr;
@@ -199,6 +202,14 @@ extern "C" DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw)
     return DCS_OK;
 }
 
+extern "C" DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable)
+{
+    if (ctx == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    ctx->handoff = enable != 0;
+    return DCS_OK;
+}
+
 // frames per wavefront.  Four lanes unpack one frame, so 16 frames fill the 64 lanes; small batches
 // use 8 or 4 frames per wavefront: more wavefronts, and a shorter serial path in each.
 static int chooseFpw(const DcsCtx *ctx, uint32_t nJobs)
@@ -217,8 +228,8 @@ extern "C" void dcs_batch_destroy(DcsBatch *b)
         return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);         // nothing of this batch is in flight when its buffers are recycled
-    void *ptrs[] = { b->dBlob, b->dSrcs, b->dSlots, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug };
-    for (int i = 0 ; i < 8 ; ++i)
+    void *ptrs[] = { b->dBlob, b->dSrcs, b->dSlots, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug, b->dHandoff };
+    for (int i = 0 ; i < 9 ; ++i)
         cacheFree(b->ctx, false, ptrs[i], b->cap[i]);
     cacheFree(b->ctx, true, b->hPcm, b->hCap[0]);
     cacheFree(b->ctx, true, b->hErr, b->hCap[1]);
@@ -288,7 +299,7 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
     b->fpw = chooseFpw(ctx, nJobs);
 
     std::vector<DcsSlot> slots;
-    b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots);
+    b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, ctx->handoff);
 
     // algorithmic bytes: compressed payload + descriptors read (one DcsSrcDesc per source, one
     // 16-byte job record per frame -- the device reads it in its DcsSlot form), PCM written
@@ -318,9 +329,11 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
         b->cap[5] = sizeof(uint32_t) * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dErr), b->cap[5]));
         b->cap[6] = sizeof(int16_t) * 16 * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsOut), b->cap[6]));
         HIPCHK(ctx, hipMemsetAsync(b->dErr, 0, sizeof(uint32_t) * nJobs, ctx->stream));
+        b->cap[8] = sizeof(unsigned long long) * 16 * (b->nChunks + 1); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dHandoff), b->cap[8]));
+        HIPCHK(ctx, hipMemsetAsync(b->dHandoff, 0, b->cap[8], ctx->stream));     // epoch 0 = never written
 #ifdef DCS_STAMPS
-        b->cap[7] = sizeof(unsigned long long) * 8 * (b->nChunks + 4); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dDebug), b->cap[7]));
-        HIPCHK(ctx, hipMemsetAsync(b->dDebug, 0, sizeof(unsigned long long) * 8 * (b->nChunks + 4), ctx->stream));
+        b->cap[7] = sizeof(unsigned long long) * 16 * (b->nChunks + 4); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dDebug), b->cap[7]));
+        HIPCHK(ctx, hipMemsetAsync(b->dDebug, 0, sizeof(unsigned long long) * 16 * (b->nChunks + 4), ctx->stream));
 #endif
         HIPCHK(ctx, hipEventCreate(&b->ev0));
         HIPCHK(ctx, hipEventCreate(&b->ev1));
@@ -365,6 +378,10 @@ extern "C" DcsStatus dcs_batch_run(DcsBatch *b, void *hipStream)
     args.tailsOut = b->dTailsOut;
     args.tables = ctx->dTables;
     args.debug = b->dDebug;
+    args.handoff = b->dHandoff;
+    if (++b->epoch == 0)
+        b->epoch = 1;                   // 0 marks words no launch has written
+    args.epoch = b->epoch;
     hipError_t e;
     e = (b->fpw == 16) ? launch<16>(args, stream) : (b->fpw == 8) ? launch<8>(args, stream) : launch<4>(args, stream);
     if (e != hipSuccess)
@@ -451,13 +468,13 @@ extern "C" DcsStatus dcs_batch_download_view(DcsBatch *b, const int16_t **pcmOut
 extern "C" void *dcs_batch_device_pcm(DcsBatch *b) { return b ? b->dPcm : nullptr; }
 
 #ifdef DCS_STAMPS
-// diagnostic builds only: copy the per-chunk phase stamps (8 x uint64 per chunk) to the host
+// diagnostic builds only: copy the per-chunk phase stamps (16 x uint64 per chunk) to the host
 extern "C" int dcs_debug_stamps(DcsBatch *b, unsigned long long *out, uint32_t capChunks)
 {
     if (b == nullptr || b->dDebug == nullptr) return -1;
     (void)hipStreamSynchronize(b->ctx->stream);
     const uint32_t n = b->nChunks < capChunks ? b->nChunks : capChunks;
-    (void)hipMemcpy(out, b->dDebug, sizeof(unsigned long long) * 8 * n, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(out, b->dDebug, sizeof(unsigned long long) * 16 * n, hipMemcpyDeviceToHost);
     return static_cast<int>(n);
 }
 #endif

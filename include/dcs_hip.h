@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DCS_ABI_VERSION 4
+#define DCS_ABI_VERSION 5
 #define DCS_FRAME_SAMPLES 240          /* PCM samples per frame (DCSDecoder.h:123: 7.68 ms at 31250 Hz) */
 #define DCS_MAX_CHANNELS 8             /* DCSDecoderNative.h:305 */
 
@@ -191,6 +191,11 @@ int       dcs_device_count(void);                  /* does not initialise the GP
 
 /* tuning: frames handled per wavefront in the kernel (4, 8 or 16); 0 = choose from batch size */
 DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw);
+/* tuning: how a frame gets the 16-sample tail of a predecessor that lies in another wavefront's chunk.  1 (default):
+ * the wavefront that decodes the predecessor publishes the tail in a device buffer and the successor picks it up
+ * after its own transform; 0: the predecessor is decoded a second time next to the successor (a "halo" slot).
+ * Same PCM either way.  Applies to batches created afterwards. */
+DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable);
 
 /* One-shot convenience: host buffers in, host buffers out (H2D, kernel, D2H on the context's
  * stream, synchronous).  pcmOut = nJobs x 240 int16; errOut (optional) = nJobs x uint32 DCS_FRAME_*.
@@ -446,12 +451,16 @@ typedef struct DcsSynthParams
 DcsStatus dcs_synth_stream(const DcsSynthParams *params, uint8_t *out, size_t cap, size_t *lenOut);
 
 /* Diagnostic: the chunk plan the kernel launch would use for `jobs` at `fpw` frames per wavefront.
- * Each slot is returned as job | prevSlot<<32 | flags<<40 (flags: 1 = halo, 2 = external tail,
- * 0x80 = padding).  One wavefront decodes one chunk of fpw slots; a frame whose overlap predecessor
- * lies in another chunk gets that predecessor decoded again as a halo slot.  `srcs` (may be NULL)
- * lets the planner also respect the kernel's LDS budget for staged compressed bytes. */
+ * Each slot is returned as job | prevSlot<<32 | flags<<40 (flags: 1 = halo, 2 = external tail, 4 = publishes its
+ * tail for a later chunk, 8 = takes its predecessor's tail from an earlier chunk, 0x80 = padding).  One wavefront
+ * decodes one chunk of fpw slots.  A frame whose overlap predecessor lies in another chunk takes the tail from the
+ * hand-off buffer when the predecessor is the last frame of an earlier chunk (and `handoff` is non-zero); otherwise
+ * the predecessor is decoded again as a halo slot.  `srcs` (may be NULL) lets the planner also respect the kernel's
+ * LDS budget for staged compressed bytes.  dcs_plan_chunks = dcs_plan_chunks2 with handoff = 1. */
 DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw,
                           uint64_t *slotsOut, size_t cap, uint32_t *nChunksOut);
+DcsStatus dcs_plan_chunks2(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, int handoff,
+                           uint64_t *slotsOut, size_t cap, uint32_t *nChunksOut);
 
 uint32_t dcs_abi_version(void);
 

@@ -47,17 +47,44 @@ def test_single_stream_every_layout(gpu_ctx, oracle, fmt, profile):
         assert not err.any()
 
 
+@pytest.mark.parametrize("handoff", [True, False], ids=["handoff", "halo"])
 @pytest.mark.parametrize("fpw", [4, 8, 16])
-def test_frames_per_wave_variants_and_halos(gpu_ctx, oracle, fpw):
-    """chunk boundaries fall inside streams: the overlap tail must come from the halo re-decode"""
+def test_frames_per_wave_variants_and_chunk_boundaries(gpu_ctx, oracle, fpw, handoff):
+    """chunk boundaries fall inside streams: the overlap tail must cross them, through the hand-off buffer
+    (published by the wavefront that decodes the predecessor) or by the halo re-decode"""
     streams = [(os_for(f, f), make_stream(f, 45 + 13 * f, seed=12000 + f, profile=f % 3), 240, 0x62 + f)
                for f in ALL_FORMATS]
     gpu_ctx.set_frames_per_wave(fpw)
+    gpu_ctx.set_tail_handoff(handoff)
     try:
         pcm, err, _ = gpu_ctx.decode_streams(streams, extra_frames=1)
     finally:
         gpu_ctx.set_frames_per_wave(0)
+        gpu_ctx.set_tail_handoff(True)
     assert_same(pcm, oracle_streams(oracle, streams, extra=1), "fpw=%d" % fpw)
+    assert not err.any()
+
+
+def test_handoff_survives_many_launches_of_one_batch(gpu_ctx, oracle):
+    """the hand-off words carry the launch's epoch: a resident batch run again and again never sees a stale tail,
+    and a batch built on recycled device buffers (another batch's old words) does not either"""
+    for rep in range(2):
+        streams = [(os_for(f), make_stream(f, 90, seed=12100 + 7 * rep + f, profile=(f + rep) % 4), 255, 0x64)
+                   for f in (D.FMT_93_T0, D.FMT_94_T1_S3, D.FMT_93B_T1)]
+        b = D.build_stream_batch(streams)
+        gpu_ctx.set_frames_per_wave(4)
+        try:
+            bt = gpu_ctx.batch(b["blob"], b["srcs"], b["jobs"])
+        finally:
+            gpu_ctx.set_frames_per_wave(0)
+        want = oracle_streams(oracle, streams)
+        for k in range(40):
+            bt.run()
+            if k in (0, 1, 39):
+                pcm, err = bt.download()[:2]
+                assert_same(pcm, want, "launch %d" % k)
+                assert not err.any()
+        bt.close()
 
 
 def test_golden_vectors(gpu_ctx):

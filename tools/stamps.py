@@ -19,7 +19,7 @@ for _ in range(3): bt.run()
 bt.sync()
 L = D.load_library()
 cap = 1 << 16
-out = np.zeros((cap, 8), dtype=np.uint64)
+out = np.zeros((cap, 16), dtype=np.uint64)
 L.dcs_debug_stamps.restype = ctypes.c_int
 n = L.dcs_debug_stamps(bt.h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(cap))
 st = out[:n].astype(np.int64)
@@ -29,5 +29,13 @@ print(wl, "fpw", fpw or "auto", "chunks", n, "median total cycles", int(np.media
 for k in range(6):
     d = st[:, k + 1] - st[:, k]
     print("  %-48s median %7d  (%.1f%%)" % (names[k] if k < 5 else names[6], int(np.median(d)), 100 * np.median(d) / np.median(tot)))
-span = st[:, 6].max() - st[:, 0].min()
-print("  first start -> last end: %d cycles (s_memtime ticks at 100 MHz? see guide) " % span)
+# finer stamps (7 is unused): 12 bit readers ready, 8 unpacker entered, 9 first band set up, 10 its symbol loop done,
+# 11 unpacker's band loop done, 13 transform passes done (then: frames that import their tail)
+fine = [(3, 12, "Q set-up + bit reader init"), (12, 8, "-> unpacker entry"), (8, 9, "first band set-up"),
+        (9, 10, "first band symbol loop"), (10, 11, "rest of the bands"), (11, 4, "DC fix-up + sync"),
+        (5, 13, "transform passes"), (13, 6, "imported tails")]
+for a_, b_, name in fine:
+    ok = (st[:, a_] != 0) & (st[:, b_] != 0)
+    if ok.any():
+        d = st[ok, b_] - st[ok, a_]
+        print("    %-44s median %7d" % (name, int(np.median(d))))
