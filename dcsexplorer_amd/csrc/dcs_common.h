@@ -59,6 +59,7 @@ struct DcsDevTables
     uint16_t pair93a[2048];             // OS93a Type-1 sample pair table (:2698-2827); read via L1/L2
     uint16_t fftCoef[256];              // sin block 0..0x7F, cos block 0x80..0xFF, bit-reversed order (:366)
     uint16_t ovlCoef[16];               // overlap window (:314)
+    int32_t  twA[8][4];                 // twiddles 0..7 as the in-lane (layout A) butterflies take them: 2 cos, 2 sin, -2 sin, 0
 };
 
 // host-side view (same structure; one process-wide immutable instance)

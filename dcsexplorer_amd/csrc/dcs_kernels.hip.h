@@ -724,8 +724,48 @@ __device__ __forceinline__ uint32_t packC(int re, int im) { return (static_cast<
 __device__ __forceinline__ int reC(uint32_t c) { return sx16(c); }
 __device__ __forceinline__ int imC(uint32_t c) { return static_cast<int>(c) >> 16; }
 
-// t = a * (c + i*s) with the reference's rounding (.cpp:500-506, :761-765), packed (re | im << 16)
-__device__ __forceinline__ uint32_t rotatePk(uint32_t A, int c, int s)
+// ---- complex rotate t = a * (c + i*s) with the reference's rounding (.cpp:500-506, :761-765) -----------------
+//
+//   t.re = RoundMultiplyResult(MR = 2 a.re c - 2 a.im s),   the rounding quirk keyed on the LAST product, a.im s
+//   t.im = RoundMultiplyResult(MR = 2 a.im c + 2 a.re s),   keyed on a.re s
+//
+// RoundMultiplyResult (.cpp:3503-3514) adds 0x8000 and clears bit 16 when the last product's low word (of the doubled
+// product) is exactly 0x8000.  That happens for one product in 32 768.  A transform stage therefore computes its
+// butterflies WITHOUT the clear while one instruction per butterfly watches for the condition, and the stage is done
+// again with the exact (slower) rotate in the rare case that any lane met it: one wave-uniform branch per stage,
+// almost never taken, and the butterflies of a stage stay in one basic block.  "Low word of 2p is 0x8000" is tested
+// on 2p + 0x8000 (for one of the two products a term the sum needs anyway): its low word is zero; the watch register
+// keeps the minimum of all those low words (it starts at 0xFFFF and, once zero, stays zero: later stages of the
+// same transform then also take the exact path, which is always right).
+// running minimum of the low words seen so far: zero as soon as one product met the condition (one VALU per butterfly)
+__device__ __forceinline__ void quirkWatch(uint32_t &watch, uint32_t a, uint32_t b)
+{
+    asm("v_min3_u16 %0, %1, %2, %3" : "=v"(watch) : "v"(watch), "v"(a), "v"(b));
+}
+__device__ __forceinline__ bool quirkSeen(uint32_t watch) { return __any((watch & 0xFFFFu) == 0); }
+// 16 x 16 -> 32 signed products of selected halves of packed registers, one instruction each
+#define DCS_MUL_SEL(dst, x, xsel, y, ysel) \
+    asm("v_mul_i32_i24_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" xsel " src1_sel:" ysel : "=v"(dst) : "v"(x), "v"(y))
+
+// registers every butterfly needs: 0x8000 in a VGPR (VOP3 takes no literal) and the watch register
+struct BflyRegs { uint32_t k8000; uint32_t watch; };
+
+// twiddles of the layout-A stages (entries 2..7 of the table; 0 and 1 are exact and need no multiplier): the same for
+// every lane, held doubled (DcsDevTables.twA), which makes the products come out as the reference's doubled MR terms
+struct TwScalar { int c2, s2, ns2; };
+struct TwA { TwScalar t[8]; };
+__device__ __forceinline__ void loadTwA(const DcsDevTables *G, TwA &W)
+{
+#pragma unroll
+    for (int k = 2 ; k < 8 ; ++k)
+    {
+        const int4 v = *reinterpret_cast<const int4 *>(G->twA[k]);
+        W.t[k] = TwScalar{ v.x, v.y, v.z };
+    }
+}
+
+// exact rotate, every case handled in line: 15 VALU
+__device__ __forceinline__ uint32_t rotateExact(uint32_t A, int c, int s)
 {
     const int are = reC(A), aim = imC(A);
     const int p2 = __mul24(aim, s);
@@ -739,43 +779,97 @@ __device__ __forceinline__ uint32_t rotatePk(uint32_t A, int c, int s)
     return __builtin_amdgcn_perm(mrI, mrR, 0x07060302u);       // (mrR >> 16) | (mrI & 0xFFFF0000)
 }
 
-// radix-2 butterfly u' = u - t, a' = u + t (saturating for the 1994+ transform, wrapping for 1993)
-template <bool SAT>
-__device__ __forceinline__ void bfly(uint32_t &U, uint32_t &A, uint32_t tw)
+// fast rotates: the result without the clear, `quirk` collects the lanes that would have needed it.
+// Doubled twiddle in registers common to all lanes: 2 unpack + 4 multiply-adds + 1 watch + 1 pack = 8 instructions
+__device__ __forceinline__ uint32_t rotateFastA(uint32_t A, const TwScalar &t, BflyRegs &R)
 {
-    const uint32_t T = rotatePk(A, sx16(tw), static_cast<int>(tw) >> 16);
-    const uint32_t u = U;
-    if (SAT) { U = pkSubSat(u, T); A = pkAddSat(u, T); }
-    else     { U = pkSub(u, T);    A = pkAdd(u, T); }
+    const int are = reC(A), aim = imC(A);
+    const uint32_t nP = static_cast<uint32_t>(__mul24(aim, t.ns2)) + R.k8000;         // 0x8000 - 2 a.im s
+    const uint32_t mrR = static_cast<uint32_t>(__mul24(are, t.c2)) + nP;
+    const uint32_t qK = static_cast<uint32_t>(__mul24(are, t.s2)) + R.k8000;          // 0x8000 + 2 a.re s
+    const uint32_t mrI = static_cast<uint32_t>(__mul24(aim, t.c2)) + qK;
+    quirkWatch(R.watch, nP, qK);
+    return __builtin_amdgcn_perm(mrI, mrR, 0x07060302u);
+}
+// per-lane twiddle, packed cos | sin << 16: 4 products + 5 adds + 1 watch + 1 pack = 11 instructions
+__device__ __forceinline__ uint32_t rotateFastB(uint32_t A, uint32_t tw, BflyRegs &R)
+{
+    int p1, p2, q1, q2;
+    DCS_MUL_SEL(p2, A, "WORD_1", tw, "WORD_1");         // a.im s
+    DCS_MUL_SEL(p1, A, "WORD_0", tw, "WORD_0");         // a.re c
+    DCS_MUL_SEL(q2, A, "WORD_0", tw, "WORD_1");         // a.re s
+    DCS_MUL_SEL(q1, A, "WORD_1", tw, "WORD_0");         // a.im c
+    const uint32_t mrR = (static_cast<uint32_t>(p1 - p2) << 1) + R.k8000;
+    const uint32_t qK = (static_cast<uint32_t>(q2) << 1) + R.k8000;
+    const uint32_t mrI = (static_cast<uint32_t>(q1) << 1) + qK;
+    quirkWatch(R.watch, (static_cast<uint32_t>(p2) << 1) + R.k8000, qK);
+    return __builtin_amdgcn_perm(mrI, mrR, 0x07060302u);
 }
 
-__device__ __forceinline__ uint32_t twAt(const uint16_t *coef, int part)
+// radix-2 butterfly outputs u - t, u + t (saturating for the 1994+ transform, wrapping for 1993)
+template <bool SAT>
+__device__ __forceinline__ void addSub(uint32_t u, uint32_t T, uint32_t &lo, uint32_t &hi)
 {
-    return static_cast<uint32_t>(coef[0x80 + part]) | (static_cast<uint32_t>(coef[part]) << 16);
+    if (SAT) { lo = pkSubSat(u, T); hi = pkAddSat(u, T); }
+    else     { lo = pkSub(u, T);    hi = pkAdd(u, T); }
 }
 
 // The first two entries of the twiddle table are exact: entry 0 = (cos, sin) = (-1.0, 0), entry 1 = (0, -1.0)
 // (0x8000 is -1.0 in 1.15; dcs_tables.cpp asserts the values).  Multiplying by them needs no multiplier and
 // never triggers the rounding quirk (the last product is 0 or a multiple of 0x8000), so the reference's result
-// reduces to  t = (-a.re, -a.im)  resp.  t = (a.im, -a.re)  with 16-bit wrap-around (-(-32768) = -32768), which
-// is what rotatePk returns for them.  The layout-A stages know their twiddle index at compile time.
-template <bool SAT>
-__device__ __forceinline__ void bflyIdx(uint32_t &U, uint32_t &A, const uint16_t *coef, int idx)
+// reduces to  t = (-a.re, -a.im)  resp.  t = (a.im, -a.re)  with 16-bit wrap-around (-(-32768) = -32768).
+__device__ __forceinline__ uint32_t rotateByMinusOne(uint32_t A) { return pkSub(0u, A); }
+__device__ __forceinline__ uint32_t rotateByMinusI(uint32_t A)
 {
-    uint32_t T;
-    if (idx == 0)
-        T = pkSub(0u, A);
-    else if (idx == 1)
-        T = __builtin_bit_cast(uint32_t, static_cast<u16x2>(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbit(A, A, 16))
-                                                              * __builtin_bit_cast(u16x2, 0xFFFF0001u)));
-    else
+    return __builtin_bit_cast(uint32_t, static_cast<u16x2>(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbit(A, A, 16))
+                                                            * __builtin_bit_cast(u16x2, 0xFFFF0001u)));
+}
+
+// One stage on the 16 registers of a lane, partner distance D registers.
+// Layout A: the twiddle index of the pair (r, r + D) is r >> SH, known at compile time.
+template <bool SAT, int D, int SH>
+__device__ __forceinline__ void stageA(uint32_t (&x)[16], const TwA &W, BflyRegs &R)
+{
+    uint32_t y[16];
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & D))
+        {
+            const int idx = r >> SH;
+            const uint32_t T = idx == 0 ? rotateByMinusOne(x[r + D]) : idx == 1 ? rotateByMinusI(x[r + D])
+                                                                                 : rotateFastA(x[r + D], W.t[idx], R);
+            addSub<SAT>(x[r], T, y[r], y[r + D]);
+        }
+    if (__builtin_expect(quirkSeen(R.watch), 0))
     {
-        bfly<SAT>(U, A, twAt(coef, idx));
-        return;
+#pragma unroll
+        for (int r = 0 ; r < 16 ; ++r)
+            if (!(r & D) && (r >> SH) >= 2)
+                addSub<SAT>(x[r], rotateExact(x[r + D], W.t[r >> SH].c2 >> 1, W.t[r >> SH].s2 >> 1), y[r], y[r + D]);
     }
-    const uint32_t u = U;
-    if (SAT) { U = pkSubSat(u, T); A = pkAddSat(u, T); }
-    else     { U = pkSub(u, T);    A = pkAdd(u, T); }
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        x[r] = y[r];
+}
+// Layout B: per-lane twiddles tw[(r >> SH)] from the lane constants
+template <bool SAT, int D, int SH>
+__device__ __forceinline__ void stageB(uint32_t (&x)[16], const uint32_t *tw, BflyRegs &R)
+{
+    uint32_t y[16];
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        if (!(r & D))
+            addSub<SAT>(x[r], rotateFastB(x[r + D], tw[r >> SH], R), y[r], y[r + D]);
+    if (__builtin_expect(quirkSeen(R.watch), 0))
+    {
+#pragma unroll
+        for (int r = 0 ; r < 16 ; ++r)
+            if (!(r & D))
+                addSub<SAT>(x[r], rotateExact(x[r + D], sx16(tw[r >> SH]), static_cast<int>(tw[r >> SH]) >> 16), y[r], y[r + D]);
+    }
+#pragma unroll
+    for (int r = 0 ; r < 16 ; ++r)
+        x[r] = y[r];
 }
 
 __device__ __forceinline__ int bitrev9(int v) { return static_cast<int>(__brev(static_cast<uint32_t>(v)) >> 23); }
@@ -834,36 +928,64 @@ __device__ __forceinline__ int swzPos(int row, int pos) { return swzQuad(row, po
 
 // 1994+ transform of 8 frames, 8 lanes each (DecoderImpl94x::TransformFrame, .cpp:397-534).
 // On return x[r'] holds point 16*l + r' = output sample pair m = 8*bitrev4(r') + bitrev3(l), shifted.
-__device__ __forceinline__ void transform94x8(const PassLane &P, const uint16_t *coef, const LaneConsts &C, uint32_t (&x)[16])
+__device__ __forceinline__ void transform94x8(const PassLane &P, const TwA &W, const LaneConsts &C, BflyRegs &R, uint32_t (&x)[16])
 {
     const int l = P.l;
     uint32_t *S = P.rowC;
     // ---- pre-passes 1 + 2 on the pairs (i, 128 - i), i = l + 8j (:403-456) ------------------------
     uint32_t An[8], Bn[8];
-#pragma unroll
-    for (int j = 0 ; j < 8 ; ++j)
     {
-        const int i = l + 8 * j;
-        const uint32_t X = P.rowC[i];
-        uint32_t Y = P.rowC[(128 - i) & 127];
-        if (i == 0) Y = 0;                                  // words 0x100/0x101 start at zero
-        // MulSS(v, 0x8000) = wrapping negate
-        const uint32_t Sm = pkAddSat(X, Y), Df = pkSubSat(X, Y);
-        const uint32_t a = pkSub(0u, __builtin_amdgcn_perm(Df, Sm, 0x07060100u));     // (-(x0+y0), -(x1-y1))
-        const uint32_t b = pkSub(0u, __builtin_amdgcn_perm(Sm, Df, 0x07060100u));     // (-(x0-y0), -(x1+y1))
-        const int b0 = reC(b), b1 = imC(b);
-        const int c0 = sx16(C.pre94[j]), c1 = static_cast<int>(C.pre94[j]) >> 16;
-        // prod0 = b1*c1 - b0*c0 ; prod1 = b1*c0 + b0*c1
-        const int p2 = __mul24(b0, c0), q2 = __mul24(b0, c1);
-        uint32_t m0 = (static_cast<uint32_t>(__mul24(b1, c1) - p2) << 1) + 0x8000u;
-        uint32_t m1 = (static_cast<uint32_t>(__mul24(b1, c0) + q2) << 1) + 0x8000u;
-        if ((p2 & 0x7FFF) == 0x4000) m0 &= ~0x10000u;
-        if ((q2 & 0x7FFF) == 0x4000) m1 &= ~0x10000u;
-        const uint32_t Pr = __builtin_amdgcn_perm(m0, m1, 0x07060302u);   // (prod1, prod0)
-        An[j] = pkAddSat(Pr, a);                                        // (prod1 + a0, prod0 + a1)
-        const uint32_t t = pkSubSat(a, Pr);                             // (a0 - prod1, a1 - prod0)
-        const uint32_t t2 = pkSubSat(Pr, a);                            // (prod1 - a0, prod0 - a1)
-        Bn[j] = __builtin_amdgcn_perm(t2, t, 0x07060100u);              // (a0 - prod1, prod0 - a1)
+        uint32_t a_[8], b_[8];
+#pragma unroll
+        for (int j = 0 ; j < 8 ; ++j)
+        {
+            const int i = l + 8 * j;
+            const uint32_t X = P.rowC[i];
+            uint32_t Y = P.rowC[(128 - i) & 127];
+            if (i == 0) Y = 0;                                  // words 0x100/0x101 start at zero
+            // MulSS(v, 0x8000) = wrapping negate
+            const uint32_t Sm = pkAddSat(X, Y), Df = pkSubSat(X, Y);
+            a_[j] = pkSub(0u, __builtin_amdgcn_perm(Df, Sm, 0x07060100u));     // (-(x0+y0), -(x1-y1))
+            b_[j] = pkSub(0u, __builtin_amdgcn_perm(Sm, Df, 0x07060100u));     // (-(x0-y0), -(x1+y1))
+        }
+        // prod0 = b1*c1 - b0*c0 (rounding keyed on b0*c0) ; prod1 = b1*c0 + b0*c1 (keyed on b0*c1); b = (b0, b1), pre94 = (c0, c1)
+        auto finish = [&](int j, uint32_t Pr)                   // Pr = (prod1, prod0)
+        {
+            const uint32_t a = a_[j];
+            An[j] = pkAddSat(Pr, a);                                        // (prod1 + a0, prod0 + a1)
+            const uint32_t t = pkSubSat(a, Pr);                             // (a0 - prod1, a1 - prod0)
+            const uint32_t t2 = pkSubSat(Pr, a);                            // (prod1 - a0, prod0 - a1)
+            Bn[j] = __builtin_amdgcn_perm(t2, t, 0x07060100u);              // (a0 - prod1, prod0 - a1)
+        };
+#pragma unroll
+        for (int j = 0 ; j < 8 ; ++j)
+        {
+            int p1, p2, q1, q2;
+            DCS_MUL_SEL(p2, b_[j], "WORD_0", C.pre94[j], "WORD_0");
+            DCS_MUL_SEL(p1, b_[j], "WORD_1", C.pre94[j], "WORD_1");
+            DCS_MUL_SEL(q2, b_[j], "WORD_0", C.pre94[j], "WORD_1");
+            DCS_MUL_SEL(q1, b_[j], "WORD_1", C.pre94[j], "WORD_0");
+            const uint32_t m0 = (static_cast<uint32_t>(p1 - p2) << 1) + R.k8000;
+            const uint32_t qK = (static_cast<uint32_t>(q2) << 1) + R.k8000;
+            const uint32_t m1 = (static_cast<uint32_t>(q1) << 1) + qK;
+            quirkWatch(R.watch, (static_cast<uint32_t>(p2) << 1) + R.k8000, qK);
+            finish(j, __builtin_amdgcn_perm(m0, m1, 0x07060302u));
+        }
+        if (__builtin_expect(quirkSeen(R.watch), 0))
+        {
+#pragma unroll
+            for (int j = 0 ; j < 8 ; ++j)
+            {
+                const int b0 = reC(b_[j]), b1 = imC(b_[j]);
+                const int c0 = sx16(C.pre94[j]), c1 = static_cast<int>(C.pre94[j]) >> 16;
+                const int p2 = __mul24(b0, c0), q2 = __mul24(b0, c1);
+                uint32_t m0 = (static_cast<uint32_t>(__mul24(b1, c1) - p2) << 1) + 0x8000u;
+                uint32_t m1 = (static_cast<uint32_t>(__mul24(b1, c0) + q2) << 1) + 0x8000u;
+                if ((p2 & 0x7FFF) == 0x4000) m0 &= ~0x10000u;
+                if ((q2 & 0x7FFF) == 0x4000) m1 &= ~0x10000u;
+                finish(j, __builtin_amdgcn_perm(m0, m1, 0x07060302u));
+            }
+        }
     }
     // point 64: real part negated, imaginary part unchanged (:403-404); the pair i = 0 of lane 0 has no
     // partner, so lane 0 places it where B[0] would go
@@ -906,15 +1028,9 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const uint16_t 
         const uint32_t u = x[r], a = x[r + 8];
         x[r] = pkAddSat(u, a); x[r + 8] = pkSubSat(u, a);
     }
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 4)) bflyIdx<true>(x[r], x[r + 4], coef, r >> 3);
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 2)) bflyIdx<true>(x[r], x[r + 2], coef, r >> 2);
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 1)) bflyIdx<true>(x[r], x[r + 1], coef, r >> 1);
+    stageA<true, 4, 3>(x, W, R);
+    stageA<true, 2, 2>(x, W, R);
+    stageA<true, 1, 1>(x, W, R);
     // ---- transpose to layout B: point p = 16 l' + r' lives in row (p >> 4), position (p & 15) ---------------
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
@@ -927,15 +1043,9 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const uint16_t 
         x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
     }
     // ---- stages d = 4, 2, 1 ------------------------------------------------------------------------------
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 4)) bfly<true>(x[r], x[r + 4], C.twB94[r >> 3]);
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 2)) bfly<true>(x[r], x[r + 2], C.twB94[2 + (r >> 2)]);
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 1)) bfly<true>(x[r], x[r + 1], C.twB94[6 + (r >> 1)]);
+    stageB<true, 4, 3>(x, C.twB94, R);
+    stageB<true, 2, 2>(x, C.twB94 + 2, R);
+    stageB<true, 1, 1>(x, C.twB94 + 6, R);
     // volume shift (:532-534)
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
@@ -945,7 +1055,7 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const uint16_t 
 // 1993 transform of 4 frames, 16 lanes each (DecoderImpl93::TransformFrame, .cpp:714-785; the DC
 // magnitude step ran in phase 1).  On return x[r'] holds point 16*l + r'; its real part is output
 // sample i = 16*bitrev4(r') + bitrev4(l), shifted.
-__device__ __forceinline__ void transform93x4(const PassLane &P, const uint16_t *coef, const LaneConsts &C, uint32_t (&x)[16])
+__device__ __forceinline__ void transform93x4(const PassLane &P, const TwA &W, const LaneConsts &C, BflyRegs &R, uint32_t (&x)[16])
 {
     const int l = P.l;
     uint32_t *S = P.rowC;
@@ -966,15 +1076,9 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const uint16_t 
         }
     }
     // ---- stages d = 64, 32, 16 (wrapping) (:742-778) ------------------------------------------------------
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 4)) bflyIdx<false>(x[r], x[r + 4], coef, r >> 3);
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 2)) bflyIdx<false>(x[r], x[r + 2], coef, r >> 2);
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 1)) bflyIdx<false>(x[r], x[r + 1], coef, r >> 1);
+    stageA<false, 4, 3>(x, W, R);
+    stageA<false, 2, 2>(x, W, R);
+    stageA<false, 1, 1>(x, W, R);
     // ---- transpose: point 16 r + l  ->  lane r, register l.  The row holds 8 x 16 dwords, so two rounds:
     // registers 0..7 feed lanes 0..7, registers 8..15 feed lanes 8..15 ---------------------------------------------
     waveSync();         // every lane has read its part of the row: the row becomes scratch
@@ -1001,18 +1105,10 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const uint16_t 
     for (int r = 0 ; r < 16 ; ++r)
         x[r] = y[r];
     // ---- stages d = 8, 4, 2, 1 -----------------------------------------------------------------------------
-#pragma unroll
-    for (int r = 0 ; r < 8 ; ++r)
-        bfly<false>(x[r], x[r + 8], C.twB93[0]);
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 4)) bfly<false>(x[r], x[r + 4], C.twB93[1 + (r >> 3)]);
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 2)) bfly<false>(x[r], x[r + 2], C.twB93[3 + (r >> 2)]);
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & 1)) bfly<false>(x[r], x[r + 1], C.twB93[7 + (r >> 1)]);
+    stageB<false, 8, 4>(x, C.twB93, R);
+    stageB<false, 4, 3>(x, C.twB93 + 1, R);
+    stageB<false, 2, 2>(x, C.twB93 + 3, R);
+    stageB<false, 1, 1>(x, C.twB93 + 7, R);
     // volume shift of the real parts (:782-785)
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
@@ -1354,7 +1450,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
     loadLaneConsts(a.tables, lane, C);
     // ---- phase 2: transform passes (8 frames x 8 lanes, or 4 frames x 16 lanes), overlap, emit ------------
     uint32_t *tails = reinterpret_cast<uint32_t *>(L.tails());         // [slot][8] dwords = 16 samples
-    const uint16_t *coef = a.tables->fftCoef;
+    TwA W;
+    loadTwA(a.tables, W);
+#ifdef DCS_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DCS_STAMP(7);
+#endif
     const int nSlots = __popcll(__ballot(live && lane < FPW));          // padding slots are trailing
     const int slotFlags = slot.flags, slotJob = static_cast<int>(slot.job), slotPrev = slot.prevSlot;
     const int jobShift = job.volShift, jobXform = job.xform, jobPrev = static_cast<int>(job.prev);
@@ -1388,10 +1489,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
         P.shiftPair = static_cast<uint32_t>(myShift) * 0x00010001u;
 
         uint32_t x[16];
+        BflyRegs R;
+        R.k8000 = 0x8000u; R.watch = 0xFFFFu;
+        asm volatile("" : "+v"(R.k8000));                    // keep it in a vector register (VOP3 takes no literal operand)
         if (xf == DCS_XFORM_94)
-            transform94x8(P, coef, C, x);
+            transform94x8(P, W, C, R, x);
         else
-            transform93x4(P, coef, C, x);
+            transform93x4(P, W, C, R, x);
+        if (s0 == 0) DCS_STAMP(14);
 
         // tail for the successor = output samples 240..255 (:569-575, :805-812): register 15 of every lane
         if (active)
@@ -1412,6 +1517,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
         }
         waveSync();
 
+        if (s0 == 0) DCS_STAMP(15);
         const bool emit = active && !(myFlags & DCS_SLOT_HALO);
         // A frame whose tail comes from an earlier chunk (DCS_SLOT_IMPORT) is finished after the last pass: its first
         // 16 output samples, not yet overlapped, wait in its tile row (dead after the transform).  Waiting here

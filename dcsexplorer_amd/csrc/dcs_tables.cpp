@@ -135,6 +135,11 @@ DcsDevTables build()
     if (kFftCoef[0x80] != 0x8000 || kFftCoef[0] != 0x0000 || kFftCoef[0x81] != 0x0000 || kFftCoef[1] != 0x8000)
         abort();
     memcpy(t.ovlCoef, kOverlapCoef, sizeof(t.ovlCoef));
+    for (int k = 0 ; k < 8 ; ++k)
+    {
+        const int c = static_cast<int16_t>(kFftCoef[0x80 + k]), sn = static_cast<int16_t>(kFftCoef[k]);
+        t.twA[k][0] = 2 * c; t.twA[k][1] = 2 * sn; t.twA[k][2] = -2 * sn; t.twA[k][3] = 0;
+    }
 
     // per-lane transform constants (see DcsLaneConsts)
     auto rev = [](int v, int bits) { int r = 0; for (int i = 0 ; i < bits ; ++i) r |= ((v >> i) & 1) << (bits - 1 - i); return r; };
@@ -173,7 +178,7 @@ const DcsDevTables &dcsTables()
 }
 
 static_assert(sizeof(DcsLdsTables) % 16 == 0, "LDS table block must be a multiple of 16 bytes");
-static_assert(sizeof(DcsLaneConsts) == 160 && offsetof(DcsDevTables, lane) % 16 == 0, "lane constants are fetched as uint4");
+static_assert(sizeof(DcsLaneConsts) == 160 && offsetof(DcsDevTables, lane) % 16 == 0 && offsetof(DcsDevTables, twA) % 16 == 0, "lane constants and twiddles are fetched as uint4");
 static_assert(sizeof(DcsSrcDesc) == 160, "DcsSrcDesc layout");
 static_assert(offsetof(DcsSrcDesc, idx) == 12, "DcsSrcDesc layout");
 static_assert(sizeof(DcsFrameJob) == 16, "DcsFrameJob layout");

@@ -33,6 +33,7 @@ for k in range(6):
 # 11 unpacker's band loop done, 13 transform passes done (then: frames that import their tail)
 fine = [(3, 12, "Q set-up + bit reader init"), (12, 8, "-> unpacker entry"), (8, 9, "first band set-up"),
         (9, 10, "first band symbol loop"), (10, 11, "rest of the bands"), (11, 4, "DC fix-up + sync"),
+        (5, 7, "lane constants arrive"), (7, 14, "first pass: transform"), (14, 15, "first pass: tails, export, sync"),
         (5, 13, "transform passes"), (13, 6, "imported tails")]
 for a_, b_, name in fine:
     ok = (st[:, a_] != 0) & (st[:, b_] != 0)
