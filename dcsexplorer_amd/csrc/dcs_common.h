@@ -39,21 +39,27 @@ struct DcsLdsTables
 };
 
 // per-lane constants of the transform passes (dcs_kernels.hip.h): twiddles and overlap-window entries that
-// depend only on the lane number, precomputed on the host so that a wavefront fetches them with ten
-// 16-byte loads per lane instead of ~40 scattered table reads
-struct DcsLaneConsts
-{
-    uint32_t pre94[8];                  // 94x pre-twiddle of pair i = l + 8j: c0 | c1 << 16 (.cpp:428-429), l = lane & 7
-    uint32_t twB94[14];                 // 94x layout-B stages: d=4 [0..1], d=2 [2..5], d=1 [6..13]; cos | sin << 16
-    uint32_t twB93[15];                 // 93 layout-B stages: d=8 [0], d=4 [1..2], d=2 [3..6], d=1 [7..14], l = lane & 15
-    uint32_t ovl94a, ovl94b;            // overlap window of pair m = bitrev3(l): co[2m] | co[2m+1]<<16 ; co[15-2m] | co[14-2m]<<16
-    uint32_t ovl93;                     // overlap window of sample i = bitrev4(l): co[i] | co[15-i]<<16
-};
+// depend only on the lane number, precomputed on the host so that a wavefront fetches them with six
+// 16-byte loads per lane instead of ~40 scattered table reads.  One 24-dword record per transform:
+//   1994+ (lane94[l], l = lane & 7 matters):  [0..7]  pre-twiddle of pair i = l + 8j: c0 | c1 << 16 (.cpp:428-429)
+//                                             [8..21] layout-B stages d=4 [8..9], d=2 [10..13], d=1 [14..21]; cos | sin << 16
+//                                             [22]    overlap window of pair m = bitrev3(l): co[2m] | co[2m+1] << 16
+//                                             [23]    co[15-2m] | co[14-2m] << 16
+//   1993  (lane93[l], l = lane & 15 matters): [0..14] layout-B stages d=8 [0], d=4 [1..2], d=2 [3..6], d=1 [7..14]
+//                                             [15]    overlap window of sample i = bitrev4(l): co[i] | co[15-i] << 16
+#define DCS_LANE_CONSTS 24
+#define DCS_K94_PRE   0
+#define DCS_K94_TWB   8
+#define DCS_K94_OVLA  22
+#define DCS_K94_OVLB  23
+#define DCS_K93_TWB   0
+#define DCS_K93_OVL   15
 
 struct DcsDevTables
 {
     DcsLdsTables lds;                   // copied to LDS by each workgroup
-    DcsLaneConsts lane[64];
+    uint32_t lane94[64][DCS_LANE_CONSTS];
+    uint32_t lane93[64][DCS_LANE_CONSTS];
     uint16_t fast94[256];               // 1994+ band-type delta code: only the host index pass reads it
     uint16_t trie94[DCS_TRIE94_MAX];
     uint16_t pair93a[2048];             // OS93a Type-1 sample pair table (:2698-2827); read via L1/L2

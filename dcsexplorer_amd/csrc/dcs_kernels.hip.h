@@ -883,18 +883,19 @@ __device__ __forceinline__ int overlapMix(int x, uint32_t cx, int o, uint32_t co
     return static_cast<int>(a + b + 0x8000u) >> 16;
 }
 
-typedef DcsLaneConsts LaneConsts;
 typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));      // 16 bytes at any dword address
 
-
-// ten 16-byte loads per lane from the host-built table
-__device__ __forceinline__ void loadLaneConsts(const DcsDevTables *G, int lane, LaneConsts &C)
+// the lane's constants for one of the two transforms (DcsDevTables.lane94 / lane93): six 16-byte loads
+struct LaneConsts { uint32_t k[DCS_LANE_CONSTS]; };
+__device__ __forceinline__ void loadLaneConsts(const DcsDevTables *G, int lane, int xform, LaneConsts &C)
 {
-    const uint4 *src = reinterpret_cast<const uint4 *>(&G->lane[lane]);
-    uint4 *dst = reinterpret_cast<uint4 *>(&C);
+    const uint4 *src = reinterpret_cast<const uint4 *>(xform == DCS_XFORM_94 ? G->lane94[lane] : G->lane93[lane]);
 #pragma unroll
-    for (int i = 0 ; i < static_cast<int>(sizeof(LaneConsts) / 16) ; ++i)
-        dst[i] = src[i];
+    for (int i = 0 ; i < DCS_LANE_CONSTS / 4 ; ++i)
+    {
+        const uint4 v = src[i];
+        C.k[4 * i] = v.x; C.k[4 * i + 1] = v.y; C.k[4 * i + 2] = v.z; C.k[4 * i + 3] = v.w;
+    }
 }
 
 // Ordering of LDS traffic between the lanes of ONE wavefront.  A wavefront's LDS instructions execute
@@ -961,10 +962,10 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const TwA &W, c
         for (int j = 0 ; j < 8 ; ++j)
         {
             int p1, p2, q1, q2;
-            DCS_MUL_SEL(p2, b_[j], "WORD_0", C.pre94[j], "WORD_0");
-            DCS_MUL_SEL(p1, b_[j], "WORD_1", C.pre94[j], "WORD_1");
-            DCS_MUL_SEL(q2, b_[j], "WORD_0", C.pre94[j], "WORD_1");
-            DCS_MUL_SEL(q1, b_[j], "WORD_1", C.pre94[j], "WORD_0");
+            DCS_MUL_SEL(p2, b_[j], "WORD_0", C.k[DCS_K94_PRE + j], "WORD_0");
+            DCS_MUL_SEL(p1, b_[j], "WORD_1", C.k[DCS_K94_PRE + j], "WORD_1");
+            DCS_MUL_SEL(q2, b_[j], "WORD_0", C.k[DCS_K94_PRE + j], "WORD_1");
+            DCS_MUL_SEL(q1, b_[j], "WORD_1", C.k[DCS_K94_PRE + j], "WORD_0");
             const uint32_t m0 = (static_cast<uint32_t>(p1 - p2) << 1) + R.k8000;
             const uint32_t qK = (static_cast<uint32_t>(q2) << 1) + R.k8000;
             const uint32_t m1 = (static_cast<uint32_t>(q1) << 1) + qK;
@@ -977,7 +978,7 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const TwA &W, c
             for (int j = 0 ; j < 8 ; ++j)
             {
                 const int b0 = reC(b_[j]), b1 = imC(b_[j]);
-                const int c0 = sx16(C.pre94[j]), c1 = static_cast<int>(C.pre94[j]) >> 16;
+                const int c0 = sx16(C.k[DCS_K94_PRE + j]), c1 = static_cast<int>(C.k[DCS_K94_PRE + j]) >> 16;
                 const int p2 = __mul24(b0, c0), q2 = __mul24(b0, c1);
                 uint32_t m0 = (static_cast<uint32_t>(__mul24(b1, c1) - p2) << 1) + 0x8000u;
                 uint32_t m1 = (static_cast<uint32_t>(__mul24(b1, c0) + q2) << 1) + 0x8000u;
@@ -1043,9 +1044,9 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const TwA &W, c
         x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
     }
     // ---- stages d = 4, 2, 1 ------------------------------------------------------------------------------
-    stageB<true, 4, 3>(x, C.twB94, R);
-    stageB<true, 2, 2>(x, C.twB94 + 2, R);
-    stageB<true, 1, 1>(x, C.twB94 + 6, R);
+    stageB<true, 4, 3>(x, C.k + DCS_K94_TWB, R);
+    stageB<true, 2, 2>(x, C.k + DCS_K94_TWB + 2, R);
+    stageB<true, 1, 1>(x, C.k + DCS_K94_TWB + 6, R);
     // volume shift (:532-534)
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
@@ -1105,10 +1106,10 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const TwA &W, c
     for (int r = 0 ; r < 16 ; ++r)
         x[r] = y[r];
     // ---- stages d = 8, 4, 2, 1 -----------------------------------------------------------------------------
-    stageB<false, 8, 4>(x, C.twB93, R);
-    stageB<false, 4, 3>(x, C.twB93 + 1, R);
-    stageB<false, 2, 2>(x, C.twB93 + 3, R);
-    stageB<false, 1, 1>(x, C.twB93 + 7, R);
+    stageB<false, 8, 4>(x, C.k + DCS_K93_TWB, R);
+    stageB<false, 4, 3>(x, C.k + DCS_K93_TWB + 1, R);
+    stageB<false, 2, 2>(x, C.k + DCS_K93_TWB + 3, R);
+    stageB<false, 1, 1>(x, C.k + DCS_K93_TWB + 7, R);
     // volume shift of the real parts (:782-785)
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
@@ -1155,6 +1156,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
         slot.runStartDw = s1.x; slot.runNDw = s1.y & 0xFFFFu; slot.poolOff = s1.y >> 16;
         slot.hdrDw = s1.z; slot.hdrSh = s1.w & 0xFFu; slot.bpl = (s1.w >> 8) & 0xFFu; slot.runPoolOff = s1.w >> 16;
     }
+
+    // the lane's transform constants for the chunk's first frame (the whole chunk, normally): requested now, needed in
+    // phase 2 (24 registers live through phase 1 buy a memory round trip at the start of phase 2)
+    int constsXform = __builtin_amdgcn_readfirstlane(static_cast<int>(slot.shiftXform >> 4)) == DCS_XFORM_94 ? DCS_XFORM_94 : DCS_XFORM_93;
+    LaneConsts C;
+    loadLaneConsts(a.tables, lane, constsXform, C);
+    TwA W;
+    loadTwA(a.tables, W);
 
     // ---- stage the shared tables (whole workgroup), clear this wavefront's tile ------------------------
     {
@@ -1446,12 +1455,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
     waveSync();
 
     DCS_STAMP(5);
-    LaneConsts C;                                   // fetched here so that they are not live during phase 1
-    loadLaneConsts(a.tables, lane, C);
     // ---- phase 2: transform passes (8 frames x 8 lanes, or 4 frames x 16 lanes), overlap, emit ------------
     uint32_t *tails = reinterpret_cast<uint32_t *>(L.tails());         // [slot][8] dwords = 16 samples
-    TwA W;
-    loadTwA(a.tables, W);
 #ifdef DCS_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DCS_STAMP(7);
@@ -1471,6 +1476,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
         while (n < G && s0 + n < nSlots && __builtin_amdgcn_readlane(jobXform, s0 + n) == xf)
             ++n;
 
+        if (xf != constsXform)
+        {
+            constsXform = xf;                       // a chunk that mixes decoders of both families
+            loadLaneConsts(a.tables, lane, constsXform, C);
+        }
         const int lpfShift = (xf == DCS_XFORM_94) ? 3 : 4;
         const int g = lane >> lpfShift;
         const bool active = g < n;
@@ -1538,8 +1548,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
                 tailPair = tails[myPrevSlot * 8 + m];
             if (deferred)
                 P.rowC[m] = x[0];
-            x[0] = packC(overlapMix(reC(x[0]), C.ovl94a & 0xFFFFu, reC(tailPair), C.ovl94b & 0xFFFFu),
-                         overlapMix(imC(x[0]), C.ovl94a >> 16, imC(tailPair), C.ovl94b >> 16));
+            x[0] = packC(overlapMix(reC(x[0]), C.k[DCS_K94_OVLA] & 0xFFFFu, reC(tailPair), C.k[DCS_K94_OVLB] & 0xFFFFu),
+                         overlapMix(imC(x[0]), C.k[DCS_K94_OVLA] >> 16, imC(tailPair), C.k[DCS_K94_OVLB] >> 16));
             if (emit)
             {
                 uint32_t *out = reinterpret_cast<uint32_t *>(a.pcm) + static_cast<size_t>(myJob) * (DCS_FRAME_SAMPLES / 2);
@@ -1566,7 +1576,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
                 tailSample = static_cast<int16_t>(reinterpret_cast<const uint16_t *>(tails)[myPrevSlot * 16 + i]);
             if (deferred)
                 P.rowC[i] = x[0];
-            x[0] = static_cast<uint32_t>(overlapMix(reC(x[0]), C.ovl93 & 0xFFFFu, tailSample, C.ovl93 >> 16)) & 0xFFFFu;
+            x[0] = static_cast<uint32_t>(overlapMix(reC(x[0]), C.k[DCS_K93_OVL] & 0xFFFFu, tailSample, C.k[DCS_K93_OVL] >> 16)) & 0xFFFFu;
             if (emit)
             {
                 int16_t *out = a.pcm + static_cast<size_t>(myJob) * DCS_FRAME_SAMPLES;
@@ -1596,6 +1606,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
         const uint32_t jobI = static_cast<uint32_t>(__builtin_amdgcn_readlane(slotJob, sI));
         const uint32_t fromChunk = static_cast<uint32_t>(__builtin_amdgcn_readlane(jobPrev, sI));
         const int lpf = (xf == DCS_XFORM_94) ? 8 : 16;
+        if (xf != constsXform)
+        {
+            constsXform = xf;                       // (the chunk's last pass ran the other transform)
+            loadLaneConsts(a.tables, lane, constsXform, C);
+        }
         if (lane < lpf)
         {
             const int k = (xf == DCS_XFORM_94) ? bitrevN(lane, 3) : bitrevN(lane, 4);
@@ -1614,11 +1629,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             const uint32_t x0 = reinterpret_cast<const uint32_t *>(L.row(sI))[k];
             if (xf == DCS_XFORM_94)
                 reinterpret_cast<uint32_t *>(a.pcm)[static_cast<size_t>(jobI) * (DCS_FRAME_SAMPLES / 2) + k] =
-                    packC(overlapMix(reC(x0), C.ovl94a & 0xFFFFu, reC(tail), C.ovl94b & 0xFFFFu),
-                          overlapMix(imC(x0), C.ovl94a >> 16, imC(tail), C.ovl94b >> 16));
+                    packC(overlapMix(reC(x0), C.k[DCS_K94_OVLA] & 0xFFFFu, reC(tail), C.k[DCS_K94_OVLB] & 0xFFFFu),
+                          overlapMix(imC(x0), C.k[DCS_K94_OVLA] >> 16, imC(tail), C.k[DCS_K94_OVLB] >> 16));
             else
                 a.pcm[static_cast<size_t>(jobI) * DCS_FRAME_SAMPLES + k] =
-                    static_cast<int16_t>(overlapMix(reC(x0), C.ovl93 & 0xFFFFu, sx16(tail), C.ovl93 >> 16));
+                    static_cast<int16_t>(overlapMix(reC(x0), C.k[DCS_K93_OVL] & 0xFFFFu, sx16(tail), C.k[DCS_K93_OVL] >> 16));
         }
     }
     DCS_STAMP(6);

@@ -146,25 +146,25 @@ DcsDevTables build()
     auto tw = [&](int part) { return static_cast<uint32_t>(kFftCoef[0x80 + part]) | (static_cast<uint32_t>(kFftCoef[part]) << 16); };
     for (int lane = 0 ; lane < 64 ; ++lane)
     {
-        DcsLaneConsts &c = t.lane[lane];
+        uint32_t *k94 = t.lane94[lane], *k93 = t.lane93[lane];
         const int l8 = lane & 7, l16 = lane & 15;
         for (int j = 0 ; j < 8 ; ++j)
         {
             const int i = l8 + 8 * j;
-            c.pre94[j] = static_cast<uint32_t>(kFftCoef[rev(2 + 4 * i, 9)]) | (static_cast<uint32_t>(kFftCoef[rev(4 * i, 9)]) << 16);
+            k94[DCS_K94_PRE + j] = static_cast<uint32_t>(kFftCoef[rev(2 + 4 * i, 9)]) | (static_cast<uint32_t>(kFftCoef[rev(4 * i, 9)]) << 16);
         }
-        for (int k = 0 ; k < 2 ; ++k) c.twB94[k] = tw(2 * l8 + k);
-        for (int k = 0 ; k < 4 ; ++k) c.twB94[2 + k] = tw(4 * l8 + k);
-        for (int k = 0 ; k < 8 ; ++k) c.twB94[6 + k] = tw(8 * l8 + k);
-        c.twB93[0] = tw(l16);
-        for (int k = 0 ; k < 2 ; ++k) c.twB93[1 + k] = tw(2 * l16 + k);
-        for (int k = 0 ; k < 4 ; ++k) c.twB93[3 + k] = tw(4 * l16 + k);
-        for (int k = 0 ; k < 8 ; ++k) c.twB93[7 + k] = tw(8 * l16 + k);
+        for (int k = 0 ; k < 2 ; ++k) k94[DCS_K94_TWB + k] = tw(2 * l8 + k);
+        for (int k = 0 ; k < 4 ; ++k) k94[DCS_K94_TWB + 2 + k] = tw(4 * l8 + k);
+        for (int k = 0 ; k < 8 ; ++k) k94[DCS_K94_TWB + 6 + k] = tw(8 * l8 + k);
+        k93[DCS_K93_TWB] = tw(l16);
+        for (int k = 0 ; k < 2 ; ++k) k93[DCS_K93_TWB + 1 + k] = tw(2 * l16 + k);
+        for (int k = 0 ; k < 4 ; ++k) k93[DCS_K93_TWB + 3 + k] = tw(4 * l16 + k);
+        for (int k = 0 ; k < 8 ; ++k) k93[DCS_K93_TWB + 7 + k] = tw(8 * l16 + k);
         const int m = rev(l8, 3);
-        c.ovl94a = static_cast<uint32_t>(kOverlapCoef[2 * m]) | (static_cast<uint32_t>(kOverlapCoef[2 * m + 1]) << 16);
-        c.ovl94b = static_cast<uint32_t>(kOverlapCoef[15 - 2 * m]) | (static_cast<uint32_t>(kOverlapCoef[14 - 2 * m]) << 16);
+        k94[DCS_K94_OVLA] = static_cast<uint32_t>(kOverlapCoef[2 * m]) | (static_cast<uint32_t>(kOverlapCoef[2 * m + 1]) << 16);
+        k94[DCS_K94_OVLB] = static_cast<uint32_t>(kOverlapCoef[15 - 2 * m]) | (static_cast<uint32_t>(kOverlapCoef[14 - 2 * m]) << 16);
         const int i = rev(l16, 4);
-        c.ovl93 = static_cast<uint32_t>(kOverlapCoef[i]) | (static_cast<uint32_t>(kOverlapCoef[15 - i]) << 16);
+        k93[DCS_K93_OVL] = static_cast<uint32_t>(kOverlapCoef[i]) | (static_cast<uint32_t>(kOverlapCoef[15 - i]) << 16);
     }
     return t;
 }
@@ -178,7 +178,7 @@ const DcsDevTables &dcsTables()
 }
 
 static_assert(sizeof(DcsLdsTables) % 16 == 0, "LDS table block must be a multiple of 16 bytes");
-static_assert(sizeof(DcsLaneConsts) == 160 && offsetof(DcsDevTables, lane) % 16 == 0 && offsetof(DcsDevTables, twA) % 16 == 0, "lane constants and twiddles are fetched as uint4");
+static_assert(offsetof(DcsDevTables, lane94) % 16 == 0 && offsetof(DcsDevTables, lane93) % 16 == 0 && offsetof(DcsDevTables, twA) % 16 == 0, "lane constants and twiddles are fetched as uint4");
 static_assert(sizeof(DcsSrcDesc) == 160, "DcsSrcDesc layout");
 static_assert(offsetof(DcsSrcDesc, idx) == 12, "DcsSrcDesc layout");
 static_assert(sizeof(DcsFrameJob) == 16, "DcsFrameJob layout");
