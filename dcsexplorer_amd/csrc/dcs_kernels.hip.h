@@ -220,11 +220,22 @@ __device__ __forceinline__ int mul24(int a, int b)
 template <bool FIRST>
 __device__ __forceinline__ void mixAdd(uint16_t *cell, int scaledProduct, uint32_t mixMul)
 {
-    const uint32_t s = static_cast<uint32_t>(scaledProduct) & 0xFFFFu;
-    uint32_t acc = s + static_cast<uint32_t>(__mul24(sx16(s), static_cast<int>(mixMul)));
+    // three instructions: the low word of the product is picked (sign- resp. zero-extended) by the operand selects
+    uint32_t t, acc;
+    asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+        : "=v"(t) : "v"(scaledProduct), "v"(mixMul));
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=v"(acc) : "v"(t), "v"(scaledProduct));
     if (!FIRST)
         acc += static_cast<uint32_t>(*cell) << 16;
     *cell = static_cast<uint16_t>(acc >> 16);
+}
+// (int16)word 0 of x times a 24-bit signed y, one instruction
+__device__ __forceinline__ int mulLowWord(uint32_t x, int y)
+{
+    int r;
+    asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(r) : "v"(x), "v"(y));
+    return r;
 }
 // the same contribution removed again (exact inverse: the MAC is additive modulo 2^16 in the high word)
 __device__ __forceinline__ void mixSub(uint16_t *cell, int scaledProduct, uint32_t mixMul)
@@ -530,17 +541,33 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         const uint32_t wMask = width != 0 ? 0xFFFFFFFFu : 0u;
         const bool ran = nS > 0 || quirk;
         if (k == 0) stamp(9);
-        for (int i = 0 ; i < nS ; ++i)
+        auto sample = [&](uint32_t in)
         {
-            const uint32_t ahead = br.prefetch();
-            const uint32_t in = static_cast<uint32_t>(static_cast<int>(br.cur() & wMask) >> shW);
-            br.skip(width, ahead);
             const uint32_t d = in + (prvDelta & m2);
             const uint32_t p = d + (prv & m0);
             prvDelta = d - (prv & ~m0);
             prv = p;
-            mixAdd<FIRST>(&row[outIdx < 256 ? outIdx : kDummyWord], mul24(sx16(p), scale), mixMul);
+            mixAdd<FIRST>(&row[min(outIdx, kDummyWord)], mulLowWord(p, scale), mixMul);
             outIdx += inc;
+        };
+        // two samples per window read: a sample is at most 16 bits wide, so the next 32 bits always hold two
+        int i = 0;
+        for ( ; i + 2 <= nS ; i += 2)
+        {
+            const uint32_t ahead = br.prefetch();
+            const uint32_t w = br.cur() & wMask;
+            br.skip(2 * width, ahead);
+            sample(static_cast<uint32_t>(static_cast<int>(w) >> shW));
+            sample(static_cast<uint32_t>(static_cast<int>(w << width) >> shW));
+        }
+        if (__any(i < nS))
+        {
+            if (i < nS)
+            {
+                const uint32_t in = static_cast<uint32_t>(static_cast<int>(br.cur() & wMask) >> shW);
+                br.skip(width);
+                sample(in);
+            }
         }
         prv &= 0xFFFFu; prvDelta &= 0xFFFFu;
         if (k == 0) stamp(10);
@@ -551,18 +578,16 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         {
             if (quirk)
             {
-                uint32_t low = static_cast<uint32_t>(mul24(sx16(prv), scale)) & 0xFFFFu;
-                const int mulLow = sx16(low);
+                uint32_t low = static_cast<uint32_t>(mulLowWord(prv, scale)) & 0xFFFFu;
+                const uint32_t addend = static_cast<uint32_t>(__mul24(sx16(low), static_cast<int>(mixMul)));
                 for (int i = 0 ; i < nQ ; ++i, outIdx += inc)
                 {
-                    if (outIdx < 256)
-                    {
-                        uint32_t acc = low + static_cast<uint32_t>(__mul24(mulLow, static_cast<int>(mixMul)));
-                        if (!FIRST)
-                            acc += static_cast<uint32_t>(row[outIdx]) << 16;
-                        row[outIdx] = static_cast<uint16_t>(acc >> 16);
-                        low = acc & 0xFFFFu;
-                    }
+                    uint16_t *cell = &row[min(outIdx, kDummyWord)];
+                    uint32_t acc = low + addend;
+                    if (!FIRST)
+                        acc += static_cast<uint32_t>(*cell) << 16;
+                    *cell = static_cast<uint16_t>(acc >> 16);
+                    low = acc & 0xFFFFu;
                 }
                 prvDelta = 0;
             }
