@@ -50,8 +50,8 @@ constexpr int kRowBytes = 528;          // 256 words + 16 bytes: 16-byte aligned
 __host__ __device__ constexpr int poolDwords(int fpw) { return static_cast<int>(dcsPoolCapacity(fpw)); }
 __host__ __device__ constexpr int subLanes(int fpw) { return 64 / fpw; }     // 16, 8 and 4 lanes per frame for fpw 4, 8, 16
 
-// per wavefront: tile rows | tails [fpw][16] i16 | bit pool
-__host__ __device__ constexpr int waveLdsBytes(int fpw) { return fpw * kRowBytes + fpw * 32 + poolDwords(fpw) * 4; }
+// per wavefront: tile rows | tails [fpw + 1][16] i16 (the last row is a sink for lane groups without a frame) | bit pool
+__host__ __device__ constexpr int waveLdsBytes(int fpw) { return fpw * kRowBytes + (fpw + 1) * 32 + poolDwords(fpw) * 4; }
 // workgroup layout: tables | the four wavefronts' bit pools | the four wavefronts' (tile rows, tails).  The pools
 // come first on purpose, see BitReader.
 __host__ __device__ constexpr int ldsBytes(int fpw)
@@ -1150,7 +1150,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = static_cast<int>(threadIdx.x) >> 6;
     const int lane = static_cast<int>(threadIdx.x) & 63;
-    constexpr int kPoolBytes = poolDwords(FPW) * 4, kTileBytes = FPW * (kRowBytes + 32);
+    constexpr int kPoolBytes = poolDwords(FPW) * 4, kTileBytes = FPW * kRowBytes + (FPW + 1) * 32;
     static_assert(kPoolBytes % 16 == 0 && kWavesPerBlock * kTileBytes >= 8192, "LDS layout");
     const Lds<FPW> L{ smem, smem + sizeof(DcsLdsTables) + kWavesPerBlock * kPoolBytes + wave * kTileBytes,
                       smem + sizeof(DcsLdsTables) + wave * kPoolBytes };
@@ -1487,8 +1487,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
     DCS_STAMP(7);
 #endif
     const int nSlots = __popcll(__ballot(live && lane < FPW));          // padding slots are trailing
-    const int slotFlags = slot.flags, slotJob = static_cast<int>(slot.job), slotPrev = slot.prevSlot;
-    const int jobShift = job.volShift, jobXform = job.xform, jobPrev = static_cast<int>(job.prev);
+    const int slotFlags = slot.flags, slotJob = static_cast<int>(slot.job);
+    const int slotWord = static_cast<int>(slot.flags | (slot.prevSlot << 8) | (static_cast<uint32_t>(job.volShift) << 16));
+    const int jobXform = job.xform, jobPrev = static_cast<int>(job.prev);
 
 #ifdef DCS_EXP_NO_PHASE2
     if (nSlots > 1000)
@@ -1510,11 +1511,24 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
         const int g = lane >> lpfShift;
         const bool active = g < n;
         const int mySlot = s0 + (active ? g : 0);
-        const int myFlags = __shfl(slotFlags, mySlot);
+        const int myWord = __shfl(slotWord, mySlot);
+        const int myFlags = myWord & 0xFF, myPrevSlot = (myWord >> 8) & 0xFF, myShift = myWord >> 16;
         const uint32_t myJob = static_cast<uint32_t>(__shfl(slotJob, mySlot));
-        const int myPrevSlot = __shfl(slotPrev, mySlot);
-        const int myShift = __shfl(jobShift, mySlot);
         const uint32_t myPrevJob = static_cast<uint32_t>(__shfl(jobPrev, mySlot));
+        const int lr = (xf == DCS_XFORM_94) ? bitrevN(lane & 7, 3) : bitrevN(lane & 15, 4);   // the output sample (pair) this lane overlaps
+
+        // a tail handed in by the caller (DCS_PREV_EXT, streaming use): requested before the transform, so that the
+        // overlap below never waits for memory
+        uint32_t extTail = 0;
+        if (__any(active && (myFlags & DCS_SLOT_EXT_TAIL) != 0))
+        {
+            if (active && (myFlags & DCS_SLOT_EXT_TAIL) != 0 && a.tailsIn != nullptr)
+            {
+                const size_t k = static_cast<size_t>(myPrevJob & 0x7FFFFFFFu);
+                extTail = (xf == DCS_XFORM_94) ? reinterpret_cast<const uint32_t *>(a.tailsIn)[k * 8 + lr]
+                                               : static_cast<uint32_t>(static_cast<uint16_t>(a.tailsIn[k * 16 + lr]));
+            }
+        }
 
         // lane groups beyond the pass's frames run the same instruction stream on a dummy row (the bit
         // pool is dead in phase 2) and store nothing
@@ -1533,21 +1547,21 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
             transform93x4(P, W, C, R, x);
         if (s0 == 0) DCS_STAMP(14);
 
-        // tail for the successor = output samples 240..255 (:569-575, :805-812): register 15 of every lane
-        if (active)
+        // tail for the successor = output samples 240..255 (:569-575, :805-812): register 15 of every lane.  Lane
+        // groups without a frame write to a spare row of the tail array.
         {
+            const int ts = active ? mySlot : FPW;
             if (xf == DCS_XFORM_94)
-                tails[mySlot * 8 + bitrevN(P.l, 3)] = x[15];
+                tails[ts * 8 + lr] = x[15];
             else
-                reinterpret_cast<uint16_t *>(tails)[mySlot * 16 + bitrevN(P.l, 4)] = static_cast<uint16_t>(x[15]);
+                reinterpret_cast<uint16_t *>(tails)[ts * 16 + lr] = static_cast<uint16_t>(x[15]);
         }
         // ... and, for the last frame of a chunk whose successor lies in a later chunk, in the hand-off buffer: the
         // payload travels inside the same 64-bit word as the launch's epoch, so no fence or flag is needed
         if (active && (myFlags & DCS_SLOT_EXPORT))
         {
-            const int k = (xf == DCS_XFORM_94) ? bitrevN(P.l, 3) : bitrevN(P.l, 4);
             const uint32_t payload = (xf == DCS_XFORM_94) ? x[15] : (x[15] & 0xFFFFu);
-            __hip_atomic_store(a.handoff + static_cast<size_t>(chunk) * 16 + k,
+            __hip_atomic_store(a.handoff + static_cast<size_t>(chunk) * 16 + lr,
                                (static_cast<unsigned long long>(a.epoch) << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         waveSync();
@@ -1559,59 +1573,44 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 3) dcsDecodeKernel(const 
         // instead would chain the chunks of a stream one behind the other (this chunk's LAST frame, which the next
         // chunk waits for, is transformed in a later pass).
         const bool deferred = active && (myFlags & DCS_SLOT_IMPORT) != 0;
+        const bool hasPrev = myPrevSlot != DCS_NO_PREV_SLOT;
+        // everybody stashes (only a deferred frame's row is read again; the row is dead otherwise)
+        P.rowC[lr] = x[0];
         if (xf == DCS_XFORM_94)
         {
             // overlap-add on sample pair m = bitrev3(l) (register 0) (:538-555)
-            const int m = bitrevN(P.l, 3);
-            uint32_t tailPair = 0;
-            if (myFlags & DCS_SLOT_EXT_TAIL)
-            {
-                if (a.tailsIn != nullptr)
-                    tailPair = reinterpret_cast<const uint32_t *>(a.tailsIn)[static_cast<size_t>(myPrevJob & 0x7FFFFFFFu) * 8 + m];
-            }
-            else if (myPrevSlot != DCS_NO_PREV_SLOT)
-                tailPair = tails[myPrevSlot * 8 + m];
-            if (deferred)
-                P.rowC[m] = x[0];
+            uint32_t tailPair = tails[(hasPrev ? myPrevSlot : mySlot) * 8 + lr];
+            tailPair = hasPrev ? tailPair : extTail;
             x[0] = packC(overlapMix(reC(x[0]), C.k[DCS_K94_OVLA] & 0xFFFFu, reC(tailPair), C.k[DCS_K94_OVLB] & 0xFFFFu),
                          overlapMix(imC(x[0]), C.k[DCS_K94_OVLA] >> 16, imC(tailPair), C.k[DCS_K94_OVLB] >> 16));
             if (emit)
             {
-                uint32_t *out = reinterpret_cast<uint32_t *>(a.pcm) + static_cast<size_t>(myJob) * (DCS_FRAME_SAMPLES / 2);
+                uint32_t *out = reinterpret_cast<uint32_t *>(a.pcm) + static_cast<size_t>(myJob) * (DCS_FRAME_SAMPLES / 2) + lr;
                 if (!deferred)
-                    out[m] = x[0];
+                    out[0] = x[0];
 #pragma unroll
                 for (int r = 1 ; r < 15 ; ++r)
-                    out[8 * bitrevN(r, 4) + m] = x[r];                 // pair 8*bitrev4(r) + bitrev3(l)
+                    out[8 * bitrevN(r, 4)] = x[r];                      // pair 8*bitrev4(r) + bitrev3(l)
                 if (a.tailsOut != nullptr)
-                    reinterpret_cast<uint32_t *>(a.tailsOut)[static_cast<size_t>(myJob) * 8 + m] = x[15];
+                    reinterpret_cast<uint32_t *>(a.tailsOut)[static_cast<size_t>(myJob) * 8 + lr] = x[15];
             }
         }
         else
         {
             // overlap-add on sample i = bitrev4(l) (register 0) (:789-802)
-            const int i = bitrevN(P.l, 4);
-            int tailSample = 0;
-            if (myFlags & DCS_SLOT_EXT_TAIL)
-            {
-                if (a.tailsIn != nullptr)
-                    tailSample = a.tailsIn[static_cast<size_t>(myPrevJob & 0x7FFFFFFFu) * 16 + i];
-            }
-            else if (myPrevSlot != DCS_NO_PREV_SLOT)
-                tailSample = static_cast<int16_t>(reinterpret_cast<const uint16_t *>(tails)[myPrevSlot * 16 + i]);
-            if (deferred)
-                P.rowC[i] = x[0];
+            int tailSample = static_cast<int16_t>(reinterpret_cast<const uint16_t *>(tails)[(hasPrev ? myPrevSlot : mySlot) * 16 + lr]);
+            tailSample = hasPrev ? tailSample : sx16(extTail);
             x[0] = static_cast<uint32_t>(overlapMix(reC(x[0]), C.k[DCS_K93_OVL] & 0xFFFFu, tailSample, C.k[DCS_K93_OVL] >> 16)) & 0xFFFFu;
             if (emit)
             {
-                int16_t *out = a.pcm + static_cast<size_t>(myJob) * DCS_FRAME_SAMPLES;
+                int16_t *out = a.pcm + static_cast<size_t>(myJob) * DCS_FRAME_SAMPLES + lr;
                 if (!deferred)
-                    out[i] = static_cast<int16_t>(x[0]);
+                    out[0] = static_cast<int16_t>(x[0]);
 #pragma unroll
                 for (int r = 1 ; r < 15 ; ++r)
-                    out[16 * bitrevN(r, 4) + i] = static_cast<int16_t>(x[r]);      // sample 16*bitrev4(r) + bitrev4(l)
+                    out[16 * bitrevN(r, 4)] = static_cast<int16_t>(x[r]);          // sample 16*bitrev4(r) + bitrev4(l)
                 if (a.tailsOut != nullptr)
-                    a.tailsOut[static_cast<size_t>(myJob) * 16 + i] = static_cast<int16_t>(x[15]);
+                    a.tailsOut[static_cast<size_t>(myJob) * 16 + lr] = static_cast<int16_t>(x[15]);
             }
         }
         waveSync();
