@@ -210,16 +210,16 @@ extern "C" DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable)
     return DCS_OK;
 }
 
-// frames per wavefront.  Four lanes unpack one frame, so 16 frames fill the 64 lanes; small batches
-// use 8 or 4 frames per wavefront: more wavefronts, and a shorter serial path in each.
+// frames per wavefront (16, 8 or 4 lanes unpack one frame together for 4, 8, 16 frames per wavefront).  Measured
+// (tools/sweep_fpw.sh): 4 while the batch fits on the chip in one round of four wavefronts per SIMD (shortest serial
+// path per wavefront); 8 up to about 200 frames per SIMD (four wavefronts per SIMD, full rounds); beyond that 16,
+// which needs the fewest instructions per frame but fits only three wavefronts per SIMD (LDS).
 static int chooseFpw(const DcsCtx *ctx, uint32_t nJobs)
 {
     if (ctx->fpwOverride != 0)
         return ctx->fpwOverride;
     const uint64_t simds = static_cast<uint64_t>(ctx->numCUs) * 4;
-    // measured (tools/fpw_sweep.py): while every wavefront of the batch fits on the chip at once (3 per SIMD),
-    // fewer frames per wavefront = more lanes per frame = shorter chains; past that, fewer, fuller wavefronts win
-    return nJobs >= simds * 40 ? 16 : nJobs >= simds * 10 ? 8 : 4;
+    return nJobs > simds * 192 ? 16 : nJobs > simds * 16 ? 8 : 4;
 }
 
 extern "C" void dcs_batch_destroy(DcsBatch *b)
