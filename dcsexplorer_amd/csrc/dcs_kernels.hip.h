@@ -245,9 +245,13 @@ __device__ __forceinline__ void mixSub(uint16_t *cell, int scaledProduct, uint32
     *cell = static_cast<uint16_t>(*cell - c);
 }
 
-__device__ __forceinline__ uint32_t scaleFactor(const DcsLdsTables *T, int code)
+// scale factor of a band (:1978-1979, :2342): mantissa {0x8000, 0x9838, 0xB505, 0xD745}[code & 3] >> (15 - ((code >> 2) & 15)).
+// The four mantissas come out of two register constants (no table read on the band set-up's critical path).
+__device__ __forceinline__ uint32_t scaleFactor(const DcsLdsTables *, int code)
 {
-    return static_cast<uint32_t>(T->scaleMant[code & 3]) >> (15 - ((code >> 2) & 15));
+    const uint32_t pair = (code & 2) ? 0xD745B505u : 0x98388000u;
+    const uint32_t mant = (code & 1) ? pair >> 16 : pair & 0xFFFFu;
+    return mant >> (15 - ((code >> 2) & 15));
 }
 
 __device__ __forceinline__ void dcFixup(uint16_t *row, uint32_t saved1)
@@ -1466,9 +1470,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
 
         DCS_STAMP(4);
         // a frame's error bits = OR over its sub-lanes
+        if (__any(err != 0))            // (rare: skip the exchange when no lane of the wavefront has anything to report)
+        {
 #pragma unroll
-        for (int m = FPW ; m < 64 ; m <<= 1)
-            err |= __shfl_xor(err, m);
+            for (int m = FPW ; m < 64 ; m <<= 1)
+                err |= __shfl_xor(err, m);
+        }
         if (live && q == 0)
         {
             if (job.xform == DCS_XFORM_93)

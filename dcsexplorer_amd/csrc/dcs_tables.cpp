@@ -129,6 +129,9 @@ DcsDevTables build()
     for (int i = 0 ; i < 18 ; ++i)
         t.lds.inputs93a[i] = kInputsPerBand93a[i];
     memcpy(t.lds.scaleMant, kScaleMant, sizeof(t.lds.scaleMant));
+    // the kernel's scaleFactor() carries the four mantissas as register constants
+    if (kScaleMant[0] != 0x8000 || kScaleMant[1] != 0x9838 || kScaleMant[2] != 0xB505 || kScaleMant[3] != 0xD745)
+        abort();
     memcpy(t.pair93a, kPair93a, sizeof(t.pair93a));
     memcpy(t.fftCoef, kFftCoef, sizeof(t.fftCoef));
     // the kernel's multiplier-free butterflies (bflyIdx) rely on these exact twiddles: (-1.0, 0) and (0, -1.0)
