@@ -142,12 +142,46 @@ struct DcsSlot                          // 32 bytes: everything the kernel needs
     uint16_t runPoolOff;                // pool dword where run k goes (a multiple of 4)
 };
 
+// Chunk packages.  Everything unpack round 0 of a chunk needs, gathered once per batch by dcsPackKernel into one
+// block at a fixed stride, so that a wavefront requests ALL of it at its first instruction (no load depends on
+// another load):  slots [fpw] (32 B) | descriptor heads [fpw] (first 40 bytes of DcsSrcDesc, padded to 48) |
+// stream headers [fpw] (16 B, already aligned; a 1-byte header zero-extended) | the split record of every lane [64]
+// (8 B; zero for a frame's first lane) | the image of the bit pool (runs placed, dwords in bit order).
+#ifdef __cplusplus
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr uint32_t dcsPkgOffDesc(int fpw) { return static_cast<uint32_t>(fpw) * 32u; }
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr uint32_t dcsPkgOffHdr(int fpw) { return static_cast<uint32_t>(fpw) * 80u; }
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr uint32_t dcsPkgOffSplit(int fpw) { return static_cast<uint32_t>(fpw) * 96u; }
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr uint32_t dcsPkgOffPool(int fpw) { return static_cast<uint32_t>(fpw) * 96u + 512u; }
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr uint32_t dcsPkgBytes(int fpw) { return dcsPkgOffPool(fpw) + dcsPoolCapacity(fpw) * 4u; }
+#endif
+
 struct DcsKernelArgs
 {
     const uint8_t      *blob;
     uint64_t            blobLen;        // bytes that may be read (allocation is padded beyond this)
     const DcsSrcDesc   *srcs;
-    const DcsSlot      *slots;          // nChunks x fpw
+    const DcsSlot      *slots;          // nChunks x fpw (read by the pack kernel only)
+    uint8_t            *packages;       // nChunks x dcsPkgBytes(fpw), see above
     uint32_t            nChunks;
     uint32_t            nJobs;
     int16_t            *pcm;            // nJobs x 240

@@ -1146,6 +1146,74 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const TwA &W, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// dcsPackKernel: builds the chunk packages (dcs_common.h) once per batch, one wavefront per chunk.  A layout
+// change only -- slots, descriptor heads, headers, split records and compressed bytes are copied next to
+// each other, the compressed dwords swapped into bit order on the way; nothing is decoded here.
+// ------------------------------------------------------------------------------------------------
+template <int FPW>
+__global__ void __launch_bounds__(64) dcsPackKernel(const DcsKernelArgs a)
+{
+    const uint32_t chunk = blockIdx.x;
+    const int lane = static_cast<int>(threadIdx.x);
+    if (chunk >= a.nChunks)
+        return;
+    constexpr int SUB = subLanes(FPW);
+    const int s = lane % FPW, q = lane / FPW;
+    uint8_t *pkg = a.packages + static_cast<size_t>(chunk) * dcsPkgBytes(FPW);
+    const DcsSlot *slots = a.slots + static_cast<size_t>(chunk) * FPW;
+    const DcsSlot sl = slots[s];
+    const uint32_t *blobW = reinterpret_cast<const uint32_t *>(a.blob);
+    const uint32_t blobWords = static_cast<uint32_t>((a.blobLen + 3) >> 2);
+    const bool has = !(sl.flags & DCS_SLOT_EMPTY) && sl.nSrc != 0;
+
+    if (lane < FPW * 2)
+        reinterpret_cast<uint4 *>(pkg)[lane] = reinterpret_cast<const uint4 *>(slots)[lane];
+    const uint32_t *sd = reinterpret_cast<const uint32_t *>(&a.srcs[has ? sl.firstSrc : 0]);
+    if (q == 0)
+    {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffDesc(FPW)) + s * 12;
+        for (int i = 0 ; i < 12 ; ++i)
+            dst[i] = (has && i < 10) ? sd[i] : 0u;
+        // the 16 header bytes at streamOff + 2 (a 1-byte header: the byte alone)
+        uint32_t *hd = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffHdr(FPW)) + s * 4;
+        uint32_t w[5] = { 0, 0, 0, 0, 0 };
+        if (has)
+            for (int i = 0 ; i < 5 ; ++i)
+                w[i] = sl.hdrDw + i < blobWords ? blobW[sl.hdrDw + i] : 0u;
+        const bool oneByte = has && (sd[2] >> 24) == 1;
+        for (int i = 0 ; i < 4 ; ++i)
+        {
+            uint32_t v = __builtin_amdgcn_alignbyte(w[i + 1], w[i], static_cast<uint32_t>(sl.hdrSh));
+            if (oneByte)
+                v = i == 0 ? (v & 0xFFu) : 0u;
+            hd[i] = v;
+        }
+    }
+    {
+        // DcsSplit of band q * bpl = split[q * bpl - 1], 8 bytes each from descriptor dword 10
+        uint2 sp = make_uint2(0, 0);
+        const int bpl = sl.bpl;
+        if (has && q != 0 && q < SUB && bpl != 0 && q * bpl < 16)
+            sp = reinterpret_cast<const uint2 *>(sd)[5 + q * bpl - 1];
+        reinterpret_cast<uint2 *>(pkg + dcsPkgOffSplit(FPW))[lane] = sp;
+    }
+    uint32_t *img = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffPool(FPW));
+    for (int i = lane ; i < poolDwords(FPW) ; i += 64)
+        img[i] = 0u;
+    __syncthreads();
+    for (int k = 0 ; k < FPW ; ++k)
+    {
+        const uint32_t n = slots[k].runNDw, st = slots[k].runStartDw, o = slots[k].runPoolOff;
+        if (n == 0)
+            break;
+        if (o + n > static_cast<uint32_t>(poolDwords(FPW)))
+            continue;                                       // cannot happen with the library's planner
+        for (uint32_t i = static_cast<uint32_t>(lane) ; i < n ; i += 64)
+            img[o + i] = st + i < blobWords ? __builtin_bswap32(blobW[st + i]) : 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
 template <int FPW>
@@ -1171,26 +1239,35 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
     const int q = lane / FPW;                       // which part of the frame it unpacks
     const bool unpacker = q < SUB;
 
-    // this lane's slot record: requested first, so that the load is in flight while the tables are staged
-    // (all sub-lanes of a slot hold the same copy; padding wavefronts of the last workgroup read slot 0)
-    struct { uint32_t job; uint32_t prevSlot, flags, nSrc, shiftXform; uint32_t firstSrc, prevJob, runStartDw, runNDw, poolOff, hdrDw, hdrSh, bpl, runPoolOff; } slot;
+    // ---- everything unpack round 0 needs comes from the chunk's package (dcs_common.h): slot, descriptor head, stream
+    // header, this lane's split record, the pool image.  All of it is requested here, before anything else, in one
+    // go; the padding wavefronts of the last workgroup read package 0 and drop out after the barrier.
+    const uint8_t *pkg = a.packages + (chunk < a.nChunks ? static_cast<size_t>(chunk) * dcsPkgBytes(FPW) : 0);
+    struct { uint32_t job; uint32_t prevSlot, flags, nSrc, shiftXform; uint32_t firstSrc, prevJob, poolOff, bpl; } slot;
+    uint4 pd0, pd1, phdr;
+    uint2 pd2, psplit;
+    constexpr int kPoolPieces = (poolDwords(FPW) + 255) / 256;
+    uint4 pimg[kPoolPieces];
     {
-        // two 16-byte loads (DcsSlot is 32 bytes and the array 32-byte aligned), fields picked apart in registers
         static_assert(sizeof(DcsSlot) == 32 && offsetof(DcsSlot, runStartDw) == 16 && offsetof(DcsSlot, hdrDw) == 24, "DcsSlot layout");
-        const uint4 *sp4 = reinterpret_cast<const uint4 *>(a.slots + (chunk < a.nChunks ? static_cast<size_t>(chunk) * FPW + s : 0));
+        const uint4 *sp4 = reinterpret_cast<const uint4 *>(pkg) + 2 * s;
         const uint4 s0 = sp4[0], s1 = sp4[1];
+        const uint4 *dp = reinterpret_cast<const uint4 *>(pkg + dcsPkgOffDesc(FPW)) + 3 * s;
+        pd0 = dp[0]; pd1 = dp[1]; pd2 = *reinterpret_cast<const uint2 *>(dp + 2);
+        phdr = reinterpret_cast<const uint4 *>(pkg + dcsPkgOffHdr(FPW))[s];
+        psplit = reinterpret_cast<const uint2 *>(pkg + dcsPkgOffSplit(FPW))[lane];
+#pragma unroll
+        for (int t = 0 ; t < kPoolPieces ; ++t)
+        {
+            const int i = lane * 4 + 256 * t;
+            pimg[t] = i < poolDwords(FPW) ? *reinterpret_cast<const uint4 *>(pkg + dcsPkgOffPool(FPW) + i * 4) : make_uint4(0, 0, 0, 0);
+        }
         slot.job = s0.x;
         slot.prevSlot = s0.y & 0xFFu; slot.flags = (s0.y >> 8) & 0xFFu; slot.nSrc = (s0.y >> 16) & 0xFFu; slot.shiftXform = s0.y >> 24;
         slot.firstSrc = s0.z; slot.prevJob = s0.w;
-        slot.runStartDw = s1.x; slot.runNDw = s1.y & 0xFFFFu; slot.poolOff = s1.y >> 16;
-        slot.hdrDw = s1.z; slot.hdrSh = s1.w & 0xFFu; slot.bpl = (s1.w >> 8) & 0xFFu; slot.runPoolOff = s1.w >> 16;
+        slot.poolOff = s1.y >> 16;
+        slot.bpl = (s1.w >> 8) & 0xFFu;
     }
-
-    // the lane's transform constants for the chunk's first frame (the whole chunk, normally): requested now, needed in
-    // phase 2 (24 registers live through phase 1 buy a memory round trip at the start of phase 2)
-    int constsXform = __builtin_amdgcn_readfirstlane(static_cast<int>(slot.shiftXform >> 4)) == DCS_XFORM_94 ? DCS_XFORM_94 : DCS_XFORM_93;
-    LaneConsts C;
-    loadLaneConsts(a.tables, lane, constsXform, C);
     TwA W;
     loadTwA(a.tables, W);
 
@@ -1209,6 +1286,20 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
         return;                                     // padding wavefront of the last workgroup
 
     DCS_STAMP(1);
+
+    // the lane's transform constants for the chunk's first frame (the whole chunk, normally): requested now, needed in
+    // phase 2
+    int constsXform = __builtin_amdgcn_readfirstlane(static_cast<int>(slot.shiftXform >> 4)) == DCS_XFORM_94 ? DCS_XFORM_94 : DCS_XFORM_93;
+    LaneConsts C;
+    loadLaneConsts(a.tables, lane, constsXform, C);
+    // the bit pool of round 0: a straight copy of the package's image
+#pragma unroll
+    for (int t = 0 ; t < kPoolPieces ; ++t)
+    {
+        const int i = lane * 4 + 256 * t;
+        if (i < poolDwords(FPW))
+            ldsWrite4(L.pool() + i, pimg[t].x, pimg[t].y, pimg[t].z, pimg[t].w);
+    }
 
     // ---- job of this lane's slot ---------------------------------------------------------------------------
     const bool live = !(slot.flags & DCS_SLOT_EMPTY);
@@ -1238,22 +1329,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
             const uint4 *sdp = reinterpret_cast<const uint4 *>(&a.srcs[has ? job.firstSrc + r : 0]);
             uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0;
             uint2 d2 = make_uint2(0, 0);
-            if (has) { d0 = sdp[0]; d1 = sdp[1]; d2 = *reinterpret_cast<const uint2 *>(sdp + 2); }
-            uint32_t hdrW[5] = { 0, 0, 0, 0, 0 };
             uint2 sp = make_uint2(0, 0);
             const int bplSlot = slot.bpl;
             if (R0)
             {
-                if (has && slot.hdrDw <= blobWords)             // (18 header bytes lie inside the blob: validated on the host)
-                {
-                    const u32x4a4 h = *reinterpret_cast<const u32x4a4 *>(blobW + slot.hdrDw);
-                    hdrW[0] = h.x; hdrW[1] = h.y; hdrW[2] = h.z; hdrW[3] = h.w;
-                    hdrW[4] = blobW[slot.hdrDw + 4];
-                }
-                // DcsSplit of band q * bpl = split[q * bpl - 1], 8 bytes each from descriptor dword 10
-                if (has && q != 0 && bplSlot != 0 && q * bplSlot < 16)
-                    sp = reinterpret_cast<const uint2 *>(sdp)[5 + q * bplSlot - 1];
+                if (has) { d0 = pd0; d1 = pd1; d2 = pd2; sp = psplit; }
             }
+            else if (has) { d0 = sdp[0]; d1 = sdp[1]; d2 = *reinterpret_cast<const uint2 *>(sdp + 2); }
             // DcsSrcDesc: [0] streamOff lo, [1] streamOff hi, [2] mixMul | format<<16 | hdrLen<<24,
             // idx at byte 12: [3] bitOff, [4] nBits | hdrBits<<16, [5..8] bandType, [9] preAdj | nBands<<16 | flags<<24,
             // [10..39] split[15], two dwords each
@@ -1278,41 +1360,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
             bool fits;
             if (R0)
             {
-                // the planner's runs (DcsSlot): 16 bytes per lane and instruction.  The blob allocation is
-                // zero-padded by 64 bytes, which covers the window look-ahead behind the last frame.
-                constexpr int kPieces = (poolDwords(FPW) + 255) / 256;
+                // (the pool was filled from the package's image)
                 off = min(static_cast<uint32_t>(slot.poolOff), static_cast<uint32_t>(poolDwords(FPW) - 1));
                 fits = true;
-                const uint32_t runN = (q == 0) ? static_cast<uint32_t>(slot.runNDw) : 0u;
-#pragma unroll 1
-                for (int k = 0 ; k < FPW ; ++k)
-                {
-                    const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(runN), k));
-                    if (n == 0)
-                        break;
-                    const uint32_t st = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(slot.runStartDw), k));
-                    const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(slot.runPoolOff), k));
-                    if ((o & 3u) != 0 || o + n > static_cast<uint32_t>(poolDwords(FPW)))
-                        continue;                                           // cannot happen with the library's planner
-                    u32x4a4 v[kPieces];
-#pragma unroll
-                    for (int t = 0 ; t < kPieces ; ++t)
-                    {
-                        const uint32_t i = static_cast<uint32_t>(lane) * 4 + 256u * t;
-                        const uint32_t w = st + i;
-                        v[t] = u32x4a4{ 0, 0, 0, 0 };
-                        if (i < n && w + 4 <= blobWords + 16 && w + 4 > w)
-                            v[t] = *reinterpret_cast<const u32x4a4 *>(blobW + w);
-                    }
-#pragma unroll
-                    for (int t = 0 ; t < kPieces ; ++t)
-                    {
-                        const uint32_t i = static_cast<uint32_t>(lane) * 4 + 256u * t;
-                        if (i < n)
-                            ldsWrite4(pool + o + i, __builtin_bswap32(v[t].x), __builtin_bswap32(v[t].y),
-                                      __builtin_bswap32(v[t].z), __builtin_bswap32(v[t].w));
-                    }
-                }
             }
             else
             {
@@ -1373,17 +1423,19 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
             }
 
             if (R0) DCS_STAMP(2);
-            // the stream header: 16 bytes at streamOff + 2, via aligned dwords
+            // the stream header: 16 bytes at streamOff + 2 (round 0: from the package, aligned and masked there)
+            if (R0)
             {
-                uint32_t sh = slot.hdrSh;
-                if (!R0)
-                {
-                    const uint32_t hw = static_cast<uint32_t>((streamOff + 2) >> 2);
-                    sh = static_cast<uint32_t>((streamOff + 2) & 3);
+                Q.h0 = has ? phdr.x : 0u; Q.h1 = has ? phdr.y : 0u; Q.h2 = has ? phdr.z : 0u; Q.h3 = has ? phdr.w : 0u;
+            }
+            else
+            {
+                const uint32_t hw = static_cast<uint32_t>((streamOff + 2) >> 2);
+                const uint32_t sh = static_cast<uint32_t>((streamOff + 2) & 3);
+                uint32_t hdrW[5];
 #pragma unroll
-                    for (int i = 0 ; i < 5 ; ++i)
-                        hdrW[i] = (has && hw + i < blobWords) ? blobW[hw + i] : 0u;
-                }
+                for (int i = 0 ; i < 5 ; ++i)
+                    hdrW[i] = (has && hw + i < blobWords) ? blobW[hw + i] : 0u;
                 Q.h0 = __builtin_amdgcn_alignbyte(hdrW[1], hdrW[0], sh);
                 Q.h1 = __builtin_amdgcn_alignbyte(hdrW[2], hdrW[1], sh);
                 Q.h2 = __builtin_amdgcn_alignbyte(hdrW[3], hdrW[2], sh);

@@ -87,8 +87,9 @@ struct DcsBatch
     int16_t *dTailsOut = nullptr;
     unsigned long long *dDebug = nullptr;   // DCS_STAMPS builds only
     unsigned long long *dHandoff = nullptr; // nChunks x 16 words (DcsKernelArgs.handoff)
+    uint8_t *dPackages = nullptr;           // nChunks x dcsPkgBytes(fpw) (DcsKernelArgs.packages)
     uint32_t epoch = 0;                     // launches of this batch so far
-    size_t cap[9] = { 0 };                  // allocated bytes of the buffers above, in that order
+    size_t cap[10] = { 0 };                 // allocated bytes of the buffers above, in that order
     // pinned host mirror of (pcm, err), filled by dcs_batch_download_view
     int16_t *hPcm = nullptr;
     uint32_t *hErr = nullptr;
@@ -228,14 +229,44 @@ extern "C" void dcs_batch_destroy(DcsBatch *b)
         return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);         // nothing of this batch is in flight when its buffers are recycled
-    void *ptrs[] = { b->dBlob, b->dSrcs, b->dSlots, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug, b->dHandoff };
-    for (int i = 0 ; i < 9 ; ++i)
+    void *ptrs[] = { b->dBlob, b->dSrcs, b->dSlots, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug, b->dHandoff, b->dPackages };
+    for (int i = 0 ; i < 10 ; ++i)
         cacheFree(b->ctx, false, ptrs[i], b->cap[i]);
     cacheFree(b->ctx, true, b->hPcm, b->hCap[0]);
     cacheFree(b->ctx, true, b->hErr, b->hCap[1]);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     delete b;
+}
+
+static DcsKernelArgs kernelArgs(const DcsBatch *b)
+{
+    DcsKernelArgs args;
+    args.blob = b->dBlob;
+    args.blobLen = b->blobLen;
+    args.srcs = b->dSrcs;
+    args.slots = b->dSlots;
+    args.packages = b->dPackages;
+    args.nChunks = b->nChunks;
+    args.nJobs = b->nJobs;
+    args.pcm = b->dPcm;
+    args.err = b->dErr;
+    args.tailsIn = b->dTailsIn;
+    args.tailsOut = b->dTailsOut;
+    args.tables = b->ctx->dTables;
+    args.debug = b->dDebug;
+    args.handoff = b->dHandoff;
+    args.epoch = b->epoch;
+    return args;
+}
+
+// once per batch: gather what unpack round 0 of every chunk needs into the chunk packages (a layout change on the
+// device; nothing is decoded)
+template <int FPW>
+static hipError_t launchPack(const DcsKernelArgs &args, hipStream_t stream)
+{
+    dcsk::dcsPackKernel<FPW><<<dim3(args.nChunks), dim3(64), 0, stream>>>(args);
+    return hipGetLastError();
 }
 
 extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
@@ -335,6 +366,11 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
         b->cap[7] = sizeof(unsigned long long) * 16 * (b->nChunks + 4); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dDebug), b->cap[7]));
         HIPCHK(ctx, hipMemsetAsync(b->dDebug, 0, sizeof(unsigned long long) * 16 * (b->nChunks + 4), ctx->stream));
 #endif
+        b->cap[9] = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPackages), b->cap[9]));
+        {
+            const DcsKernelArgs args = kernelArgs(b);
+            HIPCHK(ctx, b->fpw == 16 ? launchPack<16>(args, ctx->stream) : b->fpw == 8 ? launchPack<8>(args, ctx->stream) : launchPack<4>(args, ctx->stream));
+        }
         HIPCHK(ctx, hipEventCreate(&b->ev0));
         HIPCHK(ctx, hipEventCreate(&b->ev1));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -365,23 +401,9 @@ extern "C" DcsStatus dcs_batch_run(DcsBatch *b, void *hipStream)
         return DCS_ERR_INVALID_ARG;
     DcsCtx *ctx = b->ctx;
     hipStream_t stream = hipStream ? static_cast<hipStream_t>(hipStream) : ctx->stream;
-    DcsKernelArgs args;
-    args.blob = b->dBlob;
-    args.blobLen = b->blobLen;
-    args.srcs = b->dSrcs;
-    args.slots = b->dSlots;
-    args.nChunks = b->nChunks;
-    args.nJobs = b->nJobs;
-    args.pcm = b->dPcm;
-    args.err = b->dErr;
-    args.tailsIn = b->dTailsIn;
-    args.tailsOut = b->dTailsOut;
-    args.tables = ctx->dTables;
-    args.debug = b->dDebug;
-    args.handoff = b->dHandoff;
     if (++b->epoch == 0)
         b->epoch = 1;                   // 0 marks words no launch has written
-    args.epoch = b->epoch;
+    const DcsKernelArgs args = kernelArgs(b);
     hipError_t e;
     e = (b->fpw == 16) ? launch<16>(args, stream) : (b->fpw == 8) ? launch<8>(args, stream) : launch<4>(args, stream);
     if (e != hipSuccess)
