@@ -194,7 +194,9 @@ struct DcsKernelArgs
     // when its epoch equals `epoch` (the batch's launch counter, never 0), so the buffer is never cleared
     unsigned long long *handoff;
     uint32_t            epoch;
+    uint32_t            flags;          // DCS_BATCH_*
 };
+#define DCS_BATCH_HAS_93A_T1 1u         // some source is an OS93a Type-1 frame: workgroups stage the pair table in LDS
 
 // planner: returns the number of chunks; slots is resized to nChunks * fpw
 #ifdef __cplusplus

@@ -54,9 +54,11 @@ __host__ __device__ constexpr int subLanes(int fpw) { return 64 / fpw; }     // 
 __host__ __device__ constexpr int waveLdsBytes(int fpw) { return fpw * kRowBytes + (fpw + 1) * 32 + poolDwords(fpw) * 4; }
 // workgroup layout: tables | the four wavefronts' bit pools | the four wavefronts' (tile rows, tails).  The pools
 // come first on purpose, see BitReader.
+// ... | OS93a Type-1 pair table (4 KB; only where it fits next to three more workgroups: 4 and 8 frames per wavefront)
+__host__ __device__ constexpr bool pairTableInLds(int fpw) { return fpw <= 8; }
 __host__ __device__ constexpr int ldsBytes(int fpw)
 {
-    return static_cast<int>(sizeof(DcsLdsTables)) + kWavesPerBlock * waveLdsBytes(fpw);
+    return static_cast<int>(sizeof(DcsLdsTables)) + kWavesPerBlock * waveLdsBytes(fpw) + (pairTableInLds(fpw) ? 4096 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -611,8 +613,9 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
 // [bandBase, bandEnd); what it needs from the bands before it -- the previous scale code and whether the
 // frame already ended -- comes from the split record.
 // ------------------------------------------------------------------------------------------------
-__device__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *row, BitReader &br, int hb, uint32_t mixMul,
-                              const uint16_t *pairTable, int bandBase, int bandEnd, int prvScale, int outIdx)
+template <bool FIRST, class PairPtr>
+__device__ __forceinline__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *row, BitReader &br, int hb, uint32_t mixMul,
+                                              PairPtr pairTable, int bandBase, int bandEnd, int prvScale, int outIdx)
 {
     const uint16_t *bbBook = &T->bandBits93a[(hb & 0x60) >> 1];
     uint32_t err = 0;
@@ -653,15 +656,17 @@ __device__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *row, BitReader &b
         sf = ((sf >> 16) * mixMul) >> 15;
         const int sfs = sx16(sf);                   // truncated to 16 bits, then read as signed (:2995, :3011)
 
-        const uint16_t *pairBase = pairTable + (2 << bandBits);
+        const auto pairBase = pairTable + (2 << bandBits);
         for (int i = 0 ; i < numInputs ; ++i)
         {
-            const uint16_t *pair = pairBase + 2 * br.get(bandBits);
+            const auto pair = pairBase + 2 * br.get(bandBits);
             for (int k = 0 ; k < 2 ; ++k, ++outIdx)
             {
                 const int p = mul24(sx16(pair[k]), sfs);
-                uint16_t *cell = &row[outIdx < 256 ? outIdx : kDummyWord];      // (254 words at most with a matching record)
-                *cell = static_cast<uint16_t>(roundHi((static_cast<uint32_t>(*cell) << 16) + (static_cast<uint32_t>(p) << 1), p));
+                uint16_t *cell = &row[min(outIdx, kDummyWord)];                 // (254 words at most with a matching record)
+                // (first source of the frame: the accumulator is still zero, no index is written twice by one source)
+                const uint32_t acc = FIRST ? 0u : static_cast<uint32_t>(*cell) << 16;
+                *cell = static_cast<uint16_t>(roundHi(acc + (static_cast<uint32_t>(p) << 1), p));
             }
         }
     }
@@ -1280,6 +1285,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
         uint4 *tile = reinterpret_cast<uint4 *>(L.base);
         for (int i = lane ; i < FPW * kRowBytes / 16 ; i += 64)
             tile[i] = make_uint4(0, 0, 0, 0);
+        // batches with OS93a Type-1 frames: the 4 KB sample-pair table, one 16-byte piece per thread
+        if (pairTableInLds(FPW) && (a.flags & DCS_BATCH_HAS_93A_T1))
+            reinterpret_cast<uint4 *>(smem + ldsBytes(FPW) - 4096)[threadIdx.x] = reinterpret_cast<const uint4 *>(a.tables->pair93a)[threadIdx.x];
     }
     __syncthreads();                                // the only workgroup barrier: tables are in place
     if (chunk >= a.nChunks)
@@ -1503,9 +1511,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
             if (is93a)
             {
                 const int end = Q.bandBase + Q.nb;
-                err |= unpack93a(T, row, br, static_cast<int>(Q.h0 & 0xFFu), mixMul, a.tables->pair93a, Q.bandBase,
-                                 (end >= 16 && nBands > 16) ? nBands : end,
-                                 Q.bandBase == 0 ? 0x1A : sx16(Q.prv), Q.bandBase == 0 ? 0 : Q.outIdx);
+                const int end2 = (end >= 16 && nBands > 16) ? nBands : end;
+                const int prv0 = Q.bandBase == 0 ? 0x1A : sx16(Q.prv), out0 = Q.bandBase == 0 ? 0 : Q.outIdx;
+                if (pairTableInLds(FPW))
+                    err |= unpack93a<R0>(T, row, br, static_cast<int>(Q.h0 & 0xFFu), mixMul,
+                                         reinterpret_cast<const uint16_t *>(smem + ldsBytes(FPW) - 4096), Q.bandBase, end2, prv0, out0);
+                else
+                    err |= unpack93a<R0>(T, row, br, static_cast<int>(Q.h0 & 0xFFu), mixMul, a.tables->pair93a, Q.bandBase, end2, prv0, out0);
             }
             waveSync();
         };

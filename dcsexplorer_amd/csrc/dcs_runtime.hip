@@ -89,6 +89,7 @@ struct DcsBatch
     unsigned long long *dHandoff = nullptr; // nChunks x 16 words (DcsKernelArgs.handoff)
     uint8_t *dPackages = nullptr;           // nChunks x dcsPkgBytes(fpw) (DcsKernelArgs.packages)
     uint32_t epoch = 0;                     // launches of this batch so far
+    uint32_t flags = 0;                     // DCS_BATCH_*
     size_t cap[10] = { 0 };                 // allocated bytes of the buffers above, in that order
     // pinned host mirror of (pcm, err), filled by dcs_batch_download_view
     int16_t *hPcm = nullptr;
@@ -257,6 +258,7 @@ static DcsKernelArgs kernelArgs(const DcsBatch *b)
     args.debug = b->dDebug;
     args.handoff = b->dHandoff;
     args.epoch = b->epoch;
+    args.flags = b->flags;
     return args;
 }
 
@@ -282,6 +284,7 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
 
     // validate the description on the host: the kernel trusts indices and formats
     uint64_t payloadBits = 0;
+    uint32_t batchFlags = 0;
     for (uint32_t j = 0 ; j < nJobs ; ++j)
     {
         const DcsFrameJob &jb = jobs[j];
@@ -320,6 +323,8 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
             return DCS_ERR_INVALID_ARG;
         }
         payloadBits += sd.idx.nBits;
+        if (sd.format == DCS_FMT_93A_T1)
+            batchFlags |= DCS_BATCH_HAS_93A_T1;
     }
 
     DcsBatch *b = new (std::nothrow) DcsBatch;
@@ -328,6 +333,7 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
     b->ctx = ctx;
     b->nJobs = nJobs; b->nSrcs = nSrcs; b->nTailsIn = nTailsIn; b->blobLen = blobLen;
     b->fpw = chooseFpw(ctx, nJobs);
+    b->flags = batchFlags;
 
     std::vector<DcsSlot> slots;
     b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, ctx->handoff);
