@@ -98,7 +98,8 @@ EXPORTS = [
 
 
 def lib_path():
-    return os.path.join(HERE, "libdcs_hip.so")
+    # DCS_HIP_LIB: another build of the same library (kernel A/B comparisons, tools/ab.sh); never a different backend
+    return os.environ.get("DCS_HIP_LIB") or os.path.join(HERE, "libdcs_hip.so")
 
 
 def load_library():
