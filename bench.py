@@ -136,7 +136,7 @@ def main():
         # (tools/prof.sh), committed under profiles/; null when no profile of this workload exists
         traffic, traffic_note, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.scale == 1 and not args.fpw:       # (the committed counters are those of the plain workload)
             t = json.load(open(tpath))
             # the kernel's reads are 16-byte-per-lane loads of the chunk packages, for which FETCH_SIZE reports half
             # the bytes on gfx950 (MI355X_MICROARCH.md, HBM section): doubled here; WRITE_SIZE is exact
