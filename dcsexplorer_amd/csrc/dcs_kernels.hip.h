@@ -108,9 +108,10 @@ __device__ __forceinline__ int calcExp32(uint32_t x)
 // two 32-bit registers (hi:lo), refilled a dword at a time.  Same VALUES as ROMBitPointer
 // (DCSDecoderNative.h:229-289); the reference's byte-granular look-ahead is not observable here.
 // ------------------------------------------------------------------------------------------------
+typedef const uint32_t __attribute__((address_space(3))) *LdsDwordPtr;
 struct BitReader
 {
-    const uint32_t *p;      // pool dword after `nxt`
+    uint32_t pa;            // LDS byte address of the pool dword after `nxt`
     uint32_t hi, lo;        // the window: the next 32 bits of the stream are ({hi,lo} >> negpos) & 0xFFFFFFFF
     uint32_t nxt;           // the pool dword after lo, fetched one refill ahead so that its LDS latency is off
                             // the per-symbol critical path
@@ -125,7 +126,7 @@ struct BitReader
         hi = 0;
         lo = pool[0];
         nxt = pool[1];
-        p = pool + 2;
+        pa = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsDwordPtr)(pool + 2)));
         negpos = 0;
         skip(bitInDword);
     }
@@ -135,7 +136,7 @@ struct BitReader
     // Branch-free advance, n in 0..32.  The pool dword a refill would pull in is read every time (an LDS read costs no
     // VALU issue and its result is only needed when the window actually moves, 32 bits later); symbol loops
     // request it at the top of the iteration with prefetch() so that nothing ever waits for it.
-    __device__ __forceinline__ uint32_t prefetch() const { return *p; }
+    __device__ __forceinline__ uint32_t prefetch() const { return *reinterpret_cast<LdsDwordPtr>(static_cast<uintptr_t>(pa)); }
     __device__ __forceinline__ void skip(int n, uint32_t ahead)
     {
         negpos -= n;
@@ -143,7 +144,9 @@ struct BitReader
         hi = refill ? lo : hi;
         lo = refill ? nxt : lo;
         nxt = refill ? ahead : nxt;
-        p += refill ? 1 : 0;
+        // the address moves on by 4 bytes on a refill: sign bit of negpos, shifted and added in one instruction
+        const uint32_t sign = static_cast<uint32_t>(negpos) >> 31;
+        asm("v_lshl_add_u32 %0, %1, 2, %0" : "+v"(pa) : "v"(sign));
         negpos &= 31;
     }
     __device__ __forceinline__ void skip(int n) { skip(n, prefetch()); }
@@ -562,9 +565,9 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         {
             const uint32_t ahead = br.prefetch();
             const uint32_t w = br.cur() & wMask;
-            br.skip(2 * width, ahead);
             sample(static_cast<uint32_t>(static_cast<int>(w) >> shW));
             sample(static_cast<uint32_t>(static_cast<int>(w << width) >> shW));
+            br.skip(2 * width, ahead);          // last: the prefetched dword has had the whole iteration to arrive
         }
         if (__any(i < nS))
         {
