@@ -301,68 +301,42 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
     {
         // ---- per-band set-up -------------------------------------------------------------------------
         const int band = Q.bandBase + k;
-        int i = 0;                  // symbols still to decode in this band
-        int inc = 1;
-        bool isRaw = false;         // fixed-width band (sample codes 7..16)
-        int shPeek = 0;             // 32 - look-ahead width (raw: 32 - sample width)
-        int shIdx = 0;              // shift that turns the next 32 bits into the codebook index
-        int scale = 0;
-        const uint16_t *book = T->cb94;
-        if (k < nb)
+        // Straight-line code with selects: every lane computes the set-up of "its" band (lanes without one compute
+        // something harmless and end up with i = 0), the two table reads are independent of each other's wait.
+        const bool act = k < nb;
+        int hb = byteOf(Q.h0, Q.h1, Q.h2, Q.h3, band) & 0x7F;
+        const int count0 = band == 0 ? 7 : band == 1 ? 8 : band == 15 ? 32 : 16;      // :1848-1850
+        const bool strided = (hb & 0x40) != 0;
+        const int inc = strided ? 2 : 1;
+        const int count = strided ? count0 >> 1 : count0;
+        const int code0 = byteOf(Q.t0, Q.t1, Q.t2, Q.t3, band);
+        // Type 1: (band class, code) -> sample code and scale adjustment (:1914-1961)
+        const uint32_t x = T->xlat94[(band < 3 ? 0 : band < 6 ? 16 : 32) + (code0 & 15)];
+        const int pre = band < 3 ? static_cast<int>((Q.preAdj >> (4 * (band & 3))) & 15u) : 0;
+        const bool fatal1 = type1 && code0 > 15;
+        const int code = (type1 && !fatal1) ? static_cast<int>(x & 0xFF) : code0;
+        const int scaleCode = type1 ? hb + pre + static_cast<int>(x >> 8) : hb;
+        const uint32_t info = T->cbInfo[min(code, 7)];
+        const bool zeroBand = code0 == 0;                                   // nothing coded: skip (:1886)
+        const bool fatal = act && !zeroBand && (fatal1 || code > 16);
+        const bool stopBand = act && !zeroBand && !fatal && code == 0;      // :1985-1991
+        const bool isRaw = code > 6;                                         // fixed-width band (sample codes 7..16):
+        // the value is the top `code` bits; its two-entry "codebook" (indexed with one bit) supplies the width and the
+        // step like a real one
+        const int shPeek = 32 - (isRaw ? code : static_cast<int>(info & 0xF));   // 32 - look-ahead (raw: sample) width
+        const int shIdx = isRaw ? 31 : shPeek;                               // turns the next 32 bits into the codebook index
+        const uint16_t *book = isRaw ? T->raw94 + 2 * (min(code, 16) - 7) : T->cb94 + (info >> 4);
+        int scale = static_cast<int>(scaleFactor(T, scaleCode));
+        int i = (act && !zeroBand && !fatal && !stopBand) ? count : 0;       // symbols still to decode in this band
+        outIdx += !act ? 0 : zeroBand ? count /* the halved count, not count*inc */ : stopBand ? count * inc : 0;
+        if (fatal)
         {
-            int hb = byteOf(Q.h0, Q.h1, Q.h2, Q.h3, band) & 0x7F;
-            int count = band == 0 ? 7 : band == 1 ? 8 : band == 15 ? 32 : 16;      // :1848-1850
-            if (hb & 0x40) { inc = 2; count >>= 1; }
-            int code = byteOf(Q.t0, Q.t1, Q.t2, Q.t3, band);
-            if (code == 0)
-                outIdx += count;                    // the halved count, not count*inc (:1886)
-            else
-            {
-                int scaleCode = hb;
-                bool fatal = false;
-                if (type1)
-                {
-                    fatal = code > 15;
-                    const uint32_t x = T->xlat94[(band < 3 ? 0 : band < 6 ? 16 : 32) + (code & 15)];
-                    if (band < 3)
-                        hb += static_cast<int>((Q.preAdj >> (4 * band)) & 15u);
-                    scaleCode = hb + static_cast<int>(x >> 8);
-                    if (!fatal)
-                        code = static_cast<int>(x & 0xFF);
-                }
-                fatal = fatal || code > 16;
-                scale = static_cast<int>(scaleFactor(T, scaleCode));
-                if (fatal)
-                {
-                    err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;
-                    nb = 0;                         // stop: later bands contribute nothing
-                }
-                else if (code == 0)
-                {
-                    valid = false; err |= DCS_FRAME_STOP;       // :1985-1991
-                    outIdx += count * inc;
-                }
-                else
-                {
-                    i = count;
-                    if (code <= 6)
-                    {
-                        const uint32_t info = T->cbInfo[code];
-                        shPeek = 32 - static_cast<int>(info & 0xF);
-                        shIdx = shPeek;
-                        book = T->cb94 + (info >> 4);
-                    }
-                    else
-                    {
-                        // fixed-width code: the value is the top `code` bits; its two-entry "codebook"
-                        // (indexed with one bit) supplies the width and the step like a real one
-                        isRaw = true;
-                        shPeek = 32 - code;
-                        shIdx = 31;
-                        book = T->raw94 + 2 * (code - 7);
-                    }
-                }
-            }
+            err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;
+            nb = 0;                         // stop: later bands contribute nothing
+        }
+        if (stopBand)
+        {
+            valid = false; err |= DCS_FRAME_STOP;
         }
         if (!valid)
             scale = 0;              // after a STOP the band is still parsed, its samples contribute nothing
