@@ -425,96 +425,70 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
     for (int k = 0 ; __any(k < nb) ; ++k)
     {
         const int band = Q.bandBase + k;
-        int nS = 0;                 // samples this lane runs through the main loop
-        int width = 0;              // bits per input (0: ramp, no bits read)
-        int inc = 1, fixup = 0;
-        int scale = 0;
-        bool quirk = false;         // code 0, sub-type 1
-        int nQ = 0;
-        if (k < nb)
+        // ---- per-band set-up: straight-line code with selects (lanes without a band end up with nothing to do);
+        // only the OS93b Type-1 band-type code, a variable-length code, sits behind a (wave-uniform) branch ----------
+        const bool act = k < nb;
+        const int hb = byteOf(Q.h0, Q.h1, Q.h2, Q.h3, band) & 0x7F;
+        const int scale = static_cast<int>(scaleFactor(T, hb));
+        const bool strided = (hb >> 6) != 0;
+        // Type 0: 16 samples; a strided band starts one word further on, advances by 2 and ends one word back (:2362-2366).
+        // Type 1: 16 samples (15 in the frame's first band), or 8 at stride 2 (:2379-2381)
+        const int inc = strided ? 2 : 1;
+        const int nSamples = !type1 ? 16 : strided ? 8 : first ? 15 : 16;
+        const int stride = !type1 ? (strided ? 31 : 16) : nSamples;
+        const int fixup = (!type1 && strided) ? -1 : 0;
+        outIdx += (act && !type1 && strided) ? 1 : 0;
+
+        // the band-type field (:2388-2419): [reuse bit, if the previous band was code 0] then, Type 0:
+        // [change sub-type] [direction, if changing] [4-bit code].  Parsed from ONE window read with one advance.
+        const uint32_t bw = br.cur();
+        const bool hadReuse = reuse;
+        const bool reuseNow = hadReuse && (bw >> 31) != 0;
+        const bool parse0 = act && !reuseNow && !type1;
+        const uint32_t b = bw << (hadReuse ? 1 : 0);
+        const bool change = parse0 && (b >> 31) != 0;
+        const bool up = ((b >> 30) & 1u) != 0;
+        const int subUp = subType == 2 ? 0 : subType + 1, subDown = subType == 0 ? 2 : subType - 1;
+        subType = change ? (up ? subUp : subDown) : subType;
+        const int fixedBits = change ? 2 : 1;
+        code = parse0 ? static_cast<int>((b << fixedBits) >> 28) : code;
+        br.skip(!act ? 0 : (hadReuse ? 1 : 0) + (parse0 ? fixedBits + 4 : 0));
+        reuse = act ? reuseNow : reuse;
+        const bool vlc = act && !reuseNow && type1;
+        if (__any(vlc))
         {
-            const int hb = byteOf(Q.h0, Q.h1, Q.h2, Q.h3, band) & 0x7F;
-            scale = static_cast<int>(scaleFactor(T, hb));
-            const bool strided = (hb >> 6) != 0;
-            int nSamples, stride;
-            if (!type1)
+            if (vlc)
             {
-                nSamples = 16;
-                if (!strided) { stride = 16; }
-                else { ++outIdx; inc = 2; fixup = -1; stride = 31; }
-            }
-            else
-            {
-                if (!strided) { nSamples = stride = first ? 15 : 16; }
-                else { inc = 2; nSamples = stride = 8; }
-            }
-
-            // the band-type field (:2388-2419): [reuse bit, if the previous band was code 0] then, Type 0:
-            // [change sub-type] [direction, if changing] [4-bit code].  Parsed from ONE window read with one advance.
-            const uint32_t bw = br.cur();
-            int used = 0;
-            if (reuse)
-            {
-                reuse = (bw >> 31) != 0;
-                used = 1;
-            }
-            if (!reuse && !type1)
-            {
-                const uint32_t b = bw << used;
-                const bool change = (b >> 31) != 0;
-                const bool up = ((b >> 30) & 1u) != 0;
-                if (change)
-                    subType = up ? (subType == 2 ? 0 : subType + 1) : (subType == 0 ? 2 : subType - 1);
-                const int fixedBits = change ? 2 : 1;
-                code = static_cast<int>((b << fixedBits) >> 28);
-                used += fixedBits + 4;
-            }
-            br.skip(used);
-            if (!reuse)
-            {
-                if (type1)
-                {
-                    int v = readVlc(br, T->fast93, T->trie93);
-                    if (v < 0x1E)
-                        v -= 0x0F;
-                    else
-                    {
-                        v -= 0x2E;
-                        subType = subType != 0 ? 0 : 1;
-                    }
-                    code = (byteOf(Q.t0, Q.t1, Q.t2, Q.t3, band) + v) & 0xFFFF;
-                }
-            }
-
-            if (code == 0)
-            {
-                reuse = true;
-                if (subType == 0)
-                {
-                    outIdx += stride;
-                    prv = 0; prvDelta = 0;
-                }
-                else if (subType == 1)
-                {
-                    quirk = true; nQ = nSamples;
-                }
+                int v = readVlc(br, T->fast93, T->trie93);
+                if (v < 0x1E)
+                    v -= 0x0F;
                 else
-                    nS = nSamples;
-            }
-            else
-            {
-                width = code + (type1 ? 0 : 1);
-                if (width > 16)
                 {
-                    err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;
-                    nb = 0;
-                    width = 0;
+                    v -= 0x2E;
+                    subType = subType != 0 ? 0 : 1;
                 }
-                else
-                    nS = nSamples;
+                code = (byteOf(Q.t0, Q.t1, Q.t2, Q.t3, band) + v) & 0xFFFF;
             }
-            first = false;
         }
+
+        const bool zero = act && code == 0;
+        reuse = zero ? true : reuse;
+        const bool skipBand = zero && subType == 0;                     // nothing coded, previous input forgotten
+        const bool quirk = zero && subType == 1;                        // repeat the previous input (the quirky loop below)
+        const int nQ = nSamples;
+        const int w0 = code + (type1 ? 0 : 1);
+        const bool fatal = act && code != 0 && w0 > 16;
+        const int width = (zero || fatal || !act) ? 0 : w0;            // bits per input (0: ramp, no bits read)
+        const int nS = (!act || fatal || skipBand || quirk) ? 0 : nSamples;     // samples through the main loop
+        outIdx += skipBand ? stride : 0;
+        prv = skipBand ? 0u : prv;
+        prvDelta = skipBand ? 0u : prvDelta;
+        if (fatal)
+        {
+            err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;
+            nb = 0;
+        }
+        first = act ? false : first;
 
         // ---- main sample loop, branch-free -----------------------------------------------------------
         const uint32_t m2 = subType == 2 ? 0xFFFFu : 0u;        // add the previous delta
