@@ -42,6 +42,7 @@ struct Stamper
 };
 #define DCS_STAMP(k) stamp(k)
 
+constexpr int kHandoffL2Polls = 6;       // polls of the XCD's L2 before the polls go to memory
 constexpr int kHandoffSpins = 1 << 18;  // bound of the wait for a tail from an earlier chunk (about a second)
 constexpr int kWavesPerBlock = 4;       // wavefronts of a workgroup share one copy of the decode tables in LDS
 constexpr int kRowBytes = 528;          // 256 words + 16 bytes: 16-byte aligned rows (the transforms transpose through them
@@ -1182,7 +1183,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
     static_assert(kPoolBytes % 16 == 0 && kWavesPerBlock * kTileBytes >= 8192, "LDS layout");
     const Lds<FPW> L{ smem, smem + sizeof(DcsLdsTables) + kWavesPerBlock * kPoolBytes + wave * kTileBytes,
                       smem + sizeof(DcsLdsTables) + wave * kPoolBytes };
-    const uint32_t chunk = blockIdx.x * kWavesPerBlock + static_cast<uint32_t>(wave);
+    // Workgroups go to the eight XCDs round-robin (workgroup b -> XCD b mod 8).  Consecutive chunks of a stream hand
+    // their overlap tails to each other, so consecutive workgroups' worth of chunks are given to ONE XCD, where the
+    // hand-off word is served by that XCD's L2: XCD x takes the chunks of "logical workgroups" [x * per, (x + 1) * per).
+    // (The grid is a multiple of 8 workgroups; logical workgroups past the last chunk have nothing to do.)
+    const uint32_t perXcd = gridDim.x >> 3;
+    const uint32_t logicalWg = (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3);
+    const uint32_t chunk = logicalWg * kWavesPerBlock + static_cast<uint32_t>(wave);
 #ifdef DCS_STAMPS
     const Stamper stamp{ (lane == 0 && a.debug != nullptr && chunk < a.nChunks) ? a.debug + static_cast<size_t>(chunk) * 16 : nullptr };
 #else
@@ -1513,6 +1520,21 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
     const int slotWord = static_cast<int>(slot.flags | (slot.prevSlot << 8) | (static_cast<uint32_t>(job.volShift) << 16));
     const int jobXform = job.xform, jobPrev = static_cast<int>(job.prev);
 
+    // frames that take their tail from an earlier chunk are finished after the last pass (see below); the first poll for
+    // the first of them (normally the only one) is issued in the last pass just BEFORE that pass's PCM stores, so that
+    // its wait does not include those stores (loads and stores retire in issue order)
+    const unsigned long long importSlots = __ballot(live && lane < FPW && (slotFlags & DCS_SLOT_IMPORT) != 0);
+    const int firstImport = importSlots != 0 ? __builtin_ctzll(importSlots) : 0;
+    const int firstImportXf = __builtin_amdgcn_readlane(jobXform, firstImport);
+    const unsigned long long *firstImportSrc = a.handoff + static_cast<size_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(jobPrev, firstImport))) * 16
+                                             + ((firstImportXf == DCS_XFORM_94) ? bitrevN(lane & 7, 3) : bitrevN(lane & 15, 4));
+    unsigned long long earlyWord = 0;
+    auto earlyPoll = [&](bool lastPass)
+    {
+        if (lastPass && importSlots != 0 && lane < ((firstImportXf == DCS_XFORM_94) ? 8 : 16))
+            earlyWord = __hip_atomic_load(firstImportSrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
 #ifdef DCS_EXP_NO_PHASE2
     if (nSlots > 1000)
 #endif
@@ -1605,6 +1627,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
             tailPair = hasPrev ? tailPair : extTail;
             x[0] = packC(overlapMix(reC(x[0]), C.k[DCS_K94_OVLA] & 0xFFFFu, reC(tailPair), C.k[DCS_K94_OVLB] & 0xFFFFu),
                          overlapMix(imC(x[0]), C.k[DCS_K94_OVLA] >> 16, imC(tailPair), C.k[DCS_K94_OVLB] >> 16));
+            earlyPoll(s0 + n >= nSlots);
             if (emit)
             {
                 uint32_t *out = reinterpret_cast<uint32_t *>(a.pcm) + static_cast<size_t>(myJob) * (DCS_FRAME_SAMPLES / 2) + lr;
@@ -1623,6 +1646,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
             int tailSample = static_cast<int16_t>(reinterpret_cast<const uint16_t *>(tails)[(hasPrev ? myPrevSlot : mySlot) * 16 + lr]);
             tailSample = hasPrev ? tailSample : sx16(extTail);
             x[0] = static_cast<uint32_t>(overlapMix(reC(x[0]), C.k[DCS_K93_OVL] & 0xFFFFu, tailSample, C.k[DCS_K93_OVL] >> 16)) & 0xFFFFu;
+            earlyPoll(s0 + n >= nSlots);
             if (emit)
             {
                 int16_t *out = a.pcm + static_cast<size_t>(myJob) * DCS_FRAME_SAMPLES + lr;
@@ -1645,7 +1669,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
     // error flag, not the launch).  Lane l of the first lane group finishes sample (pair) bitrev(l), for which it
     // holds the overlap window in its constants.
     DCS_STAMP(13);
-    for (unsigned long long pending = __ballot(live && lane < FPW && (slotFlags & DCS_SLOT_IMPORT) != 0) ; pending != 0 ; pending &= pending - 1)
+    for (unsigned long long pending = importSlots ; pending != 0 ; pending &= pending - 1)
     {
         const int sI = __builtin_ctzll(pending);
         const int xf = __builtin_amdgcn_readlane(jobXform, sI);
@@ -1661,7 +1685,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
         {
             const int k = (xf == DCS_XFORM_94) ? bitrevN(lane, 3) : bitrevN(lane, 4);
             const unsigned long long *src = a.handoff + static_cast<size_t>(fromChunk) * 16 + k;
-            unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // The producer normally runs on this XCD (see the chunk mapping at the top): its write-through store has
+            // updated this XCD's L2, which a load that only bypasses the vector L1 (workgroup scope) reads in a third of
+            // the time of one that goes to memory.  After a few such polls -- the producer is late, or it ran on another
+            // XCD (the seven seams of the mapping) and this L2 may hold a stale line -- the polls go to memory.
+            unsigned long long w = (sI == firstImport) ? earlyWord : 0ull;              // (epoch 0 never matches)
+            for (int spin = 0 ; static_cast<uint32_t>(w >> 32) != a.epoch && spin < kHandoffL2Polls ; ++spin)
+                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             for (int spin = 0 ; static_cast<uint32_t>(w >> 32) != a.epoch && spin < kHandoffSpins ; ++spin)
             {
                 __builtin_amdgcn_s_sleep(2);
