@@ -721,8 +721,7 @@ __device__ __forceinline__ int imC(uint32_t c) { return static_cast<int>(c) >> 1
 // again with the exact (slower) rotate in the rare case that any lane met it: one wave-uniform branch per stage,
 // almost never taken, and the butterflies of a stage stay in one basic block.  "Low word of 2p is 0x8000" is tested
 // on 2p + 0x8000 (for one of the two products a term the sum needs anyway): its low word is zero; the watch register
-// keeps the minimum of all those low words (it starts at 0xFFFF and, once zero, stays zero: later stages of the
-// same transform then also take the exact path, which is always right).
+// keeps the minimum of all those low words (it starts at 0xFFFF and is set back to that when a stage is repeated).
 // running minimum of the low words seen so far: zero as soon as one product met the condition (one VALU per butterfly)
 __device__ __forceinline__ void quirkWatch(uint32_t &watch, uint32_t a, uint32_t b)
 {
@@ -828,6 +827,7 @@ __device__ __forceinline__ void stageA(uint32_t (&x)[16], const TwA &W, BflyRegs
         }
     if (__builtin_expect(quirkSeen(R.watch), 0))
     {
+        R.watch = 0xFFFFu;              // (start watching again: only this stage is repeated)
 #pragma unroll
         for (int r = 0 ; r < 16 ; ++r)
             if (!(r & D) && (r >> SH) >= 2)
@@ -848,6 +848,7 @@ __device__ __forceinline__ void stageB(uint32_t (&x)[16], const uint32_t *tw, Bf
             addSub<SAT>(x[r], rotateFastB(x[r + D], tw[r >> SH], R), y[r], y[r + D]);
     if (__builtin_expect(quirkSeen(R.watch), 0))
     {
+        R.watch = 0xFFFFu;              // (start watching again: only this stage is repeated)
 #pragma unroll
         for (int r = 0 ; r < 16 ; ++r)
             if (!(r & D))
@@ -960,6 +961,7 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const TwA &W, c
         }
         if (__builtin_expect(quirkSeen(R.watch), 0))
         {
+            R.watch = 0xFFFFu;
 #pragma unroll
             for (int j = 0 ; j < 8 ; ++j)
             {

@@ -30,6 +30,14 @@ names = ["tables+barrier", "staging", "hdr", "unpack", "err/dc", "(sync)", "tran
 for k in range(6):
     d = st[:, k + 1] - st[:, k]
     print("  %-16s median %7d   slowest-5%% median %7d" % (names[k] if k < 5 else names[6], np.median(d), np.median(d[slow])))
+for a_, b_, name in ((5, 13, "transform passes"), (13, 6, "imported tails"), (0, 1, "start -> after barrier")):
+    ok = (st[:, a_] != 0) & (st[:, b_] != 0)
+    d = st[:, b_] - st[:, a_]
+    print("  %-24s median %7d   slowest-5%% median %7d" % (name, np.median(d[ok]), np.median(d[ok & slow])))
+order = np.argsort(st[:, 0])
+print("  chunk start times (cycles after the first): p50 %d p95 %d max %d ; end times: p50 %d p95 %d max %d" % (
+    np.percentile(st[:, 0] - st[:, 0].min(), 50), np.percentile(st[:, 0] - st[:, 0].min(), 95), (st[:, 0] - st[:, 0].min()).max(),
+    np.percentile(st[:, 6] - st[:, 0].min(), 50), np.percentile(st[:, 6] - st[:, 0].min(), 95), (st[:, 6] - st[:, 0].min()).max()))
 # formats of the chunks (first slot's first source), slow vs all
 try:
     fpw = 4 if b["jobs"].size <= 1024 * 16 else 8 if b["jobs"].size <= 1024 * 192 else 16
