@@ -150,6 +150,22 @@ struct BitReader
         asm("v_lshl_add_u32 %0, %1, 2, %0" : "+v"(pa) : "v"(sign));
         negpos &= 31;
     }
+    // the same in seven instructions, for the hottest loop: the subtraction's borrow is the refill condition
+    // (negpos is kept in 0..31, so "negpos < n" is the unsigned borrow)
+    __device__ __forceinline__ void skipTight(uint32_t n, uint32_t ahead)
+    {
+        uint32_t t;
+        asm("v_sub_co_u32 %4, vcc, %4, %6\n\t"
+            "v_cndmask_b32 %0, %0, %1, vcc\n\t"
+            "v_cndmask_b32 %1, %1, %2, vcc\n\t"
+            "v_cndmask_b32 %2, %2, %7, vcc\n\t"
+            "v_lshrrev_b32 %5, 31, %4\n\t"
+            "v_lshl_add_u32 %3, %5, 2, %3\n\t"
+            "v_and_b32 %4, 31, %4"
+            : "+v"(hi), "+v"(lo), "+v"(nxt), "+v"(pa), "+v"(negpos), "=&v"(t)
+            : "v"(n), "v"(ahead)
+            : "vcc");
+    }
     __device__ __forceinline__ void skip(int n) { skip(n, prefetch()); }
     __device__ __forceinline__ uint32_t get(int n) { const uint32_t v = peek(n); skip(n); return v; }
 };
@@ -354,7 +370,10 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
         const int countStart = i;
         const int inc2 = inc;
         const int incBytes = inc * 2;
-        while (i > 0)
+        // (the cell pointer doubles as the loop counter: the band ends at cellEnd, a two-zeros code with one sample
+        // left overshoots it)
+        uint16_t *const cellEnd = cell + i * inc;
+        while (cell < cellEnd)
         {
             const uint32_t ahead = br.prefetch();
             const uint32_t w = br.cur();
@@ -362,14 +381,13 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
             const int vr = static_cast<int>(w) >> shPeek;
             const int vh = static_cast<int>(static_cast<int8_t>(e & 0xFF));
             const int step = static_cast<int>(e >> 13);
-            br.skip(static_cast<int>((e >> 8) & 0x1F), ahead);
+            br.skipTight((e >> 8) & 0x1Fu, ahead);
             mixAdd<FIRST>(cell, mul24(isRaw ? vr : vh, scale), mixMul);
             cell = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(cell) + incBytes * step);
-            i -= step;
         }
         outIdx += static_cast<int>(cell - cellStart);
         if (k == 0) stamp(10);
-        if (i < 0)
+        if (cell > cellEnd)
         {
             // the reference zeroes the WHOLE band buffer on this error (:2238-2239): take back what the
             // band already contributed by replaying it.  (Frames with errors are never split.)
@@ -516,7 +534,7 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
             const uint32_t w = br.cur() & wMask;
             sample(static_cast<uint32_t>(static_cast<int>(w) >> shW));
             sample(static_cast<uint32_t>(static_cast<int>(w << width) >> shW));
-            br.skip(2 * width, ahead);          // last: the prefetched dword has had the whole iteration to arrive
+            br.skipTight(static_cast<uint32_t>(2 * width), ahead);     // last: the prefetched dword has had the whole iteration to arrive
         }
         if (__any(i < nS))
         {
