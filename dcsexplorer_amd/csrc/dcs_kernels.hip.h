@@ -1242,8 +1242,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
 #pragma unroll
         for (int t = 0 ; t < kPoolPieces ; ++t)
         {
-            const int i = lane * 4 + 256 * t;
-            pimg[t] = i < poolDwords(FPW) ? *reinterpret_cast<const uint4 *>(pkg + dcsPkgOffPool(FPW) + i * 4) : make_uint4(0, 0, 0, 0);
+            // (unconditional: a predicated load would make the compiler wait for every load above before the tables
+            // are even requested; lanes past the image re-read its last 16 bytes and store nothing)
+            const int i = min(lane * 4 + 256 * t, poolDwords(FPW) - 4);
+            pimg[t] = *reinterpret_cast<const uint4 *>(pkg + dcsPkgOffPool(FPW) + i * 4);
         }
         slot.job = s0.x;
         slot.prevSlot = s0.y & 0xFFu; slot.flags = (s0.y >> 8) & 0xFFu; slot.nSrc = (s0.y >> 16) & 0xFFu; slot.shiftXform = s0.y >> 24;
