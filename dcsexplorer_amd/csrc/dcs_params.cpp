@@ -106,7 +106,7 @@ extern "C" DcsStatus dcs_stream_params_from(DcsOsVersion os, int volume, int lev
     if (mixMulScaled == nullptr || volShift == nullptr)
         return DCS_ERR_INVALID_ARG;
     const uint16_t volMult = dcs_volume_multiplier(volume);
-    const uint16_t steady = dcs_mixing_multiplier(os, level << 6, channelVolume);
+    const uint16_t steady = dcs_mixing_multiplier(os, level * 64, channelVolume);      // (level byte << 6; levels may be negative)
     uint16_t mm = firstMixMul;      // what the previous tick's UpdateMixingLevels left in the channel
     for (uint32_t f = 0 ; f < nFrames ; ++f)
     {

@@ -234,7 +234,7 @@ void DcsSequencer::loadTrack(uint32_t cn, DcsRomCursor p)       // :826-836
 void DcsSequencer::mixingLevelOp(int cur, DcsRomCursor &p, int mode, bool fade)     // :1316-1371
 {
     const uint32_t target = p.u8();
-    const int param = static_cast<int>(static_cast<int8_t>(p.u8())) << 6;
+    const int param = static_cast<int>(static_cast<int8_t>(p.u8())) * 64;
     const int steps = fade ? static_cast<int>(p.u16()) : 0;
     Mixer &m = chan(target).mixer[cur];
     m.steps = steps;
@@ -677,7 +677,7 @@ extern "C" DcsStatus dcs_seq_load_audio_stream(DcsSequencer *s, int channel, uin
     s->loadAudioStream(static_cast<uint32_t>(channel), channel, 1, s->rs->at(linearAddress));
     Mixer &m = c.mixer[channel];
     m.reset();
-    m.cur = m.target = mixingLevel << 6;
+    m.cur = m.target = mixingLevel * 64;
     return DCS_OK;
 }
 
@@ -692,7 +692,7 @@ extern "C" DcsStatus dcs_seq_load_audio_stream_mem(DcsSequencer *s, int channel,
     s->loadStreamEntry(static_cast<uint32_t>(channel), channel, 1, s->addStream(data, len, std::make_pair(static_cast<const void *>(data), size_t(0)), false));
     Mixer &m = c.mixer[channel];
     m.reset();
-    m.cur = m.target = mixingLevel << 6;
+    m.cur = m.target = mixingLevel * 64;
     return DCS_OK;
 }
 

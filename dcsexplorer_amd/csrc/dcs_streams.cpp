@@ -68,7 +68,7 @@ DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t 
             const DcsStreamInfo &pi = infos[k - 1];
             const bool stopped = pi.nValidFrames < pi.nFrames;      // cut short; an error in the very last frame
                                                                     // finds the channel already idle (:100-113)
-            firstMul = dcs_mixing_multiplier(os, stopped ? 0 : pr.level << 6, pr.channelVolume);
+            firstMul = dcs_mixing_multiplier(os, stopped ? 0 : pr.level * 64, pr.channelVolume);
         }
         st = dcs_stream_params_from(os, sr.volume, sr.level, sr.channelVolume, firstMul, nFrames, mm.data(), vs.data());
         if (st != DCS_OK)

@@ -5,7 +5,7 @@
 # pairs new[] with delete in its own destructors, hence alloc_dealloc_mismatch=0.
 set -eu
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=/tmp/dcs_asan; mkdir -p $OUT
+OUT=/tmp/dcs_asan; mkdir -p $OUT; rm -f $OUT/asanlog* $OUT/*.txt
 CL=/opt/rocm/lib/llvm/bin/clang++
 for f in dcs_tables dcs_index dcs_params dcs_synth dcs_plan dcs_streams dcs_files dcs_rom dcs_sequencer dcs_decoder_hip; do
   $CL -x c++ -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -c $ROOT/dcsexplorer_amd/csrc/$f.cpp -o $OUT/$f.o
