@@ -43,7 +43,7 @@ struct Stamper
 #define DCS_STAMP(k) stamp(k)
 
 constexpr int kHandoffL2Polls = 6;       // polls of the XCD's L2 before the polls go to memory
-constexpr int kHandoffSpins = 1 << 18;  // bound of the wait for a tail from an earlier chunk (about a second)
+constexpr unsigned long long kHandoffTimeoutTicks = 400000000ull;    // bound of the wait for a tail from another chunk: 4 s (100 MHz ticks)
 constexpr int kWavesPerBlock = 4;       // wavefronts of a workgroup share one copy of the decode tables in LDS
 constexpr int kRowBytes = 528;          // 256 words + 16 bytes: 16-byte aligned rows (the transforms transpose through them
                                         // with 128-bit accesses), rows of neighbouring frames land on different LDS banks
@@ -1714,7 +1714,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
             unsigned long long w = (sI == firstImport) ? earlyWord : 0ull;              // (epoch 0 never matches)
             for (int spin = 0 ; static_cast<uint32_t>(w >> 32) != a.epoch && spin < kHandoffL2Polls ; ++spin)
                 w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (int spin = 0 ; static_cast<uint32_t>(w >> 32) != a.epoch && spin < kHandoffSpins ; ++spin)
+            // (bounded by wall time, 100 MHz ticks: at one of the seven seams the producer is among the LAST workgroups
+            // of the grid, and in a grid of many rounds it is not even dispatched for most of the kernel's run time)
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (static_cast<uint32_t>(w >> 32) != a.epoch && __builtin_amdgcn_s_memrealtime() - t0 < kHandoffTimeoutTicks)
             {
                 __builtin_amdgcn_s_sleep(2);
                 w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
