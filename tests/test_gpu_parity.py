@@ -174,6 +174,32 @@ def test_full_size_workloads_hash_and_sampled_oracle(gpu_ctx, oracle, wl):
         assert_same(pcm[first[k]:first[k + 1]], oracle_streams(oracle, [b["streams"][k]]), "%s stream %d" % (wl, k))
 
 
+@pytest.mark.parametrize("wl", ["dcs94_65536", "dcs93_4096"])
+def test_full_size_every_plan_gives_the_same_pcm(gpu_ctx, wl):
+    """size-independent property at BASELINE sizes: the PCM does not depend on how the batch is cut into chunks
+    (4 / 8 / 16 frames per wavefront: one to many rounds of workgroups, every seam of the XCD mapping) nor on how the
+    overlap tails cross the cuts (hand-off buffer / halo re-decode); the reference hashes pin one of the plans"""
+    b = workloads.build(wl)
+    meta = json.load(open(os.path.join(GOLD, "dcs_golden_hashes.json")))["workloads"][wl]
+    first = b["first_job"]
+    want = None
+    try:
+        for fpw, handoff in ((16, True), (8, True), (4, True), (8, False), (16, False)):
+            gpu_ctx.set_frames_per_wave(fpw)
+            gpu_ctx.set_tail_handoff(handoff)
+            pcm, err = gpu_ctx.decode_batch(b["blob"], b["srcs"], b["jobs"])
+            assert not err.any()
+            if want is None:
+                want = pcm
+                got = ["%016x" % fnv1a64(pcm[first[k]:first[k + 1]].tobytes()) for k in range(len(first) - 1)]
+                assert got == meta["stream_hashes"]
+            else:
+                assert np.array_equal(pcm, want), "fpw=%d handoff=%s" % (fpw, handoff)
+    finally:
+        gpu_ctx.set_frames_per_wave(0)
+        gpu_ctx.set_tail_handoff(True)
+
+
 def test_pinned_download_view_and_buffer_reuse(gpu_ctx):
     """dcs_batch_download_view hands out the result in pinned memory; buffers of closed batches are reused"""
     b = workloads.build("dcs93_4096", n_streams=6, n_frames=20)
