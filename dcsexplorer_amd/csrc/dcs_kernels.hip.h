@@ -1226,18 +1226,19 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
     // header, this lane's split record, the pool image.  All of it is requested here, before anything else, in one
     // go; the padding wavefronts of the last workgroup read package 0 and drop out after the barrier.
     const uint8_t *pkg = a.packages + (chunk < a.nChunks ? static_cast<size_t>(chunk) * dcsPkgBytes(FPW) : 0);
-    struct { uint32_t job; uint32_t prevSlot, flags, nSrc, shiftXform; uint32_t firstSrc, prevJob, poolOff, bpl; } slot;
-    uint4 pd0, pd1, phdr;
-    uint2 pd2, psplit;
+    // The head of the package (slots, descriptor heads, headers: FPW x 96 contiguous bytes) is per-slot data: it is
+    // fetched ONCE per wavefront, 16 bytes per lane, and handed to the lanes through LDS below (fewer vector-memory
+    // instructions in the burst at the start of a kernel, where every wavefront of the chip issues its loads at once).
+    constexpr int kHeadVec = FPW * 6, kHeadLoads = (kHeadVec + 63) / 64;
+    uint4 phead[kHeadLoads];
+    uint2 psplit;
     constexpr int kPoolPieces = (poolDwords(FPW) + 255) / 256;
     uint4 pimg[kPoolPieces];
     {
         static_assert(sizeof(DcsSlot) == 32 && offsetof(DcsSlot, runStartDw) == 16 && offsetof(DcsSlot, hdrDw) == 24, "DcsSlot layout");
-        const uint4 *sp4 = reinterpret_cast<const uint4 *>(pkg) + 2 * s;
-        const uint4 s0 = sp4[0], s1 = sp4[1];
-        const uint4 *dp = reinterpret_cast<const uint4 *>(pkg + dcsPkgOffDesc(FPW)) + 3 * s;
-        pd0 = dp[0]; pd1 = dp[1]; pd2 = *reinterpret_cast<const uint2 *>(dp + 2);
-        phdr = reinterpret_cast<const uint4 *>(pkg + dcsPkgOffHdr(FPW))[s];
+#pragma unroll
+        for (int t = 0 ; t < kHeadLoads ; ++t)
+            phead[t] = reinterpret_cast<const uint4 *>(pkg)[min(lane + 64 * t, kHeadVec - 1)];
         psplit = reinterpret_cast<const uint2 *>(pkg + dcsPkgOffSplit(FPW))[lane];
 #pragma unroll
         for (int t = 0 ; t < kPoolPieces ; ++t)
@@ -1247,11 +1248,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
             const int i = min(lane * 4 + 256 * t, poolDwords(FPW) - 4);
             pimg[t] = *reinterpret_cast<const uint4 *>(pkg + dcsPkgOffPool(FPW) + i * 4);
         }
-        slot.job = s0.x;
-        slot.prevSlot = s0.y & 0xFFu; slot.flags = (s0.y >> 8) & 0xFFu; slot.nSrc = (s0.y >> 16) & 0xFFu; slot.shiftXform = s0.y >> 24;
-        slot.firstSrc = s0.z; slot.prevJob = s0.w;
-        slot.poolOff = s1.y >> 16;
-        slot.bpl = (s1.w >> 8) & 0xFFu;
     }
     TwA W;
     loadTwA(a.tables, W);
@@ -1274,6 +1270,32 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
         return;                                     // padding wavefront of the last workgroup
 
     DCS_STAMP(1);
+
+    // hand the package head to the lanes: through this wavefront's bit pool (filled with the image right after)
+    struct { uint32_t job; uint32_t prevSlot, flags, nSrc, shiftXform; uint32_t firstSrc, prevJob, poolOff, bpl; } slot;
+    uint4 pd0, pd1, phdr;
+    uint2 pd2;
+    {
+        uint4 *scratch = reinterpret_cast<uint4 *>(L.pool());
+        static_assert(kHeadVec * 16 <= poolDwords(FPW) * 4, "the package head fits in the bit pool");
+#pragma unroll
+        for (int t = 0 ; t < kHeadLoads ; ++t)
+            if (lane + 64 * t < kHeadVec)
+                scratch[lane + 64 * t] = phead[t];
+        waveSync();
+        const uint4 s0 = scratch[2 * s], s1 = scratch[2 * s + 1];
+        const uint4 *dp = scratch + FPW * 2 + 3 * s;
+        pd0 = dp[0]; pd1 = dp[1];
+        const uint4 d2v = dp[2];
+        pd2 = make_uint2(d2v.x, d2v.y);
+        phdr = scratch[FPW * 5 + s];
+        waveSync();
+        slot.job = s0.x;
+        slot.prevSlot = s0.y & 0xFFu; slot.flags = (s0.y >> 8) & 0xFFu; slot.nSrc = (s0.y >> 16) & 0xFFu; slot.shiftXform = s0.y >> 24;
+        slot.firstSrc = s0.z; slot.prevJob = s0.w;
+        slot.poolOff = s1.y >> 16;
+        slot.bpl = (s1.w >> 8) & 0xFFu;
+    }
 
     // the lane's transform constants for the chunk's first frame (the whole chunk, normally): requested now, needed in
     // phase 2
