@@ -8,14 +8,16 @@
 //            few bands each: Huffman / fixed-width fields -> dequantise -> mix-accumulate the <=255
 //            frequency-domain words into the frame's row of an LDS tile.  All 64 lanes of the wavefront
 //            work on the serial entropy decode (16..80 dependent symbol decodes per lane instead of
-//            ~250 per frame).  The compressed bytes of the chunk are first staged into an LDS pool with
-//            coalesced loads (byte-swapped to bit order), so the per-symbol critical path never waits
-//            on HBM/L2.
+//            ~250 per frame).  Everything a chunk needs -- slots, descriptor heads, headers, split records,
+//            the compressed bytes as an image of the LDS bit pool (dwords in bit order) -- was gathered once
+//            per batch into the chunk's PACKAGE by dcsPackKernel and is requested with the wavefront's first
+//            instructions, so the per-symbol critical path never waits on HBM/L2.
 //            [DecoderImpl94x/93/93a::DecompressFrame, DCSDecoderNative.cpp:1679-2261, :2293-2684,
 //             :2831-3032; ROMBitPointer, DCSDecoderNative.h:229-289]
 //   phase 2, transform, 8 or 16 lanes per frame:  register-resident fixed-point inverse transforms of
 //            8 (1994+) or 4 (1993) rows per pass, volume shift, overlap-add with the predecessor's
-//            16-sample tail (kept in LDS), 240 int16 PCM samples written per frame.
+//            16-sample tail (through LDS inside a chunk, through an epoch-tagged hand-off buffer from the
+//            chunk before), 240 int16 PCM samples written per frame.
 //            [DecoderImpl94x::TransformFrame :397-576, DecoderImpl93::TransformFrame :614-813]
 //
 // All arithmetic is the ADSP-2105 fixed-point arithmetic of the reference restated in 32-bit integer
