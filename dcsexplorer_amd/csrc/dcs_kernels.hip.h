@@ -254,6 +254,21 @@ __device__ __forceinline__ void mixAdd(uint16_t *cell, int scaledProduct, uint32
         acc += static_cast<uint32_t>(*cell) << 16;
     *cell = static_cast<uint16_t>(acc >> 16);
 }
+// the same with the low word that is ADDED taken from `addLow` instead of the product (the 1993 "repeat the previous
+// input" coding carries it from sample to sample, :2513-2534); returns the 32-bit sum
+template <bool FIRST>
+__device__ __forceinline__ uint32_t mixAddCarry(uint16_t *cell, int scaledProduct, uint32_t mixMul, uint32_t addLow)
+{
+    uint32_t t, acc;
+    asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+        : "=v"(t) : "v"(scaledProduct), "v"(mixMul));
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=v"(acc) : "v"(t), "v"(addLow));
+    if (!FIRST)
+        acc += static_cast<uint32_t>(*cell) << 16;
+    *cell = static_cast<uint16_t>(acc >> 16);
+    return acc;
+}
 // (int16)word 0 of x times a 24-bit signed y, one instruction
 __device__ __forceinline__ int mulLowWord(uint32_t x, int y)
 {
@@ -495,12 +510,13 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         const bool zero = act && code == 0;
         reuse = zero ? true : reuse;
         const bool skipBand = zero && subType == 0;                     // nothing coded, previous input forgotten
-        const bool quirk = zero && subType == 1;                        // repeat the previous input (the quirky loop below)
-        const int nQ = nSamples;
+        // repeat the previous input: rides in the main loop as a ramp with step 0 (no bits read, previous input kept),
+        // except that the low word of the product is carried from sample to sample instead of being reloaded (:2513-2534)
+        const bool quirk = zero && subType == 1;
         const int w0 = code + (type1 ? 0 : 1);
         const bool fatal = act && code != 0 && w0 > 16;
         const int width = (zero || fatal || !act) ? 0 : w0;            // bits per input (0: ramp, no bits read)
-        const int nS = (!act || fatal || skipBand || quirk) ? 0 : nSamples;     // samples through the main loop
+        const int nS = (!act || fatal || skipBand) ? 0 : nSamples;     // samples through the main loop
         outIdx += skipBand ? stride : 0;
         prv = skipBand ? 0u : prv;
         prvDelta = skipBand ? 0u : prvDelta;
@@ -517,15 +533,17 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         // width 0 (a ramp: no bits read) rides along with an all-zero mask instead of a branch
         const int shW = (32 - width) & 31;
         const uint32_t wMask = width != 0 ? 0xFFFFFFFFu : 0u;
-        const bool ran = nS > 0 || quirk;
+        const bool ran = nS > 0;
         if (k == 0) stamp(9);
+        uint32_t carry = static_cast<uint32_t>(mulLowWord(prv, scale));      // (only lanes that repeat the previous input use it)
         auto sample = [&](uint32_t in)
         {
             const uint32_t d = in + (prvDelta & m2);
             const uint32_t p = d + (prv & m0);
             prvDelta = d - (prv & ~m0);
             prv = p;
-            mixAdd<FIRST>(&row[min(outIdx, kDummyWord)], mulLowWord(p, scale), mixMul);
+            const int prod = mulLowWord(p, scale);
+            carry = mixAddCarry<FIRST>(&row[min(outIdx, kDummyWord)], prod, mixMul, quirk ? carry : static_cast<uint32_t>(prod));
             outIdx += inc;
         };
         // two samples per window read: a sample is at most 16 bits wide, so the next 32 bits always hold two
@@ -550,26 +568,6 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         prv &= 0xFFFFu; prvDelta &= 0xFFFFu;
         if (k == 0) stamp(10);
 
-        // ---- code 0 / sub-type 1: repeat the previous input; the product's low word is carried from
-        // sample to sample instead of being reloaded (:2513-2534) -------------------------------------------
-        if (__any(quirk))
-        {
-            if (quirk)
-            {
-                uint32_t low = static_cast<uint32_t>(mulLowWord(prv, scale)) & 0xFFFFu;
-                const uint32_t addend = static_cast<uint32_t>(__mul24(sx16(low), static_cast<int>(mixMul)));
-                for (int i = 0 ; i < nQ ; ++i, outIdx += inc)
-                {
-                    uint16_t *cell = &row[min(outIdx, kDummyWord)];
-                    uint32_t acc = low + addend;
-                    if (!FIRST)
-                        acc += static_cast<uint32_t>(*cell) << 16;
-                    *cell = static_cast<uint16_t>(acc >> 16);
-                    low = acc & 0xFFFFu;
-                }
-                prvDelta = 0;
-            }
-        }
         if (ran)
             outIdx += fixup;
     }
