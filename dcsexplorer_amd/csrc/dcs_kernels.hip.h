@@ -750,8 +750,8 @@ __device__ __forceinline__ bool quirkSeen(uint32_t watch) { return __any((watch 
 #define DCS_MUL_SEL(dst, x, xsel, y, ysel) \
     asm("v_mul_i32_i24_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" xsel " src1_sel:" ysel : "=v"(dst) : "v"(x), "v"(y))
 
-// registers every butterfly needs: 0x8000 in a VGPR (VOP3 takes no literal) and the watch register
-struct BflyRegs { uint32_t k8000; uint32_t watch; };
+// registers every butterfly needs: 0x8000 and 0x10000 in VGPRs (VOP3 takes no literal) and the watch register
+struct BflyRegs { uint32_t k8000, k10000; uint32_t watch; };
 
 // twiddles of the layout-A stages (entries 2..7 of the table; 0 and 1 are exact and need no multiplier): the same for
 // every lane, held doubled (DcsDevTables.twA), which makes the products come out as the reference's doubled MR terms
@@ -794,7 +794,18 @@ __device__ __forceinline__ uint32_t rotateFastA(uint32_t A, const TwScalar &t, B
     quirkWatch(R.watch, nP, qK);
     return __builtin_amdgcn_perm(mrI, mrR, 0x07060302u);
 }
-// per-lane twiddle, packed cos | sin << 16: 4 products + 5 adds + 1 watch + 1 pack = 11 instructions
+// (a << 1) + b in one instruction, kept as written (the compiler would re-associate the sums below into one more add)
+__device__ __forceinline__ uint32_t shl1Add(uint32_t a, uint32_t b)
+{
+    uint32_t r = (a << 1) + b;
+    asm("" : "+v"(r));              // (no instruction: only hides the sum from re-association)
+    return r;
+}
+// per-lane twiddle, packed cos | sin << 16: 4 products + 4 adds + 1 watch + 1 pack = 10 instructions.
+// TIGHT keeps the sums exactly as written (one instruction fewer); measured, that pays where several wavefronts share
+// a SIMD (the saturating 1994+ stages use it), while a wavefront alone on its SIMD -- the 4 096-frame 1993 batch --
+// runs 2 % faster with the compiler's own association of the sums.
+template <bool TIGHT>
 __device__ __forceinline__ uint32_t rotateFastB(uint32_t A, uint32_t tw, BflyRegs &R)
 {
     int p1, p2, q1, q2;
@@ -802,6 +813,17 @@ __device__ __forceinline__ uint32_t rotateFastB(uint32_t A, uint32_t tw, BflyReg
     DCS_MUL_SEL(p1, A, "WORD_0", tw, "WORD_0");         // a.re c
     DCS_MUL_SEL(q2, A, "WORD_0", tw, "WORD_1");         // a.re s
     DCS_MUL_SEL(q1, A, "WORD_1", tw, "WORD_0");         // a.im c
+    // MR.re = 2 p1 - 2 p2 + 0x8000 = (2 p1 + 0x10000) - (2 p2 + 0x8000);  MR.im = 2 q1 + (2 q2 + 0x8000): the terms in
+    // parentheses are the ones the watch looks at
+    if (TIGHT)
+    {
+        const uint32_t tR = shl1Add(static_cast<uint32_t>(p2), R.k8000);
+        const uint32_t mrR = shl1Add(static_cast<uint32_t>(p1), R.k10000) - tR;
+        const uint32_t qK = shl1Add(static_cast<uint32_t>(q2), R.k8000);
+        const uint32_t mrI = shl1Add(static_cast<uint32_t>(q1), qK);
+        quirkWatch(R.watch, tR, qK);
+        return __builtin_amdgcn_perm(mrI, mrR, 0x07060302u);
+    }
     const uint32_t mrR = (static_cast<uint32_t>(p1 - p2) << 1) + R.k8000;
     const uint32_t qK = (static_cast<uint32_t>(q2) << 1) + R.k8000;
     const uint32_t mrI = (static_cast<uint32_t>(q1) << 1) + qK;
@@ -863,7 +885,7 @@ __device__ __forceinline__ void stageB(uint32_t (&x)[16], const uint32_t *tw, Bf
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
         if (!(r & D))
-            addSub<SAT>(x[r], rotateFastB(x[r + D], tw[r >> SH], R), y[r], y[r + D]);
+            addSub<SAT>(x[r], rotateFastB<SAT>(x[r + D], tw[r >> SH], R), y[r], y[r + D]);
     if (__builtin_expect(quirkSeen(R.watch), 0))
     {
         R.watch = 0xFFFFu;              // (start watching again: only this stage is repeated)
@@ -971,10 +993,11 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const TwA &W, c
             DCS_MUL_SEL(p1, b_[j], "WORD_1", C.k[DCS_K94_PRE + j], "WORD_1");
             DCS_MUL_SEL(q2, b_[j], "WORD_0", C.k[DCS_K94_PRE + j], "WORD_1");
             DCS_MUL_SEL(q1, b_[j], "WORD_1", C.k[DCS_K94_PRE + j], "WORD_0");
-            const uint32_t m0 = (static_cast<uint32_t>(p1 - p2) << 1) + R.k8000;
-            const uint32_t qK = (static_cast<uint32_t>(q2) << 1) + R.k8000;
-            const uint32_t m1 = (static_cast<uint32_t>(q1) << 1) + qK;
-            quirkWatch(R.watch, (static_cast<uint32_t>(p2) << 1) + R.k8000, qK);
+            const uint32_t tR = shl1Add(static_cast<uint32_t>(p2), R.k8000);
+            const uint32_t m0 = shl1Add(static_cast<uint32_t>(p1), R.k10000) - tR;
+            const uint32_t qK = shl1Add(static_cast<uint32_t>(q2), R.k8000);
+            const uint32_t m1 = shl1Add(static_cast<uint32_t>(q1), qK);
+            quirkWatch(R.watch, tR, qK);
             finish(j, __builtin_amdgcn_perm(m0, m1, 0x07060302u));
         }
         if (__builtin_expect(quirkSeen(R.watch), 0))
@@ -1627,8 +1650,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
 
         uint32_t x[16];
         BflyRegs R;
-        R.k8000 = 0x8000u; R.watch = 0xFFFFu;
-        asm volatile("" : "+v"(R.k8000));                    // keep it in a vector register (VOP3 takes no literal operand)
+        R.k8000 = 0x8000u; R.k10000 = 0x10000u; R.watch = 0xFFFFu;
+        asm volatile("" : "+v"(R.k8000), "+v"(R.k10000));    // keep them in vector registers (VOP3 takes no literal operand)
         if (xf == DCS_XFORM_94)
             transform94x8(P, W, C, R, x);
         else
