@@ -656,46 +656,39 @@ __device__ __forceinline__ uint32_t mulRound(int a, int b)     // MultiplyAndRou
     return mr;
 }
 
-__device__ void dcMagnitude93(uint16_t *row)
+// (straight-line code with selects: it runs on one lane per frame while the rest of the wavefront waits)
+__device__ __forceinline__ void dcMagnitude93(uint16_t *row)
 {
-    uint32_t ar = row[0];
-    const bool neg = sx16(ar) < 0;
-    if (neg)
-        ar = static_cast<uint32_t>(-sx16(ar)) & 0xFFFFu;
-    const int f1 = sx16(row[1]);
-    uint32_t sr = prodSS(f1, f1) + prodSS(sx16(ar), sx16(ar));
-    int exponent = calcExp32(sr);
-    if (exponent < 0)
-        sr <<= -exponent;
-    ar = sr >> 16;
-    if (ar != 0)
-    {
-        const int x = sx16(ar);
-        uint32_t mr = 0x0D490000u;
-        mr += static_cast<uint32_t>(0x5D1D * x) << 1;
-        int mf = static_cast<int>(mulRound(x, x)) >> 16;
-        mr += static_cast<uint32_t>(-22035 * mf) << 1;
-        mf = static_cast<int>(mulRound(x, mf)) >> 16;
-        mr += static_cast<uint32_t>(0x46D6 * mf) << 1;
-        mf = static_cast<int>(mulRound(x, mf)) >> 16;
-        mr += static_cast<uint32_t>(-8790 * mf) << 1;
-        mf = static_cast<int>(mulRound(x, mf)) >> 16;
-        mr += static_cast<uint32_t>(0x072D * mf) << 1;
-        if (exponent & 1)
-        {
-            mr = mulRound(static_cast<int>(mr) >> 16, 0x5A82);
-            exponent += 1;
-        }
-        exponent = exponent / 2 + 1;
-        uint32_t sh;
-        if (exponent >= 0) sh = mr << exponent;
-        else sh = static_cast<uint32_t>(static_cast<int>(mr) >> (-exponent));     // arithmetic for negatives, logical == arithmetic for positives
-        ar = sh >> 16;
-        if (neg)
-            ar = static_cast<uint32_t>(-sx16(ar)) & 0xFFFFu;
-    }
-    row[0] = static_cast<uint16_t>(ar);
-    row[1] = 0;
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(row);            // row[0] | row[1] << 16 (rows are 16-byte aligned)
+    const int f0 = sx16(w), f1 = static_cast<int>(w) >> 16;
+    const bool neg = f0 < 0;
+    const int a0 = sx16(static_cast<uint32_t>(neg ? -f0 : f0));             // 16-bit negate: -(-32768) stays -32768
+    uint32_t sr = prodSS(f1, f1) + prodSS(a0, a0);
+    int exponent = calcExp32(sr);                                           // <= 0
+    sr <<= -exponent;
+    const int x = sx16(sr >> 16);
+    uint32_t mr = 0x0D490000u;
+    mr += static_cast<uint32_t>(0x5D1D * x) << 1;
+    int mf = static_cast<int>(mulRound(x, x)) >> 16;
+    mr += static_cast<uint32_t>(-22035 * mf) << 1;
+    mf = static_cast<int>(mulRound(x, mf)) >> 16;
+    mr += static_cast<uint32_t>(0x46D6 * mf) << 1;
+    mf = static_cast<int>(mulRound(x, mf)) >> 16;
+    mr += static_cast<uint32_t>(-8790 * mf) << 1;
+    mf = static_cast<int>(mulRound(x, mf)) >> 16;
+    mr += static_cast<uint32_t>(0x072D * mf) << 1;
+    // odd exponent: one more factor of sqrt(1/2), exponent made even; then exponent / 2 + 1 (C++ division of the
+    // reference: exact here, the value is even)
+    const bool odd = (exponent & 1) != 0;
+    const uint32_t mrOdd = mulRound(static_cast<int>(mr) >> 16, 0x5A82);
+    mr = odd ? mrOdd : mr;
+    exponent = ((exponent + (odd ? 1 : 0)) >> 1) + 1;
+    const uint32_t up = mr << (exponent & 31);
+    const uint32_t down = static_cast<uint32_t>(static_cast<int>(mr) >> ((-exponent) & 31));   // arithmetic for negatives
+    uint32_t ar = (exponent >= 0 ? up : down) >> 16;
+    ar = neg ? static_cast<uint32_t>(-sx16(ar)) & 0xFFFFu : ar;
+    ar = x != 0 ? ar : 0u;                                                  // a zero magnitude stays zero (:655)
+    *reinterpret_cast<uint32_t *>(row) = ar;                                // row[0] = magnitude, row[1] = 0
 }
 
 // ------------------------------------------------------------------------------------------------
