@@ -1528,14 +1528,31 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
                 err |= unpack93<R0>(T, row, br, Q, format, mixMul, is93, stamp);
             if (is93a)
             {
+                // With 16 lanes per frame (one band each) bands 16 and 17 go to the lanes of bands 0 and 1, the two
+                // shortest (their split records travel in the frame record's bandType bytes, dcs_scan.h); with fewer
+                // lanes per frame the lane that holds band 15 takes them as well.
+                constexpr bool kSpreadTail = SUB == 16;
                 const int end = Q.bandBase + Q.nb;
-                const int end2 = (end >= 16 && nBands > 16) ? nBands : end;
+                const int end2 = (!kSpreadTail && end >= 16 && nBands > 16) ? nBands : end;
                 const int prv0 = Q.bandBase == 0 ? 0x1A : sx16(Q.prv), out0 = Q.bandBase == 0 ? 0 : Q.outIdx;
+                const int hb0 = static_cast<int>(Q.h0 & 0xFFu);
                 if (pairTableInLds(FPW))
-                    err |= unpack93a<R0>(T, row, br, static_cast<int>(Q.h0 & 0xFFu), mixMul,
-                                         reinterpret_cast<const uint16_t *>(smem + ldsBytes(FPW) - 4096), Q.bandBase, end2, prv0, out0);
+                    err |= unpack93a<R0>(T, row, br, hb0, mixMul, reinterpret_cast<const uint16_t *>(smem + ldsBytes(FPW) - 4096),
+                                         Q.bandBase, end2, prv0, out0);
                 else
-                    err |= unpack93a<R0>(T, row, br, static_cast<int>(Q.h0 & 0xFFu), mixMul, a.tables->pair93a, Q.bandBase, end2, prv0, out0);
+                    err |= unpack93a<R0>(T, row, br, hb0, mixMul, a.tables->pair93a, Q.bandBase, end2, prv0, out0);
+                if (kSpreadTail && pairTableInLds(FPW) && q < 2 && 16 + q < nBands)
+                {
+                    const uint32_t r0 = q == 0 ? Q.t0 : Q.t2, r1 = q == 0 ? Q.t1 : Q.t3;       // DcsSplit of band 16 + q
+                    if (!((r1 >> 16) & 0x800u))                                                   // (the frame had not ended)
+                    {
+                        const uint32_t inPool2 = static_cast<uint32_t>(bitPos & 31) + (r0 & 0xFFFFu);
+                        BitReader br2;
+                        br2.init(pool + off + (inPool2 >> 5), static_cast<int>(inPool2 & 31));
+                        err |= unpack93a<R0>(T, row, br2, hb0, mixMul, reinterpret_cast<const uint16_t *>(smem + ldsBytes(FPW) - 4096),
+                                             16 + q, 17 + q, sx16(r0 >> 16), static_cast<int>((r1 >> 16) & 0x1FFu));
+                    }
+                }
             }
             waveSync();
         };

@@ -299,9 +299,23 @@ DCS_HD void dcsScan93a(DcsScan<R> &s, const DcsScanTables &tabs, DcsFrameIndex &
     int outIdx = 0;
     bool ended = false;
 
+    // An OS93a Type-1 frame has up to 18 bands but no band-type codes: the 16 bandType bytes of its record hold the
+    // split records of bands 16 and 17 (same layout as DcsSplit), so that two more lanes can share the frame's tail
+    for (int i = 0 ; i < 16 ; ++i)
+        fi.bandType[i] = 0;
     for (int band = 0 ; band < numBands ; ++band)
     {
         dcsPutSplit(fi, band, frameStart, s, outIdx, static_cast<uint32_t>(prvScale), 0, 0, ended);
+        if (band == 16 || band == 17)
+        {
+            uint8_t *rec = fi.bandType + (band - 16) * 8;
+            const uint32_t bitDelta = s.b.bitPos() - frameStart;
+            const uint32_t state = static_cast<uint32_t>(outIdx & 0x1FF) | (ended ? 0x800u : 0u);
+            rec[0] = static_cast<uint8_t>(bitDelta); rec[1] = static_cast<uint8_t>(bitDelta >> 8);
+            rec[2] = static_cast<uint8_t>(prvScale); rec[3] = static_cast<uint8_t>(static_cast<uint32_t>(prvScale) >> 8);
+            rec[4] = 0; rec[5] = 0;
+            rec[6] = static_cast<uint8_t>(state); rec[7] = static_cast<uint8_t>(state >> 8);
+        }
         if (ended)
             continue;
         if (band >= 18) { dcsFatal(s); return; }

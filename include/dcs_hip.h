@@ -97,7 +97,9 @@ typedef struct DcsFrameIndex
                                           band 0 starts at bitOff + hdrBits.  0 for the 1993 formats     */
     uint8_t  bandType[16];             /* 1994+: band-type codes AFTER this frame's header deltas;
                                           OS93b Type 1: codes carried INTO the frame (AudioStream::
-                                          bandTypeBuf); values above 255 are stored as 255               */
+                                          bandTypeBuf); values above 255 are stored as 255;
+                                          OS93a Type 1 (no band-type codes, up to 18 bands): two DcsSplit
+                                          records, of bands 16 and 17                                    */
     uint16_t preAdj;                   /* 1994+ Type 1: scale pre-adjust of bands 0..2 (4 bits each),
                                           derived from the PREVIOUS frame's codes (:1771-1773)           */
     uint8_t  nBands;                   /* populated header bands (stream constant)                       */
