@@ -619,9 +619,9 @@ __device__ __forceinline__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *r
             scaleCode -= 0x36;
         prvScale = scaleCode - bandBits * 2;
 
-        uint32_t sf = 0x8000;
-        for (int i = 0 ; i < (scaleCode & 3) ; ++i)
-            sf = (sf * 0x9838u) >> 15;
+        // 0x8000 times (0x9838 / 2^15)^(code & 3), each step truncated (:2986-2990): four constants
+        constexpr uint32_t kS1 = (0x8000u * 0x9838u) >> 15, kS2 = (kS1 * 0x9838u) >> 15, kS3 = (kS2 * 0x9838u) >> 15;
+        uint32_t sf = (scaleCode & 2) ? ((scaleCode & 1) ? kS3 : kS2) : ((scaleCode & 1) ? kS1 : 0x8000u);
         sf <<= (scaleCode >> 2);
         sf = ((sf >> 16) * mixMul) >> 15;
         const int sfs = sx16(sf);                   // truncated to 16 bits, then read as signed (:2995, :3011)
@@ -629,10 +629,11 @@ __device__ __forceinline__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *r
         const auto pairBase = pairTable + (2 << bandBits);
         for (int i = 0 ; i < numInputs ; ++i)
         {
-            const auto pair = pairBase + 2 * br.get(bandBits);
+            // (a pair sits at an even index of the table: one 32-bit read)
+            const uint32_t pairWord = *reinterpret_cast<const uint32_t *>(pairBase + 2 * br.get(bandBits));
             for (int k = 0 ; k < 2 ; ++k, ++outIdx)
             {
-                const int p = mul24(sx16(pair[k]), sfs);
+                const int p = mul24(k == 0 ? sx16(pairWord) : static_cast<int>(pairWord) >> 16, sfs);
                 uint16_t *cell = &row[min(outIdx, kDummyWord)];                 // (254 words at most with a matching record)
                 // (first source of the frame: the accumulator is still zero, no index is written twice by one source)
                 const uint32_t acc = FIRST ? 0u : static_cast<uint32_t>(*cell) << 16;

@@ -187,3 +187,4 @@ static_assert(offsetof(DcsSrcDesc, idx) == 12, "DcsSrcDesc layout");
 static_assert(sizeof(DcsFrameJob) == 16, "DcsFrameJob layout");
 static_assert(sizeof(DcsFrameIndex) == 148 && offsetof(DcsFrameIndex, split) == 28, "DcsFrameIndex layout");
 static_assert(sizeof(DcsSlot) == 32, "DcsSlot layout");
+static_assert(offsetof(DcsDevTables, pair93a) % 4 == 0, "OS93a sample pairs are read as 32-bit words");
