@@ -1558,9 +1558,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
             waveSync();
         };
 
-#ifdef DCS_EXP_NO_PHASE1
-        if (a.nChunks > 0x7FFFFFF0u)
-#endif
         {
             if (__any(myNSrc > 0))
                 unpackRound(std::true_type{}, 0);
@@ -1613,9 +1610,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
             earlyWord = __hip_atomic_load(firstImportSrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
-#ifdef DCS_EXP_NO_PHASE2
-    if (nSlots > 1000)
-#endif
     for (int s0 = 0 ; s0 < nSlots ; )
     {
         const int xf = __builtin_amdgcn_readlane(jobXform, s0);

@@ -394,11 +394,9 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
 template <int FPW>
 static hipError_t launch(const DcsKernelArgs &args, hipStream_t stream)
 {
-    // DCS_EXTRA_LDS (bytes): experiment knob, lowers occupancy by requesting unused LDS
-    static const int extraLds = getenv("DCS_EXTRA_LDS") ? atoi(getenv("DCS_EXTRA_LDS")) : 0;
     // a multiple of 8 workgroups: the kernel deals them out to the XCDs in contiguous runs of chunks (dcs_kernels.hip.h)
     const uint32_t blocks = ((args.nChunks + dcsk::kWavesPerBlock - 1) / dcsk::kWavesPerBlock + 7u) & ~7u;
-    dcsk::dcsDecodeKernel<FPW><<<dim3(blocks), dim3(64 * dcsk::kWavesPerBlock), dcsk::ldsBytes(FPW) + extraLds, stream>>>(args);
+    dcsk::dcsDecodeKernel<FPW><<<dim3(blocks), dim3(64 * dcsk::kWavesPerBlock), dcsk::ldsBytes(FPW), stream>>>(args);
     return hipGetLastError();
 }
 
