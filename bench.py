@@ -100,8 +100,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.run(stream)
+    batch.run_many(args.steps, stream)      # K launches back to back (one step = one launch), issued from C
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()

@@ -79,7 +79,7 @@ _LIB = None
 EXPORTS = [
     "dcs_abi_version", "dcs_index_stream", "dcs_volume_multiplier", "dcs_mixing_multiplier", "dcs_frame_scale",
     "dcs_stream_params", "dcs_ctx_create", "dcs_ctx_destroy", "dcs_last_error", "dcs_device_count",
-    "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run",
+    "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run", "dcs_batch_run_many",
     "dcs_batch_time", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_download_view", "dcs_batch_device_pcm",
     "dcs_batch_algorithmic_bytes", "dcs_batch_num_jobs", "dcs_decode_streams", "dcs_count_stream_frames",
     "dcs_synth_stream", "dcs_plan_chunks", "dcs_index_streams", "dcs_index_streams_gpu",
@@ -150,6 +150,8 @@ def load_library():
     L.dcs_batch_destroy.argtypes = [vp]
     L.dcs_batch_run.restype = i32
     L.dcs_batch_run.argtypes = [vp, vp]
+    L.dcs_batch_run_many.restype = i32
+    L.dcs_batch_run_many.argtypes = [vp, vp, ctypes.c_int]
     L.dcs_batch_time.restype = i32
     L.dcs_batch_time.argtypes = [vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
     L.dcs_batch_sync.restype = i32
@@ -606,6 +608,9 @@ class Batch:
 
     def run(self, stream=None):
         _check(self.L.dcs_batch_run(self.h, ctypes.c_void_p(stream) if stream else None), self.ctx.h)
+
+    def run_many(self, count, stream=None):
+        _check(self.L.dcs_batch_run_many(self.h, ctypes.c_void_p(stream) if stream else None, int(count)), self.ctx.h)
 
     def time(self, iters, stream=None):
         ms = ctypes.c_float(0)

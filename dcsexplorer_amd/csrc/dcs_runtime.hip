@@ -419,6 +419,21 @@ extern "C" DcsStatus dcs_batch_run(DcsBatch *b, void *hipStream)
     return DCS_OK;
 }
 
+// `count` launches back to back without returning to the caller in between (a caller that drives the steps from an
+// interpreted language would otherwise be slower per launch than the kernel of a small batch)
+extern "C" DcsStatus dcs_batch_run_many(DcsBatch *b, void *hipStream, int count)
+{
+    if (b == nullptr || count < 0)
+        return DCS_ERR_INVALID_ARG;
+    for (int i = 0 ; i < count ; ++i)
+    {
+        const DcsStatus st = dcs_batch_run(b, hipStream);
+        if (st != DCS_OK)
+            return st;
+    }
+    return DCS_OK;
+}
+
 extern "C" DcsStatus dcs_batch_time(DcsBatch *b, void *hipStream, int iters, float *avgMs)
 {
     if (b == nullptr || iters < 1 || avgMs == nullptr)

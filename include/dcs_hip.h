@@ -224,6 +224,8 @@ void      dcs_batch_destroy(DcsBatch *batch);
 /* Enqueue the decode on `hipStream` (a hipStream_t passed as void*; NULL = the context's stream).
  * Asynchronous: returns after the launch. */
 DcsStatus dcs_batch_run(DcsBatch *batch, void *hipStream);
+/* The same `count` times back to back (one call from the host language for many launches). */
+DcsStatus dcs_batch_run_many(DcsBatch *batch, void *hipStream, int count);
 /* Run `iters` times bracketed by HIP events on the same stream and return the average kernel
  * duration in milliseconds (what bench.py's roofline block divides by). */
 DcsStatus dcs_batch_time(DcsBatch *batch, void *hipStream, int iters, float *avgMs);
