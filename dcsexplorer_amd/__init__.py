@@ -11,6 +11,6 @@ from .api import (  # noqa: F401
     SRC_DTYPE, JOB_DTYPE, INDEX_DTYPE, IDX_SERIAL,
     DcsError, lib_path, load_library,
     index_stream, index_streams, pack_streams, stream_params, volume_multiplier, mixing_multiplier, frame_scale,
-    synth_stream, wav_header, dcsa_header, dcsa_parse, frame_diff, build_stream_batch, device_count, plan_chunks, format_os,
+    synth_stream, wav_header, dcsa_header, dcsa_parse, frame_diff, build_stream_batch, device_count, plan_chunks, pack_chunks, format_os,
     Context, Batch, RomSet, Sequencer, HW_DCS93, HW_DCS95,
 )

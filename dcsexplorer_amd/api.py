@@ -79,7 +79,7 @@ _LIB = None
 EXPORTS = [
     "dcs_abi_version", "dcs_index_stream", "dcs_volume_multiplier", "dcs_mixing_multiplier", "dcs_frame_scale",
     "dcs_stream_params", "dcs_ctx_create", "dcs_ctx_destroy", "dcs_last_error", "dcs_device_count",
-    "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run", "dcs_batch_run_many",
+    "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run", "dcs_batch_run_many", "dcs_pack_chunks",
     "dcs_batch_time", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_download_view", "dcs_batch_device_pcm",
     "dcs_batch_algorithmic_bytes", "dcs_batch_num_jobs", "dcs_decode_streams", "dcs_count_stream_frames",
     "dcs_synth_stream", "dcs_plan_chunks", "dcs_index_streams", "dcs_index_streams_gpu",
@@ -140,6 +140,8 @@ def load_library():
     L.dcs_ctx_set_frames_per_wave.argtypes = [vp, ctypes.c_int]
     L.dcs_ctx_set_tail_handoff.restype = i32
     L.dcs_ctx_set_tail_handoff.argtypes = [vp, ctypes.c_int]
+    L.dcs_pack_chunks.restype = i32
+    L.dcs_pack_chunks.argtypes = [vp, u32, vp, vp, sz, ctypes.c_int, vp, sz, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.dcs_plan_chunks2.restype = i32
     L.dcs_plan_chunks2.argtypes = [vp, u32, vp, ctypes.c_int, ctypes.c_int, vp, sz, ctypes.POINTER(u32)]
     L.dcs_decode_batch.restype = i32
@@ -473,6 +475,19 @@ def plan_chunks(jobs, fpw, srcs=None, handoff=True):
     out["prevSlot"] = (raw >> 32) & 0xFF
     out["flags"] = (raw >> 40) & 0xFF
     return out.reshape(n.value, fpw)
+
+
+def pack_chunks(blob, srcs, jobs, fpw):
+    """dcs_pack_chunks -> uint8 array [nChunks, packageBytes] (what a batch uploads for unpack round 0)"""
+    L = load_library()
+    blob_a = np.frombuffer(bytes(blob), dtype=np.uint8)
+    srcs = np.ascontiguousarray(srcs, dtype=SRC_DTYPE)
+    jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+    n, pb = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    _check(L.dcs_pack_chunks(_ptr(jobs), jobs.size, _ptr(srcs), _ptr(blob_a), blob_a.size, fpw, None, 0, ctypes.byref(n), ctypes.byref(pb)))
+    out = np.zeros((n.value, pb.value), dtype=np.uint8)
+    _check(L.dcs_pack_chunks(_ptr(jobs), jobs.size, _ptr(srcs), _ptr(blob_a), blob_a.size, fpw, _ptr(out), out.size, ctypes.byref(n), ctypes.byref(pb)))
+    return out
 
 
 def device_count():

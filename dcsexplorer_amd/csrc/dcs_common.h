@@ -142,8 +142,8 @@ struct DcsSlot                          // 32 bytes: everything the kernel needs
     uint16_t runPoolOff;                // pool dword where run k goes (a multiple of 4)
 };
 
-// Chunk packages.  Everything unpack round 0 of a chunk needs, gathered once per batch by dcsPackKernel into one
-// block at a fixed stride, so that a wavefront requests ALL of it at its first instruction (no load depends on
+// Chunk packages.  Everything unpack round 0 of a chunk needs, gathered once per batch by the host packer
+// (dcsBuildPackages, dcs_plan.cpp) into one block at a fixed stride, so that a wavefront requests ALL of it at its first instruction (no load depends on
 // another load):  slots [fpw] (32 B) | descriptor heads [fpw] (first 40 bytes of DcsSrcDesc, padded to 48) |
 // stream headers [fpw] (16 B, already aligned; a 1-byte header zero-extended) | the split record of every lane [64]
 // (8 B; zero for a frame's first lane) | the image of the bit pool (runs placed, dwords in bit order).
@@ -180,7 +180,6 @@ struct DcsKernelArgs
     const uint8_t      *blob;
     uint64_t            blobLen;        // bytes that may be read (allocation is padded beyond this)
     const DcsSrcDesc   *srcs;
-    const DcsSlot      *slots;          // nChunks x fpw (read by the pack kernel only)
     uint8_t            *packages;       // nChunks x dcsPkgBytes(fpw), see above
     uint32_t            nChunks;
     uint32_t            nJobs;
@@ -202,4 +201,7 @@ struct DcsKernelArgs
 #ifdef __cplusplus
 #include <vector>
 uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true);
+// packer: out = nChunks x dcsPkgBytes(fpw) bytes (the chunk packages described above)
+void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const DcsSrcDesc *srcs,
+                      const uint8_t *blob, size_t blobLen, uint8_t *out);
 #endif

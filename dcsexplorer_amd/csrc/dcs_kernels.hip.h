@@ -10,7 +10,7 @@
 //            work on the serial entropy decode (16..80 dependent symbol decodes per lane instead of
 //            ~250 per frame).  Everything a chunk needs -- slots, descriptor heads, headers, split records,
 //            the compressed bytes as an image of the LDS bit pool (dwords in bit order) -- was gathered once
-//            per batch into the chunk's PACKAGE by dcsPackKernel and is requested with the wavefront's first
+//            per batch into the chunk's PACKAGE by the host (dcsBuildPackages) and is requested with the wavefront's first
 //            instructions, so the per-symbol critical path never waits on HBM/L2.
 //            [DecoderImpl94x/93/93a::DecompressFrame, DCSDecoderNative.cpp:1679-2261, :2293-2684,
 //             :2831-3032; ROMBitPointer, DCSDecoderNative.h:229-289]
@@ -1137,74 +1137,6 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const TwA &W, c
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
         x[r] = pkAshr(x[r], P.shiftPair);
-}
-
-// ------------------------------------------------------------------------------------------------
-// dcsPackKernel: builds the chunk packages (dcs_common.h) once per batch, one wavefront per chunk.  A layout
-// change only -- slots, descriptor heads, headers, split records and compressed bytes are copied next to
-// each other, the compressed dwords swapped into bit order on the way; nothing is decoded here.
-// ------------------------------------------------------------------------------------------------
-template <int FPW>
-__global__ void __launch_bounds__(64) dcsPackKernel(const DcsKernelArgs a)
-{
-    const uint32_t chunk = blockIdx.x;
-    const int lane = static_cast<int>(threadIdx.x);
-    if (chunk >= a.nChunks)
-        return;
-    constexpr int SUB = subLanes(FPW);
-    const int s = lane % FPW, q = lane / FPW;
-    uint8_t *pkg = a.packages + static_cast<size_t>(chunk) * dcsPkgBytes(FPW);
-    const DcsSlot *slots = a.slots + static_cast<size_t>(chunk) * FPW;
-    const DcsSlot sl = slots[s];
-    const uint32_t *blobW = reinterpret_cast<const uint32_t *>(a.blob);
-    const uint32_t blobWords = static_cast<uint32_t>((a.blobLen + 3) >> 2);
-    const bool has = !(sl.flags & DCS_SLOT_EMPTY) && sl.nSrc != 0;
-
-    if (lane < FPW * 2)
-        reinterpret_cast<uint4 *>(pkg)[lane] = reinterpret_cast<const uint4 *>(slots)[lane];
-    const uint32_t *sd = reinterpret_cast<const uint32_t *>(&a.srcs[has ? sl.firstSrc : 0]);
-    if (q == 0)
-    {
-        uint32_t *dst = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffDesc(FPW)) + s * 12;
-        for (int i = 0 ; i < 12 ; ++i)
-            dst[i] = (has && i < 10) ? sd[i] : 0u;
-        // the 16 header bytes at streamOff + 2 (a 1-byte header: the byte alone)
-        uint32_t *hd = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffHdr(FPW)) + s * 4;
-        uint32_t w[5] = { 0, 0, 0, 0, 0 };
-        if (has)
-            for (int i = 0 ; i < 5 ; ++i)
-                w[i] = sl.hdrDw + i < blobWords ? blobW[sl.hdrDw + i] : 0u;
-        const bool oneByte = has && (sd[2] >> 24) == 1;
-        for (int i = 0 ; i < 4 ; ++i)
-        {
-            uint32_t v = __builtin_amdgcn_alignbyte(w[i + 1], w[i], static_cast<uint32_t>(sl.hdrSh));
-            if (oneByte)
-                v = i == 0 ? (v & 0xFFu) : 0u;
-            hd[i] = v;
-        }
-    }
-    {
-        // DcsSplit of band q * bpl = split[q * bpl - 1], 8 bytes each from descriptor dword 10
-        uint2 sp = make_uint2(0, 0);
-        const int bpl = sl.bpl;
-        if (has && q != 0 && q < SUB && bpl != 0 && q * bpl < 16)
-            sp = reinterpret_cast<const uint2 *>(sd)[5 + q * bpl - 1];
-        reinterpret_cast<uint2 *>(pkg + dcsPkgOffSplit(FPW))[lane] = sp;
-    }
-    uint32_t *img = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffPool(FPW));
-    for (int i = lane ; i < poolDwords(FPW) ; i += 64)
-        img[i] = 0u;
-    __syncthreads();
-    for (int k = 0 ; k < FPW ; ++k)
-    {
-        const uint32_t n = slots[k].runNDw, st = slots[k].runStartDw, o = slots[k].runPoolOff;
-        if (n == 0)
-            break;
-        if (o + n > static_cast<uint32_t>(poolDwords(FPW)))
-            continue;                                       // cannot happen with the library's planner
-        for (uint32_t i = static_cast<uint32_t>(lane) ; i < n ; i += 64)
-            img[o + i] = st + i < blobWords ? __builtin_bswap32(blobW[st + i]) : 0u;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

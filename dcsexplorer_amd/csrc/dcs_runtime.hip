@@ -74,13 +74,13 @@ struct DcsBatch
     DcsCtx *ctx = nullptr;
     uint32_t nJobs = 0, nSrcs = 0, nTailsIn = 0;
     size_t blobLen = 0;
+    size_t blobOnDevice = 0;                // bytes of the blob that were uploaded (0 when no frame has a second source)
     int fpw = 0;
     uint32_t nChunks = 0;
     uint64_t algoBytes = 0;
     // device buffers
     uint8_t *dBlob = nullptr;
     DcsSrcDesc *dSrcs = nullptr;
-    DcsSlot *dSlots = nullptr;
     int16_t *dTailsIn = nullptr;
     int16_t *dPcm = nullptr;
     uint32_t *dErr = nullptr;
@@ -230,7 +230,7 @@ extern "C" void dcs_batch_destroy(DcsBatch *b)
         return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);         // nothing of this batch is in flight when its buffers are recycled
-    void *ptrs[] = { b->dBlob, b->dSrcs, b->dSlots, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug, b->dHandoff, b->dPackages };
+    void *ptrs[] = { b->dBlob, b->dSrcs, nullptr, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug, b->dHandoff, b->dPackages };
     for (int i = 0 ; i < 10 ; ++i)
         cacheFree(b->ctx, false, ptrs[i], b->cap[i]);
     cacheFree(b->ctx, true, b->hPcm, b->hCap[0]);
@@ -244,9 +244,8 @@ static DcsKernelArgs kernelArgs(const DcsBatch *b)
 {
     DcsKernelArgs args;
     args.blob = b->dBlob;
-    args.blobLen = b->blobLen;
+    args.blobLen = b->blobOnDevice;
     args.srcs = b->dSrcs;
-    args.slots = b->dSlots;
     args.packages = b->dPackages;
     args.nChunks = b->nChunks;
     args.nJobs = b->nJobs;
@@ -260,15 +259,6 @@ static DcsKernelArgs kernelArgs(const DcsBatch *b)
     args.epoch = b->epoch;
     args.flags = b->flags;
     return args;
-}
-
-// once per batch: gather what unpack round 0 of every chunk needs into the chunk packages (a layout change on the
-// device; nothing is decoded)
-template <int FPW>
-static hipError_t launchPack(const DcsKernelArgs &args, hipStream_t stream)
-{
-    dcsk::dcsPackKernel<FPW><<<dim3(args.nChunks), dim3(64), 0, stream>>>(args);
-    return hipGetLastError();
 }
 
 extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
@@ -336,6 +326,8 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
     b->flags = batchFlags;
 
     std::vector<DcsSlot> slots;
+    uint8_t *hPackages = nullptr;           // pinned staging for the chunk packages
+    size_t pkgBytes = 0;
     b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, ctx->handoff);
 
     // algorithmic bytes: compressed payload + descriptors read (one DcsSrcDesc per source, one
@@ -345,18 +337,31 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
 
     DcsStatus st = [&]() -> DcsStatus {
         HIPCHK(ctx, hipSetDevice(ctx->device));
-        const size_t blobAlloc = ((blobLen + 3) & ~size_t(3)) + 64;         // zero tail: the bit reader prefetches past the end
-        b->cap[0] = blobAlloc; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dBlob), b->cap[0]));
-        HIPCHK(ctx, hipMemsetAsync(b->dBlob, 0, blobAlloc, ctx->stream));
-        if (blobLen)
-            HIPCHK(ctx, hipMemcpyAsync(b->dBlob, blob, blobLen, hipMemcpyHostToDevice, ctx->stream));
-        if (nSrcs)
+        // Round 0 of every frame reads the chunk packages only; the streams and the full descriptors are needed on the
+        // device just for the further sources of multi-channel frames.
+        bool multi = false;
+        for (uint32_t j = 0 ; j < nJobs && !multi ; ++j)
+            multi = jobs[j].nSrc > 1;
+        b->blobOnDevice = multi ? blobLen : 0;
+        if (multi)
+        {
+            const size_t blobAlloc = ((blobLen + 3) & ~size_t(3)) + 64;     // zero tail: the bit reader prefetches past the end
+            b->cap[0] = blobAlloc; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dBlob), b->cap[0]));
+            HIPCHK(ctx, hipMemsetAsync(b->dBlob, 0, blobAlloc, ctx->stream));
+            if (blobLen)
+                HIPCHK(ctx, hipMemcpyAsync(b->dBlob, blob, blobLen, hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (multi && nSrcs)
         {
             b->cap[1] = sizeof(DcsSrcDesc) * nSrcs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dSrcs), b->cap[1]));
             HIPCHK(ctx, hipMemcpyAsync(b->dSrcs, srcs, sizeof(DcsSrcDesc) * nSrcs, hipMemcpyHostToDevice, ctx->stream));
         }
-        b->cap[2] = sizeof(DcsSlot) * slots.size(); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dSlots), b->cap[2]));
-        HIPCHK(ctx, hipMemcpyAsync(b->dSlots, slots.data(), sizeof(DcsSlot) * slots.size(), hipMemcpyHostToDevice, ctx->stream));
+        // built in pinned host memory (recycled by the context like the device buffers): the upload runs at link speed
+        pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw);
+        HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&hPackages), pkgBytes));
+        dcsBuildPackages(slots.data(), b->nChunks, b->fpw, srcs, blob, blobLen, hPackages);
+        b->cap[9] = pkgBytes; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPackages), b->cap[9]));
+        HIPCHK(ctx, hipMemcpyAsync(b->dPackages, hPackages, pkgBytes, hipMemcpyHostToDevice, ctx->stream));
         if (nTailsIn)
         {
             b->cap[3] = sizeof(int16_t) * 16 * nTailsIn; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsIn), b->cap[3]));
@@ -372,16 +377,14 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
         b->cap[7] = sizeof(unsigned long long) * 16 * (b->nChunks + 4); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dDebug), b->cap[7]));
         HIPCHK(ctx, hipMemsetAsync(b->dDebug, 0, sizeof(unsigned long long) * 16 * (b->nChunks + 4), ctx->stream));
 #endif
-        b->cap[9] = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPackages), b->cap[9]));
-        {
-            const DcsKernelArgs args = kernelArgs(b);
-            HIPCHK(ctx, b->fpw == 16 ? launchPack<16>(args, ctx->stream) : b->fpw == 8 ? launchPack<8>(args, ctx->stream) : launchPack<4>(args, ctx->stream));
-        }
         HIPCHK(ctx, hipEventCreate(&b->ev0));
         HIPCHK(ctx, hipEventCreate(&b->ev1));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         return DCS_OK;
     }();
+    if (st != DCS_OK)
+        (void)hipStreamSynchronize(ctx->stream);    // (on success the lambda has already waited for the uploads)
+    cacheFree(ctx, true, hPackages, pkgBytes);
     if (st != DCS_OK)
     {
         dcs_batch_destroy(b);

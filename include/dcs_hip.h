@@ -466,6 +466,14 @@ DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcD
 DcsStatus dcs_plan_chunks2(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, int handoff,
                            uint64_t *slotsOut, size_t cap, uint32_t *nChunksOut);
 
+/* Diagnostic: the chunk packages dcs_batch_create uploads for `jobs` at `fpw` frames per wavefront (4, 8 or 16): per
+ * chunk, at a fixed stride of *packageBytesOut bytes, the slots (32 B each), the first 40 bytes of each slot's first
+ * DcsSrcDesc (at a 48-byte pitch), the 16 stream-header bytes of each slot, one 8-byte split record per lane, and the
+ * image of the kernel's bit pool (the chunk's compressed dwords in bit order).  out = NULL to size. */
+DcsStatus dcs_pack_chunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs,
+                          const uint8_t *blob, size_t blobLen, int fpw,
+                          uint8_t *out, size_t cap, uint32_t *nChunksOut, uint32_t *packageBytesOut);
+
 uint32_t dcs_abi_version(void);
 
 #ifdef __cplusplus

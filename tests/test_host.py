@@ -143,6 +143,62 @@ def test_chunk_plan_properties(fpw, handoff):
         assert 0 < halos_interleaved <= plan.shape[0]
 
 
+@pytest.mark.parametrize("fpw", [4, 8, 16])
+def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
+    """the host packer (what a batch uploads): slots, descriptor heads, aligned headers, per-lane split records and
+    a bit-pool image from which every frame's bits can be read back at the position its slot names"""
+    b = workloads.build("mixed_16384", n_streams=18, n_frames=29)
+    blob, srcs, jobs = bytes(b["blob"]), b["srcs"], b["jobs"]
+    pk = D.pack_chunks(blob, srcs, jobs, fpw)
+    plan = D.plan_chunks(jobs, fpw, srcs)
+    assert pk.shape[0] == plan.shape[0]
+    sub = 64 // fpw
+    off_desc, off_hdr, off_split, off_pool = fpw * 32, fpw * 80, fpw * 96, fpw * 96 + 512
+    pool_dw = max(fpw * 56, 320)
+    assert pk.shape[1] == off_pool + pool_dw * 4
+    src_bytes = srcs.view(np.uint8).reshape(srcs.size, -1)
+    seen = 0
+    for c in range(pk.shape[0]):
+        slots = pk[c, :off_desc].view("<u4").reshape(fpw, 8)
+        pool = pk[c, off_pool:].view("<u4")
+        for s in range(fpw):
+            flags = (int(slots[s, 1]) >> 8) & 0xFF
+            assert int(slots[s, 0]) == int(plan[c, s]["job"]) and flags == int(plan[c, s]["flags"])
+            if flags & 0x80:
+                continue
+            job = jobs[int(slots[s, 0])]
+            assert int(slots[s, 2]) == int(job["firstSrc"]) and ((int(slots[s, 1]) >> 16) & 0xFF) == int(job["nSrc"])
+            if job["nSrc"] == 0:
+                continue
+            sd = srcs[int(job["firstSrc"])]
+            # descriptor head: the first 40 bytes of the DcsSrcDesc
+            assert np.array_equal(pk[c, off_desc + 48 * s: off_desc + 48 * s + 40], src_bytes[int(job["firstSrc"]), :40])
+            # header: the bytes behind the U16 frame count
+            so, hl = int(sd["streamOff"]), int(sd["hdrLen"])
+            want_hdr = np.zeros(16, np.uint8); want_hdr[:hl] = np.frombuffer(blob[so + 2: so + 2 + hl], np.uint8)
+            assert np.array_equal(pk[c, off_hdr + 16 * s: off_hdr + 16 * s + 16], want_hdr)
+            # split records: lane q of the frame starts at band q * bpl
+            bpl = (int(slots[s, 7]) >> 8) & 0xFF
+            for q in range(1, sub):
+                rec = pk[c, off_split + 8 * (s + q * fpw): off_split + 8 * (s + q * fpw) + 8]
+                if bpl != 0 and q * bpl < 16:
+                    want = sd["idx"]["split"][q * bpl - 1]
+                    assert np.array_equal(rec, np.frombuffer(want.tobytes(), np.uint8))
+                else:
+                    assert not rec.any()
+            # the frame's bits, read MSB-first from the pool image at the slot's position, are the stream's
+            pool_off = int(slots[s, 5]) >> 16
+            bit0 = (so + 2 + hl) * 8 + int(sd["idx"]["bitOff"])
+            nbits = int(sd["idx"]["nBits"])
+            for k in (0, nbits // 2, max(nbits - 1, 0)):
+                pos = (bit0 & 31) + k
+                got = (int(pool[pool_off + (pos >> 5)]) >> (31 - (pos & 31))) & 1
+                byte = blob[(bit0 + k) >> 3] if ((bit0 + k) >> 3) < len(blob) else 0
+                assert got == (byte >> (7 - ((bit0 + k) & 7))) & 1
+            seen += 1
+    assert seen >= jobs.size
+
+
 def test_workload_builders_shape():
     b = workloads.build("dcs93_4096")
     assert b["jobs"].size == 4096 and b["srcs"].size == 4096
