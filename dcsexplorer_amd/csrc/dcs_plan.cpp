@@ -59,13 +59,16 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
         return (dcsPoolDwords(sd.streamOff, sd.hdrLen, sd.idx.bitOff, sd.idx.nBits) + 3) & ~3u;
     };
     auto poolFits = [&](uint32_t j, uint32_t halo, bool withHalo) {
-        for (uint32_t r = 0 ; r < DCS_MAX_CHANNELS ; ++r)
+        uint32_t rounds = jobs[j].nSrc;
+        if (withHalo && jobs[halo].nSrc > rounds)
+            rounds = jobs[halo].nSrc;
+        for (uint32_t r = 0 ; r < rounds && r < DCS_MAX_CHANNELS ; ++r)
             if (poolUse[r] + poolNeed(j, r) + (withHalo ? poolNeed(halo, r) : 0) > poolCap)
                 return false;
         return true;
     };
     auto poolAdd = [&](uint32_t j) {
-        for (uint32_t r = 0 ; r < DCS_MAX_CHANNELS ; ++r)
+        for (uint32_t r = 0 ; r < jobs[j].nSrc && r < DCS_MAX_CHANNELS ; ++r)
             poolUse[r] += poolNeed(j, r);
     };
 
@@ -283,7 +286,10 @@ static void packChunks(const DcsSlot *slots, uint32_t c0, uint32_t c1, int fpw, 
             // the image is an array of uint32 on a little-endian machine: byte j of the stream goes to byte (j ^ 3)
             for (size_t j = 0 ; j + 4 <= avail ; j += 4)
             {
-                dst[j] = blob[b0 + j + 3]; dst[j + 1] = blob[b0 + j + 2]; dst[j + 2] = blob[b0 + j + 1]; dst[j + 3] = blob[b0 + j];
+                uint32_t w;
+                memcpy(&w, blob + b0 + j, 4);
+                w = __builtin_bswap32(w);
+                memcpy(dst + j, &w, 4);
             }
             for (size_t j = avail & ~static_cast<size_t>(3) ; j < avail ; ++j)
                 dst[j ^ 3] = blob[b0 + j];
