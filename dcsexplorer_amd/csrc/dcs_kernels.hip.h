@@ -44,7 +44,6 @@ struct Stamper
 };
 #define DCS_STAMP(k) stamp(k)
 
-constexpr int kHandoffL2Polls = 6;       // polls of the XCD's L2 before the polls go to memory
 constexpr unsigned long long kHandoffTimeoutTicks = 400000000ull;    // bound of the wait for a tail from another chunk: 4 s (100 MHz ticks)
 constexpr int kWavesPerBlock = 4;       // wavefronts of a workgroup share one copy of the decode tables in LDS
 constexpr int kRowBytes = 528;          // 256 words + 16 bytes: 16-byte aligned rows (the transforms transpose through them
@@ -1152,13 +1151,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
     static_assert(kPoolBytes % 16 == 0 && kWavesPerBlock * kTileBytes >= 8192, "LDS layout");
     const Lds<FPW> L{ smem, smem + sizeof(DcsLdsTables) + kWavesPerBlock * kPoolBytes + wave * kTileBytes,
                       smem + sizeof(DcsLdsTables) + wave * kPoolBytes };
-    // Workgroups go to the eight XCDs round-robin (workgroup b -> XCD b mod 8).  Consecutive chunks of a stream hand
-    // their overlap tails to each other, so consecutive workgroups' worth of chunks are given to ONE XCD, where the
-    // hand-off word is served by that XCD's L2: XCD x takes the chunks of "logical workgroups" [x * per, (x + 1) * per).
-    // (The grid is a multiple of 8 workgroups; logical workgroups past the last chunk have nothing to do.)
-    const uint32_t perXcd = gridDim.x >> 3;
-    const uint32_t logicalWg = (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3);
-    const uint32_t chunk = logicalWg * kWavesPerBlock + static_cast<uint32_t>(wave);
+    const uint32_t chunk = blockIdx.x * kWavesPerBlock + static_cast<uint32_t>(wave);
 #ifdef DCS_STAMPS
     const Stamper stamp{ (lane == 0 && a.debug != nullptr && chunk < a.nChunks) ? a.debug + static_cast<size_t>(chunk) * 16 : nullptr };
 #else
@@ -1539,7 +1532,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
     auto earlyPoll = [&](bool lastPass)
     {
         if (lastPass && importSlots != 0 && lane < ((firstImportXf == DCS_XFORM_94) ? 8 : 16))
-            earlyWord = __hip_atomic_load(firstImportSrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            earlyWord = __hip_atomic_load(firstImportSrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     for (int s0 = 0 ; s0 < nSlots ; )
@@ -1689,20 +1682,17 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
         {
             const int k = (xf == DCS_XFORM_94) ? bitrevN(lane, 3) : bitrevN(lane, 4);
             const unsigned long long *src = a.handoff + static_cast<size_t>(fromChunk) * 16 + k;
-            // The producer normally runs on this XCD (see the chunk mapping at the top): its write-through store has
-            // updated this XCD's L2, which a load that only bypasses the vector L1 (workgroup scope) reads in a third of
-            // the time of one that goes to memory.  After a few such polls -- the producer is late, or it ran on another
-            // XCD (the seven seams of the mapping) and this L2 may hold a stale line -- the polls go to memory.
+            // (Polling at workgroup scope first -- the XCD's L2, with the chunks dealt to the XCDs in contiguous runs so
+            // that producer and consumer share one -- was tried and never saw the producer's write-through store in time:
+            // the polls go to memory.)
             unsigned long long w = (sI == firstImport) ? earlyWord : 0ull;              // (epoch 0 never matches)
-            for (int spin = 0 ; static_cast<uint32_t>(w >> 32) != a.epoch && spin < kHandoffL2Polls ; ++spin)
-                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            // (bounded by wall time, 100 MHz ticks: at one of the seven seams the producer is among the LAST workgroups
-            // of the grid, and in a grid of many rounds it is not even dispatched for most of the kernel's run time)
+            // (bounded by wall time, 100 MHz ticks)
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             while (static_cast<uint32_t>(w >> 32) != a.epoch && __builtin_amdgcn_s_memrealtime() - t0 < kHandoffTimeoutTicks)
             {
-                __builtin_amdgcn_s_sleep(2);
                 w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (static_cast<uint32_t>(w >> 32) != a.epoch)
+                    __builtin_amdgcn_s_sleep(1);
             }
             uint32_t tail = 0;
             if (static_cast<uint32_t>(w >> 32) == a.epoch)

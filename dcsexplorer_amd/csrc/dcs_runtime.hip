@@ -397,8 +397,7 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
 template <int FPW>
 static hipError_t launch(const DcsKernelArgs &args, hipStream_t stream)
 {
-    // a multiple of 8 workgroups: the kernel deals them out to the XCDs in contiguous runs of chunks (dcs_kernels.hip.h)
-    const uint32_t blocks = ((args.nChunks + dcsk::kWavesPerBlock - 1) / dcsk::kWavesPerBlock + 7u) & ~7u;
+    const uint32_t blocks = (args.nChunks + dcsk::kWavesPerBlock - 1) / dcsk::kWavesPerBlock;
     dcsk::dcsDecodeKernel<FPW><<<dim3(blocks), dim3(64 * dcsk::kWavesPerBlock), dcsk::ldsBytes(FPW), stream>>>(args);
     return hipGetLastError();
 }
