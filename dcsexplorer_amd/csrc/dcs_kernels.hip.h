@@ -113,6 +113,7 @@ __device__ __forceinline__ int calcExp32(uint32_t x)
 typedef const uint32_t __attribute__((address_space(3))) *LdsDwordPtr;
 struct BitReader
 {
+    static constexpr bool kDirect = false;
     uint32_t pa;            // LDS byte address of the pool dword after `nxt`
     uint32_t hi, lo;        // the window: the next 32 bits of the stream are ({hi,lo} >> negpos) & 0xFFFFFFFF
     uint32_t nxt;           // the pool dword after lo, fetched one refill ahead so that its LDS latency is off
@@ -171,8 +172,39 @@ struct BitReader
     __device__ __forceinline__ uint32_t get(int n) { const uint32_t v = peek(n); skip(n); return v; }
 };
 
+// The same reader without a window held in registers: only the position is kept, every look reads the two pool
+// dwords that hold the next 32 bits.  Five cheap instructions per symbol instead of the queue's eight and one register
+// instead of five, at the price of an LDS round trip per look -- which the fixed-width sample loops of the 1993 formats
+// take off the critical path, because the position of their next look does not depend on the data.  Measured: 1-2 %
+// faster with 4 frames per wavefront, no gain with 8 (the 1994+ symbol loop has the round trip on its chain), 3 % slower
+// with 16, so only the first uses it.
+struct DirectReader
+{
+    static constexpr bool kDirect = true;
+    uint32_t bp;            // LDS BIT address of the next unread bit, minus one
+
+    __device__ __forceinline__ void init(const uint32_t *pool, int bitInDword)
+    {
+        bp = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsDwordPtr)pool)) * 8u + static_cast<uint32_t>(bitInDword) - 1u;
+    }
+    // the next 32 bits, MSB first: with B bits consumed they are {W[j], W[j+1]} >> (-B & 31), j = (B - 1) >> 5
+    // (before the first bit of a dword, j is the dword before it and the shift is 0: the funnel returns W[j+1])
+    __device__ __forceinline__ uint32_t cur() const
+    {
+        const LdsDwordPtr w = reinterpret_cast<LdsDwordPtr>(static_cast<uintptr_t>((bp >> 3) & ~3u));
+        return __builtin_amdgcn_alignbit(w[0], w[1], ~bp);
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return cur() >> (32 - n); }     // n in 1..32
+    __device__ __forceinline__ uint32_t prefetch() const { return 0u; }                     // (nothing to fetch ahead)
+    __device__ __forceinline__ void skip(int n) { bp += static_cast<uint32_t>(n); }
+    __device__ __forceinline__ void skip(int n, uint32_t) { skip(n); }
+    __device__ __forceinline__ void skipTight(uint32_t n, uint32_t) { bp += n; }
+    __device__ __forceinline__ uint32_t get(int n) { const uint32_t v = peek(n); skip(n); return v; }
+};
+
 // prefix code via first-level table + trie (dcs_common.h)
-__device__ __forceinline__ int readVlc(BitReader &br, const uint16_t *fast, const uint16_t *trie)
+template <class BR>
+__device__ __forceinline__ int readVlc(BR &br, const uint16_t *fast, const uint16_t *trie)
 {
     uint32_t e = fast[br.peek(8)];
     if (e & 0x8000)
@@ -268,6 +300,22 @@ __device__ __forceinline__ uint32_t mixAddCarry(uint16_t *cell, int scaledProduc
     *cell = static_cast<uint16_t>(acc >> 16);
     return acc;
 }
+// ... and with the cell given as an LDS byte address
+typedef uint16_t __attribute__((address_space(3))) *LdsWordPtr;
+template <bool FIRST>
+__device__ __forceinline__ uint32_t mixAddCarryAt(uint32_t cellAddr, int scaledProduct, uint32_t mixMul, uint32_t addLow)
+{
+    const LdsWordPtr cell = reinterpret_cast<LdsWordPtr>(static_cast<uintptr_t>(cellAddr));
+    uint32_t t, acc;
+    asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+        : "=v"(t) : "v"(scaledProduct), "v"(mixMul));
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=v"(acc) : "v"(t), "v"(addLow));
+    if (!FIRST)
+        acc += static_cast<uint32_t>(*cell) << 16;
+    *cell = static_cast<uint16_t>(acc >> 16);
+    return acc;
+}
 // (int16)word 0 of x times a 24-bit signed y, one instruction
 __device__ __forceinline__ int mulLowWord(uint32_t x, int y)
 {
@@ -310,8 +358,8 @@ constexpr int kDummyWord = 256;         // the pad word of a tile row: sink for 
 // divergent code; the symbol loop is branch-free so that lanes with Huffman-coded bands, raw bands
 // and different codebooks all execute the same instruction stream.
 // ------------------------------------------------------------------------------------------------
-template <bool FIRST>
-__device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br, const Quarter &Q,
+template <bool FIRST, class BR>
+__device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const Quarter &Q,
                              int format, uint32_t mixMul, bool has, const Stamper &stamp)
 {
     const bool type1 = format != DCS_FMT_94_T0;
@@ -380,7 +428,7 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
         // zero product leaves the accumulator as it was).  A two-zeros code with one sample left (:2213-2218)
         // drives i to -1, which is how the error is seen after the loop.
         if (k == 0) stamp(9);
-        const BitReader bandStart = br;
+        const BR bandStart = br;
         uint16_t *cell = row + outIdx;
         uint16_t *const cellStart = cell;
         const int countStart = i;
@@ -410,7 +458,7 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
             outIdx -= inc2;                 // the second zero had no room: the band ends where it should
             if (valid)
             {
-                BitReader r2 = bandStart;
+                BR r2 = bandStart;
                 uint16_t *c2 = cellStart;
                 for (int j = countStart ; j > 1 ; )
                 {
@@ -440,8 +488,8 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BitReader &br
 // prvDelta' = st == 0 ? p - prv : d;  prv' = p.  A code-0 band of sub-type 2 (ramp, :2539-2545) is the
 // same update with in = 0, so it rides in the same loop without reading bits.
 // ------------------------------------------------------------------------------------------------
-template <bool FIRST>
-__device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br, const Quarter &Q,
+template <bool FIRST, class BR>
+__device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BR &br, const Quarter &Q,
                              int format, uint32_t mixMul, bool has, const Stamper &stamp)
 {
     const bool type1 = format == DCS_FMT_93B_T1;
@@ -454,7 +502,12 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
     bool first = Q.first, reuse = Q.reuse;
     uint32_t prv = Q.prv, prvDelta = Q.prvDelta;        // uint16 semantics: masked on use
     int code = 0;
-    int outIdx = Q.outIdx;
+    // where the next sample goes, as an LDS byte address.  Clamped to the row's pad word at every store; once there it
+    // stays there (every later update adds at least as much as the one correction below takes back), which is what an
+    // unclamped index beyond the row amounts to.
+    const uint32_t rowAddr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsWordPtr)row));
+    const uint32_t cellLim = rowAddr + 2u * kDummyWord;
+    uint32_t cellAddr = rowAddr + 2u * static_cast<uint32_t>(Q.outIdx);
 
     stamp(8);
     for (int k = 0 ; __any(k < nb) ; ++k)
@@ -468,11 +521,11 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         const bool strided = (hb >> 6) != 0;
         // Type 0: 16 samples; a strided band starts one word further on, advances by 2 and ends one word back (:2362-2366).
         // Type 1: 16 samples (15 in the frame's first band), or 8 at stride 2 (:2379-2381)
-        const int inc = strided ? 2 : 1;
+        const uint32_t incBytes = strided ? 4u : 2u;
         const int nSamples = !type1 ? 16 : strided ? 8 : first ? 15 : 16;
         const int stride = !type1 ? (strided ? 31 : 16) : nSamples;
-        const int fixup = (!type1 && strided) ? -1 : 0;
-        outIdx += (act && !type1 && strided) ? 1 : 0;
+        const uint32_t fixupBytes = (!type1 && strided) ? 0xFFFFFFFEu : 0u;       // one word back
+        cellAddr += (act && !type1 && strided) ? 2u : 0u;
 
         // the band-type field (:2388-2419): [reuse bit, if the previous band was code 0] then, Type 0:
         // [change sub-type] [direction, if changing] [4-bit code].  Parsed from ONE window read with one advance.
@@ -516,7 +569,7 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         const bool fatal = act && code != 0 && w0 > 16;
         const int width = (zero || fatal || !act) ? 0 : w0;            // bits per input (0: ramp, no bits read)
         const int nS = (!act || fatal || skipBand) ? 0 : nSamples;     // samples through the main loop
-        outIdx += skipBand ? stride : 0;
+        cellAddr += skipBand ? 2u * static_cast<uint32_t>(stride) : 0u;
         prv = skipBand ? 0u : prv;
         prvDelta = skipBand ? 0u : prvDelta;
         if (fatal)
@@ -527,6 +580,7 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         first = act ? false : first;
 
         // ---- main sample loop, branch-free -----------------------------------------------------------
+        // (three multiply-adds with 0 / 1 / -1 instead of the six operations below were measured: slower)
         const uint32_t m2 = subType == 2 ? 0xFFFFu : 0u;        // add the previous delta
         const uint32_t m0 = subType == 0 ? 0u : 0xFFFFu;        // add the previous value
         // width 0 (a ramp: no bits read) rides along with an all-zero mask instead of a branch
@@ -542,18 +596,35 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
             prvDelta = d - (prv & ~m0);
             prv = p;
             const int prod = mulLowWord(p, scale);
-            carry = mixAddCarry<FIRST>(&row[min(outIdx, kDummyWord)], prod, mixMul, quirk ? carry : static_cast<uint32_t>(prod));
-            outIdx += inc;
+            cellAddr = min(cellAddr, cellLim);
+            carry = mixAddCarryAt<FIRST>(cellAddr, prod, mixMul, quirk ? carry : static_cast<uint32_t>(prod));
+            cellAddr += incBytes;
         };
         // two samples per window read: a sample is at most 16 bits wide, so the next 32 bits always hold two
         int i = 0;
-        for ( ; i + 2 <= nS ; i += 2)
+        if constexpr (BR::kDirect)
         {
-            const uint32_t ahead = br.prefetch();
-            const uint32_t w = br.cur() & wMask;
-            sample(static_cast<uint32_t>(static_cast<int>(w) >> shW));
-            sample(static_cast<uint32_t>(static_cast<int>(w << width) >> shW));
-            br.skipTight(static_cast<uint32_t>(2 * width), ahead);     // last: the prefetched dword has had the whole iteration to arrive
+            // the position of the next pair does not depend on this one's bits: its window is requested an iteration ahead
+            uint32_t wNext = br.cur();
+            for ( ; i + 2 <= nS ; i += 2)
+            {
+                const uint32_t w = wNext & wMask;
+                br.skip(2 * width);
+                wNext = br.cur();
+                sample(static_cast<uint32_t>(static_cast<int>(w) >> shW));
+                sample(static_cast<uint32_t>(static_cast<int>(w << width) >> shW));
+            }
+        }
+        else
+        {
+            for ( ; i + 2 <= nS ; i += 2)
+            {
+                const uint32_t ahead = br.prefetch();
+                const uint32_t w = br.cur() & wMask;
+                sample(static_cast<uint32_t>(static_cast<int>(w) >> shW));
+                sample(static_cast<uint32_t>(static_cast<int>(w << width) >> shW));
+                br.skipTight(static_cast<uint32_t>(2 * width), ahead);     // last: the prefetched dword has had the whole iteration to arrive
+            }
         }
         if (__any(i < nS))
         {
@@ -567,8 +638,7 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
         prv &= 0xFFFFu; prvDelta &= 0xFFFFu;
         if (k == 0) stamp(10);
 
-        if (ran)
-            outIdx += fixup;
+        cellAddr += ran ? fixupBytes : 0u;
     }
     stamp(11);
 
@@ -582,8 +652,8 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BitReader &br
 // [bandBase, bandEnd); what it needs from the bands before it -- the previous scale code and whether the
 // frame already ended -- comes from the split record.
 // ------------------------------------------------------------------------------------------------
-template <bool FIRST, class PairPtr>
-__device__ __forceinline__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *row, BitReader &br, int hb, uint32_t mixMul,
+template <bool FIRST, class BR, class PairPtr>
+__device__ __forceinline__ uint32_t unpack93a(const DcsLdsTables *T, uint16_t *row, BR &br, int hb, uint32_t mixMul,
                                               PairPtr pairTable, int bandBase, int bandEnd, int prvScale, int outIdx)
 {
     const uint16_t *bbBook = &T->bandBits93a[(hb & 0x60) >> 1];
@@ -733,10 +803,16 @@ __device__ __forceinline__ int imC(uint32_t c) { return static_cast<int>(c) >> 1
 // almost never taken, and the butterflies of a stage stay in one basic block.  "Low word of 2p is 0x8000" is tested
 // on 2p + 0x8000 (for one of the two products a term the sum needs anyway): its low word is zero; the watch register
 // keeps the minimum of all those low words (it starts at 0xFFFF and is set back to that when a stage is repeated).
-// running minimum of the low words seen so far: zero as soon as one product met the condition (one VALU per butterfly)
+// running minimum of the low words seen so far: zero as soon as one product met the condition
 __device__ __forceinline__ void quirkWatch(uint32_t &watch, uint32_t a, uint32_t b)
 {
+#ifdef DCS_EXP_MIN3
     asm("v_min3_u16 %0, %1, %2, %3" : "=v"(watch) : "v"(watch), "v"(a), "v"(b));
+#else
+    // (two two-operand minima: v_min3_u16 runs at half rate on gfx950 -- 8.2 cycles against 2 x 2.2 where several
+    // wavefronts share the SIMD, tools/valu_latency.hip)
+    asm("v_min_u16 %0, %0, %1\n\tv_min_u16 %0, %0, %2" : "+v"(watch) : "v"(a), "v"(b));
+#endif
 }
 __device__ __forceinline__ bool quirkSeen(uint32_t watch) { return __any((watch & 0xFFFFu) == 0); }
 // 16 x 16 -> 32 signed products of selected halves of packed registers, one instruction each
@@ -744,7 +820,11 @@ __device__ __forceinline__ bool quirkSeen(uint32_t watch) { return __any((watch 
     asm("v_mul_i32_i24_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" xsel " src1_sel:" ysel : "=v"(dst) : "v"(x), "v"(y))
 
 // registers every butterfly needs: 0x8000 and 0x10000 in VGPRs (VOP3 takes no literal) and the watch register
-struct BflyRegs { uint32_t k8000, k10000; uint32_t watch; };
+struct BflyRegs
+{
+    uint32_t k8000, k10000; uint32_t watch;
+    uint32_t k4000, watchB;         // layout-B stages: rounding constant of the two-product sums, their watch (see rotateDotB)
+};
 
 // twiddles of the layout-A stages (entries 2..7 of the table; 0 and 1 are exact and need no multiplier): the same for
 // every lane, held doubled (DcsDevTables.twA), which makes the products come out as the reference's doubled MR terms
@@ -824,6 +904,36 @@ __device__ __forceinline__ uint32_t rotateFastB(uint32_t A, uint32_t tw, BflyReg
     return __builtin_amdgcn_perm(mrI, mrR, 0x07060302u);
 }
 
+// The same rotate with the two-product sums of v_dot2_i32_i16: 7 instructions.  The twiddle (c, s) is needed in three
+// arrangements, derived once per twiddle of a stage:  (c, -s) and (s, c) for the real and imaginary sums, (2s, 2s) for
+// the watch.  MR = 2 (sum + 0x4000); the sums cannot overflow (|c| + |s| <= 1.42, so |sum| < 2^31).
+//   watch: the low words of 2 a.re s and 2 a.im s from ONE packed 16-bit multiply; a low word of exactly 0x8000 is the
+//   smallest signed 16-bit number, so a packed signed minimum keeps it (the watch register starts at 0x7FFF7FFF).
+// One twiddle of these stages has s = -1.0, whose negative does not fit 16 bits: entry 1 of the table, (0, -1.0), in one
+// lane per stage.  There -s wraps to -1.0, the real sum comes out 2^16 a.im too small, and exactly that is added back
+// through the sum's constant operand (`fix`: the register's high word in that lane, 0 in the others).
+struct TwDot { uint32_t re, im, s2; };
+__device__ __forceinline__ TwDot deriveTwDot(uint32_t tw)
+{
+    TwDot d;
+    d.im = __builtin_amdgcn_alignbit(tw, tw, 16);                                                                  // (s, c)
+    d.re = __builtin_bit_cast(uint32_t, static_cast<u16x2>(__builtin_bit_cast(u16x2, tw) * __builtin_bit_cast(u16x2, 0xFFFF0001u)));   // (c, -s)
+    asm("v_pk_add_u16 %0, %1, %1 op_sel:[1,1] op_sel_hi:[1,1]" : "=v"(d.s2) : "v"(tw));                           // (2s, 2s)
+    return d;
+}
+template <bool FIX>
+__device__ __forceinline__ uint32_t rotateDotB(uint32_t A, const TwDot &t, BflyRegs &R, uint32_t fixMask)
+{
+    uint32_t xR, xI, lows;
+    const uint32_t cR = FIX ? ((A & fixMask) | R.k4000) : R.k4000;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(xR) : "v"(A), "v"(t.re), "v"(cR));
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(xI) : "v"(A), "v"(t.im), "v"(R.k4000));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(lows) : "v"(A), "v"(t.s2));
+    asm("v_pk_min_i16 %0, %0, %1" : "+v"(R.watchB) : "v"(lows));
+    return __builtin_amdgcn_perm(xI << 1, xR << 1, 0x07060302u);
+}
+__device__ __forceinline__ bool quirkSeenB(uint32_t w) { return __any((w & 0xFFFFu) == 0x8000u || (w >> 16) == 0x8000u); }
+
 // radix-2 butterfly outputs u - t, u + t (saturating for the 1994+ transform, wrapping for 1993)
 template <bool SAT>
 __device__ __forceinline__ void addSub(uint32_t u, uint32_t T, uint32_t &lo, uint32_t &hi)
@@ -864,24 +974,58 @@ __device__ __forceinline__ void stageA(uint32_t (&x)[16], const TwA &W, BflyRegs
 #pragma unroll
         for (int r = 0 ; r < 16 ; ++r)
             if (!(r & D) && (r >> SH) >= 2)
-                addSub<SAT>(x[r], rotateExact(x[r + D], W.t[r >> SH].c2 >> 1, W.t[r >> SH].s2 >> 1), y[r], y[r + D]);
+            {
+                int c2 = W.t[r >> SH].c2, s2 = W.t[r >> SH].s2;
+                asm volatile("" : "+v"(c2), "+v"(s2));          // (halved HERE, in the rare path, not ahead of the pass loop)
+                addSub<SAT>(x[r], rotateExact(x[r + D], c2 >> 1, s2 >> 1), y[r], y[r + D]);
+            }
     }
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
         x[r] = y[r];
 }
-// Layout B: per-lane twiddles tw[(r >> SH)] from the lane constants
-template <bool SAT, int D, int SH>
+// Layout B: per-lane twiddles tw[(r >> SH)] from the lane constants.  DOT selects the rotate: the two-product-sum form
+// (1993 transform) or the four-product form (1994+, where deriving three registers per twiddle for fewer butterflies
+// per twiddle does not pay; measured).
+template <bool SAT, int D, int SH, bool DOT = !SAT>
 __device__ __forceinline__ void stageB(uint32_t (&x)[16], const uint32_t *tw, BflyRegs &R)
 {
     uint32_t y[16];
-#pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        if (!(r & D))
-            addSub<SAT>(x[r], rotateFastB<SAT>(x[r + D], tw[r >> SH], R), y[r], y[r + D]);
-    if (__builtin_expect(quirkSeen(R.watch), 0))
+    bool redo;
+    if constexpr (DOT)
     {
-        R.watch = 0xFFFFu;              // (start watching again: only this stage is repeated)
+        constexpr int kTw = 8 / D;          // distinct twiddles of the stage
+        TwDot td[kTw];
+#pragma unroll
+        for (int k = 0 ; k < kTw ; ++k)
+            td[k] = deriveTwDot(tw[k]);
+        // the twiddle that can be (0, -1.0): part 1 = kTw * lane + k, i.e. k = 1 of lane 0 (the stage's only one: k = 0 of lane 1)
+        constexpr int kFix = kTw == 1 ? 0 : 1;
+        const uint32_t fixMask = tw[kFix] == 0x80000000u ? 0xFFFF0000u : 0u;
+#pragma unroll
+        for (int r = 0 ; r < 16 ; ++r)
+            if (!(r & D))
+            {
+                const uint32_t T = (r >> SH) == kFix ? rotateDotB<true>(x[r + D], td[r >> SH], R, fixMask)
+                                                     : rotateDotB<false>(x[r + D], td[r >> SH], R, 0u);
+                addSub<SAT>(x[r], T, y[r], y[r + D]);
+            }
+        redo = quirkSeenB(R.watchB);
+        if (redo)
+            R.watchB = 0x7FFF7FFFu;         // (start watching again: only this stage is repeated)
+    }
+    else
+    {
+#pragma unroll
+        for (int r = 0 ; r < 16 ; ++r)
+            if (!(r & D))
+                addSub<SAT>(x[r], rotateFastB<SAT>(x[r + D], tw[r >> SH], R), y[r], y[r + D]);
+        redo = quirkSeen(R.watch);
+        if (redo)
+            R.watch = 0xFFFFu;              // (start watching again: only this stage is repeated)
+    }
+    if (__builtin_expect(redo, 0))
+    {
 #pragma unroll
         for (int r = 0 ; r < 16 ; ++r)
             if (!(r & D))
@@ -935,7 +1079,15 @@ struct PassLane
     uint32_t *rowC;         // the frame's spectrum row in the tile; reused as transpose scratch once it is in registers
     int l;                  // lane inside the group
     uint32_t shiftPair;     // volShift | volShift << 16
+#ifdef DCS_STAMPS_XFORM
+    Stamper stamp;
+#endif
 };
+#ifdef DCS_STAMPS_XFORM
+#define DCS_XSTAMP(k) P.stamp(k)
+#else
+#define DCS_XSTAMP(k)
+#endif
 
 __device__ __forceinline__ uint4 ldsRead4(const uint32_t *p) { return *reinterpret_cast<const uint4 *>(p); }
 __device__ __forceinline__ void ldsWrite4(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
@@ -1098,12 +1250,14 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const TwA &W, c
             x[0] = A; x[8] = A;                                     // (|DC|, 0) from dcMagnitude93 (:709-710)
         }
     }
+    DCS_XSTAMP(8);
     // ---- stages d = 64, 32, 16 (wrapping) (:742-778) ------------------------------------------------------
     stageA<false, 4, 3>(x, W, R);
     stageA<false, 2, 2>(x, W, R);
     stageA<false, 1, 1>(x, W, R);
     // ---- transpose: point 16 r + l  ->  lane r, register l.  The row holds 8 x 16 dwords, so two rounds:
     // registers 0..7 feed lanes 0..7, registers 8..15 feed lanes 8..15 ---------------------------------------------
+    DCS_XSTAMP(9);
     waveSync();         // every lane has read its part of the row: the row becomes scratch
     uint32_t y[16];
 #pragma unroll
@@ -1127,11 +1281,13 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const TwA &W, c
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
         x[r] = y[r];
+    DCS_XSTAMP(10);
     // ---- stages d = 8, 4, 2, 1 -----------------------------------------------------------------------------
     stageB<false, 8, 4>(x, C.k + DCS_K93_TWB, R);
     stageB<false, 4, 3>(x, C.k + DCS_K93_TWB + 1, R);
     stageB<false, 2, 2>(x, C.k + DCS_K93_TWB + 3, R);
     stageB<false, 1, 1>(x, C.k + DCS_K93_TWB + 7, R);
+    DCS_XSTAMP(11);
     // volume shift of the real parts (:782-785)
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
@@ -1159,6 +1315,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
 #endif
     DCS_STAMP(0);
     constexpr int SUB = subLanes(FPW);              // lanes that unpack one frame together
+#ifndef DCS_DIRECT_MAX_FPW
+#define DCS_DIRECT_MAX_FPW 4
+#endif
+    // the bit reader (measured per variant, tools/ab.sh): position-only for 4 frames per wavefront, a window in registers
+    // for 8 and 16 (see DirectReader)
+    using BR = typename std::conditional<(FPW <= DCS_DIRECT_MAX_FPW), DirectReader, BitReader>::type;
     static_assert(SUB * FPW == 64 && SUB <= 16, "every lane unpacks; a frame has at most 16 split lanes");
     const int s = lane % FPW;                       // slot of this lane
     const int q = lane / FPW;                       // which part of the frame it unpacks
@@ -1172,15 +1334,16 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
     // fetched ONCE per wavefront, 16 bytes per lane, and handed to the lanes through LDS below (fewer vector-memory
     // instructions in the burst at the start of a kernel, where every wavefront of the chip issues its loads at once).
     constexpr int kHeadVec = FPW * 6, kHeadLoads = (kHeadVec + 63) / 64;
-    uint4 phead[kHeadLoads];
+    static_assert(kHeadLoads <= 2, "package head: two 16-byte loads per lane at most");
+    uint4 phead0, phead1 = make_uint4(0, 0, 0, 0);      // (named registers: an array of two ended up in scratch memory)
     uint2 psplit;
     constexpr int kPoolPieces = (poolDwords(FPW) + 255) / 256;
     uint4 pimg[kPoolPieces];
     {
         static_assert(sizeof(DcsSlot) == 32 && offsetof(DcsSlot, runStartDw) == 16 && offsetof(DcsSlot, hdrDw) == 24, "DcsSlot layout");
-#pragma unroll
-        for (int t = 0 ; t < kHeadLoads ; ++t)
-            phead[t] = reinterpret_cast<const uint4 *>(pkg)[min(lane + 64 * t, kHeadVec - 1)];
+        phead0 = reinterpret_cast<const uint4 *>(pkg)[min(lane, kHeadVec - 1)];
+        if (kHeadLoads > 1)
+            phead1 = reinterpret_cast<const uint4 *>(pkg)[min(lane + 64, kHeadVec - 1)];
         psplit = reinterpret_cast<const uint2 *>(pkg + dcsPkgOffSplit(FPW))[lane];
 #pragma unroll
         for (int t = 0 ; t < kPoolPieces ; ++t)
@@ -1196,16 +1359,33 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
 
     // ---- stage the shared tables (whole workgroup), clear this wavefront's tile ------------------------
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(&a.tables->lds);
-        uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (int i = static_cast<int>(threadIdx.x) ; i < static_cast<int>(sizeof(DcsLdsTables) / 16) ; i += 64 * kWavesPerBlock)
-            dst[i] = src[i];
+        // one 16-byte piece of the tables per thread, requested (unconditionally, see above) before the tile is cleared:
+        // the clearing needs nothing from memory and runs while all these loads are in flight
+        constexpr int kTableVec = static_cast<int>(sizeof(DcsLdsTables) / 16);
+        static_assert(kTableVec <= 64 * kWavesPerBlock, "one piece of the tables per thread");
+        const uint4 piece = reinterpret_cast<const uint4 *>(&a.tables->lds)[min(static_cast<int>(threadIdx.x), kTableVec - 1)];
+        // batches with OS93a Type-1 frames: the 4 KB sample-pair table, one 16-byte piece per thread (a uniform branch)
+        const bool stagePairs = pairTableInLds(FPW) && (a.flags & DCS_BATCH_HAS_93A_T1);
+        uint4 pairPiece = make_uint4(0, 0, 0, 0);
+        if (stagePairs)
+            pairPiece = reinterpret_cast<const uint4 *>(a.tables->pair93a)[threadIdx.x];
         uint4 *tile = reinterpret_cast<uint4 *>(L.base);
-        for (int i = lane ; i < FPW * kRowBytes / 16 ; i += 64)
-            tile[i] = make_uint4(0, 0, 0, 0);
-        // batches with OS93a Type-1 frames: the 4 KB sample-pair table, one 16-byte piece per thread
-        if (pairTableInLds(FPW) && (a.flags & DCS_BATCH_HAS_93A_T1))
-            reinterpret_cast<uint4 *>(smem + ldsBytes(FPW) - 4096)[threadIdx.x] = reinterpret_cast<const uint4 *>(a.tables->pair93a)[threadIdx.x];
+#ifndef DCS_CLEAR_FIRST_MAX_FPW
+#define DCS_CLEAR_FIRST_MAX_FPW 8
+#endif
+        // (with 16 frames per wavefront, where the clearing is four times as long and other workgroups of the CU are busy
+        // anyway, tables first measured 1 % better)
+        constexpr bool kClearFirst = FPW <= DCS_CLEAR_FIRST_MAX_FPW;
+        if (kClearFirst)
+            for (int i = lane ; i < FPW * kRowBytes / 16 ; i += 64)
+                tile[i] = make_uint4(0, 0, 0, 0);
+        if (static_cast<int>(threadIdx.x) < kTableVec)
+            reinterpret_cast<uint4 *>(smem)[threadIdx.x] = piece;
+        if (stagePairs)
+            reinterpret_cast<uint4 *>(smem + ldsBytes(FPW) - 4096)[threadIdx.x] = pairPiece;
+        if (!kClearFirst)
+            for (int i = lane ; i < FPW * kRowBytes / 16 ; i += 64)
+                tile[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();                                // the only workgroup barrier: tables are in place
     if (chunk >= a.nChunks)
@@ -1220,10 +1400,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
     {
         uint4 *scratch = reinterpret_cast<uint4 *>(L.pool());
         static_assert(kHeadVec * 16 <= poolDwords(FPW) * 4, "the package head fits in the bit pool");
-#pragma unroll
-        for (int t = 0 ; t < kHeadLoads ; ++t)
-            if (lane + 64 * t < kHeadVec)
-                scratch[lane + 64 * t] = phead[t];
+        if (lane < kHeadVec)
+            scratch[lane] = phead0;
+        if (kHeadLoads > 1 && lane + 64 < kHeadVec)
+            scratch[lane + 64] = phead1;
         waveSync();
         const uint4 s0 = scratch[2 * s], s1 = scratch[2 * s + 1];
         const uint4 *dp = scratch + FPW * 2 + 3 * s;
@@ -1437,7 +1617,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
                 }
             }
             const uint32_t inPool = static_cast<uint32_t>(bitPos & 31) + relBits;
-            BitReader br;
+            BR br;
             br.init(pool + (ok ? off + (inPool >> 5) : 0u), static_cast<int>(inPool & 31));
 
             if (R0) DCS_STAMP(12);
@@ -1449,9 +1629,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
             const bool is93a = ok && format == DCS_FMT_93A_T1 && Q.nb != 0 && !(Q.bandBase != 0 && Q.reuse);
             const bool is93 = ok && format < DCS_FMT_93A_T1;
             if (__any(is94))
-                err |= unpack94<R0>(T, row, br, Q, format, mixMul, is94, stamp);
+                err |= unpack94<R0, BR>(T, row, br, Q, format, mixMul, is94, stamp);
             if (__any(is93))
-                err |= unpack93<R0>(T, row, br, Q, format, mixMul, is93, stamp);
+                err |= unpack93<R0, BR>(T, row, br, Q, format, mixMul, is93, stamp);
             if (is93a)
             {
                 // With 16 lanes per frame (one band each) bands 16 and 17 go to the lanes of bands 0 and 1, the two
@@ -1463,19 +1643,19 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
                 const int prv0 = Q.bandBase == 0 ? 0x1A : sx16(Q.prv), out0 = Q.bandBase == 0 ? 0 : Q.outIdx;
                 const int hb0 = static_cast<int>(Q.h0 & 0xFFu);
                 if (pairTableInLds(FPW))
-                    err |= unpack93a<R0>(T, row, br, hb0, mixMul, reinterpret_cast<const uint16_t *>(smem + ldsBytes(FPW) - 4096),
+                    err |= unpack93a<R0, BR>(T, row, br, hb0, mixMul, reinterpret_cast<const uint16_t *>(smem + ldsBytes(FPW) - 4096),
                                          Q.bandBase, end2, prv0, out0);
                 else
-                    err |= unpack93a<R0>(T, row, br, hb0, mixMul, a.tables->pair93a, Q.bandBase, end2, prv0, out0);
+                    err |= unpack93a<R0, BR>(T, row, br, hb0, mixMul, a.tables->pair93a, Q.bandBase, end2, prv0, out0);
                 if (kSpreadTail && pairTableInLds(FPW) && q < 2 && 16 + q < nBands)
                 {
                     const uint32_t r0 = q == 0 ? Q.t0 : Q.t2, r1 = q == 0 ? Q.t1 : Q.t3;       // DcsSplit of band 16 + q
                     if (!((r1 >> 16) & 0x800u))                                                   // (the frame had not ended)
                     {
                         const uint32_t inPool2 = static_cast<uint32_t>(bitPos & 31) + (r0 & 0xFFFFu);
-                        BitReader br2;
+                        BR br2;
                         br2.init(pool + off + (inPool2 >> 5), static_cast<int>(inPool2 & 31));
-                        err |= unpack93a<R0>(T, row, br2, hb0, mixMul, reinterpret_cast<const uint16_t *>(smem + ldsBytes(FPW) - 4096),
+                        err |= unpack93a<R0, BR>(T, row, br2, hb0, mixMul, reinterpret_cast<const uint16_t *>(smem + ldsBytes(FPW) - 4096),
                                              16 + q, 17 + q, sx16(r0 >> 16), static_cast<int>((r1 >> 16) & 0x1FFu));
                     }
                 }
@@ -1535,13 +1715,28 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
             earlyWord = __hip_atomic_load(firstImportSrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
+    const unsigned long long slots94 = __ballot(live && lane < FPW && jobXform == DCS_XFORM_94);
     for (int s0 = 0 ; s0 < nSlots ; )
     {
+        // a pass takes the run of slots from s0 on that want the same transform (8 frames at most for 1994+, 4 for 1993)
         const int xf = __builtin_amdgcn_readlane(jobXform, s0);
         const int G = (xf == DCS_XFORM_94) ? 8 : 4;
+#ifndef DCS_RUN_BALLOT_MIN_FPW
+#define DCS_RUN_BALLOT_MIN_FPW 8
+#endif
         int n = 1;
-        while (n < G && s0 + n < nSlots && __builtin_amdgcn_readlane(jobXform, s0 + n) == xf)
-            ++n;
+        if constexpr (FPW >= DCS_RUN_BALLOT_MIN_FPW)
+        {
+            // the run length as a count of trailing zeros over a ballot
+            const unsigned long long sameXf = (xf == DCS_XFORM_94) ? slots94 : ~slots94;
+            n = min(min(static_cast<int>(__builtin_ctzll(~(sameXf >> s0))), G), nSlots - s0);
+        }
+        else
+        {
+            // (with 4 slots the loop is as short and measured faster)
+            while (n < G && s0 + n < nSlots && __builtin_amdgcn_readlane(jobXform, s0 + n) == xf)
+                ++n;
+        }
 
         if (xf != constsXform)
         {
@@ -1575,13 +1770,17 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
         // pool is dead in phase 2) and store nothing
         PassLane P;
         P.rowC = active ? reinterpret_cast<uint32_t *>(L.row(mySlot)) : L.pool();
+#ifdef DCS_STAMPS_XFORM
+        P.stamp = stamp;
+#endif
         P.l = lane & ((1 << lpfShift) - 1);
         P.shiftPair = static_cast<uint32_t>(myShift) * 0x00010001u;
 
         uint32_t x[16];
         BflyRegs R;
         R.k8000 = 0x8000u; R.k10000 = 0x10000u; R.watch = 0xFFFFu;
-        asm volatile("" : "+v"(R.k8000), "+v"(R.k10000));    // keep them in vector registers (VOP3 takes no literal operand)
+        R.k4000 = 0x4000u; R.watchB = 0x7FFF7FFFu;
+        asm volatile("" : "+v"(R.k8000), "+v"(R.k10000), "+v"(R.k4000));    // keep them in vector registers (VOP3 takes no literal operand)
         if (xf == DCS_XFORM_94)
             transform94x8(P, W, C, R, x);
         else
@@ -1682,9 +1881,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
         {
             const int k = (xf == DCS_XFORM_94) ? bitrevN(lane, 3) : bitrevN(lane, 4);
             const unsigned long long *src = a.handoff + static_cast<size_t>(fromChunk) * 16 + k;
-            // (Polling at workgroup scope first -- the XCD's L2, with the chunks dealt to the XCDs in contiguous runs so
-            // that producer and consumer share one -- was tried and never saw the producer's write-through store in time:
-            // the polls go to memory.)
+            // (Tried without gain: a second poll half way through the PCM stores; polling at workgroup scope first -- the
+            // XCD's L2, with the chunks dealt to the XCDs in contiguous runs so that producer and consumer share one --
+            // which never saw the producer's write-through store in time.  The polls go to memory.)
             unsigned long long w = (sI == firstImport) ? earlyWord : 0ull;              // (epoch 0 never matches)
             // (bounded by wall time, 100 MHz ticks)
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
