@@ -1881,9 +1881,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const 
         {
             const int k = (xf == DCS_XFORM_94) ? bitrevN(lane, 3) : bitrevN(lane, 4);
             const unsigned long long *src = a.handoff + static_cast<size_t>(fromChunk) * 16 + k;
-            // (Tried without gain: a second poll half way through the PCM stores; polling at workgroup scope first -- the
-            // XCD's L2, with the chunks dealt to the XCDs in contiguous runs so that producer and consumer share one --
-            // which never saw the producer's write-through store in time.  The polls go to memory.)
+            // (Tried without gain: a second poll half way through the PCM stores; scalar loads (s_load_dwordx16 glc) of the
+            // producer's sixteen words, which do not queue behind this wavefront's stores; polling at workgroup scope first
+            // -- the XCD's L2, with the chunks dealt to the XCDs in contiguous runs so that producer and consumer share
+            // one -- which never saw the producer's write-through store in time.  The polls go to memory.)
             unsigned long long w = (sI == firstImport) ? earlyWord : 0ull;              // (epoch 0 never matches)
             // (bounded by wall time, 100 MHz ticks)
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
