@@ -1298,7 +1298,10 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const TwA &W, c
 // the kernel
 // ------------------------------------------------------------------------------------------------
 template <int FPW>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, 4) dcsDecodeKernel(const DcsKernelArgs a)
+#ifndef DCS_MIN_WAVES
+#define DCS_MIN_WAVES 4
+#endif
+__global__ void __launch_bounds__(64 * kWavesPerBlock, DCS_MIN_WAVES) dcsDecodeKernel(const DcsKernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = static_cast<int>(threadIdx.x) >> 6;
