@@ -606,14 +606,31 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BR &br, const
         {
             // the position of the next pair does not depend on this one's bits: its window is requested an iteration ahead
             uint32_t wNext = br.cur();
-            for ( ; i + 2 <= nS ; i += 2)
+            auto pair = [&]()
             {
                 const uint32_t w = wNext & wMask;
                 br.skip(2 * width);
                 wNext = br.cur();
                 sample(static_cast<uint32_t>(static_cast<int>(w) >> shW));
                 sample(static_cast<uint32_t>(static_cast<int>(w << width) >> shW));
+            };
+#ifndef DCS_EXP_NOUNROLL93
+            // Every band of a Type-0 frame has 16 samples: when all the lanes that have a band at all have that many (a
+            // wave-uniform test), the eight pairs run as straight-line code, without the loop's bookkeeping and branch
+            if (__all(nS == 16 || nS == 0))
+            {
+                if (nS == 16)
+                {
+#pragma unroll
+                    for (int u = 0 ; u < 8 ; ++u)
+                        pair();
+                    i = 16;
+                }
             }
+            else
+#endif
+            for ( ; i + 2 <= nS ; i += 2)
+                pair();
         }
         else
         {
