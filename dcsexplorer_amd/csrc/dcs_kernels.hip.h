@@ -1318,8 +1318,19 @@ template <int FPW>
 #ifndef DCS_MIN_WAVES
 #define DCS_MIN_WAVES 4
 #endif
-__global__ void __launch_bounds__(64 * kWavesPerBlock, DCS_MIN_WAVES) dcsDecodeKernel(const DcsKernelArgs a)
+// The arguments are those of DcsKernelArgs, as separate kernel parameters: the first 16 dwords of the kernel-argument
+// segment -- everything the prologue and the single-source path need -- are then preloaded into scalar registers
+// when the wavefront is launched (-amdgpu-kernarg-preload-count, Makefile), instead of being fetched by the kernel's
+// first instructions with the package loads waiting behind that fetch.
+__global__ void __launch_bounds__(64 * kWavesPerBlock, DCS_MIN_WAVES)
+dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChunks, uint32_t kFlags, uint32_t kEpoch, uint32_t kNJobs,
+                int16_t *kPcm, unsigned long long *kHandoff, uint32_t *kErr, int16_t *kTailsOut,
+                const uint8_t *kBlob, uint64_t kBlobLen, const DcsSrcDesc *kSrcs, const int16_t *kTailsIn, unsigned long long *kDebug)
 {
+    DcsKernelArgs a;
+    a.blob = kBlob; a.blobLen = kBlobLen; a.srcs = kSrcs; a.packages = kPackages; a.nChunks = kNChunks; a.nJobs = kNJobs;
+    a.pcm = kPcm; a.err = kErr; a.tailsIn = kTailsIn; a.tailsOut = kTailsOut; a.tables = kTables; a.debug = kDebug;
+    a.handoff = kHandoff; a.epoch = kEpoch; a.flags = kFlags;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = static_cast<int>(threadIdx.x) >> 6;
     const int lane = static_cast<int>(threadIdx.x) & 63;

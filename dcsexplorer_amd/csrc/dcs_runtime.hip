@@ -398,7 +398,9 @@ template <int FPW>
 static hipError_t launch(const DcsKernelArgs &args, hipStream_t stream)
 {
     const uint32_t blocks = (args.nChunks + dcsk::kWavesPerBlock - 1) / dcsk::kWavesPerBlock;
-    dcsk::dcsDecodeKernel<FPW><<<dim3(blocks), dim3(64 * dcsk::kWavesPerBlock), dcsk::ldsBytes(FPW), stream>>>(args);
+    dcsk::dcsDecodeKernel<FPW><<<dim3(blocks), dim3(64 * dcsk::kWavesPerBlock), dcsk::ldsBytes(FPW), stream>>>(
+        args.packages, args.tables, args.nChunks, args.flags, args.epoch, args.nJobs, args.pcm, args.handoff, args.err, args.tailsOut,
+        args.blob, args.blobLen, args.srcs, args.tailsIn, args.debug);
     return hipGetLastError();
 }
 
