@@ -1451,7 +1451,8 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     }
 
     // the lane's transform constants for the chunk's first frame (the whole chunk, normally): requested now, needed in
-    // phase 2
+    // phase 2.  (Requesting them with the first loads of the kernel, which a batch flag could allow when every job runs
+    // the same transform, makes that first round trip longer: 4 % slower on the 4 096-frame batch.)
     int constsXform = __builtin_amdgcn_readfirstlane(static_cast<int>(slot.shiftXform >> 4)) == DCS_XFORM_94 ? DCS_XFORM_94 : DCS_XFORM_93;
     LaneConsts C;
     loadLaneConsts(a.tables, lane, constsXform, C);
