@@ -1,10 +1,13 @@
-// Lone-wavefront issue cost of the instruction kinds the decode kernel is made of (gfx950), dependent chains against
-// independent streams.  One wavefront per SIMD of a few CUs; cycles from s_memtime around 256 instructions.
-//   hipcc --offload-arch=gfx950 -O3 tools/valu_latency.hip -o tools/build/valu_latency && tools/build/valu_latency
+// What the instruction kinds the decode kernel is made of cost on gfx950: dependent chains against independent streams,
+// one wavefront alone on its SIMD against 2-4 wavefronts per SIMD (started together behind a barrier).  Cycles from
+// s_memtime around 256 instructions; per wavefront, and per SIMD (span of its wavefronts / instructions they issued).
+//   hipcc --offload-arch=gfx950 -O3 tools/valu_latency.hip -o tools/build/valu_latency
+//   tools/build/valu_latency <blocks> <wavefronts per block: 1, 4 = one per SIMD, 8, 16>      (on the GPU box)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <algorithm>
 
 #define REP4(x) x x x x
 #define REP16(x) REP4(REP4(x))
