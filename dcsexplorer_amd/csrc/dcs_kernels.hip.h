@@ -589,48 +589,50 @@ __device__ uint32_t unpack93(const DcsLdsTables *T, uint16_t *row, BR &br, const
         const bool ran = nS > 0;
         if (k == 0) stamp(9);
         uint32_t carry = static_cast<uint32_t>(mulLowWord(prv, scale));      // (only lanes that repeat the previous input use it)
-        auto sample = [&](uint32_t in)
+        auto sampleAt = [&](uint32_t in, auto clampTag)
         {
+            constexpr bool clamp = decltype(clampTag)::value;
             const uint32_t d = in + (prvDelta & m2);
             const uint32_t p = d + (prv & m0);
             prvDelta = d - (prv & ~m0);
             prv = p;
             const int prod = mulLowWord(p, scale);
-            cellAddr = min(cellAddr, cellLim);
+            if (clamp)
+                cellAddr = min(cellAddr, cellLim);
             carry = mixAddCarryAt<FIRST>(cellAddr, prod, mixMul, quirk ? carry : static_cast<uint32_t>(prod));
             cellAddr += incBytes;
         };
+        auto sample = [&](uint32_t in) { sampleAt(in, std::true_type()); };
         // two samples per window read: a sample is at most 16 bits wide, so the next 32 bits always hold two
         int i = 0;
         if constexpr (BR::kDirect)
         {
             // the position of the next pair does not depend on this one's bits: its window is requested an iteration ahead
             uint32_t wNext = br.cur();
-            auto pair = [&]()
+            auto pairAt = [&](auto clampTag)
             {
                 const uint32_t w = wNext & wMask;
                 br.skip(2 * width);
                 wNext = br.cur();
-                sample(static_cast<uint32_t>(static_cast<int>(w) >> shW));
-                sample(static_cast<uint32_t>(static_cast<int>(w << width) >> shW));
+                sampleAt(static_cast<uint32_t>(static_cast<int>(w) >> shW), clampTag);
+                sampleAt(static_cast<uint32_t>(static_cast<int>(w << width) >> shW), clampTag);
             };
-#ifndef DCS_EXP_NOUNROLL93
-            // Every band of a Type-0 frame has 16 samples: when all the lanes that have a band at all have that many (a
-            // wave-uniform test), the eight pairs run as straight-line code, without the loop's bookkeeping and branch
-            if (__all(nS == 16 || nS == 0))
+            // Every band of a Type-0 frame has 16 samples: when all the lanes that have a band at all have that many and
+            // room for them in their rows (a wave-uniform test; always, with records of the index pass), the eight pairs
+            // run as straight-line code, without the loop's bookkeeping and branch and without the clamp of the address
+            if (__all((nS == 16 && cellAddr + 16u * incBytes <= cellLim) || nS == 0))
             {
                 if (nS == 16)
                 {
 #pragma unroll
                     for (int u = 0 ; u < 8 ; ++u)
-                        pair();
+                        pairAt(std::false_type());
                     i = 16;
                 }
             }
             else
-#endif
-            for ( ; i + 2 <= nS ; i += 2)
-                pair();
+                for ( ; i + 2 <= nS ; i += 2)
+                    pairAt(std::true_type());
         }
         else
         {
@@ -1238,10 +1240,13 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const TwA &W, c
     stageB<true, 4, 3>(x, C.k + DCS_K94_TWB, R);
     stageB<true, 2, 2>(x, C.k + DCS_K94_TWB + 2, R);
     stageB<true, 1, 1>(x, C.k + DCS_K94_TWB + 6, R);
-    // volume shift (:532-534)
+    // volume shift (:532-534); at full volume there is none
+    if (__any(P.shiftPair != 0))
+    {
 #pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        x[r] = pkAshr(x[r], P.shiftPair);
+        for (int r = 0 ; r < 16 ; ++r)
+            x[r] = pkAshr(x[r], P.shiftPair);
+    }
 }
 
 // 1993 transform of 4 frames, 16 lanes each (DecoderImpl93::TransformFrame, .cpp:714-785; the DC
@@ -1305,10 +1310,13 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const TwA &W, c
     stageB<false, 2, 2>(x, C.k + DCS_K93_TWB + 3, R);
     stageB<false, 1, 1>(x, C.k + DCS_K93_TWB + 7, R);
     DCS_XSTAMP(11);
-    // volume shift of the real parts (:782-785)
+    // volume shift of the real parts (:782-785); at full volume there is none
+    if (__any(P.shiftPair != 0))
+    {
 #pragma unroll
-    for (int r = 0 ; r < 16 ; ++r)
-        x[r] = pkAshr(x[r], P.shiftPair);
+        for (int r = 0 ; r < 16 ; ++r)
+            x[r] = pkAshr(x[r], P.shiftPair);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
