@@ -1756,6 +1756,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     };
 
     const unsigned long long slots94 = __ballot(live && lane < FPW && jobXform == DCS_XFORM_94);
+    const bool oneXform = slots94 == 0 || slots94 == __ballot(live && lane < FPW);
     for (int s0 = 0 ; s0 < nSlots ; )
     {
         // a pass takes the run of slots from s0 on that want the same transform (8 frames at most for 1994+, 4 for 1993)
@@ -1771,6 +1772,8 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
             const unsigned long long sameXf = (xf == DCS_XFORM_94) ? slots94 : ~slots94;
             n = min(min(static_cast<int>(__builtin_ctzll(~(sameXf >> s0))), G), nSlots - s0);
         }
+        else if (oneXform)
+            n = min(G, nSlots - s0);            // the usual case: every frame of the chunk wants the same transform
         else
         {
             // (with 4 slots the loop is as short and measured faster)
