@@ -212,16 +212,17 @@ extern "C" DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable)
     return DCS_OK;
 }
 
-// frames per wavefront (16, 8 or 4 lanes unpack one frame together for 4, 8, 16 frames per wavefront).  Measured
-// (tools/sweep_fpw.sh): 4 while the batch fits on the chip in one round of four wavefronts per SIMD (shortest serial
-// path per wavefront); 8 up to about 200 frames per SIMD (four wavefronts per SIMD, full rounds); beyond that 16,
-// which needs the fewest instructions per frame but fits only three wavefronts per SIMD (LDS).
-static int chooseFpw(const DcsCtx *ctx, uint32_t nJobs)
+// Frames per wavefront, from measurement (tools/sweep_fpw.sh, tools/fpw_sweep.py): 4 (16 lanes unpack a frame: the
+// shortest serial path per wavefront) while the batch is small, 8 (four wavefronts per SIMD, full rounds) beyond.  The
+// crossover depends on what is decoded: a batch of 1994+ frames only -- the longer symbol loops -- gains from 8 lanes per
+// frame from about 10 frames per SIMD, 1993 and mixed batches from about 32.  The 16-frames variant (fewest instructions
+// per frame, but only three wavefronts per SIMD for its LDS) no longer wins at any size and is only taken on request.
+static int chooseFpw(const DcsCtx *ctx, uint32_t nJobs, bool all94)
 {
     if (ctx->fpwOverride != 0)
         return ctx->fpwOverride;
     const uint64_t simds = static_cast<uint64_t>(ctx->numCUs) * 4;
-    return nJobs > simds * 192 ? 16 : nJobs > simds * 16 ? 8 : 4;
+    return nJobs > simds * (all94 ? 10 : 32) ? 8 : 4;
 }
 
 extern "C" void dcs_batch_destroy(DcsBatch *b)
@@ -322,7 +323,12 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
         return DCS_ERR_NO_MEMORY;
     b->ctx = ctx;
     b->nJobs = nJobs; b->nSrcs = nSrcs; b->nTailsIn = nTailsIn; b->blobLen = blobLen;
-    b->fpw = chooseFpw(ctx, nJobs);
+    {
+        bool all94 = nJobs != 0;
+        for (uint32_t j = 0 ; j < nJobs && all94 ; ++j)
+            all94 = jobs[j].xform == DCS_XFORM_94;
+        b->fpw = chooseFpw(ctx, nJobs, all94);
+    }
     b->flags = batchFlags;
 
     std::vector<DcsSlot> slots;
