@@ -175,9 +175,10 @@ struct BitReader
 // The same reader without a window held in registers: only the position is kept, every look reads the two pool
 // dwords that hold the next 32 bits.  Five cheap instructions per symbol instead of the queue's eight and one register
 // instead of five, at the price of an LDS round trip per look -- which the fixed-width sample loops of the 1993 formats
-// take off the critical path, because the position of their next look does not depend on the data.  Measured: 1-2 %
-// faster with 4 frames per wavefront, no gain with 8 (the 1994+ symbol loop has the round trip on its chain), 3 % slower
-// with 16, so only the first uses it.
+// take off the critical path, because the position of their next look does not depend on the data.  Measured: the 1993
+// layouts gain at every size (1-2 % with 4 frames per wavefront, 4 % with 8), the 1994+ symbol loop, which has the round
+// trip on its chain, gains only with 4 frames per wavefront (nothing with 8, 3 % slower with 16): it keeps the window
+// in registers there.
 struct DirectReader
 {
     static constexpr bool kDirect = true;
@@ -1357,9 +1358,15 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
 #ifndef DCS_DIRECT_MAX_FPW
 #define DCS_DIRECT_MAX_FPW 4
 #endif
-    // the bit reader (measured per variant, tools/ab.sh): position-only for 4 frames per wavefront, a window in registers
-    // for 8 and 16 (see DirectReader)
-    using BR = typename std::conditional<(FPW <= DCS_DIRECT_MAX_FPW), DirectReader, BitReader>::type;
+    // the bit readers (measured per variant, tools/ab.sh): the 1993 layouts always read position-only; the 1994+ symbol
+    // loop, whose next position depends on the symbol just read, does so only with 4 frames per wavefront and keeps the
+    // window in registers with 8 and 16 (see DirectReader)
+    using BR94 = typename std::conditional<(FPW <= DCS_DIRECT_MAX_FPW), DirectReader, BitReader>::type;
+#ifdef DCS_EXP_QUEUE93
+    using BR93 = BR94;
+#else
+    using BR93 = DirectReader;
+#endif
     static_assert(SUB * FPW == 64 && SUB <= 16, "every lane unpacks; a frame has at most 16 split lanes");
     const int s = lane % FPW;                       // slot of this lane
     const int q = lane / FPW;                       // which part of the frame it unpacks
@@ -1657,8 +1664,8 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
                 }
             }
             const uint32_t inPool = static_cast<uint32_t>(bitPos & 31) + relBits;
-            BR br;
-            br.init(pool + (ok ? off + (inPool >> 5) : 0u), static_cast<int>(inPool & 31));
+            const uint32_t *brAt = pool + (ok ? off + (inPool >> 5) : 0u);
+            const int brBit = static_cast<int>(inPool & 31);
 
             if (R0) DCS_STAMP(12);
             // every lane enters the unpackers (their symbol loops are wave-convergent); lanes without a
@@ -1669,9 +1676,15 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
             const bool is93a = ok && format == DCS_FMT_93A_T1 && Q.nb != 0 && !(Q.bandBase != 0 && Q.reuse);
             const bool is93 = ok && format < DCS_FMT_93A_T1;
             if (__any(is94))
-                err |= unpack94<R0, BR>(T, row, br, Q, format, mixMul, is94, stamp);
+            {
+                BR94 br;
+                br.init(brAt, brBit);
+                err |= unpack94<R0, BR94>(T, row, br, Q, format, mixMul, is94, stamp);
+            }
+            BR93 br;
+            br.init(brAt, brBit);
             if (__any(is93))
-                err |= unpack93<R0, BR>(T, row, br, Q, format, mixMul, is93, stamp);
+                err |= unpack93<R0, BR93>(T, row, br, Q, format, mixMul, is93, stamp);
             if (is93a)
             {
                 // With 16 lanes per frame (one band each) bands 16 and 17 go to the lanes of bands 0 and 1, the two
@@ -1683,19 +1696,19 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
                 const int prv0 = Q.bandBase == 0 ? 0x1A : sx16(Q.prv), out0 = Q.bandBase == 0 ? 0 : Q.outIdx;
                 const int hb0 = static_cast<int>(Q.h0 & 0xFFu);
                 if (pairTableInLds(FPW))
-                    err |= unpack93a<R0, BR>(T, row, br, hb0, mixMul, reinterpret_cast<const uint16_t *>(smem + ldsBytes(FPW) - 4096),
+                    err |= unpack93a<R0, BR93>(T, row, br, hb0, mixMul, reinterpret_cast<const uint16_t *>(smem + ldsBytes(FPW) - 4096),
                                          Q.bandBase, end2, prv0, out0);
                 else
-                    err |= unpack93a<R0, BR>(T, row, br, hb0, mixMul, a.tables->pair93a, Q.bandBase, end2, prv0, out0);
+                    err |= unpack93a<R0, BR93>(T, row, br, hb0, mixMul, a.tables->pair93a, Q.bandBase, end2, prv0, out0);
                 if (kSpreadTail && pairTableInLds(FPW) && q < 2 && 16 + q < nBands)
                 {
                     const uint32_t r0 = q == 0 ? Q.t0 : Q.t2, r1 = q == 0 ? Q.t1 : Q.t3;       // DcsSplit of band 16 + q
                     if (!((r1 >> 16) & 0x800u))                                                   // (the frame had not ended)
                     {
                         const uint32_t inPool2 = static_cast<uint32_t>(bitPos & 31) + (r0 & 0xFFFFu);
-                        BR br2;
+                        BR93 br2;
                         br2.init(pool + off + (inPool2 >> 5), static_cast<int>(inPool2 & 31));
-                        err |= unpack93a<R0, BR>(T, row, br2, hb0, mixMul, reinterpret_cast<const uint16_t *>(smem + ldsBytes(FPW) - 4096),
+                        err |= unpack93a<R0, BR93>(T, row, br2, hb0, mixMul, reinterpret_cast<const uint16_t *>(smem + ldsBytes(FPW) - 4096),
                                              16 + q, 17 + q, sx16(r0 >> 16), static_cast<int>((r1 >> 16) & 0x1FFu));
                     }
                 }
