@@ -93,6 +93,27 @@ CASE(lds_chain,  __shared__ uint32_t tab[256]; tab[threadIdx.x & 255] = ((thread
 CASE(lds_write,  __shared__ uint32_t tab[256]; tab[threadIdx.x & 255] = 0; __syncthreads(); a = (threadIdx.x & 255) * 4,
                  "ds_write_b16 %0, %1\n ds_write_b16 %0, %2 offset:2\n ds_write_b16 %0, %1\n ds_write_b16 %0, %2 offset:2\n")
 
+// the first memory round trip of a kernel: every wavefront of the chip requests NLOADS x 16 bytes per lane of its own
+// region at once (the decode kernel's prologue asks for about 3.5 KB per wavefront), cycles until all of it is there
+template <int NLOADS>
+__global__ void k_gload(uint64_t *out, const uint4 *src, uint32_t seed)
+{
+    const size_t base = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) + seed * 0;
+    uint64_t t0, t1;
+    uint4 v[NLOADS];
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+#pragma unroll
+    for (int k = 0 ; k < NLOADS ; ++k)
+        v[k] = src[base + static_cast<size_t>(k) * gridDim.x * blockDim.x];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0 ; k < NLOADS ; ++k)
+        acc += v[k].x + v[k].w;
+    asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "+v"(acc) :: "memory");
+    if ((threadIdx.x & 63) == 0) { out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = t0; out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + 1] = t1; }
+    if (acc == 0x12345) out[0] = 0;
+}
+
 typedef void (*Kern)(uint64_t *, uint32_t);
 struct Entry { const char *name; Kern k; };
 
@@ -135,6 +156,29 @@ int main(int argc, char **argv)
         std::sort(perSimd.begin(), perSimd.end());
         printf("%-14s per wavefront: median %6.2f  min %6.2f  max %6.2f | per SIMD (span / instructions of its wavefronts): median %6.2f\n", e.name,
                perWave[perWave.size() / 2], perWave.front(), perWave.back(), perSimd[perSimd.size() / 2]);
+    }
+    {
+        uint4 *src;
+        const size_t n = static_cast<size_t>(blocks) * 64 * waves * 8;
+        hipMalloc(&src, n * sizeof(uint4));
+        hipMemset(src, 1, n * sizeof(uint4));
+        auto report = [&](const char *name)
+        {
+            hipMemcpy(h.data(), d, sizeof(uint64_t) * blocks * 32, hipMemcpyDeviceToHost);
+            std::vector<double> c;
+            for (int b = 0 ; b < blocks ; ++b)
+                for (int w = 0 ; w < waves ; ++w)
+                    c.push_back(static_cast<double>(h[(b * 16 + w) * 2 + 1] - h[(b * 16 + w) * 2]));
+            std::sort(c.begin(), c.end());
+            printf("%-14s cycles until the data is there: median %6.0f  min %6.0f  max %6.0f\n", name, c[c.size() / 2], c.front(), c.back());
+        };
+        for (int rep = 0 ; rep < 4 ; ++rep) { hipLaunchKernelGGL(k_gload<1>, dim3(blocks), dim3(64 * waves), 0, 0, d, src, 0u); hipDeviceSynchronize(); }
+        report("gload 1x16B");
+        for (int rep = 0 ; rep < 4 ; ++rep) { hipLaunchKernelGGL(k_gload<4>, dim3(blocks), dim3(64 * waves), 0, 0, d, src, 0u); hipDeviceSynchronize(); }
+        report("gload 4x16B");
+        for (int rep = 0 ; rep < 4 ; ++rep) { hipLaunchKernelGGL(k_gload<8>, dim3(blocks), dim3(64 * waves), 0, 0, d, src, 0u); hipDeviceSynchronize(); }
+        report("gload 8x16B");
+        hipFree(src);
     }
     hipFree(d);
     return 0;
