@@ -826,13 +826,9 @@ __device__ __forceinline__ int imC(uint32_t c) { return static_cast<int>(c) >> 1
 // running minimum of the low words seen so far: zero as soon as one product met the condition
 __device__ __forceinline__ void quirkWatch(uint32_t &watch, uint32_t a, uint32_t b)
 {
-#ifdef DCS_EXP_MIN3
-    asm("v_min3_u16 %0, %1, %2, %3" : "=v"(watch) : "v"(watch), "v"(a), "v"(b));
-#else
-    // (two two-operand minima: v_min3_u16 runs at half rate on gfx950 -- 8.2 cycles against 2 x 2.2 where several
-    // wavefronts share the SIMD, tools/valu_latency.hip)
+    // (two two-operand minima: v_min3_u16 would do it in one instruction but runs at half rate on gfx950 -- 8.2 cycles
+    // against 2 x 2.2 where several wavefronts share the SIMD, tools/valu_latency.hip)
     asm("v_min_u16 %0, %0, %1\n\tv_min_u16 %0, %0, %2" : "+v"(watch) : "v"(a), "v"(b));
-#endif
 }
 __device__ __forceinline__ bool quirkSeen(uint32_t watch) { return __any((watch & 0xFFFFu) == 0); }
 // 16 x 16 -> 32 signed products of selected halves of packed registers, one instruction each
@@ -1362,11 +1358,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     // loop, whose next position depends on the symbol just read, does so only with 4 frames per wavefront and keeps the
     // window in registers with 8 and 16 (see DirectReader)
     using BR94 = typename std::conditional<(FPW <= DCS_DIRECT_MAX_FPW), DirectReader, BitReader>::type;
-#ifdef DCS_EXP_QUEUE93
-    using BR93 = BR94;
-#else
     using BR93 = DirectReader;
-#endif
     static_assert(SUB * FPW == 64 && SUB <= 16, "every lane unpacks; a frame has at most 16 split lanes");
     const int s = lane % FPW;                       // slot of this lane
     const int q = lane / FPW;                       // which part of the frame it unpacks
