@@ -114,6 +114,24 @@ __global__ void k_gload(uint64_t *out, const uint4 *src, uint32_t seed)
     if (acc == 0x12345) out[0] = 0;
 }
 
+// straight-line code that is long for the instruction cache's prefetch: 2 048 eight-byte (resp. four-byte) instructions,
+// executed once per wavefront -- do they still issue at the short sequences' rate?
+#define REP512(x) REP64(x) REP64(x) REP64(x) REP64(x) REP64(x) REP64(x) REP64(x) REP64(x)
+#define LONGCASE(name, body)                                                                           \
+    __global__ void k_##name(uint64_t *out, uint32_t seed)                                             \
+    {                                                                                                  \
+        uint32_t a = threadIdx.x + seed, b = a * 3 + 1, c = a ^ 0x55, d = a + 7, e = seed | 1;         \
+        uint64_t t0, t1;                                                                               \
+        __syncthreads();                                                                               \
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");                    \
+        asm volatile(REP512(body) : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));                      \
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");                    \
+        if ((threadIdx.x & 63) == 0) { out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = t0; out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + 1] = t1; } \
+        if (a + b + c + d == 0x12345) out[0] = 0;                                                      \
+    }
+LONGCASE(long8, "v_lshl_add_u32 %0, %0, 1, %4\n v_lshl_add_u32 %1, %1, 1, %4\n v_lshl_add_u32 %2, %2, 1, %4\n v_lshl_add_u32 %3, %3, 1, %4\n")
+LONGCASE(long4, "v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n")
+
 typedef void (*Kern)(uint64_t *, uint32_t);
 struct Entry { const char *name; Kern k; };
 
@@ -156,6 +174,23 @@ int main(int argc, char **argv)
         std::sort(perSimd.begin(), perSimd.end());
         printf("%-14s per wavefront: median %6.2f  min %6.2f  max %6.2f | per SIMD (span / instructions of its wavefronts): median %6.2f\n", e.name,
                perWave[perWave.size() / 2], perWave.front(), perWave.back(), perSimd[perSimd.size() / 2]);
+    }
+    for (int which = 0 ; which < 2 ; ++which)
+    {
+        for (int rep = 0 ; rep < 3 ; ++rep)
+        {
+            if (which == 0) hipLaunchKernelGGL(k_long8, dim3(blocks), dim3(64 * waves), 0, 0, d, 777u + rep);
+            else hipLaunchKernelGGL(k_long4, dim3(blocks), dim3(64 * waves), 0, 0, d, 777u + rep);
+            hipDeviceSynchronize();
+            hipMemcpy(h.data(), d, sizeof(uint64_t) * blocks * 32, hipMemcpyDeviceToHost);
+            std::vector<double> c;
+            for (int b = 0 ; b < blocks ; ++b)
+                for (int w = 0 ; w < waves ; ++w)
+                    c.push_back(static_cast<double>(h[(b * 16 + w) * 2 + 1] - h[(b * 16 + w) * 2]) / 2048.0);
+            std::sort(c.begin(), c.end());
+            printf("%-14s launch %d: cycles per instruction over 2 048 straight-line instructions: median %5.2f  min %5.2f  max %5.2f\n",
+                   which == 0 ? "long 8-byte" : "long 4-byte", rep, c[c.size() / 2], c.front(), c.back());
+        }
     }
     {
         uint4 *src;
