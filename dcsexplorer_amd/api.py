@@ -2,6 +2,7 @@
 no Python or CPU implementation of the decode path in this package."""
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -506,9 +507,12 @@ class Context:
             msg = self.L.dcs_last_error(None)
             raise DcsError(st, msg.decode() if msg else "")
         self.h = h
+        self._batches = weakref.WeakSet()       # a DcsBatch must be destroyed before its DcsCtx (dcs_hip.h)
 
     def close(self):
         if self.h:
+            for b in list(self._batches):
+                b.close()
             self.L.dcs_ctx_destroy(self.h)
             self.h = None
 
@@ -620,6 +624,7 @@ class Batch:
                                        _ptr(tin), 0 if tin is None else tin.shape[0], ctypes.byref(h)), ctx.h)
         self.h = h
         self.n_jobs = jobs.size
+        ctx._batches.add(self)
 
     def run(self, stream=None):
         _check(self.L.dcs_batch_run(self.h, ctypes.c_void_p(stream) if stream else None), self.ctx.h)
@@ -658,7 +663,8 @@ class Batch:
 
     def close(self):
         if self.h:
-            self.L.dcs_batch_destroy(self.h)
+            if self.ctx.h:                      # (a closed context has already destroyed its batches)
+                self.L.dcs_batch_destroy(self.h)
             self.h = None
 
     def __del__(self):

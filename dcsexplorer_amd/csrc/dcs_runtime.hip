@@ -96,7 +96,17 @@ struct DcsBatch
     uint32_t *hErr = nullptr;
     size_t hCap[2] = { 0 };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // recorded behind the last launch on whatever stream the caller launched on (a caller's stream is not ordered
+    // against the context's non-blocking one): sync, download, download_view and destroy wait for it
+    hipEvent_t evDone = nullptr;
+    bool launched = false;
 };
+
+// the device work of the batch's last launch has finished (host-side wait)
+static hipError_t waitLaunched(DcsBatch *b)
+{
+    return b->launched ? hipEventSynchronize(b->evDone) : hipSuccess;
+}
 
 static std::string g_createError;
 
@@ -230,7 +240,8 @@ extern "C" void dcs_batch_destroy(DcsBatch *b)
     if (b == nullptr)
         return;
     (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);         // nothing of this batch is in flight when its buffers are recycled
+    if (b->evDone) (void)waitLaunched(b);               // nothing of this batch is in flight when its buffers are recycled,
+    (void)hipStreamSynchronize(b->ctx->stream);         // on the caller's launch stream or on the context's
     void *ptrs[] = { b->dBlob, b->dSrcs, nullptr, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug, b->dHandoff, b->dPackages };
     for (int i = 0 ; i < 10 ; ++i)
         cacheFree(b->ctx, false, ptrs[i], b->cap[i]);
@@ -238,6 +249,7 @@ extern "C" void dcs_batch_destroy(DcsBatch *b)
     cacheFree(b->ctx, true, b->hErr, b->hCap[1]);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->evDone) (void)hipEventDestroy(b->evDone);
     delete b;
 }
 
@@ -291,6 +303,13 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
             if (ext ? ((jb.prev & 0x7FFFFFFFu) >= nTailsIn || tailsIn == nullptr) : (jb.prev >= nJobs || jb.prev == j))
             {
                 ctx->lastError = "job " + std::to_string(j) + ": bad overlap predecessor";
+                return DCS_ERR_INVALID_ARG;
+            }
+            // a decoder object has ONE transform (DCSDecoderNative.cpp:3147-3160), so a frame and the frame whose tail
+            // it overlaps with share it; the two transforms also publish tails of different word counts
+            if (!ext && jobs[jb.prev].xform != jb.xform)
+            {
+                ctx->lastError = "job " + std::to_string(j) + ": overlap predecessor uses the other transform";
                 return DCS_ERR_INVALID_ARG;
             }
         }
@@ -385,6 +404,7 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
 #endif
         HIPCHK(ctx, hipEventCreate(&b->ev0));
         HIPCHK(ctx, hipEventCreate(&b->ev1));
+        HIPCHK(ctx, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         return DCS_OK;
     }();
@@ -410,12 +430,10 @@ static hipError_t launch(const DcsKernelArgs &args, hipStream_t stream)
     return hipGetLastError();
 }
 
-extern "C" DcsStatus dcs_batch_run(DcsBatch *b, void *hipStream)
+// one launch, without the completion event (the callers below record it once per call)
+static DcsStatus launchOnce(DcsBatch *b, hipStream_t stream)
 {
-    if (b == nullptr)
-        return DCS_ERR_INVALID_ARG;
     DcsCtx *ctx = b->ctx;
-    hipStream_t stream = hipStream ? static_cast<hipStream_t>(hipStream) : ctx->stream;
     if (++b->epoch == 0)
         b->epoch = 1;                   // 0 marks words no launch has written
     const DcsKernelArgs args = kernelArgs(b);
@@ -429,19 +447,40 @@ extern "C" DcsStatus dcs_batch_run(DcsBatch *b, void *hipStream)
     return DCS_OK;
 }
 
+static DcsStatus markLaunched(DcsBatch *b, hipStream_t stream)
+{
+    HIPCHK(b->ctx, hipEventRecord(b->evDone, stream));
+    b->launched = true;
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_batch_run(DcsBatch *b, void *hipStream)
+{
+    if (b == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    DcsCtx *ctx = b->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = hipStream ? static_cast<hipStream_t>(hipStream) : ctx->stream;
+    const DcsStatus st = launchOnce(b, stream);
+    return st != DCS_OK ? st : markLaunched(b, stream);
+}
+
 // `count` launches back to back without returning to the caller in between (a caller that drives the steps from an
 // interpreted language would otherwise be slower per launch than the kernel of a small batch)
 extern "C" DcsStatus dcs_batch_run_many(DcsBatch *b, void *hipStream, int count)
 {
     if (b == nullptr || count < 0)
         return DCS_ERR_INVALID_ARG;
+    DcsCtx *ctx = b->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = hipStream ? static_cast<hipStream_t>(hipStream) : ctx->stream;
     for (int i = 0 ; i < count ; ++i)
     {
-        const DcsStatus st = dcs_batch_run(b, hipStream);
+        const DcsStatus st = launchOnce(b, stream);
         if (st != DCS_OK)
             return st;
     }
-    return DCS_OK;
+    return count ? markLaunched(b, stream) : DCS_OK;
 }
 
 extern "C" DcsStatus dcs_batch_time(DcsBatch *b, void *hipStream, int iters, float *avgMs)
@@ -449,15 +488,21 @@ extern "C" DcsStatus dcs_batch_time(DcsBatch *b, void *hipStream, int iters, flo
     if (b == nullptr || iters < 1 || avgMs == nullptr)
         return DCS_ERR_INVALID_ARG;
     DcsCtx *ctx = b->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = hipStream ? static_cast<hipStream_t>(hipStream) : ctx->stream;
     HIPCHK(ctx, hipEventRecord(b->ev0, stream));
     for (int i = 0 ; i < iters ; ++i)
     {
-        DcsStatus st = dcs_batch_run(b, hipStream);
+        DcsStatus st = launchOnce(b, stream);
         if (st != DCS_OK)
             return st;
     }
     HIPCHK(ctx, hipEventRecord(b->ev1, stream));
+    {
+        const DcsStatus st = markLaunched(b, stream);
+        if (st != DCS_OK)
+            return st;
+    }
     HIPCHK(ctx, hipEventSynchronize(b->ev1));
     float ms = 0;
     HIPCHK(ctx, hipEventElapsedTime(&ms, b->ev0, b->ev1));
@@ -469,6 +514,8 @@ extern "C" DcsStatus dcs_batch_sync(DcsBatch *b)
 {
     if (b == nullptr)
         return DCS_ERR_INVALID_ARG;
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    HIPCHK(b->ctx, waitLaunched(b));
     HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
     return DCS_OK;
 }
@@ -478,6 +525,8 @@ extern "C" DcsStatus dcs_batch_download(DcsBatch *b, int16_t *pcmOut, uint32_t *
     if (b == nullptr)
         return DCS_ERR_INVALID_ARG;
     DcsCtx *ctx = b->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, waitLaunched(b));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (pcmOut)
         HIPCHK(ctx, hipMemcpy(pcmOut, b->dPcm, sizeof(int16_t) * DCS_FRAME_SAMPLES * b->nJobs, hipMemcpyDeviceToHost));
@@ -507,6 +556,8 @@ extern "C" DcsStatus dcs_batch_download_view(DcsBatch *b, const int16_t **pcmOut
         b->hCap[1] = errBytes;
         HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&b->hErr), errBytes));
     }
+    if (b->launched)
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b->evDone, 0));      // the copies follow the last launch, whatever stream it ran on
     HIPCHK(ctx, hipMemcpyAsync(b->hPcm, b->dPcm, pcmBytes, hipMemcpyDeviceToHost, ctx->stream));
     if (errOut != nullptr)
         HIPCHK(ctx, hipMemcpyAsync(b->hErr, b->dErr, errBytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -154,7 +154,7 @@ DcsStatus dcs_stream_params_from(DcsOsVersion os, int volume, int level, int cha
 /* ------------------------------------------------------------------------------------------------
  * Batch description
  */
-typedef struct DcsSrcDesc              /* one channel's contribution to one output frame; 64 bytes     */
+typedef struct DcsSrcDesc              /* one channel's contribution to one output frame; 160 bytes    */
 {
     uint64_t streamOff;                /* byte offset in the blob of the stream's U16 frame count       */
     uint16_t mixMul;                   /* Channel::mixingMultiplier after MainLoop's rescale (:264-269) */
@@ -211,7 +211,11 @@ DcsStatus dcs_decode_batch(DcsCtx *ctx,
                            int16_t *pcmOut, uint32_t *errOut, int16_t *tailsOut);
 
 /* Resident batches: upload once, run many times, download when wanted.  This is the path bench.py
- * times (inputs already in HBM when the clock starts). */
+ * times (inputs already in HBM when the clock starts).
+ * Lifetime and ordering: a batch belongs to its context and must be destroyed before it.  A run may be enqueued on
+ * any stream of the context's device; the batch remembers the completion of its last run call (an event on that
+ * stream), and dcs_batch_sync / _download / _download_view / _destroy wait for it, so a caller's own non-blocking
+ * stream needs no extra synchronisation.  Every entry point makes the context's device current. */
 typedef struct DcsBatch DcsBatch;
 
 DcsStatus dcs_batch_create(DcsCtx *ctx,

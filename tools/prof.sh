@@ -41,7 +41,7 @@ for line in open("summary.txt"):
     m = re.search(r"dcsDecodeKernel<(\d+)>.*\s([A-Z_]+)\s+dispatches=(\d+) avg=([0-9.]+)", line)
     if m:
         vals[m.group(2)] = float(m.group(4)); vals["fpw"] = int(m.group(1))
-    m = re.match(r'"void dcsk::dcsDecodeKernel<\d+>\(DcsKernelArgs\)",(\d+),(\d+),([0-9.]+)', line)
+    m = re.match(r'"void dcsk::dcsDecodeKernel<\d+>\(.*\)",(\d+),(\d+),([0-9.]+)', line)
     if m:
         vals["trace_calls"] = int(m.group(1)); vals["trace_avg_ns"] = float(m.group(3))
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
