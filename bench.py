@@ -1,17 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the batched DCS frame decode on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dcs93_4096|dcs94_65536|mixed_16384]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dcs94_65536|dcs93_4096|mixed_16384|corpus]
 
 One "step" = one pass of the hot path (one kernel launch) over one resident batch of synthetic frames.
 Metric (BASELINE.json): bit-exact int16 PCM samples/s; value = samples of all ranks / max-over-ranks time.
-Multi-GPU: one process per GPU (torch.distributed.run), each rank decodes its own range of the stream
-corpus (weak scaling, no data-path collective: frames of different streams are independent).
+
+Multi-GPU: one process per GPU.  Started as one process with --gpus N > 1 (no RANK in the environment) this script
+starts the N ranks itself (python -m torch.distributed.run ... bench.py, rendezvous on 127.0.0.1) and relays rank 0's
+JSON line; started BY torch.distributed.run it is one of the ranks.  Ranks never exchange frame data (streams are the
+independent units of the path): torch.distributed (RCCL) carries the barrier around the timed region and the max of the
+times, nothing else.
+  * dcs94_65536 / dcs93_4096 / mixed_16384: every rank decodes its own range of the seeded stream corpus, same shape per
+    rank -> "scaling": "weak".
+  * corpus (BASELINE configs[4] stand-in): ONE ragged corpus (titles x streams of U[20, 2000] frames, six layouts), cut
+    into N contiguous stream ranges balanced by total frame count (dcs_partition_streams) -> "scaling": "strong".
+
+--rehearse: no GPU is touched (gloo on CPU); the ranks run launcher, partition, host planning/packing of their share,
+barrier and max-over-ranks, and rank 0 prints the line with "value": null.  It exists so that the N-rank path can be
+exercised on a box without GPUs; it measures nothing.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,47 +35,138 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+DEFAULT_WORKLOAD = "dcs94_65536"  # BASELINE.json configs[2]: the configuration the roofline is quoted on
 
 
-def cpu_baseline(streams, budget_s=12.0):
-    """the CPU checker timed on this box's host cores on a bounded sample of the same workload: the
-    compiled reference (oracle/_ref) when it travelled with the repo, else the oracle port.  The
-    threads live inside the C library (no Python in the timed loop); each thread plays its share of the
-    streams through one decoder object, LoadAudioStream + 240 x GetNextSample per frame, the way the
-    reference's own batch decode (--extract-streams) drives the path."""
-    from oracle.dcs_oracle import Oracle, Reference, reference_available
-    kind = "reference" if reference_available() else "port"
-    chk = Reference() if kind == "reference" else Oracle()
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    frames_per_pass = sum((s[1][0] << 8) | s[1][1] for s in streams)
-    # calibrate one pass, then size the repeat count for the budget
-    t0 = time.perf_counter()
-    chk.decode_many(streams, 1, cores)
-    one = max(time.perf_counter() - t0, 1e-4)
-    repeat = max(1, int(budget_s / one))
-    t0 = time.perf_counter()
-    frames = chk.decode_many(streams, repeat, cores)
-    dt = time.perf_counter() - t0
-    return dict(value=frames * 240 / dt, unit="samples/s", cores=cores, kind=kind,
-                sample="the %d streams (%d frames) of the workload decoded %d times in %.1f s on %d threads, "
-                       "one decoder object per thread" % (len(streams), frames_per_pass, repeat, dt, cores))
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="dcs93_4096")
-    ap.add_argument("--fpw", type=int, default=0, help="frames per wavefront override (8/16/32/64)")
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD)
+    ap.add_argument("--fpw", type=int, default=0, help="frames per wavefront override (4/8/16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight: the K steps are dealt to this many batch objects "
                     "(same workload), each on a stream of its own, so that launches of different batches overlap on the GPU "
                     "(1 = the contract's back-to-back steps; more is reported as config.inflight, never the default)")
     ap.add_argument("--scale", type=int, default=1, help="decode SCALE times the workload's streams per step (further "
                     "seeds of the same recipe): the large-batch rate; not a BASELINE config")
-    args = ap.parse_args()
+    ap.add_argument("--corpus-titles", type=int, default=29)
+    ap.add_argument("--corpus-streams", type=int, default=20, help="streams per title of the corpus workload (SURVEY 8d's full "
+                    "stand-in is 600; 20 is the size whose per-stream reference hashes are committed)")
+    ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the N-rank path (gloo, no GPU, no kernel)")
+    return ap.parse_args(argv)
 
+
+# --------------------------------------------------------------------------------------------- launcher
+def launch_ranks(args):
+    """--gpus N > 1 from a plain `python bench.py`: start the N ranks.  Decided before anything touches torch or the
+    GPU; this process only waits and relays (rank 0 prints the JSON line on the shared stdout)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(streams, budget_s=10.0):
+    """the CPU checker timed on this box's host cores on a bounded sample of the same workload: the compiled reference
+    (oracle/_ref) when it travelled with the repo, else the oracle port.  The threads live inside the C library (no
+    Python in the timed loop); each thread plays its share of the streams through one decoder object, LoadAudioStream +
+    240 x GetNextSample per frame, the way the reference's own batch decode (--extract-streams) drives the path.
+    Two legs: T = 1 and T = the CPUs this process can really use."""
+    import dcsexplorer_amd as D
+    from oracle.dcs_oracle import Oracle, Reference, reference_available
+    kind = "reference" if reference_available() else "port"
+    chk = Reference() if kind == "reference" else Oracle()
+    usable = D.host_threads()                                   # affinity mask, limited by a cgroup CPU quota
+    threads = max(1, min(usable, 64))
+    frames_per_pass = sum((s[1][0] << 8) | s[1][1] for s in streams)
+
+    def leg(nthreads, budget):
+        t0 = time.perf_counter()
+        chk.decode_many(streams, 1, nthreads)                   # calibrate one pass, then size the repeat count
+        one = max(time.perf_counter() - t0, 1e-4)
+        repeat = max(1, int(budget / one))
+        t0 = time.perf_counter()
+        frames = chk.decode_many(streams, repeat, nthreads)
+        dt = time.perf_counter() - t0
+        return frames * 240 / dt, repeat, dt
+
+    v1, rep1, dt1 = leg(1, budget_s * 0.3)
+    vt, rept, dtt = leg(threads, budget_s * 0.7) if threads > 1 else (v1, rep1, dt1)
+    return dict(value=vt, unit="samples/s", cores=threads, kind=kind, threads=threads,
+                affinity_cores=len(os.sched_getaffinity(0)), os_cpu_count=os.cpu_count(), usable_cpus=usable,
+                t1_value=v1, per_thread=vt / threads,
+                sample="%d streams (%d frames) of the workload: decoded %d times in %.1f s on 1 thread and %d times in "
+                       "%.1f s on %d threads, one decoder object per thread" % (len(streams), frames_per_pass, rep1, dt1,
+                                                                               rept, dtt, threads))
+
+
+# --------------------------------------------------------------------------------------------- end to end
+def end_to_end(ctx, streams, n_frames, depth=3, lists=12):
+    """host buffers in, host buffers out (never `value`): index pass + parameters + plan + pack + H2D + kernel + D2H.
+    cold: one synchronous dcs_decode_streams call per list.  sustained: the same lists through dcs_pipeline with
+    `depth` lists in flight (host preparation of list k+1 while the GPU decodes k and k-1 comes back into pinned memory)."""
+    import numpy as np
+    import dcsexplorer_amd as D
+    refs, keep = D.make_refs(streams)
+    L = ctx.L
+    pcm = np.zeros((n_frames, 240), dtype=np.int16)
+    first = np.zeros(len(streams) + 1, dtype=np.uint32)
+
+    def one_call():
+        st = L.dcs_decode_streams(ctx.h, refs, len(streams), 0, pcm.ctypes.data_as(ctypes.c_void_p), n_frames,
+                                  first.ctypes.data_as(ctypes.c_void_p), None)
+        if st != 0:
+            raise D.DcsError(st)
+    one_call()                                                  # buffers of the context's cache exist from here on
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one_call()
+    cold_s = (time.perf_counter() - t0) / reps
+
+    pipe = ctx.pipeline(depth)
+    host_ms, dev_ms = [], []
+    for _ in range(depth):                                      # warm: every worker has had a list
+        pipe.submit_refs(refs, len(streams))
+    for _ in range(depth):
+        pipe.collect()
+    t0 = time.perf_counter()
+    done = 0
+    for k in range(lists):
+        pipe.submit_refs(refs, len(streams))                    # (blocks while `depth` lists are in flight)
+        if k >= depth - 1:
+            r = pipe.collect(); done += 1
+            host_ms.append(r[3]); dev_ms.append(r[4])
+    while done < lists:
+        r = pipe.collect(); done += 1
+        host_ms.append(r[3]); dev_ms.append(r[4])
+    sus_s = (time.perf_counter() - t0) / lists
+    pipe.close()
+    samples = n_frames * 240
+    h, d = sum(host_ms) / len(host_ms), sum(dev_ms) / len(dev_ms)
+    return {"unit": "samples/s", "frames_per_list": n_frames,
+            "cold": {"value": samples / cold_s, "ms_per_list": cold_s * 1e3,
+                     "what": "dcs_decode_streams: index + parameters + plan + pack + H2D + kernel + D2H into pageable memory, one list at a time"},
+            "sustained": {"value": samples / sus_s, "ms_per_list": sus_s * 1e3, "depth": depth, "lists": lists,
+                          "worker_host_ms": h, "worker_device_ms": d,
+                          "what": "dcs_pipeline: %d lists in flight, PCM returned in pinned memory" % depth},
+            "bound": "host" if h > d else "device+PCIe",
+            "bound_note": "per list a worker spends %.2f ms in host preparation (index pass on the host pool, parameters, "
+                          "planner, packer) and %.2f ms in upload + kernel + download" % (h, d)}
+
+
+# --------------------------------------------------------------------------------------------- one rank
+def run_rank(args):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -67,35 +174,77 @@ def main():
     from dcsexplorer_amd import sharding, workloads
 
     rank, local_rank, world = sharding.rank_info()
-
+    rehearse = args.rehearse
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif not rehearse:
         torch.cuda.set_device(local_rank)
 
-    # this rank's range of the corpus: same shape on every rank, different streams (seeds)
-    streams = sharding.rank_streams(args.workload, rank)
-    if args.scale > 1:
-        import inspect
-        fn = workloads.WORKLOADS[args.workload]
-        n = inspect.signature(fn).parameters["n_streams"].default
-        streams = fn(n_streams=n * args.scale * world)[rank * n * args.scale:(rank + 1) * n * args.scale]
-    b = D.build_stream_batch(streams)
+    # ---- this rank's share of the work ------------------------------------------------------------------------
+    corpus = args.workload == "corpus"
+    golden_range = None
+    if corpus:
+        spec = dict(titles=args.corpus_titles, streams_per_title=args.corpus_streams, max_frames=2000, seed=0x0005)
+        manifest = workloads.corpus_manifest(**spec)
+        lo, hi = sharding.rank_corpus(manifest, world, rank)           # contiguous stream range, balanced by frames
+        streams = workloads.corpus_streams(manifest, lo, hi)
+        total_frames = int(workloads.corpus_frames(manifest).sum())    # of ALL ranks: the same corpus cut N ways
+        golden_range = (spec, lo, hi)
+        scaling = "strong"
+    else:
+        streams = sharding.rank_streams(args.workload, rank)           # same shape on every rank, different seeds
+        if args.scale > 1:
+            import inspect
+            fn = workloads.WORKLOADS[args.workload]
+            n = inspect.signature(fn).parameters["n_streams"].default
+            streams = fn(n_streams=n * args.scale * world)[rank * n * args.scale:(rank + 1) * n * args.scale]
+        total_frames = None
+        scaling = "weak"
+    b = D.build_stream_batch(streams, indexer=D.index_streams)
     if args.workload == "mixed_16384":
         b, _ = workloads.interleave(b)
     n_frames = int(b["jobs"].size)
+    if total_frames is None:
+        total_frames = n_frames * world
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if rehearse:
+        # no kernel: the step is the host half of dcs_batch_create (planner + packer) for this rank's share
+        t0 = time.perf_counter()
+        for _ in range(max(1, args.steps)):
+            D.pack_chunks(b["blob"], b["srcs"], b["jobs"], 8)
+        barrier()
+        dt = sharding.max_over_ranks(time.perf_counter() - t0)
+        counts = [0] * world
+        if world > 1:
+            t = torch.zeros(world, dtype=torch.int64); t[rank] = n_frames
+            dist.all_reduce(t); counts = [int(x) for x in t]
+        else:
+            counts = [n_frames]
+        if rank == 0:
+            print(json.dumps({"metric": "bit_exact_int16_pcm_samples_per_sec", "value": None, "unit": "samples/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(1, args.steps) * 1e3,
+                              "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int16",
+                              "data": "synthetic", "rehearsal": "CPU rehearsal of the N-rank path: no GPU, no kernel, nothing measured",
+                              "config": {"workload": args.workload, "frames_per_rank": counts, "frames_total": sum(counts),
+                                         "partition": "range over streams, balanced by frames, no collective"}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     ctx = D.Context(local_rank)
     if args.fpw:
         ctx.set_frames_per_wave(args.fpw)
     batch = ctx.batch(b["blob"], b["srcs"], b["jobs"])
     stream = torch.cuda.current_stream().cuda_stream
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
 
     # further batches of the same workload on streams of their own (--inflight): a step is still one launch over one batch
     extra = [(ctx.batch(b["blob"], b["srcs"], b["jobs"]), torch.cuda.Stream()) for _ in range(max(0, args.inflight - 1))]
@@ -116,37 +265,50 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-
     dt = sharding.max_over_ranks(dt, device="cuda")
 
     # kernel-only average duration by HIP events on the launch stream (roofline denominator)
     kern_ms = batch.time(max(10, args.steps), stream)
-    algo_bytes = batch.algorithmic_bytes
+    clock_mhz = ctx.clock_mhz()             # shader clock under an integer load, measured right behind the timed launches
+    algo_bytes = batch.algorithmic_bytes    # payload + stream headers + 56 B per frame + 480 B PCM
 
-    # bit-exactness of what was just timed (rank 0, default corpus range): per-stream hashes vs the
-    # reference's committed hashes
+    # bit-exactness of what was just timed (rank 0): per-stream hashes vs the reference's committed hashes
     bit_exact = None
     if rank == 0:
-        from oracle.dcs_oracle import fnv1a64
+        from oracle.dcs_oracle import Oracle
+        orc = Oracle()
         pcm, err = batch.download()
-        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "dcs_golden_hashes.json")))["workloads"]
-        if args.workload in gold and args.scale == 1:
+        gold = None
+        if corpus:
+            cg = json.load(open(os.path.join(ROOT, "tests", "golden", "corpus_golden.json")))
+            if cg["corpus"] == golden_range[0]:
+                gold = cg["stream_hashes"][golden_range[1]:golden_range[2]]
+            first = b["first_job"]
+        elif args.scale == 1:
+            g = json.load(open(os.path.join(ROOT, "tests", "golden", "dcs_golden_hashes.json")))["workloads"]
+            gold = g.get(args.workload, {}).get("stream_hashes")
             if args.workload == "mixed_16384":
-                _, perm = workloads.interleave(D.build_stream_batch(streams))
+                plain = D.build_stream_batch(streams, indexer=D.index_streams)
+                _, perm = workloads.interleave(plain)
                 inv = np.empty_like(perm); inv[perm] = np.arange(perm.size)
                 pcm = pcm[inv]
-            first = D.build_stream_batch(streams)["first_job"] if args.workload == "mixed_16384" else b["first_job"]
-            got = ["%016x" % fnv1a64(pcm[first[k]:first[k + 1]].tobytes()) for k in range(len(first) - 1)]
-            bit_exact = bool(got == gold[args.workload]["stream_hashes"]) and not bool(err.any())
+                first = plain["first_job"]
+            else:
+                first = b["first_job"]
+        if gold is not None:
+            got = ["%016x" % orc.fnv1a64(pcm[first[k]:first[k + 1]]) for k in range(len(first) - 1)]
+            bit_exact = bool(got == gold) and not bool(err.any())
 
     if rank == 0:
-        samples = n_frames * 240 * world * args.steps
+        samples = total_frames * 240 * args.steps
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
         # HBM traffic per launch: FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes of this same command
         # (tools/prof.sh), committed under profiles/; null when no profile of this workload exists
         traffic, traffic_note, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath) and args.scale == 1 and not args.fpw:       # (the committed counters are those of the plain workload)
+        plain_run = args.scale == 1 and not args.fpw and world == 1 and args.inflight == 1 and \
+            (not corpus or (args.corpus_titles, args.corpus_streams) == (29, 20))
+        if os.path.exists(tpath) and plain_run:                  # (the committed counters are those of the plain workload)
             t = json.load(open(tpath))
             # the kernel's reads are 16-byte-per-lane loads of the chunk packages, for which FETCH_SIZE reports half
             # the bytes on gfx950 (MI355X_MICROARCH.md, HBM section): doubled here; WRITE_SIZE is exact
@@ -154,16 +316,17 @@ def main():
             traffic_note = ("2 x FETCH_SIZE + WRITE_SIZE from %s (separate --pmc passes; kilobytes; the gfx950 wide-read "
                             "correction applied to FETCH_SIZE; uncorrected sum: %d)"
                             % (os.path.relpath(tpath, ROOT), t["traffic_bytes_fetch_raw"]))
-            if "SQ_INSTS_VALU" in t and "GRBM_GUI_ACTIVE" in t:
-                # what actually bounds this integer kernel: wave64 VALU issue, 4 cycles per instruction per SIMD.
-                # Counters are from the committed profile of this workload; the cycle count is GRBM_GUI_ACTIVE
-                # (summed over the 8 XCDs) of the same profile.
+            if "SQ_INSTS_VALU" in t:
+                # what actually bounds this integer kernel: wave64 VALU issue, 4 cycles per instruction per SIMD.  The
+                # instruction count per launch is a property of (workload, binary) and comes from the committed
+                # counter pass; the cycles are THIS run's: measured kernel duration x measured shader clock.
                 simds = 256 * 4
-                cycles = t["GRBM_GUI_ACTIVE"] / 8.0
-                valu = {"valu_insts_per_launch": t["SQ_INSTS_VALU"], "simds": simds, "issue_cycles_per_inst": 4,
-                        "kernel_cycles": cycles, "frac_of_valu_issue_peak": t["SQ_INSTS_VALU"] * 4 / (simds * cycles),
-                        "lds_bank_conflict_cycles": t.get("SQ_LDS_BANK_CONFLICT"),
-                        "source": os.path.relpath(tpath, ROOT)}
+                cycles = kern_ms * 1e-3 * clock_mhz * 1e6
+                valu = {"valu_insts_per_launch": t["SQ_INSTS_VALU"], "insts_source": "from_profile: " + os.path.relpath(tpath, ROOT),
+                        "simds": simds, "issue_cycles_per_inst": 4, "kernel_cycles": cycles,
+                        "kernel_cycles_source": "in-run: kernel_avg_ms x clock_mhz (probe kernel, dcs_ctx_clock_mhz)",
+                        "clock_mhz": clock_mhz, "frac_of_valu_issue_peak": t["SQ_INSTS_VALU"] * 4 / (simds * cycles),
+                        "lds_bank_conflict_cycles": t.get("SQ_LDS_BANK_CONFLICT"), "lds_idx_active": t.get("SQ_LDS_IDX_ACTIVE")}
         out = {
             "metric": "bit_exact_int16_pcm_samples_per_sec",
             "value": samples / dt,
@@ -173,22 +336,34 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
-            "config": {"workload": args.workload, "frames_per_gpu_per_step": n_frames,
-                       "samples_per_frame": 240, "frames_per_wave": args.fpw or "auto",
+            "config": {"workload": args.workload, "frames_rank0_per_step": n_frames, "frames_all_ranks_per_step": total_frames,
+                       "samples_per_frame": 240, "frames_per_wave": batch.frames_per_wave, "wavefronts_per_launch": batch.num_chunks,
                        "arithmetic": "ADSP-2105 1.15 fixed point, 32-bit integer intermediates",
-                       "partition": "range over streams, no collective", "scale": args.scale, "inflight": args.inflight},
+                       "partition": "range over streams%s, no collective" % (", balanced by frames" if corpus else ""),
+                       "scale": args.scale, "inflight": args.inflight},
             "bit_exact": bit_exact,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "dcsDecodeKernel", "kernel_avg_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes, "valu_issue": valu},
+                         "kernel": "dcsDecodeKernel<%d>" % batch.frames_per_wave, "kernel_avg_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "algorithmic_bytes_note": "SURVEY 8(d): exact payload + stream headers + 56 B descriptor and 480 B PCM per frame "
+                                                   "(x %d frames per launch)" % n_frames,
+                         "abi_bytes_per_launch": batch.abi_bytes, "valu_issue": valu},
         }
+        if corpus:
+            out["config"]["corpus"] = golden_range[0]
+            out["config"]["rank0_stream_range"] = [golden_range[1], golden_range[2]]
+        if world == 1 and not args.no_end_to_end:
+            out["end_to_end"] = end_to_end(ctx, streams, n_frames)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(streams)
+            sample = streams if not corpus else streams[:64]
+            out["cpu_baseline"] = cpu_baseline(sample)
+            if "end_to_end" in out:
+                out["end_to_end"]["sustained_vs_cpu_baseline"] = out["end_to_end"]["sustained"]["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
 
     for bt, _ in extra:
@@ -197,6 +372,13 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

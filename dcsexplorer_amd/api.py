@@ -12,7 +12,7 @@ OS93A, OS93B, OS94, OS95 = 0, 1, 2, 3
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NO_MEMORY, ERR_CAPACITY, ERR_BAD_STREAM = -1, -2, -3, -4, -5, -6
 FMT_93_T0, FMT_93B_T1, FMT_93A_T1, FMT_94_T0, FMT_94_T1_S0, FMT_94_T1_S3 = range(6)
 FRAME_SAMPLES = 240
-FRAME_STOP, FRAME_FATAL = 1, 2
+FRAME_STOP, FRAME_FATAL, FRAME_TAIL_LOST = 1, 2, 4
 PREV_NONE = 0xFFFFFFFF
 PREV_EXT = 0x80000000
 XFORM_93, XFORM_94 = 0, 1
@@ -63,6 +63,12 @@ EXTRACT_DTYPE = np.dtype([("track", "<u4"), ("streamNum", "<u4"), ("address", "<
 HW_DCS93, HW_DCS95 = 2, 3
 
 
+class PipelineResult(ctypes.Structure):
+    _fields_ = [("pcm", ctypes.c_void_p), ("err", ctypes.c_void_p), ("frameOffsets", ctypes.c_void_p),
+                ("nFrames", ctypes.c_uint32), ("nStreams", ctypes.c_uint32), ("status", ctypes.c_int32),
+                ("hostMs", ctypes.c_float), ("deviceMs", ctypes.c_float)]
+
+
 class SynthParams(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("format", ctypes.c_int32), ("nFrames", ctypes.c_int32),
                 ("nBands", ctypes.c_int32), ("strideFromBand", ctypes.c_int32), ("profile", ctypes.c_int32),
@@ -95,6 +101,9 @@ EXPORTS = [
     "dcs_seq_plan", "dcs_seq_pending_ticks", "dcs_seq_is_fatal", "dcs_seq_host_bytes", "dcs_seq_decode",
     "dcs_seq_create_standalone", "dcs_seq_load_audio_stream_mem", "dcs_seq_rewind", "dcs_seq_set_rewindable",
     "dcs_seq_tick", "dcs_seq_fatal_tick", "dcs_seq_stream_playing",
+    "dcs_host_threads", "dcs_partition_streams", "dcs_decode_streams_sharded",
+    "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_set_test_hooks",
+    "dcs_pipeline_create", "dcs_pipeline_destroy", "dcs_pipeline_submit", "dcs_pipeline_collect",
 ]
 
 
@@ -170,7 +179,9 @@ def load_library():
     L.dcs_batch_num_jobs.restype = u32
     L.dcs_batch_num_jobs.argtypes = [vp]
     L.dcs_decode_streams.restype = i32
+    L.dcs_decode_streams.argtypes = [vp, vp, u32, u32, vp, sz, vp, vp]
     L.dcs_count_stream_frames.restype = i32
+    L.dcs_count_stream_frames.argtypes = [vp, u32, u32, ctypes.POINTER(ctypes.c_uint64)]
     L.dcs_synth_stream.restype = i32
     L.dcs_synth_stream.argtypes = [ctypes.POINTER(SynthParams), vp, sz, ctypes.POINTER(sz)]
     L.dcs_plan_chunks.restype = i32
@@ -253,6 +264,30 @@ def load_library():
     L.dcs_index_streams_gpu.argtypes = [vp, vp, sz, vp, u32, vp, ctypes.c_uint64, vp]
     L.dcs_index_streams_gpu_time.restype = i32
     L.dcs_index_streams_gpu_time.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    L.dcs_batch_abi_bytes.restype = ctypes.c_uint64
+    L.dcs_batch_abi_bytes.argtypes = [vp]
+    L.dcs_batch_num_chunks.restype = u32
+    L.dcs_batch_num_chunks.argtypes = [vp]
+    L.dcs_batch_frames_per_wave.restype = ctypes.c_int
+    L.dcs_batch_frames_per_wave.argtypes = [vp]
+    L.dcs_ctx_clock_mhz.restype = i32
+    L.dcs_ctx_clock_mhz.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.dcs_ctx_set_test_hooks.restype = i32
+    L.dcs_ctx_set_test_hooks.argtypes = [vp, u32, ctypes.c_int]
+    L.dcs_pipeline_create.restype = i32
+    L.dcs_pipeline_create.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
+    L.dcs_pipeline_destroy.restype = None
+    L.dcs_pipeline_destroy.argtypes = [vp]
+    L.dcs_pipeline_submit.restype = i32
+    L.dcs_pipeline_submit.argtypes = [vp, vp, u32, u32]
+    L.dcs_pipeline_collect.restype = i32
+    L.dcs_pipeline_collect.argtypes = [vp, ctypes.POINTER(PipelineResult)]
+    L.dcs_host_threads.restype = ctypes.c_int
+    L.dcs_host_threads.argtypes = []
+    L.dcs_partition_streams.restype = i32
+    L.dcs_partition_streams.argtypes = [vp, u32, u32, vp]
+    L.dcs_decode_streams_sharded.restype = i32
+    L.dcs_decode_streams_sharded.argtypes = [vp, u32, vp, u32, u32, vp, sz, vp, vp, vp]
     _LIB = L
     return L
 
@@ -495,6 +530,55 @@ def device_count():
     return load_library().dcs_device_count()
 
 
+def host_threads():
+    """dcs_host_threads: CPUs this process can really use (affinity mask, cgroup quota)"""
+    return load_library().dcs_host_threads()
+
+
+def partition_streams(frame_counts, n_parts):
+    """dcs_partition_streams: cut points (n_parts + 1) of contiguous ranges balanced by total frame count"""
+    fc = np.ascontiguousarray(frame_counts, dtype=np.uint32)
+    cut = np.zeros(n_parts + 1, dtype=np.uint32)
+    st = load_library().dcs_partition_streams(_ptr(fc), fc.size, n_parts, _ptr(cut))
+    if st != 0:
+        raise DcsError(st)
+    return cut
+
+
+def _stream_refs(streams):
+    keep = [np.frombuffer(bytes(s[1]), dtype=np.uint8) for s in streams]
+    refs = (StreamRef * len(streams))()
+    for k, s in enumerate(streams):
+        refs[k].data = keep[k].ctypes.data
+        refs[k].len = keep[k].size
+        refs[k].os = s[0]
+        refs[k].volume = s[2]
+        refs[k].level = s[3]
+        refs[k].channelVolume = 0xFF
+    return refs, keep
+
+
+def decode_streams_sharded(device_ids, streams, extra_frames=0):
+    """dcs_decode_streams_sharded: (os, bytes, volume, level) streams over several devices (one host thread and one
+    context per device, range partition balanced by frames) -> (pcm [frames, 240], err, first frame of each stream,
+    first stream of each device)"""
+    L = load_library()
+    streams = list(streams)
+    refs, keep = _stream_refs(streams)
+    total = int(sum(((int(k[0]) << 8) | int(k[1])) + extra_frames for k in keep))
+    pcm = np.zeros((total, FRAME_SAMPLES), dtype=np.int16)
+    err = np.zeros(total, dtype=np.uint32)
+    first = np.zeros(len(streams) + 1, dtype=np.uint32)
+    devs = np.ascontiguousarray(device_ids, dtype=np.int32)
+    cut = np.zeros(devs.size + 1, dtype=np.uint32)
+    st = L.dcs_decode_streams_sharded(_ptr(devs), devs.size, refs, len(streams), extra_frames, _ptr(pcm), total,
+                                      _ptr(first), _ptr(err), _ptr(cut))
+    if st != 0:
+        msg = L.dcs_last_error(None)
+        raise DcsError(st, msg.decode() if msg else "")
+    return pcm, err, first, cut
+
+
 # ---------------------------------------------------------------------------------------------- device side
 class Context:
     """DcsCtx: one GPU.  Raises DcsError(DCS_ERR_NO_DEVICE) when there is no gfx950 device."""
@@ -587,6 +671,18 @@ class Context:
                                                  _ptr(first), _ptr(err)), self.h)
         return pcm, err, first
 
+    def clock_mhz(self):
+        """dcs_ctx_clock_mhz: the shader clock under an integer load on every SIMD (probe kernel)"""
+        mhz = ctypes.c_float()
+        _check(self.L.dcs_ctx_clock_mhz(self.h, ctypes.byref(mhz)), self.h)
+        return mhz.value
+
+    def set_test_hooks(self, handoff_timeout_us=0, drop_exports=False):
+        _check(self.L.dcs_ctx_set_test_hooks(self.h, int(handoff_timeout_us), int(bool(drop_exports))), self.h)
+
+    def pipeline(self, depth=3):
+        return Pipeline(self, depth)
+
     def index_streams_gpu(self, streams):
         """dcs_index_streams_gpu: the index pass on the GPU, one lane per stream.  Same result as
         index_streams / index_stream."""
@@ -661,6 +757,18 @@ class Batch:
     def algorithmic_bytes(self):
         return int(self.L.dcs_batch_algorithmic_bytes(self.h))
 
+    @property
+    def abi_bytes(self):
+        return int(self.L.dcs_batch_abi_bytes(self.h))
+
+    @property
+    def num_chunks(self):
+        return int(self.L.dcs_batch_num_chunks(self.h))
+
+    @property
+    def frames_per_wave(self):
+        return int(self.L.dcs_batch_frames_per_wave(self.h))
+
     def close(self):
         if self.h:
             if self.ctx.h:                      # (a closed context has already destroyed its batches)
@@ -672,6 +780,60 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+class Pipeline:
+    """DcsPipeline: lists of whole streams in, PCM out in submission order, `depth` lists in flight"""
+
+    def __init__(self, ctx, depth=3):
+        self.ctx = ctx
+        self.L = ctx.L
+        h = ctypes.c_void_p()
+        _check(self.L.dcs_pipeline_create(ctx.h, depth, ctypes.byref(h)), ctx.h)
+        self.h = h
+        self._keep = []                         # (refs, byte buffers) of submitted lists, oldest first
+        ctx._batches.add(self)                  # closed before the context, like a batch
+
+    def submit_refs(self, refs, n, extra_frames=0, keep=None):
+        """submit a prepared StreamRef array (see make_refs); the caller keeps it alive until collected"""
+        self._keep.append((refs, keep))
+        _check(self.L.dcs_pipeline_submit(self.h, refs, n, extra_frames), self.ctx.h)
+
+    def submit(self, streams, extra_frames=0):
+        streams = list(streams)
+        refs, keep = _stream_refs(streams)
+        self.submit_refs(refs, len(streams), extra_frames, keep)
+
+    def collect(self):
+        """-> (pcm [frames, 240], err, first frame of each stream, hostMs, deviceMs): views of pinned memory, valid
+        until the next collect"""
+        r = PipelineResult()
+        st = self.L.dcs_pipeline_collect(self.h, ctypes.byref(r))
+        if self._keep:
+            self._keep.pop(0)
+        _check(st, self.ctx.h)
+        pcm = np.ctypeslib.as_array(ctypes.cast(r.pcm, ctypes.POINTER(ctypes.c_int16)), shape=(r.nFrames, FRAME_SAMPLES))
+        err = np.ctypeslib.as_array(ctypes.cast(r.err, ctypes.POINTER(ctypes.c_uint32)), shape=(r.nFrames,))
+        first = np.ctypeslib.as_array(ctypes.cast(r.frameOffsets, ctypes.POINTER(ctypes.c_uint32)), shape=(r.nStreams + 1,))
+        return pcm, err, first, r.hostMs, r.deviceMs
+
+    def close(self):
+        if self.h:
+            if self.ctx.h:
+                self.L.dcs_pipeline_destroy(self.h)
+            self.h = None
+            self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_refs(streams):
+    """StreamRef array for (os, bytes, volume, level) streams -> (refs, keep-alive buffers)"""
+    return _stream_refs(list(streams))
 
 
 class RomSet:

@@ -194,12 +194,24 @@ struct DcsKernelArgs
     unsigned long long *handoff;
     uint32_t            epoch;
     uint32_t            flags;          // DCS_BATCH_*
+    uint32_t            timeoutTicks;   // bound of the wait for a tail from another chunk, 100 MHz ticks
 };
 #define DCS_BATCH_HAS_93A_T1 1u         // some source is an OS93a Type-1 frame: workgroups stage the pair table in LDS
 
 // planner: returns the number of chunks; slots is resized to nChunks * fpw
 #ifdef __cplusplus
 #include <vector>
+// whole streams -> batch description (dcs_streams.cpp): index pass on the host pool, per-frame mixing parameters, the
+// streams laid out back to back in one blob, one job per output frame
+struct DcsBuiltStreams
+{
+    std::vector<uint8_t> blob;
+    std::vector<DcsSrcDesc> srcs;
+    std::vector<DcsFrameJob> jobs;
+    std::vector<uint32_t> firstJob;     // per stream, plus a final total
+};
+DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, DcsBuiltStreams &B,
+                          bool countOnly, bool sequence);
 uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true);
 // packer: out = nChunks x dcsPkgBytes(fpw) bytes (the chunk packages described above)
 void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const DcsSrcDesc *srcs,

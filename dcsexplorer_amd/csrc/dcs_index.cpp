@@ -6,6 +6,9 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -140,8 +143,55 @@ private:
 
 }   // namespace
 
+// Host threads this process may actually run at once: the CPUs of its affinity mask, further limited by a cgroup
+// CPU quota when there is one (a container given 16 CPUs of a 256-thread host reports 256 hardware threads).
+static long long readNumber(const char *path, bool *isMax = nullptr)
+{
+    FILE *f = fopen(path, "r");
+    if (f == nullptr)
+        return -1;
+    char word[32] = { 0 };
+    const int got = fscanf(f, "%31s", word);
+    fclose(f);
+    if (got != 1)
+        return -1;
+    if (isMax != nullptr)
+        *isMax = word[0] == 'm';                                // cgroup v2 writes "max" for "no quota"
+    return word[0] == 'm' ? -1 : atoll(word);
+}
+
+extern "C" int dcs_host_threads(void)
+{
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0)
+        n = CPU_COUNT(&set);
+    if (n <= 0)
+        n = static_cast<int>(std::thread::hardware_concurrency());
+    long long quota = -1, period = -1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r"))        // cgroup v2: "<quota|max> <period>"
+    {
+        char word[32] = { 0 };
+        if (fscanf(f, "%31s %lld", word, &period) == 2 && word[0] != 'm')
+            quota = atoll(word);
+        fclose(f);
+    }
+    else                                                        // cgroup v1
+    {
+        quota = readNumber("/sys/fs/cgroup/cpu/cpu.cfs_quota_us");
+        period = readNumber("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    }
+    if (quota > 0 && period > 0)
+    {
+        const long long q = (quota + period - 1) / period;
+        if (q >= 1 && q < n)
+            n = static_cast<int>(q);
+    }
+    return n < 1 ? 1 : n;
+}
+
 // Stream k's records go to out + firstRecord[k]; it writes at most nFrames(k) of them (the U16 prefix
-// of the stream).  nThreads 0 = the hardware threads, at most 64 and at most one per stream.
+// of the stream).  nThreads 0 = dcs_host_threads(), at most 64 and at most one per stream.
 extern "C" DcsStatus dcs_index_streams(const DcsStreamRef *streams, uint32_t nStreams, int nThreads,
                                        DcsFrameIndex *out, const uint64_t *firstRecord, DcsStreamInfo *infos)
 {
@@ -151,7 +201,7 @@ extern "C" DcsStatus dcs_index_streams(const DcsStreamRef *streams, uint32_t nSt
         return DCS_OK;
     if (nThreads <= 0)
     {
-        nThreads = static_cast<int>(std::thread::hardware_concurrency());
+        nThreads = dcs_host_threads();
         if (nThreads > 64) nThreads = 64;
     }
     if (nThreads < 1) nThreads = 1;

@@ -44,7 +44,7 @@ struct Stamper
 };
 #define DCS_STAMP(k) stamp(k)
 
-constexpr unsigned long long kHandoffTimeoutTicks = 400000000ull;    // bound of the wait for a tail from another chunk: 4 s (100 MHz ticks)
+constexpr uint32_t kHandoffTimeoutTicks = 400000000u;    // default bound of the wait for a tail from another chunk: 4 s (100 MHz ticks)
 constexpr int kWavesPerBlock = 4;       // wavefronts of a workgroup share one copy of the decode tables in LDS
 constexpr int kRowBytes = 528;          // 256 words + 16 bytes: 16-byte aligned rows (the transforms transpose through them
                                         // with 128-bit accesses), rows of neighbouring frames land on different LDS banks
@@ -1330,12 +1330,13 @@ template <int FPW>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, DCS_MIN_WAVES)
 dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChunks, uint32_t kFlags, uint32_t kEpoch, uint32_t kNJobs,
                 int16_t *kPcm, unsigned long long *kHandoff, uint32_t *kErr, int16_t *kTailsOut,
-                const uint8_t *kBlob, uint64_t kBlobLen, const DcsSrcDesc *kSrcs, const int16_t *kTailsIn, unsigned long long *kDebug)
+                const uint8_t *kBlob, uint64_t kBlobLen, const DcsSrcDesc *kSrcs, const int16_t *kTailsIn, unsigned long long *kDebug,
+                uint32_t kTimeoutTicks)
 {
     DcsKernelArgs a;
     a.blob = kBlob; a.blobLen = kBlobLen; a.srcs = kSrcs; a.packages = kPackages; a.nChunks = kNChunks; a.nJobs = kNJobs;
     a.pcm = kPcm; a.err = kErr; a.tailsIn = kTailsIn; a.tailsOut = kTailsOut; a.tables = kTables; a.debug = kDebug;
-    a.handoff = kHandoff; a.epoch = kEpoch; a.flags = kFlags;
+    a.handoff = kHandoff; a.epoch = kEpoch; a.flags = kFlags; a.timeoutTicks = kTimeoutTicks;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = static_cast<int>(threadIdx.x) >> 6;
     const int lane = static_cast<int>(threadIdx.x) & 63;
@@ -1940,7 +1941,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
             unsigned long long w = (sI == firstImport) ? earlyWord : 0ull;              // (epoch 0 never matches)
             // (bounded by wall time, 100 MHz ticks)
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (static_cast<uint32_t>(w >> 32) != a.epoch && __builtin_amdgcn_s_memrealtime() - t0 < kHandoffTimeoutTicks)
+            while (static_cast<uint32_t>(w >> 32) != a.epoch && __builtin_amdgcn_s_memrealtime() - t0 < a.timeoutTicks)
             {
                 w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (static_cast<uint32_t>(w >> 32) != a.epoch)
@@ -1950,7 +1951,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
             if (static_cast<uint32_t>(w >> 32) == a.epoch)
                 tail = static_cast<uint32_t>(w);
             else if (a.err != nullptr)
-                atomicOr(&a.err[jobI], DCS_FRAME_FATAL);
+                atomicOr(&a.err[jobI], DCS_FRAME_FATAL | DCS_FRAME_TAIL_LOST);
             const uint32_t x0 = reinterpret_cast<const uint32_t *>(L.row(sI))[k];
             if (xf == DCS_XFORM_94)
                 reinterpret_cast<uint32_t *>(a.pcm)[static_cast<size_t>(jobI) * (DCS_FRAME_SAMPLES / 2) + k] =

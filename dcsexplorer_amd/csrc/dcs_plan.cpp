@@ -361,7 +361,7 @@ void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const Dcs
 {
     // (measured on the 2 x EPYC host of an MI355X box, 65 536 frames: 1 thread 2.5 ms, 4 threads 1.2 ms, 8 and 16
     // threads no faster -- the work is memory traffic -- and they slow the single-threaded planner of the next batch down)
-    unsigned nt = nChunks >= 2048 ? std::thread::hardware_concurrency() : 1;
+    unsigned nt = nChunks >= 2048 ? static_cast<unsigned>(dcs_host_threads()) : 1;
     if (nt > 4) nt = 4;
     if (nt <= 1)
     {

@@ -8,6 +8,10 @@
 #include <string>
 #include <vector>
 #include <new>
+#include <chrono>
+#include <algorithm>
+#include <mutex>
+#include <unordered_set>
 #include "dcs_common.h"
 #include "dcs_kernels.hip.h"
 #include "dcs_scan.h"
@@ -19,6 +23,9 @@ struct DcsCtx
     DcsDevTables *dTables = nullptr;
     int fpwOverride = 0;
     bool handoff = true;                // tails cross chunk boundaries through the hand-off buffer (else: halo re-decode)
+    uint32_t handoffTimeoutTicks = dcsk::kHandoffTimeoutTicks;     // 100 MHz ticks (dcs_ctx_set_test_hooks)
+    bool dropExports = false;           // test hook: no chunk publishes its tail (dcs_ctx_set_test_hooks)
+    std::mutex cacheMutex;              // the buffer cache is shared by the pipeline's worker threads
     int numCUs = 256;
     std::string lastError;
     // inputs of the last dcs_index_streams_gpu call, resident for dcs_index_streams_gpu_time
@@ -41,6 +48,7 @@ static const size_t kCacheLimit = size_t(4) << 30;     // bytes kept per context
 
 static hipError_t cacheAlloc(DcsCtx *ctx, bool pinned, void **out, size_t bytes)
 {
+    std::unique_lock<std::mutex> lock(ctx->cacheMutex);
     std::vector<DcsCtx::Cached> &c = pinned ? ctx->pinCache : ctx->devCache;
     size_t best = c.size();
     for (size_t i = 0 ; i < c.size() ; ++i)
@@ -53,6 +61,7 @@ static hipError_t cacheAlloc(DcsCtx *ctx, bool pinned, void **out, size_t bytes)
         c.erase(c.begin() + static_cast<long>(best));
         return hipSuccess;
     }
+    lock.unlock();
     return pinned ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
 }
 
@@ -60,6 +69,7 @@ static void cacheFree(DcsCtx *ctx, bool pinned, void *p, size_t cap)
 {
     if (p == nullptr)
         return;
+    std::lock_guard<std::mutex> lock(ctx->cacheMutex);
     if (ctx->cachedBytes + cap > kCacheLimit)
     {
         if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
@@ -77,7 +87,9 @@ struct DcsBatch
     size_t blobOnDevice = 0;                // bytes of the blob that were uploaded (0 when no frame has a second source)
     int fpw = 0;
     uint32_t nChunks = 0;
-    uint64_t algoBytes = 0;
+    uint64_t algoBytes = 0;                 // payload + stream headers + 56 B per source + 480 B per frame
+    uint64_t abiBytes = 0;                  // the same with the records as the ABI has them (160 B per source, 16 per job)
+    hipStream_t stream = nullptr;           // uploads, default launches and downloads (the context's, or the batch's own)
     // device buffers
     uint8_t *dBlob = nullptr;
     DcsSrcDesc *dSrcs = nullptr;
@@ -222,6 +234,16 @@ extern "C" DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable)
     return DCS_OK;
 }
 
+extern "C" DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t handoffTimeoutUs, int dropExports)
+{
+    if (ctx == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    ctx->handoffTimeoutTicks = handoffTimeoutUs == 0 ? dcsk::kHandoffTimeoutTicks
+                             : handoffTimeoutUs > 40000000u ? 4000000000u : handoffTimeoutUs * 100u;
+    ctx->dropExports = dropExports != 0;
+    return DCS_OK;
+}
+
 // Frames per wavefront, from measurement (tools/sweep_fpw.sh, tools/fpw_sweep.py): 4 (16 lanes unpack a frame: the
 // shortest serial path per wavefront) while the batch is small, 8 (four wavefronts per SIMD, full rounds) beyond.  The
 // crossover depends on what is decoded: a batch of 1994+ frames only -- the longer symbol loops -- gains from 8 lanes per
@@ -241,7 +263,7 @@ extern "C" void dcs_batch_destroy(DcsBatch *b)
         return;
     (void)hipSetDevice(b->ctx->device);
     if (b->evDone) (void)waitLaunched(b);               // nothing of this batch is in flight when its buffers are recycled,
-    (void)hipStreamSynchronize(b->ctx->stream);         // on the caller's launch stream or on the context's
+    (void)hipStreamSynchronize(b->stream);         // on the caller's launch stream or on the context's
     void *ptrs[] = { b->dBlob, b->dSrcs, nullptr, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug, b->dHandoff, b->dPackages };
     for (int i = 0 ; i < 10 ; ++i)
         cacheFree(b->ctx, false, ptrs[i], b->cap[i]);
@@ -271,15 +293,18 @@ static DcsKernelArgs kernelArgs(const DcsBatch *b)
     args.handoff = b->dHandoff;
     args.epoch = b->epoch;
     args.flags = b->flags;
+    args.timeoutTicks = b->ctx->handoffTimeoutTicks;
     return args;
 }
 
-extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
-                                      const uint8_t *blob, size_t blobLen,
-                                      const DcsSrcDesc *srcs, uint32_t nSrcs,
-                                      const DcsFrameJob *jobs, uint32_t nJobs,
-                                      const int16_t *tailsIn, uint32_t nTailsIn,
-                                      DcsBatch **out)
+// stream: where the batch's uploads, default launches and downloads run (nullptr: the context's); handoff: how tails
+// cross chunk boundaries (DcsCtx::handoff, or forced off for the second attempt after a lost tail)
+static DcsStatus createBatch(DcsCtx *ctx,
+                             const uint8_t *blob, size_t blobLen,
+                             const DcsSrcDesc *srcs, uint32_t nSrcs,
+                             const DcsFrameJob *jobs, uint32_t nJobs,
+                             const int16_t *tailsIn, uint32_t nTailsIn,
+                             hipStream_t stream, bool handoff, DcsBatch **out)
 {
     if (ctx == nullptr || out == nullptr || jobs == nullptr || nJobs == 0 || (nSrcs != 0 && (srcs == nullptr || blob == nullptr)))
         return DCS_ERR_INVALID_ARG;
@@ -341,6 +366,7 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
     if (b == nullptr)
         return DCS_ERR_NO_MEMORY;
     b->ctx = ctx;
+    b->stream = stream ? stream : ctx->stream;
     b->nJobs = nJobs; b->nSrcs = nSrcs; b->nTailsIn = nTailsIn; b->blobLen = blobLen;
     {
         bool all94 = nJobs != 0;
@@ -353,12 +379,29 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
     std::vector<DcsSlot> slots;
     uint8_t *hPackages = nullptr;           // pinned staging for the chunk packages
     size_t pkgBytes = 0;
-    b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, ctx->handoff);
+    b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff);
+    if (ctx->dropExports)
+        for (DcsSlot &sl : slots)
+            sl.flags &= static_cast<uint8_t>(~DCS_SLOT_EXPORT);      // test hook: imports without a producer
 
-    // algorithmic bytes: compressed payload + descriptors read (one DcsSrcDesc per source, one
-    // 16-byte job record per frame -- the device reads it in its DcsSlot form), PCM written
-    b->algoBytes = (payloadBits + 7) / 8 + static_cast<uint64_t>(nSrcs) * sizeof(DcsSrcDesc)
-                 + static_cast<uint64_t>(nJobs) * sizeof(DcsFrameJob) + static_cast<uint64_t>(nJobs) * DCS_FRAME_SAMPLES * 2;
+    // algorithmic bytes per launch: the exact compressed payload, the header (and U16 frame count) of every
+    // stream the batch draws on, a 56-byte frame descriptor per source, 480 bytes of PCM per output frame.  abiBytes
+    // counts the descriptors as this ABI has them instead: 160-byte DcsSrcDesc, 16-byte DcsFrameJob.
+    {
+        uint64_t hdrBytes = 0;
+        uint64_t lastOff = ~0ull;
+        std::unordered_set<uint64_t> seen;
+        for (uint32_t k = 0 ; k < nSrcs ; ++k)
+            if (srcs[k].streamOff != lastOff)               // (the frames of a stream are normally consecutive sources)
+            {
+                lastOff = srcs[k].streamOff;
+                if (seen.insert(lastOff).second)
+                    hdrBytes += 2u + srcs[k].hdrLen;
+            }
+        const uint64_t payload = (payloadBits + 7) / 8, pcm = static_cast<uint64_t>(nJobs) * DCS_FRAME_SAMPLES * 2;
+        b->algoBytes = payload + hdrBytes + static_cast<uint64_t>(nSrcs) * 56u + pcm;
+        b->abiBytes = payload + static_cast<uint64_t>(nSrcs) * sizeof(DcsSrcDesc) + static_cast<uint64_t>(nJobs) * sizeof(DcsFrameJob) + pcm;
+    }
 
     DcsStatus st = [&]() -> DcsStatus {
         HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -372,44 +415,44 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
         {
             const size_t blobAlloc = ((blobLen + 3) & ~size_t(3)) + 64;     // zero tail: the bit reader prefetches past the end
             b->cap[0] = blobAlloc; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dBlob), b->cap[0]));
-            HIPCHK(ctx, hipMemsetAsync(b->dBlob, 0, blobAlloc, ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(b->dBlob, 0, blobAlloc, b->stream));
             if (blobLen)
-                HIPCHK(ctx, hipMemcpyAsync(b->dBlob, blob, blobLen, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(b->dBlob, blob, blobLen, hipMemcpyHostToDevice, b->stream));
         }
         if (multi && nSrcs)
         {
             b->cap[1] = sizeof(DcsSrcDesc) * nSrcs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dSrcs), b->cap[1]));
-            HIPCHK(ctx, hipMemcpyAsync(b->dSrcs, srcs, sizeof(DcsSrcDesc) * nSrcs, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(b->dSrcs, srcs, sizeof(DcsSrcDesc) * nSrcs, hipMemcpyHostToDevice, b->stream));
         }
         // built in pinned host memory (recycled by the context like the device buffers): the upload runs at link speed
         pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw);
         HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&hPackages), pkgBytes));
         dcsBuildPackages(slots.data(), b->nChunks, b->fpw, srcs, blob, blobLen, hPackages);
         b->cap[9] = pkgBytes; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPackages), b->cap[9]));
-        HIPCHK(ctx, hipMemcpyAsync(b->dPackages, hPackages, pkgBytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(b->dPackages, hPackages, pkgBytes, hipMemcpyHostToDevice, b->stream));
         if (nTailsIn)
         {
             b->cap[3] = sizeof(int16_t) * 16 * nTailsIn; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsIn), b->cap[3]));
-            HIPCHK(ctx, hipMemcpyAsync(b->dTailsIn, tailsIn, sizeof(int16_t) * 16 * nTailsIn, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(b->dTailsIn, tailsIn, sizeof(int16_t) * 16 * nTailsIn, hipMemcpyHostToDevice, b->stream));
         }
         b->cap[4] = sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPcm), b->cap[4]));
         b->cap[5] = sizeof(uint32_t) * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dErr), b->cap[5]));
         b->cap[6] = sizeof(int16_t) * 16 * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsOut), b->cap[6]));
-        HIPCHK(ctx, hipMemsetAsync(b->dErr, 0, sizeof(uint32_t) * nJobs, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(b->dErr, 0, sizeof(uint32_t) * nJobs, b->stream));
         b->cap[8] = sizeof(unsigned long long) * 16 * (b->nChunks + 1); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dHandoff), b->cap[8]));
-        HIPCHK(ctx, hipMemsetAsync(b->dHandoff, 0, b->cap[8], ctx->stream));     // epoch 0 = never written
+        HIPCHK(ctx, hipMemsetAsync(b->dHandoff, 0, b->cap[8], b->stream));     // epoch 0 = never written
 #ifdef DCS_STAMPS
         b->cap[7] = sizeof(unsigned long long) * 16 * (b->nChunks + 4); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dDebug), b->cap[7]));
-        HIPCHK(ctx, hipMemsetAsync(b->dDebug, 0, sizeof(unsigned long long) * 16 * (b->nChunks + 4), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(b->dDebug, 0, sizeof(unsigned long long) * 16 * (b->nChunks + 4), b->stream));
 #endif
         HIPCHK(ctx, hipEventCreate(&b->ev0));
         HIPCHK(ctx, hipEventCreate(&b->ev1));
         HIPCHK(ctx, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(b->stream));
         return DCS_OK;
     }();
     if (st != DCS_OK)
-        (void)hipStreamSynchronize(ctx->stream);    // (on success the lambda has already waited for the uploads)
+        (void)hipStreamSynchronize(b->stream);    // (on success the lambda has already waited for the uploads)
     cacheFree(ctx, true, hPackages, pkgBytes);
     if (st != DCS_OK)
     {
@@ -420,13 +463,25 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
     return DCS_OK;
 }
 
+extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
+                                      const uint8_t *blob, size_t blobLen,
+                                      const DcsSrcDesc *srcs, uint32_t nSrcs,
+                                      const DcsFrameJob *jobs, uint32_t nJobs,
+                                      const int16_t *tailsIn, uint32_t nTailsIn,
+                                      DcsBatch **out)
+{
+    if (ctx == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    return createBatch(ctx, blob, blobLen, srcs, nSrcs, jobs, nJobs, tailsIn, nTailsIn, nullptr, ctx->handoff, out);
+}
+
 template <int FPW>
 static hipError_t launch(const DcsKernelArgs &args, hipStream_t stream)
 {
     const uint32_t blocks = (args.nChunks + dcsk::kWavesPerBlock - 1) / dcsk::kWavesPerBlock;
     dcsk::dcsDecodeKernel<FPW><<<dim3(blocks), dim3(64 * dcsk::kWavesPerBlock), dcsk::ldsBytes(FPW), stream>>>(
         args.packages, args.tables, args.nChunks, args.flags, args.epoch, args.nJobs, args.pcm, args.handoff, args.err, args.tailsOut,
-        args.blob, args.blobLen, args.srcs, args.tailsIn, args.debug);
+        args.blob, args.blobLen, args.srcs, args.tailsIn, args.debug, args.timeoutTicks);
     return hipGetLastError();
 }
 
@@ -460,7 +515,7 @@ extern "C" DcsStatus dcs_batch_run(DcsBatch *b, void *hipStream)
         return DCS_ERR_INVALID_ARG;
     DcsCtx *ctx = b->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t stream = hipStream ? static_cast<hipStream_t>(hipStream) : ctx->stream;
+    hipStream_t stream = hipStream ? static_cast<hipStream_t>(hipStream) : b->stream;
     const DcsStatus st = launchOnce(b, stream);
     return st != DCS_OK ? st : markLaunched(b, stream);
 }
@@ -473,7 +528,7 @@ extern "C" DcsStatus dcs_batch_run_many(DcsBatch *b, void *hipStream, int count)
         return DCS_ERR_INVALID_ARG;
     DcsCtx *ctx = b->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t stream = hipStream ? static_cast<hipStream_t>(hipStream) : ctx->stream;
+    hipStream_t stream = hipStream ? static_cast<hipStream_t>(hipStream) : b->stream;
     for (int i = 0 ; i < count ; ++i)
     {
         const DcsStatus st = launchOnce(b, stream);
@@ -489,7 +544,7 @@ extern "C" DcsStatus dcs_batch_time(DcsBatch *b, void *hipStream, int iters, flo
         return DCS_ERR_INVALID_ARG;
     DcsCtx *ctx = b->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t stream = hipStream ? static_cast<hipStream_t>(hipStream) : ctx->stream;
+    hipStream_t stream = hipStream ? static_cast<hipStream_t>(hipStream) : b->stream;
     HIPCHK(ctx, hipEventRecord(b->ev0, stream));
     for (int i = 0 ; i < iters ; ++i)
     {
@@ -516,7 +571,7 @@ extern "C" DcsStatus dcs_batch_sync(DcsBatch *b)
         return DCS_ERR_INVALID_ARG;
     HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
     HIPCHK(b->ctx, waitLaunched(b));
-    HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    HIPCHK(b->ctx, hipStreamSynchronize(b->stream));
     return DCS_OK;
 }
 
@@ -527,7 +582,7 @@ extern "C" DcsStatus dcs_batch_download(DcsBatch *b, int16_t *pcmOut, uint32_t *
     DcsCtx *ctx = b->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, waitLaunched(b));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(b->stream));
     if (pcmOut)
         HIPCHK(ctx, hipMemcpy(pcmOut, b->dPcm, sizeof(int16_t) * DCS_FRAME_SAMPLES * b->nJobs, hipMemcpyDeviceToHost));
     if (errOut)
@@ -557,11 +612,11 @@ extern "C" DcsStatus dcs_batch_download_view(DcsBatch *b, const int16_t **pcmOut
         HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&b->hErr), errBytes));
     }
     if (b->launched)
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b->evDone, 0));      // the copies follow the last launch, whatever stream it ran on
-    HIPCHK(ctx, hipMemcpyAsync(b->hPcm, b->dPcm, pcmBytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(b->stream, b->evDone, 0));      // the copies follow the last launch, whatever stream it ran on
+    HIPCHK(ctx, hipMemcpyAsync(b->hPcm, b->dPcm, pcmBytes, hipMemcpyDeviceToHost, b->stream));
     if (errOut != nullptr)
-        HIPCHK(ctx, hipMemcpyAsync(b->hErr, b->dErr, errBytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(b->hErr, b->dErr, errBytes, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(ctx, hipStreamSynchronize(b->stream));
     *pcmOut = b->hPcm;
     if (errOut != nullptr)
         *errOut = b->hErr;
@@ -575,13 +630,16 @@ extern "C" void *dcs_batch_device_pcm(DcsBatch *b) { return b ? b->dPcm : nullpt
 extern "C" int dcs_debug_stamps(DcsBatch *b, unsigned long long *out, uint32_t capChunks)
 {
     if (b == nullptr || b->dDebug == nullptr) return -1;
-    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipStreamSynchronize(b->stream);
     const uint32_t n = b->nChunks < capChunks ? b->nChunks : capChunks;
     (void)hipMemcpy(out, b->dDebug, sizeof(unsigned long long) * 16 * n, hipMemcpyDeviceToHost);
     return static_cast<int>(n);
 }
 #endif
 extern "C" uint64_t dcs_batch_algorithmic_bytes(const DcsBatch *b) { return b ? b->algoBytes : 0; }
+extern "C" uint64_t dcs_batch_abi_bytes(const DcsBatch *b) { return b ? b->abiBytes : 0; }
+extern "C" uint32_t dcs_batch_num_chunks(const DcsBatch *b) { return b ? b->nChunks : 0; }
+extern "C" int dcs_batch_frames_per_wave(const DcsBatch *b) { return b ? b->fpw : 0; }
 extern "C" uint32_t dcs_batch_num_jobs(const DcsBatch *b) { return b ? b->nJobs : 0; }
 
 extern "C" DcsStatus dcs_decode_batch(DcsCtx *ctx,
@@ -591,15 +649,39 @@ extern "C" DcsStatus dcs_decode_batch(DcsCtx *ctx,
                                       const int16_t *tailsIn, uint32_t nTailsIn,
                                       int16_t *pcmOut, uint32_t *errOut, int16_t *tailsOut)
 {
-    DcsBatch *b = nullptr;
-    DcsStatus st = dcs_batch_create(ctx, blob, blobLen, srcs, nSrcs, jobs, nJobs, tailsIn, nTailsIn, &b);
-    if (st != DCS_OK)
-        return st;
-    st = dcs_batch_run(b, nullptr);
-    if (st == DCS_OK)
-        st = dcs_batch_download(b, pcmOut, errOut, tailsOut);
-    dcs_batch_destroy(b);
-    return st;
+    if (ctx == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    // Tails cross chunk boundaries through the hand-off buffer, which rests on the producing wavefront having been
+    // dispatched when its consumer waits for it: chunks are dispatched in index order on this hardware, but nothing
+    // promises it.  A consumer that waited in vain flags its frame DCS_FRAME_TAIL_LOST; the batch is then decoded again
+    // with every such predecessor re-decoded next to its successor (no dependence between wavefronts at all).
+    for (int attempt = 0 ; attempt < 2 ; ++attempt)
+    {
+        const bool handoff = ctx->handoff && attempt == 0;
+        DcsBatch *b = nullptr;
+        DcsStatus st = createBatch(ctx, blob, blobLen, srcs, nSrcs, jobs, nJobs, tailsIn, nTailsIn, nullptr, handoff, &b);
+        if (st != DCS_OK)
+            return st;
+        st = dcs_batch_run(b, nullptr);
+        bool lost = false;
+        if (st == DCS_OK && handoff)
+        {
+            // the error words first (4 bytes per frame): they say whether the PCM is worth fetching
+            std::vector<uint32_t> errTmp(errOut ? 0 : nJobs);
+            uint32_t *errWords = errOut ? errOut : errTmp.data();
+            st = dcs_batch_download(b, nullptr, errWords, nullptr);
+            for (uint32_t j = 0 ; st == DCS_OK && j < nJobs && !lost ; ++j)
+                lost = (errWords[j] & DCS_FRAME_TAIL_LOST) != 0;
+            if (st == DCS_OK && !lost)
+                st = dcs_batch_download(b, pcmOut, nullptr, tailsOut);
+        }
+        else if (st == DCS_OK)
+            st = dcs_batch_download(b, pcmOut, errOut, tailsOut);
+        dcs_batch_destroy(b);
+        if (st != DCS_OK || !lost)
+            return st;
+    }
+    return DCS_OK;
 }
 
 
@@ -821,3 +903,66 @@ extern "C" DcsStatus dcs_index_streams_gpu_time(DcsCtx *ctx, int iters, float *a
     *avgMs = ms / static_cast<float>(iters);
     return DCS_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Shader clock under load, for pricing a kernel in cycles (bench.py's VALU-issue figure): every SIMD of the chip runs
+// a dependent integer chain for a few hundred microseconds, each workgroup stamps s_memtime (shader cycles) and
+// s_memrealtime (100 MHz) around it, and the median ratio is the clock the chip held.  Not part of the decode path.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void dcsClockKernel(unsigned long long *out, int iters, uint32_t seed)
+{
+    uint32_t x = seed + threadIdx.x, y = blockIdx.x;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0 ; i < iters ; ++i)
+    {
+        x = x * 0x9E3779B1u + y;
+        y = (y ^ (x >> 7)) + 0x7F4A7C15u;
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0)
+    {
+        out[2 * blockIdx.x] = c1 - c0;
+        out[2 * blockIdx.x + 1] = (r1 - r0) + ((x ^ y) == 0x12345u ? 1u : 0u);     // (keeps the chain alive)
+    }
+}
+}   // namespace
+
+extern "C" DcsStatus dcs_ctx_clock_mhz(DcsCtx *ctx, float *mhzOut)
+{
+    if (ctx == nullptr || mhzOut == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint32_t blocks = static_cast<uint32_t>(ctx->numCUs) * 4;
+    unsigned long long *d = nullptr;
+    HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&d), sizeof(unsigned long long) * 2 * blocks));
+    std::vector<unsigned long long> h(2 * static_cast<size_t>(blocks));
+    hipError_t e = hipSuccess;
+    for (int rep = 0 ; rep < 2 && e == hipSuccess ; ++rep)      // (the first launch only warms the chip up)
+    {
+        hipLaunchKernelGGL(dcsClockKernel, dim3(blocks), dim3(256), 0, ctx->stream, d, 60000, 12345u + rep);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess)
+    {
+        ctx->lastError = std::string("clock probe failed: ") + hipGetErrorString(e);
+        return DCS_ERR_HIP;
+    }
+    std::vector<double> ratio;
+    for (uint32_t k = 0 ; k < blocks ; ++k)
+        if (h[2 * k + 1] != 0)
+            ratio.push_back(static_cast<double>(h[2 * k]) / static_cast<double>(h[2 * k + 1]));
+    if (ratio.empty())
+        return DCS_ERR_HIP;
+    std::nth_element(ratio.begin(), ratio.begin() + static_cast<long>(ratio.size() / 2), ratio.end());
+    *mhzOut = static_cast<float>(ratio[ratio.size() / 2] * 100.0);
+    return DCS_OK;
+}
+
+#include "dcs_pipeline.hip.h"

@@ -5,21 +5,15 @@
 // stream starts from a freshly constructed decoder (zero overlap tail, first-frame multiplier 0x7FFF).
 #include "dcs_common.h"
 #include <string.h>
+#include <algorithm>
+#include <thread>
 #include <vector>
 
-namespace {
-
-struct Built
-{
-    std::vector<uint8_t> blob;
-    std::vector<DcsSrcDesc> srcs;
-    std::vector<DcsFrameJob> jobs;
-    std::vector<uint32_t> firstJob;     // per stream, plus a final total
-};
+typedef DcsBuiltStreams Built;
 
 // sequence: the streams are played one after the other by ONE decoder (dcs_decode_stream_sequence)
-DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, Built &B, bool countOnly,
-                       bool sequence = false)
+DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, DcsBuiltStreams &B,
+                          bool countOnly, bool sequence)
 {
     std::vector<uint16_t> mm;
     std::vector<uint8_t> vs;
@@ -121,7 +115,11 @@ DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t 
     return DCS_OK;
 }
 
-}   // namespace
+static DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, Built &B, bool countOnly,
+                              bool sequence = false)
+{
+    return dcsBuildStreams(streams, nStreams, extraFrames, B, countOnly, sequence);
+}
 
 extern "C" DcsStatus dcs_count_stream_frames(const DcsStreamRef *streams, uint32_t nStreams,
                                              uint32_t extraFrames, uint64_t *nFramesOut)
@@ -173,4 +171,90 @@ extern "C" DcsStatus dcs_decode_stream_sequence(DcsCtx *ctx, const DcsStreamRef 
         memcpy(frameOffsets, B.firstJob.data(), sizeof(uint32_t) * B.firstJob.size());
     return dcs_decode_batch(ctx, B.blob.data(), B.blob.size(), B.srcs.data(), static_cast<uint32_t>(B.srcs.size()),
                             B.jobs.data(), static_cast<uint32_t>(B.jobs.size()), nullptr, 0, pcmOut, errOut, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Several GPUs: streams are the independent units of the path (a frame needs its stream's earlier frames for
+// its bit position and band types, DCSDecoderNative.cpp:1715, :1833), so a list of streams is cut into contiguous
+// ranges, one per device, balanced by total frame count; no device needs anything from another.
+// ---------------------------------------------------------------------------------------------------------
+extern "C" DcsStatus dcs_partition_streams(const uint32_t *frameCounts, uint32_t nStreams, uint32_t nParts,
+                                           uint32_t *firstStreamOut)
+{
+    if (nParts == 0 || firstStreamOut == nullptr || (nStreams != 0 && frameCounts == nullptr))
+        return DCS_ERR_INVALID_ARG;
+    std::vector<uint64_t> prefix(static_cast<size_t>(nStreams) + 1, 0);
+    for (uint32_t k = 0 ; k < nStreams ; ++k)
+        prefix[k + 1] = prefix[k] + frameCounts[k];
+    const uint64_t total = prefix[nStreams];
+    firstStreamOut[0] = 0;
+    firstStreamOut[nParts] = nStreams;
+    for (uint32_t r = 1 ; r < nParts ; ++r)
+    {
+        // the cut whose prefix sum lies nearest to r/nParts of the frames, never left of the previous cut
+        const uint64_t target = static_cast<uint64_t>((static_cast<unsigned __int128>(total) * r) / nParts);
+        size_t i = static_cast<size_t>(std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin());
+        if (i > 0 && target - prefix[i - 1] <= prefix[i] - target)
+            --i;
+        firstStreamOut[r] = std::max(static_cast<uint32_t>(i), firstStreamOut[r - 1]);
+    }
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_decode_streams_sharded(const int *deviceIds, uint32_t nDevices,
+                                                const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames,
+                                                int16_t *pcmOut, size_t pcmCapFrames, uint32_t *frameOffsets,
+                                                uint32_t *errOut, uint32_t *firstStreamOfDevice)
+{
+    if (deviceIds == nullptr || nDevices == 0 || streams == nullptr || nStreams == 0 || pcmOut == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    // output frames per stream, from the U16 prefix (what dcs_decode_streams will produce)
+    std::vector<uint32_t> frames(nStreams);
+    std::vector<uint64_t> firstFrame(static_cast<size_t>(nStreams) + 1, 0);
+    for (uint32_t k = 0 ; k < nStreams ; ++k)
+    {
+        if (streams[k].data == nullptr || streams[k].len < 3)
+            return DCS_ERR_INVALID_ARG;
+        frames[k] = ((static_cast<uint32_t>(streams[k].data[0]) << 8) | streams[k].data[1]) + extraFrames;
+        firstFrame[k + 1] = firstFrame[k] + frames[k];
+    }
+    if (firstFrame[nStreams] > pcmCapFrames || firstFrame[nStreams] > 0xFFFFFFFFull)
+        return DCS_ERR_CAPACITY;
+    std::vector<uint32_t> cut(static_cast<size_t>(nDevices) + 1);
+    DcsStatus st = dcs_partition_streams(frames.data(), nStreams, nDevices, cut.data());
+    if (st != DCS_OK)
+        return st;
+    if (firstStreamOfDevice != nullptr)
+        memcpy(firstStreamOfDevice, cut.data(), sizeof(uint32_t) * cut.size());
+
+    // one host thread and one context per device; every range writes its own part of the outputs
+    std::vector<DcsStatus> status(nDevices, DCS_OK);
+    std::vector<std::thread> workers;
+    for (uint32_t d = 0 ; d < nDevices ; ++d)
+    {
+        const uint32_t lo = cut[d], hi = cut[d + 1];
+        if (lo == hi)
+            continue;
+        workers.emplace_back([&, d, lo, hi]() {
+            DcsCtx *ctx = nullptr;
+            DcsStatus s = dcs_ctx_create(deviceIds[d], &ctx);
+            if (s == DCS_OK)
+            {
+                const uint64_t f0 = firstFrame[lo];
+                s = dcs_decode_streams(ctx, streams + lo, hi - lo, extraFrames, pcmOut + f0 * DCS_FRAME_SAMPLES,
+                                       static_cast<size_t>(firstFrame[hi] - f0), nullptr, errOut ? errOut + f0 : nullptr);
+                dcs_ctx_destroy(ctx);
+            }
+            status[d] = s;
+        });
+    }
+    for (std::thread &w : workers)
+        w.join();
+    if (frameOffsets != nullptr)
+        for (uint32_t k = 0 ; k <= nStreams ; ++k)
+            frameOffsets[k] = static_cast<uint32_t>(firstFrame[k]);
+    for (uint32_t d = 0 ; d < nDevices ; ++d)
+        if (status[d] != DCS_OK)
+            return status[d];
+    return DCS_OK;
 }

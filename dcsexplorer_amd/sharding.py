@@ -22,6 +22,21 @@ def rank_streams(workload, rank):
     return workloads.shifted(fn, rank * n)
 
 
+def partition_by_frames(frame_counts, world):
+    """cut points (world + 1) of contiguous stream ranges balanced by total FRAME count (the C ABI's
+    dcs_partition_streams): rank r owns streams [cut[r], cut[r+1])"""
+    from . import api
+    return [int(c) for c in api.partition_streams(frame_counts, world)]
+
+
+def rank_corpus(manifest, world, rank):
+    """(lo, hi): the range of a corpus manifest rank `rank` decodes -- the same corpus cut `world` ways
+    (strong scaling), ragged streams balanced by frames, no data-path collective"""
+    from . import workloads
+    cut = partition_by_frames(workloads.corpus_frames(manifest), world)
+    return cut[rank], cut[rank + 1]
+
+
 def partition_range(n_items, world, rank):
     """contiguous range [lo, hi) of n_items owned by `rank` (sizes differ by at most one)"""
     base, rem = divmod(n_items, world)

@@ -57,7 +57,11 @@ def streams_mixed_16384(n_streams=128, n_frames=128):
     return out
 
 
-def streams_corpus(titles=29, streams_per_title=600, max_frames=2000, seed=0x0005):
+def corpus_manifest(titles=29, streams_per_title=600, max_frames=2000, seed=0x0005):
+    """BASELINE config 5 stand-in: `titles` synthetic titles x `streams_per_title` streams of
+    U[20, max_frames] frames, the era of a title fixing its OS version and the mix of unpack layouts.  Returns the
+    list of stream recipes (os, format, frames, level, synth seed, nbands) WITHOUT writing any stream: the frame
+    counts are all a partition needs, so every rank derives the same manifest and writes only its own range."""
     out = []
     for t in range(titles):
         g = _splitmix(seed * 1000003 + t)
@@ -72,10 +76,33 @@ def streams_corpus(titles=29, streams_per_title=600, max_frames=2000, seed=0x000
             else:
                 m = (r >> 20) % 10
                 fmt = D.FMT_94_T0 if m == 0 else D.FMT_94_T1_S0 if m == 1 else D.FMT_94_T1_S3
-            s = D.synth_stream(fmt, int(nf), seed=(seed << 32) + t * 100000 + k,
-                               nbands=18 if fmt == D.FMT_93A_T1 else 16, stride_from=16, profile=0)
-            out.append((era, s, 255, 0x60 + (r >> 40) % 16))
+            out.append(dict(os=era, format=fmt, frames=int(nf), level=0x60 + (r >> 40) % 16,
+                            seed=(seed << 32) + t * 100000 + k, nbands=18 if fmt == D.FMT_93A_T1 else 16,
+                            title=t, stream=k))
     return out
+
+
+def corpus_frames(manifest):
+    return np.array([m["frames"] for m in manifest], dtype=np.uint32)
+
+
+def corpus_streams(manifest, lo=0, hi=None, threads=0):
+    """write streams [lo, hi) of a manifest: -> [(os, bytes, volume, level)].  The writer is the library's C
+    function (ctypes releases the GIL), so a thread pool scales it over the host cores."""
+    part = manifest[lo:hi]
+    def one(m):
+        return (m["os"], D.synth_stream(m["format"], m["frames"], seed=m["seed"], nbands=m["nbands"], stride_from=16,
+                                        profile=0), 255, m["level"])
+    threads = threads or min(32, D.host_threads())
+    if threads <= 1 or len(part) < 4:
+        return [one(m) for m in part]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(one, part, chunksize=max(1, len(part) // (threads * 8))))
+
+
+def streams_corpus(titles=29, streams_per_title=600, max_frames=2000, seed=0x0005):
+    return corpus_streams(corpus_manifest(titles, streams_per_title, max_frames, seed))
 
 
 def interleave(batch):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DCS_ABI_VERSION 5
+#define DCS_ABI_VERSION 6
 #define DCS_FRAME_SAMPLES 240          /* PCM samples per frame (DCSDecoder.h:123: 7.68 ms at 31250 Hz) */
 #define DCS_MAX_CHANNELS 8             /* DCSDecoderNative.h:305 */
 
@@ -67,6 +67,12 @@ typedef enum DcsFormat
 #define DCS_FRAME_STOP   1u            /* the reference's channel.stop: corrupt band, zeroed (:1989, :2216) */
 #define DCS_FRAME_FATAL  2u            /* malformed beyond what the reference defines (it has UB there):
                                           decode of the frame stops at that point; STOP is raised too    */
+#define DCS_FRAME_TAIL_LOST 4u         /* (with FATAL) not a property of the stream: the overlap tail of the frame's
+                                          predecessor, decoded by another wavefront of the same launch, did not arrive
+                                          within the wait bound, so the frame's first 16 samples lack the overlap.
+                                          dcs_decode_batch and everything built on it decode such a batch again with
+                                          the predecessor re-decoded next to its successor and never return this bit;
+                                          a caller of dcs_batch_run sees it in the error words */
 
 /* ------------------------------------------------------------------------------------------------
  * Index pass: the carried state that makes a frame independently decodable.
@@ -240,9 +246,21 @@ DcsStatus dcs_batch_download(DcsBatch *batch, int16_t *pcmOut, uint32_t *errOut,
 DcsStatus dcs_batch_download_view(DcsBatch *b, const int16_t **pcmOut, const uint32_t **errOut);
 /* device pointers, for callers that keep the PCM on the GPU (int16 [nJobs][240]) */
 void     *dcs_batch_device_pcm(DcsBatch *batch);
-/* bytes the kernel reads + writes for this batch, by the definition of SURVEY section 8(d) */
+/* bytes the kernel reads + writes per launch of this batch, by the definition of SURVEY section 8(d): exact compressed
+ * payload + the header (and U16 count) of every stream it draws on + a 56-byte frame descriptor per source + 480 bytes
+ * of PCM per output frame.  dcs_batch_abi_bytes counts the descriptors as this ABI has them (160-byte DcsSrcDesc,
+ * 16-byte DcsFrameJob) instead of 56 bytes. */
 uint64_t  dcs_batch_algorithmic_bytes(const DcsBatch *batch);
+uint64_t  dcs_batch_abi_bytes(const DcsBatch *batch);
 uint32_t  dcs_batch_num_jobs(const DcsBatch *batch);
+uint32_t  dcs_batch_num_chunks(const DcsBatch *batch);          /* wavefronts of one launch */
+int       dcs_batch_frames_per_wave(const DcsBatch *batch);     /* the kernel variant chosen for it */
+/* shader clock (MHz) the chip holds under an integer VALU load on every SIMD (a probe kernel of a few hundred
+ * microseconds; not part of the decode path): turns a kernel duration into cycles */
+DcsStatus dcs_ctx_clock_mhz(DcsCtx *ctx, float *mhzOut);
+/* test hooks: bound of a consumer's wait for a tail from another chunk in microseconds (0 = the default, 4 s), and
+ * dropExports != 0: no chunk publishes its tail, so every such wait runs into the bound (DCS_FRAME_TAIL_LOST) */
+DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t handoffTimeoutUs, int dropExports);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole-stream convenience (the reference's --extract-streams shape, DCSExplorer.cpp:1628-1907):
@@ -268,6 +286,46 @@ DcsStatus dcs_decode_streams(DcsCtx *ctx, const DcsStreamRef *streams, uint32_t 
 DcsStatus dcs_count_stream_frames(const DcsStreamRef *streams, uint32_t nStreams,
                                   uint32_t extraFrames, uint64_t *nFramesOut);
 
+/* Several GPUs of one node (the reference decodes on one thread, DCSExplorer.cpp:1742-1907).
+ * Streams are the independent units of the path, so the work is cut by plain range partition and no device needs
+ * anything from another (no collective).
+ * dcs_partition_streams: cut a list of nStreams streams with the given frame counts into nParts contiguous ranges
+ * balanced by total frame count; range r is [firstStreamOut[r], firstStreamOut[r+1]) (nParts + 1 entries; a range
+ * may be empty).  Every range's frame total lies within one (longest) stream of total / nParts.
+ * dcs_decode_streams_sharded: dcs_decode_streams over the devices `deviceIds` -- one host thread and one context
+ * per device, range d decoded on device d into its own part of pcmOut / errOut.  Same output layout and the same
+ * PCM as dcs_decode_streams on one device.  firstStreamOfDevice (optional, nDevices + 1) receives the cut. */
+DcsStatus dcs_partition_streams(const uint32_t *frameCounts, uint32_t nStreams, uint32_t nParts,
+                                uint32_t *firstStreamOut);
+DcsStatus dcs_decode_streams_sharded(const int *deviceIds, uint32_t nDevices,
+                                     const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames,
+                                     int16_t *pcmOut, size_t pcmCapFrames, uint32_t *frameOffsets,
+                                     uint32_t *errOut, uint32_t *firstStreamOfDevice);
+
+/* Batches in flight.  A caller with many lists of streams to decode (an archive, a ROM corpus) submits them and
+ * collects their PCM in submission order; `depth` host worker threads each take a list through index pass, mixing
+ * parameters, chunk plan, packing, upload, kernel and download on a HIP stream of their own, so the host preparation
+ * of one list runs while the GPU decodes another and a third comes back over PCIe into pinned memory.  Same PCM as
+ * dcs_decode_streams list by list.  The streams (and the bytes they point at) must stay valid until their list has
+ * been collected.  submit blocks while `depth` lists are between submit and collect; collect blocks until the OLDEST
+ * submitted list is finished.  The result's pointers are pinned memory of the pipeline, valid until the next
+ * collect / destroy.  The pipeline owns the context's decode work while it exists (do not decode on the same context
+ * from another thread meanwhile), and must be destroyed before the context. */
+typedef struct DcsPipeline DcsPipeline;
+typedef struct DcsPipelineResult
+{
+    const int16_t  *pcm;               /* nFrames x 240                                                    */
+    const uint32_t *err;               /* nFrames x DCS_FRAME_*                                            */
+    const uint32_t *frameOffsets;      /* nStreams + 1: first output frame of each stream                  */
+    uint32_t        nFrames, nStreams;
+    DcsStatus       status;
+    float           hostMs, deviceMs;  /* the worker's wall time in host preparation / upload + kernel + download */
+} DcsPipelineResult;
+DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, DcsPipeline **out);
+void      dcs_pipeline_destroy(DcsPipeline *p);
+DcsStatus dcs_pipeline_submit(DcsPipeline *p, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames);
+DcsStatus dcs_pipeline_collect(DcsPipeline *p, DcsPipelineResult *out);
+
 /* The stream loop of `DCSExplorer --extract-streams` exactly (DCSExplorer.cpp:1628-1907): ONE decoder
  * object plays the streams one after the other -- LoadAudioStream(0, ptr, level), nFrames + extraFrames
  * frames, ClearTracks() during the last two (ExtractToWAV :1670-1721) -- so frame 0 of every stream but the
@@ -288,6 +346,9 @@ DcsStatus dcs_decode_stream_sequence(DcsCtx *ctx, const DcsStreamRef *streams, u
  * its summary.  Both run the same walker (csrc/dcs_scan.h) and return identical records; they replace
  * the serial GetStreamInfo walk (DCSDecoderNative.cpp:1486-1537) in front of the decode kernel.
  */
+/* host threads this process can run at once: CPUs of its affinity mask, limited by a cgroup CPU quota if any
+ * (what "0 = all" means for nThreads below and for the packer's worker count) */
+int       dcs_host_threads(void);
 DcsStatus dcs_index_streams(const DcsStreamRef *streams, uint32_t nStreams, int nThreads,
                             DcsFrameIndex *out, const uint64_t *firstRecord, DcsStreamInfo *infos);
 

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(dcs):
 
 
 def test_abi_version_and_struct_sizes(dcs):
-    assert dcs.load_library().dcs_abi_version() == 5
+    assert dcs.load_library().dcs_abi_version() == 6
     assert dcs.SRC_DTYPE.itemsize == 160
     assert dcs.JOB_DTYPE.itemsize == 16
     assert dcs.INDEX_DTYPE.itemsize == 148

@@ -1,0 +1,141 @@
+"""BASELINE configs[4] on one MI355X: the reduced ragged corpus against the reference's committed per-stream hashes,
+the several-GPU entry (two contexts on the one device of the test box), batches in flight, and lost tails."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import dcsexplorer_amd as D
+from dcsexplorer_amd import workloads
+from util import ALL_FORMATS, make_stream, os_for
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def corpus():
+    g = json.load(open(os.path.join(GOLD, "corpus_golden.json")))
+    manifest = workloads.corpus_manifest(**g["corpus"])
+    return g, manifest, workloads.corpus_streams(manifest)
+
+
+def stream_hashes(oracle, pcm, first):
+    return ["%016x" % oracle.fnv1a64(pcm[first[k]:first[k + 1]]) for k in range(len(first) - 1)]
+
+
+def test_corpus_on_one_gpu_matches_reference_hashes(gpu_ctx, oracle, corpus):
+    """29 titles x 20 streams, U[20, 2000] frames, all six layouts, one launch: every stream's PCM hash equals the
+    hash of the unmodified reference's PCM (tests/golden/make_corpus_golden.py)"""
+    g, manifest, streams = corpus
+    assert g["streams"] == len(streams) == 580 and g["formats"] == [0, 1, 2, 3, 4, 5]
+    b = D.build_stream_batch(streams, indexer=D.index_streams)
+    assert int(b["jobs"].size) == g["frames"]
+    batch = gpu_ctx.batch(b["blob"], b["srcs"], b["jobs"])
+    batch.run()
+    pcm, err = batch.download_view()
+    assert not err.any()
+    got = stream_hashes(oracle, pcm, b["first_job"])
+    bad = [k for k in range(len(got)) if got[k] != g["stream_hashes"][k]]
+    assert not bad, "streams %s differ from the reference" % bad[:8]
+    assert "%016x" % oracle.fnv1a64(np.array([int(h, 16) for h in got], dtype=np.uint64)) == g["fnv1a64_of_stream_hashes"]
+    batch.close()
+
+
+def test_corpus_cut_for_several_ranks_decodes_to_the_same_pcm(gpu_ctx, oracle, corpus):
+    """what rank r of N decodes (its frame-balanced range) is exactly its part of the one-GPU result"""
+    g, manifest, streams = corpus
+    counts = workloads.corpus_frames(manifest)
+    for world in (2, 8):
+        cut = D.partition_streams(counts, world)
+        for r in (0, world - 1):
+            part = streams[cut[r]:cut[r + 1]]
+            pcm, err, first = gpu_ctx.decode_streams(part)
+            assert not err.any()
+            assert stream_hashes(oracle, pcm, first) == g["stream_hashes"][cut[r]:cut[r + 1]]
+
+
+def test_sharded_entry_two_contexts_one_device(oracle, corpus):
+    """dcs_decode_streams_sharded with the device list [0, 0]: two host threads, two contexts, the range partition and
+    the disjoint output ranges of the several-GPU path, on the one GPU a test box has"""
+    g, manifest, streams = corpus
+    sub = streams[:120]
+    pcm, err, first, cut = D.decode_streams_sharded([0, 0], sub, extra_frames=1)
+    assert list(cut) == list(D.partition_streams([((s[1][0] << 8) | s[1][1]) + 1 for s in sub], 2))
+    assert 0 < cut[1] < len(sub) and not err.any()
+    ctx = D.Context(0)
+    want, _, wfirst = ctx.decode_streams(sub, extra_frames=1)
+    ctx.close()
+    assert np.array_equal(first, wfirst) and np.array_equal(pcm, want)
+    # a frame of every stream without its taper frame hashes like the reference's
+    k = 5
+    nf = (sub[k][1][0] << 8) | sub[k][1][1]
+    assert "%016x" % oracle.fnv1a64(pcm[first[k]:first[k] + nf]) == g["stream_hashes"][k]
+
+
+def test_pipeline_returns_lists_in_order(gpu_ctx, corpus):
+    """dcs_pipeline: several lists in flight come back in submission order with the PCM of dcs_decode_streams"""
+    g, manifest, streams = corpus
+    lists = [streams[0:40], streams[40:45], streams[45:140], streams[140:141], streams[141:200]]
+    want = [gpu_ctx.decode_streams(l, extra_frames=2) for l in lists]
+    pipe = gpu_ctx.pipeline(3)
+    got = []
+    for k, l in enumerate(lists):
+        pipe.submit(l, extra_frames=2)              # (blocks while 3 lists are in flight)
+        if k >= 2:
+            pcm, err, first, _, _ = pipe.collect()
+            got.append((pcm.copy(), err.copy(), first.copy()))
+    while len(got) < len(lists):
+        pcm, err, first, _, _ = pipe.collect()
+        got.append((pcm.copy(), err.copy(), first.copy()))
+    pipe.close()
+    for (p, e, f), (wp, we, wf) in zip(got, want):
+        assert np.array_equal(f, wf) and np.array_equal(e, we) and np.array_equal(p, wp)
+
+
+def test_lost_tail_is_flagged_on_that_frame_only_and_retried(gpu_ctx, oracle):
+    """A consumer whose producer never publishes (test hook: no chunk exports its tail) waits for the bound, here
+    2 ms, and flags ITS frame DCS_FRAME_FATAL | DCS_FRAME_TAIL_LOST; the launch returns, every other frame is exact.
+    The one-shot entry points notice the flag and decode the batch again without hand-off: exact PCM, no flag."""
+    streams = [(os_for(f, f), make_stream(f, 40 + 7 * f, seed=41000 + f, profile=f % 3), 240, 0x64) for f in ALL_FORMATS]
+    want = np.concatenate([oracle.decode(os_, vol, [s], [lvl], (s[0] << 8) | s[1]) for os_, s, vol, lvl in streams])
+    b = D.build_stream_batch(streams)
+    gpu_ctx.set_frames_per_wave(4)
+    gpu_ctx.set_test_hooks(handoff_timeout_us=2000, drop_exports=True)
+    try:
+        plan = D.plan_chunks(b["jobs"], 4, b["srcs"])
+        importers = sorted(int(s["job"]) for s in plan.reshape(-1) if (s["flags"] & 0x08) and not (s["flags"] & 0x80))
+        assert importers, "the plan has no frame that takes its tail from another chunk"
+        batch = gpu_ctx.batch(b["blob"], b["srcs"], b["jobs"])
+        batch.run()
+        pcm, err = batch.download()
+        batch.close()
+        lost = sorted(int(j) for j in np.nonzero(err & D.FRAME_TAIL_LOST)[0])
+        assert lost == importers
+        assert all(err[j] & D.FRAME_FATAL for j in lost)
+        ok = np.ones(len(want), dtype=bool); ok[lost] = False
+        assert np.array_equal(pcm[ok], want[ok])                                # every other frame is exact
+        assert np.array_equal(pcm[lost][:, 16:], want[lost][:, 16:])            # and so are samples 16..239 of the flagged ones
+        # the one-shot path retries without hand-off
+        pcm2, err2 = gpu_ctx.decode_batch(b["blob"], b["srcs"], b["jobs"])
+        assert not err2.any() and np.array_equal(pcm2, want)
+    finally:
+        gpu_ctx.set_test_hooks(0, False)
+        gpu_ctx.set_frames_per_wave(0)
+
+
+def test_batch_outlives_caller_stream_ordering(gpu_ctx, oracle):
+    """a run on a caller's own non-blocking stream, then download without any synchronisation by the caller: the batch
+    waits for its own last launch"""
+    import torch
+    streams = [(D.OS95, make_stream(D.FMT_94_T1_S3, 400, seed=777, profile=0), 255, 0x64)]
+    want = oracle.decode(D.OS95, 255, [streams[0][1]], [0x64], 400)
+    b = D.build_stream_batch(streams)
+    st = torch.cuda.Stream()
+    for _ in range(5):
+        batch = gpu_ctx.batch(b["blob"], b["srcs"], b["jobs"])
+        batch.run_many(3, st.cuda_stream)
+        pcm, err = batch.download()
+        assert np.array_equal(pcm, want) and not err.any()
+        batch.close()                               # destroy right away: buffers are recycled only once the launch is done

@@ -62,3 +62,86 @@ def test_partition_range_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+CORPUS_WORKER = r'''
+import hashlib, json, os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from dcsexplorer_amd import sharding, workloads
+dist.init_process_group(backend="gloo")
+rank, local_rank, world = sharding.rank_info()
+manifest = workloads.corpus_manifest(titles=8, streams_per_title=6, max_frames=300)
+lo, hi = sharding.rank_corpus(manifest, world, rank)
+streams = workloads.corpus_streams(manifest, lo, hi)
+mine = [hashlib.sha1(s[1]).hexdigest() for s in streams]
+frames = sum((s[1][0] << 8) | s[1][1] for s in streams)
+gathered = [None] * world
+dist.all_gather_object(gathered, (rank, lo, hi, mine, frames))
+if rank == 0:
+    print(json.dumps(dict(world=world, ranks=gathered)))
+dist.destroy_process_group()
+''' % ROOT
+
+
+def test_two_ranks_cut_the_ragged_corpus_by_frames(tmp_path):
+    """BASELINE configs[4] shape: ONE ragged corpus, contiguous stream ranges balanced by total frame count
+    (SURVEY 8e); the ranges are disjoint, their union is the corpus, no rank is more than one stream off"""
+    script = tmp_path / "corpus_worker.py"
+    script.write_text(CORPUS_WORKER)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ))
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    (r0, lo0, hi0, s0, f0), (r1, lo1, hi1, s1, f1) = sorted(d["ranks"])
+    sys.path.insert(0, ROOT)
+    from dcsexplorer_amd import workloads
+    manifest = workloads.corpus_manifest(titles=8, streams_per_title=6, max_frames=300)
+    whole = workloads.corpus_streams(manifest)
+    assert lo0 == 0 and hi0 == lo1 and hi1 == len(manifest)           # disjoint, contiguous, complete
+    assert s0 + s1 == [hashlib.sha1(s[1]).hexdigest() for s in whole]
+    counts = workloads.corpus_frames(manifest)
+    assert f0 == int(counts[lo0:hi0].sum()) and f1 == int(counts[lo1:hi1].sum())
+    assert f0 + f1 == int(counts.sum())
+    assert abs(f0 - f1) <= int(counts.max())                         # at most one stream's length apart
+    assert len(set(m["os"] for m in manifest)) == 4                   # titles of all four OS generations
+
+
+def test_frame_balanced_partition_properties():
+    """dcs_partition_streams: contiguous, complete, every range within one (longest) stream of the ideal share"""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import dcsexplorer_amd as D
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 3, 17, 580, 5000):
+        counts = rng.integers(20, 2001, size=n).astype(np.uint32)
+        for world in (1, 2, 3, 4, 8):
+            cut = D.partition_streams(counts, world)
+            assert cut[0] == 0 and cut[-1] == n and all(cut[i] <= cut[i + 1] for i in range(world))
+            if n == 0:
+                continue
+            loads = [int(counts[cut[r]:cut[r + 1]].sum()) for r in range(world)]
+            assert sum(loads) == int(counts.sum())
+            ideal = counts.sum() / world
+            assert max(abs(l - ideal) for l in loads) <= counts.max()
+    # skewed: one huge stream among small ones still gives contiguous, complete ranges
+    counts = np.array([10] * 50 + [60000] + [10] * 50, dtype=np.uint32)
+    cut = D.partition_streams(counts, 4)
+    assert cut[0] == 0 and cut[-1] == 101 and sum(int(counts[cut[r]:cut[r + 1]].sum()) for r in range(4)) == counts.sum()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without RANK in the environment starts 2 ranks itself; on a box without GPUs the
+    --rehearse path (gloo) runs launcher, partition, host planning, barrier and max-over-ranks and reports n_gpus 2"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for wl, scaling in (("corpus", "strong"), ("dcs93_4096", "weak")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "1",
+                              "--workload", wl, "--corpus-titles", "8", "--corpus-streams", "4"],
+                             capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] is None and "rehearsal" in d
+        assert len(d["config"]["frames_per_rank"]) == 2 and all(f > 0 for f in d["config"]["frames_per_rank"])
