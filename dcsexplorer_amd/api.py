@@ -275,7 +275,7 @@ def load_library():
     L.dcs_ctx_set_test_hooks.restype = i32
     L.dcs_ctx_set_test_hooks.argtypes = [vp, u32, ctypes.c_int]
     L.dcs_pipeline_create.restype = i32
-    L.dcs_pipeline_create.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
+    L.dcs_pipeline_create.argtypes = [vp, ctypes.c_int, u32, ctypes.POINTER(vp)]
     L.dcs_pipeline_destroy.restype = None
     L.dcs_pipeline_destroy.argtypes = [vp]
     L.dcs_pipeline_submit.restype = i32
@@ -680,8 +680,8 @@ class Context:
     def set_test_hooks(self, handoff_timeout_us=0, drop_exports=False):
         _check(self.L.dcs_ctx_set_test_hooks(self.h, int(handoff_timeout_us), int(bool(drop_exports))), self.h)
 
-    def pipeline(self, depth=3):
-        return Pipeline(self, depth)
+    def pipeline(self, depth=3, index_on_device=False):
+        return Pipeline(self, depth, index_on_device)
 
     def index_streams_gpu(self, streams):
         """dcs_index_streams_gpu: the index pass on the GPU, one lane per stream.  Same result as
@@ -785,11 +785,11 @@ class Batch:
 class Pipeline:
     """DcsPipeline: lists of whole streams in, PCM out in submission order, `depth` lists in flight"""
 
-    def __init__(self, ctx, depth=3):
+    def __init__(self, ctx, depth=3, index_on_device=False):
         self.ctx = ctx
         self.L = ctx.L
         h = ctypes.c_void_p()
-        _check(self.L.dcs_pipeline_create(ctx.h, depth, ctypes.byref(h)), ctx.h)
+        _check(self.L.dcs_pipeline_create(ctx.h, depth, 1 if index_on_device else 0, ctypes.byref(h)), ctx.h)
         self.h = h
         self._keep = []                         # (refs, byte buffers) of submitted lists, oldest first
         ctx._batches.add(self)                  # closed before the context, like a batch

@@ -210,8 +210,17 @@ struct DcsBuiltStreams
     std::vector<DcsFrameJob> jobs;
     std::vector<uint32_t> firstJob;     // per stream, plus a final total
 };
+// index records made elsewhere (the device index pass) for streams already laid out in a blob of the caller's: the build
+// then neither walks the streams nor copies them (B.blob stays empty; sources point into the caller's blob)
+struct DcsPreIndexed
+{
+    const DcsFrameIndex *records;       // stream k's records at records + firstRecord[k]
+    const uint64_t *firstRecord;
+    const DcsStreamInfo *infos;
+    const uint64_t *streamOff;          // stream k's offset in the caller's blob
+};
 DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, DcsBuiltStreams &B,
-                          bool countOnly, bool sequence);
+                          bool countOnly, bool sequence, const DcsPreIndexed *pre = nullptr);
 uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true);
 // packer: out = nChunks x dcsPkgBytes(fpw) bytes (the chunk packages described above)
 void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const DcsSrcDesc *srcs,

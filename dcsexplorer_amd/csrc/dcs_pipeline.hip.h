@@ -25,9 +25,13 @@ struct DcsPipeline
         DcsStatus status = DCS_OK;
         bool done = false;
         double hostMs = 0, deviceMs = 0;        // preparation / upload + kernel + download, as the worker saw them
+        // index pass on the device: the streams as uploaded for it (pinned), kept for the packer
+        uint8_t *hBlob = nullptr;
+        size_t hBlobCap = 0, hBlobLen = 0;
     };
     DcsCtx *ctx = nullptr;
     int depth = 0;
+    uint32_t flags = 0;                             // DCS_PIPE_*
     std::mutex m;
     std::condition_variable work, finished, room;
     std::deque<std::shared_ptr<Job>> queue;         // submitted, not yet taken by a worker
@@ -38,6 +42,11 @@ struct DcsPipeline
     bool quit = false;
 };
 
+static double nowMs()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 static void pipelineRelease(DcsPipeline *p, std::shared_ptr<DcsPipeline::Job> &job)
 {
     if (job && job->batch)
@@ -45,12 +54,89 @@ static void pipelineRelease(DcsPipeline *p, std::shared_ptr<DcsPipeline::Job> &j
         dcs_batch_destroy(job->batch);
         job->batch = nullptr;
     }
+    if (job && job->hBlob)
+    {
+        cacheFree(p->ctx, true, job->hBlob, job->hBlobCap);
+        job->hBlob = nullptr;
+    }
     job.reset();
 }
 
-static double nowMs()
+// The index pass of one list on the device (dcsIndexKernel, one lane per stream) instead of the host pool: the streams
+// go up as they are, the records come back, and the host is left with parameters, planner and packer.  A lane walks a
+// frame some 50 times slower than a host core does, so one list takes longer this way -- but the GPU has lanes to spare
+// and the host has not: with enough lists in flight the walks of different lists overlap each other and the decode
+// kernels, and the host cores, which the index pass otherwise keeps busy nine tenths of the time, prepare other lists
+// meanwhile.  Returns DCS_OK with *usable = false when the list has to take the host path (a stream that runs past
+// its buffer: its missing bytes read as zero, which the streams laid end to end cannot express).
+static DcsStatus pipelineIndexOnDevice(DcsPipeline *p, DcsPipeline::Job *job, hipStream_t stream, bool *usable,
+                                       double *deviceMs)
 {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    *usable = false;
+    DcsCtx *ctx = p->ctx;
+    const uint32_t n = job->nStreams;
+    std::vector<DcsStreamLoc> locs(n);
+    std::vector<uint64_t> firstRecord(n), streamOff(n);
+    uint64_t totalRec = 0;
+    size_t blobLen = 0;
+    for (uint32_t k = 0 ; k < n ; ++k)
+    {
+        const DcsStreamRef &sr = job->streams[k];
+        if (sr.data == nullptr || sr.len < 3 || sr.os < DCS_OS93A || sr.os > DCS_OS95)
+            return DCS_ERR_INVALID_ARG;
+        const uint32_t nFrames = (static_cast<uint32_t>(sr.data[0]) << 8) | sr.data[1];
+        if (nFrames == 0)
+            return DCS_ERR_BAD_STREAM;
+        // no stream is longer than its header plus nFrames maximal frames (the caller's buffer may be the rest of a ROM)
+        const size_t most = 2 + 16 + (static_cast<size_t>(nFrames) * DCS_MAX_FRAME_BITS + 7) / 8 + 8;
+        const size_t len = sr.len < most ? sr.len : most;
+        blobLen = (blobLen + 3) & ~size_t(3);
+        locs[k].off = blobLen; locs[k].len = static_cast<uint32_t>(len); locs[k].os = sr.os; locs[k].firstRecord = totalRec;
+        streamOff[k] = blobLen;
+        firstRecord[k] = totalRec;
+        blobLen += len;
+        totalRec += nFrames;
+    }
+    const size_t blobCap = ((blobLen + 3 + 4) & ~size_t(3)) + 64;       // (zero tail: the packer copies whole dwords)
+    const size_t recBytes = sizeof(DcsFrameIndex) * totalRec, infoBytes = sizeof(DcsStreamInfo) * n;
+    void *hRec = nullptr, *hInfo = nullptr;
+    DcsStatus st = [&]() -> DcsStatus {
+        HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&job->hBlob), blobCap));
+        job->hBlobCap = blobCap; job->hBlobLen = blobLen;
+        HIPCHK(ctx, cacheAlloc(ctx, true, &hRec, recBytes));
+        HIPCHK(ctx, cacheAlloc(ctx, true, &hInfo, infoBytes));
+        return DCS_OK;
+    }();
+    if (st == DCS_OK)
+    {
+        memset(job->hBlob + blobLen, 0, blobCap - blobLen);
+        for (uint32_t k = 0 ; k < n ; ++k)
+        {
+            if (k + 1 < n)      // (the alignment gap in front of the next stream)
+                memset(job->hBlob + locs[k].off + locs[k].len, 0, static_cast<size_t>(locs[k + 1].off - locs[k].off) - locs[k].len);
+            memcpy(job->hBlob + locs[k].off, job->streams[k].data, locs[k].len);
+        }
+        const double t0 = nowMs();
+        st = gpuIndexOnStream(ctx, stream, job->hBlob, blobLen, locs.data(), n, static_cast<DcsFrameIndex *>(hRec), totalRec,
+                              static_cast<DcsStreamInfo *>(hInfo));
+        *deviceMs += nowMs() - t0;
+    }
+    if (st == DCS_OK)
+    {
+        const DcsStreamInfo *infos = static_cast<const DcsStreamInfo *>(hInfo);
+        bool ok = true;
+        for (uint32_t k = 0 ; k < n && ok ; ++k)
+            ok = infos[k].nFrames != 0 && static_cast<size_t>(infos[k].nBytes) <= locs[k].len;
+        if (ok)
+        {
+            const DcsPreIndexed pre{ static_cast<const DcsFrameIndex *>(hRec), firstRecord.data(), infos, streamOff.data() };
+            st = dcsBuildStreams(job->streams, n, job->extraFrames, job->built, false, false, &pre);
+            *usable = st == DCS_OK;
+        }
+    }
+    cacheFree(ctx, true, hRec, recBytes);
+    cacheFree(ctx, true, hInfo, infoBytes);
+    return st;
 }
 
 static void pipelineWorker(DcsPipeline *p, int id)
@@ -68,14 +154,25 @@ static void pipelineWorker(DcsPipeline *p, int id)
             p->queue.pop_front();
         }
         const double t0 = nowMs();
-        DcsStatus st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, job->built, false, false);
+        double indexDeviceMs = 0;
+        bool onDevice = false;
+        DcsStatus st = DCS_OK;
+        if (p->flags & DCS_PIPE_INDEX_ON_DEVICE)
+            st = pipelineIndexOnDevice(p, job.get(), p->streams[id], &onDevice, &indexDeviceMs);
+        if (st == DCS_OK && !onDevice)
+        {
+            job->built = DcsBuiltStreams();
+            st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, job->built, false, false);
+        }
+        const uint8_t *blob = onDevice ? job->hBlob : job->built.blob.data();
+        const size_t blobLen = onDevice ? job->hBlobLen : job->built.blob.size();
         double t1 = nowMs(), t2 = t1;
         // (second attempt, tails by re-decoding the predecessor, only after a lost tail: see dcs_decode_batch)
         for (int attempt = 0 ; st == DCS_OK && attempt < 2 ; ++attempt)
         {
             const bool handoff = p->ctx->handoff && attempt == 0;
             const DcsBuiltStreams &B = job->built;
-            st = createBatch(p->ctx, B.blob.data(), B.blob.size(), B.srcs.data(), static_cast<uint32_t>(B.srcs.size()),
+            st = createBatch(p->ctx, blob, blobLen, B.srcs.data(), static_cast<uint32_t>(B.srcs.size()),
                              B.jobs.data(), static_cast<uint32_t>(B.jobs.size()), nullptr, 0, p->streams[id], handoff, &job->batch);
             t2 = nowMs();
             if (st == DCS_OK) st = dcs_batch_run(job->batch, nullptr);
@@ -90,8 +187,8 @@ static void pipelineWorker(DcsPipeline *p, int id)
             job->batch = nullptr;
         }
         const double t3 = nowMs();
-        job->hostMs = (t1 - t0) + (t2 - t1);
-        job->deviceMs = t3 - t2;
+        job->hostMs = (t2 - t0) - indexDeviceMs;
+        job->deviceMs = (t3 - t2) + indexDeviceMs;
         {
             std::lock_guard<std::mutex> lk(p->m);
             job->status = st;
@@ -101,9 +198,9 @@ static void pipelineWorker(DcsPipeline *p, int id)
     }
 }
 
-extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, DcsPipeline **out)
+extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags, DcsPipeline **out)
 {
-    if (ctx == nullptr || out == nullptr || depth < 1 || depth > 16)
+    if (ctx == nullptr || out == nullptr || depth < 1 || depth > 64 || (flags & ~DCS_PIPE_INDEX_ON_DEVICE) != 0)
         return DCS_ERR_INVALID_ARG;
     *out = nullptr;
     DcsPipeline *p = new (std::nothrow) DcsPipeline;
@@ -111,6 +208,7 @@ extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, DcsPipeline **o
         return DCS_ERR_NO_MEMORY;
     p->ctx = ctx;
     p->depth = depth;
+    p->flags = flags;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     for (int i = 0 ; i < depth ; ++i)
     {

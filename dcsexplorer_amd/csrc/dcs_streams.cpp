@@ -13,7 +13,7 @@ typedef DcsBuiltStreams Built;
 
 // sequence: the streams are played one after the other by ONE decoder (dcs_decode_stream_sequence)
 DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, DcsBuiltStreams &B,
-                          bool countOnly, bool sequence)
+                          bool countOnly, bool sequence, const DcsPreIndexed *pre)
 {
     std::vector<uint16_t> mm;
     std::vector<uint8_t> vs;
@@ -36,12 +36,23 @@ DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32
     if (countOnly)
         return DCS_OK;
 
-    // the index pass over all streams, on the host worker pool (dcs_index.cpp)
-    std::vector<DcsFrameIndex> allIdx(totalSrc);
-    std::vector<DcsStreamInfo> infos(nStreams);
-    DcsStatus st = dcs_index_streams(streams, nStreams, 0, allIdx.data(), firstRecord.data(), infos.data());
-    if (st != DCS_OK)
-        return st;
+    // the index pass over all streams, on the host worker pool (dcs_index.cpp) -- unless the caller brings the records
+    std::vector<DcsFrameIndex> ownIdx;
+    std::vector<DcsStreamInfo> ownInfos;
+    DcsStatus st = DCS_OK;
+    if (pre == nullptr)
+    {
+        ownIdx.resize(totalSrc);
+        ownInfos.resize(nStreams);
+        st = dcs_index_streams(streams, nStreams, 0, ownIdx.data(), firstRecord.data(), ownInfos.data());
+        if (st != DCS_OK)
+            return st;
+    }
+    const DcsFrameIndex *allIdx = pre ? pre->records : ownIdx.data();
+    const DcsStreamInfo *infos = pre ? pre->infos : ownInfos.data();
+    if (pre != nullptr)
+        for (uint32_t k = 0 ; k < nStreams ; ++k)
+            firstRecord[k] = pre->firstRecord[k];
     B.jobs.reserve(total);
     B.srcs.reserve(totalSrc);
 
@@ -50,7 +61,7 @@ DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32
         const DcsStreamRef &sr = streams[k];
         const DcsOsVersion os = static_cast<DcsOsVersion>(sr.os);
         const uint32_t nFrames = (static_cast<uint32_t>(sr.data[0]) << 8) | sr.data[1];
-        const DcsFrameIndex *idx = allIdx.data() + firstRecord[k];
+        const DcsFrameIndex *idx = allIdx + firstRecord[k];
         const DcsStreamInfo &info = infos[k];
         mm.resize(nFrames); vs.resize(nFrames);
         uint16_t firstMul = 0x7FFF;
@@ -68,17 +79,23 @@ DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32
         if (st != DCS_OK)
             return st;
 
-        // streams are laid out back to back, each starting on a 4-byte boundary
-        while (B.blob.size() & 3)
-            B.blob.push_back(0);
-        const uint64_t streamOff = B.blob.size();
-        // only the bytes the stream uses (the caller's buffer may be the whole rest of a ROM image) ...
-        const size_t used = static_cast<size_t>(info.nBytes) < sr.len ? static_cast<size_t>(info.nBytes) : sr.len;
-        B.blob.insert(B.blob.end(), sr.data, sr.data + used);
-        // ... and a damaged or truncated stream may run past its buffer: bytes past the end read as zero (that
-        // is what the index pass assumed), not as the start of the next stream
-        if (static_cast<size_t>(info.nBytes) > sr.len)
-            B.blob.insert(B.blob.end(), static_cast<size_t>(info.nBytes) - sr.len, 0);
+        uint64_t streamOff;
+        if (pre != nullptr)
+            streamOff = pre->streamOff[k];
+        else
+        {
+            // streams are laid out back to back, each starting on a 4-byte boundary
+            while (B.blob.size() & 3)
+                B.blob.push_back(0);
+            streamOff = B.blob.size();
+            // only the bytes the stream uses (the caller's buffer may be the whole rest of a ROM image) ...
+            const size_t used = static_cast<size_t>(info.nBytes) < sr.len ? static_cast<size_t>(info.nBytes) : sr.len;
+            B.blob.insert(B.blob.end(), sr.data, sr.data + used);
+            // ... and a damaged or truncated stream may run past its buffer: bytes past the end read as zero (that
+            // is what the index pass assumed), not as the start of the next stream
+            if (static_cast<size_t>(info.nBytes) > sr.len)
+                B.blob.insert(B.blob.end(), static_cast<size_t>(info.nBytes) - sr.len, 0);
+        }
 
         const uint8_t xform = (os == DCS_OS93A || os == DCS_OS93B) ? DCS_XFORM_93 : DCS_XFORM_94;
         const uint32_t nValid = static_cast<uint32_t>(info.nValidFrames);

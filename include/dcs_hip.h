@@ -321,7 +321,12 @@ typedef struct DcsPipelineResult
     DcsStatus       status;
     float           hostMs, deviceMs;  /* the worker's wall time in host preparation / upload + kernel + download */
 } DcsPipelineResult;
-DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, DcsPipeline **out);
+/* flags: DCS_PIPE_INDEX_ON_DEVICE -- the index pass of every list runs on the GPU (one lane per stream, the walker of
+ * dcs_index_streams_gpu) instead of on the host pool.  One list takes longer that way, many lists in flight much less:
+ * the walks of different lists overlap on the GPU, and the host cores, which the index pass otherwise keeps busy most of
+ * the time, are left with parameters, planner and packer.  Worth it from about 8 lists in flight.  Same PCM either way. */
+#define DCS_PIPE_INDEX_ON_DEVICE 1u
+DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth /* 1..64 lists in flight */, uint32_t flags, DcsPipeline **out);
 void      dcs_pipeline_destroy(DcsPipeline *p);
 DcsStatus dcs_pipeline_submit(DcsPipeline *p, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames);
 DcsStatus dcs_pipeline_collect(DcsPipeline *p, DcsPipelineResult *out);

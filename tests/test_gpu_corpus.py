@@ -74,12 +74,14 @@ def test_sharded_entry_two_contexts_one_device(oracle, corpus):
     assert "%016x" % oracle.fnv1a64(pcm[first[k]:first[k] + nf]) == g["stream_hashes"][k]
 
 
-def test_pipeline_returns_lists_in_order(gpu_ctx, corpus):
-    """dcs_pipeline: several lists in flight come back in submission order with the PCM of dcs_decode_streams"""
+@pytest.mark.parametrize("on_device", [False, True], ids=["host-index", "device-index"])
+def test_pipeline_returns_lists_in_order(gpu_ctx, corpus, on_device):
+    """dcs_pipeline: several lists in flight come back in submission order with the PCM of dcs_decode_streams, whether
+    the index pass runs on the host pool or on the device"""
     g, manifest, streams = corpus
     lists = [streams[0:40], streams[40:45], streams[45:140], streams[140:141], streams[141:200]]
     want = [gpu_ctx.decode_streams(l, extra_frames=2) for l in lists]
-    pipe = gpu_ctx.pipeline(3)
+    pipe = gpu_ctx.pipeline(3, index_on_device=on_device)
     got = []
     for k, l in enumerate(lists):
         pipe.submit(l, extra_frames=2)              # (blocks while 3 lists are in flight)
@@ -139,3 +141,21 @@ def test_batch_outlives_caller_stream_ordering(gpu_ctx, oracle):
         pcm, err = batch.download()
         assert np.array_equal(pcm, want) and not err.any()
         batch.close()                               # destroy right away: buffers are recycled only once the launch is done
+
+
+def test_pipeline_device_index_with_damaged_and_rom_sized_buffers(gpu_ctx, oracle):
+    """device index pass: a stream handed over with a buffer far longer than the stream (the rest of a ROM image) is cut
+    to what it can use; a truncated stream (runs past its buffer, the missing bytes read as zero) sends its list down
+    the host path; corrupted streams keep the reference's error semantics.  PCM equals dcs_decode_streams'."""
+    from util import corrupt
+    base = [(os_for(f, 1), make_stream(f, 60 + 5 * f, seed=52000 + f, profile=f % 3), 230, 0x66) for f in ALL_FORMATS]
+    rom_sized = [(o, s + bytes(200000), v, l) for o, s, v, l in base[:3]] + base[3:]
+    truncated = base[:5] + [(base[5][0], base[5][1][:len(base[5][1]) // 2], base[5][2], base[5][3])]
+    damaged = [(o, corrupt(s, 77 + k, nflips=4), v, l) for k, (o, s, v, l) in enumerate(base)]
+    pipe = gpu_ctx.pipeline(3, index_on_device=True)
+    for lst in (rom_sized, truncated, damaged):
+        want = gpu_ctx.decode_streams(lst, extra_frames=2)
+        pipe.submit(lst, extra_frames=2)
+        pcm, err, first, _, _ = pipe.collect()
+        assert np.array_equal(first, want[2]) and np.array_equal(err, want[1]) and np.array_equal(pcm, want[0])
+    pipe.close()
