@@ -1,11 +1,20 @@
-// dcs_pipeline.hip.h -- batches in flight: the host preparation of batch k+1 (index pass, mixing parameters, chunk
-// planner, packer) runs while the GPU decodes batch k and batch k-1 comes back into pinned memory.  Included at the end
-// of dcs_runtime.hip (it uses the runtime's batch internals).
+// dcs_pipeline.hip.h -- lists of streams in flight: the host preparation of one list (index pass, mixing parameters,
+// chunk planner, packer) runs while the GPU decodes another and a third comes back into pinned memory.  Included at
+// the end of dcs_runtime.hip (it uses the runtime's batch internals).
 //
 // The reference decodes its batch job (`--extract-streams`, DCSExplorer.cpp:1742-1907) one stream after the other on
-// one thread; here a caller submits lists of whole streams and collects their PCM in submission order.  `depth` worker
-// threads each take a submitted job through all its stages on a HIP stream of their own, so the stages of different
-// jobs overlap by themselves: a worker that waits for its kernel or its copy leaves the host cores to the others.
+// one thread; here a caller submits lists of whole streams and collects their PCM in submission order.
+//
+// Two shapes, chosen at creation:
+//   index pass on the host pool (default): `depth` worker threads each take a submitted list through all its stages on
+//     a HIP stream of their own, so the stages of different lists overlap by themselves.
+//   index pass on the device (DCS_PIPE_INDEX_ON_DEVICE): the index pass is nine tenths of a list's host work (measured,
+//     tools/hostbench.cpp: 60 of 68 CPU-milliseconds for 65 536 frames), and on the device a lane walks a frame some 50
+//     times slower than a host core does -- but the GPU has lanes to spare and the host has no cores to spare.  A worker
+//     uploads its list's streams (stage A) and hands the list to the INDEXER thread, which walks the streams of ALL lists
+//     that are waiting in ONE launch (one lane per stream; the walks are latency, so a launch takes as long for eight
+//     lists as for one), copies the records back and passes the lists on; a worker then builds, plans, packs, decodes
+//     and downloads (stage B).  The host is left with about 8 CPU-milliseconds per 65 536 frames.
 #pragma once
 #include <condition_variable>
 #include <deque>
@@ -24,21 +33,37 @@ struct DcsPipeline
         const uint32_t *err = nullptr;
         DcsStatus status = DCS_OK;
         bool done = false;
-        double hostMs = 0, deviceMs = 0;        // preparation / upload + kernel + download, as the worker saw them
-        // index pass on the device: the streams as uploaded for it (pinned), kept for the packer
-        uint8_t *hBlob = nullptr;
+        double hostMs = 0, deviceMs = 0;        // wall time of the threads that worked on the list: host preparation /
+                                                // uploads + kernels + downloads (the device index pass counts here)
+        // ---- index pass on the device
+        bool onDevice = false;                  // records came from the device; the streams lie in hBlob
+        uint8_t *hBlob = nullptr;               // the streams as uploaded, end to end (pinned); the packer reads them
         size_t hBlobCap = 0, hBlobLen = 0;
+        void *dBlob = nullptr;                  // the same on the device, for the walk only
+        size_t dBlobCap = 0;
+        std::vector<DcsStreamLoc> locs;         // offsets relative to the list's blob
+        std::vector<uint64_t> firstRecord, streamOff;
+        uint64_t totalRec = 0;
+        void *hRec = nullptr, *hInfo = nullptr; // records and stream summaries as they come back (pinned)
+        size_t recBytes = 0, infoBytes = 0;
+        hipEvent_t uploaded = nullptr;
     };
+    typedef std::shared_ptr<Job> JobPtr;
+
     DcsCtx *ctx = nullptr;
     int depth = 0;
     uint32_t flags = 0;                             // DCS_PIPE_*
+    bool hadBlockingWaits = false;
     std::mutex m;
-    std::condition_variable work, finished, room;
-    std::deque<std::shared_ptr<Job>> queue;         // submitted, not yet taken by a worker
-    std::deque<std::shared_ptr<Job>> order;         // submitted, not yet collected (submission order)
-    std::shared_ptr<Job> held;                      // the job whose result the caller is reading
+    std::condition_variable work, indexWork, finished, room;
+    std::deque<JobPtr> fresh;                       // submitted, not yet taken by a worker
+    std::deque<JobPtr> toIndex;                     // uploaded, waiting for the indexer
+    std::deque<JobPtr> indexed;                     // records are back: ready for stage B
+    std::deque<JobPtr> order;                       // submitted, not yet collected (submission order)
+    JobPtr held;                                    // the list whose result the caller is reading
     std::vector<std::thread> workers;
-    std::vector<hipStream_t> streams;
+    std::thread indexer;
+    std::vector<hipStream_t> streams;               // one per worker, and one more for the indexer
     bool quit = false;
 };
 
@@ -47,38 +72,48 @@ static double nowMs()
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static void pipelineRelease(DcsPipeline *p, std::shared_ptr<DcsPipeline::Job> &job)
+static void pipelineFreeIndexBuffers(DcsPipeline *p, DcsPipeline::Job *job, bool keepHostBlob)
 {
-    if (job && job->batch)
+    DcsCtx *ctx = p->ctx;
+    if (job->dBlob) { cacheFree(ctx, false, job->dBlob, job->dBlobCap); job->dBlob = nullptr; }
+    if (job->hRec) { cacheFree(ctx, true, job->hRec, job->recBytes); job->hRec = nullptr; }
+    if (job->hInfo) { cacheFree(ctx, true, job->hInfo, job->infoBytes); job->hInfo = nullptr; }
+    if (job->hBlob && !keepHostBlob) { cacheFree(ctx, true, job->hBlob, job->hBlobCap); job->hBlob = nullptr; }
+    if (job->uploaded) { (void)hipEventDestroy(job->uploaded); job->uploaded = nullptr; }
+}
+
+static void pipelineRelease(DcsPipeline *p, DcsPipeline::JobPtr &job)
+{
+    if (job)
     {
-        dcs_batch_destroy(job->batch);
-        job->batch = nullptr;
-    }
-    if (job && job->hBlob)
-    {
-        cacheFree(p->ctx, true, job->hBlob, job->hBlobCap);
-        job->hBlob = nullptr;
+        if (job->batch)
+        {
+            dcs_batch_destroy(job->batch);
+            job->batch = nullptr;
+        }
+        pipelineFreeIndexBuffers(p, job.get(), false);
     }
     job.reset();
 }
 
-// The index pass of one list on the device (dcsIndexKernel, one lane per stream) instead of the host pool: the streams
-// go up as they are, the records come back, and the host is left with parameters, planner and packer.  A lane walks a
-// frame some 50 times slower than a host core does, so one list takes longer this way -- but the GPU has lanes to spare
-// and the host has not: with enough lists in flight the walks of different lists overlap each other and the decode
-// kernels, and the host cores, which the index pass otherwise keeps busy nine tenths of the time, prepare other lists
-// meanwhile.  Returns DCS_OK with *usable = false when the list has to take the host path (a stream that runs past
-// its buffer: its missing bytes read as zero, which the streams laid end to end cannot express).
-static DcsStatus pipelineIndexOnDevice(DcsPipeline *p, DcsPipeline::Job *job, hipStream_t stream, bool *usable,
-                                       double *deviceMs)
+static void pipelineFinish(DcsPipeline *p, const DcsPipeline::JobPtr &job, DcsStatus st)
 {
-    *usable = false;
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        job->status = st;
+        job->done = true;
+    }
+    p->finished.notify_all();
+}
+
+// stage A (device index pass): lay the list's streams end to end in pinned memory and send them up
+static DcsStatus pipelineUpload(DcsPipeline *p, DcsPipeline::Job *job, hipStream_t stream)
+{
     DcsCtx *ctx = p->ctx;
     const uint32_t n = job->nStreams;
-    std::vector<DcsStreamLoc> locs(n);
-    std::vector<uint64_t> firstRecord(n), streamOff(n);
-    uint64_t totalRec = 0;
+    job->locs.resize(n); job->firstRecord.resize(n); job->streamOff.resize(n);
     size_t blobLen = 0;
+    uint64_t totalRec = 0;
     for (uint32_t k = 0 ; k < n ; ++k)
     {
         const DcsStreamRef &sr = job->streams[k];
@@ -91,110 +126,228 @@ static DcsStatus pipelineIndexOnDevice(DcsPipeline *p, DcsPipeline::Job *job, hi
         const size_t most = 2 + 16 + (static_cast<size_t>(nFrames) * DCS_MAX_FRAME_BITS + 7) / 8 + 8;
         const size_t len = sr.len < most ? sr.len : most;
         blobLen = (blobLen + 3) & ~size_t(3);
-        locs[k].off = blobLen; locs[k].len = static_cast<uint32_t>(len); locs[k].os = sr.os; locs[k].firstRecord = totalRec;
-        streamOff[k] = blobLen;
-        firstRecord[k] = totalRec;
+        job->locs[k].off = blobLen; job->locs[k].len = static_cast<uint32_t>(len); job->locs[k].os = sr.os;
+        job->locs[k].firstRecord = totalRec;
+        job->streamOff[k] = blobLen;
+        job->firstRecord[k] = totalRec;
         blobLen += len;
         totalRec += nFrames;
     }
-    const size_t blobCap = ((blobLen + 3 + 4) & ~size_t(3)) + 64;       // (zero tail: the packer copies whole dwords)
-    const size_t recBytes = sizeof(DcsFrameIndex) * totalRec, infoBytes = sizeof(DcsStreamInfo) * n;
-    void *hRec = nullptr, *hInfo = nullptr;
-    DcsStatus st = [&]() -> DcsStatus {
-        HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&job->hBlob), blobCap));
-        job->hBlobCap = blobCap; job->hBlobLen = blobLen;
-        HIPCHK(ctx, cacheAlloc(ctx, true, &hRec, recBytes));
-        HIPCHK(ctx, cacheAlloc(ctx, true, &hInfo, infoBytes));
-        return DCS_OK;
-    }();
-    if (st == DCS_OK)
+    job->totalRec = totalRec;
+    job->hBlobLen = blobLen;
+    job->hBlobCap = ((blobLen + 3) & ~size_t(3)) + 64;          // zero tail: the walk prefetches, the packer copies whole dwords
+    job->dBlobCap = job->hBlobCap;
+    job->recBytes = sizeof(DcsFrameIndex) * totalRec;
+    job->infoBytes = sizeof(DcsStreamInfo) * n;
+    HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&job->hBlob), job->hBlobCap));
+    HIPCHK(ctx, cacheAlloc(ctx, true, &job->hRec, job->recBytes));
+    HIPCHK(ctx, cacheAlloc(ctx, true, &job->hInfo, job->infoBytes));
+    HIPCHK(ctx, cacheAlloc(ctx, false, &job->dBlob, job->dBlobCap));
+    memset(job->hBlob + blobLen, 0, job->hBlobCap - blobLen);
+    for (uint32_t k = 0 ; k < n ; ++k)
     {
-        memset(job->hBlob + blobLen, 0, blobCap - blobLen);
-        for (uint32_t k = 0 ; k < n ; ++k)
+        const DcsStreamLoc &l = job->locs[k];
+        if (k + 1 < n)          // (the alignment gap in front of the next stream)
+            memset(job->hBlob + l.off + l.len, 0, static_cast<size_t>(job->locs[k + 1].off - l.off) - l.len);
+        memcpy(job->hBlob + l.off, job->streams[k].data, l.len);
+    }
+    HIPCHK(ctx, hipEventCreateWithFlags(&job->uploaded, hipEventDisableTiming));
+    HIPCHK(ctx, hipMemcpyAsync(job->dBlob, job->hBlob, job->hBlobCap, hipMemcpyHostToDevice, stream));
+    HIPCHK(ctx, hipEventRecord(job->uploaded, stream));
+    return DCS_OK;
+}
+
+// the indexer: ONE launch of the index kernel over the streams of every list that is waiting
+static void pipelineIndexer(DcsPipeline *p)
+{
+    DcsCtx *ctx = p->ctx;
+    (void)hipSetDevice(ctx->device);
+    const hipStream_t stream = p->streams.back();
+    constexpr size_t kMaxMerge = 32;
+    for (;;)
+    {
+        std::vector<DcsPipeline::JobPtr> jobs;
         {
-            if (k + 1 < n)      // (the alignment gap in front of the next stream)
-                memset(job->hBlob + locs[k].off + locs[k].len, 0, static_cast<size_t>(locs[k + 1].off - locs[k].off) - locs[k].len);
-            memcpy(job->hBlob + locs[k].off, job->streams[k].data, locs[k].len);
+            std::unique_lock<std::mutex> lk(p->m);
+            p->indexWork.wait(lk, [&] { return p->quit || !p->toIndex.empty(); });
+            if (p->quit && p->toIndex.empty())
+                return;
+            while (!p->toIndex.empty() && jobs.size() < kMaxMerge)
+            {
+                jobs.push_back(p->toIndex.front());
+                p->toIndex.pop_front();
+            }
         }
         const double t0 = nowMs();
-        st = gpuIndexOnStream(ctx, stream, job->hBlob, blobLen, locs.data(), n, static_cast<DcsFrameIndex *>(hRec), totalRec,
-                              static_cast<DcsStreamInfo *>(hInfo));
-        *deviceMs += nowMs() - t0;
-    }
-    if (st == DCS_OK)
-    {
-        const DcsStreamInfo *infos = static_cast<const DcsStreamInfo *>(hInfo);
-        bool ok = true;
-        for (uint32_t k = 0 ; k < n && ok ; ++k)
-            ok = infos[k].nFrames != 0 && static_cast<size_t>(infos[k].nBytes) <= locs[k].len;
-        if (ok)
+        // stream locations with ABSOLUTE device addresses (the kernel's blob base is address 0), records in one buffer
+        uint32_t nStreams = 0;
+        uint64_t nRec = 0;
+        for (const DcsPipeline::JobPtr &j : jobs) { nStreams += j->nStreams; nRec += j->totalRec; }
+        std::vector<DcsStreamLoc> locs;
+        locs.reserve(nStreams);
+        uint64_t rec0 = 0;
+        for (const DcsPipeline::JobPtr &j : jobs)
         {
-            const DcsPreIndexed pre{ static_cast<const DcsFrameIndex *>(hRec), firstRecord.data(), infos, streamOff.data() };
-            st = dcsBuildStreams(job->streams, n, job->extraFrames, job->built, false, false, &pre);
-            *usable = st == DCS_OK;
+            for (const DcsStreamLoc &l : j->locs)
+            {
+                DcsStreamLoc a = l;
+                a.off = reinterpret_cast<uint64_t>(j->dBlob) + l.off;
+                a.firstRecord = rec0 + l.firstRecord;
+                locs.push_back(a);
+            }
+            rec0 += j->totalRec;
+        }
+        const size_t locBytes = sizeof(DcsStreamLoc) * nStreams, outBytes = sizeof(DcsFrameIndex) * (nRec ? nRec : 1),
+                     infoBytes = sizeof(DcsStreamInfo) * nStreams;
+        void *dLocs = nullptr, *dOut = nullptr, *dInfos = nullptr;
+        DcsStatus st = [&]() -> DcsStatus {
+            HIPCHK(ctx, cacheAlloc(ctx, false, &dLocs, locBytes));
+            HIPCHK(ctx, cacheAlloc(ctx, false, &dOut, outBytes));
+            HIPCHK(ctx, cacheAlloc(ctx, false, &dInfos, infoBytes));
+            for (const DcsPipeline::JobPtr &j : jobs)
+                HIPCHK(ctx, hipStreamWaitEvent(stream, j->uploaded, 0));
+            HIPCHK(ctx, hipMemcpyAsync(dLocs, locs.data(), locBytes, hipMemcpyHostToDevice, stream));
+            const int lanes = indexLanes(ctx, nStreams);
+            const uint32_t blocks = (nStreams + static_cast<uint32_t>(lanes) - 1) / static_cast<uint32_t>(lanes);
+            hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), 0, stream, static_cast<const uint32_t *>(nullptr),
+                               ~size_t(0) / 4, static_cast<const DcsStreamLoc *>(dLocs), nStreams, lanes, ctx->dTables,
+                               static_cast<DcsFrameIndex *>(dOut), static_cast<DcsStreamInfo *>(dInfos));
+            HIPCHK(ctx, hipGetLastError());
+            uint64_t r = 0;
+            uint32_t s0 = 0;
+            for (const DcsPipeline::JobPtr &j : jobs)
+            {
+                HIPCHK(ctx, hipMemcpyAsync(j->hRec, static_cast<DcsFrameIndex *>(dOut) + r, j->recBytes, hipMemcpyDeviceToHost, stream));
+                HIPCHK(ctx, hipMemcpyAsync(j->hInfo, static_cast<DcsStreamInfo *>(dInfos) + s0, j->infoBytes, hipMemcpyDeviceToHost, stream));
+                r += j->totalRec;
+                s0 += j->nStreams;
+            }
+            HIPCHK(ctx, streamWait(ctx, stream));
+            return DCS_OK;
+        }();
+        if (st != DCS_OK)
+            (void)streamWait(ctx, stream);
+        cacheFree(ctx, false, dLocs, locBytes);
+        cacheFree(ctx, false, dOut, outBytes);
+        cacheFree(ctx, false, dInfos, infoBytes);
+        const double dt = nowMs() - t0;
+        {
+            std::lock_guard<std::mutex> lk(p->m);
+            for (const DcsPipeline::JobPtr &j : jobs)
+            {
+                j->deviceMs += dt;
+                j->status = st;
+                p->indexed.push_back(j);
+            }
+        }
+        p->work.notify_all();
+    }
+}
+
+// stage B: from index records (device path) or from scratch (host pool) to PCM in pinned memory
+static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream_t stream)
+{
+    const double t0 = nowMs();
+    DcsStatus st = DCS_OK;
+    bool fromDevice = false;
+    if (job->hRec != nullptr)
+    {
+        // a stream that runs past its buffer reads its missing bytes as zero, which streams laid end to end cannot
+        // express: such a list (damaged input) takes the host path
+        const DcsStreamInfo *infos = static_cast<const DcsStreamInfo *>(job->hInfo);
+        fromDevice = true;
+        for (uint32_t k = 0 ; k < job->nStreams && fromDevice ; ++k)
+            fromDevice = infos[k].nFrames != 0 && static_cast<size_t>(infos[k].nBytes) <= job->locs[k].len;
+        if (fromDevice)
+        {
+            const DcsPreIndexed pre{ static_cast<const DcsFrameIndex *>(job->hRec), job->firstRecord.data(), infos, job->streamOff.data() };
+            st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, job->built, false, false, &pre);
         }
     }
-    cacheFree(ctx, true, hRec, recBytes);
-    cacheFree(ctx, true, hInfo, infoBytes);
+    if (st == DCS_OK && !fromDevice)
+    {
+        job->built = DcsBuiltStreams();
+        st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, job->built, false, false);
+    }
+    job->onDevice = fromDevice;
+    const uint8_t *blob = fromDevice ? job->hBlob : job->built.blob.data();
+    const size_t blobLen = fromDevice ? job->hBlobLen : job->built.blob.size();
+    double t1 = nowMs(), t2 = t1;
+    // (second attempt, tails by re-decoding the predecessor, only after a lost tail: see dcs_decode_batch)
+    for (int attempt = 0 ; st == DCS_OK && attempt < 2 ; ++attempt)
+    {
+        const bool handoff = p->ctx->handoff && attempt == 0;
+        const DcsBuiltStreams &B = job->built;
+        st = createBatch(p->ctx, blob, blobLen, B.srcs.data(), static_cast<uint32_t>(B.srcs.size()),
+                         B.jobs.data(), static_cast<uint32_t>(B.jobs.size()), nullptr, 0, stream, handoff, &job->batch);
+        t2 = nowMs();
+        if (st == DCS_OK) st = dcs_batch_run(job->batch, nullptr);
+        if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
+        bool lost = false;
+        if (st == DCS_OK && handoff)
+            for (size_t j = 0 ; j < B.jobs.size() && !lost ; ++j)
+                lost = (job->err[j] & DCS_FRAME_TAIL_LOST) != 0;
+        if (!lost)
+            break;
+        dcs_batch_destroy(job->batch);
+        job->batch = nullptr;
+    }
+    pipelineFreeIndexBuffers(p, job, false);        // (the packages are on the device: the streams are no longer needed)
+    const double t3 = nowMs();
+    job->hostMs += t2 - t0;
+    job->deviceMs += t3 - t2;
+    (void)t1;
     return st;
 }
 
 static void pipelineWorker(DcsPipeline *p, int id)
 {
     (void)hipSetDevice(p->ctx->device);
+    const hipStream_t stream = p->streams[id];
+    const bool deviceIndex = (p->flags & DCS_PIPE_INDEX_ON_DEVICE) != 0;
     for (;;)
     {
-        std::shared_ptr<DcsPipeline::Job> job;
+        DcsPipeline::JobPtr job;
+        bool stageB = false;
         {
             std::unique_lock<std::mutex> lk(p->m);
-            p->work.wait(lk, [&] { return p->quit || !p->queue.empty(); });
-            if (p->quit && p->queue.empty())
-                return;
-            job = p->queue.front();
-            p->queue.pop_front();
+            p->work.wait(lk, [&] { return p->quit || !p->indexed.empty() || !p->fresh.empty(); });
+            if (!p->indexed.empty())            // lists that are further along come first
+            {
+                job = p->indexed.front(); p->indexed.pop_front();
+                stageB = true;
+            }
+            else if (!p->fresh.empty())
+            {
+                job = p->fresh.front(); p->fresh.pop_front();
+            }
+            else
+                return;                         // quit
         }
-        const double t0 = nowMs();
-        double indexDeviceMs = 0;
-        bool onDevice = false;
-        DcsStatus st = DCS_OK;
-        if (p->flags & DCS_PIPE_INDEX_ON_DEVICE)
-            st = pipelineIndexOnDevice(p, job.get(), p->streams[id], &onDevice, &indexDeviceMs);
-        if (st == DCS_OK && !onDevice)
+        if (!stageB && deviceIndex)
         {
-            job->built = DcsBuiltStreams();
-            st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, job->built, false, false);
+            const double t0 = nowMs();
+            const DcsStatus st = pipelineUpload(p, job.get(), stream);
+            job->hostMs += nowMs() - t0;
+            if (st != DCS_OK)
+            {
+                pipelineFreeIndexBuffers(p, job.get(), false);
+                pipelineFinish(p, job, st);
+                continue;
+            }
+            {
+                std::lock_guard<std::mutex> lk(p->m);
+                p->toIndex.push_back(job);
+            }
+            p->indexWork.notify_one();
+            continue;
         }
-        const uint8_t *blob = onDevice ? job->hBlob : job->built.blob.data();
-        const size_t blobLen = onDevice ? job->hBlobLen : job->built.blob.size();
-        double t1 = nowMs(), t2 = t1;
-        // (second attempt, tails by re-decoding the predecessor, only after a lost tail: see dcs_decode_batch)
-        for (int attempt = 0 ; st == DCS_OK && attempt < 2 ; ++attempt)
-        {
-            const bool handoff = p->ctx->handoff && attempt == 0;
-            const DcsBuiltStreams &B = job->built;
-            st = createBatch(p->ctx, blob, blobLen, B.srcs.data(), static_cast<uint32_t>(B.srcs.size()),
-                             B.jobs.data(), static_cast<uint32_t>(B.jobs.size()), nullptr, 0, p->streams[id], handoff, &job->batch);
-            t2 = nowMs();
-            if (st == DCS_OK) st = dcs_batch_run(job->batch, nullptr);
-            if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
-            bool lost = false;
-            if (st == DCS_OK && handoff)
-                for (size_t j = 0 ; j < B.jobs.size() && !lost ; ++j)
-                    lost = (job->err[j] & DCS_FRAME_TAIL_LOST) != 0;
-            if (!lost)
-                break;
-            dcs_batch_destroy(job->batch);
-            job->batch = nullptr;
-        }
-        const double t3 = nowMs();
-        job->hostMs = (t2 - t0) - indexDeviceMs;
-        job->deviceMs = (t3 - t2) + indexDeviceMs;
-        {
-            std::lock_guard<std::mutex> lk(p->m);
-            job->status = st;
-            job->done = true;
-        }
-        p->finished.notify_all();
+        DcsStatus st = job->status;             // (the indexer's)
+        if (st == DCS_OK)
+            st = pipelineDecode(p, job.get(), stream);
+        else
+            pipelineFreeIndexBuffers(p, job.get(), false);
+        pipelineFinish(p, job, st);
     }
 }
 
@@ -210,7 +363,10 @@ extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags,
     p->depth = depth;
     p->flags = flags;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    for (int i = 0 ; i < depth ; ++i)
+    // with the index pass on the device a worker holds a list only while it works on it, so there need not be one per
+    // list in flight: as many as the host has cores, and a few more for the ones that wait for a copy
+    const int nWorkers = (flags & DCS_PIPE_INDEX_ON_DEVICE) ? std::min(depth, dcs_host_threads() + 4) : depth;
+    for (int i = 0 ; i < nWorkers + 1 ; ++i)
     {
         hipStream_t s = nullptr;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess)
@@ -222,8 +378,12 @@ extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags,
         }
         p->streams.push_back(s);
     }
-    for (int i = 0 ; i < depth ; ++i)
+    p->hadBlockingWaits = ctx->blockingWaits;
+    ctx->blockingWaits = true;
+    for (int i = 0 ; i < nWorkers ; ++i)
         p->workers.emplace_back(pipelineWorker, p, i);
+    if (flags & DCS_PIPE_INDEX_ON_DEVICE)
+        p->indexer = std::thread(pipelineIndexer, p);
     *out = p;
     return DCS_OK;
 }
@@ -233,18 +393,24 @@ extern "C" void dcs_pipeline_destroy(DcsPipeline *p)
     if (p == nullptr)
         return;
     {
-        std::lock_guard<std::mutex> lk(p->m);
+        std::unique_lock<std::mutex> lk(p->m);
+        // lists still in flight are finished first (their streams belong to the caller)
+        p->finished.wait(lk, [&] { for (const DcsPipeline::JobPtr &j : p->order) if (!j->done) return false; return true; });
         p->quit = true;
     }
     p->work.notify_all();
+    p->indexWork.notify_all();
     for (std::thread &w : p->workers)
         w.join();
+    if (p->indexer.joinable())
+        p->indexer.join();
     (void)hipSetDevice(p->ctx->device);
     pipelineRelease(p, p->held);
-    for (std::shared_ptr<DcsPipeline::Job> &j : p->order)
+    for (DcsPipeline::JobPtr &j : p->order)
         pipelineRelease(p, j);
     for (hipStream_t s : p->streams)
         (void)hipStreamDestroy(s);
+    p->ctx->blockingWaits = p->hadBlockingWaits;
     delete p;
 }
 
@@ -252,13 +418,13 @@ extern "C" DcsStatus dcs_pipeline_submit(DcsPipeline *p, const DcsStreamRef *str
 {
     if (p == nullptr || streams == nullptr || nStreams == 0)
         return DCS_ERR_INVALID_ARG;
-    std::shared_ptr<DcsPipeline::Job> job = std::make_shared<DcsPipeline::Job>();
+    DcsPipeline::JobPtr job = std::make_shared<DcsPipeline::Job>();
     job->streams = streams; job->nStreams = nStreams; job->extraFrames = extraFrames;
     {
         std::unique_lock<std::mutex> lk(p->m);
-        // at most `depth` jobs between submit and collect (each holds device and pinned buffers)
+        // at most `depth` lists between submit and collect (each holds device and pinned buffers)
         p->room.wait(lk, [&] { return static_cast<int>(p->order.size()) < p->depth; });
-        p->queue.push_back(job);
+        p->fresh.push_back(job);
         p->order.push_back(job);
     }
     p->work.notify_one();
@@ -271,7 +437,7 @@ extern "C" DcsStatus dcs_pipeline_collect(DcsPipeline *p, DcsPipelineResult *out
         return DCS_ERR_INVALID_ARG;
     (void)hipSetDevice(p->ctx->device);
     pipelineRelease(p, p->held);                    // the previous result's buffers go back to the context's cache
-    std::shared_ptr<DcsPipeline::Job> job;
+    DcsPipeline::JobPtr job;
     {
         std::unique_lock<std::mutex> lk(p->m);
         if (p->order.empty())

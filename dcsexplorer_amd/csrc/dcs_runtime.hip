@@ -26,6 +26,8 @@ struct DcsCtx
     uint32_t handoffTimeoutTicks = dcsk::kHandoffTimeoutTicks;     // 100 MHz ticks (dcs_ctx_set_test_hooks)
     bool dropExports = false;           // test hook: no chunk publishes its tail (dcs_ctx_set_test_hooks)
     std::mutex cacheMutex;              // the buffer cache is shared by the pipeline's worker threads
+    bool blockingWaits = false;         // host waits sleep on an interrupt instead of polling (set while a pipeline exists:
+                                        // its many waiting threads must leave the cores to the ones that prepare lists)
     int numCUs = 256;
     std::string lastError;
     // inputs of the last dcs_index_streams_gpu call, resident for dcs_index_streams_gpu_time
@@ -77,6 +79,24 @@ static void cacheFree(DcsCtx *ctx, bool pinned, void *p, size_t cap)
     }
     (pinned ? ctx->pinCache : ctx->devCache).push_back(DcsCtx::Cached{ p, cap });
     ctx->cachedBytes += cap;
+}
+
+// wait for everything enqueued on `stream`
+static hipError_t streamWait(DcsCtx *ctx, hipStream_t stream)
+{
+    if (!ctx->blockingWaits)
+        return hipStreamSynchronize(stream);
+    thread_local hipEvent_t ev = nullptr;
+    thread_local int evDevice = -1;
+    if (ev == nullptr || evDevice != ctx->device)
+    {
+        const hipError_t e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+        if (e != hipSuccess)
+            return e;
+        evDevice = ctx->device;
+    }
+    const hipError_t e = hipEventRecord(ev, stream);
+    return e != hipSuccess ? e : hipEventSynchronize(ev);
 }
 
 struct DcsBatch
@@ -263,7 +283,7 @@ extern "C" void dcs_batch_destroy(DcsBatch *b)
         return;
     (void)hipSetDevice(b->ctx->device);
     if (b->evDone) (void)waitLaunched(b);               // nothing of this batch is in flight when its buffers are recycled,
-    (void)hipStreamSynchronize(b->stream);         // on the caller's launch stream or on the context's
+    (void)streamWait(b->ctx, b->stream);         // on the caller's launch stream or on the context's
     void *ptrs[] = { b->dBlob, b->dSrcs, nullptr, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug, b->dHandoff, b->dPackages };
     for (int i = 0 ; i < 10 ; ++i)
         cacheFree(b->ctx, false, ptrs[i], b->cap[i]);
@@ -447,12 +467,12 @@ static DcsStatus createBatch(DcsCtx *ctx,
 #endif
         HIPCHK(ctx, hipEventCreate(&b->ev0));
         HIPCHK(ctx, hipEventCreate(&b->ev1));
-        HIPCHK(ctx, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming));
-        HIPCHK(ctx, hipStreamSynchronize(b->stream));
+        HIPCHK(ctx, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming | (ctx->blockingWaits ? hipEventBlockingSync : 0u)));
+        HIPCHK(ctx, streamWait(b->ctx, b->stream));
         return DCS_OK;
     }();
     if (st != DCS_OK)
-        (void)hipStreamSynchronize(b->stream);    // (on success the lambda has already waited for the uploads)
+        (void)streamWait(b->ctx, b->stream);    // (on success the lambda has already waited for the uploads)
     cacheFree(ctx, true, hPackages, pkgBytes);
     if (st != DCS_OK)
     {
@@ -571,7 +591,7 @@ extern "C" DcsStatus dcs_batch_sync(DcsBatch *b)
         return DCS_ERR_INVALID_ARG;
     HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
     HIPCHK(b->ctx, waitLaunched(b));
-    HIPCHK(b->ctx, hipStreamSynchronize(b->stream));
+    HIPCHK(b->ctx, streamWait(b->ctx, b->stream));
     return DCS_OK;
 }
 
@@ -582,7 +602,7 @@ extern "C" DcsStatus dcs_batch_download(DcsBatch *b, int16_t *pcmOut, uint32_t *
     DcsCtx *ctx = b->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, waitLaunched(b));
-    HIPCHK(ctx, hipStreamSynchronize(b->stream));
+    HIPCHK(ctx, streamWait(b->ctx, b->stream));
     if (pcmOut)
         HIPCHK(ctx, hipMemcpy(pcmOut, b->dPcm, sizeof(int16_t) * DCS_FRAME_SAMPLES * b->nJobs, hipMemcpyDeviceToHost));
     if (errOut)
@@ -616,7 +636,7 @@ extern "C" DcsStatus dcs_batch_download_view(DcsBatch *b, const int16_t **pcmOut
     HIPCHK(ctx, hipMemcpyAsync(b->hPcm, b->dPcm, pcmBytes, hipMemcpyDeviceToHost, b->stream));
     if (errOut != nullptr)
         HIPCHK(ctx, hipMemcpyAsync(b->hErr, b->dErr, errBytes, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(ctx, hipStreamSynchronize(b->stream));
+    HIPCHK(ctx, streamWait(b->ctx, b->stream));
     *pcmOut = b->hPcm;
     if (errOut != nullptr)
         *errOut = b->hErr;
@@ -630,7 +650,7 @@ extern "C" void *dcs_batch_device_pcm(DcsBatch *b) { return b ? b->dPcm : nullpt
 extern "C" int dcs_debug_stamps(DcsBatch *b, unsigned long long *out, uint32_t capChunks)
 {
     if (b == nullptr || b->dDebug == nullptr) return -1;
-    (void)hipStreamSynchronize(b->stream);
+    (void)streamWait(b->ctx, b->stream);
     const uint32_t n = b->nChunks < capChunks ? b->nChunks : capChunks;
     (void)hipMemcpy(out, b->dDebug, sizeof(unsigned long long) * 16 * n, hipMemcpyDeviceToHost);
     return static_cast<int>(n);
@@ -859,11 +879,11 @@ static DcsStatus gpuIndexOnStream(DcsCtx *ctx, hipStream_t stream, const uint8_t
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(out, dOut, sizeof(DcsFrameIndex) * outCap, hipMemcpyDeviceToHost, stream));
         HIPCHK(ctx, hipMemcpyAsync(infos, dInfos, infoBytes, hipMemcpyDeviceToHost, stream));
-        HIPCHK(ctx, hipStreamSynchronize(stream));
+        HIPCHK(ctx, streamWait(ctx, stream));
         return DCS_OK;
     }();
     if (st != DCS_OK)
-        (void)hipStreamSynchronize(stream);
+        (void)streamWait(ctx, stream);
     cacheFree(ctx, false, dBlob, blobAlloc);
     cacheFree(ctx, false, dLocs, locBytes);
     cacheFree(ctx, false, dOut, outBytes);
