@@ -56,7 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--corpus-streams", type=int, default=20, help="streams per title of the corpus workload (SURVEY 8d's full "
                     "stand-in is 600; 20 is the size whose per-stream reference hashes are committed)")
     ap.add_argument("--e2e-depth", type=int, default=8, help="lists in flight of end_to_end.sustained_host_index")
-    ap.add_argument("--e2e-device-depth", type=int, default=24, help="lists in flight of end_to_end.sustained_device_index")
+    ap.add_argument("--e2e-device-depth", type=int, default=32, help="lists in flight of end_to_end.sustained_device_index")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the N-rank path (gloo, no GPU, no kernel)")
     return ap.parse_args(argv)
 
@@ -113,7 +113,7 @@ def cpu_baseline(streams, budget_s=10.0):
 
 
 # --------------------------------------------------------------------------------------------- end to end
-def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=24, lists=24):
+def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
     """host buffers in, host buffers out (never `value`): index pass + parameters + plan + pack + H2D + kernel + D2H.
     cold: one synchronous dcs_decode_streams call per list.  sustained: the same lists through dcs_pipeline with
     `depth` lists in flight (host preparation of list k+1 while the GPU decodes k and k-1 comes back into pinned memory)."""

@@ -20,6 +20,7 @@
 #include <deque>
 #include <memory>
 #include <thread>
+#include <pthread.h>
 
 struct DcsPipeline
 {
@@ -27,7 +28,7 @@ struct DcsPipeline
     {
         const DcsStreamRef *streams = nullptr;
         uint32_t nStreams = 0, extraFrames = 0;
-        DcsBuiltStreams built;
+        std::vector<uint32_t> firstJob;         // first output frame of each stream, and the total
         DcsBatch *batch = nullptr;
         const int16_t *pcm = nullptr;
         const uint32_t *err = nullptr;
@@ -160,6 +161,7 @@ static DcsStatus pipelineUpload(DcsPipeline *p, DcsPipeline::Job *job, hipStream
 // the indexer: ONE launch of the index kernel over the streams of every list that is waiting
 static void pipelineIndexer(DcsPipeline *p)
 {
+    pthread_setname_np(pthread_self(), "dcs-indexer");
     DcsCtx *ctx = p->ctx;
     (void)hipSetDevice(ctx->device);
     const hipStream_t stream = p->streams.back();
@@ -209,7 +211,7 @@ static void pipelineIndexer(DcsPipeline *p)
             HIPCHK(ctx, hipMemcpyAsync(dLocs, locs.data(), locBytes, hipMemcpyHostToDevice, stream));
             const int lanes = indexLanes(ctx, nStreams);
             const uint32_t blocks = (nStreams + static_cast<uint32_t>(lanes) - 1) / static_cast<uint32_t>(lanes);
-            hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), 0, stream, static_cast<const uint32_t *>(nullptr),
+            hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), indexDynBytes(lanes), stream, static_cast<const uint32_t *>(nullptr),
                                ~size_t(0) / 4, static_cast<const DcsStreamLoc *>(dLocs), nStreams, lanes, ctx->dTables,
                                static_cast<DcsFrameIndex *>(dOut), static_cast<DcsStreamInfo *>(dInfos));
             HIPCHK(ctx, hipGetLastError());
@@ -250,34 +252,38 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     const double t0 = nowMs();
     DcsStatus st = DCS_OK;
     bool fromDevice = false;
+    // the batch description is needed only until the batch exists: one per worker thread, its memory kept from list to
+    // list (fresh multi-megabyte vectors for every list cost more in page faults than everything else the host does)
+    thread_local DcsBuiltStreams scratch;
+    DcsBuiltStreams &built = scratch;
     if (job->hRec != nullptr)
     {
-        // a stream that runs past its buffer reads its missing bytes as zero, which streams laid end to end cannot
-        // express: such a list (damaged input) takes the host path
+        // a stream whose frames run past its buffer reads the missing bytes as zero, which streams laid end to end
+        // cannot express: such a list (truncated input) takes the host path.  What counts is the bits the frames
+        // occupy, not nBytes, which includes the reference reader's look-ahead of up to three bytes (:1509).
         const DcsStreamInfo *infos = static_cast<const DcsStreamInfo *>(job->hInfo);
         fromDevice = true;
         for (uint32_t k = 0 ; k < job->nStreams && fromDevice ; ++k)
-            fromDevice = infos[k].nFrames != 0 && static_cast<size_t>(infos[k].nBytes) <= job->locs[k].len;
+            fromDevice = infos[k].nFrames != 0
+                      && 2u + static_cast<size_t>(infos[k].hdrLen) + (static_cast<size_t>(infos[k].payloadBits) + 7) / 8 <= job->locs[k].len;
         if (fromDevice)
         {
             const DcsPreIndexed pre{ static_cast<const DcsFrameIndex *>(job->hRec), job->firstRecord.data(), infos, job->streamOff.data() };
-            st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, job->built, false, false, &pre);
+            st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, built, false, false, &pre);
         }
     }
     if (st == DCS_OK && !fromDevice)
-    {
-        job->built = DcsBuiltStreams();
-        st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, job->built, false, false);
-    }
+        st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, built, false, false);
     job->onDevice = fromDevice;
-    const uint8_t *blob = fromDevice ? job->hBlob : job->built.blob.data();
-    const size_t blobLen = fromDevice ? job->hBlobLen : job->built.blob.size();
+    job->firstJob = built.firstJob;
+    const uint8_t *blob = fromDevice ? job->hBlob : built.blob.data();
+    const size_t blobLen = fromDevice ? job->hBlobLen : built.blob.size();
     double t1 = nowMs(), t2 = t1;
     // (second attempt, tails by re-decoding the predecessor, only after a lost tail: see dcs_decode_batch)
     for (int attempt = 0 ; st == DCS_OK && attempt < 2 ; ++attempt)
     {
         const bool handoff = p->ctx->handoff && attempt == 0;
-        const DcsBuiltStreams &B = job->built;
+        const DcsBuiltStreams &B = built;
         st = createBatch(p->ctx, blob, blobLen, B.srcs.data(), static_cast<uint32_t>(B.srcs.size()),
                          B.jobs.data(), static_cast<uint32_t>(B.jobs.size()), nullptr, 0, stream, handoff, &job->batch);
         t2 = nowMs();
@@ -294,6 +300,9 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     }
     pipelineFreeIndexBuffers(p, job, false);        // (the packages are on the device: the streams are no longer needed)
     const double t3 = nowMs();
+    if (getenv("DCS_PIPE_TRACE"))
+        fprintf(stderr, "pipe list: upload %.2f ms, index launch %.2f ms (records from the %s) | build %.2f create %.2f run+download %.2f\n",
+                job->hostMs, job->deviceMs, fromDevice ? "device" : "host pool", t1 - t0, t2 - t1, t3 - t2);
     job->hostMs += t2 - t0;
     job->deviceMs += t3 - t2;
     (void)t1;
@@ -302,6 +311,7 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
 
 static void pipelineWorker(DcsPipeline *p, int id)
 {
+    pthread_setname_np(pthread_self(), "dcs-worker");
     (void)hipSetDevice(p->ctx->device);
     const hipStream_t stream = p->streams[id];
     const bool deviceIndex = (p->flags & DCS_PIPE_INDEX_ON_DEVICE) != 0;
@@ -366,10 +376,17 @@ extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags,
     // with the index pass on the device a worker holds a list only while it works on it, so there need not be one per
     // list in flight: as many as the host has cores, and a few more for the ones that wait for a copy
     const int nWorkers = (flags & DCS_PIPE_INDEX_ON_DEVICE) ? std::min(depth, dcs_host_threads() + 4) : depth;
+    int prioLeast = 0, prioGreatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest);
     for (int i = 0 ; i < nWorkers + 1 ; ++i)
     {
         hipStream_t s = nullptr;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess)
+        // The indexer's stream (the last one) gets the lowest priority: not for the priority, but because streams of
+        // different priorities never share a hardware queue.  Its launches run for milliseconds (a walk is serial per
+        // stream), and a worker's copies and 40-microsecond kernels must not queue up behind one.
+        const hipError_t e = i == nWorkers ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prioLeast)
+                                           : hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e != hipSuccess)
         {
             for (hipStream_t t : p->streams) (void)hipStreamDestroy(t);
             delete p;
@@ -457,8 +474,8 @@ extern "C" DcsStatus dcs_pipeline_collect(DcsPipeline *p, DcsPipelineResult *out
     {
         out->pcm = job->pcm;
         out->err = job->err;
-        out->frameOffsets = job->built.firstJob.data();
-        out->nFrames = static_cast<uint32_t>(job->built.jobs.size());
+        out->frameOffsets = job->firstJob.data();
+        out->nFrames = job->firstJob.empty() ? 0u : job->firstJob.back();
     }
     return job->status;
 }

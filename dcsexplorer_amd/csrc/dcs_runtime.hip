@@ -396,7 +396,7 @@ static DcsStatus createBatch(DcsCtx *ctx,
     }
     b->flags = batchFlags;
 
-    std::vector<DcsSlot> slots;
+    thread_local std::vector<DcsSlot> slots;    // (kept from batch to batch: see the pipeline's scratch)
     uint8_t *hPackages = nullptr;           // pinned staging for the chunk packages
     size_t pkgBytes = 0;
     b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff);
@@ -804,12 +804,15 @@ struct DevSink
     }
 };
 
-__global__ __launch_bounds__(64) void dcsIndexKernel(const uint32_t *blobDw, size_t nDw, const DcsStreamLoc *locs,
+__global__ __launch_bounds__(64, 6) void dcsIndexKernel(const uint32_t *blobDw, size_t nDw, const DcsStreamLoc *locs,
                                                       uint32_t nStreams, int lanes, const DcsDevTables *tables,
                                                       DcsFrameIndex *out, DcsStreamInfo *infos)
 {
     __shared__ DcsLdsTables T;
-    __shared__ DcsScanMem mem[64];
+    // working records of the walking lanes only (dynamic: with one lane per wavefront a block then needs 3.4 KB, and a CU
+    // holds as many such blocks as it has wavefront slots)
+    extern __shared__ __attribute__((aligned(16))) unsigned char indexDyn[];
+    DcsScanMem *mem = reinterpret_cast<DcsScanMem *>(indexDyn);
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&tables->lds);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&T);
@@ -832,11 +835,13 @@ __global__ __launch_bounds__(64) void dcsIndexKernel(const uint32_t *blobDw, siz
 
 }   // namespace
 
+static size_t indexDynBytes(int lanes) { return (sizeof(DcsScanMem) * static_cast<size_t>(lanes) + 15) & ~size_t(15); }
+
 static hipError_t launchIndex(DcsCtx *ctx)
 {
     const uint32_t lanes = static_cast<uint32_t>(ctx->idxLanes);
     const uint32_t blocks = (ctx->idxStreams + lanes - 1) / lanes;
-    hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), 0, ctx->stream, ctx->dIdxBlob, ctx->idxBlobDw, ctx->dIdxLocs,
+    hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), indexDynBytes(ctx->idxLanes), ctx->stream, ctx->dIdxBlob, ctx->idxBlobDw, ctx->dIdxLocs,
                        ctx->idxStreams, ctx->idxLanes, ctx->dTables, ctx->dIdxOut, ctx->dIdxInfos);
     return hipGetLastError();
 }
@@ -845,7 +850,7 @@ static hipError_t launchIndex(DcsCtx *ctx)
 // divergence); many -> fill the wavefronts
 static int indexLanes(const DcsCtx *ctx, uint32_t nStreams)
 {
-    const uint32_t wavesWanted = static_cast<uint32_t>(ctx->numCUs) * 8;
+    const uint32_t wavesWanted = static_cast<uint32_t>(ctx->numCUs) * 24;       // the wavefront slots of the chip for this kernel (76 VGPRs: 6 per SIMD)
     const uint32_t lanes = (nStreams + wavesWanted - 1) / wavesWanted;
     return static_cast<int>(lanes < 1 ? 1 : lanes > 64 ? 64 : lanes);
 }
@@ -873,7 +878,7 @@ static DcsStatus gpuIndexOnStream(DcsCtx *ctx, hipStream_t stream, const uint8_t
         // anybody: nValidFrames says how many there are)
         const int lanes = indexLanes(ctx, nStreams);
         const uint32_t blocks = (nStreams + static_cast<uint32_t>(lanes) - 1) / static_cast<uint32_t>(lanes);
-        hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), 0, stream, static_cast<const uint32_t *>(dBlob), blobAlloc / 4,
+        hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), indexDynBytes(lanes), stream, static_cast<const uint32_t *>(dBlob), blobAlloc / 4,
                            static_cast<const DcsStreamLoc *>(dLocs), nStreams, lanes, ctx->dTables,
                            static_cast<DcsFrameIndex *>(dOut), static_cast<DcsStreamInfo *>(dInfos));
         HIPCHK(ctx, hipGetLastError());

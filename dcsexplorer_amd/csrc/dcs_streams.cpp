@@ -19,6 +19,10 @@ DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32
     std::vector<uint8_t> vs;
     uint64_t total = 0, totalSrc = 0;
     std::vector<uint64_t> firstRecord(nStreams);
+    // (B may be a caller's scratch that has served earlier lists: its vectors keep their memory, which matters when
+    // many lists are prepared at once -- fresh multi-megabyte vectors per list mean page faults by the thousand)
+    B.firstJob.clear();
+    B.blob.clear();
     for (uint32_t k = 0 ; k < nStreams ; ++k)
     {
         const DcsStreamRef &sr = streams[k];
@@ -53,8 +57,12 @@ DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32
     if (pre != nullptr)
         for (uint32_t k = 0 ; k < nStreams ; ++k)
             firstRecord[k] = pre->firstRecord[k];
-    B.jobs.reserve(total);
-    B.srcs.reserve(totalSrc);
+    if (total > 0xFFFFFFFFull)
+        return DCS_ERR_CAPACITY;
+    // every element is written in full below, so elements left over from an earlier list need no clearing
+    if (B.jobs.size() != total) B.jobs.resize(total);
+    if (B.srcs.size() != totalSrc) B.srcs.resize(totalSrc);
+    uint32_t nJobsOut = 0, nSrcsOut = 0;
 
     for (uint32_t k = 0 ; k < nStreams ; ++k)
     {
@@ -101,23 +109,22 @@ DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32
         const uint32_t nValid = static_cast<uint32_t>(info.nValidFrames);
         for (uint32_t f = 0 ; f < nFrames + extraFrames ; ++f)
         {
-            DcsFrameJob jb;
-            memset(&jb, 0, sizeof(jb));
+            DcsFrameJob &jb = B.jobs[nJobsOut];
+            jb.firstSrc = 0; jb.flags = 0; jb.reserved = 0;
             jb.xform = xform;
-            jb.prev = (f == 0 && !(sequence && k != 0)) ? DCS_PREV_NONE : static_cast<uint32_t>(B.jobs.size() - 1);
+            jb.prev = (f == 0 && !(sequence && k != 0)) ? DCS_PREV_NONE : nJobsOut - 1;
             if (f < nValid)
             {
-                DcsSrcDesc sd;
-                memset(&sd, 0, sizeof(sd));
+                DcsSrcDesc &sd = B.srcs[nSrcsOut];
+                static_assert(sizeof(DcsSrcDesc) == 12 + sizeof(DcsFrameIndex), "DcsSrcDesc has no padding to clear");
                 sd.streamOff = streamOff;
                 sd.mixMul = mm[f];
                 sd.format = static_cast<uint8_t>(info.format);
                 sd.hdrLen = static_cast<uint8_t>(info.hdrLen);
                 sd.idx = idx[f];
-                jb.firstSrc = static_cast<uint32_t>(B.srcs.size());
+                jb.firstSrc = nSrcsOut++;
                 jb.nSrc = 1;
                 jb.volShift = vs[f];
-                B.srcs.push_back(sd);
             }
             else
             {
@@ -126,9 +133,10 @@ DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32
                 jb.nSrc = 0;
                 jb.volShift = 8;
             }
-            B.jobs.push_back(jb);
+            ++nJobsOut;
         }
     }
+    B.srcs.resize(nSrcsOut);            // (streams cut short by an error have fewer sources than frames)
     return DCS_OK;
 }
 

@@ -1,0 +1,11 @@
+"""the device index pass alone: kernel time by number of streams (256 frames each)"""
+import sys, os
+sys.path.insert(0, os.getcwd())
+import dcsexplorer_amd as D
+from dcsexplorer_amd import workloads as W
+ctx = D.Context(0)
+base = W.streams_dcs94_65536()
+for mult in (1, 4, 8, 16, 24, 32):
+    streams = base * mult
+    ctx.index_streams_gpu(streams[:len(streams)])
+    print("%5d streams x 256 frames: index kernel %.2f ms" % (len(streams), ctx.index_gpu_time(3)))

@@ -1,0 +1,43 @@
+import sys, time, os, resource
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import dcsexplorer_amd as D
+from dcsexplorer_amd import workloads as W
+streams = W.streams_dcs94_65536()
+ctx = D.Context(0)
+refs, keep = D.make_refs(streams)
+depth = int(sys.argv[1]); dev = sys.argv[2] == "dev"
+pipe = ctx.pipeline(depth, index_on_device=dev)
+for _ in range(depth): pipe.submit_refs(refs, len(streams))
+for _ in range(depth): pipe.collect()
+n = 3 * depth
+def cpustat():
+    try:
+        return dict(l.split() for l in open('/sys/fs/cgroup/cpu.stat').read().splitlines())
+    except Exception:
+        return {}
+r0 = resource.getrusage(resource.RUSAGE_SELF); c0 = cpustat()
+t0 = time.perf_counter(); done = 0
+for k in range(n):
+    pipe.submit_refs(refs, len(streams))
+    if k >= depth - 1: pipe.collect(); done += 1
+while done < n: pipe.collect(); done += 1
+dt = time.perf_counter() - t0
+r1 = resource.getrusage(resource.RUSAGE_SELF); c1 = cpustat()
+print("ms/list", dt / n * 1e3, "cpu user ms/list", (r1.ru_utime - r0.ru_utime) / n * 1e3, "sys ms/list", (r1.ru_stime - r0.ru_stime) / n * 1e3,
+      "minflt/list", (r1.ru_minflt - r0.ru_minflt) / n, "nvcsw/list", (r1.ru_nvcsw - r0.ru_nvcsw) / n,
+      "throttled_usec/list", (int(c1.get("throttled_usec", 0)) - int(c0.get("throttled_usec", 0))) / n, "nr_throttled", int(c1.get("nr_throttled", 0)) - int(c0.get("nr_throttled", 0)))
+
+
+import glob, collections
+agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+tck = os.sysconf("SC_CLK_TCK")
+for t in glob.glob("/proc/self/task/*"):
+    try:
+        comm = open(t + "/comm").read().strip()
+        f = open(t + "/stat").read().rsplit(")", 1)[1].split()
+        agg[comm][0] += 1; agg[comm][1] += int(f[11]) / tck; agg[comm][2] += int(f[12]) / tck
+    except Exception:
+        pass
+for k, v in sorted(agg.items(), key=lambda x: -x[1][1]):
+    print("  threads %-18s n=%3d user %.2f s sys %.2f s" % (k, v[0], v[1], v[2]))
