@@ -5,8 +5,9 @@
 #include "../../include/DCSDecoderHIP.h"
 #include <string.h>
 
-namespace dcship {
+DCSHIP_NAMESPACE_BEGIN
 
+#ifndef DCSHIP_USE_REFERENCE_BASE
 // ---- DCSDecoder base mirror ------------------------------------------------------------------------------
 static std::map<std::string, const DCSDecoder::Registration &> &regMap()
 {
@@ -43,6 +44,8 @@ int16_t DCSDecoder::GetNextSample()
     return outputBuffer[sampleCounter++];
 }
 
+#endif
+
 // the same plug-in seam the reference uses for "native" / "emulator-strict" (DCSDecoderNative.cpp:18)
 static DCSDecoder::Registration registration("hip", "MI355X HIP batch decoder",
     [](DCSDecoder::Host *host) -> DCSDecoder * { return new DCSDecoderHIP(host); });
@@ -57,7 +60,13 @@ DCSDecoderHIP::~DCSDecoderHIP()
     if (ctx != nullptr) dcs_ctx_destroy(ctx);
 }
 
-void DCSDecoderHIP::InitStandalone(OSVersion v) { osVersion = v; }
+void DCSDecoderHIP::InitStandalone(OSVersion v)
+{
+    osVersion = v;
+    // each OS version goes with one board (DCSDecoderNative.cpp:32-59); SoftBoot then does not ask the ROMs
+    hwVersion = v == OSVersion::OS95 ? HWVersion::DCS95 : v == OSVersion::Invalid ? HWVersion::Invalid
+              : v == OSVersion::Unknown ? HWVersion::Unknown : HWVersion::DCS93;
+}
 
 DcsOsVersion DCSDecoderHIP::AbiOs() const
 {
@@ -78,6 +87,7 @@ bool DCSDecoderHIP::EnsureRoms()
     return roms != nullptr;
 }
 
+#ifndef DCSHIP_USE_REFERENCE_BASE
 void DCSDecoderHIP::AddROM(int n, const uint8_t *data, size_t size)
 {
     if (EnsureRoms())
@@ -173,6 +183,7 @@ DCSDecoder::ROMPointer DCSDecoderHIP::MakeROMPointer(uint32_t linearAddress) con
         return ROMPointer();
     return ROMPointer(chip - 2, p);
 }
+#endif
 
 // ---- playing ---------------------------------------------------------------------------------------------------
 bool DCSDecoderHIP::Initialize()
@@ -192,6 +203,26 @@ bool DCSDecoderHIP::Initialize()
         seq = nullptr;
     }
     ready.clear(); hostBytes.clear(); handedOut = 0; nextTick = 0;
+#ifdef DCSHIP_USE_REFERENCE_BASE
+    // The base class owns the ROM images (AddROM / LoadROMFromZipFile put them in ROM[], CheckROMs has identified them
+    // or the caller has named the versions): hand them to the C ABI's ROM set, with the versions the base holds.
+    if (roms != nullptr)
+    {
+        dcs_romset_destroy(roms);
+        roms = nullptr;
+    }
+    if (ROM[0].data != nullptr && !ROM[0].isDummy && EnsureRoms())
+    {
+        for (int i = 0 ; i < 8 ; ++i)
+            if (ROM[i].data != nullptr && !ROM[i].isDummy)
+                dcs_romset_add_rom(roms, i + 2, ROM[i].data, ROM[i].size);
+        DcsRomCheck c;
+        dcs_romset_check(roms, &c);                             // (catalog, nominal version)
+        if (hwVersion == HWVersion::DCS93 || hwVersion == HWVersion::DCS95)
+            dcs_romset_set_version(roms, hwVersion == HWVersion::DCS95 ? DCS_HW_DCS95 : DCS_HW_DCS93, AbiOs());
+    }
+    autobuffer.Set(outputBuffer, 0x1E0, 1);                     // as DCSDecoderNative.cpp:3203
+#endif
     const bool haveRoms = roms != nullptr && dcs_romset_num_tracks(roms) != 0;
     if (haveRoms)
     {
@@ -251,6 +282,20 @@ void DCSDecoderHIP::SetReportedVersionNumber(uint16_t vsn)
     }
 }
 
+#ifdef DCSHIP_USE_REFERENCE_BASE
+void DCSDecoderHIP::IRQ2Handler()
+{
+    // one byte of what the host wrote (the base class queued it in WriteDataPort, DCSDecoder.cpp:1543-1577)
+    const uint8_t data = ReadDataPort();
+    if (seq != nullptr)
+    {
+        Sync();
+        dcs_seq_write_data_port(seq, data);
+    }
+}
+#else
+void DCSDecoderHIP::IRQ2Handler() { }
+
 void DCSDecoderHIP::WriteDataPort(uint8_t data)
 {
     if (state == State::HardBoot)
@@ -264,6 +309,7 @@ void DCSDecoderHIP::WriteDataPort(uint8_t data)
         dcs_seq_write_data_port(seq, data);
     }
 }
+#endif
 
 void DCSDecoderHIP::AddTrackCommand(uint16_t trackNum)
 {
@@ -359,7 +405,7 @@ void DCSDecoderHIP::MainLoop()
         errorMessage = "The decoder performed a self-reset after encountering multiple fatal errors decoding track data.";
         return;
     }
-    memcpy(outputBuffer, ready.front().data(), sizeof(outputBuffer));
+    memcpy(outputBuffer, ready.front().data(), sizeof(int16_t) * DCS_FRAME_SAMPLES);
     ready.pop_front();
     ++handedOut;
     ++nextTick;
@@ -385,4 +431,4 @@ bool DCSDecoderHIP::DecodeStreamsBatch(const std::vector<BatchStream> &streams, 
     return st == DCS_OK;
 }
 
-}   // namespace dcship
+DCSHIP_NAMESPACE_END

@@ -855,47 +855,6 @@ static int indexLanes(const DcsCtx *ctx, uint32_t nStreams)
     return static_cast<int>(lanes < 1 ? 1 : lanes > 64 ? 64 : lanes);
 }
 
-// The index pass on the device, re-entrant: everything on `stream`, buffers from the context's cache, results into
-// caller memory (pinned, for the copies to be asynchronous).  `hBlob` must be readable up to the next multiple of four
-// past blobLen + 4.  Returns after the stream has been waited for.
-static DcsStatus gpuIndexOnStream(DcsCtx *ctx, hipStream_t stream, const uint8_t *hBlob, size_t blobLen,
-                                  const DcsStreamLoc *locs, uint32_t nStreams,
-                                  DcsFrameIndex *out, uint64_t outCap, DcsStreamInfo *infos)
-{
-    const size_t blobAlloc = (blobLen + 3 + 4) & ~size_t(3);
-    const size_t locBytes = sizeof(DcsStreamLoc) * nStreams, outBytes = sizeof(DcsFrameIndex) * (outCap ? outCap : 1),
-                 infoBytes = sizeof(DcsStreamInfo) * nStreams;
-    void *dBlob = nullptr, *dLocs = nullptr, *dOut = nullptr, *dInfos = nullptr;
-    DcsStatus st = [&]() -> DcsStatus {
-        HIPCHK(ctx, cacheAlloc(ctx, false, &dBlob, blobAlloc));
-        HIPCHK(ctx, cacheAlloc(ctx, false, &dLocs, locBytes));
-        HIPCHK(ctx, cacheAlloc(ctx, false, &dOut, outBytes));
-        HIPCHK(ctx, cacheAlloc(ctx, false, &dInfos, infoBytes));
-        HIPCHK(ctx, hipMemsetAsync(static_cast<uint8_t *>(dBlob) + (blobAlloc - 8), 0, 8, stream));
-        HIPCHK(ctx, hipMemcpyAsync(dBlob, hBlob, blobLen, hipMemcpyHostToDevice, stream));
-        HIPCHK(ctx, hipMemcpyAsync(dLocs, locs, locBytes, hipMemcpyHostToDevice, stream));
-        // (records of frames the walk never reaches -- behind a STOP -- are not written by the kernel and not read by
-        // anybody: nValidFrames says how many there are)
-        const int lanes = indexLanes(ctx, nStreams);
-        const uint32_t blocks = (nStreams + static_cast<uint32_t>(lanes) - 1) / static_cast<uint32_t>(lanes);
-        hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), indexDynBytes(lanes), stream, static_cast<const uint32_t *>(dBlob), blobAlloc / 4,
-                           static_cast<const DcsStreamLoc *>(dLocs), nStreams, lanes, ctx->dTables,
-                           static_cast<DcsFrameIndex *>(dOut), static_cast<DcsStreamInfo *>(dInfos));
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(out, dOut, sizeof(DcsFrameIndex) * outCap, hipMemcpyDeviceToHost, stream));
-        HIPCHK(ctx, hipMemcpyAsync(infos, dInfos, infoBytes, hipMemcpyDeviceToHost, stream));
-        HIPCHK(ctx, streamWait(ctx, stream));
-        return DCS_OK;
-    }();
-    if (st != DCS_OK)
-        (void)streamWait(ctx, stream);
-    cacheFree(ctx, false, dBlob, blobAlloc);
-    cacheFree(ctx, false, dLocs, locBytes);
-    cacheFree(ctx, false, dOut, outBytes);
-    cacheFree(ctx, false, dInfos, infoBytes);
-    return st;
-}
-
 extern "C" DcsStatus dcs_index_streams_gpu(DcsCtx *ctx, const uint8_t *blob, size_t blobLen,
                                            const DcsStreamLoc *streams, uint32_t nStreams,
                                            DcsFrameIndex *out, uint64_t outCap, DcsStreamInfo *infos)

@@ -8,9 +8,18 @@
 // with a one-line change.  Everything below the class is the C ABI of dcs_hip.h; the
 // frame decode itself runs in HIP kernels, there is no CPU decode path in this class.
 //
-// In this repository the base-class mirror lives in namespace dcship so that the header is
-// self-contained; inside the reference tree DCSDecoderHIP derives from the real ::DCSDecoder instead
-// (INTEGRATION.md shows the ten-line adapter).
+// Two builds of this header:
+//   * stand-alone (default): the client-facing part of the base class is mirrored in namespace dcship, so that the
+//     header is self-contained and the library builds without the reference tree;
+//   * -DDCSHIP_USE_REFERENCE_BASE, inside the reference tree: DCSDecoderHIP derives from the REAL ::DCSDecoder
+//     (DCSDecoder/DCSDecoder.h).  Everything the base already does -- AddROM, LoadROMFromZipFile, CheckROMs,
+//     GetTrackInfo, DecompileTrackProgram, ListStreams, MakeROMPointer, WriteDataPort, the boot states, the sample
+//     pump -- is inherited, not re-declared, so a caller that holds a plain DCSDecoder* (DCSExplorer.cpp:457-488)
+//     reaches this decoder through the base's own members: the ROM images the base collected in ROM[] are handed to
+//     the C ABI's ROM set in Initialize(), and the data-port bytes the base queues reach the sequencer through
+//     IRQ2Handler() -> ReadDataPort().  oracle/Makefile (target refbase) compiles exactly that against the
+//     unmodified base class, and tests/test_refbase.py drives it through a DCSDecoder* only.  In that build the class
+//     is ::DCSDecoderHIP, in the stand-alone build dcship::DCSDecoderHIP.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -21,6 +30,14 @@
 #include <vector>
 #include "dcs_hip.h"
 
+#ifdef DCSHIP_USE_REFERENCE_BASE
+#include "DCSDecoder.h"                     // the reference's own base class
+// (the class then lives in the global namespace next to ::DCSDecoder and ::DCSDecoderNative)
+#define DCSHIP_NAMESPACE_BEGIN
+#define DCSHIP_NAMESPACE_END
+#else
+#define DCSHIP_NAMESPACE_BEGIN namespace dcship {
+#define DCSHIP_NAMESPACE_END }
 namespace dcship {
 
 // ---------------------------------------------------------------------------------------------------------
@@ -100,6 +117,11 @@ protected:
     int sampleCounter = 30000;
 };
 
+}   // namespace dcship
+#endif  // DCSHIP_USE_REFERENCE_BASE
+
+DCSHIP_NAMESPACE_BEGIN
+
 // ---------------------------------------------------------------------------------------------------------
 // Mirror of class DCSDecoderNative's public surface (DCSDecoderNative.h:11-129) plus the ROM-facing part of
 // DCSDecoder's (DCSDecoder.h:230-500); the sequencer runs on the host, the frame decode on the GPU
@@ -112,6 +134,7 @@ public:
 
     const char *Name() const override { return "MI355X HIP batch decoder"; }
 
+#ifndef DCSHIP_USE_REFERENCE_BASE
     // ---- ROMs (DCSDecoder.h:230-360) ------------------------------------------------------------------------
     enum class HWVersion { Unknown, Invalid, DCS93, DCS95 };                    // DCSDecoder.h:816-822
     void AddROM(int n, const uint8_t *data, size_t size);                       // DCSDecoder.cpp:26-66 (the image is copied)
@@ -127,13 +150,14 @@ public:
     std::vector<DcsTrackOp> DecompileTrackProgram(uint16_t trackNumber);        // DCSDecoder.cpp:907-1160 (no text)
     std::vector<uint32_t> ListStreams();                                        // DCSDecoder.cpp:1248-1293
     ROMPointer MakeROMPointer(uint32_t linearAddress) const;                    // DCSDecoder.cpp:68-76
+    void WriteDataPort(uint8_t data);                           // DCSDecoder.cpp:1529-1543: the WPC board's commands
+#endif
 
     // ---- playing (DCSDecoder.h:540-620, DCSDecoderNative.h:34-129) -------------------------------------------
     // DCSDecoderNative.h:34 -- no ROMs: streams come from the caller, the OS version is given
     void InitStandalone(OSVersion osVersion);
     void SetMasterVolume(int vol) override;                     // DCSDecoderNative.h:47
     void SetReportedVersionNumber(uint16_t vsn);
-    void WriteDataPort(uint8_t data);                           // DCSDecoder.cpp:1529-1543: the WPC board's commands
     void AddTrackCommand(uint16_t trackNum);                    // DCSDecoderNative.cpp:1475
     void ClearTracks();                                         // DCSDecoderNative.h:126
 
@@ -172,7 +196,9 @@ public:
 
 protected:
     bool Initialize() override;
-    void IRQ2Handler() override { }
+    // the base class queues what the host writes to the data port and calls this per queued byte from GetNextSample
+    // (DCSDecoder.cpp:1625-1626); the mirror base has no queue, its WriteDataPort goes to the sequencer directly
+    void IRQ2Handler() override;
     void MainLoop() override;
 
 private:
@@ -184,8 +210,12 @@ private:
     DcsRomSet *roms = nullptr;
     DcsSequencer *seq = nullptr;
     int deviceId;
+#ifdef DCSHIP_USE_REFERENCE_BASE
+    uint16_t outputBuffer[0x1E0] = { 0 };       // what the base's autobuffer reads (DCSDecoderNative.cpp:3203)
+#else
     HWVersion hwVersion = HWVersion::Unknown;
     uint32_t nominalVersion = 0;
+#endif
     uint16_t reportedVersion = 0x0106;
     int masterVolume = -1;                      // last SetMasterVolume before the sequencer existed
     int lookahead = 1;
@@ -196,4 +226,4 @@ private:
     std::string zipError;
 };
 
-}   // namespace dcship
+DCSHIP_NAMESPACE_END

@@ -247,4 +247,13 @@ SCRIPTS = {
     "reset-every-tick": (24, [(0, 1, 1), (5, 1, 18), (15, 1, 2)]),
     "invalid-track-type": (12, [(0, 1, 2), (4, 1, 14)]),
     "volume-and-clear": (40, [(0, 2, 0x40), (0, 1, 2), (8, 2, 0xFF), (15, 3, 0), (20, 1, 12), (30, 2, 0)]),
+    # only what a caller that holds a plain DCSDecoder* can do (DCSExplorer.cpp:457-488): data-port bytes and
+    # SetMasterVolume.  Track commands arrive as byte pairs, like from the WPC board.
+    "port-only": (140, port_cmd(0, 1) + port_cmd(3, 2) + port_cmd(10, 3) + port_cmd(10, 4) + port_cmd(12, 5) + port_cmd(30, 6)
+                  + port_cmd(40, 7) + [(50, 0, 0x7F)] + port_cmd(70, 12)
+                  + [(80, 0, 0x55), (80, 0, 0xAA), (80, 0, 0xB0), (80, 0, 0x4F)]
+                  + [(84, 0, 0x55), (84, 0, 0xAC), (84, 0, 0x90), (84, 0, 0x6F)]
+                  + [(90, 0, 0x55), (90, 0, 0xC2), (91, 0, 0x55), (91, 0, 0xC3)]
+                  + port_cmd(95, 16) + port_cmd(100, 15) + [(105, 2, 0x60)] + port_cmd(110, 17) + port_cmd(120, 0)
+                  + port_cmd(125, 9999) + [(126, 0, 0x81), (126, 0, 0x00)] + port_cmd(130, 1) + [(135, 2, 0xE0)]),
 }

@@ -1,0 +1,74 @@
+"""DCSDecoderHIP behind the reference's REAL base class.  oracle/_ref/dcs_refbase_test is the
+class compiled with -DDCSHIP_USE_REFERENCE_BASE against /root/reference/DCSDecoder/DCSDecoder.h and linked with the
+reference's own DCSDecoder.cpp (oracle/Makefile, target refbase; build container only, the binary travels).  Its driver
+takes the decoder out of the real DCSDecoder::GetRegistrationMap() and touches it through a DCSDecoder* only."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import dcsexplorer_amd as D
+import romkit
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_seq_golden as G                     # noqa: E402
+
+EXE = os.path.join(ROOT, "oracle", "_ref", "dcs_refbase_test")
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "seq_golden.json")))
+
+
+def run_driver(tmp_path, case, script):
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/dcs_refbase_test not built (needs /root/reference; `make -C oracle refbase`)")
+    n, ev = romkit.SCRIPTS[script]
+    rs = G.build(case)
+    args = []
+    for chip, image in sorted(rs.images.items()):
+        path = tmp_path / ("u%d.rom" % chip)
+        path.write_bytes(image)
+        args.append("%d=%s" % (chip, path))
+    evf = tmp_path / "events.txt"
+    evf.write_text("".join("%d %d %d\n" % e for e in sorted(ev, key=lambda x: x[0])))
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([EXE, str(G.VOLUME), str(n), str(evf), prefix] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    info = dict(l.split("=", 1) for l in open(prefix + ".info").read().splitlines() if "=" in l)
+    pcm = np.fromfile(prefix + ".pcm", dtype=np.int16).reshape(n, 240)
+    host = [[int(x) for x in l.split()] for l in open(prefix + ".host").read().splitlines()]
+    return info, pcm, host
+
+
+def test_real_base_build_fails_loudly_without_a_gpu(tmp_path):
+    """on a box without a GPU the object still comes out of the real registration map and takes the ROMs through the
+    base class, and SoftBoot ends in InitializationError with the cause named: no silent CPU path"""
+    if D.device_count() > 0:
+        pytest.skip("a GPU is present: the loud-failure path is the CPU container's")
+    info, pcm, host = run_driver(tmp_path, G.CASES[3], "port-only")
+    assert info["name"] == "MI355X HIP batch decoder"
+    assert info["post"] == "1"                                  # the base's own CheckROMs accepted the images
+    assert info["ok"] == "0" and "HIP decoder unavailable" in info["error"]
+    assert not pcm.any() and host == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", G.CASES, ids=[c[0] for c in G.CASES])
+def test_through_a_plain_base_pointer_equals_reference(tmp_path, case):
+    """ROMs in through DCSDecoder::AddROM, commands in through DCSDecoder::WriteDataPort, samples out through
+    DCSDecoder::GetNextSample: PCM hash, host bytes (with their ticks) and final state equal what the unmodified
+    DCSDecoderNative did on the same ROMs and events (tests/golden/seq_golden.json, made by ref_seq_run)"""
+    from oracle.dcs_oracle import Oracle, Reference, reference_available
+    info, pcm, host = run_driver(tmp_path, case, "port-only")
+    gold = GOLD["%s/port-only" % case[0]]
+    assert info["post"] == "1" and info["running"] == "1"
+    assert (info["ok"] == "0") == gold["fatal"]
+    assert host == gold["host_bytes"]
+    assert "%016x" % Oracle().fnv1a64(pcm) == gold["pcm_fnv1a64"]
+    if reference_available():
+        n, ev = romkit.SCRIPTS["port-only"]
+        want, hb, _ = G.ref_run(Reference(), G.build(case), G.VOLUME, n, ev)
+        bad = np.nonzero((pcm != want).any(axis=1))[0]
+        assert bad.size == 0, "first differing ticks: %s" % bad[:8]
