@@ -67,9 +67,10 @@ struct VmState
     std::deque<uint16_t> commandQueue;
     std::deque<uint8_t> dataPortQueue;
     uint8_t lastDataPortByte = 0;
-    int nDataPortBytes = 0;
-    uint16_t dataPortWord = 0, dataPortExt = 0;
-    int dataPortTimeout = 0;
+    // host-protocol receiver (portByte): the message being assembled and how long the port has been silent
+    uint8_t portMsg[4] = { 0, 0, 0, 0 };
+    int portLen = 0;
+    int portIdleTicks = 0;
     uint8_t variables[256] = { 0 };
     bool fatal = false;
     uint64_t fatalTick = 0;                 // the first tick that produced silence because of it
@@ -123,7 +124,7 @@ struct DcsSequencer : VmState
     void loadTrack(uint32_t c, DcsRomCursor p);
     void execTrack(int c);
     void mixingLevelOp(int cur, DcsRomCursor &p, int mode, bool fade);
-    void irq2(uint8_t data);
+    void portByte(uint8_t data);
     void mainLoop();
 };
 
@@ -405,55 +406,81 @@ void DcsSequencer::execTrack(int cur)       // :838-1290
     }
 }
 
-void DcsSequencer::irq2(uint8_t data)       // :3297-3437
+// ---- the host's side of the data port ----------------------------------------------------------------------
+// What the WPC board sends is a stream of MESSAGES: a 16-bit command word, high byte first, followed -- for the
+// commands that carry a parameter -- by the parameter byte and its complement.  The table names every range of command
+// words the firmware tells apart; everything it does not list (and that has bit 15 clear) is a track number.  Same
+// behaviour as DCSDecoderNative::IRQ2Handler (DCSDecoderNative.cpp:3297-3437), which walks the same protocol as a
+// four-state byte counter.
+namespace {
+enum class PortAction : uint8_t { MasterVolume, ChannelVolume, Nothing, VersionHigh, VersionLow };
+struct PortCommand
 {
-    if (dataPortTimeout >= 13)
-        nDataPortBytes = 0;
-    switch (nDataPortBytes)
-    {
-    case 0:
-        dataPortWord = static_cast<uint16_t>(data << 8);
-        nDataPortBytes = 1;
-        break;
-    case 1:
-        dataPortWord |= data;
-        nDataPortBytes = 0;
-        if ((dataPortWord >= 0x55AA && dataPortWord <= 0x55B2) || (dataPortWord >= 0x55BA && dataPortWord <= 0x55C1))
+    uint16_t first, last;       // command words [first, last]
+    uint8_t length;             // bytes of the whole message: 2, or 4 with parameter and complement
+    PortAction action;
+};
+const PortCommand kPortCommands[] = {
+    { 0x55AA, 0x55AA, 4, PortAction::MasterVolume },
+    { 0x55AB, 0x55B2, 4, PortAction::ChannelVolume },       // channels 0..7
+    { 0x55B3, 0x55B9, 2, PortAction::Nothing },
+    { 0x55BA, 0x55C1, 4, PortAction::Nothing },             // a per-channel parameter nothing audible depends on (:3400-3420)
+    { 0x55C2, 0x55C2, 2, PortAction::VersionHigh },
+    { 0x55C3, 0x55C3, 2, PortAction::VersionLow },
+    { 0x8000, 0xFFFF, 2, PortAction::Nothing },
+};
+const int kPortSilenceTicks = 13;   // a message whose next byte takes this long is forgotten (:3301-3306)
+}   // namespace
+
+void DcsSequencer::portByte(uint8_t data)
+{
+    if (portIdleTicks >= kPortSilenceTicks)
+        portLen = 0;                                        // whatever was being assembled has gone stale
+    portIdleTicks = 0;
+    portMsg[portLen++] = data;
+    if (portLen < 2)
+        return;
+    const uint16_t word = static_cast<uint16_t>((portMsg[0] << 8) | portMsg[1]);
+    const PortCommand *cmd = nullptr;
+    for (const PortCommand &c : kPortCommands)
+        if (word >= c.first && word <= c.last)
         {
-            dataPortExt = dataPortWord;
-            nDataPortBytes = 2;
+            cmd = &c;
+            break;
         }
-        else if (dataPortWord > 0x55B2 && dataPortWord < 0x55BA)
-            ;
-        else if (dataPortWord == 0x55C2 || dataPortWord == 0x55C3)
-            toHost(static_cast<uint8_t>((dataPortWord == 0x55C2 ? reportedVersion >> 8 : reportedVersion) & 0xFF));
-        else if (dataPortWord & 0x8000)
-            ;
-        else if (dataPortWord == 0x03E7 && totan)
+    if (cmd == nullptr)
+    {
+        // a track number -- except one word "Tales of the Arabian Nights" answers itself (:3345-3351)
+        portLen = 0;
+        if (word == 0x03E7 && totan)
             toHost(0x11);
         else
-            commandQueue.push_back(dataPortWord);
+            commandQueue.push_back(word);
+        return;
+    }
+    if (portLen < cmd->length)
+        return;                                             // parameter and complement still to come
+    portLen = 0;
+    const uint8_t value = portMsg[2];
+    if (cmd->length == 4 && portMsg[3] != static_cast<uint8_t>(~value))
+        return;                                             // complement does not match: the message is dropped
+    switch (cmd->action)
+    {
+    case PortAction::MasterVolume:
+        volumeMultiplier = dcs_volume_multiplier(value);
         break;
-    case 2:
-        dataPortWord = data;
-        nDataPortBytes = 3;
+    case PortAction::ChannelVolume:
+        ch[word - 0x55AB].channelVolume = value;
         break;
-    case 3:
-        if (dataPortWord == static_cast<uint16_t>(data ^ 0xFF))
-        {
-            if (dataPortExt == 0x55AA)
-                volumeMultiplier = dcs_volume_multiplier(static_cast<uint8_t>(dataPortWord));
-            else if (dataPortExt <= 0x55B2)
-            {
-                const int c = dataPortExt - 0x55AB;
-                if (c >= 0 && c < DCS_MAX_CHANNELS)
-                    ch[c].channelVolume = static_cast<uint8_t>(dataPortWord);
-            }
-        }
-        nDataPortBytes = 0;
+    case PortAction::VersionHigh:
+        toHost(static_cast<uint8_t>(reportedVersion >> 8));
+        break;
+    case PortAction::VersionLow:
+        toHost(static_cast<uint8_t>(reportedVersion & 0xFF));
+        break;
+    case PortAction::Nothing:
         break;
     }
-    dataPortTimeout = 0;
 }
 
 // one MainLoop pass minus decompress/transform: appends one job (and its sources) to the plan
@@ -585,8 +612,8 @@ void DcsSequencer::mainLoop()
             toHost(x.timer.data);
         }
     }
-    if (++dataPortTimeout > 13)
-        dataPortTimeout = 13;
+    if (portIdleTicks < kPortSilenceTicks)
+        ++portIdleTicks;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -769,7 +796,7 @@ extern "C" DcsStatus dcs_seq_plan(DcsSequencer *s, uint32_t nTicks)
         {
             s->lastDataPortByte = s->dataPortQueue.front();
             s->dataPortQueue.pop_front();
-            s->irq2(s->lastDataPortByte);
+            s->portByte(s->lastDataPortByte);
         }
         const size_t jobsBefore = s->jobs.size(), srcsBefore = s->srcs.size();
         for (int retries = 0 ; ; )
