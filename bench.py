@@ -297,6 +297,7 @@ def run_rank(args):
             first = b["first_job"]
         elif args.scale == 1:
             g = json.load(open(os.path.join(ROOT, "tests", "golden", "dcs_golden_hashes.json")))["workloads"]
+            g.update(json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_golden.json")))["workloads"])
             gold = g.get(args.workload, {}).get("stream_hashes")
             if args.workload == "mixed_16384":
                 plain = D.build_stream_batch(streams, indexer=D.index_streams)

@@ -7,6 +7,7 @@ derived from integer seeds so the GPU box regenerates byte-identical inputs.
                  80 % Type 1 sub-type 3, 10 % Type 1 sub-type 0, 10 % Type 0
   mixed_16384    configs[3]: 128 streams x 128 frames over all six unpack layouts, frames interleaved
                  so that neighbouring frames of the batch alternate formats
+  realistic_65536  (not a BASELINE config) 256 x 256 frames of streams made by the reference's own encoder
   corpus         configs[4] stand-in: `titles` synthetic titles of `streams_per_title` streams with
                  U[20, max_frames] frames each (no ROM corpus exists in the reference tree)
 """
@@ -105,6 +106,31 @@ def streams_corpus(titles=29, streams_per_title=600, max_frames=2000, seed=0x000
     return corpus_streams(corpus_manifest(titles, streams_per_title, max_frames, seed))
 
 
+ENCODER_GOLDEN = None
+
+
+def streams_realistic_65536(n_streams=256, n_frames=256):
+    """256 streams x 256 frames made by the REFERENCE'S OWN ENCODER from a deterministic signal (24 recordings: six
+    layouts x four pitch / noise variants, committed as data in tests/golden/encoder_golden.npz by
+    tests/golden/make_encoder_golden.py), each replica at its own volume and mixing level.  Real-audio band
+    statistics instead of the seeded writer's; there is no encoder for OS93a Type 1."""
+    global ENCODER_GOLDEN
+    import os
+    if ENCODER_GOLDEN is None:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        ENCODER_GOLDEN = np.load(os.path.join(root, "tests", "golden", "encoder_golden.npz"))
+    layouts = [("94-T0", D.OS94), ("94-T1s0", D.OS95), ("94-T1s3", D.OS95), ("93b-T0", D.OS93B), ("93b-T1", D.OS93B), ("93a-T0", D.OS93A)]
+    names = [("ENC-%s-v%d" % (l, v), l, o) for v in range(4) for l, o in layouts]
+    assert n_frames == 256
+    out = []
+    for k in range(n_streams):
+        name, lay, os_ = names[k % len(names)]
+        if lay.startswith("94") and (k & 1):
+            os_ = D.OS94 if os_ == D.OS95 else D.OS95       # OS94 and OS95 share the codec
+        out.append((os_, ENCODER_GOLDEN[name + "/stream"].tobytes(), 200 + (k % 56), 0x60 + (k % 16)))
+    return out
+
+
 def interleave(batch):
     """re-order the jobs of a build_stream_batch() result round-robin over the streams, remapping the
     overlap links; returns (new batch dict, perm) with new_jobs[i] = old_jobs[perm[i]]"""
@@ -141,6 +167,7 @@ WORKLOADS = {
     "dcs93_4096": streams_dcs93_4096,
     "dcs94_65536": streams_dcs94_65536,
     "mixed_16384": streams_mixed_16384,
+    "realistic_65536": streams_realistic_65536,
 }
 
 

@@ -104,6 +104,27 @@ def test_golden_vectors(gpu_ctx):
     assert n >= 31
 
 
+def test_streams_made_by_the_reference_encoder(gpu_ctx, oracle):
+    """real-audio band statistics: the 24 recordings of tests/golden/encoder_golden.npz (made by the reference's own
+    encoder) against the unmodified reference decoder's PCM, and the realistic_65536 workload built from them against
+    its committed per-stream hashes"""
+    meta = json.load(open(os.path.join(GOLD, "encoder_golden.json")))
+    arrays = np.load(os.path.join(GOLD, "encoder_golden.npz"))
+    for c in meta["cases"]:
+        s = arrays[c["name"] + "/stream"].tobytes()
+        nf = (s[0] << 8) | s[1]
+        pcm, err, _ = gpu_ctx.decode_streams([(c["os"], s, c["volume"], c["levels"][0])], extra_frames=c["frames_out"] - nf)
+        assert not err.any()
+        assert "%016x" % oracle.fnv1a64(pcm) == c["pcm_fnv1a64"], c["name"]
+        if c["name"] + "/pcm" in arrays:
+            assert_same(pcm, arrays[c["name"] + "/pcm"], c["name"])
+    streams = workloads.WORKLOADS["realistic_65536"]()
+    pcm, err, first = gpu_ctx.decode_streams(streams)
+    assert not err.any()
+    got = ["%016x" % oracle.fnv1a64(pcm[first[k]:first[k + 1]]) for k in range(len(streams))]
+    assert got == meta["workloads"]["realistic_65536"]["stream_hashes"]
+
+
 def test_interleaved_mixed_format_batch(gpu_ctx, oracle):
     """configs[3] shape at reduced size: neighbouring frames alternate among the six layouts"""
     b = workloads.build("mixed_16384", n_streams=30, n_frames=50)

@@ -61,3 +61,31 @@ def test_oracle_matches_reference_hashes_of_full_workloads(oracle, golden, wl):
         nf = (s[0] << 8) | s[1]
         got.append("%016x" % fnv1a64(oracle.decode(os_, vol, [s], [lvl], nf).tobytes()))
     assert got == want["stream_hashes"]
+
+
+@pytest.fixture(scope="module")
+def encoder_golden():
+    return (json.load(open(os.path.join(GOLD, "encoder_golden.json"))), np.load(os.path.join(GOLD, "encoder_golden.npz")))
+
+
+def test_oracle_on_streams_made_by_the_reference_encoder(oracle, encoder_golden):
+    """24 recordings made by the reference's own encoder (tests/golden/make_encoder_golden.py): the oracle's PCM equals
+    the unmodified reference decoder's -- sample for sample for the first variant, by hash for the others"""
+    meta, arrays = encoder_golden
+    assert len(meta["cases"]) == 24
+    assert sorted(set(c["name"].split("-v")[0] for c in meta["cases"])) == ["ENC-93a-T0", "ENC-93b-T0", "ENC-93b-T1", "ENC-94-T0", "ENC-94-T1s0", "ENC-94-T1s3"]
+    for c in meta["cases"]:
+        s = arrays[c["name"] + "/stream"].tobytes()
+        pcm = oracle.decode(c["os"], c["volume"], [s], c["levels"], c["frames_out"])
+        assert "%016x" % oracle.fnv1a64(pcm) == c["pcm_fnv1a64"], c["name"]
+        if c["name"] + "/pcm" in arrays:
+            assert np.array_equal(pcm, arrays[c["name"] + "/pcm"]), c["name"]
+
+
+def test_oracle_matches_reference_hashes_of_the_realistic_workload(oracle, encoder_golden):
+    meta, _ = encoder_golden
+    want = meta["workloads"]["realistic_65536"]
+    streams = workloads.WORKLOADS["realistic_65536"]()
+    assert len(streams) == want["streams"]
+    got = ["%016x" % oracle.fnv1a64(oracle.decode(os_, vol, [s], [lvl], (s[0] << 8) | s[1])) for os_, s, vol, lvl in streams]
+    assert got == want["stream_hashes"]
