@@ -146,7 +146,8 @@ struct DcsSlot                          // 32 bytes: everything the kernel needs
 // (dcsBuildPackages, dcs_plan.cpp) into one block at a fixed stride, so that a wavefront requests ALL of it at its first instruction (no load depends on
 // another load):  slots [fpw] (32 B) | descriptor heads [fpw] (first 40 bytes of DcsSrcDesc, padded to 48) |
 // stream headers [fpw] (16 B, already aligned; a 1-byte header zero-extended) | the split record of every lane [64]
-// (8 B; zero for a frame's first lane) | the image of the bit pool (runs placed, dwords in bit order).
+// (8 B; zero for a frame's first lane; the lane's first band in bits 12..15 of its state word, bit 15 of bitDelta: no
+// bands) | the image of the bit pool (runs placed, dwords in bit order).
 #ifdef __cplusplus
 static inline
 #ifdef __HIPCC__

@@ -46,7 +46,10 @@ struct Stamper
 
 constexpr uint32_t kHandoffTimeoutTicks = 400000000u;    // default bound of the wait for a tail from another chunk: 4 s (100 MHz ticks)
 constexpr int kWavesPerBlock = 4;       // wavefronts of a workgroup share one copy of the decode tables in LDS
-constexpr int kRowBytes = 528;          // 256 words + 16 bytes: 16-byte aligned rows (the transforms transpose through them
+#ifndef DCS_ROW_BYTES
+#define DCS_ROW_BYTES 528
+#endif
+constexpr int kRowBytes = DCS_ROW_BYTES; // 256 words + 16 bytes: 16-byte aligned rows (the transforms transpose through them
                                         // with 128-bit accesses), rows of neighbouring frames land on different LDS banks
 
 __host__ __device__ constexpr int poolDwords(int fpw) { return static_cast<int>(dcsPoolCapacity(fpw)); }
@@ -1636,17 +1639,29 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
                 Q.nb = (q == 0) ? nBands : 0;
             else
             {
-                // lane q takes bands [q * bpl, (q + 1) * bpl), bpl = ceil(nBands / SUB)
                 const int nb16 = min(nBands, 16);
-                const int bpl = R0 ? bplSlot : max((nb16 + SUB - 1) / SUB, 1);
-                Q.bandBase = q * bpl;
-                Q.nb = min(max(nb16 - Q.bandBase, 0), bpl);
+                if (R0)
+                {
+                    // the packer dealt the bands out (evenly for the 1993 layouts, by cost for 1994+): this lane's first
+                    // band comes with its split record, its last one is where the next lane of the frame starts
+                    const int myBase = (sp.x & 0x8000u) ? nb16 : static_cast<int>(sp.y >> 28);
+                    const int nextBase = __shfl(myBase, lane + FPW);
+                    Q.bandBase = myBase;
+                    Q.nb = max((q == SUB - 1 ? nb16 : nextBase) - myBase, 0);
+                }
+                else
+                {
+                    // lane q takes bands [q * bpl, (q + 1) * bpl), bpl = ceil(nBands / SUB)
+                    const int bpl = max((nb16 + SUB - 1) / SUB, 1);
+                    Q.bandBase = q * bpl;
+                    Q.nb = min(max(nb16 - Q.bandBase, 0), bpl);
+                }
                 if (q != 0 && Q.nb != 0)
                 {
                     if (!R0)
                         sp = reinterpret_cast<const uint2 *>(sdp)[5 + Q.bandBase - 1];
                     const uint32_t sp0 = sp.x, sp1 = sp.y;
-                    relBits = sp0 & 0xFFFFu;
+                    relBits = sp0 & 0x7FFFu;
                     Q.prv = sp0 >> 16;
                     Q.prvDelta = sp1 & 0xFFFFu;
                     const uint32_t st = sp1 >> 16;

@@ -187,15 +187,30 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
             so, hl = int(sd["streamOff"]), int(sd["hdrLen"])
             want_hdr = np.zeros(16, np.uint8); want_hdr[:hl] = np.frombuffer(blob[so + 2: so + 2 + hl], np.uint8)
             assert np.array_equal(pk[c, off_hdr + 16 * s: off_hdr + 16 * s + 16], want_hdr)
-            # split records: lane q of the frame starts at band q * bpl
+            # per-lane records: lane q's first band (bits 12..15 of the state word; bit 15 of bitDelta = no bands) with
+            # the split record of that band's start.  The lanes cover the bands contiguously, in order, bpl bands each.
             bpl = (int(slots[s, 7]) >> 8) & 0xFF
+            nb16 = min(int(sd["idx"]["nBands"]), 16)
+            bases = [0]
             for q in range(1, sub):
-                rec = pk[c, off_split + 8 * (s + q * fpw): off_split + 8 * (s + q * fpw) + 8]
-                if bpl != 0 and q * bpl < 16:
-                    want = sd["idx"]["split"][q * bpl - 1]
-                    assert np.array_equal(rec, np.frombuffer(want.tobytes(), np.uint8))
-                else:
+                rec = pk[c, off_split + 8 * (s + q * fpw): off_split + 8 * (s + q * fpw) + 8].copy()
+                if bpl == 0:
                     assert not rec.any()
+                    continue
+                r16 = rec.view("<u2")
+                if r16[0] & 0x8000:
+                    assert int(r16[0]) == 0x8000 and not rec[2:].any()
+                    bases.append(nb16)
+                    continue
+                base = int(r16[3]) >> 12
+                assert 0 < base < nb16 and base >= bases[-1]
+                r16[3] &= 0x0FFF
+                assert np.array_equal(rec, np.frombuffer(sd["idx"]["split"][base - 1].tobytes(), np.uint8))
+                bases.append(base)
+            if bpl != 0:
+                bases.append(nb16)
+                assert all(bases[i] <= bases[i + 1] for i in range(sub))
+                assert bases[:sub] == [min(q * bpl, nb16) for q in range(sub)]
             # the frame's bits, read MSB-first from the pool image at the slot's position, are the stream's
             pool_off = int(slots[s, 5]) >> 16
             bit0 = (so + 2 + hl) * 8 + int(sd["idx"]["bitOff"])
