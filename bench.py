@@ -45,6 +45,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD)
     ap.add_argument("--fpw", type=int, default=0, help="frames per wavefront override (4/8/16)")
+    ap.add_argument("--frames-per-chunk", type=int, default=0, help="diagnostic: frames a wavefront decodes (1 = one wavefront "
+                    "per frame with the lanes of the other slots idle); 0 = every slot of the kernel variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight: the K steps are dealt to this many batch objects "
@@ -254,6 +256,8 @@ def run_rank(args):
     ctx = D.Context(local_rank)
     if args.fpw:
         ctx.set_frames_per_wave(args.fpw)
+    if args.frames_per_chunk:
+        ctx.set_frames_per_chunk(args.frames_per_chunk)
     batch = ctx.batch(b["blob"], b["srcs"], b["jobs"])
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -318,7 +322,7 @@ def run_rank(args):
         # (tools/prof.sh), committed under profiles/; null when no profile of this workload exists
         traffic, traffic_note, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        plain_run = args.scale == 1 and not args.fpw and world == 1 and args.inflight == 1 and \
+        plain_run = args.scale == 1 and not args.fpw and not args.frames_per_chunk and world == 1 and args.inflight == 1 and \
             (not corpus or (args.corpus_titles, args.corpus_streams) == (29, 20))
         if os.path.exists(tpath) and plain_run:                  # (the committed counters are those of the plain workload)
             t = json.load(open(tpath))
@@ -356,7 +360,7 @@ def run_rank(args):
                        "samples_per_frame": 240, "frames_per_wave": batch.frames_per_wave, "wavefronts_per_launch": batch.num_chunks,
                        "arithmetic": "ADSP-2105 1.15 fixed point, 32-bit integer intermediates",
                        "partition": "range over streams%s, no collective" % (", balanced by frames" if corpus else ""),
-                       "scale": args.scale, "inflight": args.inflight},
+                       "scale": args.scale, "inflight": args.inflight, "frames_per_chunk": args.frames_per_chunk or "all"},
             "bit_exact": bit_exact,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,

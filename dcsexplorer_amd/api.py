@@ -102,7 +102,7 @@ EXPORTS = [
     "dcs_seq_create_standalone", "dcs_seq_load_audio_stream_mem", "dcs_seq_rewind", "dcs_seq_set_rewindable",
     "dcs_seq_tick", "dcs_seq_fatal_tick", "dcs_seq_stream_playing",
     "dcs_host_threads", "dcs_partition_streams", "dcs_decode_streams_sharded",
-    "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_set_test_hooks",
+    "dcs_ctx_set_frames_per_chunk", "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_set_test_hooks",
     "dcs_pipeline_create", "dcs_pipeline_destroy", "dcs_pipeline_submit", "dcs_pipeline_collect",
 ]
 
@@ -264,6 +264,8 @@ def load_library():
     L.dcs_index_streams_gpu.argtypes = [vp, vp, sz, vp, u32, vp, ctypes.c_uint64, vp]
     L.dcs_index_streams_gpu_time.restype = i32
     L.dcs_index_streams_gpu_time.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    L.dcs_ctx_set_frames_per_chunk.restype = i32
+    L.dcs_ctx_set_frames_per_chunk.argtypes = [vp, ctypes.c_int]
     L.dcs_batch_abi_bytes.restype = ctypes.c_uint64
     L.dcs_batch_abi_bytes.argtypes = [vp]
     L.dcs_batch_num_chunks.restype = u32
@@ -608,6 +610,9 @@ class Context:
 
     def set_frames_per_wave(self, fpw):
         _check(self.L.dcs_ctx_set_frames_per_wave(self.h, fpw), self.h)
+
+    def set_frames_per_chunk(self, frames):
+        _check(self.L.dcs_ctx_set_frames_per_chunk(self.h, frames), self.h)
 
     def set_tail_handoff(self, enable):
         _check(self.L.dcs_ctx_set_tail_handoff(self.h, int(bool(enable))), self.h)

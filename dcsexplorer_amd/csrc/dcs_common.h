@@ -222,7 +222,8 @@ struct DcsPreIndexed
 };
 DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, DcsBuiltStreams &B,
                           bool countOnly, bool sequence, const DcsPreIndexed *pre = nullptr);
-uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true);
+uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true,
+                       int framesPerChunk = 0);
 // packer: out = nChunks x dcsPkgBytes(fpw) bytes (the chunk packages described above)
 void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const DcsSrcDesc *srcs,
                       const uint8_t *blob, size_t blobLen, uint8_t *out);

@@ -32,8 +32,11 @@ static DcsSlot makeSlot(const DcsFrameJob &jb, uint32_t job, uint8_t prevSlot, u
     return sl;
 }
 
-uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff)
+uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
+                       int framesPerChunk)
 {
+    // (diagnostic: fewer frames per chunk than the kernel variant has slots, the rest of the wavefront idles)
+    const uint32_t limit = static_cast<uint32_t>(framesPerChunk >= 1 && framesPerChunk < fpw ? framesPerChunk : fpw);
     slots.clear();
     if (nJobs == 0 || fpw < 2)
         return 0;
@@ -166,7 +169,7 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
             return handoff && homeChunk[p] != 0xFFFFFFFFu && homeChunk[p] < chunk && lastLive[homeChunk[p]] == homePos[p];
         };
         uint32_t need = (link && !inChunk(prev) && !canImport(prev)) ? 2u : 1u;
-        if (used + need > static_cast<uint32_t>(fpw) || (used != 0 && !poolFits(j, prev, need == 2)))
+        if (used + need > (need == 2 && limit < 2 ? 2u : limit) || (used != 0 && !poolFits(j, prev, need == 2)))
         {
             closeChunk();
             need = (link && !canImport(prev)) ? 2u : 1u;      // nothing of the new chunk exists yet
@@ -204,7 +207,7 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
         slotOf[j] = static_cast<uint8_t>(used++);
         homeChunk[j] = chunk;
         homePos[j] = slots.size() - 1;
-        if (used == static_cast<uint32_t>(fpw))
+        if (used >= limit)
             closeChunk();
     }
     if (used != 0)

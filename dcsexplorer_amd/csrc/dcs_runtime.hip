@@ -25,6 +25,7 @@ struct DcsCtx
     bool handoff = true;                // tails cross chunk boundaries through the hand-off buffer (else: halo re-decode)
     uint32_t handoffTimeoutTicks = dcsk::kHandoffTimeoutTicks;     // 100 MHz ticks (dcs_ctx_set_test_hooks)
     bool dropExports = false;           // test hook: no chunk publishes its tail (dcs_ctx_set_test_hooks)
+    int framesPerChunk = 0;             // diagnostic: frames a wavefront decodes (0 = as many as the kernel variant has slots)
     std::mutex cacheMutex;              // the buffer cache is shared by the pipeline's worker threads
     bool blockingWaits = false;         // host waits sleep on an interrupt instead of polling (set while a pipeline exists:
                                         // its many waiting threads must leave the cores to the ones that prepare lists)
@@ -246,6 +247,14 @@ extern "C" DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw)
     return DCS_OK;
 }
 
+extern "C" DcsStatus dcs_ctx_set_frames_per_chunk(DcsCtx *ctx, int frames)
+{
+    if (ctx == nullptr || frames < 0 || frames > 16)
+        return DCS_ERR_INVALID_ARG;
+    ctx->framesPerChunk = frames;
+    return DCS_OK;
+}
+
 extern "C" DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable)
 {
     if (ctx == nullptr)
@@ -399,7 +408,7 @@ static DcsStatus createBatch(DcsCtx *ctx,
     thread_local std::vector<DcsSlot> slots;    // (kept from batch to batch: see the pipeline's scratch)
     uint8_t *hPackages = nullptr;           // pinned staging for the chunk packages
     size_t pkgBytes = 0;
-    b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff);
+    b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk);
     if (ctx->dropExports)
         for (DcsSlot &sl : slots)
             sl.flags &= static_cast<uint8_t>(~DCS_SLOT_EXPORT);      // test hook: imports without a producer

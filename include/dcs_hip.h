@@ -199,6 +199,9 @@ int       dcs_device_count(void);                  /* does not initialise the GP
 
 /* tuning: frames handled per wavefront in the kernel (4, 8 or 16); 0 = choose from batch size */
 DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw);
+/* diagnostic: frames a wavefront decodes, when fewer than the kernel variant has slots for (the lanes of the unused
+ * slots idle): 1 = one wavefront per frame.  0 (default) = every slot is used.  Same PCM at every setting. */
+DcsStatus dcs_ctx_set_frames_per_chunk(DcsCtx *ctx, int frames);
 /* tuning: how a frame gets the 16-sample tail of a predecessor that lies in another wavefront's chunk.  1 (default):
  * the wavefront that decodes the predecessor publishes the tail in a device buffer and the successor picks it up
  * after its own transform; 0: the predecessor is decoded a second time next to the successor (a "halo" slot).
