@@ -983,7 +983,7 @@ extern "C" DcsStatus dcs_ctx_clock_mhz(DcsCtx *ctx, float *mhzOut)
     hipError_t e = hipSuccess;
     for (int rep = 0 ; rep < 2 && e == hipSuccess ; ++rep)      // (the first launch only warms the chip up)
     {
-        hipLaunchKernelGGL(dcsClockKernel, dim3(blocks), dim3(256), 0, ctx->stream, d, 60000, 12345u + rep);
+        hipLaunchKernelGGL(dcsClockKernel, dim3(blocks), dim3(256), 0, ctx->stream, d, 8000, 12345u + rep);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream);

@@ -18,6 +18,10 @@ int main(int argc,char**argv){
     dcs_index_streams(refs.data(),nStreams,1,idx.data(),first.data(),infos.data()); double t4=now();
     std::vector<DcsSlot> slots; double t5=now(); uint32_t nc=dcsPlanChunks(B.jobs.data(),(uint32_t)B.jobs.size(),B.srcs.data(),8,slots,true); double t6=now();
     std::vector<uint8_t> out((size_t)nc*dcsPkgBytes(8)); double t7=now(); dcsBuildPackages(slots.data(),nc,8,B.srcs.data(),B.blob.data(),B.blob.size(),out.data()); double t8=now();
+    // the build from records that are already there (the pipeline's device-index path)
+    { DcsBuiltStreams B2; std::vector<uint64_t> off(nStreams); uint64_t o=0; for(int k=0;k<nStreams;k++){ off[k]=o; o+=(refs[k].len+3)&~size_t(3);} DcsPreIndexed pre{idx.data(), first.data(), infos.data(), off.data()};
+      double a=now(); dcsBuildStreams(refs.data(),nStreams,0,B2,false,false,&pre); double b=now(); dcsBuildStreams(refs.data(),nStreams,0,B2,false,false,&pre); double c=now();
+      printf("build from records: first %.2f ms, again into the same vectors %.2f ms\n", b-a, c-b); }
     printf("st=%d build(all)=%.2f ms  index pooled=%.2f  index 1thr=%.2f  plan=%.2f  pack=%.2f (alloc %.2f) chunks=%u threads=%d\n",st,t1-t0,t3-t2,t4-t3,t6-t5,t8-t7,t7-t6,nc,dcs_host_threads());
   }
 }
