@@ -102,7 +102,7 @@ EXPORTS = [
     "dcs_seq_create_standalone", "dcs_seq_load_audio_stream_mem", "dcs_seq_rewind", "dcs_seq_set_rewindable",
     "dcs_seq_tick", "dcs_seq_fatal_tick", "dcs_seq_stream_playing",
     "dcs_host_threads", "dcs_partition_streams", "dcs_decode_streams_sharded",
-    "dcs_ctx_set_frames_per_chunk", "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_set_test_hooks",
+    "dcs_ctx_set_frames_per_chunk", "dcs_pack_chunks_device", "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_set_test_hooks",
     "dcs_pipeline_create", "dcs_pipeline_destroy", "dcs_pipeline_submit", "dcs_pipeline_collect",
 ]
 
@@ -264,6 +264,8 @@ def load_library():
     L.dcs_index_streams_gpu.argtypes = [vp, vp, sz, vp, u32, vp, ctypes.c_uint64, vp]
     L.dcs_index_streams_gpu_time.restype = i32
     L.dcs_index_streams_gpu_time.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    L.dcs_pack_chunks_device.restype = i32
+    L.dcs_pack_chunks_device.argtypes = [vp, vp, u32, vp, u32, vp, sz, ctypes.c_int, vp, sz, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.dcs_ctx_set_frames_per_chunk.restype = i32
     L.dcs_ctx_set_frames_per_chunk.argtypes = [vp, ctypes.c_int]
     L.dcs_batch_abi_bytes.restype = ctypes.c_uint64
@@ -685,8 +687,21 @@ class Context:
     def set_test_hooks(self, handoff_timeout_us=0, drop_exports=False):
         _check(self.L.dcs_ctx_set_test_hooks(self.h, int(handoff_timeout_us), int(bool(drop_exports))), self.h)
 
-    def pipeline(self, depth=3, index_on_device=False):
-        return Pipeline(self, depth, index_on_device)
+    def pipeline(self, depth=3, index_on_device=False, pack_on_device=False):
+        return Pipeline(self, depth, index_on_device, pack_on_device)
+
+    def pack_chunks_device(self, blob, srcs, jobs, fpw):
+        """dcs_pack_chunks_device -> uint8 array [nChunks, packageBytes], assembled by the device packer"""
+        blob_a = np.frombuffer(bytes(blob), dtype=np.uint8)
+        srcs = np.ascontiguousarray(srcs, dtype=SRC_DTYPE)
+        jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+        n, pb = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        _check(self.L.dcs_pack_chunks_device(self.h, _ptr(jobs), jobs.size, _ptr(srcs), srcs.size, _ptr(blob_a), blob_a.size, fpw,
+                                             None, 0, ctypes.byref(n), ctypes.byref(pb)), self.h)
+        out = np.zeros((n.value, pb.value), dtype=np.uint8)
+        _check(self.L.dcs_pack_chunks_device(self.h, _ptr(jobs), jobs.size, _ptr(srcs), srcs.size, _ptr(blob_a), blob_a.size, fpw,
+                                             _ptr(out), out.size, ctypes.byref(n), ctypes.byref(pb)), self.h)
+        return out
 
     def index_streams_gpu(self, streams):
         """dcs_index_streams_gpu: the index pass on the GPU, one lane per stream.  Same result as
@@ -790,11 +805,12 @@ class Batch:
 class Pipeline:
     """DcsPipeline: lists of whole streams in, PCM out in submission order, `depth` lists in flight"""
 
-    def __init__(self, ctx, depth=3, index_on_device=False):
+    def __init__(self, ctx, depth=3, index_on_device=False, pack_on_device=False):
         self.ctx = ctx
         self.L = ctx.L
         h = ctypes.c_void_p()
-        _check(self.L.dcs_pipeline_create(ctx.h, depth, 1 if index_on_device else 0, ctypes.byref(h)), ctx.h)
+        flags = (1 if index_on_device else 0) | (2 if pack_on_device else 0)
+        _check(self.L.dcs_pipeline_create(ctx.h, depth, flags, ctypes.byref(h)), ctx.h)
         self.h = h
         self._keep = []                         # (refs, byte buffers) of submitted lists, oldest first
         ctx._batches.add(self)                  # closed before the context, like a batch

@@ -199,6 +199,26 @@ struct DcsKernelArgs
 };
 #define DCS_BATCH_HAS_93A_T1 1u         // some source is an OS93a Type-1 frame: workgroups stage the pair table in LDS
 
+// A source as the planner and the DEVICE packer need it when the index records stay on the device (the pipeline's
+// device path): 24 bytes instead of the 160 of DcsSrcDesc.  `record` = index of the frame's DcsFrameIndex in the
+// device-resident record array.
+struct DcsPlanSrc
+{
+    uint64_t streamOff;
+    uint32_t bitOff;
+    uint16_t nBits;
+    uint8_t  hdrLen, nBands, flags, format;
+    uint16_t mixMul;
+    uint32_t record;
+};
+// what the index kernel writes per frame next to the full record: all the host needs for planning (8 bytes)
+struct DcsFrameDigest
+{
+    uint32_t bitOff;
+    uint16_t nBits;
+    uint8_t  nBands, flags;
+};
+
 // planner: returns the number of chunks; slots is resized to nChunks * fpw
 #ifdef __cplusplus
 #include <vector>
@@ -222,8 +242,28 @@ struct DcsPreIndexed
 };
 DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, DcsBuiltStreams &B,
                           bool countOnly, bool sequence, const DcsPreIndexed *pre = nullptr);
+// The same batch description in its light form, for packing on the device: jobs as above, sources as 24-byte
+// digests (DcsPlanSrc) that name their index record by position (`recordBase` + the stream's first record + frame).
+struct DcsDigested
+{
+    const DcsFrameDigest *digest;       // stream k's frames at digest + firstRecord[k]
+    const uint64_t *firstRecord;
+    const DcsStreamInfo *infos;
+    const uint64_t *streamOff;          // stream k's offset in the uploaded blob
+    uint32_t recordBase;                // where this list's records start in the device-resident record array
+};
+struct DcsBuiltPlan
+{
+    std::vector<DcsFrameJob> jobs;
+    std::vector<DcsPlanSrc> srcs;
+    std::vector<uint32_t> firstJob;
+};
+DcsStatus dcsBuildPlanFromDigest(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, const DcsDigested &in,
+                                 DcsBuiltPlan &P);
 uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true,
                        int framesPerChunk = 0);
+uint32_t dcsPlanChunksLite(const DcsFrameJob *jobs, uint32_t nJobs, const DcsPlanSrc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true,
+                           int framesPerChunk = 0);
 // packer: out = nChunks x dcsPkgBytes(fpw) bytes (the chunk packages described above)
 void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const DcsSrcDesc *srcs,
                       const uint8_t *blob, size_t blobLen, uint8_t *out);

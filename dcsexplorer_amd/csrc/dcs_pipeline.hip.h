@@ -15,6 +15,9 @@
 //     that are waiting in ONE launch (one lane per stream; the walks are latency, so a launch takes as long for eight
 //     lists as for one), copies the records back and passes the lists on; a worker then builds, plans, packs, decodes
 //     and downloads (stage B).  The host is left with about 8 CPU-milliseconds per 65 536 frames.
+//   ... and the packer on the device too (DCS_PIPE_PACK_ON_DEVICE): the records do not come back at all.  The indexer
+//     copies back an 8-byte digest per frame (bit offset, bit count, band count, flags), the worker plans from that, and
+//     a pack kernel assembles the packages from the records and streams that are already resident.
 #pragma once
 #include <condition_variable>
 #include <deque>
@@ -45,9 +48,14 @@ struct DcsPipeline
         std::vector<DcsStreamLoc> locs;         // offsets relative to the list's blob
         std::vector<uint64_t> firstRecord, streamOff;
         uint64_t totalRec = 0;
-        void *hRec = nullptr, *hInfo = nullptr; // records and stream summaries as they come back (pinned)
-        size_t recBytes = 0, infoBytes = 0;
+        void *hRec = nullptr, *hInfo = nullptr; // records (or, packing on the device, their digests) and stream summaries
+        size_t recBytes = 0, infoBytes = 0;     //   as they come back (pinned)
         hipEvent_t uploaded = nullptr;
+        double tSubmit = 0, tTaken = 0, tQueuedForIndex = 0, tIndexStart = 0, tIndexed = 0, tStageB = 0, tDone = 0;     // (DCS_PIPE_TRACE)
+        // packing on the device: the round's record array stays resident until every list of the round has packed
+        std::shared_ptr<void> roundRecords;
+        const DcsFrameIndex *dRecords = nullptr;
+        uint32_t recordBase = 0;
     };
     typedef std::shared_ptr<Job> JobPtr;
 
@@ -63,8 +71,9 @@ struct DcsPipeline
     std::deque<JobPtr> order;                       // submitted, not yet collected (submission order)
     JobPtr held;                                    // the list whose result the caller is reading
     std::vector<std::thread> workers;
-    std::thread indexer;
-    std::vector<hipStream_t> streams;               // one per worker, and one more for the indexer
+    std::vector<std::thread> indexers;
+    int nWorkers = 0;
+    std::vector<hipStream_t> streams;               // one per worker, and one more for each indexer
     bool quit = false;
 };
 
@@ -76,6 +85,8 @@ static double nowMs()
 static void pipelineFreeIndexBuffers(DcsPipeline *p, DcsPipeline::Job *job, bool keepHostBlob)
 {
     DcsCtx *ctx = p->ctx;
+    job->roundRecords.reset();
+    job->dRecords = nullptr;
     if (job->dBlob) { cacheFree(ctx, false, job->dBlob, job->dBlobCap); job->dBlob = nullptr; }
     if (job->hRec) { cacheFree(ctx, true, job->hRec, job->recBytes); job->hRec = nullptr; }
     if (job->hInfo) { cacheFree(ctx, true, job->hInfo, job->infoBytes); job->hInfo = nullptr; }
@@ -138,7 +149,7 @@ static DcsStatus pipelineUpload(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     job->hBlobLen = blobLen;
     job->hBlobCap = ((blobLen + 3) & ~size_t(3)) + 64;          // zero tail: the walk prefetches, the packer copies whole dwords
     job->dBlobCap = job->hBlobCap;
-    job->recBytes = sizeof(DcsFrameIndex) * totalRec;
+    job->recBytes = ((p->flags & DCS_PIPE_PACK_ON_DEVICE) ? sizeof(DcsFrameDigest) : sizeof(DcsFrameIndex)) * totalRec;
     job->infoBytes = sizeof(DcsStreamInfo) * n;
     HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&job->hBlob), job->hBlobCap));
     HIPCHK(ctx, cacheAlloc(ctx, true, &job->hRec, job->recBytes));
@@ -159,12 +170,12 @@ static DcsStatus pipelineUpload(DcsPipeline *p, DcsPipeline::Job *job, hipStream
 }
 
 // the indexer: ONE launch of the index kernel over the streams of every list that is waiting
-static void pipelineIndexer(DcsPipeline *p)
+static void pipelineIndexer(DcsPipeline *p, int which)
 {
     pthread_setname_np(pthread_self(), "dcs-indexer");
     DcsCtx *ctx = p->ctx;
     (void)hipSetDevice(ctx->device);
-    const hipStream_t stream = p->streams.back();
+    const hipStream_t stream = p->streams[static_cast<size_t>(p->nWorkers + which)];
     constexpr size_t kMaxMerge = 32;
     for (;;)
     {
@@ -181,6 +192,7 @@ static void pipelineIndexer(DcsPipeline *p)
             }
         }
         const double t0 = nowMs();
+        for (const DcsPipeline::JobPtr &j : jobs) j->tIndexStart = t0;
         // stream locations with ABSOLUTE device addresses (the kernel's blob base is address 0), records in one buffer
         uint32_t nStreams = 0;
         uint64_t nRec = 0;
@@ -199,13 +211,16 @@ static void pipelineIndexer(DcsPipeline *p)
             }
             rec0 += j->totalRec;
         }
+        const bool packOnDevice = (p->flags & DCS_PIPE_PACK_ON_DEVICE) != 0;
         const size_t locBytes = sizeof(DcsStreamLoc) * nStreams, outBytes = sizeof(DcsFrameIndex) * (nRec ? nRec : 1),
-                     infoBytes = sizeof(DcsStreamInfo) * nStreams;
-        void *dLocs = nullptr, *dOut = nullptr, *dInfos = nullptr;
+                     infoBytes = sizeof(DcsStreamInfo) * nStreams, digestBytes = sizeof(DcsFrameDigest) * (nRec ? nRec : 1);
+        void *dLocs = nullptr, *dOut = nullptr, *dInfos = nullptr, *dDigest = nullptr;
         DcsStatus st = [&]() -> DcsStatus {
             HIPCHK(ctx, cacheAlloc(ctx, false, &dLocs, locBytes));
             HIPCHK(ctx, cacheAlloc(ctx, false, &dOut, outBytes));
             HIPCHK(ctx, cacheAlloc(ctx, false, &dInfos, infoBytes));
+            if (packOnDevice)
+                HIPCHK(ctx, cacheAlloc(ctx, false, &dDigest, digestBytes));
             for (const DcsPipeline::JobPtr &j : jobs)
                 HIPCHK(ctx, hipStreamWaitEvent(stream, j->uploaded, 0));
             HIPCHK(ctx, hipMemcpyAsync(dLocs, locs.data(), locBytes, hipMemcpyHostToDevice, stream));
@@ -213,13 +228,17 @@ static void pipelineIndexer(DcsPipeline *p)
             const uint32_t blocks = (nStreams + static_cast<uint32_t>(lanes) - 1) / static_cast<uint32_t>(lanes);
             hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), indexDynBytes(lanes), stream, static_cast<const uint32_t *>(nullptr),
                                ~size_t(0) / 4, static_cast<const DcsStreamLoc *>(dLocs), nStreams, lanes, ctx->dTables,
-                               static_cast<DcsFrameIndex *>(dOut), static_cast<DcsStreamInfo *>(dInfos));
+                               static_cast<DcsFrameIndex *>(dOut), static_cast<DcsStreamInfo *>(dInfos),
+                               static_cast<DcsFrameDigest *>(dDigest));
             HIPCHK(ctx, hipGetLastError());
             uint64_t r = 0;
             uint32_t s0 = 0;
             for (const DcsPipeline::JobPtr &j : jobs)
             {
-                HIPCHK(ctx, hipMemcpyAsync(j->hRec, static_cast<DcsFrameIndex *>(dOut) + r, j->recBytes, hipMemcpyDeviceToHost, stream));
+                if (packOnDevice)
+                    HIPCHK(ctx, hipMemcpyAsync(j->hRec, static_cast<DcsFrameDigest *>(dDigest) + r, j->recBytes, hipMemcpyDeviceToHost, stream));
+                else
+                    HIPCHK(ctx, hipMemcpyAsync(j->hRec, static_cast<DcsFrameIndex *>(dOut) + r, j->recBytes, hipMemcpyDeviceToHost, stream));
                 HIPCHK(ctx, hipMemcpyAsync(j->hInfo, static_cast<DcsStreamInfo *>(dInfos) + s0, j->infoBytes, hipMemcpyDeviceToHost, stream));
                 r += j->totalRec;
                 s0 += j->nStreams;
@@ -230,8 +249,23 @@ static void pipelineIndexer(DcsPipeline *p)
         if (st != DCS_OK)
             (void)streamWait(ctx, stream);
         cacheFree(ctx, false, dLocs, locBytes);
-        cacheFree(ctx, false, dOut, outBytes);
         cacheFree(ctx, false, dInfos, infoBytes);
+        cacheFree(ctx, false, dDigest, digestBytes);
+        if (packOnDevice && st == DCS_OK)
+        {
+            // the records stay where they are until the last list of this round has run its pack kernel
+            std::shared_ptr<void> round(dOut, [ctx, outBytes](void *q) { cacheFree(ctx, false, q, outBytes); });
+            uint64_t r = 0;
+            for (const DcsPipeline::JobPtr &j : jobs)
+            {
+                j->roundRecords = round;
+                j->dRecords = static_cast<const DcsFrameIndex *>(dOut);
+                j->recordBase = static_cast<uint32_t>(r);
+                r += j->totalRec;
+            }
+        }
+        else
+            cacheFree(ctx, false, dOut, outBytes);
         const double dt = nowMs() - t0;
         {
             std::lock_guard<std::mutex> lk(p->m);
@@ -239,6 +273,7 @@ static void pipelineIndexer(DcsPipeline *p)
             {
                 j->deviceMs += dt;
                 j->status = st;
+                j->tIndexed = nowMs();
                 p->indexed.push_back(j);
             }
         }
@@ -256,6 +291,8 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     // list (fresh multi-megabyte vectors for every list cost more in page faults than everything else the host does)
     thread_local DcsBuiltStreams scratch;
     DcsBuiltStreams &built = scratch;
+    const bool packOnDevice = (p->flags & DCS_PIPE_PACK_ON_DEVICE) != 0 && job->dRecords != nullptr;
+    thread_local DcsBuiltPlan planScratch;
     if (job->hRec != nullptr)
     {
         // a stream whose frames run past its buffer reads the missing bytes as zero, which streams laid end to end
@@ -266,7 +303,13 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
         for (uint32_t k = 0 ; k < job->nStreams && fromDevice ; ++k)
             fromDevice = infos[k].nFrames != 0
                       && 2u + static_cast<size_t>(infos[k].hdrLen) + (static_cast<size_t>(infos[k].payloadBits) + 7) / 8 <= job->locs[k].len;
-        if (fromDevice)
+        if (fromDevice && packOnDevice)
+        {
+            const DcsDigested in{ static_cast<const DcsFrameDigest *>(job->hRec), job->firstRecord.data(), infos, job->streamOff.data(),
+                                  job->recordBase };
+            st = dcsBuildPlanFromDigest(job->streams, job->nStreams, job->extraFrames, in, planScratch);
+        }
+        else if (fromDevice)
         {
             const DcsPreIndexed pre{ static_cast<const DcsFrameIndex *>(job->hRec), job->firstRecord.data(), infos, job->streamOff.data() };
             st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, built, false, false, &pre);
@@ -274,8 +317,10 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     }
     if (st == DCS_OK && !fromDevice)
         st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, built, false, false);
+    const bool devicePacked = fromDevice && packOnDevice;
     job->onDevice = fromDevice;
-    job->firstJob = built.firstJob;
+    job->firstJob = devicePacked ? planScratch.firstJob : built.firstJob;
+    const size_t nJobsBuilt = devicePacked ? planScratch.jobs.size() : built.jobs.size();
     const uint8_t *blob = fromDevice ? job->hBlob : built.blob.data();
     const size_t blobLen = fromDevice ? job->hBlobLen : built.blob.size();
     double t1 = nowMs(), t2 = t1;
@@ -284,14 +329,19 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     {
         const bool handoff = p->ctx->handoff && attempt == 0;
         const DcsBuiltStreams &B = built;
-        st = createBatch(p->ctx, blob, blobLen, B.srcs.data(), static_cast<uint32_t>(B.srcs.size()),
-                         B.jobs.data(), static_cast<uint32_t>(B.jobs.size()), nullptr, 0, stream, handoff, &job->batch);
+        if (devicePacked)
+            st = createBatchOnDevice(p->ctx, planScratch.jobs.data(), static_cast<uint32_t>(planScratch.jobs.size()), planScratch.srcs.data(),
+                                     static_cast<uint32_t>(planScratch.srcs.size()), job->dRecords, static_cast<const uint8_t *>(job->dBlob),
+                                     job->hBlobLen, stream, handoff, &job->batch);
+        else
+            st = createBatch(p->ctx, blob, blobLen, B.srcs.data(), static_cast<uint32_t>(B.srcs.size()),
+                             B.jobs.data(), static_cast<uint32_t>(B.jobs.size()), nullptr, 0, stream, handoff, &job->batch);
         t2 = nowMs();
         if (st == DCS_OK) st = dcs_batch_run(job->batch, nullptr);
         if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
         bool lost = false;
         if (st == DCS_OK && handoff)
-            for (size_t j = 0 ; j < B.jobs.size() && !lost ; ++j)
+            for (size_t j = 0 ; j < nJobsBuilt && !lost ; ++j)
                 lost = (job->err[j] & DCS_FRAME_TAIL_LOST) != 0;
         if (!lost)
             break;
@@ -337,6 +387,7 @@ static void pipelineWorker(DcsPipeline *p, int id)
         if (!stageB && deviceIndex)
         {
             const double t0 = nowMs();
+            job->tTaken = t0;
             const DcsStatus st = pipelineUpload(p, job.get(), stream);
             job->hostMs += nowMs() - t0;
             if (st != DCS_OK)
@@ -347,14 +398,21 @@ static void pipelineWorker(DcsPipeline *p, int id)
             }
             {
                 std::lock_guard<std::mutex> lk(p->m);
+                job->tQueuedForIndex = nowMs();
                 p->toIndex.push_back(job);
             }
             p->indexWork.notify_one();
             continue;
         }
         DcsStatus st = job->status;             // (the indexer's)
+        job->tStageB = nowMs();
         if (st == DCS_OK)
             st = pipelineDecode(p, job.get(), stream);
+        job->tDone = nowMs();
+        if (getenv("DCS_PIPE_TRACE") && job->tIndexed != 0)
+            fprintf(stderr, "pipe life: submit->taken %.2f, upload %.2f, wait for indexer %.2f, index round %.2f, wait for worker %.2f, stage B %.2f\n",
+                    job->tTaken - job->tSubmit, job->tQueuedForIndex - job->tTaken, job->tIndexStart - job->tQueuedForIndex,
+                    job->tIndexed - job->tIndexStart, job->tStageB - job->tIndexed, job->tDone - job->tStageB);
         else
             pipelineFreeIndexBuffers(p, job.get(), false);
         pipelineFinish(p, job, st);
@@ -363,8 +421,10 @@ static void pipelineWorker(DcsPipeline *p, int id)
 
 extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags, DcsPipeline **out)
 {
-    if (ctx == nullptr || out == nullptr || depth < 1 || depth > 64 || (flags & ~DCS_PIPE_INDEX_ON_DEVICE) != 0)
+    if (ctx == nullptr || out == nullptr || depth < 1 || depth > 64 || (flags & ~(DCS_PIPE_INDEX_ON_DEVICE | DCS_PIPE_PACK_ON_DEVICE)) != 0)
         return DCS_ERR_INVALID_ARG;
+    if (flags & DCS_PIPE_PACK_ON_DEVICE)
+        flags |= DCS_PIPE_INDEX_ON_DEVICE;           // (the packer works from the records the index pass leaves on the device)
     *out = nullptr;
     DcsPipeline *p = new (std::nothrow) DcsPipeline;
     if (p == nullptr)
@@ -378,13 +438,17 @@ extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags,
     const int nWorkers = (flags & DCS_PIPE_INDEX_ON_DEVICE) ? std::min(depth, dcs_host_threads() + 4) : depth;
     int prioLeast = 0, prioGreatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest);
-    for (int i = 0 ; i < nWorkers + 1 ; ++i)
+    p->nWorkers = nWorkers;
+    // two indexers, so that one round's walk runs while the other round's lists gather and its records come back
+    const int nIndexers = (flags & DCS_PIPE_INDEX_ON_DEVICE) ? 2 : 0;
+    for (int i = 0 ; i < nWorkers + nIndexers ; ++i)
     {
         hipStream_t s = nullptr;
-        // The indexer's stream (the last one) gets the lowest priority: not for the priority, but because streams of
-        // different priorities never share a hardware queue.  Its launches run for milliseconds (a walk is serial per
-        // stream), and a worker's copies and 40-microsecond kernels must not queue up behind one.
-        const hipError_t e = i == nWorkers ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prioLeast)
+        // The indexers' streams get the lowest and the highest priority: not for the priority, but because streams of
+        // different priorities never share a hardware queue.  Their launches run for milliseconds (a walk is serial per
+        // stream, on a handful of lanes), and neither a worker's copies and 40-microsecond kernels nor the other
+        // indexer's launch must queue up behind one.
+        const hipError_t e = i >= nWorkers ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, i == nWorkers ? prioLeast : prioGreatest)
                                            : hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
         if (e != hipSuccess)
         {
@@ -399,8 +463,8 @@ extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags,
     ctx->blockingWaits = true;
     for (int i = 0 ; i < nWorkers ; ++i)
         p->workers.emplace_back(pipelineWorker, p, i);
-    if (flags & DCS_PIPE_INDEX_ON_DEVICE)
-        p->indexer = std::thread(pipelineIndexer, p);
+    for (int i = 0 ; i < nIndexers ; ++i)
+        p->indexers.emplace_back(pipelineIndexer, p, i);
     *out = p;
     return DCS_OK;
 }
@@ -419,8 +483,8 @@ extern "C" void dcs_pipeline_destroy(DcsPipeline *p)
     p->indexWork.notify_all();
     for (std::thread &w : p->workers)
         w.join();
-    if (p->indexer.joinable())
-        p->indexer.join();
+    for (std::thread &t : p->indexers)
+        t.join();
     (void)hipSetDevice(p->ctx->device);
     pipelineRelease(p, p->held);
     for (DcsPipeline::JobPtr &j : p->order)
@@ -437,6 +501,7 @@ extern "C" DcsStatus dcs_pipeline_submit(DcsPipeline *p, const DcsStreamRef *str
         return DCS_ERR_INVALID_ARG;
     DcsPipeline::JobPtr job = std::make_shared<DcsPipeline::Job>();
     job->streams = streams; job->nStreams = nStreams; job->extraFrames = extraFrames;
+    job->tSubmit = nowMs();
     {
         std::unique_lock<std::mutex> lk(p->m);
         // at most `depth` lists between submit and collect (each holds device and pinned buffers)

@@ -15,25 +15,44 @@
 #include <thread>
 #include <vector>
 
+// What the planner needs to know about a source, from either form of source record: the full descriptor of the ABI, or
+// the digest the pipeline works from when the index records stay on the device (DcsPlanSrc).
+static inline uint64_t srcStreamOff(const DcsSrcDesc &s) { return s.streamOff; }
+static inline uint32_t srcHdrLen(const DcsSrcDesc &s) { return s.hdrLen; }
+static inline uint32_t srcBitOff(const DcsSrcDesc &s) { return s.idx.bitOff; }
+static inline uint32_t srcNBits(const DcsSrcDesc &s) { return s.idx.nBits; }
+static inline int srcNBands(const DcsSrcDesc &s) { return s.idx.nBands; }
+static inline uint32_t srcFlags(const DcsSrcDesc &s) { return s.idx.flags; }
+static inline uint8_t srcFormat(const DcsSrcDesc &s) { return s.format; }
+static inline uint64_t srcStreamOff(const DcsPlanSrc &s) { return s.streamOff; }
+static inline uint32_t srcHdrLen(const DcsPlanSrc &s) { return s.hdrLen; }
+static inline uint32_t srcBitOff(const DcsPlanSrc &s) { return s.bitOff; }
+static inline uint32_t srcNBits(const DcsPlanSrc &s) { return s.nBits; }
+static inline int srcNBands(const DcsPlanSrc &s) { return s.nBands; }
+static inline uint32_t srcFlags(const DcsPlanSrc &s) { return s.flags; }
+static inline uint8_t srcFormat(const DcsPlanSrc &s) { return s.format; }
+
 // the slot of one job; where its first source's bytes go in the pool is filled in by placeFrame
-static DcsSlot makeSlot(const DcsFrameJob &jb, uint32_t job, uint8_t prevSlot, uint8_t flags, const DcsSrcDesc *srcs, int fpw)
+template <class Src>
+static DcsSlot makeSlot(const DcsFrameJob &jb, uint32_t job, uint8_t prevSlot, uint8_t flags, const Src *srcs, int fpw)
 {
     DcsSlot sl{ job, prevSlot, flags, jb.nSrc, static_cast<uint8_t>(jb.volShift | (jb.xform << 4)), jb.firstSrc, jb.prev, 0, 0, 0, 0, 0, 0, 0 };
     if (srcs != nullptr && jb.nSrc != 0)
     {
-        const DcsSrcDesc &sd = srcs[jb.firstSrc];
-        sl.hdrDw = static_cast<uint32_t>((sd.streamOff + 2) >> 2);
-        sl.hdrSh = static_cast<uint8_t>((sd.streamOff + 2) & 3);
+        const Src &sd = srcs[jb.firstSrc];
+        sl.hdrDw = static_cast<uint32_t>((srcStreamOff(sd) + 2) >> 2);
+        sl.hdrSh = static_cast<uint8_t>((srcStreamOff(sd) + 2) & 3);
         const int sub = 64 / fpw;
-        const int nb16 = sd.idx.nBands < 16 ? sd.idx.nBands : 16;
+        const int nb16 = srcNBands(sd) < 16 ? srcNBands(sd) : 16;
         const int bpl = (nb16 + sub - 1) / sub;
-        sl.bpl = (sd.idx.flags & DCS_IDX_SERIAL) ? 0 : static_cast<uint8_t>(bpl < 1 ? 1 : bpl);
+        sl.bpl = (srcFlags(sd) & DCS_IDX_SERIAL) ? 0 : static_cast<uint8_t>(bpl < 1 ? 1 : bpl);
     }
     return sl;
 }
 
-uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
-                       int framesPerChunk)
+template <class Src>
+static uint32_t planChunks(const DcsFrameJob *jobs, uint32_t nJobs, const Src *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
+                           int framesPerChunk)
 {
     // (diagnostic: fewer frames per chunk than the kernel variant has slots, the rest of the wavefront idles)
     const uint32_t limit = static_cast<uint32_t>(framesPerChunk >= 1 && framesPerChunk < fpw ? framesPerChunk : fpw);
@@ -57,9 +76,9 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
     auto poolNeed = [&](uint32_t j, uint32_t r) -> uint32_t {
         if (srcs == nullptr || r >= jobs[j].nSrc)
             return 0;
-        const DcsSrcDesc &sd = srcs[jobs[j].firstSrc + r];
+        const Src &sd = srcs[jobs[j].firstSrc + r];
         // (rounded up to the 16-byte granule of the run staging)
-        return (dcsPoolDwords(sd.streamOff, sd.hdrLen, sd.idx.bitOff, sd.idx.nBits) + 3) & ~3u;
+        return (dcsPoolDwords(srcStreamOff(sd), srcHdrLen(sd), srcBitOff(sd), srcNBits(sd)) + 3) & ~3u;
     };
     auto poolFits = [&](uint32_t j, uint32_t halo, bool withHalo) {
         uint32_t rounds = jobs[j].nSrc;
@@ -85,10 +104,10 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
     auto placeFrame = [&](DcsSlot &sl, const DcsFrameJob &jb) {
         if (srcs == nullptr || jb.nSrc == 0)
             return;
-        const DcsSrcDesc &sd = srcs[jb.firstSrc];
-        const uint64_t bitPos = (sd.streamOff + 2 + sd.hdrLen) * 8 + sd.idx.bitOff;
+        const Src &sd = srcs[jb.firstSrc];
+        const uint64_t bitPos = (srcStreamOff(sd) + 2 + srcHdrLen(sd)) * 8 + srcBitOff(sd);
         const uint32_t st = static_cast<uint32_t>(bitPos >> 5);
-        const uint32_t n = dcsPoolDwords(sd.streamOff, sd.hdrLen, sd.idx.bitOff, sd.idx.nBits);
+        const uint32_t n = dcsPoolDwords(srcStreamOff(sd), srcHdrLen(sd), srcBitOff(sd), srcNBits(sd));
         if (!runs.empty() && st >= runs.back().start && st <= runs.back().start + runs.back().n)
         {
             Run &r = runs.back();
@@ -230,7 +249,7 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
         for (uint32_t j = 0 ; j < nJobs && alike ; ++j)
             for (uint32_t r = 0 ; r < jobs[j].nSrc ; ++r)
             {
-                const int f = family(srcs[jobs[j].firstSrc + r].format);
+                const int f = family(srcFormat(srcs[jobs[j].firstSrc + r]));
                 if (fam < 0) fam = f;
                 if (f != fam) { alike = false; break; }
             }
@@ -272,6 +291,18 @@ uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc
         }
     }
     return chunk;
+}
+
+uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
+                       int framesPerChunk)
+{
+    return planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk);
+}
+
+uint32_t dcsPlanChunksLite(const DcsFrameJob *jobs, uint32_t nJobs, const DcsPlanSrc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
+                           int framesPerChunk)
+{
+    return planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk);
 }
 
 extern "C" DcsStatus dcs_plan_chunks2(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, int handoff,

@@ -124,6 +124,9 @@ struct DcsBatch
     uint32_t epoch = 0;                     // launches of this batch so far
     uint32_t flags = 0;                     // DCS_BATCH_*
     size_t cap[10] = { 0 };                 // allocated bytes of the buffers above, in that order
+    // packages assembled on the device: the plan and the source digests as uploaded for the pack kernel
+    void *dPlanSlots = nullptr, *dPlanSrcs = nullptr, *hStage = nullptr;
+    size_t planSlotsCap = 0, planSrcsCap = 0, hStageCap = 0;
     // pinned host mirror of (pcm, err), filled by dcs_batch_download_view
     int16_t *hPcm = nullptr;
     uint32_t *hErr = nullptr;
@@ -296,6 +299,9 @@ extern "C" void dcs_batch_destroy(DcsBatch *b)
     void *ptrs[] = { b->dBlob, b->dSrcs, nullptr, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug, b->dHandoff, b->dPackages };
     for (int i = 0 ; i < 10 ; ++i)
         cacheFree(b->ctx, false, ptrs[i], b->cap[i]);
+    cacheFree(b->ctx, false, b->dPlanSlots, b->planSlotsCap);
+    cacheFree(b->ctx, false, b->dPlanSrcs, b->planSrcsCap);
+    cacheFree(b->ctx, true, b->hStage, b->hStageCap);
     cacheFree(b->ctx, true, b->hPcm, b->hCap[0]);
     cacheFree(b->ctx, true, b->hErr, b->hCap[1]);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -490,6 +496,250 @@ static DcsStatus createBatch(DcsCtx *ctx,
     }
     *out = b;
     return DCS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The packer on the device: the same packages dcsBuildPackages (dcs_plan.cpp) lays out on the host, assembled by one
+// wavefront per chunk from what is already resident -- the index records the device index pass left there, the streams
+// as uploaded for that pass -- and the plan the host made from an 8-byte-per-frame digest.  Byte for byte the same
+// packages (tests/test_gpu_corpus.py compares them).  The packages buffer is zeroed beforehand.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+template <int FPW>
+__global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint32_t nChunks, const DcsPlanSrc *srcs,
+                                                      const DcsFrameIndex *records, const uint8_t *blob, uint64_t blobLen,
+                                                      uint8_t *packages)
+{
+    const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = static_cast<int>(threadIdx.x & 63);
+    if (chunk >= nChunks)
+        return;
+    uint8_t *pkg = packages + static_cast<size_t>(chunk) * dcsPkgBytes(FPW);
+    const DcsSlot *cs = slots + static_cast<size_t>(chunk) * FPW;
+    // the slots, 16 bytes per lane
+    if (lane < FPW * 2)
+        reinterpret_cast<uint4 *>(pkg)[lane] = reinterpret_cast<const uint4 *>(cs)[lane];
+    // descriptor head (the first 40 bytes of what DcsSrcDesc would be) and stream header of slot `lane`
+    if (lane < FPW)
+    {
+        const DcsSlot sl = cs[lane];
+        if (!(sl.flags & DCS_SLOT_EMPTY) && sl.nSrc != 0)
+        {
+            const DcsPlanSrc sd = srcs[sl.firstSrc];
+            const uint32_t *rec = reinterpret_cast<const uint32_t *>(&records[sd.record]);
+            uint32_t *d = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffDesc(FPW) + static_cast<size_t>(lane) * 48);
+            d[0] = static_cast<uint32_t>(sd.streamOff);
+            d[1] = static_cast<uint32_t>(sd.streamOff >> 32);
+            d[2] = static_cast<uint32_t>(sd.mixMul) | (static_cast<uint32_t>(sd.format) << 16) | (static_cast<uint32_t>(sd.hdrLen) << 24);
+            for (int i = 0 ; i < 7 ; ++i)
+                d[3 + i] = rec[i];              // bitOff, nBits | hdrBits, bandType[16], preAdj | nBands | flags
+            const uint64_t hOff = sd.streamOff + 2;
+            const uint32_t hLen = sd.hdrLen == 1 ? 1u : 16u;
+            uint32_t h[4] = { 0, 0, 0, 0 };
+            for (uint32_t i = 0 ; i < hLen ; ++i)
+                if (hOff + i < blobLen)
+                    h[i >> 2] |= static_cast<uint32_t>(blob[hOff + i]) << (8 * (i & 3));
+            uint32_t *hd = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffHdr(FPW) + static_cast<size_t>(lane) * 16);
+            hd[0] = h[0]; hd[1] = h[1]; hd[2] = h[2]; hd[3] = h[3];
+        }
+    }
+    // the lane's own record: first band and split record of the frame's q-th unpack lane
+    {
+        constexpr int SUB = 64 / FPW;
+        const int sI = lane % FPW, q = lane / FPW;
+        const DcsSlot sl = cs[sI];
+        if (q >= 1 && q < SUB && !(sl.flags & DCS_SLOT_EMPTY) && sl.nSrc != 0 && sl.bpl != 0)
+        {
+            const DcsPlanSrc sd = srcs[sl.firstSrc];
+            const int nb16 = sd.nBands < 16 ? sd.nBands : 16;
+            const int base = q * sl.bpl < nb16 ? q * sl.bpl : nb16;
+            uint32_t r0 = 0x8000u, r1 = 0;      // bitDelta bit 15: no bands for this lane
+            if (base < nb16)
+            {
+                const uint32_t *sp = reinterpret_cast<const uint32_t *>(&records[sd.record].split[base - 1]);
+                r0 = sp[0];
+                r1 = (sp[1] & 0x0FFFFFFFu) | (static_cast<uint32_t>(base) << 28);
+            }
+            uint32_t *dst = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffSplit(FPW) + static_cast<size_t>(lane) * 8);
+            dst[0] = r0; dst[1] = r1;
+        }
+    }
+    // the image of the bit pool: the chunk's runs of stream dwords, in bit order
+    uint32_t *img = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffPool(FPW));
+    for (int k = 0 ; k < FPW ; ++k)
+    {
+        const uint32_t n = cs[k].runNDw, st = cs[k].runStartDw, o = cs[k].runPoolOff;
+        if (n == 0)
+            break;
+        if (o + n > dcsPoolCapacity(FPW))
+            continue;
+        for (uint32_t i = static_cast<uint32_t>(lane) ; i < n ; i += 64)
+        {
+            const uint64_t b0 = (static_cast<uint64_t>(st) + i) * 4;
+            uint32_t w = 0;
+            if (b0 + 4 <= blobLen)
+                w = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(blob + b0));
+            else
+                for (int j = 0 ; j < 4 ; ++j)
+                    if (b0 + j < blobLen)
+                        w |= static_cast<uint32_t>(blob[b0 + j]) << (24 - 8 * j);
+            img[o + i] = w;
+        }
+    }
+}
+}   // namespace
+
+// plan on the host from source digests, pack on the device: `dRecords` (the index records as the device index pass
+// wrote them) and `dBlob` (the streams as uploaded for it) must stay valid until the pack kernel has run, i.e. until the
+// batch's stream has been waited for once
+static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint32_t nJobs, const DcsPlanSrc *srcs, uint32_t nSrcs,
+                                     const DcsFrameIndex *dRecords, const uint8_t *dBlob, uint64_t blobLen,
+                                     hipStream_t stream, bool handoff, DcsBatch **out)
+{
+    *out = nullptr;
+    DcsBatch *b = new (std::nothrow) DcsBatch;
+    if (b == nullptr)
+        return DCS_ERR_NO_MEMORY;
+    b->ctx = ctx;
+    b->stream = stream ? stream : ctx->stream;
+    b->nJobs = nJobs; b->nSrcs = nSrcs;
+    bool all94 = nJobs != 0;
+    for (uint32_t j = 0 ; j < nJobs && all94 ; ++j)
+        all94 = jobs[j].xform == DCS_XFORM_94;
+    b->fpw = chooseFpw(ctx, nJobs, all94);
+    uint64_t payloadBits = 0, hdrBytes = 0, lastOff = ~0ull;
+    for (uint32_t k = 0 ; k < nSrcs ; ++k)
+    {
+        payloadBits += srcs[k].nBits;
+        if (srcs[k].format == DCS_FMT_93A_T1)
+            b->flags |= DCS_BATCH_HAS_93A_T1;
+        if (srcs[k].streamOff != lastOff)       // (a list's frames come stream by stream)
+        {
+            lastOff = srcs[k].streamOff;
+            hdrBytes += 2u + srcs[k].hdrLen;
+        }
+    }
+    const uint64_t payload = (payloadBits + 7) / 8, pcm = static_cast<uint64_t>(nJobs) * DCS_FRAME_SAMPLES * 2;
+    b->algoBytes = payload + hdrBytes + static_cast<uint64_t>(nSrcs) * 56u + pcm;
+    b->abiBytes = payload + static_cast<uint64_t>(nSrcs) * sizeof(DcsSrcDesc) + static_cast<uint64_t>(nJobs) * sizeof(DcsFrameJob) + pcm;
+
+    thread_local std::vector<DcsSlot> slots;
+    b->nChunks = dcsPlanChunksLite(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk);
+    if (ctx->dropExports)
+        for (DcsSlot &sl : slots)
+            sl.flags &= static_cast<uint8_t>(~DCS_SLOT_EXPORT);
+    const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw);
+    void *stage = nullptr;
+    size_t stageBytes = 0;
+    DcsStatus st = [&]() -> DcsStatus {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        b->planSlotsCap = sizeof(DcsSlot) * slots.size();
+        b->planSrcsCap = sizeof(DcsPlanSrc) * (nSrcs ? nSrcs : 1);
+        HIPCHK(ctx, cacheAlloc(ctx, false, &b->dPlanSlots, b->planSlotsCap));
+        HIPCHK(ctx, cacheAlloc(ctx, false, &b->dPlanSrcs, b->planSrcsCap));
+        // (through pinned staging: a copy from pageable memory holds the calling thread until the stream gets to it)
+        stageBytes = b->planSlotsCap + sizeof(DcsPlanSrc) * nSrcs;
+        HIPCHK(ctx, cacheAlloc(ctx, true, &stage, stageBytes));
+        memcpy(stage, slots.data(), b->planSlotsCap);
+        if (nSrcs)
+            memcpy(static_cast<uint8_t *>(stage) + b->planSlotsCap, srcs, sizeof(DcsPlanSrc) * nSrcs);
+        HIPCHK(ctx, hipMemcpyAsync(b->dPlanSlots, stage, b->planSlotsCap, hipMemcpyHostToDevice, b->stream));
+        if (nSrcs)
+            HIPCHK(ctx, hipMemcpyAsync(b->dPlanSrcs, static_cast<uint8_t *>(stage) + b->planSlotsCap, sizeof(DcsPlanSrc) * nSrcs, hipMemcpyHostToDevice, b->stream));
+        b->cap[9] = pkgBytes; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPackages), b->cap[9]));
+        HIPCHK(ctx, hipMemsetAsync(b->dPackages, 0, pkgBytes, b->stream));
+        const uint32_t blocks = (b->nChunks + 3) / 4;
+        const DcsSlot *dS = static_cast<const DcsSlot *>(b->dPlanSlots);
+        const DcsPlanSrc *dP = static_cast<const DcsPlanSrc *>(b->dPlanSrcs);
+        if (b->fpw == 16)
+            hipLaunchKernelGGL(dcsPackKernel<16>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+        else if (b->fpw == 8)
+            hipLaunchKernelGGL(dcsPackKernel<8>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+        else
+            hipLaunchKernelGGL(dcsPackKernel<4>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+        HIPCHK(ctx, hipGetLastError());
+        b->cap[4] = sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPcm), b->cap[4]));
+        b->cap[5] = sizeof(uint32_t) * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dErr), b->cap[5]));
+        b->cap[6] = sizeof(int16_t) * 16 * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsOut), b->cap[6]));
+        HIPCHK(ctx, hipMemsetAsync(b->dErr, 0, sizeof(uint32_t) * nJobs, b->stream));
+        b->cap[8] = sizeof(unsigned long long) * 16 * (b->nChunks + 1); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dHandoff), b->cap[8]));
+        HIPCHK(ctx, hipMemsetAsync(b->dHandoff, 0, b->cap[8], b->stream));
+        HIPCHK(ctx, hipEventCreate(&b->ev0));
+        HIPCHK(ctx, hipEventCreate(&b->ev1));
+        HIPCHK(ctx, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming | (ctx->blockingWaits ? hipEventBlockingSync : 0u)));
+        // (nothing is waited for here: the decode launch follows the pack kernel on the same stream)
+        return DCS_OK;
+    }();
+    b->hStage = stage; b->hStageCap = stageBytes;       // (in use until the uploads have run: released with the batch)
+    if (st != DCS_OK)
+    {
+        (void)streamWait(ctx, b->stream);
+        dcs_batch_destroy(b);
+        return st;
+    }
+    *out = b;
+    return DCS_OK;
+}
+
+// Diagnostic / test entry: the packages of `jobs` as the DEVICE packer lays them out (plan from source digests on the
+// host, pack kernel on the device), for comparison with dcs_pack_chunks, the host packer.  out = NULL to size.
+extern "C" DcsStatus dcs_pack_chunks_device(DcsCtx *ctx, const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, uint32_t nSrcs,
+                                            const uint8_t *blob, size_t blobLen, int fpw,
+                                            uint8_t *out, size_t cap, uint32_t *nChunksOut, uint32_t *packageBytesOut)
+{
+    if (ctx == nullptr || jobs == nullptr || srcs == nullptr || blob == nullptr || nChunksOut == nullptr || !(fpw == 4 || fpw == 8 || fpw == 16))
+        return DCS_ERR_INVALID_ARG;
+    std::vector<DcsPlanSrc> ps(nSrcs);
+    std::vector<DcsFrameIndex> recs(nSrcs);
+    for (uint32_t k = 0 ; k < nSrcs ; ++k)
+    {
+        const DcsSrcDesc &sd = srcs[k];
+        ps[k] = DcsPlanSrc{ sd.streamOff, sd.idx.bitOff, sd.idx.nBits, sd.hdrLen, sd.idx.nBands, sd.idx.flags, sd.format, sd.mixMul, k };
+        recs[k] = sd.idx;
+    }
+    std::vector<DcsSlot> slots;
+    const uint32_t nChunks = dcsPlanChunksLite(jobs, nJobs, ps.data(), fpw, slots, true, 0);
+    *nChunksOut = nChunks;
+    if (packageBytesOut != nullptr)
+        *packageBytesOut = dcsPkgBytes(fpw);
+    if (out == nullptr)
+        return DCS_OK;
+    const size_t pkgBytes = static_cast<size_t>(nChunks) * dcsPkgBytes(fpw);
+    if (cap < pkgBytes)
+        return DCS_ERR_CAPACITY;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void *dSlots = nullptr, *dPs = nullptr, *dRecs = nullptr, *dBlob = nullptr, *dPkg = nullptr;
+    const size_t blobAlloc = ((blobLen + 3) & ~size_t(3)) + 64;
+    DcsStatus st = [&]() -> DcsStatus {
+        HIPCHK(ctx, hipMalloc(&dSlots, sizeof(DcsSlot) * slots.size()));
+        HIPCHK(ctx, hipMalloc(&dPs, sizeof(DcsPlanSrc) * (nSrcs ? nSrcs : 1)));
+        HIPCHK(ctx, hipMalloc(&dRecs, sizeof(DcsFrameIndex) * (nSrcs ? nSrcs : 1)));
+        HIPCHK(ctx, hipMalloc(&dBlob, blobAlloc));
+        HIPCHK(ctx, hipMalloc(&dPkg, pkgBytes));
+        HIPCHK(ctx, hipMemsetAsync(dBlob, 0, blobAlloc, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(dPkg, 0, pkgBytes, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(dSlots, slots.data(), sizeof(DcsSlot) * slots.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(dPs, ps.data(), sizeof(DcsPlanSrc) * nSrcs, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(dRecs, recs.data(), sizeof(DcsFrameIndex) * nSrcs, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(dBlob, blob, blobLen, hipMemcpyHostToDevice, ctx->stream));
+        const uint32_t blocks = (nChunks + 3) / 4;
+        const DcsSlot *dS = static_cast<const DcsSlot *>(dSlots);
+        const DcsPlanSrc *dP = static_cast<const DcsPlanSrc *>(dPs);
+        const DcsFrameIndex *dR = static_cast<const DcsFrameIndex *>(dRecs);
+        const uint8_t *dB = static_cast<const uint8_t *>(dBlob);
+        uint8_t *dO = static_cast<uint8_t *>(dPkg);
+        if (fpw == 16)     hipLaunchKernelGGL(dcsPackKernel<16>, dim3(blocks), dim3(256), 0, ctx->stream, dS, nChunks, dP, dR, dB, blobLen, dO);
+        else if (fpw == 8) hipLaunchKernelGGL(dcsPackKernel<8>, dim3(blocks), dim3(256), 0, ctx->stream, dS, nChunks, dP, dR, dB, blobLen, dO);
+        else               hipLaunchKernelGGL(dcsPackKernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, dS, nChunks, dP, dR, dB, blobLen, dO);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(out, dPkg, pkgBytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return DCS_OK;
+    }();
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void *q : { dSlots, dPs, dRecs, dBlob, dPkg })
+        if (q) (void)hipFree(q);
+    return st;
 }
 
 extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
@@ -805,17 +1055,22 @@ struct DevBits
 struct DevSink
 {
     DcsFrameIndex *out;
+    DcsFrameDigest *digest;     // optional: what the host planner needs, 8 bytes per frame
     uint32_t cap;
     __device__ void operator()(uint32_t f, const DcsFrameIndex &fi)
     {
         if (f < cap)
+        {
             out[f] = fi;
+            if (digest != nullptr)
+                digest[f] = DcsFrameDigest{ fi.bitOff, fi.nBits, fi.nBands, fi.flags };
+        }
     }
 };
 
 __global__ __launch_bounds__(64, 6) void dcsIndexKernel(const uint32_t *blobDw, size_t nDw, const DcsStreamLoc *locs,
                                                       uint32_t nStreams, int lanes, const DcsDevTables *tables,
-                                                      DcsFrameIndex *out, DcsStreamInfo *infos)
+                                                      DcsFrameIndex *out, DcsStreamInfo *infos, DcsFrameDigest *digest)
 {
     __shared__ DcsLdsTables T;
     // working records of the walking lanes only (dynamic: with one lane per wavefront a block then needs 3.4 KB, and a CU
@@ -837,7 +1092,7 @@ __global__ __launch_bounds__(64, 6) void dcsIndexKernel(const uint32_t *blobDw, 
     const DcsStreamLoc loc = locs[k];
     DevBits reader{ blobDw, nDw, static_cast<size_t>(loc.off), static_cast<size_t>(loc.len) };
     const uint32_t nf = (reader.byteAt(0) << 8) | reader.byteAt(1);
-    DevSink sink{ out + loc.firstRecord, nf };
+    DevSink sink{ out + loc.firstRecord, digest != nullptr ? digest + loc.firstRecord : nullptr, nf };
     const DcsScanTables tabs{ &T, tables->trie94 };
     infos[k] = dcsScanStream(loc.os, reader, tabs, &mem[threadIdx.x], sink);
 }
@@ -851,7 +1106,7 @@ static hipError_t launchIndex(DcsCtx *ctx)
     const uint32_t lanes = static_cast<uint32_t>(ctx->idxLanes);
     const uint32_t blocks = (ctx->idxStreams + lanes - 1) / lanes;
     hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), indexDynBytes(ctx->idxLanes), ctx->stream, ctx->dIdxBlob, ctx->idxBlobDw, ctx->dIdxLocs,
-                       ctx->idxStreams, ctx->idxLanes, ctx->dTables, ctx->dIdxOut, ctx->dIdxInfos);
+                       ctx->idxStreams, ctx->idxLanes, ctx->dTables, ctx->dIdxOut, ctx->dIdxInfos, static_cast<DcsFrameDigest *>(nullptr));
     return hipGetLastError();
 }
 

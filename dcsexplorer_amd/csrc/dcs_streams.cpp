@@ -140,6 +140,76 @@ DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32
     return DCS_OK;
 }
 
+// dcsBuildStreams for independent streams when the index records stay on the device: same jobs, 24-byte source digests
+DcsStatus dcsBuildPlanFromDigest(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, const DcsDigested &in,
+                                 DcsBuiltPlan &P)
+{
+    uint64_t total = 0, totalSrc = 0;
+    P.firstJob.clear();
+    for (uint32_t k = 0 ; k < nStreams ; ++k)
+    {
+        const DcsStreamRef &sr = streams[k];
+        if (sr.data == nullptr || sr.len < 3 || sr.os < DCS_OS93A || sr.os > DCS_OS95)
+            return DCS_ERR_INVALID_ARG;
+        const uint32_t nFrames = (static_cast<uint32_t>(sr.data[0]) << 8) | sr.data[1];
+        if (nFrames == 0)
+            return DCS_ERR_BAD_STREAM;
+        P.firstJob.push_back(static_cast<uint32_t>(total));
+        total += nFrames + extraFrames;
+        totalSrc += nFrames;
+    }
+    P.firstJob.push_back(static_cast<uint32_t>(total));
+    if (total > 0xFFFFFFFFull)
+        return DCS_ERR_CAPACITY;
+    if (P.jobs.size() != total) P.jobs.resize(total);
+    if (P.srcs.size() != totalSrc) P.srcs.resize(totalSrc);
+    std::vector<uint16_t> mm;
+    std::vector<uint8_t> vs;
+    uint32_t nJobsOut = 0, nSrcsOut = 0;
+    for (uint32_t k = 0 ; k < nStreams ; ++k)
+    {
+        const DcsStreamRef &sr = streams[k];
+        const DcsOsVersion os = static_cast<DcsOsVersion>(sr.os);
+        const uint32_t nFrames = (static_cast<uint32_t>(sr.data[0]) << 8) | sr.data[1];
+        const DcsStreamInfo &info = in.infos[k];
+        const DcsFrameDigest *dg = in.digest + in.firstRecord[k];
+        mm.resize(nFrames); vs.resize(nFrames);
+        const DcsStatus st = dcs_stream_params_from(os, sr.volume, sr.level, sr.channelVolume, 0x7FFF, nFrames, mm.data(), vs.data());
+        if (st != DCS_OK)
+            return st;
+        const uint8_t xform = (os == DCS_OS93A || os == DCS_OS93B) ? DCS_XFORM_93 : DCS_XFORM_94;
+        const uint32_t nValid = static_cast<uint32_t>(info.nValidFrames);
+        for (uint32_t f = 0 ; f < nFrames + extraFrames ; ++f)
+        {
+            DcsFrameJob &jb = P.jobs[nJobsOut];
+            jb.firstSrc = 0; jb.flags = 0; jb.reserved = 0;
+            jb.xform = xform;
+            jb.prev = f == 0 ? DCS_PREV_NONE : nJobsOut - 1;
+            if (f < nValid)
+            {
+                DcsPlanSrc &sd = P.srcs[nSrcsOut];
+                sd.streamOff = in.streamOff[k];
+                sd.bitOff = dg[f].bitOff; sd.nBits = dg[f].nBits; sd.nBands = dg[f].nBands; sd.flags = dg[f].flags;
+                sd.hdrLen = static_cast<uint8_t>(info.hdrLen);
+                sd.format = static_cast<uint8_t>(info.format);
+                sd.mixMul = mm[f];
+                sd.record = in.recordBase + static_cast<uint32_t>(in.firstRecord[k]) + f;
+                jb.firstSrc = nSrcsOut++;
+                jb.nSrc = 1;
+                jb.volShift = vs[f];
+            }
+            else
+            {
+                jb.nSrc = 0;
+                jb.volShift = 8;
+            }
+            ++nJobsOut;
+        }
+    }
+    P.srcs.resize(nSrcsOut);
+    return DCS_OK;
+}
+
 static DcsStatus buildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, Built &B, bool countOnly,
                               bool sequence = false)
 {

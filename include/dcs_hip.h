@@ -327,8 +327,12 @@ typedef struct DcsPipelineResult
 /* flags: DCS_PIPE_INDEX_ON_DEVICE -- the index pass of every list runs on the GPU (one lane per stream, the walker of
  * dcs_index_streams_gpu) instead of on the host pool.  One list takes longer that way, many lists in flight much less:
  * the walks of different lists overlap on the GPU, and the host cores, which the index pass otherwise keeps busy most of
- * the time, are left with parameters, planner and packer.  Worth it from about 8 lists in flight.  Same PCM either way. */
+ * the time, are left with parameters, planner and packer.  Worth it from about 8 lists in flight.  Same PCM either way.
+ * DCS_PIPE_PACK_ON_DEVICE (implies the former) -- the chunk packages are assembled on the device as well, from the
+ * index records and streams that are already resident there; the host plans from an 8-byte-per-frame digest and
+ * neither receives the records nor builds or uploads packages. */
 #define DCS_PIPE_INDEX_ON_DEVICE 1u
+#define DCS_PIPE_PACK_ON_DEVICE  2u
 DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth /* 1..64 lists in flight */, uint32_t flags, DcsPipeline **out);
 void      dcs_pipeline_destroy(DcsPipeline *p);
 DcsStatus dcs_pipeline_submit(DcsPipeline *p, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames);
@@ -546,6 +550,13 @@ DcsStatus dcs_plan_chunks2(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrc
 DcsStatus dcs_pack_chunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs,
                           const uint8_t *blob, size_t blobLen, int fpw,
                           uint8_t *out, size_t cap, uint32_t *nChunksOut, uint32_t *packageBytesOut);
+
+/* Diagnostic: the same packages as the DEVICE packer assembles them (what a DCS_PIPE_PACK_ON_DEVICE pipeline does: plan on
+ * the host from 8-byte source digests, pack kernel on the device from resident records and streams).  Byte for byte what
+ * dcs_pack_chunks returns. */
+DcsStatus dcs_pack_chunks_device(DcsCtx *ctx, const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, uint32_t nSrcs,
+                                 const uint8_t *blob, size_t blobLen, int fpw,
+                                 uint8_t *out, size_t cap, uint32_t *nChunksOut, uint32_t *packageBytesOut);
 
 uint32_t dcs_abi_version(void);
 

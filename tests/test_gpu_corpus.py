@@ -74,14 +74,34 @@ def test_sharded_entry_two_contexts_one_device(oracle, corpus):
     assert "%016x" % oracle.fnv1a64(pcm[first[k]:first[k] + nf]) == g["stream_hashes"][k]
 
 
-@pytest.mark.parametrize("on_device", [False, True], ids=["host-index", "device-index"])
+@pytest.mark.parametrize("fpw", [4, 8, 16])
+def test_device_packer_lays_out_the_same_packages_as_the_host_packer(gpu_ctx, fpw):
+    """the packer on the device (DCS_PIPE_PACK_ON_DEVICE) against the host packer: byte for byte the same packages,
+    on a batch of all six layouts, damaged streams included"""
+    from util import corrupt
+    streams = []
+    for f in ALL_FORMATS:
+        for k in range(3):
+            s = make_stream(f, 37 + 5 * k, seed=61000 + 8 * f + k, profile=k)
+            if k == 2:
+                s = corrupt(s, 9 + f, nflips=3) + bytes(512)
+            streams.append((os_for(f, k), s, 240, 0x60 + k))
+    b = D.build_stream_batch(streams, extra_frames=2)
+    host = D.pack_chunks(b["blob"], b["srcs"], b["jobs"], fpw)
+    dev = gpu_ctx.pack_chunks_device(b["blob"], b["srcs"], b["jobs"], fpw)
+    assert host.shape == dev.shape
+    bad = np.argwhere(host != dev)
+    assert bad.size == 0, "first difference: chunk %d byte %d" % (bad[0][0], bad[0][1])
+
+
+@pytest.mark.parametrize("on_device", [0, 1, 2], ids=["host-index", "device-index", "device-index-and-pack"])
 def test_pipeline_returns_lists_in_order(gpu_ctx, corpus, on_device):
     """dcs_pipeline: several lists in flight come back in submission order with the PCM of dcs_decode_streams, whether
     the index pass runs on the host pool or on the device"""
     g, manifest, streams = corpus
     lists = [streams[0:40], streams[40:45], streams[45:140], streams[140:141], streams[141:200]]
     want = [gpu_ctx.decode_streams(l, extra_frames=2) for l in lists]
-    pipe = gpu_ctx.pipeline(3, index_on_device=on_device)
+    pipe = gpu_ctx.pipeline(3, index_on_device=on_device >= 1, pack_on_device=on_device == 2)
     got = []
     for k, l in enumerate(lists):
         pipe.submit(l, extra_frames=2)              # (blocks while 3 lists are in flight)
@@ -143,7 +163,8 @@ def test_batch_outlives_caller_stream_ordering(gpu_ctx, oracle):
         batch.close()                               # destroy right away: buffers are recycled only once the launch is done
 
 
-def test_pipeline_device_index_with_damaged_and_rom_sized_buffers(gpu_ctx, oracle):
+@pytest.mark.parametrize("pack_on_device", [False, True], ids=["host-pack", "device-pack"])
+def test_pipeline_device_index_with_damaged_and_rom_sized_buffers(gpu_ctx, oracle, pack_on_device):
     """device index pass: a stream handed over with a buffer far longer than the stream (the rest of a ROM image) is cut
     to what it can use; a truncated stream (runs past its buffer, the missing bytes read as zero) sends its list down
     the host path; corrupted streams keep the reference's error semantics.  PCM equals dcs_decode_streams'."""
@@ -152,7 +173,7 @@ def test_pipeline_device_index_with_damaged_and_rom_sized_buffers(gpu_ctx, oracl
     rom_sized = [(o, s + bytes(200000), v, l) for o, s, v, l in base[:3]] + base[3:]
     truncated = base[:5] + [(base[5][0], base[5][1][:len(base[5][1]) // 2], base[5][2], base[5][3])]
     damaged = [(o, corrupt(s, 77 + k, nflips=4), v, l) for k, (o, s, v, l) in enumerate(base)]
-    pipe = gpu_ctx.pipeline(3, index_on_device=True)
+    pipe = gpu_ctx.pipeline(3, index_on_device=True, pack_on_device=pack_on_device)
     for lst in (rom_sized, truncated, damaged):
         want = gpu_ctx.decode_streams(lst, extra_frames=2)
         pipe.submit(lst, extra_frames=2)

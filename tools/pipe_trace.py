@@ -6,8 +6,8 @@ from dcsexplorer_amd import workloads as W
 streams = W.streams_dcs94_65536()
 ctx = D.Context(0)
 refs, keep = D.make_refs(streams)
-depth = int(sys.argv[1]); dev = sys.argv[2] == "dev"
-pipe = ctx.pipeline(depth, index_on_device=dev)
+depth = int(sys.argv[1]); dev = sys.argv[2] in ("dev", "devpack")
+pipe = ctx.pipeline(depth, index_on_device=dev, pack_on_device=sys.argv[2] == "devpack")
 for _ in range(depth): pipe.submit_refs(refs, len(streams))
 for _ in range(depth): pipe.collect()
 n = 3 * depth
@@ -40,4 +40,4 @@ for t in glob.glob("/proc/self/task/*"):
     except Exception:
         pass
 for k, v in sorted(agg.items(), key=lambda x: -x[1][1]):
-    print("  threads %-18s n=%3d user %.2f s sys %.2f s" % (k, v[0], v[1], v[2]))
+    sys.stderr.write("  threads %-18s n=%3d user %.2f s sys %.2f s\n" % (k, v[0], v[1], v[2]))
