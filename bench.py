@@ -60,6 +60,8 @@ def parse_args(argv=None):
     ap.add_argument("--e2e-depth", type=int, default=8, help="lists in flight of end_to_end.sustained_host_index")
     ap.add_argument("--e2e-device-depth", type=int, default=32, help="lists in flight of end_to_end.sustained_device_index")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the N-rank path (gloo, no GPU, no kernel)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing on a one-GPU box: every rank decodes on GPU 0 and gloo carries the "
+                    "barrier and the max (RCCL needs one device per rank); exercises the whole N-rank path but is no scaling measurement")
     return ap.parse_args(argv)
 
 
@@ -192,8 +194,11 @@ def run_rank(args):
     rehearse = args.rehearse
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
+        if rehearse or args.share_gpu:
             dist.init_process_group(backend="gloo")
+            if args.share_gpu:
+                local_rank = 0
+                torch.cuda.set_device(0)
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -217,7 +222,7 @@ def run_rank(args):
             import inspect
             fn = workloads.WORKLOADS[args.workload]
             n = inspect.signature(fn).parameters["n_streams"].default
-            streams = fn(n_streams=n * args.scale * world)[rank * n * args.scale:(rank + 1) * n * args.scale]
+            streams = fn(n_streams=n * args.scale, first=rank * n * args.scale)
         total_frames = None
         scaling = "weak"
     b = D.build_stream_batch(streams, indexer=D.index_streams)
@@ -282,7 +287,7 @@ def run_rank(args):
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dt = sharding.max_over_ranks(dt, device="cuda")
+    dt = sharding.max_over_ranks(dt, device=None if args.share_gpu else "cuda")
 
     # kernel-only average duration by HIP events on the launch stream (roofline denominator)
     kern_ms = batch.time(max(10, args.steps), stream)
@@ -373,6 +378,7 @@ def run_rank(args):
                        "arithmetic": "ADSP-2105 1.15 fixed point, 32-bit integer intermediates",
                        "partition": "range over streams%s, no collective" % (", balanced by frames" if corpus else ""),
                        "scale": args.scale, "inflight": args.inflight, "frames_per_chunk": args.frames_per_chunk or "all"},
+            **({"share_gpu": "all ranks on GPU 0 (test of the N-rank path on a one-GPU box): not a scaling measurement"} if args.share_gpu else {}),
             "bit_exact": bit_exact,
             "bit_exact_note": bit_exact_note,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -26,9 +26,9 @@ def _splitmix(seed):
         yield z ^ (z >> 31)
 
 
-def streams_dcs93_4096(n_streams=64, n_frames=64):
+def streams_dcs93_4096(n_streams=64, n_frames=64, first=0):
     out = []
-    for k in range(n_streams):
+    for k in range(first, first + n_streams):
         strided = (k % 10) == 9
         s = D.synth_stream(D.FMT_93_T0, n_frames, seed=0x93020002 + k, nbands=12 if strided else 16,
                            stride_from=6 if strided else 16, profile=0)
@@ -36,9 +36,9 @@ def streams_dcs93_4096(n_streams=64, n_frames=64):
     return out
 
 
-def streams_dcs94_65536(n_streams=256, n_frames=256):
+def streams_dcs94_65536(n_streams=256, n_frames=256, first=0):
     out = []
-    for k in range(n_streams):
+    for k in range(first, first + n_streams):
         m = k % 10
         fmt = D.FMT_94_T0 if m == 0 else D.FMT_94_T1_S0 if m == 1 else D.FMT_94_T1_S3
         s = D.synth_stream(fmt, n_frames, seed=0x94000003 + k, nbands=16, stride_from=16 if (k % 7) else 12,
@@ -47,9 +47,9 @@ def streams_dcs94_65536(n_streams=256, n_frames=256):
     return out
 
 
-def streams_mixed_16384(n_streams=128, n_frames=128):
+def streams_mixed_16384(n_streams=128, n_frames=128, first=0):
     out = []
-    for k in range(n_streams):
+    for k in range(first, first + n_streams):
         fmt = k % 6
         os_ = D.format_os(fmt, prefer_95=bool(k & 8), prefer_93a=bool(k & 8))
         s = D.synth_stream(fmt, n_frames, seed=0x00040004 + k, nbands=18 if fmt == D.FMT_93A_T1 else 16,
@@ -109,7 +109,7 @@ def streams_corpus(titles=29, streams_per_title=600, max_frames=2000, seed=0x000
 ENCODER_GOLDEN = None
 
 
-def streams_realistic_65536(n_streams=256, n_frames=256):
+def streams_realistic_65536(n_streams=256, n_frames=256, first=0):
     """256 streams x 256 frames made by the REFERENCE'S OWN ENCODER from a deterministic signal (24 recordings: six
     layouts x four pitch / noise variants, committed as data in tests/golden/encoder_golden.npz by
     tests/golden/make_encoder_golden.py), each replica at its own volume and mixing level.  Real-audio band
@@ -123,7 +123,7 @@ def streams_realistic_65536(n_streams=256, n_frames=256):
     names = [("ENC-%s-v%d" % (l, v), l, o) for v in range(4) for l, o in layouts]
     assert n_frames == 256
     out = []
-    for k in range(n_streams):
+    for k in range(first, first + n_streams):
         name, lay, os_ = names[k % len(names)]
         if lay.startswith("94") and (k & 1):
             os_ = D.OS94 if os_ == D.OS95 else D.OS95       # OS94 and OS95 share the codec
@@ -158,9 +158,7 @@ def interleave(batch):
 def shifted(fn, stream_offset):
     """the same workload shape over a different range of the (unbounded) seeded corpus: stream k of the
     result is stream k + stream_offset of the corpus.  Used to give every rank its own range."""
-    import inspect
-    n = inspect.signature(fn).parameters["n_streams"].default
-    return fn(n_streams=n + stream_offset)[stream_offset:]
+    return fn(first=stream_offset)
 
 
 WORKLOADS = {
