@@ -180,3 +180,36 @@ def test_pipeline_device_index_with_damaged_and_rom_sized_buffers(gpu_ctx, oracl
         pcm, err, first, _, _ = pipe.collect()
         assert np.array_equal(first, want[2]) and np.array_equal(err, want[1]) and np.array_equal(pcm, want[0])
     pipe.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["host-index", "device-index", "device-index-and-pack"])
+def test_pipeline_reports_a_bad_list_and_carries_on(gpu_ctx, oracle, mode):
+    """a list with an unusable stream (zero frames) comes back with an error status in its turn; the lists around it are
+    decoded as if nothing had happened; destroying a pipeline with lists still in flight finishes them first"""
+    good = [(os_for(f, 0), make_stream(f, 30 + f, seed=71000 + f), 255, 0x64) for f in ALL_FORMATS]
+    bad = good[:2] + [(D.OS94, bytes([0, 0]) + bytes(40), 255, 0x64)] + good[2:]
+    want = gpu_ctx.decode_streams(good)
+    pipe = gpu_ctx.pipeline(4, index_on_device=mode >= 1, pack_on_device=mode == 2)
+    pipe.submit(good)
+    pipe.submit(bad)
+    pipe.submit(good)
+    pcm, err, first, _, _ = pipe.collect()
+    assert np.array_equal(pcm, want[0]) and np.array_equal(first, want[2])
+    with pytest.raises(D.DcsError) as e:
+        pipe.collect()
+    assert e.value.status == D.api.ERR_BAD_STREAM
+    pcm, err, first, _, _ = pipe.collect()
+    assert np.array_equal(pcm, want[0])
+    pipe.submit(good)                       # still in flight when the pipeline is closed
+    pipe.close()
+
+
+def test_sharded_entry_reports_errors():
+    """bad arguments and an unusable device come back as status codes, not crashes"""
+    good = [(D.OS95, make_stream(D.FMT_94_T1_S3, 20, seed=5), 255, 0x64)]
+    with pytest.raises(D.DcsError):
+        D.decode_streams_sharded([0, 99], good * 4)         # device 99 does not exist
+    with pytest.raises(D.DcsError):
+        D.decode_streams_sharded([0], [(D.OS94, bytes([0, 0, 0, 0]), 255, 0x64)])    # zero frames
+    pcm, err, first, cut = D.decode_streams_sharded([0, 0, 0, 0], good)              # more devices than streams
+    assert pcm.shape[0] == 20 and list(cut)[0] == 0 and list(cut)[-1] == 1

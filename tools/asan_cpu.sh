@@ -18,7 +18,7 @@ cp $OUT/libdcs_hip.so $ROOT/dcsexplorer_amd/libdcs_hip.so
 ASAN=$($CL -print-file-name=libclang_rt.asan-x86_64.so)
 cd $ROOT
 rc=0
-for t in tests/test_host.py tests/test_files.py tests/test_rom.py tests/test_sequencer.py tests/test_abi.py; do
+for t in tests/test_host.py tests/test_files.py tests/test_rom.py tests/test_sequencer.py tests/test_abi.py tests/test_multirank_gloo.py; do
   LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:alloc_dealloc_mismatch=0:log_path=$OUT/asanlog \
     python -m pytest $t -x -q -m "not gpu" -p no:cacheprovider > $OUT/$(basename $t).txt 2>&1 || rc=1
   echo "$t: $(tail -1 $OUT/$(basename $t).txt)"
