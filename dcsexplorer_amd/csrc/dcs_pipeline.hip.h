@@ -435,7 +435,9 @@ extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags,
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // with the index pass on the device a worker holds a list only while it works on it, so there need not be one per
     // list in flight: as many as the host has cores, and a few more for the ones that wait for a copy
-    const int nWorkers = (flags & DCS_PIPE_INDEX_ON_DEVICE) ? std::min(depth, dcs_host_threads() + 4) : depth;
+    int nWorkers = (flags & DCS_PIPE_INDEX_ON_DEVICE) ? std::min(depth, dcs_host_threads() + 4) : depth;
+    if (const char *w = getenv("DCS_PIPE_WORKERS"))
+        nWorkers = std::max(1, std::min(64, atoi(w)));
     int prioLeast = 0, prioGreatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest);
     p->nWorkers = nWorkers;
