@@ -1025,28 +1025,62 @@ struct DevBits
         q1 = rawAt(nextDw + 1);
         pos = 0; hi = 0; any = false;
     }
+    __device__ void refill()
+    {
+        win |= static_cast<uint64_t>(streamBits(nextDw, q0)) << (32 - have);
+        have += 32;
+        ++nextDw;
+        q0 = q1;
+        q1 = rawAt(nextDw + 1);
+    }
     __device__ uint32_t peek(int n)
     {
         any = true;
         const uint32_t reach = pos + static_cast<uint32_t>(n);
         hi = reach > hi ? reach : hi;
         if (have < n)
-        {
-            win |= static_cast<uint64_t>(streamBits(nextDw, q0)) << (32 - have);
-            have += 32;
-            ++nextDw;
-            q0 = q1;
-            q1 = rawAt(nextDw + 1);
-        }
-        return n == 0 ? 0u : static_cast<uint32_t>(win >> (64 - n));
+            refill();
+        // (the next n <= 32 bits are the top of the window's upper half: a 32-bit shift)
+        return n == 0 ? 0u : static_cast<uint32_t>(win >> 32) >> (32 - n);
+    }
+    // n bits of what a peek(m >= n) at this position has just looked at
+    __device__ void consume(int n)
+    {
+        win <<= n;
+        have -= n;
+        pos += static_cast<uint32_t>(n);
     }
     __device__ uint32_t get(int n)
     {
         const uint32_t r = peek(n);
-        win <<= n;
-        have -= n;
-        pos += static_cast<uint32_t>(n);
+        consume(n);
         return r;
+    }
+    // `count` fields of `width` bits whose values nobody needs: the position moves on by their total length, the byte
+    // pointer the reference would have is computed from the last field's look (see the header comment), and the window is
+    // read afresh at the new position when the run does not end inside it
+    __device__ void skipRun(int count, int width)
+    {
+        if (count <= 0 || width <= 0)
+            return;
+        any = true;
+        const uint32_t total = static_cast<uint32_t>(count) * static_cast<uint32_t>(width);
+        pos += total;
+        hi = pos > hi ? pos : hi;               // the last field's look reached exactly its own end
+        if (total <= static_cast<uint32_t>(have))
+        {
+            win = total >= 64 ? 0 : win << total;
+            have -= static_cast<int>(total);
+            return;
+        }
+        const size_t bit = (base + payOff) * 8 + pos;
+        const size_t w = bit >> 5;
+        const uint32_t skip = static_cast<uint32_t>(bit & 31);
+        win = ((static_cast<uint64_t>(streamBits(w, rawAt(w))) << 32) | streamBits(w + 1, rawAt(w + 1))) << skip;
+        have = 64 - static_cast<int>(skip);
+        nextDw = w + 2;
+        q0 = rawAt(nextDw);
+        q1 = rawAt(nextDw + 1);
     }
     __device__ uint32_t bitPos() const { return pos; }
     __device__ size_t bytesFetched() const { return any ? payOff + (hi >> 3) + 1 : payOff; }

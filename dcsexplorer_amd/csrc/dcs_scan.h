@@ -57,6 +57,19 @@ struct DcsBits
         buf <<= n;
         return r;
     }
+    // n bits of what a peek(m >= n) at this position has just looked at (that peek has pulled every byte a get(n) would)
+    DCS_HD void consume(int n)
+    {
+        nBits -= n;
+        buf <<= n;
+    }
+    // `count` fields of `width` bits whose values nobody needs: read one by one, the byte pointer must end up where the
+    // reference's does (the device reader, which computes that pointer instead of keeping it, steps over them at once)
+    DCS_HD void skipRun(int count, int width)
+    {
+        for (int i = 0 ; i < count ; ++i)
+            get(width);
+    }
     DCS_HD uint32_t bitPos() const { return static_cast<uint32_t>((p - payOff) * 8 - static_cast<size_t>(nBits)); }
 };
 
@@ -166,7 +179,7 @@ DCS_HD void dcsScan94(DcsScan<R> &s, const DcsScanTables &tabs, DcsFrameIndex &f
             for (int i = count ; i != 0 ; --i)
             {
                 const uint32_t e = book[s.b.peek(maxBits)];
-                s.b.get(static_cast<int>((e >> 8) & 0x1F));
+                s.b.consume(static_cast<int>((e >> 8) & 0x1F));     // (a code is never longer than its book's look-ahead)
                 if ((e >> 13) == 2)
                 {
                     if (i >= 2) --i;
@@ -176,8 +189,7 @@ DCS_HD void dcsScan94(DcsScan<R> &s, const DcsScanTables &tabs, DcsFrameIndex &f
         }
         else
         {
-            for (int i = 0 ; i < count ; ++i)
-                s.b.get(code);
+            s.b.skipRun(count, code);
         }
     }
 }
@@ -259,7 +271,10 @@ DCS_HD void dcsScan93(DcsScan<R> &s, const DcsScanTables &tabs, DcsFrameIndex &f
             if (width > 16) { dcsFatal(s); return; }
             // the sample values are needed only for the carried (prv, prvDelta) pair (:2565-2599)
             uint32_t last = 0, last2 = 0;
-            for (int i = 0 ; i < nSamples ; ++i)
+            // (directly coded samples: only the last two are carried on)
+            const int skipped = (subType == 0 && nSamples > 2) ? nSamples - 2 : 0;
+            s.b.skipRun(skipped, width);
+            for (int i = skipped ; i < nSamples ; ++i)
             {
                 uint32_t in = s.b.get(width);
                 if (in & (1u << (width - 1)))
@@ -342,8 +357,7 @@ DCS_HD void dcsScan93a(DcsScan<R> &s, const DcsScanTables &tabs, DcsFrameIndex &
         if (scaleCode > 0x39)
             scaleCode -= 0x36;
         prvScale = scaleCode - bandBits * 2;
-        for (int i = 0 ; i < numInputs ; ++i)
-            s.b.get(bandBits);
+        s.b.skipRun(numInputs, bandBits);
     }
 }
 
