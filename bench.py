@@ -201,7 +201,19 @@ def run_rank(args):
                 torch.cuda.set_device(0)
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                # (one collective now, so that a broken RCCL set-up shows here and not inside the timed region)
+                probe = torch.zeros(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as e:          # the data path has no collective: gloo can carry the barrier and the max
+                sys.stderr.write("bench.py: RCCL unavailable (%s); barrier and max over gloo\n" % e)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group(backend="gloo")
+                args.share_gpu = False
+                args.gloo_fallback = True
     elif not rehearse:
         torch.cuda.set_device(local_rank)
 
@@ -287,7 +299,7 @@ def run_rank(args):
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dt = sharding.max_over_ranks(dt, device=None if args.share_gpu else "cuda")
+    dt = sharding.max_over_ranks(dt, device=None if (args.share_gpu or getattr(args, "gloo_fallback", False)) else "cuda")
 
     # kernel-only average duration by HIP events on the launch stream (roofline denominator)
     kern_ms = batch.time(max(10, args.steps), stream)
