@@ -213,3 +213,26 @@ def test_sharded_entry_reports_errors():
         D.decode_streams_sharded([0], [(D.OS94, bytes([0, 0, 0, 0]), 255, 0x64)])    # zero frames
     pcm, err, first, cut = D.decode_streams_sharded([0, 0, 0, 0], good)              # more devices than streams
     assert pcm.shape[0] == 20 and list(cut)[0] == 0 and list(cut)[-1] == 1
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["host-index", "device-index", "device-index-and-pack"])
+def test_pipeline_soak(gpu_ctx, mode):
+    """a few hundred lists through 12 slots in flight: every list's PCM is checked (tools/pipe_soak.py runs the same for
+    thousands of lists and watches the memory)"""
+    import zlib
+    base = workloads.streams_mixed_16384(n_streams=24, n_frames=40)
+    variants = [base[i:] + base[:i] for i in (0, 5, 11)]
+    want = [zlib.crc32(gpu_ctx.decode_streams(v)[0].tobytes()) for v in variants]
+    refs = [D.make_refs(v) for v in variants]
+    pipe = gpu_ctx.pipeline(12, index_on_device=mode >= 1, pack_on_device=mode == 2)
+    n, done, bad = 240, 0, 0
+    for k in range(n):
+        pipe.submit_refs(refs[k % 3][0], len(variants[k % 3]))
+        if k >= 11:
+            pcm, err, _, _, _ = pipe.collect()
+            bad += zlib.crc32(pcm.tobytes()) != want[done % 3] or bool(err.any()); done += 1
+    while done < n:
+        pcm, err, _, _, _ = pipe.collect()
+        bad += zlib.crc32(pcm.tobytes()) != want[done % 3] or bool(err.any()); done += 1
+    pipe.close()
+    assert bad == 0
