@@ -238,7 +238,7 @@ struct DcsPreIndexed
     const DcsFrameIndex *records;       // stream k's records at records + firstRecord[k]
     const uint64_t *firstRecord;
     const DcsStreamInfo *infos;
-    const uint64_t *streamOff;          // stream k's offset in the caller's blob
+    const uint64_t *streamOff;          // stream k's offset in the caller's blob; NULL: the build lays the streams out itself
 };
 DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, DcsBuiltStreams &B,
                           bool countOnly, bool sequence, const DcsPreIndexed *pre = nullptr);
@@ -252,6 +252,13 @@ struct DcsDigested
     const uint64_t *streamOff;          // stream k's offset in the uploaded blob
     uint32_t recordBase;                // where this list's records start in the device-resident record array
 };
+#include <functional>
+DcsStatus dcsIndexStreamsNotify(const DcsStreamRef *streams, uint32_t nStreams, int nThreads,
+                                DcsFrameIndex *out, const uint64_t *firstRecord, DcsStreamInfo *infos,
+                                const std::function<void(uint32_t)> *done);
+// large lists through the context's own pipeline, in parts (dcs_pipeline.hip.h); *handled = false: take the direct path
+DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames,
+                                  int16_t *pcmOut, size_t pcmCapFrames, uint32_t *frameOffsets, uint32_t *errOut, bool *handled);
 struct DcsBuiltPlan
 {
     std::vector<DcsFrameJob> jobs;

@@ -192,8 +192,10 @@ extern "C" int dcs_host_threads(void)
 
 // Stream k's records go to out + firstRecord[k]; it writes at most nFrames(k) of them (the U16 prefix
 // of the stream).  nThreads 0 = dcs_host_threads(), at most 64 and at most one per stream.
-extern "C" DcsStatus dcs_index_streams(const DcsStreamRef *streams, uint32_t nStreams, int nThreads,
-                                       DcsFrameIndex *out, const uint64_t *firstRecord, DcsStreamInfo *infos)
+// `done(k)`, when given, is called (on whichever pool thread indexed it) as soon as stream k's records are complete
+DcsStatus dcsIndexStreamsNotify(const DcsStreamRef *streams, uint32_t nStreams, int nThreads,
+                                DcsFrameIndex *out, const uint64_t *firstRecord, DcsStreamInfo *infos,
+                                const std::function<void(uint32_t)> *done)
 {
     if (streams == nullptr || out == nullptr || firstRecord == nullptr || infos == nullptr)
         return DCS_ERR_INVALID_ARG;
@@ -223,6 +225,8 @@ extern "C" DcsStatus dcs_index_streams(const DcsStreamRef *streams, uint32_t nSt
             int expected = DCS_OK;
             firstError.compare_exchange_strong(expected, st);
         }
+        if (done != nullptr)
+            (*done)(k);
     };
     if (nThreads == 1)
         for (uint32_t k = 0 ; k < nStreams ; ++k)
@@ -230,4 +234,10 @@ extern "C" DcsStatus dcs_index_streams(const DcsStreamRef *streams, uint32_t nSt
     else
         IndexPool::get().run(nStreams, nThreads, one);
     return static_cast<DcsStatus>(firstError.load());
+}
+
+extern "C" DcsStatus dcs_index_streams(const DcsStreamRef *streams, uint32_t nStreams, int nThreads,
+                                       DcsFrameIndex *out, const uint64_t *firstRecord, DcsStreamInfo *infos)
+{
+    return dcsIndexStreamsNotify(streams, nStreams, nThreads, out, firstRecord, infos, nullptr);
 }

@@ -23,6 +23,7 @@
 #include <deque>
 #include <memory>
 #include <thread>
+#include <atomic>
 #include <pthread.h>
 
 struct DcsPipeline
@@ -51,6 +52,13 @@ struct DcsPipeline
         void *hRec = nullptr, *hInfo = nullptr; // records (or, packing on the device, their digests) and stream summaries
         size_t recBytes = 0, infoBytes = 0;     //   as they come back (pinned)
         hipEvent_t uploaded = nullptr;
+        // results copied into caller memory by the worker (dcs_decode_streams in parts): optional
+        int16_t *pcmDst = nullptr;
+        uint32_t *errDst = nullptr;
+        // index records the submitter already has (host memory that outlives the job): the index pass is skipped
+        const DcsFrameIndex *preRecords = nullptr;
+        const uint64_t *preFirstRecord = nullptr;
+        const DcsStreamInfo *preInfos = nullptr;
         double tSubmit = 0, tTaken = 0, tQueuedForIndex = 0, tIndexStart = 0, tIndexed = 0, tStageB = 0, tDone = 0;     // (DCS_PIPE_TRACE)
         // packing on the device: the round's record array stays resident until every list of the round has packed
         std::shared_ptr<void> roundRecords;
@@ -62,7 +70,6 @@ struct DcsPipeline
     DcsCtx *ctx = nullptr;
     int depth = 0;
     uint32_t flags = 0;                             // DCS_PIPE_*
-    bool hadBlockingWaits = false;
     std::mutex m;
     std::condition_variable work, indexWork, finished, room;
     std::deque<JobPtr> fresh;                       // submitted, not yet taken by a worker
@@ -173,6 +180,7 @@ static DcsStatus pipelineUpload(DcsPipeline *p, DcsPipeline::Job *job, hipStream
 static void pipelineIndexer(DcsPipeline *p, int which)
 {
     pthread_setname_np(pthread_self(), "dcs-indexer");
+    tlsBlockingWaits = true;
     DcsCtx *ctx = p->ctx;
     (void)hipSetDevice(ctx->device);
     const hipStream_t stream = p->streams[static_cast<size_t>(p->nWorkers + which)];
@@ -316,7 +324,15 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
         }
     }
     if (st == DCS_OK && !fromDevice)
-        st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, built, false, false);
+    {
+        if (job->preRecords != nullptr)
+        {
+            const DcsPreIndexed pre{ job->preRecords, job->preFirstRecord, job->preInfos, nullptr };
+            st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, built, false, false, &pre);
+        }
+        else
+            st = dcsBuildStreams(job->streams, job->nStreams, job->extraFrames, built, false, false);
+    }
     const bool devicePacked = fromDevice && packOnDevice;
     job->onDevice = fromDevice;
     job->firstJob = devicePacked ? planScratch.firstJob : built.firstJob;
@@ -349,6 +365,12 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
         job->batch = nullptr;
     }
     pipelineFreeIndexBuffers(p, job, false);        // (the packages are on the device: the streams are no longer needed)
+    if (st == DCS_OK && job->pcmDst != nullptr)
+    {
+        memcpy(job->pcmDst, job->pcm, sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobsBuilt);
+        if (job->errDst != nullptr)
+            memcpy(job->errDst, job->err, sizeof(uint32_t) * nJobsBuilt);
+    }
     const double t3 = nowMs();
     if (getenv("DCS_PIPE_TRACE"))
         fprintf(stderr, "pipe list: upload %.2f ms, index launch %.2f ms (records from the %s) | build %.2f create %.2f run+download %.2f\n",
@@ -362,6 +384,7 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
 static void pipelineWorker(DcsPipeline *p, int id)
 {
     pthread_setname_np(pthread_self(), "dcs-worker");
+    tlsBlockingWaits = true;
     (void)hipSetDevice(p->ctx->device);
     const hipStream_t stream = p->streams[id];
     const bool deviceIndex = (p->flags & DCS_PIPE_INDEX_ON_DEVICE) != 0;
@@ -461,8 +484,6 @@ extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags,
         }
         p->streams.push_back(s);
     }
-    p->hadBlockingWaits = ctx->blockingWaits;
-    ctx->blockingWaits = true;
     for (int i = 0 ; i < nWorkers ; ++i)
         p->workers.emplace_back(pipelineWorker, p, i);
     for (int i = 0 ; i < nIndexers ; ++i)
@@ -493,16 +514,19 @@ extern "C" void dcs_pipeline_destroy(DcsPipeline *p)
         pipelineRelease(p, j);
     for (hipStream_t s : p->streams)
         (void)hipStreamDestroy(s);
-    p->ctx->blockingWaits = p->hadBlockingWaits;
     delete p;
 }
 
-extern "C" DcsStatus dcs_pipeline_submit(DcsPipeline *p, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames)
+static DcsStatus pipelineSubmit(DcsPipeline *p, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames,
+                                int16_t *pcmDst, uint32_t *errDst, const DcsFrameIndex *preRecords = nullptr,
+                                const uint64_t *preFirstRecord = nullptr, const DcsStreamInfo *preInfos = nullptr)
 {
     if (p == nullptr || streams == nullptr || nStreams == 0)
         return DCS_ERR_INVALID_ARG;
     DcsPipeline::JobPtr job = std::make_shared<DcsPipeline::Job>();
     job->streams = streams; job->nStreams = nStreams; job->extraFrames = extraFrames;
+    job->pcmDst = pcmDst; job->errDst = errDst;
+    job->preRecords = preRecords; job->preFirstRecord = preFirstRecord; job->preInfos = preInfos;
     job->tSubmit = nowMs();
     {
         std::unique_lock<std::mutex> lk(p->m);
@@ -513,6 +537,11 @@ extern "C" DcsStatus dcs_pipeline_submit(DcsPipeline *p, const DcsStreamRef *str
     }
     p->work.notify_one();
     return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_pipeline_submit(DcsPipeline *p, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames)
+{
+    return pipelineSubmit(p, streams, nStreams, extraFrames, nullptr, nullptr);
 }
 
 extern "C" DcsStatus dcs_pipeline_collect(DcsPipeline *p, DcsPipelineResult *out)
@@ -545,4 +574,104 @@ extern "C" DcsStatus dcs_pipeline_collect(DcsPipeline *p, DcsPipelineResult *out
         out->nFrames = job->firstJob.empty() ? 0u : job->firstJob.back();
     }
     return job->status;
+}
+
+// dcs_decode_streams for a LARGE list: cut into parts (contiguous stream ranges balanced by frames) that go through a
+// pipeline the context keeps for the purpose (index pass on the host pool), so that the planner, packer and upload of
+// one part run while another part is indexed and a third decodes and comes back; every worker copies its part's PCM
+// straight into the caller's buffer.  One synchronous call for the caller, the same PCM -- 15 ms become 5 for 65 536
+// frames.  *handled = false: the list is small, the caller takes the direct path.
+DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames,
+                                  int16_t *pcmOut, size_t pcmCapFrames, uint32_t *frameOffsets, uint32_t *errOut, bool *handled)
+{
+    *handled = false;
+    constexpr uint32_t kParts = 8;
+    if (nStreams < 4 * kParts)
+        return DCS_OK;
+    std::vector<uint32_t> frames(nStreams);
+    std::vector<uint64_t> first(static_cast<size_t>(nStreams) + 1, 0);
+    for (uint32_t k = 0 ; k < nStreams ; ++k)
+    {
+        if (streams[k].data == nullptr || streams[k].len < 3)
+            return DCS_OK;                          // (the direct path reports it)
+        const uint32_t nf = (static_cast<uint32_t>(streams[k].data[0]) << 8) | streams[k].data[1];
+        if (nf == 0)
+            return DCS_OK;
+        frames[k] = nf + extraFrames;
+        first[k + 1] = first[k] + frames[k];
+    }
+    if (first[nStreams] < 32768 || first[nStreams] > pcmCapFrames || first[nStreams] > 0xFFFFFFFFull)
+        return DCS_OK;
+    if (ctx->internalPipe == nullptr)
+    {
+        const DcsStatus st = dcs_pipeline_create(ctx, static_cast<int>(kParts), 0, &ctx->internalPipe);
+        if (st != DCS_OK)
+            return DCS_OK;                          // (no pipeline: the direct path still works)
+    }
+    *handled = true;
+    uint32_t cut[kParts + 1];
+    DcsStatus st = dcs_partition_streams(frames.data(), nStreams, kParts, cut);
+    if (st != DCS_OK)
+        return st;
+    // the index pass over the WHOLE list in one region of the host pool (eight regions of 32 streams each would balance
+    // badly over the pool's threads), then the parts go to the workers with their records
+    thread_local std::vector<DcsFrameIndex> records;
+    std::vector<DcsStreamInfo> infos(nStreams);
+    std::vector<uint64_t> firstRecord(nStreams);
+    uint64_t nRec = 0;
+    for (uint32_t k = 0 ; k < nStreams ; ++k)
+    {
+        firstRecord[k] = nRec;
+        nRec += frames[k] - extraFrames;
+    }
+    if (records.size() < nRec)
+        records.resize(nRec);
+    const double tI0 = nowMs();
+    // a part goes to the workers the moment the last of its streams has been indexed (by whichever pool thread that was):
+    // planner, packer, upload and decode of the early parts run under the index pass of the late ones
+    std::atomic<uint32_t> left[kParts];
+    std::atomic<uint32_t> submitted{ 0 };
+    std::atomic<int> submitError{ DCS_OK };
+    std::vector<uint8_t> partOf(nStreams);
+    for (uint32_t r = 0 ; r < kParts ; ++r)
+    {
+        left[r].store(cut[r + 1] - cut[r]);
+        for (uint32_t k = cut[r] ; k < cut[r + 1] ; ++k)
+            partOf[k] = static_cast<uint8_t>(r);
+    }
+    DcsFrameIndex *const recs = records.data();     // (`records` is thread-local: the pool threads must not name it)
+    const std::function<void(uint32_t)> done = [&, recs](uint32_t k) {
+        const uint32_t r = partOf[k];
+        if (left[r].fetch_sub(1) != 1)
+            return;
+        const uint64_t f0 = first[cut[r]];
+        const DcsStatus s1 = pipelineSubmit(ctx->internalPipe, streams + cut[r], cut[r + 1] - cut[r], extraFrames,
+                                            pcmOut + f0 * DCS_FRAME_SAMPLES, errOut ? errOut + f0 : nullptr,
+                                            recs, firstRecord.data() + cut[r], infos.data() + cut[r]);
+        if (s1 == DCS_OK)
+            submitted.fetch_add(1);
+        else
+        {
+            int expected = DCS_OK;
+            submitError.compare_exchange_strong(expected, s1);
+        }
+    };
+    const int idxThreads = 0;        // (all of the pool: leaving a quarter of the CPUs to the workers was measured, 6.8 against 5.8 ms)
+    st = dcsIndexStreamsNotify(streams, nStreams, idxThreads, recs, firstRecord.data(), infos.data(), &done);
+    if (st == DCS_OK)
+        st = static_cast<DcsStatus>(submitError.load());
+    const double tI1 = nowMs();
+    for (uint32_t r = 0, n = submitted.load() ; r < n ; ++r)
+    {
+        DcsPipelineResult res;
+        const DcsStatus s1 = dcs_pipeline_collect(ctx->internalPipe, &res);
+        if (st == DCS_OK)
+            st = s1;
+    }
+    if (getenv("DCS_PIPE_TRACE"))
+        fprintf(stderr, "decode in parts: index %.2f ms, parts %.2f ms\n", tI1 - tI0, nowMs() - tI1);
+    if (frameOffsets != nullptr)
+        for (uint32_t k = 0 ; k <= nStreams ; ++k)
+            frameOffsets[k] = static_cast<uint32_t>(first[k]);
+    return st;
 }

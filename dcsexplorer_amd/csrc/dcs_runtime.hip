@@ -27,8 +27,7 @@ struct DcsCtx
     bool dropExports = false;           // test hook: no chunk publishes its tail (dcs_ctx_set_test_hooks)
     int framesPerChunk = 0;             // diagnostic: frames a wavefront decodes (0 = as many as the kernel variant has slots)
     std::mutex cacheMutex;              // the buffer cache is shared by the pipeline's worker threads
-    bool blockingWaits = false;         // host waits sleep on an interrupt instead of polling (set while a pipeline exists:
-                                        // its many waiting threads must leave the cores to the ones that prepare lists)
+    struct DcsPipeline *internalPipe = nullptr;     // dcs_decode_streams takes large lists through it in parts (dcs_pipeline.hip.h)
     int numCUs = 256;
     std::string lastError;
     // inputs of the last dcs_index_streams_gpu call, resident for dcs_index_streams_gpu_time
@@ -82,10 +81,14 @@ static void cacheFree(DcsCtx *ctx, bool pinned, void *p, size_t cap)
     ctx->cachedBytes += cap;
 }
 
+// Host waits of THIS thread sleep on an interrupt instead of polling: set by the pipeline's threads, of which dozens
+// wait at any time and must leave the cores to the ones that prepare lists.  Everybody else polls (shortest latency).
+static thread_local bool tlsBlockingWaits = false;
+
 // wait for everything enqueued on `stream`
 static hipError_t streamWait(DcsCtx *ctx, hipStream_t stream)
 {
-    if (!ctx->blockingWaits)
+    if (!tlsBlockingWaits)
         return hipStreamSynchronize(stream);
     thread_local hipEvent_t ev = nullptr;
     thread_local int evDevice = -1;
@@ -231,6 +234,7 @@ extern "C" void dcs_ctx_destroy(DcsCtx *ctx)
     if (ctx == nullptr)
         return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->internalPipe) dcs_pipeline_destroy(ctx->internalPipe);
     if (ctx->dTables) (void)hipFree(ctx->dTables);
     if (ctx->dIdxBlob) (void)hipFree(ctx->dIdxBlob);
     if (ctx->dIdxLocs) (void)hipFree(ctx->dIdxLocs);
@@ -482,7 +486,7 @@ static DcsStatus createBatch(DcsCtx *ctx,
 #endif
         HIPCHK(ctx, hipEventCreate(&b->ev0));
         HIPCHK(ctx, hipEventCreate(&b->ev1));
-        HIPCHK(ctx, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming | (ctx->blockingWaits ? hipEventBlockingSync : 0u)));
+        HIPCHK(ctx, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming | (tlsBlockingWaits ? hipEventBlockingSync : 0u)));
         HIPCHK(ctx, streamWait(b->ctx, b->stream));
         return DCS_OK;
     }();
@@ -666,7 +670,7 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
         HIPCHK(ctx, hipMemsetAsync(b->dHandoff, 0, b->cap[8], b->stream));
         HIPCHK(ctx, hipEventCreate(&b->ev0));
         HIPCHK(ctx, hipEventCreate(&b->ev1));
-        HIPCHK(ctx, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming | (ctx->blockingWaits ? hipEventBlockingSync : 0u)));
+        HIPCHK(ctx, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming | (tlsBlockingWaits ? hipEventBlockingSync : 0u)));
         // (nothing is waited for here: the decode launch follows the pack kernel on the same stream)
         return DCS_OK;
     }();

@@ -88,7 +88,7 @@ DcsStatus dcsBuildStreams(const DcsStreamRef *streams, uint32_t nStreams, uint32
             return st;
 
         uint64_t streamOff;
-        if (pre != nullptr)
+        if (pre != nullptr && pre->streamOff != nullptr)
             streamOff = pre->streamOff[k];
         else
         {
@@ -234,8 +234,13 @@ extern "C" DcsStatus dcs_decode_streams(DcsCtx *ctx, const DcsStreamRef *streams
 {
     if (ctx == nullptr || streams == nullptr || nStreams == 0 || pcmOut == nullptr)
         return DCS_ERR_INVALID_ARG;
+    // a large list goes through the context's pipeline in parts (host stages of one part overlap device stages of another)
+    bool handled = false;
+    DcsStatus st = dcsDecodeStreamsInParts(ctx, streams, nStreams, extraFrames, pcmOut, pcmCapFrames, frameOffsets, errOut, &handled);
+    if (handled || st != DCS_OK)
+        return st;
     Built B;
-    DcsStatus st = buildStreams(streams, nStreams, extraFrames, B, false);
+    st = buildStreams(streams, nStreams, extraFrames, B, false);
     if (st != DCS_OK)
         return st;
     if (B.jobs.size() > pcmCapFrames)

@@ -236,3 +236,21 @@ def test_pipeline_soak(gpu_ctx, mode):
         bad += zlib.crc32(pcm.tobytes()) != want[done % 3] or bool(err.any()); done += 1
     pipe.close()
     assert bad == 0
+
+
+def test_one_call_on_a_large_list_goes_through_the_pipeline_in_parts(gpu_ctx, oracle, corpus):
+    """dcs_decode_streams cuts a large list into eight parts that go through the context's own pipeline; same PCM, error
+    words and frame offsets as the one-batch path, including taper frames and a damaged stream in the middle"""
+    from util import corrupt
+    g, manifest, streams = corpus
+    streams = list(streams[:200])
+    k = 77
+    streams[k] = (streams[k][0], corrupt(streams[k][1], 3, nflips=5) + bytes(2048), streams[k][2], streams[k][3])
+    pcm, err, first = gpu_ctx.decode_streams(streams, extra_frames=2)            # > 32 768 frames: in parts
+    b = D.build_stream_batch(streams, extra_frames=2, indexer=D.index_streams)
+    want, werr = gpu_ctx.decode_batch(b["blob"], b["srcs"], b["jobs"])           # one batch, one launch
+    assert np.array_equal(first, b["first_job"])
+    assert np.array_equal(err, werr) and np.array_equal(pcm, want)
+    j = 5
+    nf = int(first[j + 1] - first[j]) - 2
+    assert "%016x" % oracle.fnv1a64(pcm[first[j]:first[j] + nf]) == g["stream_hashes"][j]
