@@ -102,7 +102,7 @@ EXPORTS = [
     "dcs_seq_create_standalone", "dcs_seq_load_audio_stream_mem", "dcs_seq_rewind", "dcs_seq_set_rewindable",
     "dcs_seq_tick", "dcs_seq_fatal_tick", "dcs_seq_stream_playing",
     "dcs_host_threads", "dcs_partition_streams", "dcs_decode_streams_sharded",
-    "dcs_ctx_set_frames_per_chunk", "dcs_pack_chunks_device", "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_set_test_hooks",
+    "dcs_ctx_set_frames_per_chunk", "dcs_index_stream_literal", "dcs_pack_chunks_device", "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_set_test_hooks",
     "dcs_pipeline_create", "dcs_pipeline_destroy", "dcs_pipeline_submit", "dcs_pipeline_collect",
 ]
 
@@ -131,6 +131,8 @@ def load_library():
     L.dcs_abi_version.restype = u32
     L.dcs_index_stream.restype = i32
     L.dcs_index_stream.argtypes = [i32, vp, sz, vp, u32, ctypes.POINTER(StreamInfo)]
+    L.dcs_index_stream_literal.restype = i32
+    L.dcs_index_stream_literal.argtypes = [i32, vp, sz, vp, u32, ctypes.POINTER(StreamInfo)]
     L.dcs_volume_multiplier.restype = ctypes.c_uint16
     L.dcs_volume_multiplier.argtypes = [ctypes.c_int]
     L.dcs_mixing_multiplier.restype = ctypes.c_uint16
@@ -307,14 +309,15 @@ def _check(st, ctx=None):
 
 
 # ---------------------------------------------------------------------------------------------- host side
-def index_stream(os_, stream):
-    """dcs_index_stream: returns (index records as INDEX_DTYPE array, StreamInfo)"""
+def index_stream(os_, stream, literal=False):
+    """dcs_index_stream (literal: dcs_index_stream_literal): returns (index records as INDEX_DTYPE array, StreamInfo)"""
     L = load_library()
     buf = np.frombuffer(bytes(stream), dtype=np.uint8)
     nframes = (int(buf[0]) << 8) | int(buf[1])
     out = np.zeros(max(nframes, 1), dtype=INDEX_DTYPE)
     info = StreamInfo()
-    st = L.dcs_index_stream(os_, _ptr(buf), buf.size, _ptr(out), nframes, ctypes.byref(info))
+    fn = L.dcs_index_stream_literal if literal else L.dcs_index_stream
+    st = fn(os_, _ptr(buf), buf.size, _ptr(out), nframes, ctypes.byref(info))
     if st != 0:
         raise DcsError(st)
     return out[:info.nValidFrames], info

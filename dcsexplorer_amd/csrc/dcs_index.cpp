@@ -6,6 +6,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <vector>
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,6 +18,97 @@ struct HostFetch
     const uint8_t *data;
     size_t len;
     uint32_t operator()(size_t i) const { return i < len ? data[i] : 0u; }
+};
+
+// The reader the host walk uses: a 64-bit window refilled four bytes at a time.  The reference reader's byte pointer
+// (what StreamInfo.nBytes reports, DcsBits in dcs_scan.h reproduces it literally) is not kept but computed, as the
+// device reader does: a Peek(n) at bit position B leaves that pointer at floor((B + n) / 8) + 1 bytes into the payload,
+// so after the walk it stands at the maximum of that over every look.  Same records and the same nBytes as DcsBits
+// (tests/test_host.py holds both against the oracle and the compiled reference), about twice as fast.
+struct WinBits
+{
+    const uint8_t *data;
+    size_t len;                 // bytes past it read as zero
+    size_t payOff = 0;
+    size_t next = 0;            // next byte to pull into the window
+    uint64_t win = 0;           // unread bits, MSB first
+    int have = 0;
+    uint32_t pos = 0;           // payload bits consumed
+    uint32_t hi = 0;            // max over looks of (pos + n)
+    bool any = false;
+
+    uint32_t byteAt(size_t i) const { return i < len ? data[i] : 0u; }
+    void setPayload(size_t off) { payOff = next = off; win = 0; have = 0; pos = 0; hi = 0; any = false; }
+    uint32_t load32(size_t i) const
+    {
+        if (i + 4 <= len)
+        {
+            uint32_t w;
+            memcpy(&w, data + i, 4);
+            return __builtin_bswap32(w);
+        }
+        return (byteAt(i) << 24) | (byteAt(i + 1) << 16) | (byteAt(i + 2) << 8) | byteAt(i + 3);
+    }
+    void refill()
+    {
+        win |= static_cast<uint64_t>(load32(next)) << (32 - have);
+        next += 4;
+        have += 32;
+    }
+    uint32_t peek(int n)
+    {
+        any = true;
+        const uint32_t reach = pos + static_cast<uint32_t>(n);
+        hi = reach > hi ? reach : hi;
+        if (have < n)
+            refill();
+        return n == 0 ? 0u : static_cast<uint32_t>(win >> 32) >> (32 - n);
+    }
+    // the next n bits without counting as a look of the reference's reader (nBytes is unaffected): for the multi-code table
+    uint32_t look(int n)
+    {
+        if (have < n)
+            refill();
+        return static_cast<uint32_t>(win >> 32) >> (32 - n);
+    }
+    void consume(int n)
+    {
+        // (after look(), which may leave fewer than n <= 32 valid bits only at the very end of the data, where zeros follow)
+        win <<= n;
+        have -= n;
+        pos += static_cast<uint32_t>(n);
+    }
+    uint32_t get(int n)
+    {
+        const uint32_t r = peek(n);
+        consume(n);
+        return r;
+    }
+    void skipRun(int count, int width)
+    {
+        if (count <= 0 || width <= 0)
+            return;
+        any = true;
+        const uint32_t total = static_cast<uint32_t>(count) * static_cast<uint32_t>(width);
+        pos += total;
+        hi = pos > hi ? pos : hi;               // the last field's look reached exactly its own end
+        if (total <= static_cast<uint32_t>(have))
+        {
+            win = total >= 64 ? 0 : win << total;
+            have -= static_cast<int>(total);
+            return;
+        }
+        const size_t bit = payOff * 8 + pos;
+        next = bit >> 3;
+        win = 0;
+        have = 0;
+        refill();
+        const int skip = static_cast<int>(bit & 7);
+        win <<= skip;
+        have -= skip;
+    }
+    uint32_t bitPos() const { return pos; }
+    size_t bytesFetched() const { return any ? payOff + (hi >> 3) + 1 : payOff; }
 };
 
 struct ArraySink
@@ -34,13 +126,42 @@ struct ArraySink
 
 }   // namespace
 
+// the multi-code table of DcsScanTables, built once from the sample codebooks
+static const uint16_t *multi94Table()
+{
+    static const std::vector<uint16_t> table = [] {
+        const DcsLdsTables &T = dcsTables().lds;
+        std::vector<uint16_t> t(static_cast<size_t>(6) << DCS_MULTI_BITS, 0);
+        for (int code = 1 ; code <= 6 ; ++code)
+        {
+            const int maxBits = T.cbInfo[code] & 0xF;
+            const uint16_t *book = T.cb94 + (T.cbInfo[code] >> 4);
+            for (uint32_t v = 0 ; v < (1u << DCS_MULTI_BITS) ; ++v)
+            {
+                int at = 0, steps = 0;
+                // a code is taken only if its whole look-ahead lies inside the DCS_MULTI_BITS bits
+                while (at + maxBits <= DCS_MULTI_BITS && steps < 200)
+                {
+                    const uint32_t idx = (v >> (DCS_MULTI_BITS - at - maxBits)) & ((1u << maxBits) - 1);
+                    const uint32_t e = book[idx];
+                    at += static_cast<int>((e >> 8) & 0x1F);
+                    steps += static_cast<int>(e >> 13) == 2 ? 2 : 1;
+                }
+                t[(static_cast<size_t>(code - 1) << DCS_MULTI_BITS) + v] = static_cast<uint16_t>(at | (steps << 8));
+            }
+        }
+        return t;
+    }();
+    return table.data();
+}
+
 extern "C" DcsStatus dcs_index_stream(DcsOsVersion os, const uint8_t *stream, size_t len,
                                       DcsFrameIndex *out, uint32_t cap, DcsStreamInfo *info)
 {
     if (stream == nullptr || len < 3 || os < DCS_OS93A || os > DCS_OS95 || (out == nullptr && cap != 0))
         return DCS_ERR_INVALID_ARG;
-    DcsBits<HostFetch> reader{ HostFetch{ stream, len } };
-    const DcsScanTables tabs{ &dcsTables().lds, dcsTables().trie94 };
+    WinBits reader{ stream, len };
+    const DcsScanTables tabs{ &dcsTables().lds, dcsTables().trie94, multi94Table() };
     ArraySink sink{ out, cap };
     DcsScanMem mem;
     const DcsStreamInfo si = dcsScanStream(static_cast<int>(os), reader, tabs, &mem, sink);
@@ -50,6 +171,26 @@ extern "C" DcsStatus dcs_index_stream(DcsOsVersion os, const uint8_t *stream, si
         return DCS_ERR_BAD_STREAM;
     if (out == nullptr && cap == 0)
         return DCS_OK;
+    return sink.overflow ? DCS_ERR_CAPACITY : DCS_OK;
+}
+
+// Diagnostic: the same walk with the reader that keeps the reference's byte pointer LITERALLY (DcsBits, dcs_scan.h:
+// Peek pulls whole bytes while nBits <= n) and without the multi-code table.  The tests hold dcs_index_stream against it:
+// same records, same nBytes.
+extern "C" DcsStatus dcs_index_stream_literal(DcsOsVersion os, const uint8_t *stream, size_t len,
+                                              DcsFrameIndex *out, uint32_t cap, DcsStreamInfo *info)
+{
+    if (stream == nullptr || len < 3 || os < DCS_OS93A || os > DCS_OS95 || (out == nullptr && cap != 0))
+        return DCS_ERR_INVALID_ARG;
+    DcsBits<HostFetch> reader{ HostFetch{ stream, len } };
+    const DcsScanTables tabs{ &dcsTables().lds, dcsTables().trie94, nullptr };
+    ArraySink sink{ out, cap };
+    DcsScanMem mem;
+    const DcsStreamInfo si = dcsScanStream(static_cast<int>(os), reader, tabs, &mem, sink);
+    if (info != nullptr)
+        *info = si;
+    if (si.nFrames == 0)
+        return DCS_ERR_BAD_STREAM;
     return sink.overflow ? DCS_ERR_CAPACITY : DCS_OK;
 }
 

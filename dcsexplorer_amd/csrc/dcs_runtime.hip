@@ -1047,6 +1047,7 @@ struct DevBits
         // (the next n <= 32 bits are the top of the window's upper half: a 32-bit shift)
         return n == 0 ? 0u : static_cast<uint32_t>(win >> 32) >> (32 - n);
     }
+    __device__ uint32_t look(int n) { if (have < n) refill(); return static_cast<uint32_t>(win >> 32) >> (32 - n); }
     // n bits of what a peek(m >= n) at this position has just looked at
     __device__ void consume(int n)
     {
@@ -1131,7 +1132,7 @@ __global__ __launch_bounds__(64, 6) void dcsIndexKernel(const uint32_t *blobDw, 
     DevBits reader{ blobDw, nDw, static_cast<size_t>(loc.off), static_cast<size_t>(loc.len) };
     const uint32_t nf = (reader.byteAt(0) << 8) | reader.byteAt(1);
     DevSink sink{ out + loc.firstRecord, digest != nullptr ? digest + loc.firstRecord : nullptr, nf };
-    const DcsScanTables tabs{ &T, tables->trie94 };
+    const DcsScanTables tabs{ &T, tables->trie94, nullptr };
     infos[k] = dcsScanStream(loc.os, reader, tabs, &mem[threadIdx.x], sink);
 }
 

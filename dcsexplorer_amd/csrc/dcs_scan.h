@@ -19,10 +19,14 @@
 #define DCS_HD
 #endif
 
+// (host only) several 1994+ sample codes per look: entry [code - 1][next DCS_MULTI_BITS bits] = total length of the
+// codes that lie entirely inside those bits, look-ahead of the last one included | sample positions they stand for << 8
+#define DCS_MULTI_BITS 14
 struct DcsScanTables
 {
     const DcsLdsTables *lds;
     const uint16_t *trie94;
+    const uint16_t *multi94 = nullptr;      // [6][1 << DCS_MULTI_BITS], or null (the device walk: no room in LDS)
 };
 
 // MSB-first reader with the reference's look-ahead policy (ROMBitPointer, DCSDecoderNative.h:229-289):
@@ -63,6 +67,9 @@ struct DcsBits
         nBits -= n;
         buf <<= n;
     }
+    // (a look that must not move the byte pointer is not something this literal reader can do: it is not used with the
+    // multi-code table)
+    DCS_HD uint32_t look(int n) { return peek(n); }
     // `count` fields of `width` bits whose values nobody needs: read one by one, the byte pointer must end up where the
     // reference's does (the device reader, which computes that pointer instead of keeping it, steps over them at once)
     DCS_HD void skipRun(int count, int width)
@@ -176,7 +183,23 @@ DCS_HD void dcsScan94(DcsScan<R> &s, const DcsScanTables &tabs, DcsFrameIndex &f
         {
             const int maxBits = T.cbInfo[code] & 0xF;
             const uint16_t *book = T.cb94 + (T.cbInfo[code] >> 4);
-            for (int i = count ; i != 0 ; --i)
+            int i = count;
+            // several codes per look while more samples remain than the look covers (so that the "two zeros with one
+            // slot left" case, and every band's last look -- the one that can decide nBytes --, stay with the loop below)
+            if (tabs.multi94 != nullptr)
+            {
+                const uint16_t *multi = tabs.multi94 + (static_cast<size_t>(code - 1) << DCS_MULTI_BITS);
+                for (;;)
+                {
+                    const uint32_t e = multi[s.b.look(DCS_MULTI_BITS)];
+                    const int steps = static_cast<int>(e >> 8);
+                    if (steps == 0 || steps >= i)
+                        break;
+                    s.b.consume(static_cast<int>(e & 0xFF));
+                    i -= steps;
+                }
+            }
+            for ( ; i != 0 ; --i)
             {
                 const uint32_t e = book[s.b.peek(maxBits)];
                 s.b.consume(static_cast<int>((e >> 8) & 0x1F));     // (a code is never longer than its book's look-ahead)

@@ -134,6 +134,12 @@ typedef struct DcsStreamInfo           /* DCSDecoderNative::StreamInfo (DCSDecod
 DcsStatus dcs_index_stream(DcsOsVersion os, const uint8_t *stream, size_t len,
                            DcsFrameIndex *out, uint32_t cap, DcsStreamInfo *info);
 
+/* Diagnostic: the same scan with a reader that keeps the reference reader's byte pointer literally (Peek pulls whole
+ * bytes while nBits <= n, DCSDecoderNative.h:271) and decodes one code per look.  dcs_index_stream computes that pointer
+ * instead and takes several codes per look; both return the same records and the same nBytes (tested). */
+DcsStatus dcs_index_stream_literal(DcsOsVersion os, const uint8_t *stream, size_t len,
+                                   DcsFrameIndex *out, uint32_t cap, DcsStreamInfo *info);
+
 /* ------------------------------------------------------------------------------------------------
  * Per-frame mixing parameters (host arithmetic; inputs to the hot path)
  */

@@ -37,6 +37,31 @@ def test_index_pass_matches_oracle_probes(oracle, fmt):
                (oi["nBytes"], oi["formatType"], oi["formatSubType"], oi["header"])
 
 
+def test_fast_walk_equals_literal_walk():
+    """dcs_index_stream (64-bit window, byte pointer computed, several 1994+ codes per look) against the walk with the
+    literal restatement of the reference's reader, one code per look: same records, same StreamInfo incl. nBytes, on
+    every layout and profile, on corrupted streams and on streams cut short in the middle of a frame"""
+    import ctypes
+    n = 0
+    for fmt in ALL_FORMATS:
+        for k in range(12):
+            s = make_stream(fmt, 40 + k, seed=8800 + fmt * 32 + k, profile=k % 4, stride_from=16 if k % 3 else 8)
+            variants = [s, corrupt(s, 200 + k, nflips=4), s[:len(s) * 2 // 3], s + bytes(7)]
+            for v in variants:
+                os_ = os_for(fmt, k)
+                try:
+                    a, ia = D.index_stream(os_, v)
+                except D.DcsError as e:
+                    with pytest.raises(D.DcsError):
+                        D.index_stream(os_, v, literal=True)
+                    continue
+                b, ib = D.index_stream(os_, v, literal=True)
+                assert a.tobytes() == b.tobytes(), (fmt, k)
+                assert bytes(ctypes.string_at(ctypes.byref(ia), ctypes.sizeof(ia))) == bytes(ctypes.string_at(ctypes.byref(ib), ctypes.sizeof(ib)))
+                n += 1
+    assert n > 250
+
+
 def test_index_pass_error_semantics_match_oracle(oracle):
     """corrupted payloads: the stream ends at the first frame that raises STOP/FATAL, like the
     reference's channel.stop sweep (DCSDecoderNative.cpp:95-116)"""
