@@ -1,5 +1,5 @@
 import sys, os, time, ctypes
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import dcsexplorer_amd as D
 from dcsexplorer_amd import workloads as W

@@ -1,6 +1,6 @@
 """the device index pass alone: kernel time by number of streams (256 frames each)"""
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dcsexplorer_amd as D
 from dcsexplorer_amd import workloads as W
 ctx = D.Context(0)

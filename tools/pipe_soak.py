@@ -1,6 +1,6 @@
 """soak test of dcs_pipeline on a GPU box: many lists through every mode, PCM of every list hashed and compared, memory watched"""
 import sys, os, time, resource, zlib
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import dcsexplorer_amd as D
 from dcsexplorer_amd import workloads as W
