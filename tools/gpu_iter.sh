@@ -7,7 +7,7 @@ if [ "$2" != "notest" ]; then
   tail -2 $OUT/pytest.log
 fi
 for wl in dcs93_4096 dcs94_65536 mixed_16384; do
-  timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err || { tail -5 $OUT/bench_$wl.err; exit 1; }
+  timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-end-to-end > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err || { tail -5 $OUT/bench_$wl.err; exit 1; }
   python - $OUT/bench_$wl.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))
