@@ -142,6 +142,23 @@ struct DcsSlot                          // 32 bytes: everything the kernel needs
     uint16_t runPoolOff;                // pool dword where run k goes (a multiple of 4)
 };
 
+// Which header bands the q-th unpack lane of a frame takes: lane q starts at dcsLaneFirstBand(q) and ends where lane
+// q + 1 starts.  The 1993 layouts (sixteen bands of sixteen samples) get bpl consecutive bands per lane.  The bands of a
+// 1994+ frame hold 7, 8, 13 x 16 and 32 samples: there bands 0 and 1 count as one and band 15 as two, which with eight
+// lanes gives {0, 1, 2} {3, 4} ... {13, 14} {15}, 31 or 32 samples for every lane (the symbol loop works through them in
+// rounds of 7, 9 and 16 iterations, unpack94 in dcs_kernels.hip.h).  With sixteen lanes a lane has one band either way.
+#ifdef __cplusplus
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr int dcsLaneFirstBand(int format, int q, int bpl, int nb16)
+{
+    const int b = q * bpl + ((format >= DCS_FMT_94_T0 && q != 0 && bpl > 1) ? 1 : 0);
+    return b < nb16 ? b : nb16;
+}
+#endif
+
 // Chunk packages.  Everything unpack round 0 of a chunk needs, gathered once per batch by the host packer
 // (dcsBuildPackages, dcs_plan.cpp) into one block at a fixed stride, so that a wavefront requests ALL of it at its first instruction (no load depends on
 // another load):  slots [fpw] (32 B) | descriptor heads [fpw] (first 40 bytes of DcsSrcDesc, padded to 48) |

@@ -173,6 +173,13 @@ struct BitReader
     }
     __device__ __forceinline__ void skip(int n) { skip(n, prefetch()); }
     __device__ __forceinline__ uint32_t get(int n) { const uint32_t v = peek(n); skip(n); return v; }
+    // where the reader stands, as an LDS bit address (lo is the dword at pa - 8 unless nothing of it has been read),
+    // and a reader put there: what a band's error path needs to go over the band again
+    __device__ __forceinline__ uint32_t bitAddr() const { return (pa - 8u) * 8u - static_cast<uint32_t>(negpos); }
+    __device__ __forceinline__ void initAt(uint32_t bits)
+    {
+        init((const uint32_t *)reinterpret_cast<LdsDwordPtr>(static_cast<uintptr_t>((bits >> 5) << 2)), static_cast<int>(bits & 31u));
+    }
 };
 
 // The same reader without a window held in registers: only the position is kept, every look reads the two pool
@@ -204,6 +211,8 @@ struct DirectReader
     __device__ __forceinline__ void skip(int n, uint32_t) { skip(n); }
     __device__ __forceinline__ void skipTight(uint32_t n, uint32_t) { bp += n; }
     __device__ __forceinline__ uint32_t get(int n) { const uint32_t v = peek(n); skip(n); return v; }
+    __device__ __forceinline__ uint32_t bitAddr() const { return bp + 1u; }
+    __device__ __forceinline__ void initAt(uint32_t bits) { bp = bits - 1u; }
 };
 
 // prefix code via first-level table + trie (dcs_common.h)
@@ -289,6 +298,21 @@ __device__ __forceinline__ void mixAdd(uint16_t *cell, int scaledProduct, uint32
         acc += static_cast<uint32_t>(*cell) << 16;
     *cell = static_cast<uint16_t>(acc >> 16);
 }
+// ... with the cell given as an LDS byte address
+typedef uint16_t __attribute__((address_space(3))) *LdsWordPtr;
+template <bool FIRST>
+__device__ __forceinline__ void mixAddAt(uint32_t cellAddr, int scaledProduct, uint32_t mixMul)
+{
+    const LdsWordPtr cell = reinterpret_cast<LdsWordPtr>(static_cast<uintptr_t>(cellAddr));
+    uint32_t t, acc;
+    asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+        : "=v"(t) : "v"(scaledProduct), "v"(mixMul));
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=v"(acc) : "v"(t), "v"(scaledProduct));
+    if (!FIRST)
+        acc += static_cast<uint32_t>(*cell) << 16;
+    *cell = static_cast<uint16_t>(acc >> 16);
+}
 // the same with the low word that is ADDED taken from `addLow` instead of the product (the 1993 "repeat the previous
 // input" coding carries it from sample to sample, :2513-2534); returns the 32-bit sum
 template <bool FIRST>
@@ -305,7 +329,6 @@ __device__ __forceinline__ uint32_t mixAddCarry(uint16_t *cell, int scaledProduc
     return acc;
 }
 // ... and with the cell given as an LDS byte address
-typedef uint16_t __attribute__((address_space(3))) *LdsWordPtr;
 template <bool FIRST>
 __device__ __forceinline__ uint32_t mixAddCarryAt(uint32_t cellAddr, int scaledProduct, uint32_t mixMul, uint32_t addLow)
 {
@@ -362,7 +385,7 @@ constexpr int kDummyWord = 256;         // the pad word of a tile row: sink for 
 // divergent code; the symbol loop is branch-free so that lanes with Huffman-coded bands, raw bands
 // and different codebooks all execute the same instruction stream.
 // ------------------------------------------------------------------------------------------------
-template <bool FIRST, class BR>
+template <bool FIRST, class BR, int SUB>
 __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const Quarter &Q,
                              int format, uint32_t mixMul, bool has, const Stamper &stamp)
 {
@@ -381,102 +404,128 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const
     const uint32_t saved1 = (owner && !FIRST) ? row[1] : 0u;
 
     stamp(8);
-    // (the trip count is the largest nb of the wavefront: one ballot per band instead of a reduction up front)
-    for (int k = 0 ; __any(k < nb) ; ++k)
+    // The lanes of a wavefront run the symbol loop together, and a lane's bands differ in length (7, 8, 13 x 16 and 32
+    // samples), so the loop is run in ROUNDS of at most 7, 9, then 16 samples per lane at a time, and only
+    // between rounds does a lane whose band has run out set the next one up (the set-up is some 60 instructions for the
+    // whole wavefront however many lanes need it).  A band that is longer than the round simply goes on in the next one.
+    // With the bands dealt out as {0, 1, 2} {3, 4} ... {13, 14} {15} (eight lanes per frame, dcsLaneFirstBand) every
+    // lane has 31 or 32 samples and the wavefront is through after 7 + 9 + 16 iterations; one band per lane per round
+    // (round 1's form) cost 16 + 32.
+    int k = 0;                                  // bands this lane has started
+    // (cells as LDS byte addresses: 32-bit arithmetic in the loop)
+    uint32_t cell = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsWordPtr)row)) + 2u * static_cast<uint32_t>(outIdx);   // where the next sample goes
+    uint32_t cellEnd = cell;                    // end of the band in progress; == cell: no band in progress
+    uint32_t cellStart = cell;                  // ... its start and where its bits began, for the error path
+    uint32_t startBits = 0;
+    const uint16_t *book = T->cb94;
+    int shPeek = 0, shIdx = 0, scale = 0;
+    uint32_t incSh = 1;                         // log2 of the bytes from one sample of the band to the next (strided: 4)
+    bool isRaw = false;
+    for (int round = 0 ; ; ++round)
     {
-        // ---- per-band set-up -------------------------------------------------------------------------
-        const int band = Q.bandBase + k;
-        // Straight-line code with selects: every lane computes the set-up of "its" band (lanes without one compute
-        // something harmless and end up with i = 0), the two table reads are independent of each other's wait.
-        const bool act = k < nb;
-        int hb = byteOf(Q.h0, Q.h1, Q.h2, Q.h3, band) & 0x7F;
-        const int count0 = band == 0 ? 7 : band == 1 ? 8 : band == 15 ? 32 : 16;      // :1848-1850
-        const bool strided = (hb & 0x40) != 0;
-        const int inc = strided ? 2 : 1;
-        const int count = strided ? count0 >> 1 : count0;
-        const int code0 = byteOf(Q.t0, Q.t1, Q.t2, Q.t3, band);
-        // Type 1: (band class, code) -> sample code and scale adjustment (:1914-1961)
-        const uint32_t x = T->xlat94[(band < 3 ? 0 : band < 6 ? 16 : 32) + (code0 & 15)];
-        const int pre = band < 3 ? static_cast<int>((Q.preAdj >> (4 * (band & 3))) & 15u) : 0;
-        const bool fatal1 = type1 && code0 > 15;
-        const int code = (type1 && !fatal1) ? static_cast<int>(x & 0xFF) : code0;
-        const int scaleCode = type1 ? hb + pre + static_cast<int>(x >> 8) : hb;
-        const uint32_t info = T->cbInfo[min(code, 7)];
-        const bool zeroBand = code0 == 0;                                   // nothing coded: skip (:1886)
-        const bool fatal = act && !zeroBand && (fatal1 || code > 16);
-        const bool stopBand = act && !zeroBand && !fatal && code == 0;      // :1985-1991
-        const bool isRaw = code > 6;                                         // fixed-width band (sample codes 7..16):
-        // the value is the top `code` bits; its two-entry "codebook" (indexed with one bit) supplies the width and the
-        // step like a real one
-        const int shPeek = 32 - (isRaw ? code : static_cast<int>(info & 0xF));   // 32 - look-ahead (raw: sample) width
-        const int shIdx = isRaw ? 31 : shPeek;                               // turns the next 32 bits into the codebook index
-        const uint16_t *book = isRaw ? T->raw94 + 2 * (min(code, 16) - 7) : T->cb94 + (info >> 4);
-        int scale = static_cast<int>(scaleFactor(T, scaleCode));
-        int i = (act && !zeroBand && !fatal && !stopBand) ? count : 0;       // symbols still to decode in this band
-        outIdx += !act ? 0 : zeroBand ? count /* the halved count, not count*inc */ : stopBand ? count * inc : 0;
-        if (fatal)
+        // ---- a band that overshot its end: a two-zeros code with one sample left (:2213-2218) --------------------
+        if (cell > cellEnd)
         {
-            err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;
-            nb = 0;                         // stop: later bands contribute nothing
-        }
-        if (stopBand)
-        {
+            // the reference zeroes the WHOLE band buffer on this error (:2238-2239): take back what the
+            // band already contributed by replaying it.  (Frames with errors are never split.)
+            cell -= 1u << incSh;                // the second zero had no room: the band ends where it should
+            if (valid)
+            {
+                BR r2;
+                r2.initAt(startBits);
+                uint32_t c2 = cellStart;
+                while (c2 + (1u << incSh) < cellEnd)            // (more than one sample left)
+                {
+                    const uint32_t e = book[r2.cur() >> shIdx];
+                    r2.skip(static_cast<int>((e >> 8) & 0x1F));
+                    const uint32_t step = e >> 13;
+                    if (step == 1)
+                        mixSub((uint16_t *)reinterpret_cast<LdsWordPtr>(static_cast<uintptr_t>(c2)),
+                               mul24(static_cast<int>(static_cast<int8_t>(e & 0xFF)), scale), mixMul);
+                    c2 += step << incSh;
+                }
+            }
             valid = false; err |= DCS_FRAME_STOP;
+            cellEnd = cell;
         }
-        if (!valid)
-            scale = 0;              // after a STOP the band is still parsed, its samples contribute nothing
+        // ---- per-band set-up for the lanes that are between bands ---------------------------------------------
+        const bool start = cell == cellEnd && k < nb;
+        if (!__any(start || cell < cellEnd))
+            break;
+        if (start)
+        {
+            const int band = Q.bandBase + k;
+            ++k;
+            int hb = byteOf(Q.h0, Q.h1, Q.h2, Q.h3, band) & 0x7F;
+            const int count0 = band == 0 ? 7 : band == 1 ? 8 : band == 15 ? 32 : 16;      // :1848-1850
+            const bool strided = (hb & 0x40) != 0;
+            const int count = strided ? count0 >> 1 : count0;
+            const int code0 = byteOf(Q.t0, Q.t1, Q.t2, Q.t3, band);
+            // Type 1: (band class, code) -> sample code and scale adjustment (:1914-1961)
+            const uint32_t x = T->xlat94[(band < 3 ? 0 : band < 6 ? 16 : 32) + (code0 & 15)];
+            const int pre = band < 3 ? static_cast<int>((Q.preAdj >> (4 * (band & 3))) & 15u) : 0;
+            const bool fatal1 = type1 && code0 > 15;
+            const int code = (type1 && !fatal1) ? static_cast<int>(x & 0xFF) : code0;
+            const int scaleCode = type1 ? hb + pre + static_cast<int>(x >> 8) : hb;
+            const uint32_t info = T->cbInfo[min(code, 7)];
+            const bool zeroBand = code0 == 0;                                   // nothing coded: skip (:1886)
+            const bool fatal = !zeroBand && (fatal1 || code > 16);
+            const bool stopBand = !zeroBand && !fatal && code == 0;             // :1985-1991
+            isRaw = code > 6;                                                    // fixed-width band (sample codes 7..16):
+            // the value is the top `code` bits; its two-entry "codebook" (indexed with one bit) supplies the width and the
+            // step like a real one
+            shPeek = 32 - (isRaw ? code : static_cast<int>(info & 0xF));        // 32 - look-ahead (raw: sample) width
+            shIdx = isRaw ? 31 : shPeek;                                         // turns the next 32 bits into the codebook index
+            book = isRaw ? T->raw94 + 2 * (min(code, 16) - 7) : T->cb94 + (info >> 4);
+            scale = static_cast<int>(scaleFactor(T, scaleCode));
+            const int i = (!zeroBand && !fatal && !stopBand) ? count : 0;       // symbols to decode in this band
+            incSh = strided ? 2u : 1u;
+            // (a band without a code moves on by the halved count, not by count * inc)
+            cell += zeroBand ? 2u * static_cast<uint32_t>(count) : stopBand ? static_cast<uint32_t>(count) << incSh : 0u;
+            if (fatal)
+            {
+                err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;
+                nb = 0;                         // stop: later bands contribute nothing
+            }
+            if (stopBand)
+            {
+                valid = false; err |= DCS_FRAME_STOP;
+            }
+            if (!valid)
+                scale = 0;              // after a STOP the band is still parsed, its samples contribute nothing
+            cellStart = cell;
+            cellEnd = cell + (static_cast<uint32_t>(i) << incSh);
+            startBits = br.bitAddr();
+        }
 
         // ---- symbol loop, branch-free ------------------------------------------------------------------
         // One codebook entry drives everything: value, code length and how many samples it stands for
         // (the "two zeros" code, :2200-2212, has value 0 and step 2, so it needs no special store: adding a
         // zero product leaves the accumulator as it was).  A two-zeros code with one sample left (:2213-2218)
-        // drives i to -1, which is how the error is seen after the loop.
-        if (k == 0) stamp(9);
-        const BR bandStart = br;
-        uint16_t *cell = row + outIdx;
-        uint16_t *const cellStart = cell;
-        const int countStart = i;
-        const int inc2 = inc;
-        const int incBytes = inc * 2;
-        // (the cell pointer doubles as the loop counter: the band ends at cellEnd, a two-zeros code with one sample
-        // left overshoots it)
-        uint16_t *const cellEnd = cell + i * inc;
-        while (cell < cellEnd)
+        // drives the cell past cellEnd, which is how the error is seen at the top of the next round.
+        if (round == 0) stamp(9);
+        // (the round is bounded in samples, not iterations: a symbol is at least one sample, and the loop's only test
+        // stays the cell against an end)
+        // (sixteen lanes per frame: one band per lane, no band of a lane waits for another's, so a round is a band)
+        const uint32_t roundLen = SUB == 16 ? 32u : round == 0 ? 7u : round == 1 ? 9u : 16u;
+        const uint32_t roundEnd = min(cellEnd, cell + (roundLen << incSh));
+        if (cell < roundEnd)
         {
-            const uint32_t ahead = br.prefetch();
-            const uint32_t w = br.cur();
-            const uint32_t e = book[w >> shIdx];
-            const int vr = static_cast<int>(w) >> shPeek;
-            const int vh = static_cast<int>(static_cast<int8_t>(e & 0xFF));
-            const int step = static_cast<int>(e >> 13);
-            br.skipTight((e >> 8) & 0x1Fu, ahead);
-            mixAdd<FIRST>(cell, mul24(isRaw ? vr : vh, scale), mixMul);
-            cell = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(cell) + incBytes * step);
-        }
-        outIdx += static_cast<int>(cell - cellStart);
-        if (k == 0) stamp(10);
-        if (cell > cellEnd)
-        {
-            // the reference zeroes the WHOLE band buffer on this error (:2238-2239): take back what the
-            // band already contributed by replaying it.  (Frames with errors are never split.)
-            outIdx -= inc2;                 // the second zero had no room: the band ends where it should
-            if (valid)
+            do
             {
-                BR r2 = bandStart;
-                uint16_t *c2 = cellStart;
-                for (int j = countStart ; j > 1 ; )
-                {
-                    const uint32_t e = book[r2.cur() >> shIdx];
-                    r2.skip(static_cast<int>((e >> 8) & 0x1F));
-                    const int step = static_cast<int>(e >> 13);
-                    if (step == 1)
-                        mixSub(c2, mul24(static_cast<int>(static_cast<int8_t>(e & 0xFF)), scale), mixMul);
-                    c2 += inc2 * step;
-                    j -= step;
-                }
+                const uint32_t ahead = br.prefetch();
+                const uint32_t w = br.cur();
+                const uint32_t e = book[w >> shIdx];
+                const int vr = static_cast<int>(w) >> shPeek;
+                const int vh = static_cast<int>(static_cast<int8_t>(e & 0xFF));
+                const uint32_t step = e >> 13;
+                br.skipTight((e >> 8) & 0x1Fu, ahead);
+                mixAddAt<FIRST>(cell, mul24(isRaw ? vr : vh, scale), mixMul);
+                cell += step << incSh;
             }
-            valid = false; err |= DCS_FRAME_STOP;
+            while (cell < roundEnd);
         }
+        if (round == 0) stamp(10);
     }
 
     if (owner)
@@ -1642,7 +1691,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
                 const int nb16 = min(nBands, 16);
                 if (R0)
                 {
-                    // the packer dealt the bands out (evenly for the 1993 layouts, by cost for 1994+): this lane's first
+                    // the packer dealt the bands out (dcsLaneFirstBand): this lane's first
                     // band comes with its split record, its last one is where the next lane of the frame starts
                     const int myBase = (sp.x & 0x8000u) ? nb16 : static_cast<int>(sp.y >> 28);
                     const int nextBase = __shfl(myBase, lane + FPW);
@@ -1651,10 +1700,10 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
                 }
                 else
                 {
-                    // lane q takes bands [q * bpl, (q + 1) * bpl), bpl = ceil(nBands / SUB)
+                    // the same deal as the packer's, worked out here: bpl = ceil(nBands / SUB)
                     const int bpl = max((nb16 + SUB - 1) / SUB, 1);
-                    Q.bandBase = q * bpl;
-                    Q.nb = min(max(nb16 - Q.bandBase, 0), bpl);
+                    Q.bandBase = dcsLaneFirstBand(format, q, bpl, nb16);
+                    Q.nb = (q == SUB - 1 ? nb16 : dcsLaneFirstBand(format, q + 1, bpl, nb16)) - Q.bandBase;
                 }
                 if (q != 0 && Q.nb != 0)
                 {
@@ -1687,7 +1736,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
             {
                 BR94 br;
                 br.init(brAt, brBit);
-                err |= unpack94<R0, BR94>(T, row, br, Q, format, mixMul, is94, stamp);
+                err |= unpack94<R0, BR94, SUB>(T, row, br, Q, format, mixMul, is94, stamp);
             }
             BR93 br;
             br.init(brAt, brBit);

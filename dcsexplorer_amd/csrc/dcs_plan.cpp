@@ -359,20 +359,16 @@ static void packChunks(const DcsSlot *slots, uint32_t c0, uint32_t c1, int fpw, 
             const size_t hLen = sd.hdrLen == 1 ? 1 : 16;
             for (size_t i = 0 ; i < hLen ; ++i)
                 hd[i] = hOff + i < blobLen ? blob[hOff + i] : 0;
-            // Which header bands the frame's q-th unpack lane (lane = s + q * fpw) takes: its first band travels in bits
-            // 12..15 of the state word of the lane's split record (the record of that band's start, split[band - 1]);
-            // a lane without bands has bit 15 of bitDelta set.  Every lane gets bpl consecutive bands.  (Dealing the
-            // 1994+ bands out by what they cost -- 7, 8, 16 x 13, 32 samples: {0,1,2} {3,4} ... {13,14} {15} for 8 lanes --
-            // was measured: 48.7 instead of 39.0 us on the 65 536-frame batch.  The band loop runs in lockstep, one band
-            // per lane per round, so a wavefront pays the LONGEST band of every round: 16 + 32 with two bands each,
-            // 32 + 16 + 16 when one lane takes three short bands and another the long one alone.)
+            // Which header bands the frame's q-th unpack lane (lane = s + q * fpw) takes (dcsLaneFirstBand): its first band
+            // travels in bits 12..15 of the state word of the lane's split record (the record of that band's start,
+            // split[band - 1]); a lane without bands has bit 15 of bitDelta set.
             const int bpl = sl.bpl;
             if (bpl == 0)
                 continue;                                   // one lane unpacks the whole frame
             const int nb16 = sd.idx.nBands < 16 ? sd.idx.nBands : 16;
             int base[17];
             for (int q = 0 ; q <= sub ; ++q)
-                base[q] = q * bpl < nb16 ? q * bpl : nb16;
+                base[q] = dcsLaneFirstBand(sd.format, q, bpl, nb16);
             for (int q = 1 ; q < sub ; ++q)
             {
                 DcsSplit rec;

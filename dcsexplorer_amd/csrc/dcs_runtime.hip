@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
         {
             const DcsPlanSrc sd = srcs[sl.firstSrc];
             const int nb16 = sd.nBands < 16 ? sd.nBands : 16;
-            const int base = q * sl.bpl < nb16 ? q * sl.bpl : nb16;
+            const int base = dcsLaneFirstBand(sd.format, q, sl.bpl, nb16);
             uint32_t r0 = 0x8000u, r1 = 0;      // bitDelta bit 15: no bands for this lane
             if (base < nb16)
             {

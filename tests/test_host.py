@@ -213,7 +213,9 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
             want_hdr = np.zeros(16, np.uint8); want_hdr[:hl] = np.frombuffer(blob[so + 2: so + 2 + hl], np.uint8)
             assert np.array_equal(pk[c, off_hdr + 16 * s: off_hdr + 16 * s + 16], want_hdr)
             # per-lane records: lane q's first band (bits 12..15 of the state word; bit 15 of bitDelta = no bands) with
-            # the split record of that band's start.  The lanes cover the bands contiguously, in order, bpl bands each.
+            # the split record of that band's start.  The lanes cover the bands contiguously, in order: bpl bands each for
+            # the 1993 layouts; in a 1994+ frame (bands of 7, 8, 13 x 16 and 32 samples) bands 0 and 1 count as one and
+            # band 15 as two, so with more than one band per lane every lane after the first starts one band later.
             bpl = (int(slots[s, 7]) >> 8) & 0xFF
             nb16 = min(int(sd["idx"]["nBands"]), 16)
             bases = [0]
@@ -235,7 +237,8 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
             if bpl != 0:
                 bases.append(nb16)
                 assert all(bases[i] <= bases[i + 1] for i in range(sub))
-                assert bases[:sub] == [min(q * bpl, nb16) for q in range(sub)]
+                later = 1 if int(sd["format"]) >= D.FMT_94_T0 and bpl > 1 else 0
+                assert bases[:sub] == [min(q * bpl + (later if q else 0), nb16) for q in range(sub)]
             # the frame's bits, read MSB-first from the pool image at the slot's position, are the stream's
             pool_off = int(slots[s, 5]) >> 16
             bit0 = (so + 2 + hl) * 8 + int(sd["idx"]["bitOff"])
