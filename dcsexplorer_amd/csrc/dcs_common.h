@@ -36,7 +36,18 @@ struct DcsLdsTables
     uint8_t  inputs93a[24];             // inputs per band, 18 used (:2865)
     uint16_t scaleMant[4];              // 0x8000, 0x9838, 0xB505, 0xD745 (:1978)
     uint16_t raw94[20];                 // two-entry "codebooks" of the fixed-width sample codes 7..16: width<<8 | 1<<13
+    // Everything the 1994+ band set-up derives from a band-type code (:1886-2005), resolved once (dcs_tables.cpp) so that
+    // the kernel's set-up is one look-up: [0..50] Type 1, [band class 0..2][min(code, 16)]; [51..68] Type 0, [min(code, 17)].
+    // Entry: the codebook's offset in this block, in half-words (bits 0..10) | 32 - look-ahead width (11..15) | shift
+    // that turns the next 32 bits into the codebook index (16..20) | DCS_B94_RAW | _ZERO | _STOP | _FATAL | scale
+    // adjustment << 25.
+    uint32_t band94[72];
 };
+#define DCS_B94_RAW      (1u << 21)     // fixed-width samples (sample codes 7..16)
+#define DCS_B94_ZERO     (1u << 22)     // nothing coded (:1886)
+#define DCS_B94_STOP     (1u << 23)     // sample code 0 behind a non-zero band-type code (:1985-1991)
+#define DCS_B94_FATAL    (1u << 24)     // no such code (:1914, :1999)
+#define DCS_B94_TYPE0    51             // first Type-0 entry
 
 // per-lane constants of the transform passes (dcs_kernels.hip.h): twiddles and overlap-window entries that
 // depend only on the lane number, precomputed on the host so that a wavefront fetches them with six

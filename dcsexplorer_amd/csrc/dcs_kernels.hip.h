@@ -412,6 +412,7 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const
     // lane has 31 or 32 samples and the wavefront is through after 7 + 9 + 16 iterations; one band per lane per round
     // (round 1's form) cost 16 + 32.
     int k = 0;                                  // bands this lane has started
+    const int keyLim = type1 ? 16 : 17;         // band-type codes beyond this all mean the same (no such code)
     // (cells as LDS byte addresses: 32-bit arithmetic in the loop)
     uint32_t cell = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsWordPtr)row)) + 2u * static_cast<uint32_t>(outIdx);   // where the next sample goes
     uint32_t cellEnd = cell;                    // end of the band in progress; == cell: no band in progress
@@ -456,45 +457,40 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const
         {
             const int band = Q.bandBase + k;
             ++k;
-            int hb = byteOf(Q.h0, Q.h1, Q.h2, Q.h3, band) & 0x7F;
-            const int count0 = band == 0 ? 7 : band == 1 ? 8 : band == 15 ? 32 : 16;      // :1848-1850
-            const bool strided = (hb & 0x40) != 0;
-            const int count = strided ? count0 >> 1 : count0;
+            // what the band-type code means comes out of one table (DcsLdsTables.band94): codebook, look-ahead width,
+            // fixed-width or not, scale adjustment, and whether the band is empty or in error
+            const int hb = byteOf(Q.h0, Q.h1, Q.h2, Q.h3, band) & 0x7F;
             const int code0 = byteOf(Q.t0, Q.t1, Q.t2, Q.t3, band);
-            // Type 1: (band class, code) -> sample code and scale adjustment (:1914-1961)
-            const uint32_t x = T->xlat94[(band < 3 ? 0 : band < 6 ? 16 : 32) + (code0 & 15)];
-            const int pre = band < 3 ? static_cast<int>((Q.preAdj >> (4 * (band & 3))) & 15u) : 0;
-            const bool fatal1 = type1 && code0 > 15;
-            const int code = (type1 && !fatal1) ? static_cast<int>(x & 0xFF) : code0;
-            const int scaleCode = type1 ? hb + pre + static_cast<int>(x >> 8) : hb;
-            const uint32_t info = T->cbInfo[min(code, 7)];
-            const bool zeroBand = code0 == 0;                                   // nothing coded: skip (:1886)
-            const bool fatal = !zeroBand && (fatal1 || code > 16);
-            const bool stopBand = !zeroBand && !fatal && code == 0;             // :1985-1991
-            isRaw = code > 6;                                                    // fixed-width band (sample codes 7..16):
-            // the value is the top `code` bits; its two-entry "codebook" (indexed with one bit) supplies the width and the
-            // step like a real one
-            shPeek = 32 - (isRaw ? code : static_cast<int>(info & 0xF));        // 32 - look-ahead (raw: sample) width
-            shIdx = isRaw ? 31 : shPeek;                                         // turns the next 32 bits into the codebook index
-            book = isRaw ? T->raw94 + 2 * (min(code, 16) - 7) : T->cb94 + (info >> 4);
-            scale = static_cast<int>(scaleFactor(T, scaleCode));
-            const int i = (!zeroBand && !fatal && !stopBand) ? count : 0;       // symbols to decode in this band
-            incSh = strided ? 2u : 1u;
-            // (a band without a code moves on by the halved count, not by count * inc)
-            cell += zeroBand ? 2u * static_cast<uint32_t>(count) : stopBand ? static_cast<uint32_t>(count) << incSh : 0u;
+            const int cls = band < 3 ? 0 : band < 6 ? 17 : 34;
+            const int key = min(code0, keyLim) + (type1 ? cls : DCS_B94_TYPE0);
+            const uint32_t e = T->band94[key];
+            // samples of the band (:1848-1850): 7, 8, 16 ... 16, 32; halved for a strided band
+            const int count0 = band < 2 ? 7 + band : band == 15 ? 32 : 16;
+            const uint32_t strided = (static_cast<uint32_t>(hb) >> 6) & 1u;
+            const uint32_t count = static_cast<uint32_t>(count0) >> strided;
+            incSh = 1u + strided;
+            // Type 1: scale = header byte + pre-adjust (bands 0..2, from the previous frame's codes) + the code's own (:1914-1961)
+            const int pre = (type1 && band < 3) ? static_cast<int>((Q.preAdj >> (4 * band)) & 15u) : 0;
+            scale = static_cast<int>(scaleFactor(T, hb + pre + static_cast<int>(e >> 25)));
+            book = reinterpret_cast<const uint16_t *>(T) + (e & 0x7FFu);
+            shPeek = static_cast<int>((e >> 11) & 31u);
+            shIdx = static_cast<int>((e >> 16) & 31u);
+            isRaw = (e & DCS_B94_RAW) != 0;
+            // (no band-type code stands for sample code 0 -- dcs_tables.cpp checks it --, so the STOP of :1985-1991 cannot
+            // happen: a band is empty, in error, or has `count` samples)
+            const bool zeroBand = (e & DCS_B94_ZERO) != 0, fatal = (e & DCS_B94_FATAL) != 0;
+            const uint32_t i = (e & (DCS_B94_ZERO | DCS_B94_FATAL)) == 0 ? count : 0u;      // symbols to decode in this band
+            // (a band without a code moves on by the halved count, not by count * inc, :1886)
+            cell += zeroBand ? 2u * count : 0u;
             if (fatal)
             {
                 err |= DCS_FRAME_FATAL | DCS_FRAME_STOP;
                 nb = 0;                         // stop: later bands contribute nothing
             }
-            if (stopBand)
-            {
-                valid = false; err |= DCS_FRAME_STOP;
-            }
             if (!valid)
                 scale = 0;              // after a STOP the band is still parsed, its samples contribute nothing
             cellStart = cell;
-            cellEnd = cell + (static_cast<uint32_t>(i) << incSh);
+            cellEnd = cell + (i << incSh);
             startBits = br.bitAddr();
         }
 

@@ -1,5 +1,6 @@
 // dcs_tables.cpp -- expands the canonical code lists of dcs_tables.h into the lookup structures the
 // kernels (and the host index pass) use.  See dcs_common.h for the layouts.
+#include <cstddef>
 #include "dcs_common.h"
 #include "dcs_tables.h"
 #include <stdlib.h>
@@ -123,6 +124,33 @@ DcsDevTables build()
         t.lds.xlat94[32 + i] = kXlatB6F[i];
         t.lds.preAdj94[i] = kPreAdjSub0[i];
         t.lds.preAdj94[16 + i] = kPreAdjSub3[i];
+    }
+    // band94: the set-up of unpack94 (dcs_kernels.hip.h) as a table; the expressions are the ones the index pass walks
+    // (dcs_scan.h: dcsScan94), evaluated for every band class and band-type code
+    for (int k = 0 ; k < 72 ; ++k)
+    {
+        const bool type1 = k < DCS_B94_TYPE0;
+        const int cls = type1 ? k / 17 : 0, code0 = type1 ? k % 17 : k - DCS_B94_TYPE0;
+        if (k > DCS_B94_TYPE0 + 17)
+            continue;                                           // padding
+        const uint32_t x = t.lds.xlat94[cls * 16 + (code0 & 15)];
+        const bool fatal1 = type1 && code0 > 15;
+        const int code = (type1 && !fatal1) ? static_cast<int>(x & 0xFF) : code0;
+        const uint32_t adj = type1 ? x >> 8 : 0;
+        const bool zero = code0 == 0;
+        const bool fatal = !zero && (fatal1 || code > 16);
+        const bool stop = !zero && !fatal && code == 0;
+        const bool raw = code > 6;
+        const uint32_t info = t.lds.cbInfo[code < 7 ? code : 7];
+        const uint32_t shPeek = 32u - (raw ? static_cast<uint32_t>(code < 16 ? code : 16) : (info & 0xF));
+        const uint32_t shIdx = raw ? 31u : shPeek;
+        const size_t book = raw ? offsetof(DcsLdsTables, raw94) / 2 + 2 * static_cast<size_t>((code < 16 ? code : 16) - 7)
+                                : offsetof(DcsLdsTables, cb94) / 2 + (info >> 4);
+        // (the kernel's set-up leaves the STOP of :1985-1991 out: no band-type code but 0 translates to sample code 0)
+        if (book > 0x7FF || adj > 0x7F || stop)
+            abort();
+        t.lds.band94[k] = static_cast<uint32_t>(book) | ((shPeek & 31u) << 11) | ((shIdx & 31u) << 16) | (raw ? DCS_B94_RAW : 0u)
+                        | (zero ? DCS_B94_ZERO : 0u) | (stop ? DCS_B94_STOP : 0u) | (fatal ? DCS_B94_FATAL : 0u) | (adj << 25);
     }
     memcpy(t.lds.bandBits93a, kBandBits93a, sizeof(t.lds.bandBits93a));
     memcpy(t.lds.scaleCb93a, kScaleCb93a, sizeof(t.lds.scaleCb93a));
