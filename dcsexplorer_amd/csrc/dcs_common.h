@@ -157,7 +157,9 @@ struct DcsSlot                          // 32 bytes: everything the kernel needs
 // q + 1 starts.  The 1993 layouts (sixteen bands of sixteen samples) get bpl consecutive bands per lane.  The bands of a
 // 1994+ frame hold 7, 8, 13 x 16 and 32 samples: there bands 0 and 1 count as one and band 15 as two, which with eight
 // lanes gives {0, 1, 2} {3, 4} ... {13, 14} {15}, 31 or 32 samples for every lane (the symbol loop works through them in
-// rounds of 7, 9 and 16 iterations, unpack94 in dcs_kernels.hip.h).  With sixteen lanes a lane has one band either way.
+// rounds of 7, 9 and 16 samples, unpack94 in dcs_kernels.hip.h).  With sixteen lanes it is {0, 1} {2} ... {14} {15} and
+// the last lane is left for the second half of band 15, which the packers give it when the index pass recorded where
+// that half starts (dcsMid15: split[14].prv / .prvDelta, dcs_scan.h).
 #ifdef __cplusplus
 static inline
 #ifdef __HIPCC__
@@ -165,8 +167,20 @@ __host__ __device__
 #endif
 constexpr int dcsLaneFirstBand(int format, int q, int bpl, int nb16)
 {
-    const int b = q * bpl + ((format >= DCS_FMT_94_T0 && q != 0 && bpl > 1) ? 1 : 0);
+    const int b = q * bpl + ((format >= DCS_FMT_94_T0 && q != 0) ? 1 : 0);
     return b < nb16 ? b : nb16;
+}
+// state word of a lane that starts in the middle of band 15: output index | DCS_MID15_STRADDLE (bit 9) | this flag
+#define DCS_SPLIT_MID15 0x800u
+#define DCS_MID15_STRADDLE 0x200u
+// ... and whether the frame's last lane does: one band per lane, all sixteen bands, a recorded middle
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr bool dcsMid15(int format, int bpl, int nb16, uint32_t midBits)
+{
+    return format >= DCS_FMT_94_T0 && bpl == 1 && nb16 == 16 && midBits != 0;
 }
 #endif
 

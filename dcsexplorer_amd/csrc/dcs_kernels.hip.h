@@ -262,6 +262,9 @@ struct Quarter
     uint32_t prv, prvDelta;
     int subType;
     bool reuse, first;
+    // 1994+, sixteen lanes per frame: band 15 shared by two lanes (dcsMid15).  midEnd: this lane's band 15 ends at the
+    // middle; midStart: it starts there, midStraddle: one sample later (a two-zeros code ran across)
+    bool midEnd, midStart, midStraddle;
 };
 
 // byte b (0..15) of four registers; explicit selects so that nothing is indexed in memory
@@ -398,7 +401,10 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const
     const int b1 = Q.bandBase + nb;
     const int before = Q.bandBase <= 0 ? 0 : Q.bandBase == 1 ? 7 : 15 + 16 * (Q.bandBase - 2);
     const int upTo = b1 <= 0 ? 0 : b1 == 1 ? 7 : b1 >= 16 ? 255 : 15 + 16 * (b1 - 2);
-    int outIdx = min(Q.outIdx, 256 - (upTo - before));
+    // (a lane that starts in the middle of band 15 has sixteen tile words to go at most; one sample fewer -- one word, or
+    // two in a strided band, header bit 6 -- behind a straddling code)
+    const int midAdvance = 16 - (Q.midStraddle ? 1 + static_cast<int>((Q.h3 >> 30) & 1u) : 0);
+    int outIdx = min(Q.outIdx, 256 - ((SUB == 16 && Q.midStart) ? midAdvance : upTo - before));
     bool valid = true;
     const bool owner = has && Q.bandBase == 0;          // the lane that holds band 0 does the DC fix-up
     const uint32_t saved1 = (owner && !FIRST) ? row[1] : 0u;
@@ -425,6 +431,8 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const
     for (int round = 0 ; ; ++round)
     {
         // ---- a band that overshot its end: a two-zeros code with one sample left (:2213-2218) --------------------
+        if (SUB == 16 && Q.midEnd && cell > cellEnd)
+            cellEnd = cell;                     // (not an error: a two-zeros code across the middle of band 15, where this lane stops)
         if (cell > cellEnd)
         {
             // the reference zeroes the WHOLE band buffer on this error (:2238-2239): take back what the
@@ -479,7 +487,14 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const
             // (no band-type code stands for sample code 0 -- dcs_tables.cpp checks it --, so the STOP of :1985-1991 cannot
             // happen: a band is empty, in error, or has `count` samples)
             const bool zeroBand = (e & DCS_B94_ZERO) != 0, fatal = (e & DCS_B94_FATAL) != 0;
-            const uint32_t i = (e & (DCS_B94_ZERO | DCS_B94_FATAL)) == 0 ? count : 0u;      // symbols to decode in this band
+            uint32_t i = (e & (DCS_B94_ZERO | DCS_B94_FATAL)) == 0 ? count : 0u;      // symbols to decode in this band
+            if (SUB == 16 && band == 15 && i != 0)
+            {
+                // band 15 shared by two lanes: the first stops at the first code boundary with half of the samples done,
+                // the second starts there (its output index came with its record)
+                if (Q.midEnd) i = count - (count >> 1);
+                if (Q.midStart) i = (count >> 1) - (Q.midStraddle ? 1u : 0u);
+            }
             // (a band without a code moves on by the halved count, not by count * inc, :1886)
             cell += zeroBand ? 2u * count : 0u;
             if (fatal)
@@ -502,8 +517,7 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const
         if (round == 0) stamp(9);
         // (the round is bounded in samples, not iterations: a symbol is at least one sample, and the loop's only test
         // stays the cell against an end)
-        // (sixteen lanes per frame: one band per lane, no band of a lane waits for another's, so a round is a band)
-        const uint32_t roundLen = SUB == 16 ? 32u : round == 0 ? 7u : round == 1 ? 9u : 16u;
+        const uint32_t roundLen = round == 0 ? 7u : round == 1 ? 9u : 16u;
         const uint32_t roundEnd = min(cellEnd, cell + (roundLen << incSh));
         if (cell < roundEnd)
         {
@@ -1680,6 +1694,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
             Q.prv = 0; Q.prvDelta = 0;
             Q.subType = (format == DCS_FMT_93B_T1) ? 0 : 2;
             Q.reuse = false; Q.first = true;
+            Q.midEnd = Q.midStart = Q.midStraddle = false;
             if (serial)
                 Q.nb = (q == 0) ? nBands : 0;
             else
@@ -1693,6 +1708,17 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
                     const int nextBase = __shfl(myBase, lane + FPW);
                     Q.bandBase = myBase;
                     Q.nb = max((q == SUB - 1 ? nb16 : nextBase) - myBase, 0);
+                    if (SUB == 16)
+                    {
+                        // the frame's last lane may hold the second half of band 15; the lane before it then stops there
+                        const bool mid = format >= DCS_FMT_94_T0 && q == SUB - 1 && myBase == 15 && (sp.y & (DCS_SPLIT_MID15 << 16)) != 0;
+                        const bool nextMid = __shfl(static_cast<int>(mid), lane + FPW) != 0;
+                        Q.midStart = mid;
+                        Q.midStraddle = mid && (sp.y & (DCS_MID15_STRADDLE << 16)) != 0;
+                        Q.midEnd = q == SUB - 2 && nextMid;
+                        if (Q.midEnd)
+                            Q.nb = 16 - myBase;
+                    }
                 }
                 else
                 {

@@ -373,7 +373,13 @@ static void packChunks(const DcsSlot *slots, uint32_t c0, uint32_t c1, int fpw, 
             {
                 DcsSplit rec;
                 memset(&rec, 0, sizeof(rec));
-                if (base[q] >= nb16)
+                if (q == sub - 1 && dcsMid15(sd.format, bpl, nb16, sd.idx.split[14].prv))
+                {
+                    // the second half of band 15 (1994+, one band per lane)
+                    rec.bitDelta = sd.idx.split[14].prv;
+                    rec.state = static_cast<uint16_t>((sd.idx.split[14].prvDelta & 0x3FFu) | DCS_SPLIT_MID15 | (15u << 12));
+                }
+                else if (base[q] >= nb16)
                     rec.bitDelta = 0x8000u;                 // no bands for this lane
                 else
                 {

@@ -558,7 +558,14 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
             const int nb16 = sd.nBands < 16 ? sd.nBands : 16;
             const int base = dcsLaneFirstBand(sd.format, q, sl.bpl, nb16);
             uint32_t r0 = 0x8000u, r1 = 0;      // bitDelta bit 15: no bands for this lane
-            if (base < nb16)
+            const uint32_t *mid = reinterpret_cast<const uint32_t *>(&records[sd.record].split[14]);
+            if (q == SUB - 1 && dcsMid15(sd.format, sl.bpl, nb16, mid[0] >> 16))
+            {
+                // the second half of band 15 (1994+, one band per lane)
+                r0 = mid[0] >> 16;
+                r1 = ((mid[1] & 0x3FFu) | DCS_SPLIT_MID15 | (15u << 12)) << 16;
+            }
+            else if (base < nb16)
             {
                 const uint32_t *sp = reinterpret_cast<const uint32_t *>(&records[sd.record].split[base - 1]);
                 r0 = sp[0];

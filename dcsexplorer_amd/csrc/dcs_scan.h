@@ -127,6 +127,18 @@ DCS_HD inline void dcsPutSplit(DcsFrameIndex &fi, int band, uint32_t frameStart,
     sp.state = static_cast<uint16_t>((outIdx & 0x1FF) | (subType << 9) | (reuse ? 0x800 : 0));
 }
 
+// 1994+: the decoder state in the MIDDLE of band 15 (32 samples, twice any other band), kept in the two fields of that
+// band's split record that only the 1993 formats use: prv = bits from the frame's first bit to the first code that starts
+// with at least half of the band's samples done, prvDelta = output index there | DCS_MID15_STRADDLE when a two-zeros
+// code carried one sample across the middle.  prv == 0: no such point (the band is empty or the frame ended before it).
+template <class R>
+DCS_HD inline void dcsPutMid15(DcsFrameIndex &fi, uint32_t frameStart, const DcsScan<R> &s, int outIdx, bool straddle)
+{
+    DcsSplit &sp = fi.split[14];
+    sp.prv = static_cast<uint16_t>(s.b.bitPos() - frameStart);
+    sp.prvDelta = static_cast<uint16_t>((outIdx & 0x1FF) | (straddle ? DCS_MID15_STRADDLE : 0u));
+}
+
 // --- 1994+ frame (:1679-2261) -----------------------------------------------------------------
 template <class R>
 DCS_HD void dcsScan94(DcsScan<R> &s, const DcsScanTables &tabs, DcsFrameIndex &fi)
@@ -184,31 +196,46 @@ DCS_HD void dcsScan94(DcsScan<R> &s, const DcsScanTables &tabs, DcsFrameIndex &f
             const int maxBits = T.cbInfo[code] & 0xF;
             const uint16_t *book = T.cb94 + (T.cbInfo[code] >> 4);
             int i = count;
-            // several codes per look while more samples remain than the look covers (so that the "two zeros with one
-            // slot left" case, and every band's last look -- the one that can decide nBytes --, stay with the loop below)
-            if (tabs.multi94 != nullptr)
+            // Band 15 is twice as long as the others: its samples are walked in two halves, and where the second one
+            // starts -- the first code boundary with at least half of the samples done -- is recorded, so that two lanes
+            // can share the band (dcsPutMid15).  Every other band is one piece.
+            for (int piece = band == 15 ? 0 : 1 ; piece < 2 ; ++piece)
             {
-                const uint16_t *multi = tabs.multi94 + (static_cast<size_t>(code - 1) << DCS_MULTI_BITS);
-                for (;;)
+                const int lim = piece == 0 ? count / 2 : 0;         // samples left when the piece is done
+                // several codes per look while more samples remain than the look covers (so that the "two zeros with one
+                // slot left" case, and every band's last look -- the one that can decide nBytes --, stay with the loop below)
+                if (tabs.multi94 != nullptr)
                 {
-                    const uint32_t e = multi[s.b.look(DCS_MULTI_BITS)];
-                    const int steps = static_cast<int>(e >> 8);
-                    if (steps == 0 || steps >= i)
-                        break;
-                    s.b.consume(static_cast<int>(e & 0xFF));
-                    i -= steps;
+                    const uint16_t *multi = tabs.multi94 + (static_cast<size_t>(code - 1) << DCS_MULTI_BITS);
+                    for (;;)
+                    {
+                        const uint32_t e = multi[s.b.look(DCS_MULTI_BITS)];
+                        const int steps = static_cast<int>(e >> 8);
+                        if (steps == 0 || steps >= i - lim)
+                            break;
+                        s.b.consume(static_cast<int>(e & 0xFF));
+                        i -= steps;
+                    }
                 }
-            }
-            for ( ; i != 0 ; --i)
-            {
-                const uint32_t e = book[s.b.peek(maxBits)];
-                s.b.consume(static_cast<int>((e >> 8) & 0x1F));     // (a code is never longer than its book's look-ahead)
-                if ((e >> 13) == 2)
+                for ( ; i > lim ; --i)
                 {
-                    if (i >= 2) --i;
-                    else { s.err |= DCS_FRAME_STOP; i = 1; }        // :2213-2218
+                    const uint32_t e = book[s.b.peek(maxBits)];
+                    s.b.consume(static_cast<int>((e >> 8) & 0x1F));     // (a code is never longer than its book's look-ahead)
+                    if ((e >> 13) == 2)
+                    {
+                        if (i >= 2) --i;
+                        else { s.err |= DCS_FRAME_STOP; i = 1; }        // :2213-2218
+                    }
                 }
+                if (piece == 0)
+                    dcsPutMid15(fi, frameStart, s, outIdx - i * inc, i < lim);
             }
+        }
+        else if (band == 15)
+        {
+            s.b.skipRun(count - count / 2, code);
+            dcsPutMid15(fi, frameStart, s, outIdx - (count / 2) * inc, false);
+            s.b.skipRun(count / 2, code);
         }
         else
         {

@@ -47,6 +47,30 @@ def test_single_stream_every_layout(gpu_ctx, oracle, fmt, profile):
         assert not err.any()
 
 
+def test_band_15_shared_by_two_lanes(gpu_ctx, oracle):
+    """sixteen lanes per frame (4 frames per wavefront): band 15 of a 1994+ frame, twice as long as any other, is unpacked
+    by two lanes, the second starting where the index pass saw the first code boundary past the middle.  Streams with many
+    two-zeros codes, strided and not, so that codes run across the middle in both kinds; against the oracle, and the same
+    PCM from the other two kernel variants."""
+    streams, straddles = [], [0, 0]
+    for fmt in (D.FMT_94_T0, D.FMT_94_T1_S0, D.FMT_94_T1_S3):
+        for k in range(6):
+            s = make_stream(fmt, 90, seed=9900 + fmt * 16 + k, profile=2 if k % 2 else 0, stride_from=16 if k < 3 else 12)
+            idx, info = D.index_stream(os_for(fmt, k), s)
+            straddles[1 if info.header[15] & 0x40 else 0] += int(((idx["split"][:, 14]["prvDelta"] >> 9) & 1).sum())
+            streams.append((os_for(fmt, k), s, 255 - 7 * k, 0x64))
+    assert straddles[0] > 10 and straddles[1] > 10
+    want = oracle_streams(oracle, streams, extra=1)
+    try:
+        for fpw in (4, 8, 16):
+            gpu_ctx.set_frames_per_wave(fpw)
+            pcm, err, _ = gpu_ctx.decode_streams(streams, extra_frames=1)
+            assert_same(pcm, want, "fpw=%d" % fpw)
+            assert not err.any()
+    finally:
+        gpu_ctx.set_frames_per_wave(0)
+
+
 @pytest.mark.parametrize("handoff", [True, False], ids=["handoff", "halo"])
 @pytest.mark.parametrize("fpw", [4, 8, 16])
 def test_frames_per_wave_variants_and_chunk_boundaries(gpu_ctx, oracle, fpw, handoff):

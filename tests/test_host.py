@@ -37,6 +37,30 @@ def test_index_pass_matches_oracle_probes(oracle, fmt):
                (oi["nBytes"], oi["formatType"], oi["formatSubType"], oi["header"])
 
 
+def test_index_pass_records_the_middle_of_band_15():
+    """1994+: band 15 has 32 samples, twice any other band; the index pass notes where its second half starts (the first
+    code boundary with half of the samples done) in the two fields of that band's split record the 1993 formats use, so
+    that two lanes can share the band.  Checked here: position and output index are consistent with the band's own
+    record, a two-zeros code across the middle shows as one sample more, an empty band has no middle."""
+    seen = {"plain": 0, "straddle": 0, "strided_plain": 0, "strided_straddle": 0, "empty": 0}
+    for fmt in (D.FMT_94_T0, D.FMT_94_T1_S0, D.FMT_94_T1_S3):
+        for k in range(6):
+            s = make_stream(fmt, 80, seed=9900 + fmt * 16 + k, profile=2 if k % 2 else 0, stride_from=16 if k < 3 else 12)
+            idx, info = D.index_stream(os_for(fmt, k), s)
+            strided = (info.header[15] & 0x40) != 0
+            for r in idx:
+                sp = r["split"][14]
+                start, mid, st = int(sp["state"]) & 0x1FF, int(sp["prvDelta"]) & 0x1FF, int(sp["prvDelta"]) >> 9
+                if r["bandType"][15] == 0:
+                    assert int(sp["prv"]) == 0 and int(sp["prvDelta"]) == 0
+                    seen["empty"] += 1
+                    continue
+                assert int(sp["bitDelta"]) < int(sp["prv"]) < int(r["nBits"])
+                assert st in (0, 1) and mid == start + 16 + (2 if strided else 1) * st
+                seen[("strided_" if strided else "") + ("straddle" if st else "plain")] += 1
+    assert all(v > 0 for v in seen.values()), seen
+
+
 def test_fast_walk_equals_literal_walk():
     """dcs_index_stream (64-bit window, byte pointer computed, several 1994+ codes per look) against the walk with the
     literal restatement of the reference's reader, one code per look: same records, same StreamInfo incl. nBytes, on
@@ -193,6 +217,7 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
     assert pk.shape[1] == off_pool + pool_dw * 4
     src_bytes = srcs.view(np.uint8).reshape(srcs.size, -1)
     seen = 0
+    n_shared = [0]
     for c in range(pk.shape[0]):
         slots = pk[c, :off_desc].view("<u4").reshape(fpw, 8)
         pool = pk[c, off_pool:].view("<u4")
@@ -215,9 +240,13 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
             # per-lane records: lane q's first band (bits 12..15 of the state word; bit 15 of bitDelta = no bands) with
             # the split record of that band's start.  The lanes cover the bands contiguously, in order: bpl bands each for
             # the 1993 layouts; in a 1994+ frame (bands of 7, 8, 13 x 16 and 32 samples) bands 0 and 1 count as one and
-            # band 15 as two, so with more than one band per lane every lane after the first starts one band later.
+            # band 15 as two, so every lane after the first starts one band later; with one band per lane the last lane
+            # takes the second half of band 15.
             bpl = (int(slots[s, 7]) >> 8) & 0xFF
             nb16 = min(int(sd["idx"]["nBands"]), 16)
+            is94 = int(sd["format"]) >= D.FMT_94_T0
+            mid = sd["idx"]["split"][14]
+            shared15 = is94 and bpl == 1 and nb16 == 16 and int(mid["prv"]) != 0
             bases = [0]
             for q in range(1, sub):
                 rec = pk[c, off_split + 8 * (s + q * fpw): off_split + 8 * (s + q * fpw) + 8].copy()
@@ -225,6 +254,12 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
                     assert not rec.any()
                     continue
                 r16 = rec.view("<u2")
+                if q == sub - 1 and shared15:
+                    # the second half of band 15: where the index pass saw the first code with half of the samples done
+                    assert list(r16) == [int(mid["prv"]), 0, 0, (int(mid["prvDelta"]) & 0x3FF) | 0x800 | (15 << 12)]
+                    assert 0 < int(mid["prv"]) < int(sd["idx"]["nBits"]) and int(mid["prv"]) > int(mid["bitDelta"])
+                    bases.append(15)
+                    continue
                 if r16[0] & 0x8000:
                     assert int(r16[0]) == 0x8000 and not rec[2:].any()
                     bases.append(nb16)
@@ -237,8 +272,11 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
             if bpl != 0:
                 bases.append(nb16)
                 assert all(bases[i] <= bases[i + 1] for i in range(sub))
-                later = 1 if int(sd["format"]) >= D.FMT_94_T0 and bpl > 1 else 0
-                assert bases[:sub] == [min(q * bpl + (later if q else 0), nb16) for q in range(sub)]
+                want = [min(q * bpl + (1 if is94 and q else 0), nb16) for q in range(sub)]
+                if shared15:
+                    want[sub - 1] = 15
+                    n_shared[0] += 1
+                assert bases[:sub] == want
             # the frame's bits, read MSB-first from the pool image at the slot's position, are the stream's
             pool_off = int(slots[s, 5]) >> 16
             bit0 = (so + 2 + hl) * 8 + int(sd["idx"]["bitOff"])
@@ -250,6 +288,7 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
                 assert got == (byte >> (7 - ((bit0 + k) & 7))) & 1
             seen += 1
     assert seen >= jobs.size
+    assert (n_shared[0] > 0) == (fpw == 4)          # one band per lane: band 15 of the 1994+ frames goes to two lanes
 
 
 def test_workload_builders_shape():
