@@ -37,7 +37,12 @@ struct Stamper
 {
 #ifdef DCS_STAMPS
     unsigned long long *p;          // this chunk's 16 stamps; null on every lane but lane 0
+    // (DCS_STAMPS_REALTIME: the 100 MHz clock all compute units share, for a timeline of the launch: tools/timeline.py)
+#ifdef DCS_STAMPS_REALTIME
+    __device__ __forceinline__ void operator()(int k) const { if (p != nullptr) p[k] = __builtin_amdgcn_s_memrealtime(); }
+#else
     __device__ __forceinline__ void operator()(int k) const { if (p != nullptr) p[k] = __builtin_amdgcn_s_memtime(); }
+#endif
 #else
     __device__ __forceinline__ void operator()(int) const { }
 #endif
