@@ -373,6 +373,10 @@ def run_rank(args):
                         "simds": simds, "issue_cycles_per_inst": 4, "kernel_cycles": cycles,
                         "kernel_cycles_source": "in-run: kernel_avg_ms x clock_mhz (probe kernel, dcs_ctx_clock_mhz)",
                         "clock_mhz": clock_mhz, "frac_of_valu_issue_peak": t["SQ_INSTS_VALU"] * 4 / (simds * cycles),
+                        "pricing_note": "every wave64 VALU instruction priced at 4 cycles of its SIMD: what multiplies, SDWA, packed "
+                                        "and other 8-byte encodings take (4.2-4.4 measured, tools/valu_latency.hip); plain 4-byte "
+                                        "VOP1/VOP2 complete in 2.2, so this is an upper estimate of the SIMDs' VALU occupancy and "
+                                        "reaches 1.0 on launches long enough for ramp and tail not to count",
                         "lds_bank_conflict_cycles": t.get("SQ_LDS_BANK_CONFLICT"), "lds_idx_active": t.get("SQ_LDS_IDX_ACTIVE")}
         out = {
             "metric": "bit_exact_int16_pcm_samples_per_sec",

@@ -81,13 +81,21 @@ typedef enum DcsFormat
  * earlier frame (:1715, :2260), and the 1994+/1993b-Type-1 formats delta-code band types (:1833, :2428).
  */
 /* Decoder state at the start of header band k+1, k = 0..14: lets up to 16 lanes unpack one frame in
- * parallel.  The kernel gives a frame 4, 8 or 16 lanes (64 / frames-per-wavefront); lane q takes bands
- * [q * bpl, (q + 1) * bpl) with bpl = ceil(nBands / lanes) and starts from split[q * bpl - 1]. */
+ * parallel.  The kernel gives a frame 4, 8 or 16 lanes (64 / frames-per-wavefront); with bpl = ceil(nBands /
+ * lanes), lane q of a 1993-layout frame takes bands [q * bpl, (q + 1) * bpl) and starts from split[q * bpl - 1];
+ * in a 1994+ frame, whose bands hold 7, 8, 13 x 16 and 32 samples, every lane after the first starts one band
+ * later (bands 0 and 1 count as one, band 15 as two).  The library's packers do the dealing; a caller only
+ * supplies the records. */
 typedef struct DcsSplit
 {
     uint16_t bitDelta;                 /* bits from the frame's first bit to the band's first bit         */
-    uint16_t prv;                      /* 1993 formats: prvInput      (:2317)                             */
-    uint16_t prvDelta;                 /* 1993 formats: prvInputDelta (:2318)                             */
+    uint16_t prv;                      /* 1993 formats: prvInput      (:2317)
+                                          1994+, split[14] only: bits from the frame's first bit to the
+                                          first code of band 15 that starts with half of the band's samples
+                                          done (0: none recorded; then one lane unpacks the whole band)     */
+    uint16_t prvDelta;                 /* 1993 formats: prvInputDelta (:2318)
+                                          1994+, split[14] only: output index at that code (bits 0..8) |
+                                          0x200 when a two-zeros code carried one sample across the middle */
     uint16_t state;                    /* output index (bits 0..8) | band sub-type << 9 (2 bits) |
                                           "reuse type 0" flag << 11 (:2319, :2388)                         */
 } DcsSplit;
