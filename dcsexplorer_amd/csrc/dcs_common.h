@@ -165,11 +165,33 @@ static inline
 #ifdef __HIPCC__
 __host__ __device__
 #endif
-constexpr int dcsLaneFirstBand(int format, int q, int bpl, int nb16)
+constexpr int dcsLaneFirstBand(int format, int q, int bpl, int nbEnd)
 {
+    // OS93a Type 1: eighteen bands of 2, 2, 2, 2, 3, 4, 5, 6, 5, 6, 7, 9, 11, 14, 12, 12, 12, 13 sample pairs
+    // (DCSDecoderNative.cpp:2865).  The lanes of a wavefront walk their k-th bands together, so what counts is the
+    // longest k-th band: {0,1,2} {3,4,5} {6,7} {8,9} ... {16,17} with eight lanes (12 + 14 + 4 pairs; two bands per
+    // lane in order cost 12 + 14 + 12 + 13), {0,1} {2,3} {4} {5} ... {17} with sixteen, {0..6} {7..10} {11..13} {14..17}
+    // with four.  (nbEnd: 18 or the stream's own band count.)
+    if (format == DCS_FMT_93A_T1)
+    {
+        const int b = bpl == 1 ? (q < 2 ? 2 * q : q + 2) : bpl == 2 ? (q < 2 ? 3 * q : 2 * q + 2) : (q == 0 ? 0 : q == 1 ? 7 : q == 2 ? 11 : 14);
+        return b < nbEnd ? b : nbEnd;
+    }
     const int b = q * bpl + ((format >= DCS_FMT_94_T0 && q != 0) ? 1 : 0);
-    return b < nb16 ? b : nb16;
+    return b < nbEnd ? b : nbEnd;
 }
+// the band where the lanes' dealing ends: sixteen header bands, eighteen for OS93a Type 1
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr int dcsDealEnd(int format, int nBands)
+{
+    return format == DCS_FMT_93A_T1 ? (nBands < 18 ? nBands : 18) : (nBands < 16 ? nBands : 16);
+}
+// OS93a Type 1: a lane's first band can be 16 or 17; then this bit of its state word is set and bits 12..15 hold band - 16
+// (the record itself comes from the frame record's bandType bytes, dcs_scan.h)
+#define DCS_SPLIT_BASE16 0x200u
 // state word of a lane that starts in the middle of band 15: output index | DCS_MID15_STRADDLE (bit 9) | this flag
 #define DCS_SPLIT_MID15 0x800u
 #define DCS_MID15_STRADDLE 0x200u

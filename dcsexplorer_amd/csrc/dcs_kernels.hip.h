@@ -1709,10 +1709,13 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
                 {
                     // the packer dealt the bands out (dcsLaneFirstBand): this lane's first
                     // band comes with its split record, its last one is where the next lane of the frame starts
-                    const int myBase = (sp.x & 0x8000u) ? nb16 : static_cast<int>(sp.y >> 28);
+                    const bool f93a = format == DCS_FMT_93A_T1;
+                    const int nbEnd = f93a ? min(nBands, 18) : nb16;
+                    const int myBase = (sp.x & 0x8000u) ? nbEnd
+                                     : static_cast<int>(sp.y >> 28) + ((f93a && (sp.y & (DCS_SPLIT_BASE16 << 16)) != 0) ? 16 : 0);
                     const int nextBase = __shfl(myBase, lane + FPW);
                     Q.bandBase = myBase;
-                    Q.nb = max((q == SUB - 1 ? nb16 : nextBase) - myBase, 0);
+                    Q.nb = max((q == SUB - 1 ? nbEnd : nextBase) - myBase, 0);
                     if (SUB == 16)
                     {
                         // the frame's last lane may hold the second half of band 15; the lane before it then stops there
@@ -1727,10 +1730,19 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
                 }
                 else
                 {
-                    // the same deal as the packer's, worked out here: bpl = ceil(nBands / SUB)
+                    // further sources of a frame: the deal worked out here, bpl = ceil(nBands / SUB) (OS93a Type 1: bands in
+                    // order, the tail handled below)
                     const int bpl = max((nb16 + SUB - 1) / SUB, 1);
-                    Q.bandBase = dcsLaneFirstBand(format, q, bpl, nb16);
-                    Q.nb = (q == SUB - 1 ? nb16 : dcsLaneFirstBand(format, q + 1, bpl, nb16)) - Q.bandBase;
+                    if (format == DCS_FMT_93A_T1)
+                    {
+                        Q.bandBase = min(q * bpl, nb16);
+                        Q.nb = min(max(nb16 - Q.bandBase, 0), bpl);
+                    }
+                    else
+                    {
+                        Q.bandBase = dcsLaneFirstBand(format, q, bpl, nb16);
+                        Q.nb = (q == SUB - 1 ? nb16 : dcsLaneFirstBand(format, q + 1, bpl, nb16)) - Q.bandBase;
+                    }
                 }
                 if (q != 0 && Q.nb != 0)
                 {
@@ -1771,12 +1783,13 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
                 err |= unpack93<R0, BR93>(T, row, br, Q, format, mixMul, is93, stamp);
             if (is93a)
             {
-                // With 16 lanes per frame (one band each) bands 16 and 17 go to the lanes of bands 0 and 1, the two
-                // shortest (their split records travel in the frame record's bandType bytes, dcs_scan.h); with fewer
-                // lanes per frame the lane that holds band 15 takes them as well.
-                constexpr bool kSpreadTail = SUB == 16;
+                // Round 0: the packer dealt all eighteen bands out (dcsLaneFirstBand), a lane walks [bandBase, bandBase + nb).
+                // Further sources of a frame (the deal made above, bands 0..15 in order): with 16 lanes per frame bands 16
+                // and 17 go to the lanes of bands 0 and 1, the two shortest (their split records travel in the frame record's
+                // bandType bytes, dcs_scan.h); with fewer lanes per frame the lane that holds band 15 takes them as well.
+                constexpr bool kSpreadTail = SUB == 16 && !R0;
                 const int end = Q.bandBase + Q.nb;
-                const int end2 = (!kSpreadTail && end >= 16 && nBands > 16) ? nBands : end;
+                const int end2 = (!R0 && SUB != 16 && end >= 16 && nBands > 16) ? nBands : end;
                 const int prv0 = Q.bandBase == 0 ? 0x1A : sx16(Q.prv), out0 = Q.bandBase == 0 ? 0 : Q.outIdx;
                 const int hb0 = static_cast<int>(Q.h0 & 0xFFu);
                 if (pairTableInLds(FPW))

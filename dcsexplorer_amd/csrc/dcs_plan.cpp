@@ -366,9 +366,10 @@ static void packChunks(const DcsSlot *slots, uint32_t c0, uint32_t c1, int fpw, 
             if (bpl == 0)
                 continue;                                   // one lane unpacks the whole frame
             const int nb16 = sd.idx.nBands < 16 ? sd.idx.nBands : 16;
+            const int nbEnd = dcsDealEnd(sd.format, sd.idx.nBands);
             int base[17];
             for (int q = 0 ; q <= sub ; ++q)
-                base[q] = dcsLaneFirstBand(sd.format, q, bpl, nb16);
+                base[q] = dcsLaneFirstBand(sd.format, q, bpl, nbEnd);
             for (int q = 1 ; q < sub ; ++q)
             {
                 DcsSplit rec;
@@ -379,8 +380,14 @@ static void packChunks(const DcsSlot *slots, uint32_t c0, uint32_t c1, int fpw, 
                     rec.bitDelta = sd.idx.split[14].prv;
                     rec.state = static_cast<uint16_t>((sd.idx.split[14].prvDelta & 0x3FFu) | DCS_SPLIT_MID15 | (15u << 12));
                 }
-                else if (base[q] >= nb16)
+                else if (base[q] >= nbEnd)
                     rec.bitDelta = 0x8000u;                 // no bands for this lane
+                else if (base[q] >= 16)
+                {
+                    // OS93a Type 1, bands 16 and 17: their records travel in the frame record's bandType bytes
+                    memcpy(&rec, sd.idx.bandType + (base[q] - 16) * 8, 8);
+                    rec.state = static_cast<uint16_t>((rec.state & 0x0DFFu) | DCS_SPLIT_BASE16 | (static_cast<unsigned>(base[q] - 16) << 12));
+                }
                 else
                 {
                     rec = sd.idx.split[base[q] - 1];

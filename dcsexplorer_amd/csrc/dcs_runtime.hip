@@ -556,7 +556,8 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
         {
             const DcsPlanSrc sd = srcs[sl.firstSrc];
             const int nb16 = sd.nBands < 16 ? sd.nBands : 16;
-            const int base = dcsLaneFirstBand(sd.format, q, sl.bpl, nb16);
+            const int nbEnd = dcsDealEnd(sd.format, sd.nBands);
+            const int base = dcsLaneFirstBand(sd.format, q, sl.bpl, nbEnd);
             uint32_t r0 = 0x8000u, r1 = 0;      // bitDelta bit 15: no bands for this lane
             const uint32_t *mid = reinterpret_cast<const uint32_t *>(&records[sd.record].split[14]);
             if (q == SUB - 1 && dcsMid15(sd.format, sl.bpl, nb16, mid[0] >> 16))
@@ -565,7 +566,17 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
                 r0 = mid[0] >> 16;
                 r1 = ((mid[1] & 0x3FFu) | DCS_SPLIT_MID15 | (15u << 12)) << 16;
             }
-            else if (base < nb16)
+            else if (base >= nbEnd)
+                ;
+            else if (base >= 16)
+            {
+                // OS93a Type 1, bands 16 and 17: their records travel in the frame record's bandType bytes (at byte 8 of
+                // the record, so dword-aligned)
+                const uint32_t *sp = reinterpret_cast<const uint32_t *>(records[sd.record].bandType) + 2 * (base - 16);
+                r0 = sp[0];
+                r1 = (sp[1] & 0x0DFFFFFFu) | (DCS_SPLIT_BASE16 << 16) | (static_cast<uint32_t>(base - 16) << 28);
+            }
+            else
             {
                 const uint32_t *sp = reinterpret_cast<const uint32_t *>(&records[sd.record].split[base - 1]);
                 r0 = sp[0];

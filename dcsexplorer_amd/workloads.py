@@ -161,7 +161,20 @@ def shifted(fn, stream_offset):
     return fn(first=stream_offset)
 
 
+def streams_one_layout(fmt, n_streams=512, n_frames=128, first=0):
+    """diagnostic (tools/per_format.py, tools/stamps.py layout_<k>): one unpack layout on its own, 65 536 frames"""
+    out = []
+    for k in range(first, first + n_streams):
+        s = D.synth_stream(fmt, n_frames, seed=0x5150000 + fmt * 4096 + k, nbands=18 if fmt == D.FMT_93A_T1 else 16,
+                           stride_from=16, profile=k % 3)
+        out.append((D.format_os(fmt, prefer_95=bool(k & 1), prefer_93a=bool(k & 1)), s, 230, 0x64))
+    return out
+
+
 WORKLOADS = {
+    "layout_0": lambda **kw: streams_one_layout(0, **kw), "layout_1": lambda **kw: streams_one_layout(1, **kw),
+    "layout_2": lambda **kw: streams_one_layout(2, **kw), "layout_3": lambda **kw: streams_one_layout(3, **kw),
+    "layout_4": lambda **kw: streams_one_layout(4, **kw), "layout_5": lambda **kw: streams_one_layout(5, **kw),
     "dcs93_4096": streams_dcs93_4096,
     "dcs94_65536": streams_dcs94_65536,
     "mixed_16384": streams_mixed_16384,

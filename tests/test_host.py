@@ -217,7 +217,7 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
     assert pk.shape[1] == off_pool + pool_dw * 4
     src_bytes = srcs.view(np.uint8).reshape(srcs.size, -1)
     seen = 0
-    n_shared = [0]
+    n_shared, n_93a = [0], [0]
     for c in range(pk.shape[0]):
         slots = pk[c, :off_desc].view("<u4").reshape(fpw, 8)
         pool = pk[c, off_pool:].view("<u4")
@@ -245,6 +245,8 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
             bpl = (int(slots[s, 7]) >> 8) & 0xFF
             nb16 = min(int(sd["idx"]["nBands"]), 16)
             is94 = int(sd["format"]) >= D.FMT_94_T0
+            is93a = int(sd["format"]) == D.FMT_93A_T1
+            nb_end = min(int(sd["idx"]["nBands"]), 18) if is93a else nb16
             mid = sd["idx"]["split"][14]
             shared15 = is94 and bpl == 1 and nb16 == 16 and int(mid["prv"]) != 0
             bases = [0]
@@ -262,17 +264,31 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
                     continue
                 if r16[0] & 0x8000:
                     assert int(r16[0]) == 0x8000 and not rec[2:].any()
-                    bases.append(nb16)
+                    bases.append(nb_end)
                     continue
                 base = int(r16[3]) >> 12
-                assert 0 < base < nb16 and base >= bases[-1]
-                r16[3] &= 0x0FFF
-                assert np.array_equal(rec, np.frombuffer(sd["idx"]["split"][base - 1].tobytes(), np.uint8))
+                if is93a and (int(r16[3]) & 0x200):
+                    # OS93a Type 1, a lane that starts at band 16 or 17: the record from the frame record's bandType bytes
+                    base += 16
+                    r16[3] &= 0x0DFF
+                    assert np.array_equal(rec[:6], np.asarray(sd["idx"]["bandType"][(base - 16) * 8:(base - 16) * 8 + 6], np.uint8))
+                    assert int(r16[3]) == (int(sd["idx"]["bandType"][(base - 16) * 8 + 6]) | int(sd["idx"]["bandType"][(base - 16) * 8 + 7]) << 8) & 0x0DFF
+                else:
+                    r16[3] &= 0x0FFF
+                    assert np.array_equal(rec, np.frombuffer(sd["idx"]["split"][base - 1].tobytes(), np.uint8))
+                assert 0 < base < nb_end and base >= bases[-1]
                 bases.append(base)
             if bpl != 0:
-                bases.append(nb16)
+                bases.append(nb_end)
                 assert all(bases[i] <= bases[i + 1] for i in range(sub))
-                want = [min(q * bpl + (1 if is94 and q else 0), nb16) for q in range(sub)]
+                if is93a:
+                    # eighteen bands of 2, 2, 2, 2, 3, 4, 5, 6, 5, 6, 7, 9, 11, 14, 12, 12, 12, 13 sample pairs, dealt so that the
+                    # lanes' k-th bands are of a size
+                    start = {1: lambda q: 2 * q if q < 2 else q + 2, 2: lambda q: 3 * q if q < 2 else 2 * q + 2}.get(bpl, lambda q: (0, 7, 11, 14)[q])
+                    want = [min(start(q), nb_end) for q in range(sub)]
+                    n_93a[0] += 1
+                else:
+                    want = [min(q * bpl + (1 if is94 and q else 0), nb16) for q in range(sub)]
                 if shared15:
                     want[sub - 1] = 15
                     n_shared[0] += 1
@@ -289,6 +305,7 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
             seen += 1
     assert seen >= jobs.size
     assert (n_shared[0] > 0) == (fpw == 4)          # one band per lane: band 15 of the 1994+ frames goes to two lanes
+    assert n_93a[0] > 0
 
 
 def test_workload_builders_shape():

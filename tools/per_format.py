@@ -5,15 +5,13 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import dcsexplorer_amd as D
+from dcsexplorer_amd import workloads
 
 NAMES = {D.FMT_93_T0: "93-T0", D.FMT_93B_T1: "93b-T1", D.FMT_93A_T1: "93a-T1", D.FMT_94_T0: "94-T0", D.FMT_94_T1_S0: "94-T1s0", D.FMT_94_T1_S3: "94-T1s3"}
 ctx = D.Context(0)
 n_streams, n_frames = 512, 128
 for fmt in sorted(NAMES):
-    streams = []
-    for k in range(n_streams):
-        s = D.synth_stream(fmt, n_frames, seed=0x5150000 + fmt * 4096 + k, nbands=18 if fmt == D.FMT_93A_T1 else 16, stride_from=16, profile=k % 3)
-        streams.append((D.format_os(fmt, prefer_95=bool(k & 1), prefer_93a=bool(k & 1)), s, 230, 0x64))
+    streams = workloads.streams_one_layout(fmt, n_streams, n_frames)
     b = D.build_stream_batch(streams)
     line = "%-8s %6d frames, %5.0f bits/frame:" % (NAMES[fmt], b["jobs"].size, float(b["srcs"]["idx"]["nBits"].mean()))
     for fpw in (4, 8, 16):
