@@ -391,6 +391,17 @@ static DcsStatus createBatch(DcsCtx *ctx,
         bool ok = ix.hdrBits <= ix.nBits && ix.nBands <= (sd.format == DCS_FMT_93A_T1 ? 31 : 16);
         for (int k = 0 ; k < 15 && ok ; ++k)
             ok = ix.split[k].bitDelta <= ix.nBits && (ix.split[k].state & 0x1FFu) <= 256u;
+        // the two places a lane can start from besides the band starts: the middle of band 15 of a 1994+ frame
+        // (split[14].prv / .prvDelta) and bands 16 and 17 of an OS93a Type-1 frame (records in the bandType bytes)
+        if (ok && sd.format >= DCS_FMT_94_T0)
+            ok = ix.split[14].prv <= ix.nBits && (ix.split[14].prvDelta & 0x1FFu) <= 256u;
+        if (ok && sd.format == DCS_FMT_93A_T1)
+            for (int k = 0 ; k < 2 && ok ; ++k)
+            {
+                DcsSplit t;
+                memcpy(&t, ix.bandType + 8 * k, sizeof(t));
+                ok = t.bitDelta <= ix.nBits && (t.state & 0x1FFu) <= 256u;
+            }
         if (!ok)
         {
             ctx->lastError = "source " + std::to_string(s) + ": inconsistent frame index record";

@@ -354,6 +354,14 @@ def test_caller_made_index_records_cannot_break_the_launch(gpu_ctx):
     bad["idx"]["split"][3]["state"][2] = 0x1FF                  # output index outside the row
     with pytest.raises(D.DcsError):
         gpu_ctx.decode_batch(batch["blob"], bad, batch["jobs"])
+    bad = srcs.copy()
+    bad["idx"]["split"][7]["prv"][14] = 50000                    # 1994+: the middle of band 15 beyond the frame
+    with pytest.raises(D.DcsError):
+        gpu_ctx.decode_batch(batch["blob"], bad, batch["jobs"])
+    bad = srcs.copy()
+    bad["idx"]["split"][7]["prvDelta"][14] = 0x1F0               # ... its output index outside the row
+    with pytest.raises(D.DcsError):
+        gpu_ctx.decode_batch(batch["blob"], bad, batch["jobs"])
     # swap the records of the two streams (stream offsets stay): self-consistent, but not these bytes' records
     n = 40
     swapped = srcs.copy()
