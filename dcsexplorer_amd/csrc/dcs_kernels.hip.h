@@ -230,12 +230,19 @@ __device__ __forceinline__ int readVlc(BR &br, const uint16_t *fast, const uint1
         br.skip(static_cast<int>((e >> 8) & 0xF));
         return static_cast<int>(e & 0xFF);
     }
+    // the rest of a long code (30 bits at most, dcs_tables.h) bit by bit, from ONE look at the stream: a reader round
+    // trip per bit, on top of the trie's, is what made this path cost 2 900 cycles where any lane of the wavefront took it
     br.skip(8);
+    uint32_t w = br.cur();
+    int n = 0;
     do
     {
-        e = trie[e + br.get(1)];
+        e = trie[e + (w >> 31)];
+        w <<= 1;
+        ++n;
     }
-    while (!(e & 0x8000));
+    while (!(e & 0x8000) && n < 24);
+    br.skip(n);
     return static_cast<int>(e & 0xFF);
 }
 
