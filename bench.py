@@ -304,7 +304,9 @@ def run_rank(args):
     dt = sharding.max_over_ranks(dt, device=None if (args.share_gpu or getattr(args, "gloo_fallback", False)) else "cuda")
 
     # kernel-only average duration by HIP events on the launch stream (roofline denominator)
-    kern_ms = batch.time(max(10, args.steps), stream)
+    # (three runs of K launches, the median: the host now and then falls behind 8-us kernels and an average over one
+    # run then includes the gaps)
+    kern_ms = sorted(batch.time(max(10, args.steps), stream) for _ in range(3))[1]
     clock_mhz = ctx.clock_mhz()             # shader clock under an integer load, measured right behind the timed launches
     algo_bytes = batch.algorithmic_bytes    # payload + stream headers + 56 B per frame + 480 B PCM
 
