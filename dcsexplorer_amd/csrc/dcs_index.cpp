@@ -27,6 +27,7 @@ struct HostFetch
 // (tests/test_host.py holds both against the oracle and the compiled reference), about twice as fast.
 struct WinBits
 {
+    static constexpr bool kAnalytic = true;
     const uint8_t *data;
     size_t len;                 // bytes past it read as zero
     size_t payOff = 0;
@@ -77,6 +78,13 @@ struct WinBits
         win <<= n;
         have -= n;
         pos += static_cast<uint32_t>(n);
+    }
+    // n bits looked at with look() and consumed, counted like n looks of one bit each: the last reaches pos + n
+    void took(int n)
+    {
+        consume(n);
+        any = true;
+        hi = pos > hi ? pos : hi;
     }
     uint32_t get(int n)
     {
@@ -161,7 +169,7 @@ extern "C" DcsStatus dcs_index_stream(DcsOsVersion os, const uint8_t *stream, si
     if (stream == nullptr || len < 3 || os < DCS_OS93A || os > DCS_OS95 || (out == nullptr && cap != 0))
         return DCS_ERR_INVALID_ARG;
     WinBits reader{ stream, len };
-    const DcsScanTables tabs{ &dcsTables().lds, dcsTables().trie94, multi94Table() };
+    const DcsScanTables tabs{ &dcsTables().lds, dcsTables().trie94, multi94Table(), dcsTables().fast94 };
     ArraySink sink{ out, cap };
     DcsScanMem mem;
     const DcsStreamInfo si = dcsScanStream(static_cast<int>(os), reader, tabs, &mem, sink);

@@ -609,10 +609,29 @@ DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint
             return DCS_OK;                          // (no pipeline: the direct path still works)
     }
     *handled = true;
+    // The parts taper: the call ends one part's latency (build, create, upload, kernel, download) after the index pass
+    // has reached the list's last stream, so the last parts are small -- 4 4 4 4 3 2 2 1 twenty-fourths of the frames
+    // (equal parts: 4.6 ms for 65 536 frames, of which 1.45 behind the index pass).
+    static const uint32_t kWeight[kParts] = { 4, 4, 4, 4, 3, 2, 2, 1 };
     uint32_t cut[kParts + 1];
-    DcsStatus st = dcs_partition_streams(frames.data(), nStreams, kParts, cut);
-    if (st != DCS_OK)
-        return st;
+    {
+        uint32_t wSum = 0, wAcc = 0;
+        for (uint32_t r = 0 ; r < kParts ; ++r)
+            wSum += kWeight[r];
+        cut[0] = 0;
+        for (uint32_t r = 1 ; r < kParts ; ++r)
+        {
+            wAcc += kWeight[r - 1];
+            const uint64_t target = first[nStreams] * wAcc / wSum;
+            uint32_t k = static_cast<uint32_t>(std::lower_bound(first.begin(), first.end(), target) - first.begin());
+            // every part keeps at least one stream (nStreams >= 4 * kParts)
+            k = std::max(k, cut[r - 1] + 1);
+            k = std::min(k, nStreams - (kParts - r));
+            cut[r] = k;
+        }
+        cut[kParts] = nStreams;
+    }
+    DcsStatus st = DCS_OK;
     // the index pass over the WHOLE list in one region of the host pool (eight regions of 32 streams each would balance
     // badly over the pool's threads), then the parts go to the workers with their records
     thread_local std::vector<DcsFrameIndex> records;

@@ -1012,6 +1012,7 @@ namespace {
 // maximum of that over every read.
 struct DevBits
 {
+    static constexpr bool kAnalytic = true;
     const uint32_t *blobDw;
     size_t nDw;                 // dwords allocated behind blobDw
     size_t base;                // byte offset of the stream in the blob
@@ -1083,6 +1084,13 @@ struct DevBits
         win <<= n;
         have -= n;
         pos += static_cast<uint32_t>(n);
+    }
+    // n bits looked at with look() and consumed, counted like n looks of one bit each: the last reaches pos + n
+    __device__ void took(int n)
+    {
+        consume(n);
+        any = true;
+        hi = pos > hi ? pos : hi;
     }
     __device__ uint32_t get(int n)
     {
@@ -1161,7 +1169,7 @@ __global__ __launch_bounds__(64, 6) void dcsIndexKernel(const uint32_t *blobDw, 
     DevBits reader{ blobDw, nDw, static_cast<size_t>(loc.off), static_cast<size_t>(loc.len) };
     const uint32_t nf = (reader.byteAt(0) << 8) | reader.byteAt(1);
     DevSink sink{ out + loc.firstRecord, digest != nullptr ? digest + loc.firstRecord : nullptr, nf };
-    const DcsScanTables tabs{ &T, tables->trie94, nullptr };
+    const DcsScanTables tabs{ &T, tables->trie94, nullptr, tables->fast94 };
     infos[k] = dcsScanStream(loc.os, reader, tabs, &mem[threadIdx.x], sink);
 }
 

@@ -27,6 +27,7 @@ struct DcsScanTables
     const DcsLdsTables *lds;
     const uint16_t *trie94;
     const uint16_t *multi94 = nullptr;      // [6][1 << DCS_MULTI_BITS], or null (the device walk: no room in LDS)
+    const uint16_t *fast94 = nullptr;       // first-level table of the 1994+ band-type delta code (dcs_common.h), or null
 };
 
 // MSB-first reader with the reference's look-ahead policy (ROMBitPointer, DCSDecoderNative.h:229-289):
@@ -36,6 +37,7 @@ struct DcsScanTables
 template <class Fetch>
 struct DcsBits
 {
+    static constexpr bool kAnalytic = false;    // the byte pointer is kept, look by look
     Fetch fetch;
     size_t payOff = 0;
     size_t p = 0;
@@ -110,6 +112,32 @@ DCS_HD inline int dcsReadVlc(R &b, const uint16_t *trie)
     return static_cast<int>(e & 0xFF);
 }
 
+// The same through the first-level table: eight bits at a look, the rest of a longer code bit by bit.  For readers that
+// COMPUTE the reference reader's byte pointer (R::kAnalytic: WinBits, DevBits): the tree walk's looks, one bit each, reach
+// as far as the code's last bit, which is what took() records.  The literal reader keeps the walk above.
+template <class R>
+DCS_HD inline int dcsReadVlcFast(R &b, const uint16_t *fast, const uint16_t *trie)
+{
+    if constexpr (R::kAnalytic)
+    {
+        if (fast != nullptr)
+        {
+            uint32_t e = fast[b.look(8)];
+            if (e & 0x8000)
+            {
+                b.took(static_cast<int>((e >> 8) & 0xF));
+                return static_cast<int>(e & 0xFF);
+            }
+            b.took(8);
+            do
+                e = trie[e + b.get(1)];
+            while (!(e & 0x8000));
+            return static_cast<int>(e & 0xFF);
+        }
+    }
+    return dcsReadVlc(b, trie);
+}
+
 template <class R>
 DCS_HD inline void dcsFatal(DcsScan<R> &s) { s.err |= DCS_FRAME_FATAL | DCS_FRAME_STOP; }
 
@@ -161,7 +189,7 @@ DCS_HD void dcsScan94(DcsScan<R> &s, const DcsScanTables &tabs, DcsFrameIndex &f
 
     // frame header: one delta code per populated band (:1780-1834)
     for (int i = 0 ; i < s.nBands ; ++i)
-        s.bandType[i] = static_cast<uint16_t>(s.bandType[i] + dcsReadVlc(s.b, trie94) - 16);
+        s.bandType[i] = static_cast<uint16_t>(s.bandType[i] + dcsReadVlcFast(s.b, tabs.fast94, trie94) - 16);
     fi.hdrBits = static_cast<uint16_t>(s.b.bitPos() - frameStart);
     for (int i = 0 ; i < 16 ; ++i)
         fi.bandType[i] = static_cast<uint8_t>(s.bandType[i] > 255 ? 255 : s.bandType[i]);
@@ -290,7 +318,7 @@ DCS_HD void dcsScan93(DcsScan<R> &s, const DcsScanTables &tabs, DcsFrameIndex &f
             }
             else
             {
-                int v = dcsReadVlc(s.b, T.trie93);
+                int v = dcsReadVlcFast(s.b, T.fast93, T.trie93);
                 if (v < 0x1E)
                     v -= 0x0F;                                      // :2668-2681
                 else
