@@ -122,10 +122,8 @@ typedef const uint32_t __attribute__((address_space(3))) *LdsDwordPtr;
 struct BitReader
 {
     static constexpr bool kDirect = false;
-    uint32_t pa;            // LDS byte address of the pool dword after `nxt`
+    uint32_t pa;            // LDS byte address of the pool dword after `lo`
     uint32_t hi, lo;        // the window: the next 32 bits of the stream are ({hi,lo} >> negpos) & 0xFFFFFFFF
-    uint32_t nxt;           // the pool dword after lo, fetched one refill ahead so that its LDS latency is off
-                            // the per-symbol critical path
     int negpos;             // 0..31: unread bits of the window that lie below the next 32
 
     // A reader never runs more than about 1 KB past where it started (16 bands x 32 symbols x 16 bits), and in
@@ -136,8 +134,7 @@ struct BitReader
     {
         hi = 0;
         lo = pool[0];
-        nxt = pool[1];
-        pa = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsDwordPtr)(pool + 2)));
+        pa = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsDwordPtr)(pool + 1)));
         negpos = 0;
         skip(bitInDword);
     }
@@ -145,42 +142,42 @@ struct BitReader
     __device__ __forceinline__ uint32_t cur() const { return __builtin_amdgcn_alignbit(hi, lo, static_cast<uint32_t>(negpos)); }
     __device__ __forceinline__ uint32_t peek(int n) const { return cur() >> (32 - n); }     // n in 1..32
     // Branch-free advance, n in 0..32.  The pool dword a refill would pull in is read every time (an LDS read costs no
-    // VALU issue and its result is only needed when the window actually moves, 32 bits later); symbol loops
-    // request it at the top of the iteration with prefetch() so that nothing ever waits for it.
+    // VALU issue): symbol loops request it at the top of the iteration with prefetch() and it is there when the
+    // iteration's last instructions, the advance, need it -- the loop waits for its codebook read in between anyway.  (A
+    // third window register that took the dword one refill ahead, so that nothing waited for it, cost one more select
+    // per symbol and bought nothing: 20 instead of 19 instructions.)
     __device__ __forceinline__ uint32_t prefetch() const { return *reinterpret_cast<LdsDwordPtr>(static_cast<uintptr_t>(pa)); }
     __device__ __forceinline__ void skip(int n, uint32_t ahead)
     {
         negpos -= n;
         const bool refill = negpos < 0;
         hi = refill ? lo : hi;
-        lo = refill ? nxt : lo;
-        nxt = refill ? ahead : nxt;
+        lo = refill ? ahead : lo;
         // the address moves on by 4 bytes on a refill: sign bit of negpos, shifted and added in one instruction
         const uint32_t sign = static_cast<uint32_t>(negpos) >> 31;
         asm("v_lshl_add_u32 %0, %1, 2, %0" : "+v"(pa) : "v"(sign));
         negpos &= 31;
     }
-    // the same in seven instructions, for the hottest loop: the subtraction's borrow is the refill condition
+    // the same in six instructions, for the hottest loop: the subtraction's borrow is the refill condition
     // (negpos is kept in 0..31, so "negpos < n" is the unsigned borrow)
     __device__ __forceinline__ void skipTight(uint32_t n, uint32_t ahead)
     {
         uint32_t t;
-        asm("v_sub_co_u32 %4, vcc, %4, %6\n\t"
+        asm("v_sub_co_u32 %3, vcc, %3, %5\n\t"
             "v_cndmask_b32 %0, %0, %1, vcc\n\t"
-            "v_cndmask_b32 %1, %1, %2, vcc\n\t"
-            "v_cndmask_b32 %2, %2, %7, vcc\n\t"
-            "v_lshrrev_b32 %5, 31, %4\n\t"
-            "v_lshl_add_u32 %3, %5, 2, %3\n\t"
-            "v_and_b32 %4, 31, %4"
-            : "+v"(hi), "+v"(lo), "+v"(nxt), "+v"(pa), "+v"(negpos), "=&v"(t)
+            "v_cndmask_b32 %1, %1, %6, vcc\n\t"
+            "v_lshrrev_b32 %4, 31, %3\n\t"
+            "v_lshl_add_u32 %2, %4, 2, %2\n\t"
+            "v_and_b32 %3, 31, %3"
+            : "+v"(hi), "+v"(lo), "+v"(pa), "+v"(negpos), "=&v"(t)
             : "v"(n), "v"(ahead)
             : "vcc");
     }
     __device__ __forceinline__ void skip(int n) { skip(n, prefetch()); }
     __device__ __forceinline__ uint32_t get(int n) { const uint32_t v = peek(n); skip(n); return v; }
-    // where the reader stands, as an LDS bit address (lo is the dword at pa - 8 unless nothing of it has been read),
+    // where the reader stands, as an LDS bit address (lo is the dword at pa - 4 unless nothing of it has been read),
     // and a reader put there: what a band's error path needs to go over the band again
-    __device__ __forceinline__ uint32_t bitAddr() const { return (pa - 8u) * 8u - static_cast<uint32_t>(negpos); }
+    __device__ __forceinline__ uint32_t bitAddr() const { return (pa - 4u) * 8u - static_cast<uint32_t>(negpos); }
     __device__ __forceinline__ void initAt(uint32_t bits)
     {
         init((const uint32_t *)reinterpret_cast<LdsDwordPtr>(static_cast<uintptr_t>((bits >> 5) << 2)), static_cast<int>(bits & 31u));
@@ -439,7 +436,7 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const
     const uint16_t *book = T->cb94;
     int shPeek = 0, shIdx = 0, scale = 0;
     uint32_t incSh = 1;                         // log2 of the bytes from one sample of the band to the next (strided: 4)
-    bool isRaw = false;
+    uint32_t valOff = 0, valWidth = 8;          // where the sample sits in (window's high half | codebook entry)
     for (int round = 0 ; ; ++round)
     {
         // ---- a band that overshot its end: a two-zeros code with one sample left (:2213-2218) --------------------
@@ -495,7 +492,9 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const
             book = reinterpret_cast<const uint16_t *>(T) + (e & 0x7FFu);
             shPeek = static_cast<int>((e >> 11) & 31u);
             shIdx = static_cast<int>((e >> 16) & 31u);
-            isRaw = (e & DCS_B94_RAW) != 0;
+            const bool isRaw = (e & DCS_B94_RAW) != 0;
+            valOff = isRaw ? static_cast<uint32_t>(shPeek) : 0u;
+            valWidth = isRaw ? 32u - static_cast<uint32_t>(shPeek) : 8u;
             // (no band-type code stands for sample code 0 -- dcs_tables.cpp checks it --, so the STOP of :1985-1991 cannot
             // happen: a band is empty, in error, or has `count` samples)
             const bool zeroBand = (e & DCS_B94_ZERO) != 0, fatal = (e & DCS_B94_FATAL) != 0;
@@ -538,11 +537,12 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const
                 const uint32_t ahead = br.prefetch();
                 const uint32_t w = br.cur();
                 const uint32_t e = book[w >> shIdx];
-                const int vr = static_cast<int>(w) >> shPeek;
-                const int vh = static_cast<int>(static_cast<int8_t>(e & 0xFF));
+                // the sample: the entry's low byte, or the window's top `width` bits -- one bit-field extract from
+                // (window's high half | entry), at a position and width that are the band's
+                const int v = __builtin_amdgcn_sbfe(__builtin_amdgcn_perm(w, e, 0x07060100u), valOff, valWidth);
                 const uint32_t step = e >> 13;
                 br.skipTight((e >> 8) & 0x1Fu, ahead);
-                mixAddAt<FIRST>(cell, mul24(isRaw ? vr : vh, scale), mixMul);
+                mixAddAt<FIRST>(cell, mul24(v, scale), mixMul);
                 cell += step << incSh;
             }
             while (cell < roundEnd);
