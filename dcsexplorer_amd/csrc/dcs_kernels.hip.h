@@ -920,14 +920,17 @@ struct BflyRegs
 // every lane, held doubled (DcsDevTables.twA), which makes the products come out as the reference's doubled MR terms
 struct TwScalar { int c2, s2, ns2; };
 struct TwA { TwScalar t[8]; };
-__device__ __forceinline__ void loadTwA(const DcsDevTables *G, TwA &W)
+// The six of them are constants of the format (cos, sin of entries 2..7 of the reference's twiddle table, in 1.15,
+// doubled; dcs_tables.cpp checks them against the table it uploads): written into the code they need no load, no
+// registers across phase 1 and no spills -- as eighteen scalar loads at the kernel's start they were spilled to
+// vector-register lanes and read back, forty instructions per wavefront.
+constexpr int kTwADoubled[8][2] = { { -65536, 0 }, { 0, -65536 }, { -46340, -46340 }, { 46340, -46340 },
+                                    { -60548, -25080 }, { 25080, -60548 }, { -25080, -60548 }, { 60548, -25080 } };
+__device__ __forceinline__ void loadTwA(const DcsDevTables *, TwA &W)
 {
 #pragma unroll
     for (int k = 2 ; k < 8 ; ++k)
-    {
-        const int4 v = *reinterpret_cast<const int4 *>(G->twA[k]);
-        W.t[k] = TwScalar{ v.x, v.y, v.z };
-    }
+        W.t[k] = TwScalar{ kTwADoubled[k][0], kTwADoubled[k][1], -kTwADoubled[k][1] };
 }
 
 // exact rotate, every case handled in line: 15 VALU

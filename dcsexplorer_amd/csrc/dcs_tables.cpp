@@ -166,10 +166,15 @@ DcsDevTables build()
     if (kFftCoef[0x80] != 0x8000 || kFftCoef[0] != 0x0000 || kFftCoef[0x81] != 0x0000 || kFftCoef[1] != 0x8000)
         abort();
     memcpy(t.ovlCoef, kOverlapCoef, sizeof(t.ovlCoef));
+    // (the kernel carries these as constants: kTwADoubled in dcs_kernels.hip.h)
+    static const int kTwAInKernel[8][2] = { { -65536, 0 }, { 0, -65536 }, { -46340, -46340 }, { 46340, -46340 },
+                                            { -60548, -25080 }, { 25080, -60548 }, { -25080, -60548 }, { 60548, -25080 } };
     for (int k = 0 ; k < 8 ; ++k)
     {
         const int c = static_cast<int16_t>(kFftCoef[0x80 + k]), sn = static_cast<int16_t>(kFftCoef[k]);
         t.twA[k][0] = 2 * c; t.twA[k][1] = 2 * sn; t.twA[k][2] = -2 * sn; t.twA[k][3] = 0;
+        if (kTwAInKernel[k][0] != 2 * c || kTwAInKernel[k][1] != 2 * sn)
+            abort();
     }
 
     // per-lane transform constants (see DcsLaneConsts)
