@@ -49,6 +49,8 @@ def parse_args(argv=None):
                     "per frame with the lanes of the other slots idle); 0 = every slot of the kernel variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--clock-settle-ms", type=float, default=50.0, help="run the clock-probe kernel (not a step) this long before the "
+                    "warm-up steps, so that the shader clock has left its idle state when the K steps are timed (0: do not)")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight: the K steps are dealt to this many batch objects "
                     "(same workload), each on a stream of its own, so that launches of different batches overlap on the GPU "
                     "(1 = the contract's back-to-back steps; more is reported as config.inflight, never the default)")
@@ -287,6 +289,13 @@ def run_rank(args):
     lanes = [(batch, stream)] + [(bt, st.cuda_stream) for bt, st in extra]
     share = [args.steps // len(lanes) + (1 if k < args.steps % len(lanes) else 0) for k in range(len(lanes))]
 
+    # The shader clock of an idle MI355X sits at 2.14 GHz and takes about 20 ms of load to reach its 2.4 GHz (the set-up
+    # above is seconds of host work with the GPU idle, and W + K steps of this workload are under a millisecond): the
+    # clock-probe kernel, which is no step, is run for --clock-settle-ms first, so that the K steps are timed at the clock
+    # a job of any length runs at (tools/step_overhead.py: 38.1 us per step without, 35.0 with, 33.9 when K = 200)
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.clock_settle_ms:
+        ctx.clock_mhz()
     for _ in range(args.warmup):
         for bt, st in lanes:
             bt.run(st)
@@ -397,7 +406,7 @@ def run_rank(args):
                        "samples_per_frame": 240, "frames_per_wave": batch.frames_per_wave, "wavefronts_per_launch": batch.num_chunks,
                        "arithmetic": "ADSP-2105 1.15 fixed point, 32-bit integer intermediates",
                        "partition": "range over streams%s, no collective" % (", balanced by frames" if corpus else ""),
-                       "scale": args.scale, "inflight": args.inflight, "frames_per_chunk": args.frames_per_chunk or "all"},
+                       "scale": args.scale, "inflight": args.inflight, "clock_settle_ms": args.clock_settle_ms, "frames_per_chunk": args.frames_per_chunk or "all"},
             **({"share_gpu": "all ranks on GPU 0 (test of the N-rank path on a one-GPU box): not a scaling measurement"} if args.share_gpu else {}),
             "bit_exact": bit_exact,
             "bit_exact_note": bit_exact_note,
