@@ -137,11 +137,12 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
             raise D.DcsError(st)
     for _ in range(3):
         one_call()                                              # buffers of the context's cache exist from here on
-    reps = 5
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    calls = []
+    for _ in range(9):
+        t0 = time.perf_counter()
         one_call()
-    cold_s = (time.perf_counter() - t0) / reps
+        calls.append(time.perf_counter() - t0)
+    cold_s = sorted(calls)[len(calls) // 2]                     # the median call (one in ten meets a page-fault storm or a busy host)
 
     def sustained(depth, on_device, pack_on_device=False):
         pipe = ctx.pipeline(depth, index_on_device=on_device, pack_on_device=pack_on_device)
@@ -175,7 +176,7 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
     samples = n_frames * 240
     return {"unit": "samples/s", "frames_per_list": n_frames,
             "cold": {"value": samples / cold_s, "ms_per_list": cold_s * 1e3,
-                     "what": "dcs_decode_streams, one synchronous call per list into pageable memory: index + parameters + plan + pack + "
+                     "what": "dcs_decode_streams, one synchronous call per list into pageable memory (median of nine calls): index + parameters + plan + pack + "
                              "H2D + kernel + D2H (a list this large goes through the context's own pipeline in eight parts)"},
             "sustained": dict(best, what="dcs_pipeline, the fastest of the three configurations below: lists in flight, PCM "
                                          "returned in pinned memory, collected in submission order"),
