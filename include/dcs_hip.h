@@ -100,8 +100,8 @@ typedef struct DcsSplit
                                           "reuse type 0" flag << 11 (:2319, :2388)                         */
 } DcsSplit;
 
-#define DCS_IDX_SERIAL 1u              /* flags: do not split this frame (a band raised an error, or the
-                                          layout has no split points: OS93a Type 1)                        */
+#define DCS_IDX_SERIAL 1u              /* flags: do not split this frame (a band raised an error): one lane
+                                          unpacks all of it                                                */
 
 typedef struct DcsFrameIndex
 {
