@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Seeded fuzz of the decode path on a GPU box: lists of random streams (every layout, 1..18 bands, strided from a random
 band, four symbol profiles, some with flipped payload bits or cut short) decoded with 4, 8 and 16 frames per wavefront
-and held against the oracle, PCM and error words.  argv[1]: seconds to run (default 120), argv[2]: first seed."""
+and held against the oracle; every fourth seed also a multi-channel mix of 2..6 streams on one decoder.  argv[1]: seconds to run (default 120), argv[2]: first seed."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,12 +9,13 @@ import numpy as np
 import dcsexplorer_amd as D
 from oracle.dcs_oracle import Oracle
 from util import ALL_FORMATS, FORMAT_NAMES, make_stream, os_for, corrupt, splitmix
+from mixer_ref import build_mix_batch
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 orc = Oracle()
 ctx = D.Context(0)
-t0 = time.time(); lists = frames = 0; seed = seed0
+t0 = time.time(); lists = frames = mixes = 0; seed = seed0
 by_fmt = {f: 0 for f in ALL_FORMATS}
 while time.time() - t0 < budget:
     g = splitmix(0xF022 + seed)
@@ -52,6 +53,35 @@ while time.time() - t0 < budget:
             bad = np.argwhere(pcm != want) if pcm.shape == want.shape else None
             print("MISMATCH seed %d fpw %d: %s" % (seed, fpw, "shape" if bad is None else "%d samples in %d frames, first frame %d" % (len(bad), len(set(bad[:, 0])), bad[0][0])))
             sys.exit(1)
-    lists += 1; frames += want.shape[0]; seed += 1
-print("fuzz: %d lists (%d frames x 3 kernel variants) in %.0f s, seeds %d..%d, all bit-exact; streams by layout: %s" %
-      (lists, frames, time.time() - t0, seed0, seed - 1, {FORMAT_NAMES[f]: n for f, n in by_fmt.items()}))
+    lists += 1; frames += want.shape[0]
+    # every fourth seed also a multi-channel mix: 2..6 streams of one OS version on the channels of one decoder (the
+    # further sources of a frame take the kernel's general path, whose deal of the bands is made in the kernel)
+    if seed % 4 == 0:
+        os_ = [D.OS93A, D.OS93B, D.OS94, D.OS95][next(g) % 4]
+        fmts = {D.OS93A: [D.FMT_93_T0, D.FMT_93A_T1], D.OS93B: [D.FMT_93_T0, D.FMT_93B_T1]}.get(os_, [D.FMT_94_T0, D.FMT_94_T1_S0, D.FMT_94_T1_S3])
+        nch = 2 + next(g) % 5
+        chans, levels = [], []
+        for c in range(nch):
+            fmt = fmts[next(g) % len(fmts)]
+            nb_max = 18 if fmt == D.FMT_93A_T1 else 16
+            nbands = nb_max if next(g) % 3 else 1 + next(g) % nb_max
+            stride_from = 16 if next(g) % 2 else next(g) % 16
+            if fmt == D.FMT_93_T0 and stride_from < 16:
+                nbands = min(nbands, 12)
+            chans.append(make_stream(fmt, 4 + next(g) % 40, seed=(seed << 8) + 100 + c, profile=next(g) % 4, stride_from=stride_from, nbands=nbands))
+            levels.append(0x20 + next(g) % 0x60)
+        vol = 128 + next(g) % 128
+        n_out = max((c[0] << 8) | c[1] for c in chans) + 2
+        b = build_mix_batch(os_, vol, chans, levels, n_out)
+        want = orc.decode(os_, vol, chans, levels, n_out)
+        for fpw in (4, 8, 16):
+            ctx.set_frames_per_wave(fpw)
+            pcm, err = ctx.decode_batch(b["blob"], b["srcs"], b["jobs"])
+            if not np.array_equal(pcm, want):
+                bad = np.argwhere(pcm != want)
+                print("MISMATCH (mix of %d) seed %d fpw %d: %d samples in %d frames, first frame %d" % (nch, seed, fpw, len(bad), len(set(bad[:, 0])), bad[0][0]))
+                sys.exit(1)
+        mixes += 1; frames += n_out
+    seed += 1
+print("fuzz: %d lists and %d multi-channel mixes (%d frames x 3 kernel variants) in %.0f s, seeds %d..%d, all bit-exact; streams by layout: %s" %
+      (lists, mixes, frames, time.time() - t0, seed0, seed - 1, {FORMAT_NAMES[f]: n for f, n in by_fmt.items()}))
