@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Seeded fuzz of the decode path on a GPU box: lists of random streams (every layout, 1..18 bands, strided from a random
 band, four symbol profiles, some with flipped payload bits or cut short) decoded with 4, 8 and 16 frames per wavefront
-and held against the oracle; every fourth seed also a multi-channel mix of 2..6 streams on one decoder.  argv[1]: seconds to run (default 120), argv[2]: first seed."""
+and held against the oracle, the device's index pass held against the host's; every fourth seed also a multi-channel mix of 2..6 streams on one decoder.  argv[1]: seconds to run (default 120), argv[2]: first seed."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -43,6 +43,12 @@ while time.time() - t0 < budget:
     except Exception as e:
         print("seed %d: oracle refused a stream (%s); skipped" % (seed, e)); seed += 1; continue
     want = np.concatenate(ref)
+    # the index pass on the device (one lane per stream) against the host walk: same records, same StreamInfo
+    host = D.index_streams(streams)
+    dev = ctx.index_streams_gpu(streams)
+    for k, ((hr, hi), (dr, di)) in enumerate(zip(host, dev)):
+        if hr.tobytes() != dr.tobytes() or bytes(hi) != bytes(di):
+            print("MISMATCH (index pass) seed %d stream %d" % (seed, k)); sys.exit(1)
     for fpw in (4, 8, 16):
         ctx.set_frames_per_wave(fpw)
         try:
