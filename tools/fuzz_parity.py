@@ -15,7 +15,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 orc = Oracle()
 ctx = D.Context(0)
-t0 = time.time(); lists = frames = mixes = 0; seed = seed0
+t0 = t_said = time.time(); lists = frames = mixes = 0; seed = seed0
 by_fmt = {f: 0 for f in ALL_FORMATS}
 while time.time() - t0 < budget:
     g = splitmix(0xF022 + seed)
@@ -89,5 +89,8 @@ while time.time() - t0 < budget:
                 sys.exit(1)
         mixes += 1; frames += n_out
     seed += 1
+    if time.time() - t_said > 30:               # (a line now and then: a silent command is taken to be hung)
+        t_said = time.time()
+        print("  ... %d lists, %d mixes, %.0f s" % (lists, mixes, t_said - t0), flush=True)
 print("fuzz: %d lists and %d multi-channel mixes (%d frames x 3 kernel variants) in %.0f s, seeds %d..%d, all bit-exact; streams by layout: %s" %
       (lists, mixes, frames, time.time() - t0, seed0, seed - 1, {FORMAT_NAMES[f]: n for f, n in by_fmt.items()}))
