@@ -42,6 +42,7 @@ struct DcsLdsTables
     // that turns the next 32 bits into the codebook index (16..20) | DCS_B94_RAW | _ZERO | _STOP | _FATAL | scale
     // adjustment << 25.
     uint32_t band94[72];
+    uint16_t scale64[64];               // scale factor of a band by the low six bits of its scale code (:1978-1979, :2342)
 };
 #define DCS_B94_RAW      (1u << 21)     // fixed-width samples (sample codes 7..16)
 #define DCS_B94_ZERO     (1u << 22)     // nothing coded (:1886)

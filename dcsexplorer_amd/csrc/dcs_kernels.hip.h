@@ -370,13 +370,12 @@ __device__ __forceinline__ void mixSub(uint16_t *cell, int scaledProduct, uint32
     *cell = static_cast<uint16_t>(*cell - c);
 }
 
-// scale factor of a band (:1978-1979, :2342): mantissa {0x8000, 0x9838, 0xB505, 0xD745}[code & 3] >> (15 - ((code >> 2) & 15)).
-// The four mantissas come out of two register constants (no table read on the band set-up's critical path).
-__device__ __forceinline__ uint32_t scaleFactor(const DcsLdsTables *, int code)
+// scale factor of a band (:1978-1979, :2342): mantissa {0x8000, 0x9838, 0xB505, 0xD745}[code & 3] >> (15 - ((code >> 2) & 15)),
+// one read of the 64-entry table (ten instructions as arithmetic on two register constants; the read's latency is hidden
+// where several wavefronts share the SIMD and costs nothing measurable where one has it to itself)
+__device__ __forceinline__ uint32_t scaleFactor(const DcsLdsTables *T, int code)
 {
-    const uint32_t pair = (code & 2) ? 0xD745B505u : 0x98388000u;
-    const uint32_t mant = (code & 1) ? pair >> 16 : pair & 0xFFFFu;
-    return mant >> (15 - ((code >> 2) & 15));
+    return T->scale64[code & 63];
 }
 
 __device__ __forceinline__ void dcFixup(uint16_t *row, uint32_t saved1)

@@ -157,7 +157,9 @@ DcsDevTables build()
     for (int i = 0 ; i < 18 ; ++i)
         t.lds.inputs93a[i] = kInputsPerBand93a[i];
     memcpy(t.lds.scaleMant, kScaleMant, sizeof(t.lds.scaleMant));
-    // the kernel's scaleFactor() carries the four mantissas as register constants
+    for (int c = 0 ; c < 64 ; ++c)
+        t.lds.scale64[c] = static_cast<uint16_t>(kScaleMant[c & 3] >> (15 - ((c >> 2) & 15)));
+    // (unpack93a in the kernel derives its own constants from the second mantissa)
     if (kScaleMant[0] != 0x8000 || kScaleMant[1] != 0x9838 || kScaleMant[2] != 0xB505 || kScaleMant[3] != 0xD745)
         abort();
     memcpy(t.pair93a, kPair93a, sizeof(t.pair93a));
