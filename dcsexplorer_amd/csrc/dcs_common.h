@@ -24,17 +24,14 @@
 
 struct DcsLdsTables
 {
+    // ---- what the decode kernel stages (the first DCS_LDS_DECODE_BYTES) -----------------------------------------------
     uint16_t cb94[DCS_CB94_TOTAL];      // entry = sample (signed byte, 0 for the two-zeros code) | nBits<<8 | step<<13
                                         // (step = samples the code stands for: 1, or 2 for two zeros; .cpp:2046-2175)
-    uint16_t cbInfo[8];                 // per sample code 1..6: maxBits | (base offset into cb94)<<4
     uint16_t fast93[256];
     uint16_t trie93[DCS_TRIE93_MAX];
-    uint16_t xlat94[48];                // [band class 0..2][code] = typeCode | scalingAdj<<8 (:1926-1953)
-    uint8_t  preAdj94[32];              // [0..15] sub-type 0 map, [16..31] sub-type 1..3 map (:1744-1749)
     uint16_t bandBits93a[64];           // bandBits (0xFF = end of frame) | prefixBits<<8 (:2878-2902)
     uint16_t scaleCb93a[80];            // value (0xFF = escape) | nBits<<8 | subTable<<12 (:2938-2959)
     uint8_t  inputs93a[24];             // inputs per band, 18 used (:2865)
-    uint16_t scaleMant[4];              // 0x8000, 0x9838, 0xB505, 0xD745 (:1978)
     uint16_t raw94[20];                 // two-entry "codebooks" of the fixed-width sample codes 7..16: width<<8 | 1<<13
     // Everything the 1994+ band set-up derives from a band-type code (:1886-2005), resolved once (dcs_tables.cpp) so that
     // the kernel's set-up is one look-up: [0..50] Type 1, [band class 0..2][min(code, 16)]; [51..68] Type 0, [min(code, 17)].
@@ -43,7 +40,17 @@ struct DcsLdsTables
     // adjustment << 25.
     uint32_t band94[72];
     uint16_t scale64[64];               // scale factor of a band by the low six bits of its scale code (:1978-1979, :2342)
+    uint8_t  padDecode_[8];
+    // ---- the index walk only (dcs_scan.h; the index kernel stages the whole block) ---------------------------------------
+    uint16_t cbInfo[8];                 // per sample code 1..6: maxBits | (base offset into cb94)<<4
+    uint16_t xlat94[48];                // [band class 0..2][code] = typeCode | scalingAdj<<8 (:1926-1953)
+    uint8_t  preAdj94[32];              // [0..15] sub-type 0 map, [16..31] sub-type 1..3 map (:1744-1749)
+    uint16_t scaleMant[4];              // 0x8000, 0x9838, 0xB505, 0xD745 (:1978)
+    uint8_t  pad_[8];
 };
+// (gfx950 hands LDS out in 1 280-byte pieces: with 16 frames per wavefront a workgroup's 4 x 12 576 bytes leave 3 456
+// for the tables if three workgroups are to share a CU)
+#define DCS_LDS_DECODE_BYTES 3424
 #define DCS_B94_RAW      (1u << 21)     // fixed-width samples (sample codes 7..16)
 #define DCS_B94_ZERO     (1u << 22)     // nothing coded (:1886)
 #define DCS_B94_STOP     (1u << 23)     // sample code 0 behind a non-zero band-type code (:1985-1991)

@@ -68,7 +68,7 @@ __host__ __device__ constexpr int waveLdsBytes(int fpw) { return fpw * kRowBytes
 __host__ __device__ constexpr bool pairTableInLds(int fpw) { return fpw <= 8; }
 __host__ __device__ constexpr int ldsBytes(int fpw)
 {
-    return static_cast<int>(sizeof(DcsLdsTables)) + kWavesPerBlock * waveLdsBytes(fpw) + (pairTableInLds(fpw) ? 4096 : 0);
+    return DCS_LDS_DECODE_BYTES + kWavesPerBlock * waveLdsBytes(fpw) + (pairTableInLds(fpw) ? 4096 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1418,8 +1418,8 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     const int lane = static_cast<int>(threadIdx.x) & 63;
     constexpr int kPoolBytes = poolDwords(FPW) * 4, kTileBytes = FPW * kRowBytes + (FPW + 1) * 32;
     static_assert(kPoolBytes % 16 == 0 && kWavesPerBlock * kTileBytes >= 8192, "LDS layout");
-    const Lds<FPW> L{ smem, smem + sizeof(DcsLdsTables) + kWavesPerBlock * kPoolBytes + wave * kTileBytes,
-                      smem + sizeof(DcsLdsTables) + wave * kPoolBytes };
+    const Lds<FPW> L{ smem, smem + DCS_LDS_DECODE_BYTES + kWavesPerBlock * kPoolBytes + wave * kTileBytes,
+                      smem + DCS_LDS_DECODE_BYTES + wave * kPoolBytes };
     const uint32_t chunk = blockIdx.x * kWavesPerBlock + static_cast<uint32_t>(wave);
 #ifdef DCS_STAMPS
     const Stamper stamp{ (lane == 0 && a.debug != nullptr && chunk < a.nChunks) ? a.debug + static_cast<size_t>(chunk) * 16 : nullptr };
@@ -1476,7 +1476,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     {
         // one 16-byte piece of the tables per thread, requested (unconditionally, see above) before the tile is cleared:
         // the clearing needs nothing from memory and runs while all these loads are in flight
-        constexpr int kTableVec = static_cast<int>(sizeof(DcsLdsTables) / 16);
+        constexpr int kTableVec = DCS_LDS_DECODE_BYTES / 16;
         static_assert(kTableVec <= 64 * kWavesPerBlock, "one piece of the tables per thread");
         const uint4 piece = reinterpret_cast<const uint4 *>(&a.tables->lds)[min(static_cast<int>(threadIdx.x), kTableVec - 1)];
         // batches with OS93a Type-1 frames: the 4 KB sample-pair table, one 16-byte piece per thread (a uniform branch)

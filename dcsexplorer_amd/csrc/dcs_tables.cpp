@@ -216,6 +216,7 @@ const DcsDevTables &dcsTables()
 }
 
 static_assert(sizeof(DcsLdsTables) % 16 == 0, "LDS table block must be a multiple of 16 bytes");
+static_assert(DCS_LDS_DECODE_BYTES % 16 == 0 && DCS_LDS_DECODE_BYTES == offsetof(DcsLdsTables, cbInfo), "the decode kernel stages the block up to the index walk's tables");
 static_assert(offsetof(DcsDevTables, lane94) % 16 == 0 && offsetof(DcsDevTables, lane93) % 16 == 0 && offsetof(DcsDevTables, twA) % 16 == 0, "lane constants and twiddles are fetched as uint4");
 static_assert(sizeof(DcsSrcDesc) == 160, "DcsSrcDesc layout");
 static_assert(offsetof(DcsSrcDesc, idx) == 12, "DcsSrcDesc layout");
