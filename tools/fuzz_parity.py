@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Seeded fuzz of the decode path on a GPU box: lists of random streams (every layout, 1..18 bands, strided from a random
 band, four symbol profiles, some with flipped payload bits or cut short) decoded with 4, 8 and 16 frames per wavefront
-and held against the oracle, the device's index pass held against the host's; every fourth seed also a multi-channel mix of 2..6 streams on one decoder.  argv[1]: seconds to run (default 120), argv[2]: first seed."""
+and held against the oracle, the device's index pass held against the host's; every fourth seed also a multi-channel mix of 2..6 streams on one decoder, every eighth the list through dcs_pipeline.  argv[1]: seconds to run (default 120), argv[2]: first seed."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,7 +15,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 orc = Oracle()
 ctx = D.Context(0)
-t0 = t_said = time.time(); lists = frames = mixes = 0; seed = seed0
+t0 = t_said = time.time(); lists = frames = mixes = piped = 0; seed = seed0
+pipes = [ctx.pipeline(3, index_on_device=m >= 1, pack_on_device=m == 2) for m in range(3)]
 by_fmt = {f: 0 for f in ALL_FORMATS}
 while time.time() - t0 < budget:
     g = splitmix(0xF022 + seed)
@@ -60,6 +61,17 @@ while time.time() - t0 < budget:
             print("MISMATCH seed %d fpw %d: %s" % (seed, fpw, "shape" if bad is None else "%d samples in %d frames, first frame %d" % (len(bad), len(set(bad[:, 0])), bad[0][0])))
             sys.exit(1)
     lists += 1; frames += want.shape[0]
+    # every eighth seed the list also goes through dcs_pipeline in its three modes (index pass on the host pool / on the
+    # device / index pass and packer on the device), twice in flight
+    if seed % 8 == 0:
+        ctx.set_frames_per_wave(0)
+        for mode, pipe in enumerate(pipes):
+            pipe.submit(streams, extra_frames=1); pipe.submit(streams, extra_frames=1)
+            for _ in range(2):
+                pcm, err, first, _, _ = pipe.collect()
+                if pcm.shape != want.shape or not np.array_equal(pcm, want):
+                    print("MISMATCH (pipeline mode %d) seed %d" % (mode, seed)); sys.exit(1)
+        piped += 1
     # every fourth seed also a multi-channel mix: 2..6 streams of one OS version on the channels of one decoder (the
     # further sources of a frame take the kernel's general path, whose deal of the bands is made in the kernel)
     if seed % 4 == 0:
@@ -92,5 +104,7 @@ while time.time() - t0 < budget:
     if time.time() - t_said > 30:               # (a line now and then: a silent command is taken to be hung)
         t_said = time.time()
         print("  ... %d lists, %d mixes, %.0f s" % (lists, mixes, t_said - t0), flush=True)
-print("fuzz: %d lists and %d multi-channel mixes (%d frames x 3 kernel variants) in %.0f s, seeds %d..%d, all bit-exact; streams by layout: %s" %
-      (lists, mixes, frames, time.time() - t0, seed0, seed - 1, {FORMAT_NAMES[f]: n for f, n in by_fmt.items()}))
+for pipe in pipes:
+    pipe.close()
+print("fuzz: %d lists (%d of them also through the pipeline's three modes) and %d multi-channel mixes (%d frames x 3 kernel variants) in %.0f s, seeds %d..%d, all bit-exact; streams by layout: %s" %
+      (lists, piped, mixes, frames, time.time() - t0, seed0, seed - 1, {FORMAT_NAMES[f]: n for f, n in by_fmt.items()}))
