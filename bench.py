@@ -308,9 +308,9 @@ def run_rank(args):
         if k:
             bt.run_many(k, st)              # K launches back to back (one step = one launch), issued from C
     torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0           # this rank's K steps are done; the job's time is the MAX of this over the ranks
+    barrier()                               # (the closing bracket; its own latency -- an RCCL all-reduce, 50-100 us against
+    torch.cuda.synchronize()                #  0.7 ms of steps at the driver's K = 20 -- is no part of any rank's K steps)
     dt = sharding.max_over_ranks(dt, device=None if (args.share_gpu or getattr(args, "gloo_fallback", False)) else "cuda")
 
     # kernel-only average duration by HIP events on the launch stream (roofline denominator)
