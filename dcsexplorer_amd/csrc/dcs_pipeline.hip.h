@@ -457,8 +457,12 @@ extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags,
     p->flags = flags;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // with the index pass on the device a worker holds a list only while it works on it, so there need not be one per
-    // list in flight: as many as the host has cores, and a few more for the ones that wait for a copy
-    int nWorkers = (flags & DCS_PIPE_INDEX_ON_DEVICE) ? std::min(depth, dcs_host_threads() + 4) : depth;
+    // list in flight: as many as the host has cores, and a few more for the ones that wait for a copy.  With the packer on
+    // the device as well a list costs a worker under a millisecond of its own work, and what more workers add is contention
+    // inside the HIP runtime: measured with 32 lists in flight on 16 CPUs, 4 to 6 workers 1.65-1.95 ms per list at 7-9 CPU-ms,
+    // 10 workers 1.8-2.4, 20 workers 2.1-2.5 at 18-22 CPU-ms (tools/pipe_trace.py)
+    int nWorkers = (flags & DCS_PIPE_PACK_ON_DEVICE)  ? std::min(depth, std::max(4, dcs_host_threads() / 3))
+                 : (flags & DCS_PIPE_INDEX_ON_DEVICE) ? std::min(depth, dcs_host_threads() + 4) : depth;
     if (const char *w = getenv("DCS_PIPE_WORKERS"))
         nWorkers = std::max(1, std::min(64, atoi(w)));
     int prioLeast = 0, prioGreatest = 0;

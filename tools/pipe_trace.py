@@ -16,6 +16,19 @@ def cpustat():
         return dict(l.split() for l in open('/sys/fs/cgroup/cpu.stat').read().splitlines())
     except Exception:
         return {}
+def threadstat():
+    import glob, collections
+    agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    tck = os.sysconf("SC_CLK_TCK")
+    for t in glob.glob("/proc/self/task/*"):
+        try:
+            comm = open(t + "/comm").read().strip()
+            f = open(t + "/stat").read().rsplit(")", 1)[1].split()
+            agg[comm][0] += 1; agg[comm][1] += int(f[11]) / tck; agg[comm][2] += int(f[12]) / tck
+        except Exception:
+            pass
+    return agg
+th0 = threadstat()
 r0 = resource.getrusage(resource.RUSAGE_SELF); c0 = cpustat()
 t0 = time.perf_counter(); done = 0
 for k in range(n):
@@ -29,15 +42,8 @@ print("ms/list", dt / n * 1e3, "cpu user ms/list", (r1.ru_utime - r0.ru_utime) /
       "throttled_usec/list", (int(c1.get("throttled_usec", 0)) - int(c0.get("throttled_usec", 0))) / n, "nr_throttled", int(c1.get("nr_throttled", 0)) - int(c0.get("nr_throttled", 0)))
 
 
-import glob, collections
-agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-tck = os.sysconf("SC_CLK_TCK")
-for t in glob.glob("/proc/self/task/*"):
-    try:
-        comm = open(t + "/comm").read().strip()
-        f = open(t + "/stat").read().rsplit(")", 1)[1].split()
-        agg[comm][0] += 1; agg[comm][1] += int(f[11]) / tck; agg[comm][2] += int(f[12]) / tck
-    except Exception:
-        pass
-for k, v in sorted(agg.items(), key=lambda x: -x[1][1]):
-    sys.stderr.write("  threads %-18s n=%3d user %.2f s sys %.2f s\n" % (k, v[0], v[1], v[2]))
+# CPU time by thread name over the measured lists only
+th1 = threadstat()
+for k in sorted(th1, key=lambda k: -(th1[k][1] - th0.get(k, [0, 0, 0])[1])):
+    u = th1[k][1] - th0.get(k, [0, 0.0, 0.0])[1]; sy = th1[k][2] - th0.get(k, [0, 0.0, 0.0])[2]
+    sys.stderr.write("  threads %-18s n=%3d user %.2f ms/list sys %.2f ms/list\n" % (k, th1[k][0], u / n * 1e3, sy / n * 1e3))
