@@ -364,6 +364,14 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
         dcs_batch_destroy(job->batch);
         job->batch = nullptr;
     }
+    // A failed list may have left its pack kernel (which reads dBlob and the round's records) in flight: nothing of it
+    // runs any more when those buffers go back to the cache, which knows nothing of streams.  (A list that succeeded has
+    // waited for its PCM, which the worker's stream delivers after everything else.)
+    if (st != DCS_OK)
+    {
+        if (job->batch != nullptr) { dcs_batch_destroy(job->batch); job->batch = nullptr; }
+        (void)streamWait(p->ctx, stream);
+    }
     pipelineFreeIndexBuffers(p, job, false);        // (the packages are on the device: the streams are no longer needed)
     if (st == DCS_OK && job->pcmDst != nullptr)
     {
@@ -433,11 +441,12 @@ static void pipelineWorker(DcsPipeline *p, int id)
             st = pipelineDecode(p, job.get(), stream);
         job->tDone = nowMs();
         if (getenv("DCS_PIPE_TRACE") && job->tIndexed != 0)
+        {
             fprintf(stderr, "pipe life: submit->taken %.2f, upload %.2f, wait for indexer %.2f, index round %.2f, wait for worker %.2f, stage B %.2f\n",
                     job->tTaken - job->tSubmit, job->tQueuedForIndex - job->tTaken, job->tIndexStart - job->tQueuedForIndex,
                     job->tIndexed - job->tIndexStart, job->tStageB - job->tIndexed, job->tDone - job->tStageB);
-        else
-            pipelineFreeIndexBuffers(p, job.get(), false);
+        }
+        pipelineFreeIndexBuffers(p, job.get(), false);      // (a list whose indexer failed still holds them)
         pipelineFinish(p, job, st);
     }
 }
@@ -455,7 +464,12 @@ extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags,
     p->ctx = ctx;
     p->depth = depth;
     p->flags = flags;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (hipSetDevice(ctx->device) != hipSuccess)
+    {
+        delete p;
+        setError(ctx, "dcs_pipeline_create: hipSetDevice failed");
+        return DCS_ERR_HIP;
+    }
     // with the index pass on the device a worker holds a list only while it works on it, so there need not be one per
     // list in flight: as many as the host has cores, and a few more for the ones that wait for a copy.  With the packer on
     // the device as well a list costs a worker under a millisecond of its own work, and what more workers add is contention
@@ -483,7 +497,7 @@ extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags,
         {
             for (hipStream_t t : p->streams) (void)hipStreamDestroy(t);
             delete p;
-            ctx->lastError = "dcs_pipeline_create: hipStreamCreate failed";
+            setError(ctx, "dcs_pipeline_create: hipStreamCreate failed");
             return DCS_ERR_HIP;
         }
         p->streams.push_back(s);

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <mutex>
 #include <unordered_set>
+#include <unordered_map>
 #include "dcs_common.h"
 #include "dcs_kernels.hip.h"
 #include "dcs_scan.h"
@@ -29,7 +30,8 @@ struct DcsCtx
     std::mutex cacheMutex;              // the buffer cache is shared by the pipeline's worker threads
     struct DcsPipeline *internalPipe = nullptr;     // dcs_decode_streams takes large lists through it in parts (dcs_pipeline.hip.h)
     int numCUs = 256;
-    std::string lastError;
+    std::string lastError;              // written through setError only (the pipeline's threads fail concurrently)
+    std::mutex errMutex;
     // inputs of the last dcs_index_streams_gpu call, resident for dcs_index_streams_gpu_time
     uint32_t *dIdxBlob = nullptr;
     DcsStreamLoc *dIdxLocs = nullptr;
@@ -44,6 +46,9 @@ struct DcsCtx
     struct Cached { void *p; size_t cap; };
     std::vector<Cached> devCache, pinCache;
     size_t cachedBytes = 0;
+    // real size of every buffer handed out by cacheAlloc (a reused buffer may be up to twice what was asked for; the
+    // callers only remember what they asked for, and the cache must account for what it really holds)
+    std::unordered_map<void *, size_t> liveCap;
 };
 
 static const size_t kCacheLimit = size_t(4) << 30;     // bytes kept per context, device + pinned
@@ -60,11 +65,18 @@ static hipError_t cacheAlloc(DcsCtx *ctx, bool pinned, void **out, size_t bytes)
     {
         *out = c[best].p;
         ctx->cachedBytes -= c[best].cap;
+        ctx->liveCap[c[best].p] = c[best].cap;
         c.erase(c.begin() + static_cast<long>(best));
         return hipSuccess;
     }
     lock.unlock();
-    return pinned ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+    const hipError_t e = pinned ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+    if (e == hipSuccess)
+    {
+        lock.lock();
+        ctx->liveCap[*out] = bytes;
+    }
+    return e;
 }
 
 static void cacheFree(DcsCtx *ctx, bool pinned, void *p, size_t cap)
@@ -72,6 +84,12 @@ static void cacheFree(DcsCtx *ctx, bool pinned, void *p, size_t cap)
     if (p == nullptr)
         return;
     std::lock_guard<std::mutex> lock(ctx->cacheMutex);
+    const auto live = ctx->liveCap.find(p);
+    if (live != ctx->liveCap.end())
+    {
+        cap = live->second;             // what the buffer really holds, not what its last user asked for
+        ctx->liveCap.erase(live);
+    }
     if (ctx->cachedBytes + cap > kCacheLimit)
     {
         if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
@@ -90,17 +108,25 @@ static hipError_t streamWait(DcsCtx *ctx, hipStream_t stream)
 {
     if (!tlsBlockingWaits)
         return hipStreamSynchronize(stream);
-    thread_local hipEvent_t ev = nullptr;
-    thread_local int evDevice = -1;
-    if (ev == nullptr || evDevice != ctx->device)
+    // one blocking event per thread and device, destroyed when the thread ends (pipeline workers and indexers come and
+    // go with their pipeline)
+    struct ThreadEvent
     {
-        const hipError_t e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+        hipEvent_t ev = nullptr;
+        int device = -1;
+        ~ThreadEvent() { if (ev != nullptr) (void)hipEventDestroy(ev); }
+    };
+    thread_local ThreadEvent te;
+    if (te.ev == nullptr || te.device != ctx->device)
+    {
+        if (te.ev != nullptr) { (void)hipEventDestroy(te.ev); te.ev = nullptr; }
+        const hipError_t e = hipEventCreateWithFlags(&te.ev, hipEventBlockingSync | hipEventDisableTiming);
         if (e != hipSuccess)
             return e;
-        evDevice = ctx->device;
+        te.device = ctx->device;
     }
-    const hipError_t e = hipEventRecord(ev, stream);
-    return e != hipSuccess ? e : hipEventSynchronize(ev);
+    const hipError_t e = hipEventRecord(te.ev, stream);
+    return e != hipSuccess ? e : hipEventSynchronize(te.ev);
 }
 
 struct DcsBatch
@@ -148,6 +174,18 @@ static hipError_t waitLaunched(DcsBatch *b)
 }
 
 static std::string g_createError;
+static std::mutex g_createErrorMutex;
+
+static void setError(DcsCtx *ctx, const std::string &text)
+{
+    std::lock_guard<std::mutex> lock(ctx->errMutex);
+    ctx->lastError = text;
+}
+static void setCreateError(const std::string &text)
+{
+    std::lock_guard<std::mutex> lock(g_createErrorMutex);
+    g_createError = text;
+}
 
 #define HIPCHK(ctx, call)                                                                        \
     do {                                                                                         \
@@ -155,7 +193,7 @@ static std::string g_createError;
         if (e_ != hipSuccess) {                                                                  \
             char buf_[256];                                                                      \
             snprintf(buf_, sizeof(buf_), "%s failed: %s", #call, hipGetErrorString(e_));         \
-            (ctx)->lastError = buf_;                                                             \
+            setError((ctx), buf_);                                                               \
             return DCS_ERR_HIP;                                                                  \
         }                                                                                        \
     } while (0)
@@ -172,7 +210,19 @@ extern "C" int dcs_device_count(void)
 
 extern "C" const char *dcs_last_error(const DcsCtx *ctx)
 {
-    return ctx ? ctx->lastError.c_str() : g_createError.c_str();
+    // a copy owned by the calling thread: the string itself may be rewritten by a pipeline thread at any time
+    thread_local std::string copy;
+    if (ctx != nullptr)
+    {
+        std::lock_guard<std::mutex> lock(const_cast<DcsCtx *>(ctx)->errMutex);
+        copy = ctx->lastError;
+    }
+    else
+    {
+        std::lock_guard<std::mutex> lock(g_createErrorMutex);
+        copy = g_createError;
+    }
+    return copy.c_str();
 }
 
 extern "C" DcsStatus dcs_ctx_create(int deviceId, DcsCtx **out)
@@ -184,23 +234,23 @@ extern "C" DcsStatus dcs_ctx_create(int deviceId, DcsCtx **out)
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
     {
-        g_createError = "no HIP device available (this library has no CPU fallback)";
+        setCreateError("no HIP device available (this library has no CPU fallback)");
         return DCS_ERR_NO_DEVICE;
     }
     if (deviceId < 0 || deviceId >= n)
     {
-        g_createError = "device id out of range";
+        setCreateError("device id out of range");
         return DCS_ERR_INVALID_ARG;
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, deviceId) != hipSuccess)
     {
-        g_createError = "hipGetDeviceProperties failed";
+        setCreateError("hipGetDeviceProperties failed");
         return DCS_ERR_NO_DEVICE;
     }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     {
-        g_createError = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+        setCreateError(std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
         return DCS_ERR_NO_DEVICE;
     }
 
@@ -221,7 +271,7 @@ extern "C" DcsStatus dcs_ctx_create(int deviceId, DcsCtx **out)
     }();
     if (st != DCS_OK)
     {
-        g_createError = ctx->lastError;
+        setCreateError(dcs_last_error(ctx));
         dcs_ctx_destroy(ctx);
         return st;
     }
@@ -358,7 +408,7 @@ static DcsStatus createBatch(DcsCtx *ctx,
         if (jb.nSrc > DCS_MAX_CHANNELS || jb.volShift > 8 || jb.xform > DCS_XFORM_94
             || (jb.nSrc != 0 && (jb.firstSrc >= nSrcs || jb.firstSrc + jb.nSrc > nSrcs)))
         {
-            ctx->lastError = "job " + std::to_string(j) + ": bad source range / volShift / xform";
+            setError(ctx, "job " + std::to_string(j) + ": bad source range / volShift / xform");
             return DCS_ERR_INVALID_ARG;
         }
         if (jb.prev != DCS_PREV_NONE)
@@ -366,14 +416,14 @@ static DcsStatus createBatch(DcsCtx *ctx,
             const bool ext = (jb.prev & DCS_PREV_EXT) != 0;
             if (ext ? ((jb.prev & 0x7FFFFFFFu) >= nTailsIn || tailsIn == nullptr) : (jb.prev >= nJobs || jb.prev == j))
             {
-                ctx->lastError = "job " + std::to_string(j) + ": bad overlap predecessor";
+                setError(ctx, "job " + std::to_string(j) + ": bad overlap predecessor");
                 return DCS_ERR_INVALID_ARG;
             }
             // a decoder object has ONE transform (DCSDecoderNative.cpp:3147-3160), so a frame and the frame whose tail
             // it overlaps with share it; the two transforms also publish tails of different word counts
             if (!ext && jobs[jb.prev].xform != jb.xform)
             {
-                ctx->lastError = "job " + std::to_string(j) + ": overlap predecessor uses the other transform";
+                setError(ctx, "job " + std::to_string(j) + ": overlap predecessor uses the other transform");
                 return DCS_ERR_INVALID_ARG;
             }
         }
@@ -383,7 +433,7 @@ static DcsStatus createBatch(DcsCtx *ctx,
         const DcsSrcDesc &sd = srcs[s];
         if (sd.format > DCS_FMT_94_T1_S3 || (sd.hdrLen != 16 && sd.hdrLen != 1) || sd.streamOff + 2 + sd.hdrLen > blobLen)
         {
-            ctx->lastError = "source " + std::to_string(s) + ": bad format / header length / stream offset";
+            setError(ctx, "source " + std::to_string(s) + ": bad format / header length / stream offset");
             return DCS_ERR_INVALID_ARG;
         }
         // the index record steers where lanes start reading and writing inside LDS: it must be self-consistent
@@ -404,7 +454,7 @@ static DcsStatus createBatch(DcsCtx *ctx,
             }
         if (!ok)
         {
-            ctx->lastError = "source " + std::to_string(s) + ": inconsistent frame index record";
+            setError(ctx, "source " + std::to_string(s) + ": inconsistent frame index record");
             return DCS_ERR_INVALID_ARG;
         }
         payloadBits += sd.idx.nBits;
@@ -808,7 +858,7 @@ static DcsStatus launchOnce(DcsBatch *b, hipStream_t stream)
     e = (b->fpw == 16) ? launch<16>(args, stream) : (b->fpw == 8) ? launch<8>(args, stream) : launch<4>(args, stream);
     if (e != hipSuccess)
     {
-        ctx->lastError = std::string("kernel launch failed: ") + hipGetErrorString(e);
+        setError(ctx, std::string("kernel launch failed: ") + hipGetErrorString(e));
         return DCS_ERR_HIP;
     }
     return DCS_OK;
@@ -1026,7 +1076,11 @@ struct DevBits
     size_t nextDw = 0;          // dword index of q0
     uint32_t q0 = 0, q1 = 0;    // prefetched raw dwords
 
-    __device__ uint32_t rawAt(size_t w) const { return w < nDw ? blobDw[w] : 0u; }
+    // (bounded by the STREAM, not only by the allocation: a damaged stream may announce frames far beyond its bytes, and the
+    // pipeline's launch, whose streams are absolute addresses, has no allocation bound at all.  Bytes past the stream read
+    // as zero anyway -- streamBits -- so the records do not change.  The dword that straddles the stream's end is read
+    // whole: every caller pads its blob by at least a dword.)
+    __device__ uint32_t rawAt(size_t w) const { return (w < nDw && w * 4 < base + len) ? blobDw[w] : 0u; }
     __device__ uint32_t byteAt(size_t i) const
     {
         if (i >= len)
@@ -1203,7 +1257,7 @@ extern "C" DcsStatus dcs_index_streams_gpu(DcsCtx *ctx, const uint8_t *blob, siz
         return DCS_ERR_INVALID_ARG;
     if (blob == nullptr || streams == nullptr || nStreams == 0 || out == nullptr || infos == nullptr)
     {
-        ctx->lastError = "dcs_index_streams_gpu: null argument or no streams";
+        setError(ctx, "dcs_index_streams_gpu: null argument or no streams");
         return DCS_ERR_INVALID_ARG;
     }
     // every stream must lie in the blob and its records (at most its U16 frame count) in `out`
@@ -1212,13 +1266,13 @@ extern "C" DcsStatus dcs_index_streams_gpu(DcsCtx *ctx, const uint8_t *blob, siz
         const DcsStreamLoc &l = streams[k];
         if (l.len < 3 || l.off > blobLen || l.len > blobLen - l.off || l.os < DCS_OS93A || l.os > DCS_OS95)
         {
-            ctx->lastError = "dcs_index_streams_gpu: stream " + std::to_string(k) + " outside the blob or bad OS version";
+            setError(ctx, "dcs_index_streams_gpu: stream " + std::to_string(k) + " outside the blob or bad OS version");
             return DCS_ERR_INVALID_ARG;
         }
         const uint64_t nf = (static_cast<uint64_t>(blob[l.off]) << 8) | blob[l.off + 1];
         if (l.firstRecord > outCap || nf > outCap - l.firstRecord)
         {
-            ctx->lastError = "dcs_index_streams_gpu: records of stream " + std::to_string(k) + " do not fit in out";
+            setError(ctx, "dcs_index_streams_gpu: records of stream " + std::to_string(k) + " do not fit in out");
             return DCS_ERR_CAPACITY;
         }
     }
@@ -1255,7 +1309,7 @@ extern "C" DcsStatus dcs_index_streams_gpu_time(DcsCtx *ctx, int iters, float *a
         return DCS_ERR_INVALID_ARG;
     if (ctx->idxStreams == 0)
     {
-        ctx->lastError = "dcs_index_streams_gpu_time: no resident index inputs";
+        setError(ctx, "dcs_index_streams_gpu_time: no resident index inputs");
         return DCS_ERR_INVALID_ARG;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1322,7 +1376,7 @@ extern "C" DcsStatus dcs_ctx_clock_mhz(DcsCtx *ctx, float *mhzOut)
     (void)hipFree(d);
     if (e != hipSuccess)
     {
-        ctx->lastError = std::string("clock probe failed: ") + hipGetErrorString(e);
+        setError(ctx, std::string("clock probe failed: ") + hipGetErrorString(e));
         return DCS_ERR_HIP;
     }
     std::vector<double> ratio;

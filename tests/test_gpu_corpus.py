@@ -182,6 +182,31 @@ def test_pipeline_device_index_with_damaged_and_rom_sized_buffers(gpu_ctx, oracl
     pipe.close()
 
 
+@pytest.mark.parametrize("pack_on_device", [False, True], ids=["host-pack", "device-pack"])
+def test_pipeline_device_index_stream_that_announces_far_more_than_it_holds(gpu_ctx, oracle, pack_on_device):
+    """the LAST stream of a small list claims 65 535 frames, and its header makes the zero bits behind its few bytes parse
+    as valid frames (1993 Type 0: "no sub-type change, code 0" is five zero bits per band), so the device walk goes on for
+    650 KB past the stream: it must read those bytes as zero WITHOUT touching memory behind the stream (the pipeline's
+    launch has no allocation bound: stream locations are absolute addresses).  Same PCM as the synchronous call."""
+    good = [(os_for(f, 1), make_stream(f, 20 + f, seed=88000 + f), 255, 0x64) for f in ALL_FORMATS[:3]]
+    runaway = bytes([0xFF, 0xFF]) + bytes([0x28] * 12 + [0x7F] * 4) + bytes(6)
+    lst = good + [(D.OS93B, runaway, 255, 0x64)]
+    want = gpu_ctx.decode_streams(lst, extra_frames=2)
+    assert want[0].shape[0] == sum(20 + f + 2 for f in range(3)) + 65535 + 2
+    pipe = gpu_ctx.pipeline(2, index_on_device=True, pack_on_device=pack_on_device)
+    for _ in range(2):
+        pipe.submit(lst, extra_frames=2)
+    for _ in range(2):
+        pcm, err, first, _, _ = pipe.collect()
+        assert np.array_equal(first, want[2]) and np.array_equal(err, want[1]) and np.array_equal(pcm, want[0])
+    pipe.close()
+    # ... and through the one-shot device index entry: the records equal the host walk's
+    recs_h, info_h = D.index_stream(D.OS93B, runaway)
+    (recs_d, info_d), = gpu_ctx.index_streams_gpu([(D.OS93B, runaway)])
+    assert info_d.nValidFrames == info_h.nValidFrames == 65535 and info_d.nBytes == info_h.nBytes
+    assert recs_d.tobytes() == recs_h.tobytes()
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2], ids=["host-index", "device-index", "device-index-and-pack"])
 def test_pipeline_reports_a_bad_list_and_carries_on(gpu_ctx, oracle, mode):
     """a list with an unusable stream (zero frames) comes back with an error status in its turn; the lists around it are
