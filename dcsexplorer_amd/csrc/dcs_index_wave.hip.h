@@ -1,0 +1,722 @@
+// dcs_index_wave.hip.h -- the index pass on the device, ONE WAVEFRONT PER STREAM.
+//
+// The walk that finds where every frame of a stream starts (DCSDecoderNative::GetStreamInfo, DCSDecoderNative.cpp:1486-1537)
+// is serial from frame to frame and from band to band, but not inside a band: a band's codebook is fixed once its
+// band-type code is known, so the 64 lanes look up the code that WOULD start at each of the next 64 bit positions at
+// once, and the chain through those candidates -- position += length of the code found there -- is followed on the
+// scalar unit with one v_readlane and one s_add per symbol (no memory or LDS access on the chain).  The same scheme
+// takes the frame header's band-type delta codes (:1780-1834), and the delta / double-delta sample runs of the 1993
+// layouts (:2565-2599) become two wavefront sums.  Everything else of the walk is control flow on values all lanes
+// share: it runs once per wavefront on the scalar unit, the stream's bits come out of a register window (64 + 64
+// dwords of the stream held one per lane, a third block in flight) through v_readlane.
+//
+// What it writes is what the one-lane walker of dcs_scan.h writes on the host (dcs_index_stream): the same
+// DcsFrameIndex per frame, the same DcsStreamInfo including the reference reader's byte pointer (nBytes, computed like
+// WinBits / the former DevBits do: the maximum over all looks of position + width).  tests/ and tools/fuzz_parity.py
+// hold the two against each other on every layout, on damaged and on truncated streams.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dcs_common.h"
+#include "dcs_scan.h"
+
+namespace dcsidx {
+
+constexpr int kWaves = 4;               // wavefronts (= streams) per workgroup; they share the tables in LDS
+constexpr int kRingDw = 256;            // per wavefront: LDS mirror of the register window, for per-lane gathers
+constexpr int kRecDw = 40;              // staging of one record (37 dwords) or one stream summary (12)
+static_assert(sizeof(DcsFrameIndex) == 148 && sizeof(DcsStreamInfo) == 48 && sizeof(DcsFrameDigest) == 8, "record layouts");
+
+struct IndexLds
+{
+    DcsLdsTables T;
+    uint16_t fast94[256];
+    uint16_t trie94[DCS_TRIE94_MAX];
+    uint32_t ring[kWaves][kRingDw];
+    uint32_t rec[kWaves][kRecDw];
+};
+
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(lane))); }
+// v_writelane: two scalar operands are one too many for gfx950's constant bus, and this compiler has no builtin that would
+// route the lane number through M0; a compare and a select do the same
+__device__ __forceinline__ uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t wl(uint32_t old, uint32_t lane, uint32_t val) { return laneId() == lane ? val : old; }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+// lanes exchange data through LDS in program order; the fence keeps the compiler from moving accesses across
+__device__ __forceinline__ void waveSync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sum over the sixteen lanes of a row (all lanes of the row receive it): quad swap, quad-pair swap, half mirror, mirror
+__device__ __forceinline__ uint32_t rowSum16(uint32_t x)
+{
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x140, 0xF, 0xF, true));   // row_mirror
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The stream's bits.  All state but W0..W2 is the same on every lane (the compiler keeps it in scalar registers).
+// Positions count bits from the dword that holds the stream's first byte, so they fit 32 bits whatever the address.
+// Window: lane l of W0 / W1 holds dword B + l / B + 64 + l as 32 MSB-first stream bits (bytes outside the stream
+// zero), W2 the block after, requested when the window last moved and not waited for until it moves again; `ring`
+// mirrors W0 and W1 in LDS for the gathers.  A 64-bit scalar window (win, have) serves the single-field reads.
+// The reference reader's byte pointer (ROMBitPointer, DCSDecoderNative.h:229-289: Peek(n) pulls whole bytes while
+// nBits <= n) is computed, not kept: after Peek(n) at bit position p it stands at floor((p + n) / 8) + 1.
+// ---------------------------------------------------------------------------------------------------------
+struct WaveBits
+{
+    static constexpr bool kAnalytic = true;
+    const uint32_t *sBase;      // the dword that holds the stream's first byte
+    uint32_t endByte;           // bytes from sBase to the stream's end
+    uint32_t nDwValid;          // dwords that hold stream bytes
+    uint32_t payBit = 0;        // first payload bit
+    uint32_t pos = 0;           // payload bits consumed
+    uint32_t hi = 0;            // max over looks of pos + n
+    bool any = false;
+    uint32_t B = 0;
+    uint32_t W0 = 0, W1 = 0, W2 = 0;
+    uint32_t *ring;
+    uint32_t lane;
+    uint64_t win = 0;
+    int have = 0;
+
+    // dword d of the stream as stream bits; nothing behind the stream's last dword is touched (a damaged stream may
+    // announce frames far beyond its bytes; the caller's buffer ends somewhere behind the stream's last dword)
+    __device__ __forceinline__ uint32_t load(uint32_t d) const
+    {
+        uint32_t raw = 0;
+        if (d < nDwValid)
+            raw = sBase[d];
+        const uint32_t lo = d * 4;
+        if (lo + 4 > endByte)
+        {
+            const uint32_t keep = lo >= endByte ? 0u : endByte - lo;        // 0..3 bytes
+            raw &= keep == 0 ? 0u : (0xFFFFFFFFu >> (32 - 8 * keep));
+        }
+        return __builtin_bswap32(raw);
+    }
+    __device__ __forceinline__ void reload()
+    {
+        B = (payBit + pos) >> 5;
+        W0 = load(B + lane);
+        W1 = load(B + 64 + lane);
+        W2 = load(B + 128 + lane);
+        waveSync();
+        ring[(B + lane) & (kRingDw - 1)] = W0;
+        ring[(B + 64 + lane) & (kRingDw - 1)] = W1;
+        waveSync();
+    }
+    __device__ __forceinline__ void setPayload(uint32_t skewPlusOff)
+    {
+        payBit = skewPlusOff * 8;
+        pos = 0; hi = 0; any = false; have = 0;
+        reload();
+    }
+    // the dword of the current position lies in W0
+    __device__ __forceinline__ void ensure()
+    {
+        uint32_t j = ((payBit + pos) >> 5) - B;
+        while (j >= 64)
+        {
+            if (j >= 192)
+            {
+                reload();
+                return;
+            }
+            W0 = W1; W1 = W2; B += 64; j -= 64;
+            waveSync();
+            ring[(B + 64 + lane) & (kRingDw - 1)] = W1;
+            waveSync();
+            W2 = load(B + 128 + lane);
+        }
+    }
+    __device__ __forceinline__ uint32_t windowDword(uint32_t j) const       // j < 128, the same on every lane
+    {
+        const uint32_t a = rl(W0, j & 63), b = rl(W1, j & 63);
+        return j < 64 ? a : b;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        ensure();
+        const uint32_t a = payBit + pos;
+        const uint32_t j = (a >> 5) - B;
+        const uint32_t sh = a & 31;
+        win = ((static_cast<uint64_t>(windowDword(j)) << 32) | windowDword(j + 1)) << sh;
+        have = 64 - static_cast<int>(sh);
+    }
+    __device__ __forceinline__ uint32_t look(int n)
+    {
+        if (have < n)
+            refill();
+        return n == 0 ? 0u : static_cast<uint32_t>(win >> 32) >> (32 - n);
+    }
+    __device__ __forceinline__ uint32_t peek(int n)
+    {
+        any = true;
+        hi = umax(hi, pos + static_cast<uint32_t>(n));
+        return look(n);
+    }
+    __device__ __forceinline__ void consume(int n)
+    {
+        win <<= n;
+        have -= n;
+        pos += static_cast<uint32_t>(n);
+    }
+    __device__ __forceinline__ void took(int n)
+    {
+        consume(n);
+        any = true;
+        hi = umax(hi, pos);
+    }
+    __device__ __forceinline__ uint32_t get(int n)
+    {
+        const uint32_t r = peek(n);
+        consume(n);
+        return r;
+    }
+    // `count` fields of `width` bits whose values nobody needs (the last field's look reaches exactly its own end)
+    __device__ __forceinline__ void skipRun(int count, int width)
+    {
+        if (count <= 0 || width <= 0)
+            return;
+        any = true;
+        const uint32_t total = static_cast<uint32_t>(count) * static_cast<uint32_t>(width);
+        pos += total;
+        hi = umax(hi, pos);
+        if (total <= static_cast<uint32_t>(have))
+        {
+            win = total >= 64 ? 0 : win << total;
+            have -= static_cast<int>(total);
+        }
+        else
+            have = 0;
+    }
+    // the next 32 bits at `off` bits behind the current position, per lane (ensure() first; off < 1 900)
+    __device__ __forceinline__ uint32_t gather32(uint32_t off) const
+    {
+        const uint32_t a = payBit + pos + off;
+        const uint32_t d = a >> 5;
+        const uint32_t h = ring[d & (kRingDw - 1)], l = ring[(d + 1) & (kRingDw - 1)];
+        return static_cast<uint32_t>((((static_cast<uint64_t>(h) << 32) | l) << (a & 31)) >> 32);
+    }
+    __device__ __forceinline__ uint32_t bitPos() const { return pos; }
+    __device__ __forceinline__ uint32_t bytesFetched(uint32_t payOff) const { return any ? payOff + (hi >> 3) + 1 : payOff; }
+};
+
+// One walk: the stream's constants, what the decoder carries from frame to frame, and the record under construction.
+struct Walk
+{
+    WaveBits b;
+    const IndexLds *L;
+    uint32_t lane;
+    int os = 0, format = 0, nBands = 0;
+    bool type1 = false, sub0 = false;
+    uint32_t vHeader = 0;       // lane i < 16: header byte i
+    uint32_t vBandType = 0;     // lane i < 16: AudioStream::bandTypeBuf[i]
+    uint32_t vBB = 0, vSc1 = 0, vInputs = 0;    // OS93a Type 1: the stream's band-bits codebook, the first level of the scale
+                                                // codebook, inputs per band -- one entry per lane
+    uint32_t err = 0;
+    // the record
+    uint32_t vSplitLo = 0, vSplitHi = 0;        // lane k < 15: split[k] = bitDelta | prv << 16, prvDelta | state << 16
+    uint32_t vRecBT = 0;                        // lane i < 16: byte i of the record's bandType field
+    uint32_t hdrBits = 0, preAdj = 0;
+
+    __device__ __forceinline__ void fatal() { err |= DCS_FRAME_FATAL | DCS_FRAME_STOP; }
+    __device__ __forceinline__ void putSplit(int band, uint32_t bitDelta, uint32_t prv, uint32_t prvDelta, uint32_t state)
+    {
+        if (band < 1 || band > 15)
+            return;
+        vSplitLo = wl(vSplitLo, static_cast<uint32_t>(band - 1), (bitDelta & 0xFFFFu) | (prv << 16));
+        vSplitHi = wl(vSplitHi, static_cast<uint32_t>(band - 1), (prvDelta & 0xFFFFu) | (state << 16));
+    }
+};
+
+// A run of Huffman-coded samples (:2186-2225): symbols from the current position until `rem` samples are accounted for
+// (a two-zeros code counts for two).  Returns what is left: 0, or -1 when the last code was a two-zeros code with one
+// sample to go.  `info` = look-ahead width | codebook offset << 4 (DcsLdsTables::cbInfo).
+__device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *cb94, uint32_t info, int rem)
+{
+    const uint32_t maxBits = info & 0xF;
+    const uint16_t *book = cb94 + (info >> 4);
+    b.any = true;
+    do
+    {
+        b.ensure();
+        // lane l: the code that would start l bits from here -- its length, and minus the samples it stands for in the upper half
+        const uint32_t e = book[b.gather32(b.lane) >> (32 - maxBits)];
+        const uint32_t v = ((e >> 8) & 0x1Fu) - ((e >> 13) == 2 ? 0x20000u : 0x10000u);
+        // state: bits walked | samples left - 1 << 16.  Done when the samples run out (sign) or the walk leaves the 64 candidates.
+        uint32_t state = static_cast<uint32_t>(rem - 1) << 16;
+        uint32_t se;
+        do
+        {
+            se = rl(v, state & 63u);
+            state += se;
+        }
+        while ((state & 0x80000040u) == 0);
+        const uint32_t off = state & 0xFFFFu;
+        rem = (static_cast<int32_t>(state) >> 16) + 1;
+        b.hi = umax(b.hi, b.pos + off - (se & 0xFFFFu) + maxBits);      // the last symbol's look
+        b.pos += off;
+    }
+    while (rem > 0);
+    b.have = 0;
+    return rem;
+}
+
+// The frame header of a 1994+ frame: one band-type delta code per populated band (:1780-1834), lane k < nBands
+// receives code k's payload (delta + 16).  Candidates through the first-level table; a code longer than eight bits
+// (rare) is walked through the trie on the scalar unit.
+__device__ __forceinline__ uint32_t headerDeltas94(Walk &s)
+{
+    WaveBits &b = s.b;
+    uint32_t vDelta = 16;
+    int band = 0;
+    while (band < s.nBands)
+    {
+        b.ensure();
+        const uint32_t e = s.L->fast94[b.gather32(b.lane) >> 24];
+        uint32_t off = 0;
+        bool longCode = false;
+        while (band < s.nBands && off < 64)
+        {
+            const uint32_t se = rl(e, off);
+            if (!(se & 0x8000u)) { longCode = true; break; }
+            vDelta = wl(vDelta, static_cast<uint32_t>(band), se & 0xFFu);
+            off += (se >> 8) & 0xFu;
+            ++band;
+        }
+        b.pos += off;
+        b.have = 0;
+        if (longCode)
+        {
+            vDelta = wl(vDelta, static_cast<uint32_t>(band), static_cast<uint32_t>(dcsReadVlcFast(b, s.L->fast94, s.L->trie94)));
+            ++band;
+        }
+    }
+    if (s.nBands > 0)
+    {
+        b.any = true;
+        b.hi = umax(b.hi, b.pos);       // (a code's one-bit looks reach its last bit)
+    }
+    return vDelta;
+}
+
+// --- 1994+ frame (:1679-2261; the walk of dcsScan94, dcs_scan.h) ---------------------------------------------------
+__device__ void scan94(Walk &s)
+{
+    WaveBits &b = s.b;
+    const DcsLdsTables &T = s.L->T;
+    const uint32_t lane = s.lane;
+    const uint32_t frameStart = b.pos;
+
+    // Type 1 indexes its pre-adjust map with the previous frame's codes of bands 0..2 (:1744-1773)
+    if (s.type1)
+    {
+        if (__ballot(lane < 3 && s.vBandType > 15) != 0) { s.fatal(); return; }
+        const uint32_t p = lane < 3 ? T.preAdj94[(s.sub0 ? 0u : 16u) + (s.vBandType & 15u)] : 0u;
+        s.preAdj = rl(p, 0) | (rl(p, 1) << 4) | (rl(p, 2) << 8);
+    }
+
+    const uint32_t vDelta = headerDeltas94(s);
+    if (static_cast<int>(lane) < s.nBands)
+        s.vBandType = (s.vBandType + vDelta - 16u) & 0xFFFFu;
+    s.hdrBits = (b.pos - frameStart) & 0xFFFFu;
+    s.vRecBT = s.vBandType > 255u ? 255u : s.vBandType;
+
+    // per band, all at once: the sample code behind the band-type code (:1914-1961) and its codebook
+    uint32_t vCode = s.vBandType;
+    if (s.type1)
+        vCode = T.xlat94[(lane < 3 ? 0u : lane < 6 ? 16u : 32u) + (s.vBandType & 15u)] & 0xFFu;
+    const uint32_t vInfo = T.cbInfo[vCode < 8u ? vCode : 0u];
+
+    int outIdx = 1;
+    for (int band = 0 ; band < s.nBands ; ++band)
+    {
+        s.putSplit(band, b.pos - frameStart, 0, 0, static_cast<uint32_t>(outIdx) & 0x1FFu);
+        const uint32_t hb = rl(s.vHeader, static_cast<uint32_t>(band)) & 0x7Fu;
+        int count = band == 0 ? 7 : band == 1 ? 8 : band == 15 ? 32 : 16;      // :1848-1850
+        int inc = 1;
+        if (hb & 0x40) { count /= 2; inc = 2; }
+        const uint32_t raw = rl(s.vBandType, static_cast<uint32_t>(band));
+        if (raw == 0)
+        {
+            outIdx += count;                            // the halved count (:1886)
+            continue;
+        }
+        int code = static_cast<int>(raw);
+        if (s.type1)
+        {
+            if (raw > 15) { s.fatal(); return; }
+            code = static_cast<int>(rl(vCode, static_cast<uint32_t>(band)));
+        }
+        if (code > 16) { s.fatal(); return; }
+        outIdx += count * inc;
+        if (code == 0)
+        {
+            s.err |= DCS_FRAME_STOP;                    // :1985-1991, consumes nothing
+        }
+        else if (code <= 6)
+        {
+            const uint32_t info = rl(vInfo, static_cast<uint32_t>(band));
+            int i = count;
+            // band 15 in two halves; where the second one starts is recorded (dcsPutMid15, dcs_scan.h)
+            for (int piece = band == 15 ? 0 : 1 ; piece < 2 ; ++piece)
+            {
+                const int lim = piece == 0 ? count / 2 : 0;
+                if (i > lim)
+                {
+                    const int r = huffRun(b, T.cb94, info, i - lim);
+                    i = lim + r;
+                    if (r < 0 && lim == 0) { s.err |= DCS_FRAME_STOP; i = 0; }      // two zeros with one slot left (:2213-2218)
+                }
+                if (piece == 0)
+                {
+                    const uint32_t lo = rl(s.vSplitLo, 14), hiw = rl(s.vSplitHi, 14);
+                    s.vSplitLo = wl(s.vSplitLo, 14, (lo & 0xFFFFu) | (((b.pos - frameStart) & 0xFFFFu) << 16));
+                    s.vSplitHi = wl(s.vSplitHi, 14, (hiw & 0xFFFF0000u) | (static_cast<uint32_t>(outIdx - i * inc) & 0x1FFu) | (i < lim ? DCS_MID15_STRADDLE : 0u));
+                }
+            }
+        }
+        else if (band == 15)
+        {
+            b.skipRun(count - count / 2, code);
+            const uint32_t lo = rl(s.vSplitLo, 14), hiw = rl(s.vSplitHi, 14);
+            s.vSplitLo = wl(s.vSplitLo, 14, (lo & 0xFFFFu) | (((b.pos - frameStart) & 0xFFFFu) << 16));
+            s.vSplitHi = wl(s.vSplitHi, 14, (hiw & 0xFFFF0000u) | (static_cast<uint32_t>(outIdx - (count / 2) * inc) & 0x1FFu));
+            b.skipRun(count / 2, code);
+        }
+        else
+        {
+            b.skipRun(count, code);
+        }
+    }
+}
+
+// --- 1993 frame, Type 0 and OS93b Type 1 (:2293-2615; dcsScan93) ------------------------------------------------------
+__device__ void scan93(Walk &s)
+{
+    WaveBits &b = s.b;
+    const DcsLdsTables &T = s.L->T;
+    const uint32_t lane = s.lane;
+    const bool type1 = s.type1;
+    const uint32_t frameStart = b.pos;
+    bool first = true, reuse = false;
+    int code = 0;
+    int subType = type1 ? 0 : 2;
+    uint32_t prv = 0, prvDelta = 0;
+    int outIdx = 1;
+
+    s.vRecBT = s.vBandType > 255u ? 255u : s.vBandType;
+
+    for (int band = 0 ; band < s.nBands ; ++band)
+    {
+        s.putSplit(band, b.pos - frameStart, prv, prvDelta,
+                   (static_cast<uint32_t>(outIdx) & 0x1FFu) | (static_cast<uint32_t>(subType) << 9) | (reuse ? 0x800u : 0u));
+        const uint32_t hb = rl(s.vHeader, static_cast<uint32_t>(band)) & 0x7Fu;
+        const bool strided = (hb >> 6) != 0;
+        int nSamples, inc = 1, fixup = 0, stride;
+        if (!type1)
+        {
+            nSamples = 16;
+            if (!strided) stride = 16;
+            else { ++outIdx; inc = 2; fixup = -1; stride = 31; }
+        }
+        else
+        {
+            if (!strided) nSamples = stride = first ? 15 : 16;
+            else { inc = 2; nSamples = stride = 8; }
+        }
+
+        if (reuse)
+            reuse = b.get(1) != 0;
+        if (!reuse)
+        {
+            if (!type1)
+            {
+                if (b.get(1))
+                    subType = b.get(1) ? (subType + 1) % 3 : (subType + 2) % 3;     // :2402-2414
+                code = static_cast<int>(b.get(4));
+            }
+            else
+            {
+                int v = dcsReadVlcFast(b, T.fast93, T.trie93);
+                if (v < 0x1E)
+                    v -= 0x0F;                                      // :2668-2681
+                else
+                {
+                    v -= 0x2E;
+                    subType = subType != 0 ? 0 : 1;
+                }
+                const uint32_t bt = (rl(s.vBandType, static_cast<uint32_t>(band)) + static_cast<uint32_t>(v)) & 0xFFFFu;
+                s.vBandType = wl(s.vBandType, static_cast<uint32_t>(band), bt);
+                code = static_cast<int>(bt);
+            }
+        }
+
+        if (code == 0)
+        {
+            reuse = true;                                           // :2455
+            if (subType == 0) { outIdx += stride; prv = 0; prvDelta = 0; }
+            else if (subType == 1) { prvDelta = 0; outIdx += nSamples * inc + fixup; }
+            else
+            {
+                prv = (prv + static_cast<uint32_t>(nSamples) * prvDelta) & 0xFFFFu;
+                outIdx += nSamples * inc + fixup;
+            }
+        }
+        else
+        {
+            const int width = code + (type1 ? 0 : 1);
+            if (width > 16) { s.fatal(); return; }
+            if (subType == 0)
+            {
+                // directly coded samples: only the last two are carried on (:2565-2599)
+                uint32_t last = 0, last2 = 0;
+                const int skipped = nSamples > 2 ? nSamples - 2 : 0;
+                b.skipRun(skipped, width);
+                for (int i = skipped ; i < nSamples ; ++i)
+                {
+                    uint32_t in = b.get(width);
+                    if (in & (1u << (width - 1)))
+                        in |= 0xFFFFFFFFu << width;
+                    in &= 0xFFFF;
+                    last2 = last; last = in;
+                }
+                prv = last;
+                prvDelta = (last - last2) & 0xFFFF;
+            }
+            else
+            {
+                // delta (1) and double-delta (2) coding: lane i reads sample i; what is carried on are sums
+                b.ensure();
+                uint32_t x = b.gather32(lane * static_cast<uint32_t>(width)) >> (32 - width);
+                if (x & (1u << (width - 1)))
+                    x |= 0xFFFFFFFFu << width;
+                if (static_cast<int>(lane) >= nSamples)
+                    x = 0;
+                const uint32_t sum = rl(rowSum16(x), 0);
+                if (subType == 1)
+                {
+                    prvDelta = rl(x, static_cast<uint32_t>(nSamples - 1)) & 0xFFFFu;
+                    prv = (prv + sum) & 0xFFFFu;
+                }
+                else
+                {
+                    const uint32_t weighted = rl(rowSum16(x * (static_cast<uint32_t>(nSamples) - lane)), 0);
+                    prv = (prv + static_cast<uint32_t>(nSamples) * prvDelta + weighted) & 0xFFFFu;
+                    prvDelta = (prvDelta + sum) & 0xFFFFu;
+                }
+                b.any = true;
+                b.pos += static_cast<uint32_t>(nSamples * width);
+                b.hi = umax(b.hi, b.pos);
+                b.have = 0;
+            }
+            outIdx += nSamples * inc + fixup;
+        }
+        first = false;
+    }
+}
+
+// --- OS93a Type 1 frame (:2831-3032; dcsScan93a) -------------------------------------------------------------------------
+__device__ void scan93a(Walk &s)
+{
+    WaveBits &b = s.b;
+    const DcsLdsTables &T = s.L->T;
+    const int numBands = s.nBands;
+    const uint32_t frameStart = b.pos;
+    int prvScale = 0x1A;
+    int outIdx = 0;
+    bool ended = false;
+
+    s.vRecBT = 0;
+    for (int band = 0 ; band < numBands ; ++band)
+    {
+        const uint32_t state = (static_cast<uint32_t>(outIdx) & 0x1FFu) | (ended ? 0x800u : 0u);
+        s.putSplit(band, b.pos - frameStart, static_cast<uint32_t>(prvScale) & 0xFFFFu, 0, state);
+        if (band == 16 || band == 17)
+        {
+            // the records of bands 16 and 17 travel in the record's 16 bandType bytes
+            const uint32_t at = static_cast<uint32_t>(band - 16) * 8;
+            const uint32_t bitDelta = b.pos - frameStart;
+            s.vRecBT = wl(s.vRecBT, at + 0, bitDelta & 0xFFu);
+            s.vRecBT = wl(s.vRecBT, at + 1, (bitDelta >> 8) & 0xFFu);
+            s.vRecBT = wl(s.vRecBT, at + 2, static_cast<uint32_t>(prvScale) & 0xFFu);
+            s.vRecBT = wl(s.vRecBT, at + 3, (static_cast<uint32_t>(prvScale) >> 8) & 0xFFu);
+            s.vRecBT = wl(s.vRecBT, at + 6, state & 0xFFu);
+            s.vRecBT = wl(s.vRecBT, at + 7, (state >> 8) & 0xFFu);
+        }
+        if (ended)
+            continue;
+        if (band >= 18) { s.fatal(); return; }
+        const int numInputs = static_cast<int>(rl(s.vInputs, static_cast<uint32_t>(band)));
+        const uint32_t e = rl(s.vBB, b.peek(4));
+        b.get(static_cast<int>(e >> 8));
+        const int bandBits = static_cast<int>(e & 0xFF);
+        if (bandBits == 0xFF)
+        {
+            ended = true;
+            continue;
+        }
+        outIdx += numInputs * 2;
+        if (bandBits == 0)
+            continue;
+        uint32_t sc = rl(s.vSc1, b.peek(4));
+        b.get(static_cast<int>((sc >> 8) & 0xF));
+        if ((sc & 0xFF) == 0xFF)
+        {
+            sc = uni(T.scaleCb93a[((sc >> 12) << 4) + b.peek(4)]);
+            b.get(static_cast<int>((sc >> 8) & 0xF) - 4);
+        }
+        int scaleCode = prvScale + static_cast<int>(sc & 0xFF) - 1 + bandBits * 2;
+        if (scaleCode > 0x39)
+            scaleCode -= 0x36;
+        prvScale = scaleCode - bandBits * 2;
+        b.skipRun(numInputs, bandBits);
+    }
+}
+
+// stream k of the launch is walked by wavefront k
+__global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blobBase, const DcsStreamLoc *locs, uint32_t nStreams,
+                                                                  const DcsDevTables *tables, DcsFrameIndex *out, DcsStreamInfo *infos,
+                                                                  DcsFrameDigest *digest)
+{
+    __shared__ IndexLds L;
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tables->lds);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&L.T);
+        for (uint32_t i = threadIdx.x ; i < sizeof(DcsLdsTables) / 4 ; i += blockDim.x)
+            dst[i] = src[i];
+        for (uint32_t i = threadIdx.x ; i < 256 ; i += blockDim.x)
+            L.fast94[i] = tables->fast94[i];
+        for (uint32_t i = threadIdx.x ; i < DCS_TRIE94_MAX ; i += blockDim.x)
+            L.trie94[i] = tables->trie94[i];
+    }
+    __syncthreads();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * kWaves + wave;
+    if (k >= nStreams)
+        return;
+    const DcsStreamLoc loc = locs[k];
+    const int os = loc.os;
+    const uint8_t *stream = reinterpret_cast<const uint8_t *>(blobBase + loc.off);     // (blobBase 0: the locations are device addresses)
+    const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(stream) & 3);
+    const uint32_t len = loc.len;
+
+    Walk s;
+    s.L = &L;
+    s.lane = lane;
+    s.os = os;
+    s.b.sBase = reinterpret_cast<const uint32_t *>(stream - skew);
+    s.b.endByte = skew + len;
+    s.b.nDwValid = (skew + len + 3) / 4;
+    s.b.ring = L.ring[wave];
+    s.b.lane = lane;
+    uint32_t *rec = L.rec[wave];
+
+    // container (InitChannelStream :1433-1463, InitStreamPlayback :1595-1641): lane l looks at byte l of the stream
+    const uint32_t vByte = (lane < 18 && lane < len) ? stream[lane] : 0u;
+    const uint32_t nFrames = (rl(vByte, 0) << 8) | rl(vByte, 1);
+    const bool typeBit = (rl(vByte, 2) & 0x80u) != 0;
+    const uint32_t hdrLen = (os == DCS_OS93A && typeBit) ? 1u : 16u;
+    s.vHeader = (lane < hdrLen && lane + 2 < len) ? stream[lane + 2] : 0u;
+    s.b.setPayload(skew + 2 + hdrLen);
+    const uint32_t h0 = rl(s.vHeader, 0), h1 = rl(s.vHeader, 1), h2 = rl(s.vHeader, 2);
+    if (os == DCS_OS93A && typeBit)
+        s.nBands = static_cast<int>(h0 & 0x1F);
+    else
+    {
+        const unsigned long long ends = __ballot(lane < 16 && (s.vHeader & 0x7Fu) == 0x7Fu);
+        s.nBands = ends != 0 ? static_cast<int>(__builtin_ctzll(ends)) : 16;
+    }
+    int format;
+    if (os == DCS_OS93A)
+        format = typeBit ? DCS_FMT_93A_T1 : DCS_FMT_93_T0;
+    else if (os == DCS_OS93B)
+        format = typeBit ? DCS_FMT_93B_T1 : DCS_FMT_93_T0;
+    else if (!typeBit)
+        format = DCS_FMT_94_T0;
+    else
+        format = (((h1 | h2) & 0x80u) == 0) ? DCS_FMT_94_T1_S0 : DCS_FMT_94_T1_S3;
+    s.format = format;
+    s.type1 = typeBit;
+    s.sub0 = ((h1 | h2) & 0x80u) == 0;
+    if (format == DCS_FMT_93A_T1)
+    {
+        s.vBB = L.T.bandBits93a[((h0 & 0x60u) >> 1) + (lane & 15)];
+        s.vSc1 = L.T.scaleCb93a[lane & 15];
+        s.vInputs = L.T.inputs93a[lane < 24 ? lane : 0];
+    }
+
+    DcsFrameIndex *const outRec = out + loc.firstRecord;
+    DcsFrameDigest *const outDigest = digest != nullptr ? digest + loc.firstRecord : nullptr;
+    uint32_t valid = 0, payloadBits = 0;
+    for (uint32_t f = 0 ; f < nFrames ; ++f)
+    {
+        const uint32_t frameBit = s.b.pos;
+        s.err = 0;
+        s.vSplitLo = 0; s.vSplitHi = 0; s.vRecBT = 0; s.hdrBits = 0; s.preAdj = 0;
+        switch (format)
+        {
+        case DCS_FMT_93_T0:
+        case DCS_FMT_93B_T1: scan93(s); break;
+        case DCS_FMT_93A_T1: scan93a(s); break;
+        default:             scan94(s); break;
+        }
+        const uint32_t nBits = (s.b.pos - frameBit) & 0xFFFFu;
+        const uint32_t flags = ((s.err << 4) | (s.err != 0 ? DCS_IDX_SERIAL : 0u)) & 0xFFu;
+        // the record, put together in LDS and written out 37 dwords wide
+        waveSync();
+        if (lane < 16)
+            reinterpret_cast<uint8_t *>(rec)[8 + lane] = static_cast<uint8_t>(s.vRecBT);
+        if (lane < 15)
+        {
+            rec[7 + 2 * lane] = s.vSplitLo;
+            rec[8 + 2 * lane] = s.vSplitHi;
+        }
+        if (lane == 0)
+        {
+            rec[0] = frameBit;
+            rec[1] = nBits | (s.hdrBits << 16);
+            rec[6] = (s.preAdj & 0xFFFFu) | (static_cast<uint32_t>(s.nBands) << 16) | (flags << 24);
+        }
+        waveSync();
+        if (lane < 37)
+            reinterpret_cast<uint32_t *>(outRec + valid)[lane] = rec[lane];
+        if (outDigest != nullptr && lane == 0)
+            outDigest[valid] = DcsFrameDigest{ frameBit, static_cast<uint16_t>(nBits), static_cast<uint8_t>(s.nBands), static_cast<uint8_t>(flags) };
+        ++valid;
+        payloadBits = s.b.pos;
+        if (s.err != 0)
+            break;                  // the reference stops the channel on the next tick (:95-116)
+    }
+
+    // the stream's summary (GetStreamInfo :1486-1537)
+    waveSync();
+    if (lane < 16)
+        reinterpret_cast<uint8_t *>(rec)[16 + lane] = static_cast<uint8_t>(s.vHeader);
+    if (lane == 0)
+    {
+        rec[0] = nFrames;
+        rec[1] = s.b.bytesFetched(2 + hdrLen);
+        rec[2] = typeBit ? 1u : 0u;
+        rec[3] = (os == DCS_OS94 || os == DCS_OS95) ? (((h1 & 0x80u) >> 6) | ((h1 & 0x80u) >> 7)) : 0u;     // sic (:1517)
+        rec[8] = static_cast<uint32_t>(format);
+        rec[9] = hdrLen;
+        rec[10] = valid;
+        rec[11] = payloadBits;
+    }
+    waveSync();
+    if (lane < 12)
+        reinterpret_cast<uint32_t *>(infos + k)[lane] = rec[lane];
+}
+
+}   // namespace dcsidx

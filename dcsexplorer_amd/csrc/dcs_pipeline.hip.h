@@ -232,13 +232,9 @@ static void pipelineIndexer(DcsPipeline *p, int which)
             for (const DcsPipeline::JobPtr &j : jobs)
                 HIPCHK(ctx, hipStreamWaitEvent(stream, j->uploaded, 0));
             HIPCHK(ctx, hipMemcpyAsync(dLocs, locs.data(), locBytes, hipMemcpyHostToDevice, stream));
-            const int lanes = indexLanes(ctx, nStreams);
-            const uint32_t blocks = (nStreams + static_cast<uint32_t>(lanes) - 1) / static_cast<uint32_t>(lanes);
-            hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), indexDynBytes(lanes), stream, static_cast<const uint32_t *>(nullptr),
-                               ~size_t(0) / 4, static_cast<const DcsStreamLoc *>(dLocs), nStreams, lanes, ctx->dTables,
-                               static_cast<DcsFrameIndex *>(dOut), static_cast<DcsStreamInfo *>(dInfos),
-                               static_cast<DcsFrameDigest *>(dDigest));
-            HIPCHK(ctx, hipGetLastError());
+            // (stream locations are device addresses: each list's streams lie in its own buffer)
+            HIPCHK(ctx, launchIndexWave(stream, 0, static_cast<const DcsStreamLoc *>(dLocs), nStreams, ctx->dTables, static_cast<DcsFrameIndex *>(dOut),
+                                        static_cast<DcsStreamInfo *>(dInfos), static_cast<DcsFrameDigest *>(dDigest)));
             uint64_t r = 0;
             uint32_t s0 = 0;
             for (const DcsPipeline::JobPtr &j : jobs)

@@ -16,6 +16,7 @@
 #include "dcs_common.h"
 #include "dcs_kernels.hip.h"
 #include "dcs_scan.h"
+#include "dcs_index_wave.hip.h"
 
 struct DcsCtx
 {
@@ -40,7 +41,6 @@ struct DcsCtx
     size_t idxBlobLen = 0, idxBlobDw = 0;
     uint32_t idxStreams = 0;
     uint64_t idxCap = 0;
-    int idxLanes = 1;
     // device and pinned-host buffers of destroyed batches, kept for the next batch (hipMalloc / hipFree cost
     // about as much as decoding a few thousand frames)
     struct Cached { void *p; size_t cap; };
@@ -1048,205 +1048,22 @@ extern "C" DcsStatus dcs_decode_batch(DcsCtx *ctx,
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Index kernel: the walker of dcs_scan.h with one lane per stream.  The walk is serial inside a stream
-// (each frame starts where the last one ended), so the parallelism is across streams only; `lanes`
-// active lanes per wavefront spread few streams over many CUs instead of packing them into divergent
-// waves.  Stream bytes are fetched a dword at a time; the small code tables sit in LDS.
+// Index pass on the device: one wavefront per stream (dcs_index_wave.hip.h).  The walk is serial from frame to frame,
+// so a launch takes as long as its longest stream; four streams share a workgroup (and its LDS copy of the tables).
 // ---------------------------------------------------------------------------------------------------------
-namespace {
-
-// Device-side reader of the walker: a 64-bit MSB-first window refilled a dword at a time, the next
-// dwords prefetched.  The reference reader's byte pointer (what StreamInfo.nBytes reports, see DcsBits in
-// dcs_scan.h) is not emulated byte by byte but computed: Peek(n) at bit position B leaves the pointer
-// at floor((B + n) / 8) + 1 bytes into the payload at least, so the pointer after the walk is the
-// maximum of that over every read.
-struct DevBits
+static hipError_t launchIndexWave(hipStream_t stream, uintptr_t blobBase, const DcsStreamLoc *dLocs, uint32_t nStreams, const DcsDevTables *dTables,
+                                  DcsFrameIndex *dOut, DcsStreamInfo *dInfos, DcsFrameDigest *dDigest)
 {
-    static constexpr bool kAnalytic = true;
-    const uint32_t *blobDw;
-    size_t nDw;                 // dwords allocated behind blobDw
-    size_t base;                // byte offset of the stream in the blob
-    size_t len;                 // stream bytes; bytes past it read as zero
-    size_t payOff = 0;
-    uint64_t win = 0;           // unread bits, MSB first
-    int have = 0;               // valid bits in win
-    uint32_t pos = 0;           // payload bits consumed
-    uint32_t hi = 0;            // max over reads of (pos + n)
-    bool any = false;
-    size_t nextDw = 0;          // dword index of q0
-    uint32_t q0 = 0, q1 = 0;    // prefetched raw dwords
-
-    // (bounded by the STREAM, not only by the allocation: a damaged stream may announce frames far beyond its bytes, and the
-    // pipeline's launch, whose streams are absolute addresses, has no allocation bound at all.  Bytes past the stream read
-    // as zero anyway -- streamBits -- so the records do not change.  The dword that straddles the stream's end is read
-    // whole: every caller pads its blob by at least a dword.)
-    __device__ uint32_t rawAt(size_t w) const { return (w < nDw && w * 4 < base + len) ? blobDw[w] : 0u; }
-    __device__ uint32_t byteAt(size_t i) const
-    {
-        if (i >= len)
-            return 0;
-        const size_t a = base + i;
-        return (rawAt(a >> 2) >> ((a & 3) * 8)) & 0xFF;
-    }
-    // dword w of the blob as 32 MSB-first stream bits, bytes outside [base, base+len) zeroed
-    __device__ uint32_t streamBits(size_t w, uint32_t raw) const
-    {
-        const size_t lo = w * 4;
-        if (lo + 4 > base + len)
-        {
-            const size_t end = base + len;
-            const uint32_t keep = lo >= end ? 0u : static_cast<uint32_t>(end - lo);     // 0..3 bytes
-            raw &= keep == 0 ? 0u : (0xFFFFFFFFu >> (32 - 8 * keep));
-        }
-        return __builtin_bswap32(raw);
-    }
-    __device__ void setPayload(size_t off)
-    {
-        payOff = off;
-        const size_t a = base + off;
-        const size_t w = a >> 2;
-        const uint32_t skip = static_cast<uint32_t>(a & 3) * 8;
-        win = static_cast<uint64_t>(streamBits(w, rawAt(w))) << (32 + skip);
-        have = 32 - static_cast<int>(skip);
-        nextDw = w + 1;
-        q0 = rawAt(nextDw);
-        q1 = rawAt(nextDw + 1);
-        pos = 0; hi = 0; any = false;
-    }
-    __device__ void refill()
-    {
-        win |= static_cast<uint64_t>(streamBits(nextDw, q0)) << (32 - have);
-        have += 32;
-        ++nextDw;
-        q0 = q1;
-        q1 = rawAt(nextDw + 1);
-    }
-    __device__ uint32_t peek(int n)
-    {
-        any = true;
-        const uint32_t reach = pos + static_cast<uint32_t>(n);
-        hi = reach > hi ? reach : hi;
-        if (have < n)
-            refill();
-        // (the next n <= 32 bits are the top of the window's upper half: a 32-bit shift)
-        return n == 0 ? 0u : static_cast<uint32_t>(win >> 32) >> (32 - n);
-    }
-    __device__ uint32_t look(int n) { if (have < n) refill(); return static_cast<uint32_t>(win >> 32) >> (32 - n); }
-    // n bits of what a peek(m >= n) at this position has just looked at
-    __device__ void consume(int n)
-    {
-        win <<= n;
-        have -= n;
-        pos += static_cast<uint32_t>(n);
-    }
-    // n bits looked at with look() and consumed, counted like n looks of one bit each: the last reaches pos + n
-    __device__ void took(int n)
-    {
-        consume(n);
-        any = true;
-        hi = pos > hi ? pos : hi;
-    }
-    __device__ uint32_t get(int n)
-    {
-        const uint32_t r = peek(n);
-        consume(n);
-        return r;
-    }
-    // `count` fields of `width` bits whose values nobody needs: the position moves on by their total length, the byte
-    // pointer the reference would have is computed from the last field's look (see the header comment), and the window is
-    // read afresh at the new position when the run does not end inside it
-    __device__ void skipRun(int count, int width)
-    {
-        if (count <= 0 || width <= 0)
-            return;
-        any = true;
-        const uint32_t total = static_cast<uint32_t>(count) * static_cast<uint32_t>(width);
-        pos += total;
-        hi = pos > hi ? pos : hi;               // the last field's look reached exactly its own end
-        if (total <= static_cast<uint32_t>(have))
-        {
-            win = total >= 64 ? 0 : win << total;
-            have -= static_cast<int>(total);
-            return;
-        }
-        const size_t bit = (base + payOff) * 8 + pos;
-        const size_t w = bit >> 5;
-        const uint32_t skip = static_cast<uint32_t>(bit & 31);
-        win = ((static_cast<uint64_t>(streamBits(w, rawAt(w))) << 32) | streamBits(w + 1, rawAt(w + 1))) << skip;
-        have = 64 - static_cast<int>(skip);
-        nextDw = w + 2;
-        q0 = rawAt(nextDw);
-        q1 = rawAt(nextDw + 1);
-    }
-    __device__ uint32_t bitPos() const { return pos; }
-    __device__ size_t bytesFetched() const { return any ? payOff + (hi >> 3) + 1 : payOff; }
-};
-
-struct DevSink
-{
-    DcsFrameIndex *out;
-    DcsFrameDigest *digest;     // optional: what the host planner needs, 8 bytes per frame
-    uint32_t cap;
-    __device__ void operator()(uint32_t f, const DcsFrameIndex &fi)
-    {
-        if (f < cap)
-        {
-            out[f] = fi;
-            if (digest != nullptr)
-                digest[f] = DcsFrameDigest{ fi.bitOff, fi.nBits, fi.nBands, fi.flags };
-        }
-    }
-};
-
-__global__ __launch_bounds__(64, 6) void dcsIndexKernel(const uint32_t *blobDw, size_t nDw, const DcsStreamLoc *locs,
-                                                      uint32_t nStreams, int lanes, const DcsDevTables *tables,
-                                                      DcsFrameIndex *out, DcsStreamInfo *infos, DcsFrameDigest *digest)
-{
-    __shared__ DcsLdsTables T;
-    // working records of the walking lanes only (dynamic: with one lane per wavefront a block then needs 3.4 KB, and a CU
-    // holds as many such blocks as it has wavefront slots)
-    extern __shared__ __attribute__((aligned(16))) unsigned char indexDyn[];
-    DcsScanMem *mem = reinterpret_cast<DcsScanMem *>(indexDyn);
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tables->lds);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&T);
-        for (uint32_t i = threadIdx.x ; i < sizeof(DcsLdsTables) / 4 ; i += blockDim.x)
-            dst[i] = src[i];
-    }
-    __syncthreads();
-    if (static_cast<int>(threadIdx.x) >= lanes)
-        return;
-    const uint32_t k = blockIdx.x * static_cast<uint32_t>(lanes) + threadIdx.x;
-    if (k >= nStreams)
-        return;
-    const DcsStreamLoc loc = locs[k];
-    DevBits reader{ blobDw, nDw, static_cast<size_t>(loc.off), static_cast<size_t>(loc.len) };
-    const uint32_t nf = (reader.byteAt(0) << 8) | reader.byteAt(1);
-    DevSink sink{ out + loc.firstRecord, digest != nullptr ? digest + loc.firstRecord : nullptr, nf };
-    const DcsScanTables tabs{ &T, tables->trie94, nullptr, tables->fast94 };
-    infos[k] = dcsScanStream(loc.os, reader, tabs, &mem[threadIdx.x], sink);
-}
-
-}   // namespace
-
-static size_t indexDynBytes(int lanes) { return (sizeof(DcsScanMem) * static_cast<size_t>(lanes) + 15) & ~size_t(15); }
-
-static hipError_t launchIndex(DcsCtx *ctx)
-{
-    const uint32_t lanes = static_cast<uint32_t>(ctx->idxLanes);
-    const uint32_t blocks = (ctx->idxStreams + lanes - 1) / lanes;
-    hipLaunchKernelGGL(dcsIndexKernel, dim3(blocks), dim3(64), indexDynBytes(ctx->idxLanes), ctx->stream, ctx->dIdxBlob, ctx->idxBlobDw, ctx->dIdxLocs,
-                       ctx->idxStreams, ctx->idxLanes, ctx->dTables, ctx->dIdxOut, ctx->dIdxInfos, static_cast<DcsFrameDigest *>(nullptr));
+    const uint32_t blocks = (nStreams + dcsidx::kWaves - 1) / dcsidx::kWaves;
+    hipLaunchKernelGGL(dcsidx::dcsIndexWaveKernel, dim3(blocks), dim3(dcsidx::kWaves * 64), 0, stream, blobBase, dLocs, nStreams, dTables,
+                       dOut, dInfos, dDigest);
     return hipGetLastError();
 }
 
-// lanes of a wavefront that walk a stream: few streams -> one lane per wavefront on as many CUs as possible (no
-// divergence); many -> fill the wavefronts
-static int indexLanes(const DcsCtx *ctx, uint32_t nStreams)
+static hipError_t launchIndex(DcsCtx *ctx)
 {
-    const uint32_t wavesWanted = static_cast<uint32_t>(ctx->numCUs) * 24;       // the wavefront slots of the chip for this kernel (76 VGPRs: 6 per SIMD)
-    const uint32_t lanes = (nStreams + wavesWanted - 1) / wavesWanted;
-    return static_cast<int>(lanes < 1 ? 1 : lanes > 64 ? 64 : lanes);
+    return launchIndexWave(ctx->stream, reinterpret_cast<uintptr_t>(ctx->dIdxBlob), ctx->dIdxLocs, ctx->idxStreams, ctx->dTables, ctx->dIdxOut,
+                           ctx->dIdxInfos, nullptr);
 }
 
 extern "C" DcsStatus dcs_index_streams_gpu(DcsCtx *ctx, const uint8_t *blob, size_t blobLen,
@@ -1295,7 +1112,6 @@ extern "C" DcsStatus dcs_index_streams_gpu(DcsCtx *ctx, const uint8_t *blob, siz
     ctx->idxBlobDw = blobAlloc / 4;
     ctx->idxStreams = nStreams;
     ctx->idxCap = outCap;
-    ctx->idxLanes = indexLanes(ctx, nStreams);
     HIPCHK(ctx, launchIndex(ctx));
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->dIdxOut, sizeof(DcsFrameIndex) * outCap, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(infos, ctx->dIdxInfos, sizeof(DcsStreamInfo) * nStreams, hipMemcpyDeviceToHost, ctx->stream));
