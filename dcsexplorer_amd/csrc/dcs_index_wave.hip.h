@@ -21,6 +21,18 @@
 
 namespace dcsidx {
 
+// diagnostic build only (-DDCS_IDX_STAMPS): shader cycles by phase, summed over the streams of a launch
+#ifdef DCS_IDX_STAMPS
+__device__ unsigned long long g_idxStamps[16];
+#define IDX_T0(name) const unsigned long long name = __builtin_amdgcn_s_memtime()
+#define IDX_ACC(b, k, t0) (b).acc[k] += __builtin_amdgcn_s_memtime() - (t0)
+#define IDX_CNT(b, k, n) (b).acc[k] += (n)
+#else
+#define IDX_T0(name)
+#define IDX_ACC(b, k, t0)
+#define IDX_CNT(b, k, n)
+#endif
+
 constexpr int kWaves = 4;               // wavefronts (= streams) per workgroup; they share the tables in LDS
 constexpr int kRingDw = 256;            // per wavefront: LDS mirror of the register window, for per-lane gathers
 constexpr int kRecDw = 40;              // staging of one record (37 dwords) or one stream summary (12)
@@ -61,6 +73,16 @@ __device__ __forceinline__ uint32_t rowSum16(uint32_t x)
     return x;
 }
 
+// inclusive prefix sum over the sixteen lanes of a row
+__device__ __forceinline__ uint32_t rowScan16(uint32_t x)
+{
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x111, 0xF, 0xF, true));   // row_shr:1
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x112, 0xF, 0xF, true));   // row_shr:2
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x114, 0xF, 0xF, true));   // row_shr:4
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x118, 0xF, 0xF, true));   // row_shr:8
+    return x;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // The stream's bits.  All state but W0..W2 is the same on every lane (the compiler keeps it in scalar registers).
 // Positions count bits from the dword that holds the stream's first byte, so they fit 32 bits whatever the address.
@@ -73,7 +95,8 @@ __device__ __forceinline__ uint32_t rowSum16(uint32_t x)
 struct WaveBits
 {
     static constexpr bool kAnalytic = true;
-    const uint32_t *sBase;      // the dword that holds the stream's first byte
+    const uint32_t __attribute__((address_space(1))) *sBase;      // the dword that holds the stream's first byte (global memory: a generic
+                                                                   // pointer would make every load a flat one, which LDS waits wait for too)
     uint32_t endByte;           // bytes from sBase to the stream's end
     uint32_t nDwValid;          // dwords that hold stream bytes
     uint32_t payBit = 0;        // first payload bit
@@ -86,6 +109,9 @@ struct WaveBits
     uint32_t lane;
     uint64_t win = 0;
     int have = 0;
+#ifdef DCS_IDX_STAMPS
+    unsigned long long acc[12] = { 0 };     // 0 walk, 1 header deltas, 2 huffRun, 3 its chains, 4 record out, 5 slides, 6 runs, 7 symbols, 8 frames, 9 per-band set-up of scan94
+#endif
 
     // dword d of the stream as stream bits; nothing behind the stream's last dword is touched (a damaged stream may
     // announce frames far beyond its bytes; the caller's buffer ends somewhere behind the stream's last dword)
@@ -125,6 +151,7 @@ struct WaveBits
         uint32_t j = ((payBit + pos) >> 5) - B;
         while (j >= 64)
         {
+            IDX_T0(tSlide);
             if (j >= 192)
             {
                 reload();
@@ -135,6 +162,7 @@ struct WaveBits
             ring[(B + 64 + lane) & (kRingDw - 1)] = W1;
             waveSync();
             W2 = load(B + 128 + lane);
+            IDX_ACC(*this, 5, tSlide);
         }
     }
     __device__ __forceinline__ uint32_t windowDword(uint32_t j) const       // j < 128, the same on every lane
@@ -220,6 +248,7 @@ struct Walk
     bool type1 = false, sub0 = false;
     uint32_t vHeader = 0;       // lane i < 16: header byte i
     uint32_t vBandType = 0;     // lane i < 16: AudioStream::bandTypeBuf[i]
+    uint32_t vCount = 0, vInc = 0;              // 1994+, lane i < 16: samples of band i (:1848-1862) and their spacing
     uint32_t vBB = 0, vSc1 = 0, vInputs = 0;    // OS93a Type 1: the stream's band-bits codebook, the first level of the scale
                                                 // codebook, inputs per band -- one entry per lane
     uint32_t err = 0;
@@ -238,14 +267,40 @@ struct Walk
     }
 };
 
+// The chain through the candidates: state = bits walked | samples left - 1 << 16, v = per lane the length of the code
+// that starts there minus, in the upper half, the samples it stands for.  Ends when the samples run out (sign bit) or
+// the walk leaves the 64 candidates (bit 6); `se` = the last candidate taken.  Written out because the loop the
+// compiler makes of it pays a taken branch per symbol (62 cycles a symbol measured, against ~20 for this form: eight
+// steps in a row whose exits are branches NOT taken).
+__device__ __forceinline__ void chain(uint32_t v, uint32_t &state, uint32_t &se)
+{
+    uint32_t t;
+#define DCS_CHAIN_STEP                                  \
+        "v_readlane_b32 %[se], %[v], %[st]\n\t"          \
+        "s_add_u32 %[st], %[st], %[se]\n\t"              \
+        "s_and_b32 %[t], %[st], 0x80000040\n\t"          \
+        "s_cbranch_scc1 2f\n\t"
+    asm volatile("s_nop 0\n"
+                 "1:\n\t"
+                 DCS_CHAIN_STEP DCS_CHAIN_STEP DCS_CHAIN_STEP DCS_CHAIN_STEP
+                 DCS_CHAIN_STEP DCS_CHAIN_STEP DCS_CHAIN_STEP DCS_CHAIN_STEP
+                 "s_branch 1b\n"
+                 "2:\n\t"
+                 : [st] "+s"(state), [se] "=&s"(se), [t] "=&s"(t)
+                 : [v] "v"(v)
+                 : "scc");
+#undef DCS_CHAIN_STEP
+}
+
 // A run of Huffman-coded samples (:2186-2225): symbols from the current position until `rem` samples are accounted for
 // (a two-zeros code counts for two).  Returns what is left: 0, or -1 when the last code was a two-zeros code with one
-// sample to go.  `info` = look-ahead width | codebook offset << 4 (DcsLdsTables::cbInfo).
-__device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *cb94, uint32_t info, int rem)
+// sample to go.  `book` = the codebook's direct look-up table on the next `maxBits` bits.
+__device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *book, uint32_t maxBits, int rem)
 {
-    const uint32_t maxBits = info & 0xF;
-    const uint16_t *book = cb94 + (info >> 4);
     b.any = true;
+    IDX_T0(tRun);
+    IDX_CNT(b, 6, 1);
+    IDX_CNT(b, 7, rem);
     do
     {
         b.ensure();
@@ -255,12 +310,9 @@ __device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *cb94, uint32
         // state: bits walked | samples left - 1 << 16.  Done when the samples run out (sign) or the walk leaves the 64 candidates.
         uint32_t state = static_cast<uint32_t>(rem - 1) << 16;
         uint32_t se;
-        do
-        {
-            se = rl(v, state & 63u);
-            state += se;
-        }
-        while ((state & 0x80000040u) == 0);
+        IDX_T0(tChain);
+        chain(v, state, se);
+        IDX_ACC(b, 3, tChain);
         const uint32_t off = state & 0xFFFFu;
         rem = (static_cast<int32_t>(state) >> 16) + 1;
         b.hi = umax(b.hi, b.pos + off - (se & 0xFFFFu) + maxBits);      // the last symbol's look
@@ -268,6 +320,7 @@ __device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *cb94, uint32
     }
     while (rem > 0);
     b.have = 0;
+    IDX_ACC(b, 2, tRun);
     return rem;
 }
 
@@ -310,6 +363,10 @@ __device__ __forceinline__ uint32_t headerDeltas94(Walk &s)
 }
 
 // --- 1994+ frame (:1679-2261; the walk of dcsScan94, dcs_scan.h) ---------------------------------------------------
+// Once the frame header is read, everything about a band but the length of its Huffman-coded samples follows from its
+// band-type code and the stream header: lane b works that out for band b (one look-up in the decode kernel's set-up
+// table, DcsLdsTables::band94), output indices and the bits of the fixed-width bands become prefix sums over the lanes,
+// and what is left to do one after the other are the Huffman-coded bands.
 __device__ void scan94(Walk &s)
 {
     WaveBits &b = s.b;
@@ -325,79 +382,96 @@ __device__ void scan94(Walk &s)
         s.preAdj = rl(p, 0) | (rl(p, 1) << 4) | (rl(p, 2) << 8);
     }
 
+    IDX_T0(tHdr);
     const uint32_t vDelta = headerDeltas94(s);
+    IDX_ACC(b, 1, tHdr);
     if (static_cast<int>(lane) < s.nBands)
         s.vBandType = (s.vBandType + vDelta - 16u) & 0xFFFFu;
-    s.hdrBits = (b.pos - frameStart) & 0xFFFFu;
+    const uint32_t hdrBits = b.pos - frameStart;
+    s.hdrBits = hdrBits & 0xFFFFu;
     s.vRecBT = s.vBandType > 255u ? 255u : s.vBandType;
 
-    // per band, all at once: the sample code behind the band-type code (:1914-1961) and its codebook
-    uint32_t vCode = s.vBandType;
-    if (s.type1)
-        vCode = T.xlat94[(lane < 3 ? 0u : lane < 6 ? 16u : 32u) + (s.vBandType & 15u)] & 0xFFu;
-    const uint32_t vInfo = T.cbInfo[vCode < 8u ? vCode : 0u];
+    // lane b: band b (:1848-2005 through the table: code translation, codebook, fixed width, no such code)
+    const uint32_t raw = s.vBandType;
+    const uint32_t at = s.type1 ? (lane < 3 ? 0u : lane < 6 ? 17u : 34u) + (raw < 16u ? raw : 16u)
+                                : static_cast<uint32_t>(DCS_B94_TYPE0) + (raw < 17u ? raw : 17u);
+    const uint32_t d = T.band94[lane < 16 ? at : 0u];
+    const bool active = static_cast<int>(lane) < s.nBands;
+    const unsigned long long fatalBands = __ballot(active && (d & DCS_B94_FATAL) != 0);
+    const uint32_t procEnd = fatalBands != 0 ? static_cast<uint32_t>(__builtin_ctzll(fatalBands)) : static_cast<uint32_t>(s.nBands);
+    const bool coded = lane < procEnd && raw != 0;
+    const bool rawBand = coded && (d & DCS_B94_RAW) != 0;
+    const bool huffBand = coded && (d & DCS_B94_RAW) == 0;
+    const uint32_t width = 32u - ((d >> 11) & 31u);             // fixed sample width, or the codebook's look-ahead
+    const uint32_t adv = lane >= procEnd ? 0u : raw == 0 ? s.vCount : s.vCount * s.vInc;      // (the halved count, :1886)
+    const uint32_t fixedBits = rawBand ? s.vCount * width : 0u;
+    const uint32_t advIncl = rowScan16(adv), fixedIncl = rowScan16(fixedBits);
+    const uint32_t outIdxB = 1u + advIncl - adv;                // output index at the band's start
+    const uint32_t fixedBefore = fixedIncl - fixedBits;         // bits of the fixed-width bands before it
 
-    int outIdx = 1;
-    for (int band = 0 ; band < s.nBands ; ++band)
+    // the Huffman-coded bands, one after the other
+    uint32_t vHuffBefore = 0;                                   // lane b: bits of the Huffman-coded bands before band b
+    uint32_t huffBits = 0, midBit = 0, midIdx = 0;
+    const uint32_t base = frameStart + hdrBits;
+    for (uint32_t left = static_cast<uint32_t>(__ballot(huffBand)) ; left != 0 ; left &= left - 1)
     {
-        s.putSplit(band, b.pos - frameStart, 0, 0, static_cast<uint32_t>(outIdx) & 0x1FFu);
-        const uint32_t hb = rl(s.vHeader, static_cast<uint32_t>(band)) & 0x7Fu;
-        int count = band == 0 ? 7 : band == 1 ? 8 : band == 15 ? 32 : 16;      // :1848-1850
-        int inc = 1;
-        if (hb & 0x40) { count /= 2; inc = 2; }
-        const uint32_t raw = rl(s.vBandType, static_cast<uint32_t>(band));
-        if (raw == 0)
+        const uint32_t h = static_cast<uint32_t>(__builtin_ctz(left));
+        const uint32_t start = base + rl(fixedBefore, h) + huffBits;
+        b.pos = start;
+        const uint32_t dh = rl(d, h);
+        const uint16_t *book = reinterpret_cast<const uint16_t *>(&T) + (dh & 0x7FFu);
+        const uint32_t maxBits = 32u - ((dh >> 11) & 31u);
+        const int count = static_cast<int>(rl(s.vCount, h));
+        if (h != 15)
         {
-            outIdx += count;                            // the halved count (:1886)
-            continue;
-        }
-        int code = static_cast<int>(raw);
-        if (s.type1)
-        {
-            if (raw > 15) { s.fatal(); return; }
-            code = static_cast<int>(rl(vCode, static_cast<uint32_t>(band)));
-        }
-        if (code > 16) { s.fatal(); return; }
-        outIdx += count * inc;
-        if (code == 0)
-        {
-            s.err |= DCS_FRAME_STOP;                    // :1985-1991, consumes nothing
-        }
-        else if (code <= 6)
-        {
-            const uint32_t info = rl(vInfo, static_cast<uint32_t>(band));
-            int i = count;
-            // band 15 in two halves; where the second one starts is recorded (dcsPutMid15, dcs_scan.h)
-            for (int piece = band == 15 ? 0 : 1 ; piece < 2 ; ++piece)
-            {
-                const int lim = piece == 0 ? count / 2 : 0;
-                if (i > lim)
-                {
-                    const int r = huffRun(b, T.cb94, info, i - lim);
-                    i = lim + r;
-                    if (r < 0 && lim == 0) { s.err |= DCS_FRAME_STOP; i = 0; }      // two zeros with one slot left (:2213-2218)
-                }
-                if (piece == 0)
-                {
-                    const uint32_t lo = rl(s.vSplitLo, 14), hiw = rl(s.vSplitHi, 14);
-                    s.vSplitLo = wl(s.vSplitLo, 14, (lo & 0xFFFFu) | (((b.pos - frameStart) & 0xFFFFu) << 16));
-                    s.vSplitHi = wl(s.vSplitHi, 14, (hiw & 0xFFFF0000u) | (static_cast<uint32_t>(outIdx - i * inc) & 0x1FFu) | (i < lim ? DCS_MID15_STRADDLE : 0u));
-                }
-            }
-        }
-        else if (band == 15)
-        {
-            b.skipRun(count - count / 2, code);
-            const uint32_t lo = rl(s.vSplitLo, 14), hiw = rl(s.vSplitHi, 14);
-            s.vSplitLo = wl(s.vSplitLo, 14, (lo & 0xFFFFu) | (((b.pos - frameStart) & 0xFFFFu) << 16));
-            s.vSplitHi = wl(s.vSplitHi, 14, (hiw & 0xFFFF0000u) | (static_cast<uint32_t>(outIdx - (count / 2) * inc) & 0x1FFu));
-            b.skipRun(count / 2, code);
+            if (huffRun(b, book, maxBits, count) < 0)
+                s.err |= DCS_FRAME_STOP;                        // two zeros with one slot left (:2213-2218)
         }
         else
         {
-            b.skipRun(count, code);
+            // band 15 in two halves; where the second one starts is recorded (dcsPutMid15, dcs_scan.h)
+            const int lim = count / 2;
+            const int inc = static_cast<int>(rl(s.vInc, 15));
+            int i = lim + huffRun(b, book, maxBits, count - lim);
+            midBit = (b.pos - frameStart) & 0xFFFFu;
+            midIdx = ((rl(outIdxB, 15) + static_cast<uint32_t>((count - i) * inc)) & 0x1FFu) | (i < lim ? DCS_MID15_STRADDLE : 0u);
+            if (i > 0 && huffRun(b, book, maxBits, i) < 0)
+                s.err |= DCS_FRAME_STOP;
         }
+        const uint32_t len = b.pos - start;
+        huffBits += len;
+        vHuffBefore += lane > h ? len : 0u;
     }
+    b.pos = base + rl(fixedIncl, 15) + huffBits;
+    b.have = 0;
+    // the fixed-width bands' looks: the last one's reaches furthest, exactly to its end
+    const uint32_t bitDelta = hdrBits + fixedBefore + vHuffBefore;
+    const uint32_t rawBands = static_cast<uint32_t>(__ballot(rawBand));
+    if (rawBands != 0)
+    {
+        const uint32_t r = 31u - static_cast<uint32_t>(__builtin_clz(rawBands));
+        b.any = true;
+        b.hi = umax(b.hi, frameStart + rl(bitDelta, r) + rl(fixedBits, r));
+    }
+    if (lane == 15 && rawBand)
+    {
+        const uint32_t second = s.vCount / 2;
+        midBit = (bitDelta + (s.vCount - second) * width) & 0xFFFFu;
+        midIdx = (outIdxB + (s.vCount - second) * s.vInc) & 0x1FFu;
+    }
+    // split[b - 1] = the state at the start of band b: every band walked, and the one that was fatal
+    const bool recorded = lane >= 1 && static_cast<int>(lane) < s.nBands && lane <= procEnd;
+    uint32_t lo = recorded ? (bitDelta & 0xFFFFu) : 0u;
+    uint32_t hiw = recorded ? (outIdxB & 0x1FFu) << 16 : 0u;
+    if (lane == 15 && coded)
+    {
+        lo |= midBit << 16;
+        hiw |= midIdx;
+    }
+    s.vSplitLo = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(lo), 0x101, 0xF, 0xF, true));     // row_shl:1: lane k takes lane k + 1
+    s.vSplitHi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(hiw), 0x101, 0xF, 0xF, true));
+    if (fatalBands != 0)
+        s.fatal();
 }
 
 // --- 1993 frame, Type 0 and OS93b Type 1 (:2293-2615; dcsScan93) ------------------------------------------------------
@@ -615,7 +689,7 @@ __global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blob
     s.L = &L;
     s.lane = lane;
     s.os = os;
-    s.b.sBase = reinterpret_cast<const uint32_t *>(stream - skew);
+    s.b.sBase = (const uint32_t __attribute__((address_space(1))) *)(reinterpret_cast<uintptr_t>(stream) - skew);
     s.b.endByte = skew + len;
     s.b.nDwValid = (skew + len + 3) / 4;
     s.b.ring = L.ring[wave];
@@ -649,6 +723,12 @@ __global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blob
     s.format = format;
     s.type1 = typeBit;
     s.sub0 = ((h1 | h2) & 0x80u) == 0;
+    {
+        const uint32_t full = lane == 0 ? 7u : lane == 1 ? 8u : lane == 15 ? 32u : 16u;        // :1848-1850
+        const bool strided = (s.vHeader & 0x40u) != 0;                                             // :1858-1862
+        s.vCount = lane < 16 ? (strided ? full / 2 : full) : 0u;
+        s.vInc = strided ? 2u : 1u;
+    }
     if (format == DCS_FMT_93A_T1)
     {
         s.vBB = L.T.bandBits93a[((h0 & 0x60u) >> 1) + (lane & 15)];
@@ -662,6 +742,8 @@ __global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blob
     for (uint32_t f = 0 ; f < nFrames ; ++f)
     {
         const uint32_t frameBit = s.b.pos;
+        IDX_T0(tWalk);
+        IDX_CNT(s.b, 8, 1);
         s.err = 0;
         s.vSplitLo = 0; s.vSplitHi = 0; s.vRecBT = 0; s.hdrBits = 0; s.preAdj = 0;
         switch (format)
@@ -671,6 +753,8 @@ __global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blob
         case DCS_FMT_93A_T1: scan93a(s); break;
         default:             scan94(s); break;
         }
+        IDX_ACC(s.b, 0, tWalk);
+        IDX_T0(tOut);
         const uint32_t nBits = (s.b.pos - frameBit) & 0xFFFFu;
         const uint32_t flags = ((s.err << 4) | (s.err != 0 ? DCS_IDX_SERIAL : 0u)) & 0xFFu;
         // the record, put together in LDS and written out 37 dwords wide
@@ -694,6 +778,7 @@ __global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blob
         if (outDigest != nullptr && lane == 0)
             outDigest[valid] = DcsFrameDigest{ frameBit, static_cast<uint16_t>(nBits), static_cast<uint8_t>(s.nBands), static_cast<uint8_t>(flags) };
         ++valid;
+        IDX_ACC(s.b, 4, tOut);
         payloadBits = s.b.pos;
         if (s.err != 0)
             break;                  // the reference stops the channel on the next tick (:95-116)
@@ -717,6 +802,11 @@ __global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blob
     waveSync();
     if (lane < 12)
         reinterpret_cast<uint32_t *>(infos + k)[lane] = rec[lane];
+#ifdef DCS_IDX_STAMPS
+    if (lane == 0)
+        for (int i = 0 ; i < 12 ; ++i)
+            atomicAdd(&g_idxStamps[i], s.b.acc[i]);
+#endif
 }
 
 }   // namespace dcsidx

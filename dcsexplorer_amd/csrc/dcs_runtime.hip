@@ -1119,6 +1119,17 @@ extern "C" DcsStatus dcs_index_streams_gpu(DcsCtx *ctx, const uint8_t *blob, siz
     return DCS_OK;
 }
 
+#ifdef DCS_IDX_STAMPS
+// diagnostic build: the index kernel's cycle accumulators since the last call (tools/index_stamps.py)
+extern "C" int dcs_debug_index_stamps(unsigned long long *out12)
+{
+    unsigned long long zero[16] = { 0 };
+    if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(dcsidx::g_idxStamps), 12 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(dcsidx::g_idxStamps), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" DcsStatus dcs_index_streams_gpu_time(DcsCtx *ctx, int iters, float *avgMs)
 {
     if (ctx == nullptr || avgMs == nullptr || iters < 1)
