@@ -60,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--corpus-streams", type=int, default=20, help="streams per title of the corpus workload (SURVEY 8d's full "
                     "stand-in is 600; 20 is the size whose per-stream reference hashes are committed)")
     ap.add_argument("--e2e-depth", type=int, default=8, help="lists in flight of end_to_end.sustained_host_index")
-    ap.add_argument("--e2e-device-depth", type=int, default=32, help="lists in flight of end_to_end.sustained_device_index")
+    ap.add_argument("--e2e-device-depth", type=int, default=48, help="lists in flight of end_to_end.sustained_device_index")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the N-rank path (gloo, no GPU, no kernel)")
     ap.add_argument("--share-gpu", action="store_true", help="testing on a one-GPU box: every rank decodes on GPU 0 and gloo carries the "
                     "barrier and the max (RCCL needs one device per rank); exercises the whole N-rank path but is no scaling measurement")
@@ -165,7 +165,7 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
         per_list = (time.perf_counter() - t0) / n_lists
         pipe.close()
         return {"value": n_frames * 240 / per_list, "ms_per_list": per_list * 1e3, "depth": depth, "lists": n_lists,
-                "index_pass": "device (dcsIndexKernel, one lane per stream)" if on_device else "host pool",
+                "index_pass": "device (dcsIndexWaveKernel, one wavefront per stream)" if on_device else "host pool",
                 "packer": "device (dcsPackKernel, from resident records and streams)" if pack_on_device else "host",
                 "worker_host_ms": sum(host_ms) / len(host_ms), "worker_device_ms": sum(dev_ms) / len(dev_ms)}
 

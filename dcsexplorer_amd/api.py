@@ -707,7 +707,7 @@ class Context:
         return out
 
     def index_streams_gpu(self, streams):
-        """dcs_index_streams_gpu: the index pass on the GPU, one lane per stream.  Same result as
+        """dcs_index_streams_gpu: the index pass on the GPU, one wavefront per stream.  Same result as
         index_streams / index_stream."""
         streams = list(streams)
         if not streams:

@@ -85,7 +85,13 @@ struct DcsDevTables
     uint16_t fftCoef[256];              // sin block 0..0x7F, cos block 0x80..0xFF, bit-reversed order (:366)
     uint16_t ovlCoef[16];               // overlap window (:314)
     int32_t  twA[8][4];                 // twiddles 0..7 as the in-lane (layout A) butterflies take them: 2 cos, 2 sin, -2 sin, 0
+    // The device index pass (dcs_index_wave.hip.h) takes several 1994+ sample codes per step: per codebook 1..6 and for the
+    // next DCS_IDX_MULTI_BITS bits, the codes that lie entirely inside them, as long as they stand for at most
+    // DCS_IDX_MULTI_SAMPLES samples together (at least one code): total length | samples << 4
+    uint8_t  multi94[6][1 << 10];
 };
+#define DCS_IDX_MULTI_BITS 10
+#define DCS_IDX_MULTI_SAMPLES 4
 
 // host-side view (same structure; one process-wide immutable instance)
 const DcsDevTables &dcsTables();

@@ -43,7 +43,8 @@ struct IndexLds
     DcsLdsTables T;
     uint16_t fast94[256];
     uint16_t trie94[DCS_TRIE94_MAX];
-    uint32_t ring[kWaves][kRingDw];
+    uint8_t multi94[6][1 << DCS_IDX_MULTI_BITS];
+    uint32_t ring[kWaves][kRingDw + 2];     // (slot 0 once more behind the end: a gather reads two neighbours with one instruction)
     uint32_t rec[kWaves][kRecDw];
 };
 
@@ -128,6 +129,13 @@ struct WaveBits
         }
         return __builtin_bswap32(raw);
     }
+    __device__ __forceinline__ void ringPut(uint32_t d, uint32_t v)
+    {
+        const uint32_t slot = d & (kRingDw - 1);
+        ring[slot] = v;
+        if (slot == 0)
+            ring[kRingDw] = v;
+    }
     __device__ __forceinline__ void reload()
     {
         B = (payBit + pos) >> 5;
@@ -135,8 +143,8 @@ struct WaveBits
         W1 = load(B + 64 + lane);
         W2 = load(B + 128 + lane);
         waveSync();
-        ring[(B + lane) & (kRingDw - 1)] = W0;
-        ring[(B + 64 + lane) & (kRingDw - 1)] = W1;
+        ringPut(B + lane, W0);
+        ringPut(B + 64 + lane, W1);
         waveSync();
     }
     __device__ __forceinline__ void setPayload(uint32_t skewPlusOff)
@@ -159,7 +167,7 @@ struct WaveBits
             }
             W0 = W1; W1 = W2; B += 64; j -= 64;
             waveSync();
-            ring[(B + 64 + lane) & (kRingDw - 1)] = W1;
+            ringPut(B + 64 + lane, W1);
             waveSync();
             W2 = load(B + 128 + lane);
             IDX_ACC(*this, 5, tSlide);
@@ -231,7 +239,8 @@ struct WaveBits
     {
         const uint32_t a = payBit + pos + off;
         const uint32_t d = a >> 5;
-        const uint32_t h = ring[d & (kRingDw - 1)], l = ring[(d + 1) & (kRingDw - 1)];
+        const uint32_t *p = ring + (d & (kRingDw - 1));
+        const uint32_t h = p[0], l = p[1];
         return static_cast<uint32_t>((((static_cast<uint64_t>(h) << 32) | l) << (a & 31)) >> 32);
     }
     __device__ __forceinline__ uint32_t bitPos() const { return pos; }
@@ -294,8 +303,11 @@ __device__ __forceinline__ void chain(uint32_t v, uint32_t &state, uint32_t &se)
 
 // A run of Huffman-coded samples (:2186-2225): symbols from the current position until `rem` samples are accounted for
 // (a two-zeros code counts for two).  Returns what is left: 0, or -1 when the last code was a two-zeros code with one
-// sample to go.  `book` = the codebook's direct look-up table on the next `maxBits` bits.
-__device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *book, uint32_t maxBits, int rem)
+// sample to go.  `book` = the codebook's direct look-up table on the next `maxBits` bits, `multi` = its several-codes
+// table (DcsDevTables::multi94): while more than DCS_IDX_MULTI_SAMPLES samples are to go a step of the chain takes
+// all the codes of such an entry, the band's last codes go one by one (so the two-zeros rule and the run's last look,
+// the one that can decide nBytes, are the reference's).
+__device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *book, uint32_t maxBits, const uint8_t *multi, int rem)
 {
     b.any = true;
     IDX_T0(tRun);
@@ -304,18 +316,32 @@ __device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *book, uint32
     do
     {
         b.ensure();
-        // lane l: the code that would start l bits from here -- its length, and minus the samples it stands for in the upper half
-        const uint32_t e = book[b.gather32(b.lane) >> (32 - maxBits)];
-        const uint32_t v = ((e >> 8) & 0x1Fu) - ((e >> 13) == 2 ? 0x20000u : 0x10000u);
-        // state: bits walked | samples left - 1 << 16.  Done when the samples run out (sign) or the walk leaves the 64 candidates.
-        uint32_t state = static_cast<uint32_t>(rem - 1) << 16;
-        uint32_t se;
+        // lane l: the code(s) that would start l bits from here -- length, and minus the samples in the upper half
+        const uint32_t w = b.gather32(b.lane);
+        const uint32_t e = book[w >> (32 - maxBits)];
+        const uint32_t m = multi[w >> (32 - DCS_IDX_MULTI_BITS)];
+        const uint32_t vSingle = ((e >> 8) & 0x1Fu) - ((e >> 13) == 2 ? 0x20000u : 0x10000u);
+        const uint32_t vMulti = (m & 15u) - ((m >> 4) << 16);
+        // state: bits walked | samples left - 1 (single) or - 1 - DCS_IDX_MULTI_SAMPLES (multi) << 16.  A chain ends when
+        // the samples run out (sign) or the walk leaves the 64 candidates (bit 6).
+        uint32_t off = 0, se;
         IDX_T0(tChain);
-        chain(v, state, se);
+        if (rem > DCS_IDX_MULTI_SAMPLES)
+        {
+            uint32_t state = static_cast<uint32_t>(rem - 1 - DCS_IDX_MULTI_SAMPLES) << 16;
+            chain(vMulti, state, se);
+            off = state & 0xFFFFu;
+            rem = (static_cast<int32_t>(state) >> 16) + 1 + DCS_IDX_MULTI_SAMPLES;
+        }
+        if (rem <= DCS_IDX_MULTI_SAMPLES && off < 64)
+        {
+            uint32_t state = off | (static_cast<uint32_t>(rem - 1) << 16);
+            chain(vSingle, state, se);
+            off = state & 0xFFFFu;
+            rem = (static_cast<int32_t>(state) >> 16) + 1;
+            b.hi = umax(b.hi, b.pos + off - (se & 0xFFFFu) + maxBits);      // the last symbol's look
+        }
         IDX_ACC(b, 3, tChain);
-        const uint32_t off = state & 0xFFFFu;
-        rem = (static_cast<int32_t>(state) >> 16) + 1;
-        b.hi = umax(b.hi, b.pos + off - (se & 0xFFFFu) + maxBits);      // the last symbol's look
         b.pos += off;
     }
     while (rem > 0);
@@ -325,34 +351,56 @@ __device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *book, uint32
 }
 
 // The frame header of a 1994+ frame: one band-type delta code per populated band (:1780-1834), lane k < nBands
-// receives code k's payload (delta + 16).  Candidates through the first-level table; a code longer than eight bits
-// (rare) is walked through the trie on the scalar unit.
+// receives code k's payload (delta + 16).  Candidates through the first-level table; the chain takes eight codes
+// without a test (eight codes of at most eight bits stay inside the 64 candidates) and only marks where it has been;
+// which code is whose follows from the marks afterwards (a lane's rank among them), and the payloads travel to
+// their bands' lanes in one ds_permute.  A code longer than eight bits (rare) sends the rest of the header through the
+// trie on the scalar unit.
 __device__ __forceinline__ uint32_t headerDeltas94(Walk &s)
 {
     WaveBits &b = s.b;
+    const uint32_t lane = s.lane;
     uint32_t vDelta = 16;
     int band = 0;
     while (band < s.nBands)
     {
         b.ensure();
-        const uint32_t e = s.L->fast94[b.gather32(b.lane) >> 24];
-        uint32_t off = 0;
-        bool longCode = false;
-        while (band < s.nBands && off < 64)
+        const uint32_t e = s.L->fast94[b.gather32(lane) >> 24];
+        const bool leaf = (e & 0x8000u) != 0;
+        const uint32_t vLen = leaf ? (e >> 8) & 0xFu : 0u;      // (the chain does not get past a long code)
+        unsigned long long marks = 0;
+        uint32_t off = 0, t;
+#define DCS_HDR_STEP                                    \
+            "s_bitset1_b64 %[m], %[off]\n\t"             \
+            "v_readlane_b32 %[t], %[v], %[off]\n\t"       \
+            "s_add_u32 %[off], %[off], %[t]\n\t"
+        asm volatile("s_nop 0\n\t"
+                     DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP
+                     : [m] "+s"(marks), [off] "+s"(off), [t] "=&s"(t)
+                     : [v] "v"(vLen)
+                     : "scc");
+#undef DCS_HDR_STEP
+        const int n = s.nBands - band < 8 ? s.nBands - band : 8;
+        const bool marked = ((marks >> lane) & 1) != 0;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(marks >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(marks), 0u));
+        const bool mine = marked && static_cast<int>(rank) < n;
+        if (__ballot(mine && !leaf) != 0)
         {
-            const uint32_t se = rl(e, off);
-            if (!(se & 0x8000u)) { longCode = true; break; }
-            vDelta = wl(vDelta, static_cast<uint32_t>(band), se & 0xFFu);
-            off += (se >> 8) & 0xFu;
-            ++band;
+            // a long code among them: this and the remaining codes one by one
+            b.have = 0;
+            for ( ; band < s.nBands ; ++band)
+                vDelta = wl(vDelta, static_cast<uint32_t>(band), static_cast<uint32_t>(dcsReadVlcFast(b, s.L->fast94, s.L->trie94)));
+            break;
         }
-        b.pos += off;
+        const uint32_t got = static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>((mine ? static_cast<uint32_t>(band) + rank : 63u) << 2),
+                                                                                 static_cast<int>(e & 0xFFu)));
+        if (static_cast<int>(lane) >= band && static_cast<int>(lane) < band + n)
+            vDelta = got;
+        // where the next code starts: behind the eighth, or at the mark of rank n
+        const uint32_t adv = n == 8 ? off : static_cast<uint32_t>(__builtin_ctzll(__ballot(marked && static_cast<int>(rank) == n)));
+        b.pos += adv;
         b.have = 0;
-        if (longCode)
-        {
-            vDelta = wl(vDelta, static_cast<uint32_t>(band), static_cast<uint32_t>(dcsReadVlcFast(b, s.L->fast94, s.L->trie94)));
-            ++band;
-        }
+        band += n;
     }
     if (s.nBands > 0)
     {
@@ -409,6 +457,12 @@ __device__ void scan94(Walk &s)
     const uint32_t outIdxB = 1u + advIncl - adv;                // output index at the band's start
     const uint32_t fixedBefore = fixedIncl - fixedBits;         // bits of the fixed-width bands before it
 
+    // what a Huffman-coded band's walk needs, in two words: bits of the fixed-width bands before it | samples << 16, and
+    // codebook (byte offset in the tables) | its several-codes table (of the six: look-aheads 2, 3, 5, 7, 8, 9, :2005) << 12
+    // | look-ahead << 25
+    const uint32_t vRunA = fixedBefore | (s.vCount << 16);
+    const uint32_t vRunB = ((d & 0x7FFu) * 2u) | ((width <= 3u ? width - 2u : width == 5u ? 2u : width - 4u) << 22) | (width << 25);
+
     // the Huffman-coded bands, one after the other
     uint32_t vHuffBefore = 0;                                   // lane b: bits of the Huffman-coded bands before band b
     uint32_t huffBits = 0, midBit = 0, midIdx = 0;
@@ -416,15 +470,16 @@ __device__ void scan94(Walk &s)
     for (uint32_t left = static_cast<uint32_t>(__ballot(huffBand)) ; left != 0 ; left &= left - 1)
     {
         const uint32_t h = static_cast<uint32_t>(__builtin_ctz(left));
-        const uint32_t start = base + rl(fixedBefore, h) + huffBits;
+        const uint32_t runA = rl(vRunA, h), runB = rl(vRunB, h);
+        const uint32_t start = base + (runA & 0xFFFFu) + huffBits;
         b.pos = start;
-        const uint32_t dh = rl(d, h);
-        const uint16_t *book = reinterpret_cast<const uint16_t *>(&T) + (dh & 0x7FFu);
-        const uint32_t maxBits = 32u - ((dh >> 11) & 31u);
-        const int count = static_cast<int>(rl(s.vCount, h));
+        const uint16_t *book = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(&T) + (runB & 0xFFFu));
+        const uint8_t *multi = &s.L->multi94[0][0] + ((runB >> 12) & 0x1FFFu);
+        const uint32_t maxBits = runB >> 25;
+        const int count = static_cast<int>(runA >> 16);
         if (h != 15)
         {
-            if (huffRun(b, book, maxBits, count) < 0)
+            if (huffRun(b, book, maxBits, multi, count) < 0)
                 s.err |= DCS_FRAME_STOP;                        // two zeros with one slot left (:2213-2218)
         }
         else
@@ -432,10 +487,10 @@ __device__ void scan94(Walk &s)
             // band 15 in two halves; where the second one starts is recorded (dcsPutMid15, dcs_scan.h)
             const int lim = count / 2;
             const int inc = static_cast<int>(rl(s.vInc, 15));
-            int i = lim + huffRun(b, book, maxBits, count - lim);
+            int i = lim + huffRun(b, book, maxBits, multi, count - lim);
             midBit = (b.pos - frameStart) & 0xFFFFu;
             midIdx = ((rl(outIdxB, 15) + static_cast<uint32_t>((count - i) * inc)) & 0x1FFu) | (i < lim ? DCS_MID15_STRADDLE : 0u);
-            if (i > 0 && huffRun(b, book, maxBits, i) < 0)
+            if (i > 0 && huffRun(b, book, maxBits, multi, i) < 0)
                 s.err |= DCS_FRAME_STOP;
         }
         const uint32_t len = b.pos - start;
@@ -657,10 +712,19 @@ __device__ void scan93a(Walk &s)
     }
 }
 
+// where a stream's results go when the streams of one launch belong to different owners (the pipeline's lists, each
+// with buffers of its own)
+struct StreamOut
+{
+    DcsFrameIndex *records;
+    DcsFrameDigest *digest;     // may be null
+    DcsStreamInfo *info;
+};
+
 // stream k of the launch is walked by wavefront k
 __global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blobBase, const DcsStreamLoc *locs, uint32_t nStreams,
                                                                   const DcsDevTables *tables, DcsFrameIndex *out, DcsStreamInfo *infos,
-                                                                  DcsFrameDigest *digest)
+                                                                  DcsFrameDigest *digest, const StreamOut *outs)
 {
     __shared__ IndexLds L;
     {
@@ -672,6 +736,8 @@ __global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blob
             L.fast94[i] = tables->fast94[i];
         for (uint32_t i = threadIdx.x ; i < DCS_TRIE94_MAX ; i += blockDim.x)
             L.trie94[i] = tables->trie94[i];
+        for (uint32_t i = threadIdx.x ; i < sizeof(L.multi94) / 4 ; i += blockDim.x)
+            reinterpret_cast<uint32_t *>(L.multi94)[i] = reinterpret_cast<const uint32_t *>(tables->multi94)[i];
     }
     __syncthreads();
     const uint32_t wave = uni(threadIdx.x >> 6);
@@ -736,8 +802,21 @@ __global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blob
         s.vInputs = L.T.inputs93a[lane < 24 ? lane : 0];
     }
 
-    DcsFrameIndex *const outRec = out + loc.firstRecord;
-    DcsFrameDigest *const outDigest = digest != nullptr ? digest + loc.firstRecord : nullptr;
+    // (one array for the launch, or per stream)
+    DcsFrameIndex *outRec;
+    DcsFrameDigest *outDigest;
+    DcsStreamInfo *outInfo;
+    if (outs != nullptr)
+    {
+        const StreamOut o = outs[k];
+        outRec = o.records; outDigest = o.digest; outInfo = o.info;
+    }
+    else
+    {
+        outRec = out + loc.firstRecord;
+        outDigest = digest != nullptr ? digest + loc.firstRecord : nullptr;
+        outInfo = infos + k;
+    }
     uint32_t valid = 0, payloadBits = 0;
     for (uint32_t f = 0 ; f < nFrames ; ++f)
     {
@@ -757,24 +836,24 @@ __global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blob
         IDX_T0(tOut);
         const uint32_t nBits = (s.b.pos - frameBit) & 0xFFFFu;
         const uint32_t flags = ((s.err << 4) | (s.err != 0 ? DCS_IDX_SERIAL : 0u)) & 0xFFu;
-        // the record, put together in LDS and written out 37 dwords wide
-        waveSync();
-        if (lane < 16)
-            reinterpret_cast<uint8_t *>(rec)[8 + lane] = static_cast<uint8_t>(s.vRecBT);
-        if (lane < 15)
+        // the record, every lane its part (nothing waits for these stores)
         {
-            rec[7 + 2 * lane] = s.vSplitLo;
-            rec[8 + 2 * lane] = s.vSplitHi;
+            uint8_t *const r8 = reinterpret_cast<uint8_t *>(outRec + valid);
+            uint32_t *const r32 = reinterpret_cast<uint32_t *>(r8);
+            if (lane < 16)
+                r8[8 + lane] = static_cast<uint8_t>(s.vRecBT);
+            if (lane < 15)
+            {
+                r32[7 + 2 * lane] = s.vSplitLo;
+                r32[8 + 2 * lane] = s.vSplitHi;
+            }
+            if (lane == 0)
+            {
+                r32[0] = frameBit;
+                r32[1] = nBits | (s.hdrBits << 16);
+                r32[6] = (s.preAdj & 0xFFFFu) | (static_cast<uint32_t>(s.nBands) << 16) | (flags << 24);
+            }
         }
-        if (lane == 0)
-        {
-            rec[0] = frameBit;
-            rec[1] = nBits | (s.hdrBits << 16);
-            rec[6] = (s.preAdj & 0xFFFFu) | (static_cast<uint32_t>(s.nBands) << 16) | (flags << 24);
-        }
-        waveSync();
-        if (lane < 37)
-            reinterpret_cast<uint32_t *>(outRec + valid)[lane] = rec[lane];
         if (outDigest != nullptr && lane == 0)
             outDigest[valid] = DcsFrameDigest{ frameBit, static_cast<uint16_t>(nBits), static_cast<uint8_t>(s.nBands), static_cast<uint8_t>(flags) };
         ++valid;
@@ -801,7 +880,7 @@ __global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blob
     }
     waveSync();
     if (lane < 12)
-        reinterpret_cast<uint32_t *>(infos + k)[lane] = rec[lane];
+        reinterpret_cast<uint32_t *>(outInfo)[lane] = rec[lane];
 #ifdef DCS_IDX_STAMPS
     if (lane == 0)
         for (int i = 0 ; i < 12 ; ++i)

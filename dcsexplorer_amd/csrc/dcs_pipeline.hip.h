@@ -8,13 +8,12 @@
 // Two shapes, chosen at creation:
 //   index pass on the host pool (default): `depth` worker threads each take a submitted list through all its stages on
 //     a HIP stream of their own, so the stages of different lists overlap by themselves.
-//   index pass on the device (DCS_PIPE_INDEX_ON_DEVICE): the index pass is nine tenths of a list's host work (measured,
-//     tools/hostbench.cpp: 60 of 68 CPU-milliseconds for 65 536 frames), and on the device a lane walks a frame some 50
-//     times slower than a host core does -- but the GPU has lanes to spare and the host has no cores to spare.  A worker
-//     uploads its list's streams (stage A) and hands the list to the INDEXER thread, which walks the streams of ALL lists
-//     that are waiting in ONE launch (one lane per stream; the walks are latency, so a launch takes as long for eight
-//     lists as for one), copies the records back and passes the lists on; a worker then builds, plans, packs, decodes
-//     and downloads (stage B).  The host is left with about 8 CPU-milliseconds per 65 536 frames.
+//   index pass on the device (DCS_PIPE_INDEX_ON_DEVICE): the index pass is most of a list's host work (tools/hostbench.cpp:
+//     35 of 45 CPU-milliseconds for 65 536 frames), and the host has no cores to spare.  A worker uploads its list's streams
+//     (stage A) and hands the list to an INDEXER thread, which walks the streams of the lists that are waiting -- one
+//     wavefront per stream, dcs_index_wave.hip.h; a round of up to 2 048 streams takes 2.4 to 2.7 ms whatever their number,
+//     every list's records go to buffers of its own -- copies the records back and passes the lists on; a worker then
+//     builds, plans, packs, decodes and downloads (stage B).
 //   ... and the packer on the device too (DCS_PIPE_PACK_ON_DEVICE): the records do not come back at all.  The indexer
 //     copies back an 8-byte digest per frame (bit offset, bit count, band count, flags), the worker plans from that, and
 //     a pack kernel assembles the packages from the records and streams that are already resident.
@@ -60,10 +59,11 @@ struct DcsPipeline
         const uint64_t *preFirstRecord = nullptr;
         const DcsStreamInfo *preInfos = nullptr;
         double tSubmit = 0, tTaken = 0, tQueuedForIndex = 0, tIndexStart = 0, tIndexed = 0, tStageB = 0, tDone = 0;     // (DCS_PIPE_TRACE)
-        // packing on the device: the round's record array stays resident until every list of the round has packed
-        std::shared_ptr<void> roundRecords;
-        const DcsFrameIndex *dRecords = nullptr;
-        uint32_t recordBase = 0;
+        // what the index round writes for this list (device; fixed sizes per list, so the context's cache serves them): the
+        // records -- which stay resident for the device packer --, their digests, the stream summaries
+        void *dRec = nullptr, *dDigest = nullptr, *dInfo = nullptr;
+        size_t dRecBytes = 0, dDigestBytes = 0;
+        const DcsFrameIndex *dRecords = nullptr;    // = dRec once the round has run
     };
     typedef std::shared_ptr<Job> JobPtr;
 
@@ -89,11 +89,21 @@ static double nowMs()
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// DCS_PIPE_TRACE=2: what every pipeline thread did and when (tools/pipe_threads.py reads it from stderr)
+static void pipeLog(const char *who, int id, const char *what, double t0, double t1, size_t q1 = 0, size_t q2 = 0)
+{
+    static const bool on = getenv("DCS_PIPE_TRACE") != nullptr && atoi(getenv("DCS_PIPE_TRACE")) >= 2;
+    if (on)
+        fprintf(stderr, "pipe thread: %s %d %s %.3f %.3f %zu %zu\n", who, id, what, t0, t1, q1, q2);
+}
+
 static void pipelineFreeIndexBuffers(DcsPipeline *p, DcsPipeline::Job *job, bool keepHostBlob)
 {
     DcsCtx *ctx = p->ctx;
-    job->roundRecords.reset();
     job->dRecords = nullptr;
+    if (job->dRec) { cacheFree(ctx, false, job->dRec, job->dRecBytes); job->dRec = nullptr; }
+    if (job->dDigest) { cacheFree(ctx, false, job->dDigest, job->dDigestBytes); job->dDigest = nullptr; }
+    if (job->dInfo) { cacheFree(ctx, false, job->dInfo, job->infoBytes); job->dInfo = nullptr; }
     if (job->dBlob) { cacheFree(ctx, false, job->dBlob, job->dBlobCap); job->dBlob = nullptr; }
     if (job->hRec) { cacheFree(ctx, true, job->hRec, job->recBytes); job->hRec = nullptr; }
     if (job->hInfo) { cacheFree(ctx, true, job->hInfo, job->infoBytes); job->hInfo = nullptr; }
@@ -158,10 +168,18 @@ static DcsStatus pipelineUpload(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     job->dBlobCap = job->hBlobCap;
     job->recBytes = ((p->flags & DCS_PIPE_PACK_ON_DEVICE) ? sizeof(DcsFrameDigest) : sizeof(DcsFrameIndex)) * totalRec;
     job->infoBytes = sizeof(DcsStreamInfo) * n;
+    const double tu0 = nowMs();
     HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&job->hBlob), job->hBlobCap));
     HIPCHK(ctx, cacheAlloc(ctx, true, &job->hRec, job->recBytes));
     HIPCHK(ctx, cacheAlloc(ctx, true, &job->hInfo, job->infoBytes));
     HIPCHK(ctx, cacheAlloc(ctx, false, &job->dBlob, job->dBlobCap));
+    job->dRecBytes = sizeof(DcsFrameIndex) * (totalRec ? totalRec : 1);
+    job->dDigestBytes = sizeof(DcsFrameDigest) * (totalRec ? totalRec : 1);
+    HIPCHK(ctx, cacheAlloc(ctx, false, &job->dRec, job->dRecBytes));
+    if (p->flags & DCS_PIPE_PACK_ON_DEVICE)
+        HIPCHK(ctx, cacheAlloc(ctx, false, &job->dDigest, job->dDigestBytes));
+    HIPCHK(ctx, cacheAlloc(ctx, false, &job->dInfo, job->infoBytes));
+    const double tu1 = nowMs();
     memset(job->hBlob + blobLen, 0, job->hBlobCap - blobLen);
     for (uint32_t k = 0 ; k < n ; ++k)
     {
@@ -170,9 +188,12 @@ static DcsStatus pipelineUpload(DcsPipeline *p, DcsPipeline::Job *job, hipStream
             memset(job->hBlob + l.off + l.len, 0, static_cast<size_t>(job->locs[k + 1].off - l.off) - l.len);
         memcpy(job->hBlob + l.off, job->streams[k].data, l.len);
     }
+    const double tu2 = nowMs();
     HIPCHK(ctx, hipEventCreateWithFlags(&job->uploaded, hipEventDisableTiming));
     HIPCHK(ctx, hipMemcpyAsync(job->dBlob, job->hBlob, job->hBlobCap, hipMemcpyHostToDevice, stream));
     HIPCHK(ctx, hipEventRecord(job->uploaded, stream));
+    if (getenv("DCS_PIPE_TRACE"))
+        fprintf(stderr, "pipe upload: allocs %.2f, memcpy %.2f, hip calls %.2f\n", tu1 - tu0, tu2 - tu1, nowMs() - tu2);
     return DCS_OK;
 }
 
@@ -184,7 +205,14 @@ static void pipelineIndexer(DcsPipeline *p, int which)
     DcsCtx *ctx = p->ctx;
     (void)hipSetDevice(ctx->device);
     const hipStream_t stream = p->streams[static_cast<size_t>(p->nWorkers + which)];
-    constexpr size_t kMaxMerge = 32;
+    // A round takes the lists that are waiting, up to about an eighth of the chip's wavefront slots (one wavefront walks one
+    // stream, for milliseconds): the decode kernels of the lists further along must find room next to it, and beyond that
+    // size a round's time grows with its streams anyway (2 048 streams x 256 frames 2.7 ms, 8 192 6.0 ms).
+    size_t maxRoundStreams = static_cast<size_t>(ctx->numCUs) * 8;
+    if (const char *e = getenv("DCS_PIPE_ROUND_STREAMS"))
+        maxRoundStreams = static_cast<size_t>(std::max(1, atoi(e)));
+    void *hTable = nullptr, *dTable = nullptr;      // the round's stream locations and result addresses, as uploaded
+    size_t tableCap = 0;
     for (;;)
     {
         std::vector<DcsPipeline::JobPtr> jobs;
@@ -192,85 +220,71 @@ static void pipelineIndexer(DcsPipeline *p, int which)
             std::unique_lock<std::mutex> lk(p->m);
             p->indexWork.wait(lk, [&] { return p->quit || !p->toIndex.empty(); });
             if (p->quit && p->toIndex.empty())
-                return;
-            while (!p->toIndex.empty() && jobs.size() < kMaxMerge)
             {
+                if (hTable) (void)hipHostFree(hTable);
+                if (dTable) (void)hipFree(dTable);
+                return;
+            }
+            size_t roundStreams = 0;
+            while (!p->toIndex.empty() && (jobs.empty() || roundStreams + p->toIndex.front()->nStreams <= maxRoundStreams))
+            {
+                roundStreams += p->toIndex.front()->nStreams;
                 jobs.push_back(p->toIndex.front());
                 p->toIndex.pop_front();
             }
         }
         const double t0 = nowMs();
         for (const DcsPipeline::JobPtr &j : jobs) j->tIndexStart = t0;
-        // stream locations with ABSOLUTE device addresses (the kernel's blob base is address 0), records in one buffer
+        // stream locations with ABSOLUTE device addresses (the kernel's blob base is address 0); every list's results go to
+        // buffers of its own, so a round allocates nothing but its table of locations (kept from round to round)
         uint32_t nStreams = 0;
-        uint64_t nRec = 0;
-        for (const DcsPipeline::JobPtr &j : jobs) { nStreams += j->nStreams; nRec += j->totalRec; }
-        std::vector<DcsStreamLoc> locs;
-        locs.reserve(nStreams);
-        uint64_t rec0 = 0;
-        for (const DcsPipeline::JobPtr &j : jobs)
-        {
-            for (const DcsStreamLoc &l : j->locs)
-            {
-                DcsStreamLoc a = l;
-                a.off = reinterpret_cast<uint64_t>(j->dBlob) + l.off;
-                a.firstRecord = rec0 + l.firstRecord;
-                locs.push_back(a);
-            }
-            rec0 += j->totalRec;
-        }
+        for (const DcsPipeline::JobPtr &j : jobs) nStreams += j->nStreams;
+        const size_t locBytes = sizeof(DcsStreamLoc) * nStreams, tableBytes = locBytes + sizeof(dcsidx::StreamOut) * nStreams;
         const bool packOnDevice = (p->flags & DCS_PIPE_PACK_ON_DEVICE) != 0;
-        const size_t locBytes = sizeof(DcsStreamLoc) * nStreams, outBytes = sizeof(DcsFrameIndex) * (nRec ? nRec : 1),
-                     infoBytes = sizeof(DcsStreamInfo) * nStreams, digestBytes = sizeof(DcsFrameDigest) * (nRec ? nRec : 1);
-        void *dLocs = nullptr, *dOut = nullptr, *dInfos = nullptr, *dDigest = nullptr;
         DcsStatus st = [&]() -> DcsStatus {
-            HIPCHK(ctx, cacheAlloc(ctx, false, &dLocs, locBytes));
-            HIPCHK(ctx, cacheAlloc(ctx, false, &dOut, outBytes));
-            HIPCHK(ctx, cacheAlloc(ctx, false, &dInfos, infoBytes));
-            if (packOnDevice)
-                HIPCHK(ctx, cacheAlloc(ctx, false, &dDigest, digestBytes));
+            if (tableCap < tableBytes)
+            {
+                if (hTable) (void)hipHostFree(hTable);
+                if (dTable) (void)hipFree(dTable);
+                hTable = nullptr; dTable = nullptr; tableCap = 0;
+                const size_t want = tableBytes * 2;
+                HIPCHK(ctx, hipHostMalloc(&hTable, want, hipHostMallocDefault));
+                HIPCHK(ctx, hipMalloc(&dTable, want));
+                tableCap = want;
+            }
+            DcsStreamLoc *locs = static_cast<DcsStreamLoc *>(hTable);
+            dcsidx::StreamOut *outs = reinterpret_cast<dcsidx::StreamOut *>(static_cast<uint8_t *>(hTable) + locBytes);
+            uint32_t k = 0;
+            for (const DcsPipeline::JobPtr &j : jobs)
+                for (uint32_t i = 0 ; i < j->nStreams ; ++i, ++k)
+                {
+                    const DcsStreamLoc &l = j->locs[i];
+                    locs[k] = l;
+                    locs[k].off = reinterpret_cast<uint64_t>(j->dBlob) + l.off;
+                    outs[k].records = static_cast<DcsFrameIndex *>(j->dRec) + l.firstRecord;
+                    outs[k].digest = j->dDigest != nullptr ? static_cast<DcsFrameDigest *>(j->dDigest) + l.firstRecord : nullptr;
+                    outs[k].info = static_cast<DcsStreamInfo *>(j->dInfo) + i;
+                }
             for (const DcsPipeline::JobPtr &j : jobs)
                 HIPCHK(ctx, hipStreamWaitEvent(stream, j->uploaded, 0));
-            HIPCHK(ctx, hipMemcpyAsync(dLocs, locs.data(), locBytes, hipMemcpyHostToDevice, stream));
-            // (stream locations are device addresses: each list's streams lie in its own buffer)
-            HIPCHK(ctx, launchIndexWave(stream, 0, static_cast<const DcsStreamLoc *>(dLocs), nStreams, ctx->dTables, static_cast<DcsFrameIndex *>(dOut),
-                                        static_cast<DcsStreamInfo *>(dInfos), static_cast<DcsFrameDigest *>(dDigest)));
-            uint64_t r = 0;
-            uint32_t s0 = 0;
+            HIPCHK(ctx, hipMemcpyAsync(dTable, hTable, tableBytes, hipMemcpyHostToDevice, stream));
+            HIPCHK(ctx, launchIndexWave(stream, 0, static_cast<const DcsStreamLoc *>(dTable), nStreams, ctx->dTables, nullptr, nullptr, nullptr,
+                                        reinterpret_cast<const dcsidx::StreamOut *>(static_cast<const uint8_t *>(dTable) + locBytes)));
             for (const DcsPipeline::JobPtr &j : jobs)
             {
-                if (packOnDevice)
-                    HIPCHK(ctx, hipMemcpyAsync(j->hRec, static_cast<DcsFrameDigest *>(dDigest) + r, j->recBytes, hipMemcpyDeviceToHost, stream));
-                else
-                    HIPCHK(ctx, hipMemcpyAsync(j->hRec, static_cast<DcsFrameIndex *>(dOut) + r, j->recBytes, hipMemcpyDeviceToHost, stream));
-                HIPCHK(ctx, hipMemcpyAsync(j->hInfo, static_cast<DcsStreamInfo *>(dInfos) + s0, j->infoBytes, hipMemcpyDeviceToHost, stream));
-                r += j->totalRec;
-                s0 += j->nStreams;
+                HIPCHK(ctx, hipMemcpyAsync(j->hRec, packOnDevice ? j->dDigest : j->dRec, j->recBytes, hipMemcpyDeviceToHost, stream));
+                HIPCHK(ctx, hipMemcpyAsync(j->hInfo, j->dInfo, j->infoBytes, hipMemcpyDeviceToHost, stream));
             }
             HIPCHK(ctx, streamWait(ctx, stream));
             return DCS_OK;
         }();
         if (st != DCS_OK)
             (void)streamWait(ctx, stream);
-        cacheFree(ctx, false, dLocs, locBytes);
-        cacheFree(ctx, false, dInfos, infoBytes);
-        cacheFree(ctx, false, dDigest, digestBytes);
         if (packOnDevice && st == DCS_OK)
-        {
-            // the records stay where they are until the last list of this round has run its pack kernel
-            std::shared_ptr<void> round(dOut, [ctx, outBytes](void *q) { cacheFree(ctx, false, q, outBytes); });
-            uint64_t r = 0;
             for (const DcsPipeline::JobPtr &j : jobs)
-            {
-                j->roundRecords = round;
-                j->dRecords = static_cast<const DcsFrameIndex *>(dOut);
-                j->recordBase = static_cast<uint32_t>(r);
-                r += j->totalRec;
-            }
-        }
-        else
-            cacheFree(ctx, false, dOut, outBytes);
+                j->dRecords = static_cast<const DcsFrameIndex *>(j->dRec);      // (they stay until the list has packed)
         const double dt = nowMs() - t0;
+        pipeLog("indexer", which, "round", t0, nowMs(), jobs.size(), nStreams);
         {
             std::lock_guard<std::mutex> lk(p->m);
             for (const DcsPipeline::JobPtr &j : jobs)
@@ -309,8 +323,7 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
                       && 2u + static_cast<size_t>(infos[k].hdrLen) + (static_cast<size_t>(infos[k].payloadBits) + 7) / 8 <= job->locs[k].len;
         if (fromDevice && packOnDevice)
         {
-            const DcsDigested in{ static_cast<const DcsFrameDigest *>(job->hRec), job->firstRecord.data(), infos, job->streamOff.data(),
-                                  job->recordBase };
+            const DcsDigested in{ static_cast<const DcsFrameDigest *>(job->hRec), job->firstRecord.data(), infos, job->streamOff.data(), 0 };
             st = dcsBuildPlanFromDigest(job->streams, job->nStreams, job->extraFrames, in, planScratch);
         }
         else if (fromDevice)
@@ -350,7 +363,14 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
                              B.jobs.data(), static_cast<uint32_t>(B.jobs.size()), nullptr, 0, stream, handoff, &job->batch);
         t2 = nowMs();
         if (st == DCS_OK) st = dcs_batch_run(job->batch, nullptr);
+        // (DCS_PIPE_TRACE=3 waits for the kernels first, so that the thread log tells them from the copies)
+        const double tk0 = nowMs();
+        static const bool splitWait = getenv("DCS_PIPE_TRACE") != nullptr && atoi(getenv("DCS_PIPE_TRACE")) >= 3;
+        if (st == DCS_OK && splitWait) st = dcs_batch_sync(job->batch);
+        const double tk1 = nowMs();
         if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
+        pipeLog("worker", 0, "kernels", tk0, tk1);
+        pipeLog("worker", 0, "download", tk1, nowMs());
         bool lost = false;
         if (st == DCS_OK && handoff)
             for (size_t j = 0 ; j < nJobsBuilt && !lost ; ++j)
@@ -417,6 +437,7 @@ static void pipelineWorker(DcsPipeline *p, int id)
             job->tTaken = t0;
             const DcsStatus st = pipelineUpload(p, job.get(), stream);
             job->hostMs += nowMs() - t0;
+            pipeLog("worker", id, "upload", t0, nowMs());
             if (st != DCS_OK)
             {
                 pipelineFreeIndexBuffers(p, job.get(), false);
@@ -435,6 +456,7 @@ static void pipelineWorker(DcsPipeline *p, int id)
         job->tStageB = nowMs();
         if (st == DCS_OK)
             st = pipelineDecode(p, job.get(), stream);
+        pipeLog("worker", id, "stageB", job->tStageB, nowMs());
         job->tDone = nowMs();
         if (getenv("DCS_PIPE_TRACE") && job->tIndexed != 0)
         {
@@ -541,11 +563,13 @@ static DcsStatus pipelineSubmit(DcsPipeline *p, const DcsStreamRef *streams, uin
     job->streams = streams; job->nStreams = nStreams; job->extraFrames = extraFrames;
     job->pcmDst = pcmDst; job->errDst = errDst;
     job->preRecords = preRecords; job->preFirstRecord = preFirstRecord; job->preInfos = preInfos;
-    job->tSubmit = nowMs();
+    const double ts0 = nowMs();
     {
         std::unique_lock<std::mutex> lk(p->m);
         // at most `depth` lists between submit and collect (each holds device and pinned buffers)
         p->room.wait(lk, [&] { return static_cast<int>(p->order.size()) < p->depth; });
+        job->tSubmit = nowMs();
+        pipeLog("caller", 0, "submit-wait", ts0, job->tSubmit);
         p->fresh.push_back(job);
         p->order.push_back(job);
     }

@@ -45,13 +45,15 @@ struct DcsCtx
     // about as much as decoding a few thousand frames)
     struct Cached { void *p; size_t cap; };
     std::vector<Cached> devCache, pinCache;
-    size_t cachedBytes = 0;
+    size_t cachedBytes = 0, cachedPinBytes = 0;
     // real size of every buffer handed out by cacheAlloc (a reused buffer may be up to twice what was asked for; the
     // callers only remember what they asked for, and the cache must account for what it really holds)
     std::unordered_map<void *, size_t> liveCap;
 };
 
-static const size_t kCacheLimit = size_t(4) << 30;     // bytes kept per context, device + pinned
+// bytes kept per context.  Device: a list in flight holds ~80 MB and a pipeline keeps up to 64 of them, and giving a
+// buffer back with hipFree waits for the WHOLE device (milliseconds while an index round runs): the card has 288 GB.
+static const size_t kDevCacheLimit = size_t(32) << 30, kPinCacheLimit = size_t(8) << 30;
 
 static hipError_t cacheAlloc(DcsCtx *ctx, bool pinned, void **out, size_t bytes)
 {
@@ -64,7 +66,7 @@ static hipError_t cacheAlloc(DcsCtx *ctx, bool pinned, void **out, size_t bytes)
     if (best != c.size())
     {
         *out = c[best].p;
-        ctx->cachedBytes -= c[best].cap;
+        (pinned ? ctx->cachedPinBytes : ctx->cachedBytes) -= c[best].cap;
         ctx->liveCap[c[best].p] = c[best].cap;
         c.erase(c.begin() + static_cast<long>(best));
         return hipSuccess;
@@ -90,13 +92,14 @@ static void cacheFree(DcsCtx *ctx, bool pinned, void *p, size_t cap)
         cap = live->second;             // what the buffer really holds, not what its last user asked for
         ctx->liveCap.erase(live);
     }
-    if (ctx->cachedBytes + cap > kCacheLimit)
+    size_t &held = pinned ? ctx->cachedPinBytes : ctx->cachedBytes;
+    if (held + cap > (pinned ? kPinCacheLimit : kDevCacheLimit))
     {
         if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
         return;
     }
     (pinned ? ctx->pinCache : ctx->devCache).push_back(DcsCtx::Cached{ p, cap });
-    ctx->cachedBytes += cap;
+    held += cap;
 }
 
 // Host waits of THIS thread sleep on an interrupt instead of polling: set by the pipeline's threads, of which dozens
@@ -187,9 +190,15 @@ static void setCreateError(const std::string &text)
     g_createError = text;
 }
 
+// (DCS_HIP_SLOW=<microseconds>: report every runtime call that takes longer, a diagnostic for the pipeline's threads)
+static double hipchkNow() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static const double g_hipSlowUs = getenv("DCS_HIP_SLOW") ? atof(getenv("DCS_HIP_SLOW")) : 0.0;
 #define HIPCHK(ctx, call)                                                                        \
     do {                                                                                         \
+        const double t_ = g_hipSlowUs > 0 ? hipchkNow() : 0.0;                                   \
         hipError_t e_ = (call);                                                                  \
+        if (g_hipSlowUs > 0 && hipchkNow() - t_ > g_hipSlowUs)                                   \
+            fprintf(stderr, "slow hip call: %.0f us %s\n", hipchkNow() - t_, #call);             \
         if (e_ != hipSuccess) {                                                                  \
             char buf_[256];                                                                      \
             snprintf(buf_, sizeof(buf_), "%s failed: %s", #call, hipGetErrorString(e_));         \
@@ -1052,11 +1061,11 @@ extern "C" DcsStatus dcs_decode_batch(DcsCtx *ctx,
 // so a launch takes as long as its longest stream; four streams share a workgroup (and its LDS copy of the tables).
 // ---------------------------------------------------------------------------------------------------------
 static hipError_t launchIndexWave(hipStream_t stream, uintptr_t blobBase, const DcsStreamLoc *dLocs, uint32_t nStreams, const DcsDevTables *dTables,
-                                  DcsFrameIndex *dOut, DcsStreamInfo *dInfos, DcsFrameDigest *dDigest)
+                                  DcsFrameIndex *dOut, DcsStreamInfo *dInfos, DcsFrameDigest *dDigest, const dcsidx::StreamOut *dOuts = nullptr)
 {
     const uint32_t blocks = (nStreams + dcsidx::kWaves - 1) / dcsidx::kWaves;
     hipLaunchKernelGGL(dcsidx::dcsIndexWaveKernel, dim3(blocks), dim3(dcsidx::kWaves * 64), 0, stream, blobBase, dLocs, nStreams, dTables,
-                       dOut, dInfos, dDigest);
+                       dOut, dInfos, dDigest, dOuts);
     return hipGetLastError();
 }
 

@@ -1,8 +1,9 @@
 // dcs_scan.h -- the index pass: walks a DCS stream and records, for every frame, the carried state that
 // makes it independently decodable (DcsFrameIndex: bit offset, band-type codes, split records).
 //
-// One implementation, compiled for the host (dcs_index.cpp, dcs_index_stream) and for the device
-// (dcs_index_kernel in dcs_runtime.hip, one lane per stream), so both produce identical records.
+// Compiled for the host (dcs_index.cpp, dcs_index_stream: the product's host index pass and the checker of the
+// device's).  The device walks a stream with a whole wavefront (dcs_index_wave.hip.h: the same parse, its Huffman runs
+// and frame headers taken 64 candidate positions at a time) and must produce identical records (tests/, tools/fuzz_parity.py).
 // It replaces the serial walk of DCSDecoderNative::GetStreamInfo (DCSDecoderNative.cpp:1486-1537), which
 // finds the end of a stream the same way: by running the frame decompressor over every frame.  This
 // walker follows the LENGTHS of the coded fields (plus, for the 1993 formats, the two carried sample

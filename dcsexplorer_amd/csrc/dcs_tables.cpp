@@ -111,6 +111,28 @@ DcsDevTables build()
     };
     put(1, kVlc94Sample1); put(2, kVlc94Sample2); put(3, kVlc94Sample3);
     put(4, kVlc94Sample4); put(5, kVlc94Sample5); put(6, kVlc94Sample6);
+    // several codes per look for the device index pass: a code is taken when its bits are all there (a prefix code is known by
+    // its own bits: the look-up with the missing look-ahead bits as zeros finds it)
+    for (int k = 1 ; k <= 6 ; ++k)
+    {
+        const uint16_t *book = cb + (t.lds.cbInfo[k] >> 4);
+        for (uint32_t x = 0 ; x < (1u << DCS_IDX_MULTI_BITS) ; ++x)
+        {
+            uint32_t at = 0, samples = 0;
+            for (;;)
+            {
+                const uint32_t idx = ((x << at) & ((1u << DCS_IDX_MULTI_BITS) - 1)) >> (DCS_IDX_MULTI_BITS - maxBits[k]);
+                const uint32_t e = book[idx], len = (e >> 8) & 0x1F, step = (e >> 13) == 2 ? 2 : 1;
+                if (len == 0 || at + len > DCS_IDX_MULTI_BITS || samples + step > DCS_IDX_MULTI_SAMPLES)
+                    break;
+                at += len;
+                samples += step;
+            }
+            if (at == 0 || samples == 0)
+                abort();                        // (every book's longest code is shorter than the look)
+            t.multi94[k - 1][x] = static_cast<uint8_t>(at | (samples << 4));
+        }
+    }
     for (int w = 7 ; w <= 16 ; ++w)
         t.lds.raw94[2 * (w - 7)] = t.lds.raw94[2 * (w - 7) + 1] = static_cast<uint16_t>((w << 8) | (1 << 13));
 

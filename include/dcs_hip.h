@@ -338,7 +338,7 @@ typedef struct DcsPipelineResult
     DcsStatus       status;
     float           hostMs, deviceMs;  /* the worker's wall time in host preparation / upload + kernel + download */
 } DcsPipelineResult;
-/* flags: DCS_PIPE_INDEX_ON_DEVICE -- the index pass of every list runs on the GPU (one lane per stream, the walker of
+/* flags: DCS_PIPE_INDEX_ON_DEVICE -- the index pass of every list runs on the GPU (one wavefront per stream, the walk of
  * dcs_index_streams_gpu) instead of on the host pool.  One list takes longer that way, many lists in flight much less:
  * the walks of different lists overlap on the GPU, and the host cores, which the index pass otherwise keeps busy most of
  * the time, are left with parameters, planner and packer.  Worth it from about 8 lists in flight.  Same PCM either way.
@@ -366,7 +366,7 @@ DcsStatus dcs_decode_stream_sequence(DcsCtx *ctx, const DcsStreamRef *streams, u
 
 /* ------------------------------------------------------------------------------------------------
  * Index many streams at once: on `nThreads` host threads (0 = all hardware threads), or on the GPU with
- * one lane per stream (dcs_index_streams_gpu; the streams are given as offsets into one blob, which is
+ * one wavefront per stream (dcs_index_streams_gpu; the streams are given as offsets into one blob, which is
  * uploaded, walked by the index kernel and the records downloaded).  Stream k's records go to
  * out + firstRecord(k), at most nFrames(k) of them (nFrames = the stream's U16 prefix); infos[k] receives
  * its summary.  Both run the same walker (csrc/dcs_scan.h) and return identical records; they replace

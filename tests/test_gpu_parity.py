@@ -284,7 +284,7 @@ def test_batch_is_idempotent_and_resident(gpu_ctx):
 
 @pytest.mark.gpu
 def test_gpu_index_pass_equals_host_index_pass(gpu_ctx, oracle):
-    """dcs_index_streams_gpu (one lane per stream) must return the host walker's records bit for bit --
+    """dcs_index_streams_gpu (one wavefront per stream) must return the host walker's records bit for bit --
     valid streams of every layout, corrupted streams, ragged lengths -- and decode to the oracle's PCM."""
     streams = []
     for i, fmt in enumerate(ALL_FORMATS * 4):

@@ -44,7 +44,7 @@ while time.time() - t0 < budget:
     except Exception as e:
         print("seed %d: oracle refused a stream (%s); skipped" % (seed, e)); seed += 1; continue
     want = np.concatenate(ref)
-    # the index pass on the device (one lane per stream) against the host walk: same records, same StreamInfo
+    # the index pass on the device (one wavefront per stream) against the host walk: same records, same StreamInfo
     host = D.index_streams(streams)
     dev = ctx.index_streams_gpu(streams)
     for k, ((hr, hi), (dr, di)) in enumerate(zip(host, dev)):
