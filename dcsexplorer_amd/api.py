@@ -95,7 +95,7 @@ EXPORTS = [
     "dcs_romset_create", "dcs_romset_destroy", "dcs_romset_last_error", "dcs_romset_add_rom", "dcs_romset_load_zip",
     "dcs_romset_load_zip_memory", "dcs_romset_check", "dcs_romset_set_version", "dcs_romset_num_tracks",
     "dcs_romset_pointer", "dcs_romset_track_info", "dcs_romset_decompile", "dcs_romset_list_streams",
-    "dcs_romset_extract_plan", "dcs_romset_stream_refs",
+    "dcs_romset_extract_plan", "dcs_romset_stream_refs", "dcs_romset_extract_tracks_plan", "dcs_extract_tracks",
     "dcs_seq_create", "dcs_seq_destroy", "dcs_seq_last_error", "dcs_seq_set_master_volume", "dcs_seq_set_reported_version",
     "dcs_seq_write_data_port", "dcs_seq_add_track_command", "dcs_seq_clear_tracks", "dcs_seq_load_audio_stream",
     "dcs_seq_plan", "dcs_seq_pending_ticks", "dcs_seq_is_fatal", "dcs_seq_host_bytes", "dcs_seq_decode",
@@ -232,6 +232,10 @@ def load_library():
     L.dcs_romset_list_streams.argtypes = [vp, vp, u32, ctypes.POINTER(u32)]
     L.dcs_romset_extract_plan.restype = i32
     L.dcs_romset_extract_plan.argtypes = [vp, vp, u32, ctypes.POINTER(u32)]
+    L.dcs_romset_extract_tracks_plan.restype = i32
+    L.dcs_romset_extract_tracks_plan.argtypes = [vp, vp, u32, ctypes.POINTER(u32)]
+    L.dcs_extract_tracks.restype = i32
+    L.dcs_extract_tracks.argtypes = [vp, vp, vp, u32, vp, sz, vp, vp]
     L.dcs_romset_stream_refs.restype = i32
     L.dcs_romset_stream_refs.argtypes = [vp, vp, u32, ctypes.c_int, vp]
     L.dcs_seq_create.restype = vp
@@ -681,6 +685,16 @@ class Context:
                                                  _ptr(first), _ptr(err)), self.h)
         return pcm, err, first
 
+    def extract_tracks(self, romset, plan):
+        """dcs_extract_tracks: the --extract-tracks loop on one decoder, every tick planned ahead on the host sequencer,
+        one launch.  plan: [(track, frames)] (RomSet.extract_tracks_plan); -> (pcm [frames, 240], first frame of each track)"""
+        items = np.array(plan, dtype=np.uint32).reshape(-1, 2)
+        total = int(items[:, 1].sum()) if len(plan) else 0
+        pcm = np.zeros((max(total, 1), FRAME_SAMPLES), dtype=np.int16)
+        first = np.zeros(len(plan) + 1, dtype=np.uint32)
+        _check(self.L.dcs_extract_tracks(self.h, romset.h, _ptr(items), len(plan), _ptr(pcm), total, _ptr(first), None), self.h)
+        return pcm[:total], first
+
     def clock_mhz(self):
         """dcs_ctx_clock_mhz: the shader clock under an integer load on every SIMD (probe kernel)"""
         mhz = ctypes.c_float()
@@ -937,6 +951,17 @@ class RomSet:
         a = np.zeros(max(n.value, 1), dtype=EXTRACT_DTYPE)
         _rs_check(self.L.dcs_romset_extract_plan(self.h, _ptr(a), n.value, ctypes.byref(n)), self)
         return a[:n.value]
+
+    def extract_tracks_plan(self):
+        """dcs_romset_extract_tracks_plan: [(track, frames of its WAV file)] of the --extract-tracks loop"""
+        n = ctypes.c_uint32()
+        _rs_check(self.L.dcs_romset_extract_tracks_plan(self.h, None, 0, ctypes.byref(n)), self)
+        a = np.zeros((max(n.value, 1), 2), dtype=np.uint32)
+        _rs_check(self.L.dcs_romset_extract_tracks_plan(self.h, _ptr(a), n.value, ctypes.byref(n)), self)
+        return [(int(t), int(f)) for t, f in a[:n.value]]
+
+    def add_rom(self, chip, data):
+        _rs_check(self.L.dcs_romset_add_rom(self.h, chip, bytes(data), len(data)), self)
 
     def stream_refs(self, items, volume):
         refs = (StreamRef * max(len(items), 1))()

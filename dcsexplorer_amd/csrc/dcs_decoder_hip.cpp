@@ -377,6 +377,7 @@ void DCSDecoderHIP::MainLoop()
         if (dcs_seq_plan(seq, static_cast<uint32_t>(lookahead)) != DCS_OK
             || dcs_seq_decode(ctx, seq, pcm.data(), static_cast<size_t>(lookahead), nullptr) != DCS_OK)
         {
+            memset(outputBuffer, 0, sizeof(outputBuffer));
             state = State::DecoderFatalError;
             errorMessage = std::string("HIP decode failed: ") + dcs_last_error(ctx);
             return;
@@ -400,7 +401,9 @@ void DCSDecoderHIP::MainLoop()
     }
     if (dcs_seq_fatal_tick(seq) <= nextTick)
     {
-        // the reference gives up after four failed passes in a row (DCSDecoder.cpp:1637-1645)
+        // the reference gives up after four failed passes in a row (DCSDecoder.cpp:1637-1645) and answers THIS call with
+        // silence (:1661); the base class, which sees this MainLoop return normally, hands out the buffer's first sample
+        memset(outputBuffer, 0, sizeof(outputBuffer));
         state = State::DecoderFatalError;
         errorMessage = "The decoder performed a self-reset after encountering multiple fatal errors decoding track data.";
         return;

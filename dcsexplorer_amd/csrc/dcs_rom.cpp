@@ -481,6 +481,34 @@ extern "C" DcsStatus dcs_romset_extract_plan(const DcsRomSet *rs, DcsExtractItem
     return DCS_OK;
 }
 
+// Which tracks `--extract-tracks` extracts and how many frames of each (DCSExplorer.cpp:1735-1925): type-1 tracks with at
+// least one Play opcode in their program; ExtractToWAV takes the running time as a uint16_t and adds two (:1667-1672)
+extern "C" DcsStatus dcs_romset_extract_tracks_plan(const DcsRomSet *rs, DcsExtractTrack *items, uint32_t cap, uint32_t *nOut)
+{
+    if (rs == nullptr || nOut == nullptr || (items == nullptr && cap != 0))
+        return DCS_ERR_INVALID_ARG;
+    std::vector<DcsExtractTrack> plan;
+    std::vector<DcsTrackOp> v;
+    for (uint32_t t = 0 ; t < rs->nTracks ; ++t)
+    {
+        DcsTrackInfo ti;
+        if (dcs_romset_track_info(rs, t, &ti) != DCS_OK || ti.type != 1)
+            continue;
+        decompile(rs, t, v);
+        bool plays = false;
+        for (const DcsTrackOp &op : v)
+            plays = plays || op.opcode == 0x01;
+        if (plays)
+            plan.push_back(DcsExtractTrack{ t, static_cast<uint32_t>(static_cast<uint16_t>(static_cast<uint16_t>(ti.time) + 2)) });
+    }
+    *nOut = static_cast<uint32_t>(plan.size());
+    if (cap < plan.size())
+        return cap == 0 ? DCS_OK : DCS_ERR_CAPACITY;
+    if (!plan.empty())
+        memcpy(items, plan.data(), sizeof(DcsExtractTrack) * plan.size());
+    return DCS_OK;
+}
+
 // The plan as input of dcs_decode_stream_sequence / dcs_decode_streams: each stream where it lies in its ROM image
 extern "C" DcsStatus dcs_romset_stream_refs(const DcsRomSet *rs, const DcsExtractItem *items, uint32_t n, int volume, DcsStreamRef *refs)
 {

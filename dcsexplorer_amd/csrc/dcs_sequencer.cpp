@@ -884,3 +884,45 @@ extern "C" DcsStatus dcs_seq_decode(DcsCtx *ctx, DcsSequencer *s, int16_t *pcmOu
     // the blob and the stream cache stay: streams already copied are reused by later plans
     return DCS_OK;
 }
+
+// The track loop of `DCSExplorer --extract-tracks` (DCSExplorer.cpp:1628-1721, :1905-1925) on one sequencer: all ticks of
+// all tracks planned ahead, one launch.
+extern "C" DcsStatus dcs_extract_tracks(DcsCtx *ctx, const DcsRomSet *rs, const DcsExtractTrack *items, uint32_t n,
+                                        int16_t *pcmOut, size_t pcmCapFrames, uint32_t *frameOffsets, uint32_t *errOut)
+{
+    if (ctx == nullptr || rs == nullptr || (items == nullptr && n != 0) || pcmOut == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    uint64_t total = 0;
+    for (uint32_t i = 0 ; i < n ; ++i)
+        total += items[i].nFrames;
+    if (total > pcmCapFrames || total > 0xFFFFFFFFull)
+        return DCS_ERR_CAPACITY;
+    DcsSequencer *seq = dcs_seq_create(rs);                 // (the state SoftBoot leaves)
+    if (seq == nullptr)
+        return DCS_ERR_BAD_STREAM;
+    DcsStatus st = dcs_seq_set_master_volume(seq, 255);
+    uint32_t at = 0;
+    for (uint32_t i = 0 ; i < n && st == DCS_OK ; ++i)
+    {
+        if (frameOffsets != nullptr)
+            frameOffsets[i] = at;
+        st = dcs_seq_clear_tracks(seq);
+        if (st == DCS_OK) st = dcs_seq_add_track_command(seq, static_cast<uint16_t>(items[i].track));
+        const uint32_t nFrames = items[i].nFrames;
+        // every frame but the last two in one go; ClearTracks() behind each of those (ExtractToWAV :1701-1712)
+        const uint32_t plain = nFrames > 2 ? nFrames - 2 : 0;
+        if (st == DCS_OK && plain != 0) st = dcs_seq_plan(seq, plain);
+        for (uint32_t f = plain ; f < nFrames && st == DCS_OK ; ++f)
+        {
+            st = dcs_seq_plan(seq, 1);
+            if (st == DCS_OK) st = dcs_seq_clear_tracks(seq);
+        }
+        at += nFrames;
+    }
+    if (frameOffsets != nullptr)
+        frameOffsets[n] = at;
+    if (st == DCS_OK && total != 0)
+        st = dcs_seq_decode(ctx, seq, pcmOut, pcmCapFrames, errOut);
+    dcs_seq_destroy(seq);
+    return st;
+}

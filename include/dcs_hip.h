@@ -464,6 +464,15 @@ DcsStatus   dcs_romset_list_streams(const DcsRomSet *rs, uint32_t *addrs, uint32
 DcsStatus   dcs_romset_extract_plan(const DcsRomSet *rs, DcsExtractItem *items, uint32_t cap, uint32_t *nOut);
 DcsStatus   dcs_romset_stream_refs(const DcsRomSet *rs, const DcsExtractItem *items, uint32_t n, int volume,
                                    DcsStreamRef *refs);
+/* which tracks `DCSExplorer --extract-tracks` extracts (DCSExplorer.cpp:1735-1925): every type-1 track whose program
+ * holds at least one Play opcode, and the frames ExtractToWAV writes for it -- the track's running time as a
+ * uint16_t plus two, in uint16_t arithmetic as there (:1667-1672) */
+typedef struct DcsExtractTrack
+{
+    uint32_t track;
+    uint32_t nFrames;                  /* frames of the track's WAV file                                    */
+} DcsExtractTrack;
+DcsStatus   dcs_romset_extract_tracks_plan(const DcsRomSet *rs, DcsExtractTrack *items, uint32_t cap, uint32_t *nOut);
 
 /* ------------------------------------------------------------------------------------------------
  * Track-program sequencer: everything DCSDecoderNative::MainLoop does per 7.68 ms tick except decompress
@@ -506,6 +515,16 @@ uint32_t    dcs_seq_host_bytes(DcsSequencer *seq, DcsHostByte *out, uint32_t cap
 /* decode the pending plan (pcmOut = pending ticks x 240 samples) in one launch and clear it; the overlap
  * tail carries into the next plan */
 DcsStatus   dcs_seq_decode(DcsCtx *ctx, DcsSequencer *seq, int16_t *pcmOut, size_t pcmCapFrames, uint32_t *errOut);
+
+/* The track loop of `DCSExplorer --extract-tracks` exactly (DCSExplorer.cpp:1628-1721, :1905-1925): ONE decoder --
+ * SoftBoot, SetMasterVolume(255) -- plays the tracks one after the other: ClearTracks(), AddTrackCommand(track), nFrames
+ * frames, ClearTracks() after each of the last two.  Whatever a track leaves behind (channel state, mixing levels, a
+ * deferred track, the overlap tail) is what the next one starts from, as there.  The sequencer runs all of it ahead on
+ * the host and the frames of every track are decoded in ONE kernel launch.  pcmOut receives the tracks back to back,
+ * frameOffsets (n + 1, optional) the first frame of each; hostBytes / nHostBytes (optional) what the decoder sent to the
+ * host meanwhile, ticks counted from the first track's first frame. */
+DcsStatus   dcs_extract_tracks(DcsCtx *ctx, const DcsRomSet *rs, const DcsExtractTrack *items, uint32_t n,
+                               int16_t *pcmOut, size_t pcmCapFrames, uint32_t *frameOffsets, uint32_t *errOut);
 
 /* ------------------------------------------------------------------------------------------------
  * Output formats of the reference's extraction and validation modes.
