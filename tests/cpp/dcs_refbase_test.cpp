@@ -5,6 +5,10 @@
 // GetNextSample.  Test infrastructure: built by oracle/Makefile (target refbase) into oracle/_ref/, where the
 // reference's base class is compiled in; never part of libdcs_hip.so.
 //
+//   dcs_refbase_test standalone <os 0..3> <volume> <level> <lookahead> <nFrames> <stream.bin> <out.pcm>
+//     the ROM-less recipe of DCSEncoder.cpp:522-571 and EncoderTester.cpp:85-137 with the class under its own name, as
+//     those callers hold it: InitStandalone(os), SetDefaultVolume, SoftBoot, LoadAudioStream(0, ROMPointer(0, p), level),
+//     nFrames x 240 GetNextSample -- the sample pump, the boot state machine and the autobuffer are the REAL base's
 //   dcs_refbase_test <volume> <nTicks> <events.txt> <outPrefix> <chip>=<romfile> ...
 //     events.txt: one "<tick> <kind> <value>" per line; kind 0 = WriteDataPort(value), 2 = SetMasterVolume(value)
 //     writes <outPrefix>.pcm (int16, nTicks x 240), <outPrefix>.host ("<tick> <byte>" per byte sent to the host) and
@@ -15,6 +19,7 @@
 #include <string>
 #include <vector>
 #include "DCSDecoder.h"
+#include "DCSDecoderHIP.h"
 
 struct CaptureHost : DCSDecoder::Host
 {
@@ -38,8 +43,37 @@ static std::vector<uint8_t> readFile(const char *path)
     return v;
 }
 
+static int standalone(int argc, char **argv)
+{
+    if (argc != 9) { fprintf(stderr, "usage: see the comment at the top of dcs_refbase_test.cpp\n"); return 2; }
+    static const DCSDecoder::OSVersion kOs[4] = { DCSDecoder::OSVersion::OS93a, DCSDecoder::OSVersion::OS93b, DCSDecoder::OSVersion::OS94, DCSDecoder::OSVersion::OS95 };
+    const int os = atoi(argv[2]), volume = atoi(argv[3]), level = atoi(argv[4]), lookahead = atoi(argv[5]), nFrames = atoi(argv[6]);
+    std::vector<uint8_t> stream = readFile(argv[7]);
+    stream.resize(stream.size() + 64, 0);           // (the reference's callers hand over buffers that end behind the stream too)
+    DCSDecoder::MinHost host;
+    DCSDecoderHIP dec(&host);
+    dec.SetLookahead(lookahead);
+    dec.InitStandalone(kOs[os & 3]);
+    dec.SetDefaultVolume(volume);
+    dec.SoftBoot();
+    if (!dec.IsOK()) { fprintf(stderr, "decoder not OK: %s\n", dec.GetErrorMessage().c_str()); return 4; }
+    dec.LoadAudioStream(0, DCSDecoder::ROMPointer(0, stream.data()), level);
+    std::vector<int16_t> pcm;
+    for (int f = 0 ; f < nFrames ; ++f)
+        for (int i = 0 ; i < 240 ; ++i)
+            pcm.push_back(dec.GetNextSample());
+    if (!dec.IsOK()) { fprintf(stderr, "decoder failed: %s\n", dec.GetErrorMessage().c_str()); return 5; }
+    FILE *f = fopen(argv[8], "wb");
+    if (f == nullptr) return 2;
+    fwrite(pcm.data(), sizeof(int16_t), pcm.size(), f);
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && strcmp(argv[1], "standalone") == 0)
+        return standalone(argc, argv);
     if (argc < 6) { fprintf(stderr, "usage: see the comment at the top of dcs_refbase_test.cpp\n"); return 2; }
     const int volume = atoi(argv[1]), nTicks = atoi(argv[2]);
     const std::string prefix = argv[4];

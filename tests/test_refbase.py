@@ -72,3 +72,32 @@ def test_through_a_plain_base_pointer_equals_reference(tmp_path, case):
         want, hb, _ = G.ref_run(Reference(), G.build(case), G.VOLUME, n, ev)
         bad = np.nonzero((pcm != want).any(axis=1))[0]
         assert bad.size == 0, "first differing ticks: %s" % bad[:8]
+
+
+ENC = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_golden.json")))["cases"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lookahead", [1, 64])
+@pytest.mark.parametrize("case", ENC, ids=[c["name"] for c in ENC])
+def test_rom_less_recipe_behind_the_real_base(tmp_path, case, lookahead):
+    """InitStandalone / SetDefaultVolume / SoftBoot / LoadAudioStream(0, ROMPointer(0, p), level) / GetNextSample, as
+    DCSEncoder.cpp:522-571 and EncoderTester.cpp:85-137 drive the native decoder, on the 24 streams the reference's own
+    encoder made (six layouts, all four OS versions; volume / level 255 / 0x64, 220 / 0x7F, 0x67 / 0x64, 240 / 0x50): the
+    PCM the unmodified DCSDecoderNative produced for the same calls (tests/golden/encoder_golden.json), whether the class
+    decodes tick by tick or 64 ticks per launch"""
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/dcs_refbase_test not built (needs /root/reference; `make -C oracle refbase`)")
+    from oracle.dcs_oracle import Oracle
+    z = np.load(os.path.join(ROOT, "tests", "golden", "encoder_golden.npz"))
+    sf = tmp_path / "s.bin"
+    sf.write_bytes(z[case["name"] + "/stream"].tobytes())
+    out = tmp_path / "o.pcm"
+    n = case["frames_out"]
+    r = subprocess.run([EXE, "standalone", str(case["os"]), str(case["volume"]), str(case["levels"][0]), str(lookahead), str(n), str(sf), str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    pcm = np.fromfile(out, dtype=np.int16).reshape(n, 240)
+    assert "%016x" % Oracle().fnv1a64(pcm) == case["pcm_fnv1a64"]
+    if case["name"] + "/pcm" in z:
+        assert np.array_equal(pcm, z[case["name"] + "/pcm"])
