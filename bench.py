@@ -61,6 +61,7 @@ def parse_args(argv=None):
                     "stand-in is 600; 20 is the size whose per-stream reference hashes are committed)")
     ap.add_argument("--e2e-depth", type=int, default=8, help="lists in flight of end_to_end.sustained_host_index")
     ap.add_argument("--e2e-device-depth", type=int, default=48, help="lists in flight of end_to_end.sustained_device_index")
+    ap.add_argument("--e2e-lists", type=int, default=96, help="lists per rank of the N-rank end_to_end measurement (at least twice the depth)")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the N-rank path (gloo, no GPU, no kernel)")
     ap.add_argument("--share-gpu", action="store_true", help="testing on a one-GPU box: every rank decodes on GPU 0 and gloo carries the "
                     "barrier and the max (RCCL needs one device per rank); exercises the whole N-rank path but is no scaling measurement")
@@ -185,6 +186,61 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
                     "(parameters, planner, packer; with the host pool also the index pass) and in upload + kernels + "
                     "download (with the device index pass also that walk, which is latency, not occupancy: the walks of "
                     "the lists in flight overlap)"}
+
+
+def end_to_end_ranks(ctx, streams, n_frames, world, rank, device, depth=48, lists=96):
+    """N ranks on one node, each with a pipeline of its own (index pass and packer on the device) over its own lists, all
+    sharing the box's host CPUs: value = the samples all ranks delivered / the slowest rank's time (barrier before the
+    clock starts).  Per rank: ms per list, the worker threads' wall time per list, CPU-milliseconds per list."""
+    import resource
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import dcsexplorer_amd as D
+    refs, keep = D.make_refs(streams)
+    pipe = ctx.pipeline(depth, index_on_device=True, pack_on_device=True)
+    for _ in range(depth):
+        pipe.submit_refs(refs, len(streams))
+    for _ in range(depth):
+        pipe.collect()
+    n_lists = max(lists, 2 * depth)
+    host_ms, dev_ms = [], []
+    dist.barrier()
+    r0 = resource.getrusage(resource.RUSAGE_SELF)
+    t0 = time.perf_counter()
+    done = 0
+    for k in range(n_lists):
+        pipe.submit_refs(refs, len(streams))
+        if k >= depth - 1:
+            r = pipe.collect(); done += 1
+            host_ms.append(r[3]); dev_ms.append(r[4])
+    while done < n_lists:
+        r = pipe.collect(); done += 1
+        host_ms.append(r[3]); dev_ms.append(r[4])
+    dt = time.perf_counter() - t0
+    r1 = resource.getrusage(resource.RUSAGE_SELF)
+    pipe.close()
+    dist.barrier()
+    cpu_ms = ((r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)) * 1e3 / n_lists
+    mine = torch.zeros(world, 5, dtype=torch.float64, device=device if device is not None else "cpu")
+    mine[rank] = torch.tensor([dt, n_lists, sum(host_ms) / len(host_ms), sum(dev_ms) / len(dev_ms), cpu_ms], dtype=torch.float64)
+    dist.all_reduce(mine)
+    rows = mine.cpu().numpy()
+    slowest = float(rows[:, 0].max())
+    total_lists = float(rows[:, 1].sum())
+    usable = D.host_threads()
+    return {"unit": "samples/s", "frames_per_list": n_frames,
+            "sustained": {"value": total_lists * n_frames * 240 / slowest, "ms_per_list": slowest / total_lists * 1e3, "depth_per_rank": depth,
+                          "lists_per_rank": n_lists, "ranks": world,
+                          "what": "every rank its own dcs_pipeline (index pass and packer on the device), lists in flight, PCM returned in "
+                                  "pinned memory; all ranks' samples over the slowest rank's time"},
+            "per_rank": [{"rank": r, "ms_per_list": float(rows[r, 0] / rows[r, 1] * 1e3), "worker_host_ms": float(rows[r, 2]),
+                          "worker_device_ms": float(rows[r, 3]), "cpu_ms_per_list": float(rows[r, 4])} for r in range(world)],
+            "usable_cpus": usable,
+            "host_ceiling": {"cpu_ms_per_list": float(rows[:, 4].mean()), "lists_per_s_the_cpus_allow": usable * 1e3 / max(float(rows[:, 4].mean()), 1e-9),
+                             "samples_per_s_the_cpus_allow": usable * 1e3 / max(float(rows[:, 4].mean()), 1e-9) * n_frames * 240,
+                             "note": "the ranks of a node share its host CPUs (usable_cpus: affinity mask and cgroup quota): CPU-milliseconds "
+                                     "per list times lists per second cannot exceed them, whatever the number of GPUs"}}
 
 
 # --------------------------------------------------------------------------------------------- one rank
@@ -358,6 +414,13 @@ def run_rank(args):
             bit_exact = ok
             bit_exact_note = "%d of this rank's %d streams compared with the oracle sample for sample (no committed hashes at this corpus size)" % (len(pick), len(streams))
 
+    # host buffers in, host buffers out on every rank at once (never `value`): what N ranks do to the node's host CPUs
+    e2e_ranks = None
+    if world > 1 and not args.no_end_to_end and not corpus:
+        e2e_ranks = end_to_end_ranks(ctx, streams, n_frames, world, rank,
+                                     None if (args.share_gpu or getattr(args, "gloo_fallback", False)) else "cuda",
+                                     depth=args.e2e_device_depth, lists=args.e2e_lists)
+
     if rank == 0:
         samples = total_frames * 240 * args.steps
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
@@ -424,6 +487,8 @@ def run_rank(args):
             out["config"]["rank0_stream_range"] = [golden_range[1], golden_range[2]]
         if world == 1 and not args.no_end_to_end:
             out["end_to_end"] = end_to_end(ctx, streams, n_frames, depth=args.e2e_depth, dev_depth=args.e2e_device_depth)
+        if e2e_ranks is not None:
+            out["end_to_end"] = e2e_ranks
         if world == 1 and not args.no_cpu_baseline:
             sample = streams if not corpus else streams[:64]
             out["cpu_baseline"] = cpu_baseline(sample)

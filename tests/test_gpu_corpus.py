@@ -2,6 +2,7 @@
 the several-GPU entry (two contexts on the one device of the test box), batches in flight, and lost tails."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ from util import ALL_FORMATS, make_stream, os_for
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -279,3 +281,22 @@ def test_one_call_on_a_large_list_goes_through_the_pipeline_in_parts(gpu_ctx, or
     j = 5
     nf = int(first[j + 1] - first[j]) - 2
     assert "%016x" % oracle.fnv1a64(pcm[first[j]:first[j] + nf]) == g["stream_hashes"][j]
+
+
+def test_bench_two_ranks_on_one_gpu_runs_launcher_ranks_and_kernel(tmp_path):
+    """bench.py --gpus 2 --share-gpu: the launcher starts its two ranks (gloo carries barrier and max; both decode on GPU 0),
+    every rank times its K launches, and every rank runs a pipeline of its own for the N-rank end_to_end figure: the line
+    says n_gpus 2, carries per-rank host figures, and rank 0's PCM equals the reference's hashes"""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "1",
+                        "--e2e-device-depth", "8", "--e2e-lists", "16"], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["bit_exact"] is True and "share_gpu" in out
+    assert out["value"] > 1e9 and out["config"]["frames_all_ranks_per_step"] == 2 * out["config"]["frames_rank0_per_step"]
+    e = out["end_to_end"]
+    assert e["sustained"]["ranks"] == 2 and len(e["per_rank"]) == 2 and e["usable_cpus"] >= 1
+    assert all(p["worker_host_ms"] > 0 and p["cpu_ms_per_list"] > 0 for p in e["per_rank"])
+    assert e["sustained"]["value"] > 1e9
