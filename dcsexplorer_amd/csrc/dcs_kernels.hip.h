@@ -49,7 +49,11 @@ struct Stamper
 };
 #define DCS_STAMP(k) stamp(k)
 
-constexpr uint32_t kHandoffTimeoutTicks = 400000000u;    // default bound of the wait for a tail from another chunk: 4 s (100 MHz ticks)
+// default bound of the wait for a tail from another chunk: 50 ms (100 MHz ticks).  A producer publishes before it waits for
+// anything and is dispatched ahead of its consumers, so a wait is microseconds; the bound only has to outlast what can keep a
+// dispatched-ahead producer from running at all (other kernels holding the chip: the pipeline's index rounds are 3 to 15 ms),
+// and a wait that does run into it costs one more decode of the batch with re-decoded predecessors, not a wrong sample.
+constexpr uint32_t kHandoffTimeoutTicks = 5000000u;
 constexpr int kWavesPerBlock = 4;       // wavefronts of a workgroup share one copy of the decode tables in LDS
 #ifndef DCS_ROW_BYTES
 #define DCS_ROW_BYTES 528

@@ -249,7 +249,14 @@ DcsStatus dcs_batch_create(DcsCtx *ctx,
                            DcsBatch **batch);
 void      dcs_batch_destroy(DcsBatch *batch);
 /* Enqueue the decode on `hipStream` (a hipStream_t passed as void*; NULL = the context's stream).
- * Asynchronous: returns after the launch. */
+ * Asynchronous: returns after the launch.
+ * A frame whose predecessor's overlap tail comes from another wavefront of the launch waits for it at most 50 ms; if it
+ * does not come (no measured case; the bound covers hardware that dispatched workgroups out of order) the frame's error
+ * word carries DCS_FRAME_FATAL | DCS_FRAME_TAIL_LOST and its first 16 samples lack the overlap -- nothing else is
+ * affected.  A caller of the resident-batch entries who sees that flag creates the batch again after
+ * dcs_ctx_set_tail_handoff(ctx, 0) (predecessors re-decoded next to their successors: no wavefront waits for another)
+ * and runs it once more; dcs_decode_batch, dcs_decode_streams, the sequencer, the class and the pipeline do exactly that
+ * by themselves and never return the flag. */
 DcsStatus dcs_batch_run(DcsBatch *batch, void *hipStream);
 /* The same `count` times back to back (one call from the host language for many launches). */
 DcsStatus dcs_batch_run_many(DcsBatch *batch, void *hipStream, int count);
@@ -275,7 +282,7 @@ int       dcs_batch_frames_per_wave(const DcsBatch *batch);     /* the kernel va
 /* shader clock (MHz) the chip holds under an integer VALU load on every SIMD (a probe kernel of a few hundred
  * microseconds; not part of the decode path): turns a kernel duration into cycles */
 DcsStatus dcs_ctx_clock_mhz(DcsCtx *ctx, float *mhzOut);
-/* test hooks: bound of a consumer's wait for a tail from another chunk in microseconds (0 = the default, 4 s), and
+/* test hooks: bound of a consumer's wait for a tail from another chunk in microseconds (0 = the default, 50 ms), and
  * dropExports != 0: no chunk publishes its tail, so every such wait runs into the bound (DCS_FRAME_TAIL_LOST) */
 DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t handoffTimeoutUs, int dropExports);
 

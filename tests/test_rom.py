@@ -4,6 +4,7 @@ UNMODIFIED reference's (tests/golden/rom_golden.json, made by tests/golden/make_
 as well where oracle/_ref is present).  The zip member-recognition heuristics have no compiled twin here (the
 reference's zip loader needs <Windows.h>): they are tested against the rules stated in
 DCSDecoderZipLoader.cpp:106-203 only -- parity unpinned for that one function."""
+import ctypes
 import json
 import os
 import sys
@@ -92,6 +93,102 @@ def test_zip_loader_cactus_canyon_u7_quirk():
     size_of_u7 = lambda rs: (rs.check(), rs.pointer(5 << 21)[2])[1]
     assert size_of_u7(D.RomSet(zip_bytes=rs_img.zip_bytes(names=names), zip_name="cc_13.zip")) == 0x80000
     assert size_of_u7(D.RomSet(zip_bytes=rs_img.zip_bytes(names=names), zip_name="afm_113.zip")) == 0x2000
+
+
+def zip_rules_twin(members, zip_base, explicit_u2=None):
+    """An independent statement of LoadROMFromZipFile's member recognition (DCSDecoderZipLoader.cpp:123-203) with Python's
+    `re` (the three patterns are the format's, character for character): members = [(name, bytes)] in archive order ->
+    {chip: member index}, or None when no member passes for U2.  NOT the reference (its loader needs <Windows.h>, which
+    this image lacks, and a stand-in header is not a build of the reference): parity of this one function stays
+    unpinned; this twin only holds the library's C++ against a second reading of the same rules."""
+    import re
+    chip_of = {}
+    taken = set()
+    for i, (name, data) in enumerate(members):
+        is_jump = len(data) >= 3 and (data[0] & 0xFC) == 0x18 and (data[2] & 0x0F) == 0x0F
+        if (is_jump and "2" in name) or (explicit_u2 is not None and name.lower() == explicit_u2.lower()):
+            chip_of[2] = i
+            taken.add(i)
+            break
+    if 2 not in chip_of:
+        return None
+    sig = re.compile(rb"[SU]([^\d]*)(\d).*?\s+\d\d/\d\d/\d\d", re.S)
+    cactus = re.match(r"^cc_\d.*", zip_base, re.I) is not None
+    for n in range(3, 10):
+        for i, (name, data) in enumerate(members):
+            if i in taken or str(n) not in name:
+                continue
+            text = data.split(b"\0", 1)[0] if b"\0" in data[:256] else None
+            m = sig.fullmatch(text) if text is not None else None
+            digit = m.group(2).decode() if m else ""
+            if digit == str(n) or (cactus and m is not None and n == 7 and digit == "6"):
+                chip_of[n] = i
+                taken.add(i)
+                break
+    return chip_of
+
+
+def test_zip_member_recognition_against_a_second_reading_of_the_rules():
+    """400 seeded archives of made-up members -- names with several digits, version numbers, upper and lower case; images that
+    start with well-formed, malformed or missing signatures, a JUMP or not -- : which member the library takes for which chip
+    (read back through the size of the image behind each chip) equals what the twin above says, Cactus Canyon's zip name
+    included.  (No table of the 29 titles' real member names is committed: the reference tree names the sets,
+    Tests/test-all.bat:27-57, but not their members, and a list from memory would be no fixture.)"""
+    import io
+    import zipfile
+    from util import splitmix
+    for seed in range(400):
+        g = splitmix(0x21F0 + seed)
+        n_members = 2 + next(g) % 9
+        members = []
+        for k in range(n_members):
+            stem = ["snd", "s", "u", "rom", "cc", "afm_s", "ng_u", "v1_", "l"][next(g) % 9]
+            name = "%s%d%s%d.%s" % (stem, next(g) % 10, ["", "_", "v", "S", "-u"][next(g) % 5], next(g) % 10, ["rom", "bin", "l1", "1_0"][next(g) % 4])
+            if next(g) % 4 == 0:
+                name = name.upper()
+            # (a power of two, as AddROM demands; distinct sizes tell the members apart; 0x2000 is what an absent chip reads as)
+            size = [0x100, 0x200, 0x400, 0x800, 0x1000, 0x4000, 0x8000, 0x10000, 0x20000, 0x40000, 0x80000][len(members)]
+            img = bytearray(b"\xFF" * size)
+            kind = next(g) % 8
+            d = next(g) % 10
+            if kind == 0:
+                img[0:4] = bytes([0x18 + next(g) % 4, next(g) % 256, 0x0F | (next(g) % 16) << 4, 0])     # a JUMP
+            elif kind in (1, 2, 3):
+                text = "%s%s%d %s %02d/%02d/%02d" % ("SU"[next(g) % 2], ["", "ND ", "-"][next(g) % 3], d, ["Sound", "v1.0 L-%d" % (next(g) % 10), ""][next(g) % 3],
+                                                      next(g) % 13, next(g) % 32, next(g) % 100)
+                img[0:len(text) + 1] = text.encode() + b"\0"
+            elif kind == 4:
+                text = "S%d no date here" % d
+                img[0:len(text) + 1] = text.encode() + b"\0"
+            elif kind == 5:
+                text = "X%d Sound 01/02/94" % d
+                img[0:len(text) + 1] = text.encode() + b"\0"
+            members.append((name, bytes(img)))
+        if len({len(m[1]) for m in members}) != len(members) or len({m[0].lower() for m in members}) != len(members):
+            continue
+        zip_base = ["cc_13.zip", "CC_1x.zip", "afm_113b.zip", "sttng_l7.zip", "ccx.zip"][next(g) % 5]
+        buf = io.BytesIO()
+        with zipfile.ZipFile(buf, "w", zipfile.ZIP_DEFLATED) as z:
+            for name, data in members:
+                z.writestr(name, data)
+        want = zip_rules_twin(members, zip_base)
+        if want is None:
+            with pytest.raises(D.DcsError):
+                D.RomSet(zip_bytes=buf.getvalue(), zip_name=zip_base)
+            continue
+        rs = D.RomSet(zip_bytes=buf.getvalue(), zip_name=zip_base)
+        L = rs.L
+        for chip in range(2, 10):
+            p, avail, c = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_int()
+            # (linear address with the DCS-95 bank layout: chip select from bit 21)
+            L.dcs_romset_set_version(rs.h, D.api.HW_DCS95 if hasattr(D.api, "HW_DCS95") else 3, D.OS95)
+            L.dcs_romset_pointer(rs.h, (chip - 2) << 21, ctypes.byref(p), ctypes.byref(avail), ctypes.byref(c))
+            got = avail.value
+            exp = len(members[want[chip]][1]) if chip in want else None
+            if exp is None:
+                assert got not in {len(m[1]) for m in members}, "seed %d: chip %d taken from a member the rules reject" % (seed, chip)
+            else:
+                assert got == exp, "seed %d: chip %d is %d bytes, the rules say member %r (%d bytes)" % (seed, chip, got, members[want[chip]][0], exp)
 
 
 @pytest.mark.gpu
