@@ -106,19 +106,26 @@ def streams_corpus(titles=29, streams_per_title=600, max_frames=2000, seed=0x000
     return corpus_streams(corpus_manifest(titles, streams_per_title, max_frames, seed))
 
 
-ENCODER_GOLDEN = None
+RECORDINGS = None
+
+
+def register_recordings(recordings):
+    """hand the package the encoder-made recordings the `realistic_65536` workload is built from: a mapping with
+    "ENC-<layout>-v<k>/stream" -> bytes-like for the six layouts x four variants.  The package itself reads no data
+    files: bench.py and the tests load tests/golden/encoder_golden.npz (made by tests/golden/make_encoder_golden.py) and
+    register it."""
+    global RECORDINGS
+    RECORDINGS = recordings
 
 
 def streams_realistic_65536(n_streams=256, n_frames=256, first=0):
     """256 streams x 256 frames made by the REFERENCE'S OWN ENCODER from a deterministic signal (24 recordings: six
-    layouts x four pitch / noise variants, committed as data in tests/golden/encoder_golden.npz by
-    tests/golden/make_encoder_golden.py), each replica at its own volume and mixing level.  Real-audio band
-    statistics instead of the seeded writer's; there is no encoder for OS93a Type 1."""
-    global ENCODER_GOLDEN
-    import os
-    if ENCODER_GOLDEN is None:
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        ENCODER_GOLDEN = np.load(os.path.join(root, "tests", "golden", "encoder_golden.npz"))
+    layouts x four pitch / noise variants; see register_recordings), each replica at its own volume and mixing level.
+    Real-audio band statistics instead of the seeded writer's; there is no encoder for OS93a Type 1."""
+    if RECORDINGS is None:
+        raise RuntimeError("realistic_65536 needs the encoder-made recordings: call workloads.register_recordings() first "
+                           "(bench.py and tests/conftest.py do, with tests/golden/encoder_golden.npz)")
+    ENCODER_GOLDEN = RECORDINGS
     layouts = [("94-T0", D.OS94), ("94-T1s0", D.OS95), ("94-T1s3", D.OS95), ("93b-T0", D.OS93B), ("93b-T1", D.OS93B), ("93a-T0", D.OS93A)]
     names = [("ENC-%s-v%d" % (l, v), l, o) for v in range(4) for l, o in layouts]
     assert n_frames == 256
@@ -127,7 +134,7 @@ def streams_realistic_65536(n_streams=256, n_frames=256, first=0):
         name, lay, os_ = names[k % len(names)]
         if lay.startswith("94") and (k & 1):
             os_ = D.OS94 if os_ == D.OS95 else D.OS95       # OS94 and OS95 share the codec
-        out.append((os_, ENCODER_GOLDEN[name + "/stream"].tobytes(), 200 + (k % 56), 0x60 + (k % 16)))
+        out.append((os_, bytes(np.asarray(ENCODER_GOLDEN[name + "/stream"]).tobytes()), 200 + (k % 56), 0x60 + (k % 16)))
     return out
 
 

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the encoder-made recordings behind the realistic_65536 workload are test data: the package reads no files itself
+    import numpy as np
+    from dcsexplorer_amd import workloads
+    workloads.register_recordings(np.load(os.path.join(ROOT, "tests", "golden", "encoder_golden.npz")))
 
 
 @pytest.fixture(scope="session")

@@ -57,3 +57,14 @@ def test_product_never_references_oracle():
     for hdr in os.listdir(os.path.join(ROOT, "include")):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         assert "dcs_oracle" not in text
+
+
+def test_product_reads_no_test_data():
+    """the package opens nothing under tests/ (the encoder-made recordings of one workload are handed to it:
+    workloads.register_recordings)"""
+    pkg = os.path.join(ROOT, "dcsexplorer_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            text = open(os.path.join(pkg, f)).read()
+            assert '"tests"' not in text and "tests/golden/" not in text.replace("tests/golden/encoder_golden.npz (made", "").replace(
+                "tests/golden/make_encoder_golden.py", "").replace("with tests/golden/encoder_golden.npz", ""), f

@@ -71,12 +71,14 @@ def test_band_15_shared_by_two_lanes(gpu_ctx, oracle):
         gpu_ctx.set_frames_per_wave(0)
 
 
-def test_seeded_fuzz_lists_for_a_few_seconds():
+def test_seeded_fuzz_lists_for_a_minute():
     """tools/fuzz_parity.py: random lists (every layout, 1..18 bands, any stride start, damaged and truncated streams) through
-    the three kernel variants against the oracle; a few seconds of it here, minutes of it per round"""
+    the three kernel variants against the oracle, the device index walk against the host walk, every eighth list through
+    the pipeline's three modes, every fourth seed a multi-channel mix; a minute of it here (some 3 000 lists), tens of
+    minutes of it per round (profiles/)"""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "6", "424242"], capture_output=True, text=True, timeout=300)
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "60", "424242"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "all bit-exact" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
