@@ -6,7 +6,7 @@ TAG=${1:-r1}; WL=${2:-dcs94_65536}; shift 2 || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --workload $WL --steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end $*"
+BENCH="python3 $PWD/bench.py --workload $WL --steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end --no-second-workload $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.log
 for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
