@@ -405,7 +405,10 @@ void DCSDecoderHIP::MainLoop()
         // silence (:1661); the base class, which sees this MainLoop return normally, hands out the buffer's first sample
         memset(outputBuffer, 0, sizeof(outputBuffer));
         state = State::DecoderFatalError;
-        errorMessage = "The decoder performed a self-reset after encountering multiple fatal errors decoding track data.";
+        // (the reference's text, DCSDecoder.cpp:1657-1659: callers print it)
+        errorMessage = "The decoder performed a self-reset after encountering "
+                       "multiple fatal errors decoding track data.  This usually indicates "
+                       "that the ROM image is invalid or corrupted.";
         return;
     }
     memcpy(outputBuffer, ready.front().data(), sizeof(int16_t) * DCS_FRAME_SAMPLES);
