@@ -47,6 +47,21 @@ def test_native_driver_reproduces_the_goldens(tmp_path, name, mode):
     assert {k: hashlib.sha256(v).hexdigest() for k, v in files.items()} == g["files"]
 
 
+@pytest.mark.parametrize("name", [n for n, _, m in X.CASES if "tracks" in m])
+def test_tracks_plan_names_the_references_files(name):
+    """dcs_romset_extract_tracks_plan (host only): the tracks the reference's loop wrote a WAV for, and frame counts whose WAV
+    sizes add up to the bytes the reference wrote"""
+    rs = D.RomSet(images=BUILD[name]().images)
+    rs.check()
+    plan = rs.extract_tracks_plan()
+    g = GOLD["%s/tracks" % name]
+    assert ["x_%04x.wav" % t for t, _ in plan] == sorted(g["files"])
+    assert sum(44 + 480 * n for _, n in plan) == g["bytes"]
+    for t, n in plan:
+        ti = rs.track_info(t)
+        assert ti.type == 1 and n == ((ti.time & 0xFFFF) + 2) & 0xFFFF
+
+
 def test_hip_driver_fails_loudly_without_a_gpu(tmp_path):
     """no GPU: the class behind the real base ends SoftBoot in an error state and every sample is silence -- never the
     reference's PCM from some other path"""
