@@ -146,8 +146,8 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
         calls.append(time.perf_counter() - t0)
     cold_s = sorted(calls)[len(calls) // 2]                     # the median call (one in ten meets a page-fault storm or a busy host)
 
-    def sustained(depth, on_device, pack_on_device=False):
-        pipe = ctx.pipeline(depth, index_on_device=on_device, pack_on_device=pack_on_device)
+    def sustained(depth, on_device, pack_on_device=False, plan_on_device=False):
+        pipe = ctx.pipeline(depth, index_on_device=on_device, pack_on_device=pack_on_device, plan_on_device=plan_on_device)
         host_ms, dev_ms = [], []
         for _ in range(depth):                                  # warm: every worker has had a list
             pipe.submit_refs(refs, len(streams))
@@ -169,20 +169,23 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
         return {"value": n_frames * 240 / per_list, "ms_per_list": per_list * 1e3, "depth": depth, "lists": n_lists,
                 "index_pass": "device (dcsIndexWaveKernel, one wavefront per stream)" if on_device else "host pool",
                 "packer": "device (dcsPackKernel, from resident records and streams)" if pack_on_device else "host",
+                "planner": "device (dcsPlanKernel, one thread per chunk)" if plan_on_device else "host",
                 "worker_host_ms": sum(host_ms) / len(host_ms), "worker_device_ms": sum(dev_ms) / len(dev_ms)}
 
     host_idx = sustained(depth, False)
     dev_idx = sustained(dev_depth, True)
     dev_pack = sustained(dev_depth, True, True)
-    best = max((host_idx, dev_idx, dev_pack), key=lambda r: r["value"])
+    dev_plan = sustained(dev_depth, True, True, True)
+    best = max((host_idx, dev_idx, dev_pack, dev_plan), key=lambda r: r["value"])
     samples = n_frames * 240
     return {"unit": "samples/s", "frames_per_list": n_frames,
             "cold": {"value": samples / cold_s, "ms_per_list": cold_s * 1e3,
                      "what": "dcs_decode_streams, one synchronous call per list into pageable memory (median of nine calls): index + parameters + plan + pack + "
                              "H2D + kernel + D2H (a list this large goes through the context's own pipeline in eight parts)"},
-            "sustained": dict(best, what="dcs_pipeline, the fastest of the three configurations below: lists in flight, PCM "
+            "sustained": dict(best, what="dcs_pipeline, the fastest of the four configurations below: lists in flight, PCM "
                                          "returned in pinned memory, collected in submission order"),
             "sustained_host_index": host_idx, "sustained_device_index": dev_idx, "sustained_device_index_and_pack": dev_pack,
+            "sustained_device_index_plan_and_pack": dev_plan,
             "note": "worker_host_ms / worker_device_ms: wall time one worker thread spends per list in host preparation "
                     "(parameters, planner, packer; with the host pool also the index pass) and in upload + kernels + "
                     "download (with the device index pass also that walk, which is latency, not occupancy: the walks of "

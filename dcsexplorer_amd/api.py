@@ -66,7 +66,7 @@ HW_DCS93, HW_DCS95 = 2, 3
 class PipelineResult(ctypes.Structure):
     _fields_ = [("pcm", ctypes.c_void_p), ("err", ctypes.c_void_p), ("frameOffsets", ctypes.c_void_p),
                 ("nFrames", ctypes.c_uint32), ("nStreams", ctypes.c_uint32), ("status", ctypes.c_int32),
-                ("hostMs", ctypes.c_float), ("deviceMs", ctypes.c_float)]
+                ("hostMs", ctypes.c_float), ("deviceMs", ctypes.c_float), ("path", ctypes.c_uint32)]
 
 
 class SynthParams(ctypes.Structure):
@@ -704,8 +704,8 @@ class Context:
     def set_test_hooks(self, handoff_timeout_us=0, drop_exports=False):
         _check(self.L.dcs_ctx_set_test_hooks(self.h, int(handoff_timeout_us), int(bool(drop_exports))), self.h)
 
-    def pipeline(self, depth=3, index_on_device=False, pack_on_device=False):
-        return Pipeline(self, depth, index_on_device, pack_on_device)
+    def pipeline(self, depth=3, index_on_device=False, pack_on_device=False, plan_on_device=False):
+        return Pipeline(self, depth, index_on_device, pack_on_device, plan_on_device)
 
     def pack_chunks_device(self, blob, srcs, jobs, fpw):
         """dcs_pack_chunks_device -> uint8 array [nChunks, packageBytes], assembled by the device packer"""
@@ -822,11 +822,11 @@ class Batch:
 class Pipeline:
     """DcsPipeline: lists of whole streams in, PCM out in submission order, `depth` lists in flight"""
 
-    def __init__(self, ctx, depth=3, index_on_device=False, pack_on_device=False):
+    def __init__(self, ctx, depth=3, index_on_device=False, pack_on_device=False, plan_on_device=False):
         self.ctx = ctx
         self.L = ctx.L
         h = ctypes.c_void_p()
-        flags = (1 if index_on_device else 0) | (2 if pack_on_device else 0)
+        flags = (1 if index_on_device else 0) | (2 if pack_on_device else 0) | (4 if plan_on_device else 0)
         _check(self.L.dcs_pipeline_create(ctx.h, depth, flags, ctypes.byref(h)), ctx.h)
         self.h = h
         self._keep = []                         # (refs, byte buffers) of submitted lists, oldest first
@@ -844,9 +844,11 @@ class Pipeline:
 
     def collect(self):
         """-> (pcm [frames, 240], err, first frame of each stream, hostMs, deviceMs): views of pinned memory, valid
-        until the next collect"""
+        until the next collect.  self.last_path: the stages of that list that ran on the device (bit 0 index walk, bit 1
+        packer, bit 2 planner)"""
         r = PipelineResult()
         st = self.L.dcs_pipeline_collect(self.h, ctypes.byref(r))
+        self.last_path = int(r.path)
         if self._keep:
             self._keep.pop(0)
         _check(st, self.ctx.h)

@@ -289,6 +289,21 @@ struct DcsPlanSrc
     uint16_t mixMul;
     uint32_t record;
 };
+// What the DEVICE planner (dcsPlanKernel, dcs_runtime.hip) is told about a stream of a list of whole streams -- everything
+// the host knows without walking the stream: where it lies, its frame count, layout and mixing parameters.  40 bytes.
+struct DcsPlanStream
+{
+    uint64_t streamOff;                 // offset of the stream in the list's blob
+    uint32_t len;                       // bytes that belong to it
+    uint32_t firstRecord;               // its records in the list's record array
+    uint32_t firstJob;                  // its first output frame
+    uint32_t nFrames;                   // the stream's U16 frame count (output frames: nFrames + extraFrames)
+    uint16_t mixMul0, mixMulN;          // rescaled mixing multiplier of frame 0 / of every later frame (dcs_stream_params_from)
+    uint8_t  volShift0, volShiftN;
+    uint8_t  xform, hdrLen, format, pad_[3];
+};
+#define DCS_PLAN_POOL_OVERFLOW 1u       // flag word of the device planner: some chunk's compressed bytes do not fit the bit pool
+#define DCS_PLAN_TRUNCATED     2u       // ... some stream's frames run past its buffer
 // what the index kernel writes per frame next to the full record: all the host needs for planning (8 bytes)
 struct DcsFrameDigest
 {

@@ -41,6 +41,7 @@ struct DcsPipeline
                                                 // uploads + kernels + downloads (the device index pass counts here)
         // ---- index pass on the device
         bool onDevice = false;                  // records came from the device; the streams lie in hBlob
+        uint32_t path = 0;                      // DCS_PIPE_*: the stages of THIS list that ran on the device
         uint8_t *hBlob = nullptr;               // the streams as uploaded, end to end (pinned); the packer reads them
         size_t hBlobCap = 0, hBlobLen = 0;
         void *dBlob = nullptr;                  // the same on the device, for the walk only
@@ -64,6 +65,7 @@ struct DcsPipeline
         void *dRec = nullptr, *dDigest = nullptr, *dInfo = nullptr;
         size_t dRecBytes = 0, dDigestBytes = 0;
         const DcsFrameIndex *dRecords = nullptr;    // = dRec once the round has run
+        // planner on the device: the list's stream locations and result addresses as the index kernel takes them
     };
     typedef std::shared_ptr<Job> JobPtr;
 
@@ -170,13 +172,17 @@ static DcsStatus pipelineUpload(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     job->infoBytes = sizeof(DcsStreamInfo) * n;
     const double tu0 = nowMs();
     HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&job->hBlob), job->hBlobCap));
-    HIPCHK(ctx, cacheAlloc(ctx, true, &job->hRec, job->recBytes));
-    HIPCHK(ctx, cacheAlloc(ctx, true, &job->hInfo, job->infoBytes));
+    const bool planOnDevice = (p->flags & DCS_PIPE_PLAN_ON_DEVICE) != 0;       // (then nothing of the index pass comes back to the host)
+    if (!planOnDevice)
+    {
+        HIPCHK(ctx, cacheAlloc(ctx, true, &job->hRec, job->recBytes));
+        HIPCHK(ctx, cacheAlloc(ctx, true, &job->hInfo, job->infoBytes));
+    }
     HIPCHK(ctx, cacheAlloc(ctx, false, &job->dBlob, job->dBlobCap));
     job->dRecBytes = sizeof(DcsFrameIndex) * (totalRec ? totalRec : 1);
     job->dDigestBytes = sizeof(DcsFrameDigest) * (totalRec ? totalRec : 1);
     HIPCHK(ctx, cacheAlloc(ctx, false, &job->dRec, job->dRecBytes));
-    if (p->flags & DCS_PIPE_PACK_ON_DEVICE)
+    if ((p->flags & DCS_PIPE_PACK_ON_DEVICE) && !planOnDevice)
         HIPCHK(ctx, cacheAlloc(ctx, false, &job->dDigest, job->dDigestBytes));
     HIPCHK(ctx, cacheAlloc(ctx, false, &job->dInfo, job->infoBytes));
     const double tu1 = nowMs();
@@ -271,10 +277,11 @@ static void pipelineIndexer(DcsPipeline *p, int which)
             HIPCHK(ctx, launchIndexWave(stream, 0, static_cast<const DcsStreamLoc *>(dTable), nStreams, ctx->dTables, nullptr, nullptr, nullptr,
                                         reinterpret_cast<const dcsidx::StreamOut *>(static_cast<const uint8_t *>(dTable) + locBytes)));
             for (const DcsPipeline::JobPtr &j : jobs)
-            {
-                HIPCHK(ctx, hipMemcpyAsync(j->hRec, packOnDevice ? j->dDigest : j->dRec, j->recBytes, hipMemcpyDeviceToHost, stream));
-                HIPCHK(ctx, hipMemcpyAsync(j->hInfo, j->dInfo, j->infoBytes, hipMemcpyDeviceToHost, stream));
-            }
+                if (j->hRec != nullptr)         // (planner on the device: the records stay where they are)
+                {
+                    HIPCHK(ctx, hipMemcpyAsync(j->hRec, packOnDevice ? j->dDigest : j->dRec, j->recBytes, hipMemcpyDeviceToHost, stream));
+                    HIPCHK(ctx, hipMemcpyAsync(j->hInfo, j->dInfo, j->infoBytes, hipMemcpyDeviceToHost, stream));
+                }
             HIPCHK(ctx, streamWait(ctx, stream));
             return DCS_OK;
         }();
@@ -344,6 +351,7 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     }
     const bool devicePacked = fromDevice && packOnDevice;
     job->onDevice = fromDevice;
+    job->path = fromDevice ? (DCS_PIPE_INDEX_ON_DEVICE | (devicePacked ? DCS_PIPE_PACK_ON_DEVICE : 0u)) : 0u;
     job->firstJob = devicePacked ? planScratch.firstJob : built.firstJob;
     const size_t nJobsBuilt = devicePacked ? planScratch.jobs.size() : built.jobs.size();
     const uint8_t *blob = fromDevice ? job->hBlob : built.blob.data();
@@ -405,6 +413,100 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     return st;
 }
 
+// Planner on the device (DCS_PIPE_PLAN_ON_DEVICE), stage B: the list's index records are on the device (an indexer's round
+// put them there); planner, packer and decode kernels and the PCM's way down are queued on the worker's stream, and the one
+// wait is for the PCM.  Returns DCS_OK with *served = false when the arithmetic plan cannot serve the list (DCS_PLAN_*):
+// the caller then takes the host-planned path.
+static DcsStatus pipelineDecodePlanned(DcsPipeline *p, DcsPipeline::Job *job, hipStream_t stream, bool *served)
+{
+    DcsCtx *ctx = p->ctx;
+    *served = false;
+    const double t0 = nowMs();
+    DcsStatus st = DCS_OK;
+    const uint32_t n = job->nStreams;
+    // what the host knows of every stream without walking it
+    thread_local std::vector<DcsPlanStream> table;
+    table.resize(n);
+    job->firstJob.resize(static_cast<size_t>(n) + 1);
+    uint64_t nJobs = 0, payload = 0;
+    bool all94 = true, has93a = false;
+    for (uint32_t k = 0 ; k < n ; ++k)
+    {
+        const DcsStreamRef &sr = job->streams[k];
+        const uint8_t *d = sr.data;
+        const uint32_t len = job->locs[k].len;
+        const uint32_t nFrames = (static_cast<uint32_t>(d[0]) << 8) | d[1];
+        const bool typeBit = (d[2] & 0x80) != 0;
+        const uint32_t h12 = (len > 3 ? d[3] : 0u) | (len > 4 ? d[4] : 0u);
+        const DcsOsVersion os = static_cast<DcsOsVersion>(sr.os);
+        DcsPlanStream &t = table[k];
+        t = DcsPlanStream{};
+        t.hdrLen = (os == DCS_OS93A && typeBit) ? 1 : 16;
+        t.format = static_cast<uint8_t>(os == DCS_OS93A ? (typeBit ? DCS_FMT_93A_T1 : DCS_FMT_93_T0)
+                                      : os == DCS_OS93B ? (typeBit ? DCS_FMT_93B_T1 : DCS_FMT_93_T0)
+                                      : !typeBit ? DCS_FMT_94_T0 : (h12 & 0x80) == 0 ? DCS_FMT_94_T1_S0 : DCS_FMT_94_T1_S3);
+        t.xform = (os == DCS_OS93A || os == DCS_OS93B) ? DCS_XFORM_93 : DCS_XFORM_94;
+        all94 = all94 && t.xform == DCS_XFORM_94;
+        has93a = has93a || t.format == DCS_FMT_93A_T1;
+        t.streamOff = job->streamOff[k];
+        t.len = len;
+        t.firstRecord = static_cast<uint32_t>(job->firstRecord[k]);
+        t.firstJob = static_cast<uint32_t>(nJobs);
+        t.nFrames = nFrames;
+        uint16_t mm[2]; uint8_t vs[2];
+        st = dcs_stream_params_from(os, sr.volume, sr.level, sr.channelVolume, 0x7FFF, 2, mm, vs);    // frame 0, and every later frame
+        if (st != DCS_OK)
+            return st;
+        t.mixMul0 = mm[0]; t.mixMulN = mm[1]; t.volShift0 = vs[0]; t.volShiftN = vs[1];
+        job->firstJob[k] = static_cast<uint32_t>(nJobs);
+        nJobs += nFrames + job->extraFrames;
+        payload += len;
+    }
+    job->firstJob[n] = static_cast<uint32_t>(nJobs);
+    if (nJobs > 0xFFFFFFFFull || job->totalRec > 0xFFFFFFFFull)
+        return DCS_ERR_CAPACITY;
+    st = createBatchPlannedOnDevice(ctx, table.data(), n, job->extraFrames, static_cast<uint32_t>(nJobs), static_cast<uint32_t>(job->totalRec), all94,
+                                    has93a, payload, static_cast<const DcsFrameIndex *>(job->dRec), static_cast<const DcsStreamInfo *>(job->dInfo),
+                                    static_cast<const uint8_t *>(job->dBlob), job->hBlobLen, stream, &job->batch);
+    const double t1 = nowMs();
+    pipeLog("worker", 0, "plan-queue", t0, t1);
+    if (st == DCS_OK) st = dcs_batch_run(job->batch, nullptr);
+    if (st == DCS_OK) st = batchQueuePlanFlag(job->batch);
+    const double t2 = nowMs();
+    pipeLog("worker", 0, "run-queue", t1, t2);
+    if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
+    pipeLog("worker", 0, "download", t2, nowMs());
+    bool lost = false;
+    uint32_t flag = 0;
+    if (st == DCS_OK)
+    {
+        flag = batchPlanFlag(job->batch);
+        for (size_t j = 0 ; j < nJobs && !lost && flag == 0 ; ++j)
+            lost = (job->err[j] & DCS_FRAME_TAIL_LOST) != 0;
+    }
+    job->hostMs += t1 - t0;
+    job->deviceMs += nowMs() - t1;
+    if (st != DCS_OK || flag != 0 || lost)
+    {
+        // not served (or failed): nothing of this attempt stays; (a lost tail -- see dcs_decode_batch -- also goes to the other path)
+        if (job->batch != nullptr) { dcs_batch_destroy(job->batch); job->batch = nullptr; }
+        (void)streamWait(ctx, stream);
+        pipelineFreeIndexBuffers(p, job, false);
+        return st;
+    }
+    job->onDevice = true;
+    job->path = DCS_PIPE_INDEX_ON_DEVICE | DCS_PIPE_PACK_ON_DEVICE | DCS_PIPE_PLAN_ON_DEVICE;
+    pipelineFreeIndexBuffers(p, job, false);
+    if (job->pcmDst != nullptr)
+    {
+        memcpy(job->pcmDst, job->pcm, sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs);
+        if (job->errDst != nullptr)
+            memcpy(job->errDst, job->err, sizeof(uint32_t) * nJobs);
+    }
+    *served = true;
+    return DCS_OK;
+}
+
 static void pipelineWorker(DcsPipeline *p, int id)
 {
     pthread_setname_np(pthread_self(), "dcs-worker");
@@ -454,7 +556,17 @@ static void pipelineWorker(DcsPipeline *p, int id)
         }
         DcsStatus st = job->status;             // (the indexer's)
         job->tStageB = nowMs();
-        if (st == DCS_OK)
+        if (st == DCS_OK && (p->flags & DCS_PIPE_PLAN_ON_DEVICE))
+        {
+            bool served = false;
+            st = pipelineDecodePlanned(p, job.get(), stream, &served);
+            if (st == DCS_OK && !served)
+            {
+                pipeLog("worker", id, "not-served", job->tStageB, nowMs());
+                st = pipelineDecode(p, job.get(), stream);       // (host index pass, host planner: serves every list)
+            }
+        }
+        else if (st == DCS_OK)
             st = pipelineDecode(p, job.get(), stream);
         pipeLog("worker", id, "stageB", job->tStageB, nowMs());
         job->tDone = nowMs();
@@ -471,8 +583,11 @@ static void pipelineWorker(DcsPipeline *p, int id)
 
 extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags, DcsPipeline **out)
 {
-    if (ctx == nullptr || out == nullptr || depth < 1 || depth > 64 || (flags & ~(DCS_PIPE_INDEX_ON_DEVICE | DCS_PIPE_PACK_ON_DEVICE)) != 0)
+    if (ctx == nullptr || out == nullptr || depth < 1 || depth > 64 ||
+        (flags & ~(DCS_PIPE_INDEX_ON_DEVICE | DCS_PIPE_PACK_ON_DEVICE | DCS_PIPE_PLAN_ON_DEVICE)) != 0)
         return DCS_ERR_INVALID_ARG;
+    if (flags & DCS_PIPE_PLAN_ON_DEVICE)
+        flags |= DCS_PIPE_PACK_ON_DEVICE;
     if (flags & DCS_PIPE_PACK_ON_DEVICE)
         flags |= DCS_PIPE_INDEX_ON_DEVICE;           // (the packer works from the records the index pass leaves on the device)
     *out = nullptr;
@@ -493,7 +608,9 @@ extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags,
     // the device as well a list costs a worker under a millisecond of its own work, and what more workers add is contention
     // inside the HIP runtime: measured with 32 lists in flight on 16 CPUs, 4 to 6 workers 1.65-1.95 ms per list at 7-9 CPU-ms,
     // 10 workers 1.8-2.4, 20 workers 2.1-2.5 at 18-22 CPU-ms (tools/pipe_trace.py)
-    int nWorkers = (flags & DCS_PIPE_PACK_ON_DEVICE)  ? std::min(depth, std::max(4, dcs_host_threads() / 3))
+    // planner on the device too: a worker spends a third of a millisecond on a list and then sleeps until its PCM is down
+    int nWorkers = (flags & DCS_PIPE_PLAN_ON_DEVICE)  ? std::min(depth, 8)
+                 : (flags & DCS_PIPE_PACK_ON_DEVICE)  ? std::min(depth, std::max(4, dcs_host_threads() / 3))
                  : (flags & DCS_PIPE_INDEX_ON_DEVICE) ? std::min(depth, dcs_host_threads() + 4) : depth;
     if (const char *w = getenv("DCS_PIPE_WORKERS"))
         nWorkers = std::max(1, std::min(64, atoi(w)));
@@ -603,6 +720,7 @@ extern "C" DcsStatus dcs_pipeline_collect(DcsPipeline *p, DcsPipelineResult *out
     out->status = job->status;
     out->nStreams = job->nStreams;
     out->hostMs = static_cast<float>(job->hostMs);
+    out->path = job->path;
     out->deviceMs = static_cast<float>(job->deviceMs);
     if (job->status == DCS_OK)
     {

@@ -157,7 +157,7 @@ struct DcsBatch
     uint32_t flags = 0;                     // DCS_BATCH_*
     size_t cap[10] = { 0 };                 // allocated bytes of the buffers above, in that order
     // packages assembled on the device: the plan and the source digests as uploaded for the pack kernel
-    void *dPlanSlots = nullptr, *dPlanSrcs = nullptr, *hStage = nullptr;
+    void *dPlanSlots = nullptr, *dPlanSrcs = nullptr, *hStage = nullptr, *dTable = nullptr;      // (dTable: the stream table of the device planner; cap[2])
     size_t planSlotsCap = 0, planSrcsCap = 0, hStageCap = 0;
     // pinned host mirror of (pcm, err), filled by dcs_batch_download_view
     int16_t *hPcm = nullptr;
@@ -359,7 +359,7 @@ extern "C" void dcs_batch_destroy(DcsBatch *b)
     (void)hipSetDevice(b->ctx->device);
     if (b->evDone) (void)waitLaunched(b);               // nothing of this batch is in flight when its buffers are recycled,
     (void)streamWait(b->ctx, b->stream);         // on the caller's launch stream or on the context's
-    void *ptrs[] = { b->dBlob, b->dSrcs, nullptr, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug, b->dHandoff, b->dPackages };
+    void *ptrs[] = { b->dBlob, b->dSrcs, b->dTable, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug, b->dHandoff, b->dPackages };
     for (int i = 0 ; i < 10 ; ++i)
         cacheFree(b->ctx, false, ptrs[i], b->cap[i]);
     cacheFree(b->ctx, false, b->dPlanSlots, b->planSlotsCap);
@@ -681,6 +681,122 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
 }
 }   // namespace
 
+// ---------------------------------------------------------------------------------------------------------
+// The planner on the device, for lists of WHOLE STREAMS (the pipeline's third step onto the device: the index records never
+// leave it, and the host neither waits for them nor plans).  The job list of such a list is regular -- stream k's frames
+// f = 0 .. nFrames + extraFrames - 1 one after the other, each the successor of the one before -- so the chunk plan is
+// arithmetic: chunk c holds jobs c * FPW .. c * FPW + FPW - 1, a frame whose predecessor lies in the chunk before imports
+// its tail from there.  One thread per chunk writes the chunk's slots (run placement as the host planner does it,
+// dcs_plan.cpp: placeFrame) and the source digests of its frames.  What the arithmetic plan cannot express is reported in
+// a flag word and the list then takes the host planner's path: a chunk whose compressed bytes overflow the bit pool (the
+// host planner closes such a chunk early), a stream whose frames run past its buffer.  A stream the index pass stopped
+// early (nValidFrames < nFrames) needs no flag: its remaining frames are silent here as there.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+template <int FPW>
+__global__ __launch_bounds__(256) void dcsPlanKernel(const DcsPlanStream *streams, uint32_t nStreams, uint32_t extraFrames, uint32_t nJobs,
+                                                      const DcsFrameIndex *records, const DcsStreamInfo *infos,
+                                                      DcsSlot *slots, DcsPlanSrc *srcs, uint32_t *flagWord)
+{
+    const uint32_t nChunks = (nJobs + FPW - 1) / FPW;
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nChunks)
+        return;
+    // the stream of the chunk's first job: the last stream whose first job is not behind it
+    uint32_t lo = 0, hi = nStreams - 1;
+    const uint32_t j0 = c * FPW;
+    while (lo < hi)
+    {
+        const uint32_t mid = (lo + hi + 1) / 2;
+        if (streams[mid].firstJob <= j0) lo = mid; else hi = mid - 1;
+    }
+    uint32_t k = lo;
+    DcsPlanStream st = streams[k];
+    uint32_t nValid = min(static_cast<uint32_t>(infos[k].nValidFrames), st.nFrames);
+    uint32_t flags = 0;
+
+    DcsSlot out[FPW];
+    uint32_t nRuns = 0, runUse = 0, poolUse = 0, curStart = 0, curN = 0, curOff = 0;    // cur*: the chunk's last run
+    const DcsSlot empty{ 0xFFFFFFFFu, DCS_NO_PREV_SLOT, DCS_SLOT_EMPTY, 0, 0, 0, DCS_PREV_NONE, 0, 0, 0, 0, 0, 0, 0 };
+    for (int p = 0 ; p < FPW ; ++p)
+    {
+        const uint32_t j = j0 + static_cast<uint32_t>(p);
+        if (j >= nJobs) { out[p] = empty; continue; }
+        while (k + 1 < nStreams && j >= streams[k + 1].firstJob)
+        {
+            ++k;
+            st = streams[k];
+            nValid = min(static_cast<uint32_t>(infos[k].nValidFrames), st.nFrames);
+        }
+        const uint32_t f = j - st.firstJob, framesOut = st.nFrames + extraFrames;
+        const bool has = f < nValid;
+        if (f == 0)
+        {
+            // (what counts is the bits the frames occupy, not nBytes, which includes the reference reader's look-ahead)
+            const DcsStreamInfo in = infos[k];
+            if (in.nFrames == 0 || 2u + static_cast<uint32_t>(in.hdrLen) + (in.payloadBits + 7) / 8 > st.len)
+                flags |= DCS_PLAN_TRUNCATED;
+        }
+        DcsSlot sl{ j, DCS_NO_PREV_SLOT, 0, static_cast<uint8_t>(has ? 1 : 0),
+                    static_cast<uint8_t>((has ? (f == 0 ? st.volShift0 : st.volShiftN) : 8) | (st.xform << 4)),
+                    has ? st.firstRecord + f : 0u, f == 0 ? DCS_PREV_NONE : j - 1, 0, 0, 0, 0, 0, 0, 0 };
+        if (f != 0)
+        {
+            if (p != 0)
+                sl.prevSlot = static_cast<uint8_t>(p - 1);
+            else
+            {
+                sl.flags |= DCS_SLOT_IMPORT;            // the chunk before publishes the tail (its last frame is this one's predecessor)
+                sl.prevJob = c - 1;
+            }
+        }
+        if ((p == FPW - 1 || j + 1 == nJobs) && f + 1 < framesOut && j + 1 < nJobs)
+            sl.flags |= DCS_SLOT_EXPORT;
+        if (has)
+        {
+            const uint32_t *rec = reinterpret_cast<const uint32_t *>(&records[st.firstRecord + f]);
+            const uint32_t bitOff = rec[0], nBits = rec[1] & 0xFFFFu, nBands = (rec[6] >> 16) & 0xFFu, fl = rec[6] >> 24;
+            sl.hdrDw = static_cast<uint32_t>((st.streamOff + 2) >> 2);
+            sl.hdrSh = static_cast<uint8_t>((st.streamOff + 2) & 3);
+            const uint32_t sub = 64 / FPW, nb16 = nBands < 16 ? nBands : 16;
+            const uint32_t bpl = (nb16 + sub - 1) / sub;
+            sl.bpl = (fl & DCS_IDX_SERIAL) ? 0 : static_cast<uint8_t>(bpl < 1 ? 1 : bpl);
+            // where the frame's bytes go in the pool: it extends the chunk's last run or opens a new one (placeFrame, dcs_plan.cpp)
+            const uint64_t bitPos = (st.streamOff + 2 + st.hdrLen) * 8 + bitOff;
+            const uint32_t s0 = static_cast<uint32_t>(bitPos >> 5);
+            const uint32_t n = dcsPoolDwords(st.streamOff, st.hdrLen, bitOff, nBits);
+            if (nRuns != 0 && s0 >= curStart && s0 <= curStart + curN)
+                curN = max(curN, s0 + n - curStart);
+            else
+            {
+                curStart = s0; curN = n; curOff = runUse;
+                ++nRuns;
+            }
+            runUse = curOff + ((curN + 3) & ~3u);
+            sl.poolOff = static_cast<uint16_t>(curOff + (s0 - curStart));
+            poolUse += (n + 3) & ~3u;
+            srcs[st.firstRecord + f] = DcsPlanSrc{ st.streamOff, bitOff, static_cast<uint16_t>(nBits), st.hdrLen, static_cast<uint8_t>(nBands),
+                                                   static_cast<uint8_t>(fl), st.format, f == 0 ? st.mixMul0 : st.mixMulN, st.firstRecord + f };
+        }
+        out[p] = sl;
+        if (has)
+            for (int r = 0 ; r <= p ; ++r)                  // slot k carries run k (constant subscripts: the slots stay in registers)
+                if (static_cast<uint32_t>(r) + 1 == nRuns)
+                {
+                    out[r].runStartDw = curStart;
+                    out[r].runNDw = static_cast<uint16_t>(curN);
+                    out[r].runPoolOff = static_cast<uint16_t>(curOff);
+                }
+    }
+    if (poolUse > dcsPoolCapacity(FPW) || runUse > dcsPoolCapacity(FPW))
+        flags |= DCS_PLAN_POOL_OVERFLOW;
+    for (int p = 0 ; p < FPW ; ++p)
+        slots[static_cast<size_t>(c) * FPW + p] = out[p];
+    if (flags != 0)
+        atomicOr(flagWord, flags);
+}
+}   // namespace
+
 // plan on the host from source digests, pack on the device: `dRecords` (the index records as the device index pass
 // wrote them) and `dBlob` (the streams as uploaded for it) must stay valid until the pack kernel has run, i.e. until the
 // batch's stream has been waited for once
@@ -772,6 +888,104 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
     *out = b;
     return DCS_OK;
 }
+
+// Plan AND pack on the device (dcsPlanKernel above): nothing of the list's index results is needed on the host.  `table`
+// describes the streams (host memory; copied), dRecords / dInfos are what the index kernel wrote or is still writing on
+// `stream`, dBlob the streams as uploaded.  The planner's flag word (DCS_PLAN_*) is copied to *flagOut (pinned memory of the
+// batch) behind the decode launch by batchQueuePlanFlag; a non-zero flag means the PCM of this batch is not to be used.
+static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *table, uint32_t nStreams, uint32_t extraFrames, uint32_t nJobs,
+                                            uint32_t nRecords, bool all94, bool has93aT1, uint64_t payloadBytes, const DcsFrameIndex *dRecords,
+                                            const DcsStreamInfo *dInfos, const uint8_t *dBlob, uint64_t blobLen, hipStream_t stream, DcsBatch **out)
+{
+    *out = nullptr;
+    if (nStreams == 0 || nJobs == 0)
+        return DCS_ERR_INVALID_ARG;
+    DcsBatch *b = new (std::nothrow) DcsBatch;
+    if (b == nullptr)
+        return DCS_ERR_NO_MEMORY;
+    b->ctx = ctx;
+    b->stream = stream ? stream : ctx->stream;
+    b->nJobs = nJobs; b->nSrcs = nRecords;
+    b->fpw = chooseFpw(ctx, nJobs, all94);
+    if (has93aT1)
+        b->flags |= DCS_BATCH_HAS_93A_T1;
+    const uint64_t pcm = static_cast<uint64_t>(nJobs) * DCS_FRAME_SAMPLES * 2;
+    b->algoBytes = payloadBytes + static_cast<uint64_t>(nRecords) * 56u + pcm;
+    b->abiBytes = payloadBytes + static_cast<uint64_t>(nRecords) * sizeof(DcsSrcDesc) + static_cast<uint64_t>(nJobs) * sizeof(DcsFrameJob) + pcm;
+    b->nChunks = (nJobs + static_cast<uint32_t>(b->fpw) - 1) / static_cast<uint32_t>(b->fpw);
+    const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw);
+    void *dTable = nullptr;
+    const size_t tableBytes = sizeof(DcsPlanStream) * nStreams;
+    DcsStatus st = [&]() -> DcsStatus {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        b->planSlotsCap = sizeof(DcsSlot) * static_cast<size_t>(b->nChunks) * static_cast<size_t>(b->fpw);
+        b->planSrcsCap = sizeof(DcsPlanSrc) * (nRecords ? nRecords : 1);
+        HIPCHK(ctx, cacheAlloc(ctx, false, &b->dPlanSlots, b->planSlotsCap));
+        HIPCHK(ctx, cacheAlloc(ctx, false, &b->dPlanSrcs, b->planSrcsCap));
+        // the stream table through pinned staging (a copy from pageable memory holds the calling thread), its device copy
+        // behind it in the same allocation is not needed: the table is small, it rides in the slots' buffer's neighbour
+        b->hStageCap = tableBytes + 16;
+        HIPCHK(ctx, cacheAlloc(ctx, true, &b->hStage, b->hStageCap));
+        memcpy(static_cast<uint8_t *>(b->hStage) + 16, table, tableBytes);
+        memset(b->hStage, 0, 16);
+        b->cap[2] = tableBytes;
+        HIPCHK(ctx, cacheAlloc(ctx, false, &dTable, tableBytes));
+        b->dTable = dTable;
+        HIPCHK(ctx, hipMemcpyAsync(dTable, static_cast<uint8_t *>(b->hStage) + 16, tableBytes, hipMemcpyHostToDevice, b->stream));
+        b->cap[9] = pkgBytes; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPackages), b->cap[9]));
+        HIPCHK(ctx, hipMemsetAsync(b->dPackages, 0, pkgBytes, b->stream));
+        b->cap[4] = sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPcm), b->cap[4]));
+        b->cap[5] = sizeof(uint32_t) * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dErr), b->cap[5]));
+        b->cap[6] = sizeof(int16_t) * 16 * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsOut), b->cap[6]));
+        HIPCHK(ctx, hipMemsetAsync(b->dErr, 0, sizeof(uint32_t) * nJobs, b->stream));
+        b->cap[8] = sizeof(unsigned long long) * 16 * (b->nChunks + 1); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dHandoff), b->cap[8]));
+        HIPCHK(ctx, hipMemsetAsync(b->dHandoff, 0, b->cap[8], b->stream));      // (epoch 0 = never written; the planner's flag word lies behind the last chunk's words)
+        uint32_t *flagWord = reinterpret_cast<uint32_t *>(b->dHandoff + static_cast<size_t>(b->nChunks) * 16) + 2;
+        const uint32_t planBlocks = (b->nChunks + 255) / 256;
+        DcsSlot *dS = static_cast<DcsSlot *>(b->dPlanSlots);
+        DcsPlanSrc *dP = static_cast<DcsPlanSrc *>(b->dPlanSrcs);
+        const DcsPlanStream *dT = static_cast<const DcsPlanStream *>(dTable);
+        const uint32_t blocks = (b->nChunks + 3) / 4;
+        if (b->fpw == 16)
+        {
+            hipLaunchKernelGGL(dcsPlanKernel<16>, dim3(planBlocks), dim3(256), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
+            hipLaunchKernelGGL(dcsPackKernel<16>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+        }
+        else if (b->fpw == 8)
+        {
+            hipLaunchKernelGGL(dcsPlanKernel<8>, dim3(planBlocks), dim3(256), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
+            hipLaunchKernelGGL(dcsPackKernel<8>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+        }
+        else
+        {
+            hipLaunchKernelGGL(dcsPlanKernel<4>, dim3(planBlocks), dim3(256), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
+            hipLaunchKernelGGL(dcsPackKernel<4>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipEventCreate(&b->ev0));
+        HIPCHK(ctx, hipEventCreate(&b->ev1));
+        HIPCHK(ctx, hipEventCreateWithFlags(&b->evDone, hipEventDisableTiming | (tlsBlockingWaits ? hipEventBlockingSync : 0u)));
+        return DCS_OK;
+    }();
+    if (st != DCS_OK)
+    {
+        (void)streamWait(ctx, b->stream);
+        dcs_batch_destroy(b);
+        return st;
+    }
+    *out = b;
+    return DCS_OK;
+}
+
+// queue the copy of the planner's flag word into the batch's pinned staging (behind whatever runs on the batch's stream);
+// read it with batchPlanFlag once the stream has been waited for
+static DcsStatus batchQueuePlanFlag(DcsBatch *b)
+{
+    const uint32_t *flagWord = reinterpret_cast<const uint32_t *>(b->dHandoff + static_cast<size_t>(b->nChunks) * 16) + 2;
+    HIPCHK(b->ctx, hipMemcpyAsync(b->hStage, flagWord, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    return DCS_OK;
+}
+static uint32_t batchPlanFlag(const DcsBatch *b) { return *static_cast<const volatile uint32_t *>(b->hStage); }
 
 // Diagnostic / test entry: the packages of `jobs` as the DEVICE packer lays them out (plan from source digests on the
 // host, pack kernel on the device), for comparison with dcs_pack_chunks, the host packer.  out = NULL to size.

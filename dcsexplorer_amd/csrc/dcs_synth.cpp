@@ -102,14 +102,14 @@ void synth94(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
         int sc;
         if (type1)
         {
-            typical[b] = P.profile == 1 ? rng.range(6, 10) : P.profile == 2 ? rng.range(0, 4) : rng.range(2, 8);
-            cap[b] = P.profile == 3 ? 15 : 11;
+            typical[b] = P.profile == 4 ? 15 : P.profile == 1 ? rng.range(6, 10) : P.profile == 2 ? rng.range(0, 4) : rng.range(2, 8);
+            cap[b] = P.profile >= 3 ? 15 : 11;
             sc = (rng.range(1, 3) << 2) | rng.range(0, 3);
         }
         else
         {
-            typical[b] = P.profile == 1 ? rng.range(5, 9) : P.profile == 2 ? rng.range(0, 3) : rng.range(2, 6);
-            cap[b] = P.profile == 3 ? 16 : 10;
+            typical[b] = P.profile == 4 ? 16 : P.profile == 1 ? rng.range(5, 9) : P.profile == 2 ? rng.range(0, 3) : rng.range(2, 6);
+            cap[b] = P.profile >= 3 ? 16 : 10;
             sc = (clampi(11 - typical[b], 2, 10) << 2) | rng.range(0, 3);
         }
         hdr[b] = static_cast<uint8_t>(sc | (b >= P.strideFromBand ? 0x40 : 0));
@@ -145,6 +145,8 @@ void synth94(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
                 if (target > typical[b] + 3) target = typical[b] + 3;
                 if (P.profile == 2 && rng.chance(40)) target = 0;
             }
+            if (P.profile == 4)
+                target = cap[b];            // saturated: every band at its widest code, every frame
             target = clampi(target, 0, cap[b] < maxCode ? cap[b] : maxCode);
             int delta = clampi(target - code[b], -16, 14);
             code[b] += delta;
@@ -176,7 +178,7 @@ void synth94(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
                     else
                     {
                         int v = clampi(rng.smallSigned(ref), -ref, ref - 1);
-                        if (P.profile == 3) v = rng.range(-ref, ref - 1);
+                        if (P.profile >= 3) v = rng.range(-ref, ref - 1);
                         putSample94(w, c, v + ref);
                         --i;
                     }
@@ -187,7 +189,7 @@ void synth94(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
                 const int lim = 1 << (c - 1);
                 for (int i = 0 ; i < count ; ++i)
                 {
-                    int v = (P.profile == 3 || rng.chance(10)) ? rng.range(-lim, lim - 1)
+                    int v = (P.profile >= 3 || rng.chance(10)) ? rng.range(-lim, lim - 1)
                                                                : clampi(rng.smallSigned(lim), -lim, lim - 1);
                     w.putSigned(v, c);
                 }
@@ -247,7 +249,7 @@ void synth93(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
             const int nSamples = !type1 ? 16 : strided ? 8 : first ? 15 : 16;
             const int maxCode = type1 ? 16 : 15;
 
-            bool wantZero = rng.chance(P.profile == 2 ? 45 : 12);
+            bool wantZero = rng.chance(P.profile == 2 ? 45 : 12) && P.profile != 4;
             if (reuse)
             {
                 bool again = wantZero || rng.chance(30);
@@ -257,8 +259,9 @@ void synth93(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
             if (!reuse)
             {
                 int target = wantZero ? 0
-                    : clampi(wTyp[b] + rng.range(-1, 1) - (type1 ? 0 : 1), 1, P.profile == 3 ? maxCode : 11);
+                    : clampi(wTyp[b] + rng.range(-1, 1) - (type1 ? 0 : 1), 1, P.profile >= 3 ? maxCode : 11);
                 if (P.profile == 3 && rng.chance(25)) target = rng.range(0, maxCode);
+                if (P.profile == 4) target = maxCode;       // saturated: the widest samples in every band
                 if (!type1)
                 {
                     if (rng.chance(20))
@@ -305,9 +308,9 @@ void synth93(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
                 int last = 0, last2 = 0;
                 for (int i = 0 ; i < nSamples ; ++i)
                 {
-                    int v = (P.profile == 3 || subType == 0) ? rng.range(-lim, lim - 1)
+                    int v = (P.profile >= 3 || subType == 0) ? rng.range(-lim, lim - 1)
                                                              : clampi(rng.smallSigned(lim), -lim, lim - 1);
-                    if (subType != 0 && P.profile != 3)
+                    if (subType != 0 && P.profile < 3)
                     {
                         // mean-revert: flip the sign if the running value would leave the bound
                         int nd = subType == 1 ? v : prvDelta + v;
@@ -391,7 +394,7 @@ void synth93a(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
     {
         int prvScale = 0x1A;
         // occasionally end the frame early with the explicit end code (:2921-2923)
-        const int endAt = rng.chance(20) ? rng.range(0, numBands - 1) : numBands;
+        const int endAt = (rng.chance(20) && P.profile != 4) ? rng.range(0, numBands - 1) : numBands;
         for (int band = 0 ; band < numBands ; ++band)
         {
             if (band == endAt)
@@ -403,12 +406,14 @@ void synth93a(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
             do
                 bits = rng.chance(P.profile == 2 ? 45 : 15) ? 0 : rng.range(1, 9);
             while (!bbHave[bits]);
+            if (P.profile == 4)                             // saturated: the most bits this group's codebook has
+                for (bits = 9 ; !bbHave[bits] ; --bits) { }
             w.put(bbCode[bits].code, bbCode[bits].len);
             if (bits == 0)
                 continue;
 
             // choose the scale step so that the scale code lands in a moderate range
-            int target = P.profile == 3 ? rng.range(0, 0x39) : rng.range(0x1C, 0x2A);
+            int target = P.profile >= 3 ? rng.range(0, 0x39) : rng.range(0x1C, 0x2A);
             int v = clampi(target - prvScale + 1 - 2 * bits, 0, 0x35);
             while (!scHave[v]) v = (v + 1) % 0x36;
             w.put(scCode[v].code, scCode[v].len);

@@ -344,6 +344,8 @@ typedef struct DcsPipelineResult
     uint32_t        nFrames, nStreams;
     DcsStatus       status;
     float           hostMs, deviceMs;  /* the worker's wall time in host preparation / upload + kernel + download */
+    uint32_t        path;              /* DCS_PIPE_*: the stages of THIS list that ran on the device (a list the device
+                                          stages cannot serve -- see the flags -- takes the host's, same PCM)          */
 } DcsPipelineResult;
 /* flags: DCS_PIPE_INDEX_ON_DEVICE -- the index pass of every list runs on the GPU (one wavefront per stream, the walk of
  * dcs_index_streams_gpu) instead of on the host pool.  One list takes longer that way, many lists in flight much less:
@@ -354,6 +356,14 @@ typedef struct DcsPipelineResult
  * neither receives the records nor builds or uploads packages. */
 #define DCS_PIPE_INDEX_ON_DEVICE 1u
 #define DCS_PIPE_PACK_ON_DEVICE  2u
+/* DCS_PIPE_PLAN_ON_DEVICE (implies the two above) -- the chunk plan is made on the device as well (dcsPlanKernel): a list of
+ * whole streams has a regular job list, so its plan is arithmetic, one thread per chunk.  Nothing of the index results
+ * comes back to the host; a worker lays the list's streams out and uploads them, and once the walk is done queues planner,
+ * packer, decode kernel and the copy down on one stream and sleeps until the PCM is there.  A list the arithmetic plan
+ * cannot serve (a chunk whose compressed bytes overflow the kernel's bit pool, where the host planner closes the chunk
+ * early; a stream that runs past its buffer) is decoded by the host-planned path instead, same PCM
+ * (DcsPipelineResult.path tells). */
+#define DCS_PIPE_PLAN_ON_DEVICE  4u
 DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth /* 1..64 lists in flight */, uint32_t flags, DcsPipeline **out);
 void      dcs_pipeline_destroy(DcsPipeline *p);
 DcsStatus dcs_pipeline_submit(DcsPipeline *p, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames);
@@ -563,7 +573,9 @@ typedef struct DcsSynthParams
     int32_t  nBands;                   /* populated header bands: 1..16 (93a Type 1: 1..18)             */
     int32_t  strideFromBand;           /* first band carrying the half-density 0x40 bit; >= 16 = none   */
     int32_t  profile;                  /* 0 = default mix, 1 = dense (wide codes), 2 = sparse (many zero
-                                          bands), 3 = adversarial edge cases (max widths, deep codes)   */
+                                          bands), 3 = adversarial edge cases (max widths, deep codes),
+                                          4 = saturated (every band at its widest code in every frame:
+                                          the largest frames the formats can express, ~500 bytes)         */
     int32_t  reserved;
 } DcsSynthParams;
 

@@ -96,14 +96,14 @@ def test_device_packer_lays_out_the_same_packages_as_the_host_packer(gpu_ctx, fp
     assert bad.size == 0, "first difference: chunk %d byte %d" % (bad[0][0], bad[0][1])
 
 
-@pytest.mark.parametrize("on_device", [0, 1, 2], ids=["host-index", "device-index", "device-index-and-pack"])
+@pytest.mark.parametrize("on_device", [0, 1, 2, 3], ids=["host-index", "device-index", "device-index-and-pack", "device-index-plan-and-pack"])
 def test_pipeline_returns_lists_in_order(gpu_ctx, corpus, on_device):
     """dcs_pipeline: several lists in flight come back in submission order with the PCM of dcs_decode_streams, whether
     the index pass runs on the host pool or on the device"""
     g, manifest, streams = corpus
     lists = [streams[0:40], streams[40:45], streams[45:140], streams[140:141], streams[141:200]]
     want = [gpu_ctx.decode_streams(l, extra_frames=2) for l in lists]
-    pipe = gpu_ctx.pipeline(3, index_on_device=on_device >= 1, pack_on_device=on_device == 2)
+    pipe = gpu_ctx.pipeline(3, index_on_device=on_device >= 1, pack_on_device=on_device >= 2, plan_on_device=on_device == 3)
     got = []
     for k, l in enumerate(lists):
         pipe.submit(l, extra_frames=2)              # (blocks while 3 lists are in flight)
@@ -165,7 +165,7 @@ def test_batch_outlives_caller_stream_ordering(gpu_ctx, oracle):
         batch.close()                               # destroy right away: buffers are recycled only once the launch is done
 
 
-@pytest.mark.parametrize("pack_on_device", [False, True], ids=["host-pack", "device-pack"])
+@pytest.mark.parametrize("pack_on_device", [0, 1, 2], ids=["host-pack", "device-pack", "device-plan-and-pack"])
 def test_pipeline_device_index_with_damaged_and_rom_sized_buffers(gpu_ctx, oracle, pack_on_device):
     """device index pass: a stream handed over with a buffer far longer than the stream (the rest of a ROM image) is cut
     to what it can use; a truncated stream (runs past its buffer, the missing bytes read as zero) sends its list down
@@ -175,16 +175,17 @@ def test_pipeline_device_index_with_damaged_and_rom_sized_buffers(gpu_ctx, oracl
     rom_sized = [(o, s + bytes(200000), v, l) for o, s, v, l in base[:3]] + base[3:]
     truncated = base[:5] + [(base[5][0], base[5][1][:len(base[5][1]) // 2], base[5][2], base[5][3])]
     damaged = [(o, corrupt(s, 77 + k, nflips=4), v, l) for k, (o, s, v, l) in enumerate(base)]
-    pipe = gpu_ctx.pipeline(3, index_on_device=True, pack_on_device=pack_on_device)
-    for lst in (rom_sized, truncated, damaged):
-        want = gpu_ctx.decode_streams(lst, extra_frames=2)
-        pipe.submit(lst, extra_frames=2)
-        pcm, err, first, _, _ = pipe.collect()
-        assert np.array_equal(first, want[2]) and np.array_equal(err, want[1]) and np.array_equal(pcm, want[0])
+    pipe = gpu_ctx.pipeline(3, index_on_device=True, pack_on_device=pack_on_device >= 1, plan_on_device=pack_on_device == 2)
+    for extra in (2, 0):                # (without taper frames a stream's last frame and the next one's first share chunks)
+        for lst in (rom_sized, truncated, damaged):
+            want = gpu_ctx.decode_streams(lst, extra_frames=extra)
+            pipe.submit(lst, extra_frames=extra)
+            pcm, err, first, _, _ = pipe.collect()
+            assert np.array_equal(first, want[2]) and np.array_equal(err, want[1]) and np.array_equal(pcm, want[0])
     pipe.close()
 
 
-@pytest.mark.parametrize("pack_on_device", [False, True], ids=["host-pack", "device-pack"])
+@pytest.mark.parametrize("pack_on_device", [0, 1, 2], ids=["host-pack", "device-pack", "device-plan-and-pack"])
 def test_pipeline_device_index_stream_that_announces_far_more_than_it_holds(gpu_ctx, oracle, pack_on_device):
     """the LAST stream of a small list claims 65 535 frames, and its header makes the zero bits behind its few bytes parse
     as valid frames (1993 Type 0: "no sub-type change, code 0" is five zero bits per band), so the device walk goes on for
@@ -195,7 +196,7 @@ def test_pipeline_device_index_stream_that_announces_far_more_than_it_holds(gpu_
     lst = good + [(D.OS93B, runaway, 255, 0x64)]
     want = gpu_ctx.decode_streams(lst, extra_frames=2)
     assert want[0].shape[0] == sum(20 + f + 2 for f in range(3)) + 65535 + 2
-    pipe = gpu_ctx.pipeline(2, index_on_device=True, pack_on_device=pack_on_device)
+    pipe = gpu_ctx.pipeline(2, index_on_device=True, pack_on_device=pack_on_device >= 1, plan_on_device=pack_on_device == 2)
     for _ in range(2):
         pipe.submit(lst, extra_frames=2)
     for _ in range(2):
@@ -209,14 +210,45 @@ def test_pipeline_device_index_stream_that_announces_far_more_than_it_holds(gpu_
     assert recs_d.tobytes() == recs_h.tobytes()
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2], ids=["host-index", "device-index", "device-index-and-pack"])
+def test_saturated_frames_fill_the_bit_pool_and_the_device_planner_hands_the_list_back(gpu_ctx, oracle):
+    """synth profile 4: every band at its widest code in every frame, ~500 bytes a frame where the workloads have ~100.  The
+    chunks' compressed bytes then no longer fit the kernel's bit pool: the host planner closes such chunks early, the
+    device planner (arithmetic chunks) flags the list and the pipeline decodes it through the host planner -- same PCM as
+    the oracle's either way, with 4, 8 and 16 frames per wavefront; DcsPipelineResult.path tells which stages ran where."""
+    lst = [(os_for(f, f & 1), make_stream(f, 48 + f, seed=66000 + f, profile=4), 255, 0x64) for f in ALL_FORMATS]
+    assert max(len(s) / (48.0 + f) for f, (_, s, _, _) in zip(ALL_FORMATS, lst)) > 480
+    easy = [(os_for(f, f & 1), make_stream(f, 48 + f, seed=66100 + f), 255, 0x64) for f in ALL_FORMATS]
+    want = np.concatenate([oracle.decode(o, v, [s], [l], ((s[0] << 8) | s[1]) + 2) for o, s, v, l in lst])
+    try:
+        for fpw in (4, 8, 16):
+            gpu_ctx.set_frames_per_wave(fpw)
+            pcm, err, _ = gpu_ctx.decode_streams(lst, extra_frames=2)
+            assert np.array_equal(pcm, want) and not err.any(), "fpw %d" % fpw
+            for mode in range(4):
+                pipe = gpu_ctx.pipeline(2, index_on_device=mode >= 1, pack_on_device=mode >= 2, plan_on_device=mode == 3)
+                pipe.submit(lst, extra_frames=2)
+                pipe.submit(easy, extra_frames=2)
+                pcm, err, _, _, _ = pipe.collect()
+                assert np.array_equal(pcm, want) and not err.any(), "fpw %d mode %d" % (fpw, mode)
+                hard_path = pipe.last_path
+                pipe.collect()
+                easy_path = pipe.last_path
+                pipe.close()
+                assert easy_path == (0, 1, 3, 7)[mode]
+                if mode == 3:
+                    assert hard_path == 0          # handed back: host index pass, host planner, host packer
+    finally:
+        gpu_ctx.set_frames_per_wave(0)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["host-index", "device-index", "device-index-and-pack", "device-index-plan-and-pack"])
 def test_pipeline_reports_a_bad_list_and_carries_on(gpu_ctx, oracle, mode):
     """a list with an unusable stream (zero frames) comes back with an error status in its turn; the lists around it are
     decoded as if nothing had happened; destroying a pipeline with lists still in flight finishes them first"""
     good = [(os_for(f, 0), make_stream(f, 30 + f, seed=71000 + f), 255, 0x64) for f in ALL_FORMATS]
     bad = good[:2] + [(D.OS94, bytes([0, 0]) + bytes(40), 255, 0x64)] + good[2:]
     want = gpu_ctx.decode_streams(good)
-    pipe = gpu_ctx.pipeline(4, index_on_device=mode >= 1, pack_on_device=mode == 2)
+    pipe = gpu_ctx.pipeline(4, index_on_device=mode >= 1, pack_on_device=mode >= 2, plan_on_device=mode == 3)
     pipe.submit(good)
     pipe.submit(bad)
     pipe.submit(good)
@@ -242,7 +274,7 @@ def test_sharded_entry_reports_errors():
     assert pcm.shape[0] == 20 and list(cut)[0] == 0 and list(cut)[-1] == 1
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2], ids=["host-index", "device-index", "device-index-and-pack"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["host-index", "device-index", "device-index-and-pack", "device-index-plan-and-pack"])
 def test_pipeline_soak(gpu_ctx, mode):
     """a few hundred lists through 12 slots in flight: every list's PCM is checked (tools/pipe_soak.py runs the same for
     thousands of lists and watches the memory)"""
@@ -251,7 +283,7 @@ def test_pipeline_soak(gpu_ctx, mode):
     variants = [base[i:] + base[:i] for i in (0, 5, 11)]
     want = [zlib.crc32(gpu_ctx.decode_streams(v)[0].tobytes()) for v in variants]
     refs = [D.make_refs(v) for v in variants]
-    pipe = gpu_ctx.pipeline(12, index_on_device=mode >= 1, pack_on_device=mode == 2)
+    pipe = gpu_ctx.pipeline(12, index_on_device=mode >= 1, pack_on_device=mode >= 2, plan_on_device=mode == 3)
     n, done, bad = 240, 0, 0
     for k in range(n):
         pipe.submit_refs(refs[k % 3][0], len(variants[k % 3]))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Seeded fuzz of the decode path on a GPU box: lists of random streams (every layout, 1..18 bands, strided from a random
-band, four symbol profiles, some with flipped payload bits or cut short) decoded with 4, 8 and 16 frames per wavefront
+band, five symbol profiles, some with flipped payload bits or cut short) decoded with 4, 8 and 16 frames per wavefront
 and held against the oracle, the device's index pass held against the host's; every fourth seed also a multi-channel mix of 2..6 streams on one decoder, every eighth the list through dcs_pipeline.  argv[1]: seconds to run (default 120), argv[2]: first seed."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 orc = Oracle()
 ctx = D.Context(0)
 t0 = t_said = time.time(); lists = frames = mixes = piped = 0; seed = seed0
-pipes = [ctx.pipeline(3, index_on_device=m >= 1, pack_on_device=m == 2) for m in range(3)]
+pipes = [ctx.pipeline(3, index_on_device=m >= 1, pack_on_device=m >= 2, plan_on_device=m == 3) for m in range(4)]
 by_fmt = {f: 0 for f in ALL_FORMATS}
 while time.time() - t0 < budget:
     g = splitmix(0xF022 + seed)
@@ -29,7 +29,7 @@ while time.time() - t0 < budget:
         stride_from = 16 if next(g) % 2 else next(g) % 16
         if fmt == D.FMT_93_T0 and stride_from < 16:
             nbands = min(nbands, 12)                  # (Type 0 strided bands span 32 slots)
-        s = make_stream(fmt, nfr, seed=(seed << 8) + k, profile=next(g) % 4, stride_from=stride_from, nbands=nbands)
+        s = make_stream(fmt, nfr, seed=(seed << 8) + k, profile=next(g) % 5, stride_from=stride_from, nbands=nbands)
         r = next(g) % 8
         if r == 0 and len(s) > 24:
             s = corrupt(s, next(g) & 0xFFFF, nflips=1 + next(g) % 4) + bytes(256)
@@ -61,15 +61,18 @@ while time.time() - t0 < budget:
             print("MISMATCH seed %d fpw %d: %s" % (seed, fpw, "shape" if bad is None else "%d samples in %d frames, first frame %d" % (len(bad), len(set(bad[:, 0])), bad[0][0])))
             sys.exit(1)
     lists += 1; frames += want.shape[0]
-    # every eighth seed the list also goes through dcs_pipeline in its three modes (index pass on the host pool / on the
-    # device / index pass and packer on the device), twice in flight
+    # every eighth seed the list also goes through dcs_pipeline in its four modes (index pass on the host pool / on the
+    # device / index pass and packer on the device / planner too), in flight twice: once with the taper frame, once without
+    # (then a stream's last frame and the next one's first sit side by side in a chunk)
     if seed % 8 == 0:
         ctx.set_frames_per_wave(0)
+        ends = np.cumsum([r.shape[0] for r in ref]) - 1
+        bare = np.delete(want, ends, axis=0)
         for mode, pipe in enumerate(pipes):
-            pipe.submit(streams, extra_frames=1); pipe.submit(streams, extra_frames=1)
-            for _ in range(2):
+            pipe.submit(streams, extra_frames=1); pipe.submit(streams, extra_frames=0)
+            for w in (want, bare):
                 pcm, err, first, _, _ = pipe.collect()
-                if pcm.shape != want.shape or not np.array_equal(pcm, want):
+                if pcm.shape != w.shape or not np.array_equal(pcm, w):
                     print("MISMATCH (pipeline mode %d) seed %d" % (mode, seed)); sys.exit(1)
         piped += 1
     # every fourth seed also a multi-channel mix: 2..6 streams of one OS version on the channels of one decoder (the
@@ -86,7 +89,7 @@ while time.time() - t0 < budget:
             stride_from = 16 if next(g) % 2 else next(g) % 16
             if fmt == D.FMT_93_T0 and stride_from < 16:
                 nbands = min(nbands, 12)
-            chans.append(make_stream(fmt, 4 + next(g) % 40, seed=(seed << 8) + 100 + c, profile=next(g) % 4, stride_from=stride_from, nbands=nbands))
+            chans.append(make_stream(fmt, 4 + next(g) % 40, seed=(seed << 8) + 100 + c, profile=next(g) % 5, stride_from=stride_from, nbands=nbands))
             levels.append(0x20 + next(g) % 0x60)
         vol = 128 + next(g) % 128
         n_out = max((c[0] << 8) | c[1] for c in chans) + 2
@@ -106,5 +109,5 @@ while time.time() - t0 < budget:
         print("  ... %d lists, %d mixes, %.0f s" % (lists, mixes, t_said - t0), flush=True)
 for pipe in pipes:
     pipe.close()
-print("fuzz: %d lists (%d of them also through the pipeline's three modes) and %d multi-channel mixes (%d frames x 3 kernel variants) in %.0f s, seeds %d..%d, all bit-exact; streams by layout: %s" %
+print("fuzz: %d lists (%d of them also through the pipeline's four modes) and %d multi-channel mixes (%d frames x 3 kernel variants) in %.0f s, seeds %d..%d, all bit-exact; streams by layout: %s" %
       (lists, piped, mixes, frames, time.time() - t0, seed0, seed - 1, {FORMAT_NAMES[f]: n for f, n in by_fmt.items()}))

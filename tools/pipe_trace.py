@@ -6,10 +6,12 @@ from dcsexplorer_amd import workloads as W
 streams = W.streams_dcs94_65536()
 ctx = D.Context(0)
 refs, keep = D.make_refs(streams)
-depth = int(sys.argv[1]); dev = sys.argv[2] in ("dev", "devpack")
-pipe = ctx.pipeline(depth, index_on_device=dev, pack_on_device=sys.argv[2] == "devpack")
-for _ in range(depth): pipe.submit_refs(refs, len(streams))
-for _ in range(depth): pipe.collect()
+depth = int(sys.argv[1]); dev = sys.argv[2] in ("dev", "devpack", "devplan")
+pipe = ctx.pipeline(depth, index_on_device=dev, pack_on_device=sys.argv[2] in ("devpack", "devplan"), plan_on_device=sys.argv[2] == "devplan")
+# warm-up: the context's buffer cache takes about three rounds of `depth` lists until nothing is allocated any more
+for _ in range(3):
+    for _ in range(depth): pipe.submit_refs(refs, len(streams))
+    for _ in range(depth): pipe.collect()
 n = 3 * depth
 def cpustat():
     try:
