@@ -231,7 +231,7 @@ def second_workload(ctx, args, torch, name="realistic_65536"):
 
 
 def end_to_end_ranks(ctx, streams, n_frames, world, rank, device, depth=48, lists=96):
-    """N ranks on one node, each with a pipeline of its own (index pass and packer on the device) over its own lists, all
+    """N ranks on one node, each with a pipeline of its own (index pass, planner and packer on the device) over its own lists, all
     sharing the box's host CPUs: value = the samples all ranks delivered / the slowest rank's time (barrier before the
     clock starts).  Per rank: ms per list, the worker threads' wall time per list, CPU-milliseconds per list."""
     import resource
@@ -240,7 +240,7 @@ def end_to_end_ranks(ctx, streams, n_frames, world, rank, device, depth=48, list
     import torch.distributed as dist
     import dcsexplorer_amd as D
     refs, keep = D.make_refs(streams)
-    pipe = ctx.pipeline(depth, index_on_device=True, pack_on_device=True)
+    pipe = ctx.pipeline(depth, index_on_device=True, pack_on_device=True, plan_on_device=True)
     for _ in range(depth):
         pipe.submit_refs(refs, len(streams))
     for _ in range(depth):
@@ -274,7 +274,7 @@ def end_to_end_ranks(ctx, streams, n_frames, world, rank, device, depth=48, list
     return {"unit": "samples/s", "frames_per_list": n_frames,
             "sustained": {"value": total_lists * n_frames * 240 / slowest, "ms_per_list": slowest / total_lists * 1e3, "depth_per_rank": depth,
                           "lists_per_rank": n_lists, "ranks": world,
-                          "what": "every rank its own dcs_pipeline (index pass and packer on the device), lists in flight, PCM returned in "
+                          "what": "every rank its own dcs_pipeline (index pass, planner and packer on the device), lists in flight, PCM returned in "
                                   "pinned memory; all ranks' samples over the slowest rank's time"},
             "per_rank": [{"rank": r, "ms_per_list": float(rows[r, 0] / rows[r, 1] * 1e3), "worker_host_ms": float(rows[r, 2]),
                           "worker_device_ms": float(rows[r, 3]), "cpu_ms_per_list": float(rows[r, 4])} for r in range(world)],
