@@ -2,6 +2,7 @@
 // include/dcs_hip.h).  The product path has no CPU decode: without a usable gfx950 device
 // dcs_ctx_create fails and nothing below can run.
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -102,8 +103,14 @@ static void cacheFree(DcsCtx *ctx, bool pinned, void *p, size_t cap)
     held += cap;
 }
 
-// Host waits of THIS thread sleep on an interrupt instead of polling: set by the pipeline's threads, of which dozens
-// wait at any time and must leave the cores to the ones that prepare lists.  Everybody else polls (shortest latency).
+static double hipchkNow() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Host waits of THIS thread leave the core to others: set by the pipeline's threads, of which dozens wait at any time while
+// a few prepare lists.  The runtime's own waits do not do that on this stack -- hipStreamSynchronize and hipEventSynchronize
+// burn the waiting thread's core for the whole wait, with an event created hipEventBlockingSync as well (tools/wait_cost.hip:
+// 8.00 ms of thread CPU time for a wait of 8.01 ms) -- so such a thread records an event and asks for it between sleeps: a
+// short look first (the kernels of a small list are done in microseconds), then naps of 50 us, which the kernel's timer slack
+// makes ~110.  DCS_WAIT_RUNTIME=1 restores hipEventSynchronize.  Everybody else polls inside the runtime (shortest latency).
 static thread_local bool tlsBlockingWaits = false;
 
 // wait for everything enqueued on `stream`
@@ -111,8 +118,8 @@ static hipError_t streamWait(DcsCtx *ctx, hipStream_t stream)
 {
     if (!tlsBlockingWaits)
         return hipStreamSynchronize(stream);
-    // one blocking event per thread and device, destroyed when the thread ends (pipeline workers and indexers come and
-    // go with their pipeline)
+    // one event per thread and device, destroyed when the thread ends (pipeline workers and indexers come and go with
+    // their pipeline)
     struct ThreadEvent
     {
         hipEvent_t ev = nullptr;
@@ -128,8 +135,24 @@ static hipError_t streamWait(DcsCtx *ctx, hipStream_t stream)
             return e;
         te.device = ctx->device;
     }
-    const hipError_t e = hipEventRecord(te.ev, stream);
-    return e != hipSuccess ? e : hipEventSynchronize(te.ev);
+    hipError_t e = hipEventRecord(te.ev, stream);
+    if (e != hipSuccess)
+        return e;
+    static const bool runtimeWait = getenv("DCS_WAIT_RUNTIME") != nullptr && atoi(getenv("DCS_WAIT_RUNTIME")) != 0;
+    if (runtimeWait)
+        return hipEventSynchronize(te.ev);
+    const double t0 = hipchkNow();
+    for (;;)
+    {
+        e = hipEventQuery(te.ev);
+        if (e != hipErrorNotReady)
+            return e;
+        if (hipchkNow() - t0 > 30.0)
+        {
+            timespec nap{ 0, 50000 };
+            nanosleep(&nap, nullptr);
+        }
+    }
 }
 
 struct DcsBatch
@@ -191,7 +214,6 @@ static void setCreateError(const std::string &text)
 }
 
 // (DCS_HIP_SLOW=<microseconds>: report every runtime call that takes longer, a diagnostic for the pipeline's threads)
-static double hipchkNow() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static const double g_hipSlowUs = getenv("DCS_HIP_SLOW") ? atof(getenv("DCS_HIP_SLOW")) : 0.0;
 #define HIPCHK(ctx, call)                                                                        \
     do {                                                                                         \
