@@ -75,6 +75,17 @@ class SynthParams(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+def _view(ptr, ctype, dtype, shape):
+    """a numpy view of library memory (np.ctypeslib.as_array costs 0.6 ms per call for a 15 M-element array)"""
+    addr = ptr.value if isinstance(ptr, ctypes.c_void_p) else ptr
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if n == 0 or not addr:
+        return np.zeros(shape, dtype=dtype)
+    return np.frombuffer((ctype * n).from_address(addr), dtype=dtype).reshape(shape)
+
+
 class DcsError(RuntimeError):
     def __init__(self, status, msg=""):
         super().__init__("libdcs_hip status %d %s" % (status, msg))
@@ -786,8 +797,8 @@ class Batch:
         valid until the batch is run again or closed"""
         p, e = ctypes.c_void_p(), ctypes.c_void_p()
         _check(self.L.dcs_batch_download_view(self.h, ctypes.byref(p), ctypes.byref(e)), self.ctx.h)
-        pcm = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_int16)), shape=(self.n_jobs, FRAME_SAMPLES))
-        err = np.ctypeslib.as_array(ctypes.cast(e, ctypes.POINTER(ctypes.c_uint32)), shape=(self.n_jobs,))
+        pcm = _view(p, ctypes.c_int16, np.int16, (self.n_jobs, FRAME_SAMPLES))
+        err = _view(e, ctypes.c_uint32, np.uint32, (self.n_jobs,))
         return pcm, err
 
     @property
@@ -852,9 +863,9 @@ class Pipeline:
         if self._keep:
             self._keep.pop(0)
         _check(st, self.ctx.h)
-        pcm = np.ctypeslib.as_array(ctypes.cast(r.pcm, ctypes.POINTER(ctypes.c_int16)), shape=(r.nFrames, FRAME_SAMPLES))
-        err = np.ctypeslib.as_array(ctypes.cast(r.err, ctypes.POINTER(ctypes.c_uint32)), shape=(r.nFrames,))
-        first = np.ctypeslib.as_array(ctypes.cast(r.frameOffsets, ctypes.POINTER(ctypes.c_uint32)), shape=(r.nStreams + 1,))
+        pcm = _view(r.pcm, ctypes.c_int16, np.int16, (r.nFrames, FRAME_SAMPLES))
+        err = _view(r.err, ctypes.c_uint32, np.uint32, (r.nFrames,))
+        first = _view(r.frameOffsets, ctypes.c_uint32, np.uint32, (r.nStreams + 1,))
         return pcm, err, first, r.hostMs, r.deviceMs
 
     def close(self):

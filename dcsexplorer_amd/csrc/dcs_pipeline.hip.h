@@ -703,8 +703,12 @@ extern "C" DcsStatus dcs_pipeline_collect(DcsPipeline *p, DcsPipelineResult *out
 {
     if (p == nullptr || out == nullptr)
         return DCS_ERR_INVALID_ARG;
+    const double tc0 = nowMs();
     (void)hipSetDevice(p->ctx->device);
+    const double tc1 = nowMs();
     pipelineRelease(p, p->held);                    // the previous result's buffers go back to the context's cache
+    pipeLog("caller", 0, "set-device", tc0, tc1);
+    pipeLog("caller", 0, "release", tc1, nowMs());
     DcsPipeline::JobPtr job;
     {
         std::unique_lock<std::mutex> lk(p->m);

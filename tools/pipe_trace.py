@@ -27,6 +27,8 @@ def threadstat():
             comm = open(t + "/comm").read().strip()
             f = open(t + "/stat").read().rsplit(")", 1)[1].split()
             agg[comm][0] += 1; agg[comm][1] += int(f[11]) / tck; agg[comm][2] += int(f[12]) / tck
+            tid = "tid " + t.rsplit("/", 1)[1] + " (" + comm + ")"
+            agg[tid][0] += 1; agg[tid][1] += int(f[11]) / tck; agg[tid][2] += int(f[12]) / tck
         except Exception:
             pass
     return agg
@@ -48,4 +50,5 @@ print("ms/list", dt / n * 1e3, "cpu user ms/list", (r1.ru_utime - r0.ru_utime) /
 th1 = threadstat()
 for k in sorted(th1, key=lambda k: -(th1[k][1] - th0.get(k, [0, 0, 0])[1])):
     u = th1[k][1] - th0.get(k, [0, 0.0, 0.0])[1]; sy = th1[k][2] - th0.get(k, [0, 0.0, 0.0])[2]
-    sys.stderr.write("  threads %-18s n=%3d user %.2f ms/list sys %.2f ms/list\n" % (k, th1[k][0], u / n * 1e3, sy / n * 1e3))
+    if (u + sy) / n * 1e3 >= 0.05:
+        sys.stderr.write("  threads %-18s n=%3d user %.2f ms/list sys %.2f ms/list\n" % (k, th1[k][0], u / n * 1e3, sy / n * 1e3))
