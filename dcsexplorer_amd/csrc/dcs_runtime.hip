@@ -970,24 +970,24 @@ static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *ta
         b->cap[8] = sizeof(unsigned long long) * 16 * (b->nChunks + 1); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dHandoff), b->cap[8]));
         HIPCHK(ctx, hipMemsetAsync(b->dHandoff, 0, b->cap[8], b->stream));      // (epoch 0 = never written; the planner's flag word lies behind the last chunk's words)
         uint32_t *flagWord = reinterpret_cast<uint32_t *>(b->dHandoff + static_cast<size_t>(b->nChunks) * 16) + 2;
-        const uint32_t planBlocks = (b->nChunks + 255) / 256;
+        const uint32_t planBlocks = (b->nChunks + 63) / 64;         // (one wavefront per workgroup: a thread's work is serial, the chunks should spread over the CUs)
         DcsSlot *dS = static_cast<DcsSlot *>(b->dPlanSlots);
         DcsPlanSrc *dP = static_cast<DcsPlanSrc *>(b->dPlanSrcs);
         const DcsPlanStream *dT = static_cast<const DcsPlanStream *>(dTable);
         const uint32_t blocks = (b->nChunks + 3) / 4;
         if (b->fpw == 16)
         {
-            hipLaunchKernelGGL(dcsPlanKernel<16>, dim3(planBlocks), dim3(256), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
+            hipLaunchKernelGGL(dcsPlanKernel<16>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
             hipLaunchKernelGGL(dcsPackKernel<16>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
         }
         else if (b->fpw == 8)
         {
-            hipLaunchKernelGGL(dcsPlanKernel<8>, dim3(planBlocks), dim3(256), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
+            hipLaunchKernelGGL(dcsPlanKernel<8>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
             hipLaunchKernelGGL(dcsPackKernel<8>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
         }
         else
         {
-            hipLaunchKernelGGL(dcsPlanKernel<4>, dim3(planBlocks), dim3(256), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
+            hipLaunchKernelGGL(dcsPlanKernel<4>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
             hipLaunchKernelGGL(dcsPackKernel<4>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
         }
         HIPCHK(ctx, hipGetLastError());
