@@ -1189,6 +1189,7 @@ extern "C" DcsStatus dcs_batch_sync(DcsBatch *b)
     HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
     HIPCHK(b->ctx, waitLaunched(b));
     HIPCHK(b->ctx, streamWait(b->ctx, b->stream));
+    b->settled = true;
     return DCS_OK;
 }
 
@@ -1200,6 +1201,7 @@ extern "C" DcsStatus dcs_batch_download(DcsBatch *b, int16_t *pcmOut, uint32_t *
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, waitLaunched(b));
     HIPCHK(ctx, streamWait(b->ctx, b->stream));
+    b->settled = true;          // (the copies below are synchronous)
     if (pcmOut)
         HIPCHK(ctx, hipMemcpy(pcmOut, b->dPcm, sizeof(int16_t) * DCS_FRAME_SAMPLES * b->nJobs, hipMemcpyDeviceToHost));
     if (errOut)

@@ -364,6 +364,7 @@ typedef struct DcsPipelineResult
  * early; a stream that runs past its buffer) is decoded by the host-planned path instead, same PCM
  * (DcsPipelineResult.path tells). */
 #define DCS_PIPE_PLAN_ON_DEVICE  4u
+#define DCS_PIPE_ALL_ON_DEVICE   7u      /* the three together: what a caller with many lists in flight wants */
 DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth /* 1..64 lists in flight */, uint32_t flags, DcsPipeline **out);
 void      dcs_pipeline_destroy(DcsPipeline *p);
 DcsStatus dcs_pipeline_submit(DcsPipeline *p, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames);
