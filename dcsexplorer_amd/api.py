@@ -97,7 +97,7 @@ _LIB = None
 EXPORTS = [
     "dcs_abi_version", "dcs_index_stream", "dcs_volume_multiplier", "dcs_mixing_multiplier", "dcs_frame_scale",
     "dcs_stream_params", "dcs_ctx_create", "dcs_ctx_destroy", "dcs_last_error", "dcs_device_count",
-    "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run", "dcs_batch_run_many", "dcs_pack_chunks",
+    "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_ctx_set_large_list_path", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run", "dcs_batch_run_many", "dcs_pack_chunks",
     "dcs_batch_time", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_download_view", "dcs_batch_device_pcm",
     "dcs_batch_algorithmic_bytes", "dcs_batch_num_jobs", "dcs_decode_streams", "dcs_count_stream_frames",
     "dcs_synth_stream", "dcs_plan_chunks", "dcs_index_streams", "dcs_index_streams_gpu",
@@ -163,6 +163,8 @@ def load_library():
     L.dcs_ctx_set_frames_per_wave.argtypes = [vp, ctypes.c_int]
     L.dcs_ctx_set_tail_handoff.restype = i32
     L.dcs_ctx_set_tail_handoff.argtypes = [vp, ctypes.c_int]
+    L.dcs_ctx_set_large_list_path.restype = i32
+    L.dcs_ctx_set_large_list_path.argtypes = [vp, ctypes.c_int]
     L.dcs_pack_chunks.restype = i32
     L.dcs_pack_chunks.argtypes = [vp, u32, vp, vp, sz, ctypes.c_int, vp, sz, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.dcs_plan_chunks2.restype = i32
@@ -636,6 +638,10 @@ class Context:
 
     def set_tail_handoff(self, enable):
         _check(self.L.dcs_ctx_set_tail_handoff(self.h, int(bool(enable))), self.h)
+
+    def set_large_list_path(self, on_device):
+        """dcs_decode_streams on a large list: index walk, planner and packer on the device (default) or the host's pool"""
+        _check(self.L.dcs_ctx_set_large_list_path(self.h, int(bool(on_device))), self.h)
 
     def decode_batch(self, blob, srcs, jobs, tails_in=None, want_tails=False):
         blob_a = np.frombuffer(bytes(blob), dtype=np.uint8)

@@ -71,6 +71,7 @@ struct DcsPipeline
 
     DcsCtx *ctx = nullptr;
     int depth = 0;
+    size_t roundGather = 0;                 // > 1: an index round waits (briefly) until so many lists are there
     uint32_t flags = 0;                             // DCS_PIPE_*
     std::mutex m;
     std::condition_variable work, indexWork, finished, room;
@@ -92,6 +93,9 @@ static double nowMs()
 }
 
 // DCS_PIPE_TRACE=2: what every pipeline thread did and when (tools/pipe_threads.py reads it from stderr)
+// internal flag: the pipeline's threads wait by polling inside the runtime (shortest latency) instead of napping
+static constexpr uint32_t kPipeLatency = 0x100u;
+
 static void pipeLog(const char *who, int id, const char *what, double t0, double t1, size_t q1 = 0, size_t q2 = 0)
 {
     static const bool on = getenv("DCS_PIPE_TRACE") != nullptr && atoi(getenv("DCS_PIPE_TRACE")) >= 2;
@@ -207,7 +211,7 @@ static DcsStatus pipelineUpload(DcsPipeline *p, DcsPipeline::Job *job, hipStream
 static void pipelineIndexer(DcsPipeline *p, int which)
 {
     pthread_setname_np(pthread_self(), "dcs-indexer");
-    tlsBlockingWaits = true;
+    tlsBlockingWaits = (p->flags & kPipeLatency) == 0;      // (the context's own pipeline serves ONE waiting caller: its threads poll)
     DcsCtx *ctx = p->ctx;
     (void)hipSetDevice(ctx->device);
     const hipStream_t stream = p->streams[static_cast<size_t>(p->nWorkers + which)];
@@ -225,6 +229,9 @@ static void pipelineIndexer(DcsPipeline *p, int which)
         {
             std::unique_lock<std::mutex> lk(p->m);
             p->indexWork.wait(lk, [&] { return p->quit || !p->toIndex.empty(); });
+            // (a caller that submits the parts of ONE list wants them in one round: wait a moment for the rest)
+            if (p->roundGather > 1 && !p->quit)
+                p->indexWork.wait_for(lk, std::chrono::microseconds(400), [&] { return p->quit || p->toIndex.size() >= p->roundGather; });
             if (p->quit && p->toIndex.empty())
             {
                 if (hTable) (void)hipHostFree(hTable);
@@ -510,7 +517,7 @@ static DcsStatus pipelineDecodePlanned(DcsPipeline *p, DcsPipeline::Job *job, hi
 static void pipelineWorker(DcsPipeline *p, int id)
 {
     pthread_setname_np(pthread_self(), "dcs-worker");
-    tlsBlockingWaits = true;
+    tlsBlockingWaits = (p->flags & kPipeLatency) == 0;      // (the context's own pipeline serves ONE waiting caller: its threads poll)
     (void)hipSetDevice(p->ctx->device);
     const hipStream_t stream = p->streams[id];
     const bool deviceIndex = (p->flags & DCS_PIPE_INDEX_ON_DEVICE) != 0;
@@ -551,7 +558,7 @@ static void pipelineWorker(DcsPipeline *p, int id)
                 job->tQueuedForIndex = nowMs();
                 p->toIndex.push_back(job);
             }
-            p->indexWork.notify_one();
+            p->indexWork.notify_all();
             continue;
         }
         DcsStatus st = job->status;             // (the indexer's)
@@ -581,10 +588,19 @@ static void pipelineWorker(DcsPipeline *p, int id)
     }
 }
 
+static DcsStatus pipelineCreate(DcsCtx *ctx, int depth, uint32_t flags, DcsPipeline **out);
+
 extern "C" DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth, uint32_t flags, DcsPipeline **out)
 {
-    if (ctx == nullptr || out == nullptr || depth < 1 || depth > 64 ||
-        (flags & ~(DCS_PIPE_INDEX_ON_DEVICE | DCS_PIPE_PACK_ON_DEVICE | DCS_PIPE_PLAN_ON_DEVICE)) != 0)
+    if ((flags & ~(DCS_PIPE_INDEX_ON_DEVICE | DCS_PIPE_PACK_ON_DEVICE | DCS_PIPE_PLAN_ON_DEVICE)) != 0)
+        return DCS_ERR_INVALID_ARG;
+    return pipelineCreate(ctx, depth, flags, out);
+}
+
+// (flags may carry kPipeLatency, which the public entry does not accept)
+static DcsStatus pipelineCreate(DcsCtx *ctx, int depth, uint32_t flags, DcsPipeline **out)
+{
+    if (ctx == nullptr || out == nullptr || depth < 1 || depth > 64)
         return DCS_ERR_INVALID_ARG;
     if (flags & DCS_PIPE_PLAN_ON_DEVICE)
         flags |= DCS_PIPE_PACK_ON_DEVICE;
@@ -762,17 +778,21 @@ DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint
     }
     if (first[nStreams] < 32768 || first[nStreams] > pcmCapFrames || first[nStreams] > 0xFFFFFFFFull)
         return DCS_OK;
+    const bool onDevice = ctx->largeListOnDevice;
     if (ctx->internalPipe == nullptr)
     {
-        const DcsStatus st = dcs_pipeline_create(ctx, static_cast<int>(kParts), 0, &ctx->internalPipe);
+        const DcsStatus st = pipelineCreate(ctx, static_cast<int>(kParts), (onDevice ? DCS_PIPE_ALL_ON_DEVICE : 0u) | kPipeLatency, &ctx->internalPipe);
         if (st != DCS_OK)
             return DCS_OK;                          // (no pipeline: the direct path still works)
+        if (onDevice)
+            ctx->internalPipe->roundGather = kParts;
     }
     *handled = true;
     // The parts taper: the call ends one part's latency (build, create, upload, kernel, download) after the index pass
     // has reached the list's last stream, so the last parts are small -- 4 4 4 4 3 2 2 1 twenty-fourths of the frames
     // (equal parts: 4.6 ms for 65 536 frames, of which 1.45 behind the index pass).
-    static const uint32_t kWeight[kParts] = { 4, 4, 4, 4, 3, 2, 2, 1 };
+    static const uint32_t kWeightHost[kParts] = { 4, 4, 4, 4, 3, 2, 2, 1 }, kWeightDevice[kParts] = { 3, 3, 3, 3, 3, 3, 3, 3 };
+    const uint32_t *kWeight = onDevice ? kWeightDevice : kWeightHost;
     uint32_t cut[kParts + 1];
     {
         uint32_t wSum = 0, wAcc = 0;
@@ -836,9 +856,24 @@ DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint
         }
     };
     const int idxThreads = 0;        // (all of the pool: leaving a quarter of the CPUs to the workers was measured, 6.8 against 5.8 ms)
-    st = dcsIndexStreamsNotify(streams, nStreams, idxThreads, recs, firstRecord.data(), infos.data(), &done);
-    if (st == DCS_OK)
-        st = static_cast<DcsStatus>(submitError.load());
+    if (onDevice)
+    {
+        // every part at once: index walk, planner, packer and decode on the device, the workers copy the PCM out
+        for (uint32_t r = 0 ; r < kParts && st == DCS_OK ; ++r)
+        {
+            const uint64_t f0 = first[cut[r]];
+            st = pipelineSubmit(ctx->internalPipe, streams + cut[r], cut[r + 1] - cut[r], extraFrames,
+                                pcmOut + f0 * DCS_FRAME_SAMPLES, errOut ? errOut + f0 : nullptr);
+            if (st == DCS_OK)
+                submitted.fetch_add(1);
+        }
+    }
+    else
+    {
+        st = dcsIndexStreamsNotify(streams, nStreams, idxThreads, recs, firstRecord.data(), infos.data(), &done);
+        if (st == DCS_OK)
+            st = static_cast<DcsStatus>(submitError.load());
+    }
     const double tI1 = nowMs();
     for (uint32_t r = 0, n = submitted.load() ; r < n ; ++r)
     {

@@ -29,6 +29,7 @@ struct DcsCtx
     uint32_t handoffTimeoutTicks = dcsk::kHandoffTimeoutTicks;     // 100 MHz ticks (dcs_ctx_set_test_hooks)
     bool dropExports = false;           // test hook: no chunk publishes its tail (dcs_ctx_set_test_hooks)
     int framesPerChunk = 0;             // diagnostic: frames a wavefront decodes (0 = as many as the kernel variant has slots)
+    bool largeListOnDevice = true;      // dcs_decode_streams on a large list: index walk, planner and packer on the device (dcs_ctx_set_large_list_path)
     std::mutex cacheMutex;              // the buffer cache is shared by the pipeline's worker threads
     struct DcsPipeline *internalPipe = nullptr;     // dcs_decode_streams takes large lists through it in parts (dcs_pipeline.hip.h)
     int numCUs = 256;
@@ -349,6 +350,19 @@ extern "C" DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable)
     if (ctx == nullptr)
         return DCS_ERR_INVALID_ARG;
     ctx->handoff = enable != 0;
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_ctx_set_large_list_path(DcsCtx *ctx, int onDevice)
+{
+    if (ctx == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    if (ctx->largeListOnDevice != (onDevice != 0) && ctx->internalPipe != nullptr)
+    {
+        dcs_pipeline_destroy(ctx->internalPipe);        // (made for the other path; the next large list makes its own)
+        ctx->internalPipe = nullptr;
+    }
+    ctx->largeListOnDevice = onDevice != 0;
     return DCS_OK;
 }
 

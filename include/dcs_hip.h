@@ -221,6 +221,11 @@ DcsStatus dcs_ctx_set_frames_per_chunk(DcsCtx *ctx, int frames);
  * after its own transform; 0: the predecessor is decoded a second time next to the successor (a "halo" slot).
  * Same PCM either way.  Applies to batches created afterwards. */
 DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable);
+/* tuning: how dcs_decode_streams takes a LARGE list (32 768 frames and more, 32 streams and more), which it cuts into
+ * eight parts that go through a pipeline of the context's own.  1 (default): index walk, planner and packer of every part
+ * on the device (DCS_PIPE_ALL_ON_DEVICE; 3.8 ms for 256 x 256 frames, ~2 CPU-ms); 0: the index pass on the host's worker
+ * pool with the parts following it (4.0-4.4 ms, ~45 CPU-ms on 16 threads).  Same PCM either way. */
+DcsStatus dcs_ctx_set_large_list_path(DcsCtx *ctx, int onDevice);
 
 /* One-shot convenience: host buffers in, host buffers out (H2D, kernel, D2H on the context's
  * stream, synchronous).  pcmOut = nJobs x 240 int16; errOut (optional) = nJobs x uint32 DCS_FRAME_*.

@@ -297,15 +297,25 @@ def test_pipeline_soak(gpu_ctx, mode):
     assert bad == 0
 
 
-def test_one_call_on_a_large_list_goes_through_the_pipeline_in_parts(gpu_ctx, oracle, corpus):
-    """dcs_decode_streams cuts a large list into eight parts that go through the context's own pipeline; same PCM, error
-    words and frame offsets as the one-batch path, including taper frames and a damaged stream in the middle"""
+@pytest.mark.parametrize("on_device", [True, False], ids=["parts-on-device", "parts-behind-host-index"])
+def test_one_call_on_a_large_list_goes_through_the_pipeline_in_parts(gpu_ctx, oracle, corpus, on_device):
+    """dcs_decode_streams cuts a large list into eight parts that go through the context's own pipeline -- index walk,
+    planner and packer on the device (the default), or behind the host pool's index pass (dcs_ctx_set_large_list_path);
+    same PCM, error words and frame offsets as the one-batch path, including taper frames, a damaged stream in the middle
+    and a truncated one (whose part the device stages hand back to the host's)"""
     from util import corrupt
     g, manifest, streams = corpus
     streams = list(streams[:200])
     k = 77
     streams[k] = (streams[k][0], corrupt(streams[k][1], 3, nflips=5) + bytes(2048), streams[k][2], streams[k][3])
-    pcm, err, first = gpu_ctx.decode_streams(streams, extra_frames=2)            # > 32 768 frames: in parts
+    k = 150
+    streams[k] = (streams[k][0], streams[k][1][:len(streams[k][1]) // 2], streams[k][2], streams[k][3])
+    gpu_ctx.set_large_list_path(on_device)
+    try:
+        for _ in range(2):                                                       # (the second call finds the pipeline made)
+            pcm, err, first = gpu_ctx.decode_streams(streams, extra_frames=2)    # > 32 768 frames: in parts
+    finally:
+        gpu_ctx.set_large_list_path(True)
     b = D.build_stream_batch(streams, extra_frames=2, indexer=D.index_streams)
     want, werr = gpu_ctx.decode_batch(b["blob"], b["srcs"], b["jobs"])           # one batch, one launch
     assert np.array_equal(first, b["first_job"])
