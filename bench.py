@@ -180,8 +180,9 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
     samples = n_frames * 240
     return {"unit": "samples/s", "frames_per_list": n_frames,
             "cold": {"value": samples / cold_s, "ms_per_list": cold_s * 1e3,
-                     "what": "dcs_decode_streams, one synchronous call per list into pageable memory (median of nine calls): index + parameters + plan + pack + "
-                             "H2D + kernel + D2H (a list this large goes through the context's own pipeline in eight parts)"},
+                     "what": "dcs_decode_streams, one synchronous call per list into pageable memory (median of nine calls): H2D + index + plan + pack + "
+                             "kernel + D2H + copy out (a list this large goes through the context's own pipeline in eight parts, index walk, planner and "
+                             "packer on the device)"},
             "sustained": dict(best, what="dcs_pipeline, the fastest of the four configurations below: lists in flight, PCM "
                                          "returned in pinned memory, collected in submission order"),
             "sustained_host_index": host_idx, "sustained_device_index": dev_idx, "sustained_device_index_and_pack": dev_pack,

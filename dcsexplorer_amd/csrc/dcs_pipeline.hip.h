@@ -200,7 +200,7 @@ static DcsStatus pipelineUpload(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     }
     const double tu2 = nowMs();
     HIPCHK(ctx, hipEventCreateWithFlags(&job->uploaded, hipEventDisableTiming));
-    HIPCHK(ctx, hipMemcpyAsync(job->dBlob, job->hBlob, job->hBlobCap, hipMemcpyHostToDevice, stream));
+    HIPCHK(ctx, copyByKernel(stream, job->dBlob, job->hBlob, job->hBlobCap));
     HIPCHK(ctx, hipEventRecord(job->uploaded, stream));
     if (getenv("DCS_PIPE_TRACE"))
         fprintf(stderr, "pipe upload: allocs %.2f, memcpy %.2f, hip calls %.2f\n", tu1 - tu0, tu2 - tu1, nowMs() - tu2);
@@ -280,7 +280,7 @@ static void pipelineIndexer(DcsPipeline *p, int which)
                 }
             for (const DcsPipeline::JobPtr &j : jobs)
                 HIPCHK(ctx, hipStreamWaitEvent(stream, j->uploaded, 0));
-            HIPCHK(ctx, hipMemcpyAsync(dTable, hTable, tableBytes, hipMemcpyHostToDevice, stream));
+            HIPCHK(ctx, copyByKernel(stream, dTable, hTable, tableBytes));
             HIPCHK(ctx, launchIndexWave(stream, 0, static_cast<const DcsStreamLoc *>(dTable), nStreams, ctx->dTables, nullptr, nullptr, nullptr,
                                         reinterpret_cast<const dcsidx::StreamOut *>(static_cast<const uint8_t *>(dTable) + locBytes)));
             for (const DcsPipeline::JobPtr &j : jobs)
@@ -383,6 +383,7 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
         static const bool splitWait = getenv("DCS_PIPE_TRACE") != nullptr && atoi(getenv("DCS_PIPE_TRACE")) >= 3;
         if (st == DCS_OK && splitWait) st = dcs_batch_sync(job->batch);
         const double tk1 = nowMs();
+        if (st == DCS_OK) job->batch->downByKernel = (p->flags & kPipeLatency) != 0;
         if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
         pipeLog("worker", 0, "kernels", tk0, tk1);
         pipeLog("worker", 0, "download", tk1, nowMs());
@@ -481,6 +482,7 @@ static DcsStatus pipelineDecodePlanned(DcsPipeline *p, DcsPipeline::Job *job, hi
     if (st == DCS_OK) st = batchQueuePlanFlag(job->batch);
     const double t2 = nowMs();
     pipeLog("worker", 0, "run-queue", t1, t2);
+    if (st == DCS_OK) job->batch->downByKernel = (p->flags & kPipeLatency) != 0;
     if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
     pipeLog("worker", 0, "download", t2, nowMs());
     bool lost = false;

@@ -156,6 +156,39 @@ static hipError_t streamWait(DcsCtx *ctx, hipStream_t stream)
     }
 }
 
+// A copy between pinned host memory and device memory done by a kernel on `stream` (both sides are device-visible
+// addresses; 4-byte granularity).  The pipeline's small uploads go this way: hipMemcpyAsync from pinned memory now and then
+// holds the CALLING thread for ~7 ms -- several threads at once, released together -- which a launch has not been seen to
+// do (DCS_HIP_SLOW, tools/cold_trace.py; profiles/NOTES.md item 17).  The PCM's way down stays with the copy engines.
+namespace {
+__global__ __launch_bounds__(256) void dcsCopyKernel(uint32_t *dst, const uint32_t *src, size_t nDw)
+{
+    const size_t n4 = nDw / 4, stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0)
+    {
+        for (size_t i = t ; i < n4 ; i += stride)
+            reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+        for (size_t i = n4 * 4 + t ; i < nDw ; i += stride)
+            dst[i] = src[i];
+    }
+    else
+        for (size_t i = t ; i < nDw ; i += stride)
+            dst[i] = src[i];
+}
+}   // namespace
+static hipError_t copyByKernel(hipStream_t stream, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0)
+        return hipSuccess;
+    if ((bytes & 3u) != 0 || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 3u) != 0)
+        return hipErrorInvalidValue;
+    const size_t nDw = bytes / 4;
+    const unsigned blocks = static_cast<unsigned>(std::min<size_t>((nDw / 4 + 255) / 256 + 1, 1024));
+    hipLaunchKernelGGL(dcsCopyKernel, dim3(blocks), dim3(256), 0, stream, static_cast<uint32_t *>(dst), static_cast<const uint32_t *>(src), nDw);
+    return hipGetLastError();
+}
+
 struct DcsBatch
 {
     DcsCtx *ctx = nullptr;
@@ -192,6 +225,7 @@ struct DcsBatch
     // against the context's non-blocking one): sync, download, download_view and destroy wait for it
     hipEvent_t evDone = nullptr;
     bool launched = false;
+    bool downByKernel = false;  // the PCM's way down by dcsCopyKernel instead of the copy engines (the context's own pipeline: one waiting caller)
     bool settled = false;       // a wait has covered everything enqueued for this batch and nothing was enqueued since
 };
 
@@ -222,7 +256,7 @@ static const double g_hipSlowUs = getenv("DCS_HIP_SLOW") ? atof(getenv("DCS_HIP_
         const double t_ = g_hipSlowUs > 0 ? hipchkNow() : 0.0;                                   \
         hipError_t e_ = (call);                                                                  \
         if (g_hipSlowUs > 0 && hipchkNow() - t_ > g_hipSlowUs)                                   \
-            fprintf(stderr, "slow hip call: %.0f us %s\n", hipchkNow() - t_, #call);             \
+            fprintf(stderr, "slow hip call: %.0f us %s [from %.3f ms]\n", hipchkNow() - t_, #call, t_ * 1e-3);  \
         if (e_ != hipSuccess) {                                                                  \
             char buf_[256];                                                                      \
             snprintf(buf_, sizeof(buf_), "%s failed: %s", #call, hipGetErrorString(e_));         \
@@ -894,9 +928,9 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
         memcpy(stage, slots.data(), b->planSlotsCap);
         if (nSrcs)
             memcpy(static_cast<uint8_t *>(stage) + b->planSlotsCap, srcs, sizeof(DcsPlanSrc) * nSrcs);
-        HIPCHK(ctx, hipMemcpyAsync(b->dPlanSlots, stage, b->planSlotsCap, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(ctx, copyByKernel(b->stream, b->dPlanSlots, stage, b->planSlotsCap));
         if (nSrcs)
-            HIPCHK(ctx, hipMemcpyAsync(b->dPlanSrcs, static_cast<uint8_t *>(stage) + b->planSlotsCap, sizeof(DcsPlanSrc) * nSrcs, hipMemcpyHostToDevice, b->stream));
+            HIPCHK(ctx, copyByKernel(b->stream, b->dPlanSrcs, static_cast<uint8_t *>(stage) + b->planSlotsCap, sizeof(DcsPlanSrc) * nSrcs));
         b->cap[9] = pkgBytes; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPackages), b->cap[9]));
         HIPCHK(ctx, hipMemsetAsync(b->dPackages, 0, pkgBytes, b->stream));
         const uint32_t blocks = (b->nChunks + 3) / 4;
@@ -974,7 +1008,7 @@ static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *ta
         b->cap[2] = tableBytes;
         HIPCHK(ctx, cacheAlloc(ctx, false, &dTable, tableBytes));
         b->dTable = dTable;
-        HIPCHK(ctx, hipMemcpyAsync(dTable, static_cast<uint8_t *>(b->hStage) + 16, tableBytes, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(ctx, copyByKernel(b->stream, dTable, static_cast<uint8_t *>(b->hStage) + 16, tableBytes));
         b->cap[9] = pkgBytes; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPackages), b->cap[9]));
         HIPCHK(ctx, hipMemsetAsync(b->dPackages, 0, pkgBytes, b->stream));
         b->cap[4] = sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPcm), b->cap[4]));
@@ -1026,7 +1060,7 @@ static DcsStatus batchQueuePlanFlag(DcsBatch *b)
 {
     const uint32_t *flagWord = reinterpret_cast<const uint32_t *>(b->dHandoff + static_cast<size_t>(b->nChunks) * 16) + 2;
     b->settled = false;
-    HIPCHK(b->ctx, hipMemcpyAsync(b->hStage, flagWord, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(b->ctx, copyByKernel(b->stream, b->hStage, flagWord, sizeof(uint32_t)));
     return DCS_OK;
 }
 static uint32_t batchPlanFlag(const DcsBatch *b) { return *static_cast<const volatile uint32_t *>(b->hStage); }
@@ -1246,9 +1280,18 @@ extern "C" DcsStatus dcs_batch_download_view(DcsBatch *b, const int16_t **pcmOut
     }
     if (b->launched)
         HIPCHK(ctx, hipStreamWaitEvent(b->stream, b->evDone, 0));      // the copies follow the last launch, whatever stream it ran on
-    HIPCHK(ctx, hipMemcpyAsync(b->hPcm, b->dPcm, pcmBytes, hipMemcpyDeviceToHost, b->stream));
-    if (errOut != nullptr)
-        HIPCHK(ctx, hipMemcpyAsync(b->hErr, b->dErr, errBytes, hipMemcpyDeviceToHost, b->stream));
+    if (b->downByKernel)
+    {
+        HIPCHK(ctx, copyByKernel(b->stream, b->hPcm, b->dPcm, pcmBytes));
+        if (errOut != nullptr)
+            HIPCHK(ctx, copyByKernel(b->stream, b->hErr, b->dErr, errBytes));
+    }
+    else
+    {
+        HIPCHK(ctx, hipMemcpyAsync(b->hPcm, b->dPcm, pcmBytes, hipMemcpyDeviceToHost, b->stream));
+        if (errOut != nullptr)
+            HIPCHK(ctx, hipMemcpyAsync(b->hErr, b->dErr, errBytes, hipMemcpyDeviceToHost, b->stream));
+    }
     HIPCHK(ctx, streamWait(b->ctx, b->stream));
     b->settled = true;          // (uploads and pack kernels ran on b->stream before, the launches are behind evDone)
     *pcmOut = b->hPcm;
