@@ -5,7 +5,7 @@
 // The reference decodes its batch job (`--extract-streams`, DCSExplorer.cpp:1742-1907) one stream after the other on
 // one thread; here a caller submits lists of whole streams and collects their PCM in submission order.
 //
-// Two shapes, chosen at creation:
+// Shapes, chosen at creation:
 //   index pass on the host pool (default): `depth` worker threads each take a submitted list through all its stages on
 //     a HIP stream of their own, so the stages of different lists overlap by themselves.
 //   index pass on the device (DCS_PIPE_INDEX_ON_DEVICE): the index pass is most of a list's host work (tools/hostbench.cpp:
@@ -17,6 +17,11 @@
 //   ... and the packer on the device too (DCS_PIPE_PACK_ON_DEVICE): the records do not come back at all.  The indexer
 //     copies back an 8-byte digest per frame (bit offset, bit count, band count, flags), the worker plans from that, and
 //     a pack kernel assembles the packages from the records and streams that are already resident.
+//   ... and the planner (DCS_PIPE_PLAN_ON_DEVICE): nothing of the index results comes back.  A list of whole streams has a
+//     regular job list, so one thread per chunk works the chunk plan out (dcsPlanKernel); a worker queues planner, packer,
+//     decode kernel and the copy down behind the indexers' round and sleeps until the PCM is there.  Lists the arithmetic
+//     plan cannot serve are decoded by the host-planned path (DcsPipelineResult.path).
+// The context keeps a pipeline of its own for dcs_decode_streams on a large list (dcsDecodeStreamsInParts below).
 #pragma once
 #include <condition_variable>
 #include <deque>
@@ -625,8 +630,9 @@ static DcsStatus pipelineCreate(DcsCtx *ctx, int depth, uint32_t flags, DcsPipel
     // list in flight: as many as the host has cores, and a few more for the ones that wait for a copy.  With the packer on
     // the device as well a list costs a worker under a millisecond of its own work, and what more workers add is contention
     // inside the HIP runtime: measured with 32 lists in flight on 16 CPUs, 4 to 6 workers 1.65-1.95 ms per list at 7-9 CPU-ms,
-    // 10 workers 1.8-2.4, 20 workers 2.1-2.5 at 18-22 CPU-ms (tools/pipe_trace.py)
-    // planner on the device too: a worker spends a third of a millisecond on a list and then sleeps until its PCM is down
+    // 10 workers 1.8-2.4, 20 workers 2.1-2.5 at 18-22 CPU-ms (tools/pipe_trace.py, round 2).  Planner on the device too: a
+    // worker spends a third of a millisecond on a list and then sleeps until its PCM is down; 0.70-0.77 ms per list with 6,
+    // 8, 12, 16 or 24 of them (round 3: the link is what bounds it)
     int nWorkers = (flags & DCS_PIPE_PLAN_ON_DEVICE)  ? std::min(depth, 8)
                  : (flags & DCS_PIPE_PACK_ON_DEVICE)  ? std::min(depth, std::max(4, dcs_host_threads() / 3))
                  : (flags & DCS_PIPE_INDEX_ON_DEVICE) ? std::min(depth, dcs_host_threads() + 4) : depth;
