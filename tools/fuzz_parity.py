@@ -15,7 +15,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 orc = Oracle()
 ctx = D.Context(0)
-t0 = t_said = time.time(); lists = frames = mixes = piped = 0; seed = seed0
+t0 = t_said = time.time(); lists = frames = mixes = piped = large = 0; seed = seed0
 pipes = [ctx.pipeline(3, index_on_device=m >= 1, pack_on_device=m >= 2, plan_on_device=m == 3) for m in range(4)]
 by_fmt = {f: 0 for f in ALL_FORMATS}
 while time.time() - t0 < budget:
@@ -103,11 +103,38 @@ while time.time() - t0 < budget:
                 print("MISMATCH (mix of %d) seed %d fpw %d: %d samples in %d frames, first frame %d" % (nch, seed, fpw, len(bad), len(set(bad[:, 0])), bad[0][0]))
                 sys.exit(1)
         mixes += 1; frames += n_out
+    # every 64th seed a LARGE list (40 streams of 820..900 frames: over 32 768 frames), which dcs_decode_streams cuts into
+    # parts that go through the context's own pipeline -- with the parts' index walk, planner and packer on the device, and
+    # behind the host pool's index pass -- against the oracle
+    if seed % 64 == 0:
+        ctx.set_frames_per_wave(0)
+        big, bwant = [], []
+        for k in range(40):
+            fmt = ALL_FORMATS[next(g) % 6]
+            s = make_stream(fmt, 820 + next(g) % 81, seed=(seed << 8) + 200 + k, profile=next(g) % 4)
+            if next(g) % 16 == 0:
+                s = corrupt(s, next(g) & 0xFFFF, nflips=2) + bytes(256)
+            elif next(g) % 16 == 1:
+                s = s[:18 + (len(s) - 18) // 2]
+            os_ = os_for(fmt, next(g) & 1)
+            big.append((os_, s, 128 + next(g) % 128, 0x20 + next(g) % 0x60))
+        try:
+            bwant = np.concatenate([orc.decode(o, v, [s], [l], ((s[0] << 8) | s[1]) + 2) for o, s, v, l in big])
+        except Exception as e:
+            bwant = None
+        if bwant is not None:
+            for on_device in (True, False):
+                ctx.set_large_list_path(on_device)
+                pcm, err, _ = ctx.decode_streams(big, extra_frames=2)
+                if pcm.shape != bwant.shape or not np.array_equal(pcm, bwant):
+                    print("MISMATCH (large list, parts %s) seed %d" % ("on the device" if on_device else "behind the host index", seed)); sys.exit(1)
+            ctx.set_large_list_path(True)
+            large += 1
     seed += 1
     if time.time() - t_said > 30:               # (a line now and then: a silent command is taken to be hung)
         t_said = time.time()
         print("  ... %d lists, %d mixes, %.0f s" % (lists, mixes, t_said - t0), flush=True)
 for pipe in pipes:
     pipe.close()
-print("fuzz: %d lists (%d of them also through the pipeline's four modes) and %d multi-channel mixes (%d frames x 3 kernel variants) in %.0f s, seeds %d..%d, all bit-exact; streams by layout: %s" %
-      (lists, piped, mixes, frames, time.time() - t0, seed0, seed - 1, {FORMAT_NAMES[f]: n for f, n in by_fmt.items()}))
+print("fuzz: %d lists (%d of them also through the pipeline's four modes), %d large lists through dcs_decode_streams' two paths and %d multi-channel mixes (%d frames x 3 kernel variants) in %.0f s, seeds %d..%d, all bit-exact; streams by layout: %s" %
+      (lists, piped, large, mixes, frames, time.time() - t0, seed0, seed - 1, {FORMAT_NAMES[f]: n for f, n in by_fmt.items()}))
