@@ -320,6 +320,8 @@ __device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *book, uint32
         const uint32_t w = b.gather32(b.lane);
         const uint32_t e = book[w >> (32 - maxBits)];
         const uint32_t m = multi[w >> (32 - DCS_IDX_MULTI_BITS)];
+        asm volatile("" :: "v"(e), "v"(m));         // both reads on their way before anything waits (the compiler otherwise
+                                                    // sinks the second one behind the test of `rem`: a second LDS round trip)
         const uint32_t vSingle = ((e >> 8) & 0x1Fu) - ((e >> 13) == 2 ? 0x20000u : 0x10000u);
         const uint32_t vMulti = (m & 15u) - ((m >> 4) << 16);
         // state: bits walked | samples left - 1 (single) or - 1 - DCS_IDX_MULTI_SAMPLES (multi) << 16.  A chain ends when
@@ -433,6 +435,7 @@ __device__ void scan94(Walk &s)
     IDX_T0(tHdr);
     const uint32_t vDelta = headerDeltas94(s);
     IDX_ACC(b, 1, tHdr);
+    IDX_T0(tSetup);
     if (static_cast<int>(lane) < s.nBands)
         s.vBandType = (s.vBandType + vDelta - 16u) & 0xFFFFu;
     const uint32_t hdrBits = b.pos - frameStart;
@@ -467,6 +470,8 @@ __device__ void scan94(Walk &s)
     uint32_t vHuffBefore = 0;                                   // lane b: bits of the Huffman-coded bands before band b
     uint32_t huffBits = 0, midBit = 0, midIdx = 0;
     const uint32_t base = frameStart + hdrBits;
+    IDX_ACC(b, 9, tSetup);
+    IDX_T0(tLoop);
     for (uint32_t left = static_cast<uint32_t>(__ballot(huffBand)) ; left != 0 ; left &= left - 1)
     {
         const uint32_t h = static_cast<uint32_t>(__builtin_ctz(left));
@@ -497,6 +502,8 @@ __device__ void scan94(Walk &s)
         huffBits += len;
         vHuffBefore += lane > h ? len : 0u;
     }
+    IDX_ACC(b, 10, tLoop);
+    IDX_T0(tTail);
     b.pos = base + rl(fixedIncl, 15) + huffBits;
     b.have = 0;
     // the fixed-width bands' looks: the last one's reaches furthest, exactly to its end
@@ -527,6 +534,7 @@ __device__ void scan94(Walk &s)
     s.vSplitHi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(hiw), 0x101, 0xF, 0xF, true));
     if (fatalBands != 0)
         s.fatal();
+    IDX_ACC(b, 11, tTail);
 }
 
 // --- 1993 frame, Type 0 and OS93b Type 1 (:2293-2615; dcsScan93) ------------------------------------------------------

@@ -13,10 +13,10 @@ out = (ctypes.c_ulonglong * 12)()
 ctx.L.dcs_debug_index_stamps(out)
 ctx.index_streams_gpu(streams)
 ctx.L.dcs_debug_index_stamps(out)
-names = ["walk", "header deltas", "huffRun", "  its chains", "record out", "slides", "runs", "symbols", "frames", "-", "-", "-"]
+names = ["walk", "header deltas", "huffRun", "  its chains", "record out", "slides", "runs", "symbols", "frames", "94: set-up", "94: band loop", "94: tail"]
 fr = max(out[8], 1)
 print("%s: %d streams, %d frames; kernel %.2f ms" % (which, len(streams), out[8], ctx.index_gpu_time(3)))
-for k in range(9):
+for k in range(12):
     print("  %-14s %12d  %9.1f per frame" % (names[k], out[k], out[k] / fr))
 if out[6]:
     print("  per run: %.0f cycles, %.1f symbols; per symbol of chain: %.1f cycles" % (out[2] / out[6], out[7] / out[6], out[3] / max(out[7], 1)))
