@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the batched DCS frame decode on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dcs94_65536|dcs93_4096|mixed_16384|corpus]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload survey3_65536|dcs94_65536|dcs93_4096|mixed_16384|realistic_65536|corpus]
 
 One "step" = one pass of the hot path (one kernel launch) over one resident batch of synthetic frames.
 Metric (BASELINE.json): bit-exact int16 PCM samples/s; value = samples of all ranks / max-over-ranks time.
@@ -11,7 +11,7 @@ starts the N ranks itself (python -m torch.distributed.run ... bench.py, rendezv
 JSON line; started BY torch.distributed.run it is one of the ranks.  Ranks never exchange frame data (streams are the
 independent units of the path): torch.distributed (RCCL) carries the barrier around the timed region and the max of the
 times, nothing else.
-  * dcs94_65536 / dcs93_4096 / mixed_16384: every rank decodes its own range of the seeded stream corpus, same shape per
+  * survey3_65536 / dcs94_65536 / dcs93_4096 / mixed_16384: every rank decodes its own range of the seeded stream corpus, same shape per
     rank -> "scaling": "weak".
   * corpus (BASELINE configs[4] stand-in): ONE ragged corpus (titles x streams of U[20, 2000] frames, six layouts), cut
     into N contiguous stream ranges balanced by total frame count (dcs_partition_streams) -> "scaling": "strong".
@@ -35,7 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-DEFAULT_WORKLOAD = "dcs94_65536"  # BASELINE.json configs[2]: the configuration the roofline is quoted on
+DEFAULT_WORKLOAD = "survey3_65536"  # BASELINE.json configs[2] as SURVEY.md 8(d) specifies it (12 bands, 120 B/frame): the configuration the roofline is quoted on
+PREVIOUS_DEFAULT = "dcs94_65536"   # rounds 1 and 2 quoted configs[2] on this one (16 bands, 96 B/frame): still reported, as third_workload
 
 
 def parse_args(argv=None):
@@ -194,8 +195,8 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
 
 
 def second_workload(ctx, args, torch, name="realistic_65536"):
-    """The default workload's streams come from the seeded writer at ~96 B/frame; what the reference's ENCODER makes of audio is
-    denser in places and half of it is 1993-layout (256-point transform).  The same 256 x 256 frames of encoder-made streams
+    """The default workload's streams come from the seeded writer; what the reference's ENCODER makes of audio has other band
+    statistics and half of it is 1993-layout (256-point transform).  The same 256 x 256 frames of encoder-made streams
     (tests/golden/encoder_golden.npz, reference hashes committed) are therefore timed next to it with the same procedure: K
     launches between synchronisations, and the kernel alone by HIP events."""
     import dcsexplorer_amd as D
@@ -215,13 +216,18 @@ def second_workload(ctx, args, torch, name="realistic_65536"):
     dt = time.perf_counter() - t0
     kern_ms = sorted(batch.time(max(10, args.steps), stream) for _ in range(3))[1]
     pcm, err = batch.download()
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_golden.json")))["workloads"][name]["stream_hashes"]
+    gold_file = "encoder_golden.json" if name == "realistic_65536" else "dcs_golden_hashes.json"
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", gold_file)))["workloads"][name]["stream_hashes"]
     orc = Oracle()
     first = b["first_job"]
     got = ["%016x" % orc.fnv1a64(pcm[first[k]:first[k + 1]]) for k in range(len(first) - 1)]
     achieved = batch.algorithmic_bytes / (kern_ms * 1e-3) / 1e9
-    out = {"workload": name, "what": "256 streams x 256 frames made by the reference's own encoder (six layouts, 57-102 B/frame, 14 of 16 bands "
-                                     "coded); same steps, same timing procedure as `value`",
+    what = {"realistic_65536": "256 streams x 256 frames made by the reference's own encoder (six layouts, 57-102 B/frame, 14 of 16 bands "
+                               "coded); same steps, same timing procedure as `value`",
+            "dcs94_65536": "the configs[2] workload of rounds 1 and 2: the same 256 x 256 1994+ frames and layout mix with 16 populated bands "
+                           "at 96 B/frame (the default follows SURVEY.md section 8(d) Config 3: 12 bands, 120 B/frame); same steps, same timing "
+                           "procedure as `value`"}[name]
+    out = {"workload": name, "what": what,
            "value": n_frames * 240 * args.steps / dt, "unit": "samples/s", "ms_per_step": dt / args.steps * 1e3, "frames_per_step": n_frames,
            "kernel_avg_ms": kern_ms, "frames_per_wave": batch.frames_per_wave,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -511,7 +517,11 @@ def run_rank(args):
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
-            "config": {"workload": args.workload, "frames_rank0_per_step": n_frames, "frames_all_ranks_per_step": total_frames,
+            "config": {"workload": args.workload,
+                       "workload_is": {"survey3_65536": "BASELINE configs[2] as SURVEY.md 8(d) Config 3 specifies it: 256 streams x 256 1994+ frames, 80 % Type 1 "
+                                                        "sub-type 3, 10 % Type 1 sub-type 0, 10 % Type 0, 12 populated bands, 120 B/frame",
+                                       "dcs94_65536": "BASELINE configs[2], the form of rounds 1 and 2: 16 populated bands, 96 B/frame"}.get(args.workload, args.workload),
+                       "frames_rank0_per_step": n_frames, "frames_all_ranks_per_step": total_frames,
                        "samples_per_frame": 240, "frames_per_wave": batch.frames_per_wave, "wavefronts_per_launch": batch.num_chunks,
                        "arithmetic": "ADSP-2105 1.15 fixed point, 32-bit integer intermediates",
                        "partition": "range over streams%s, no collective" % (", balanced by frames" if corpus else ""),
@@ -532,6 +542,7 @@ def run_rank(args):
             out["config"]["rank0_stream_range"] = [golden_range[1], golden_range[2]]
         if world == 1 and args.workload == DEFAULT_WORKLOAD and not args.no_second_workload and args.scale == 1:
             out["second_workload"] = second_workload(ctx, args, torch)
+            out["third_workload"] = second_workload(ctx, args, torch, name=PREVIOUS_DEFAULT)
         if world == 1 and not args.no_end_to_end:
             out["end_to_end"] = end_to_end(ctx, streams, n_frames, depth=args.e2e_depth, dev_depth=args.e2e_device_depth)
         if e2e_ranks is not None:

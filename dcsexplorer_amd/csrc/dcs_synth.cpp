@@ -102,14 +102,14 @@ void synth94(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
         int sc;
         if (type1)
         {
-            typical[b] = P.profile == 4 ? 15 : P.profile == 1 ? rng.range(6, 10) : P.profile == 2 ? rng.range(0, 4) : rng.range(2, 8);
+            typical[b] = P.profile == 5 ? rng.range(12, 15) : P.profile == 4 ? 15 : P.profile == 1 ? rng.range(6, 10) : P.profile == 2 ? rng.range(0, 4) : rng.range(2, 8);
             cap[b] = P.profile >= 3 ? 15 : 11;
             sc = (rng.range(1, 3) << 2) | rng.range(0, 3);
         }
         else
         {
-            typical[b] = P.profile == 4 ? 16 : P.profile == 1 ? rng.range(5, 9) : P.profile == 2 ? rng.range(0, 3) : rng.range(2, 6);
-            cap[b] = P.profile >= 3 ? 16 : 10;
+            typical[b] = P.profile == 5 ? rng.range(5, 8) : P.profile == 4 ? 16 : P.profile == 1 ? rng.range(5, 9) : P.profile == 2 ? rng.range(0, 3) : rng.range(2, 6);
+            cap[b] = P.profile == 5 ? 10 : P.profile >= 3 ? 16 : 10;
             sc = (clampi(11 - typical[b], 2, 10) << 2) | rng.range(0, 3);
         }
         hdr[b] = static_cast<uint8_t>(sc | (b >= P.strideFromBand ? 0x40 : 0));
@@ -136,7 +136,18 @@ void synth94(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
         {
             int target = code[b];
             uint32_t r = rng.below(100);
-            if (f == 0 || r >= 70)
+            if (P.profile == 5)
+            {
+                // SURVEY config 3: band-type deltas 0 : 70 %, +-1 : 20 %, +-2 : 8 %, anything : 2 %, clamped to the layout's range;
+                // the sign leans towards the band's typical code, which keeps the density near the encoder's ~120 bytes a frame
+                const int towards = target < typical[b] ? 1 : -1;
+                const int sign = rng.chance(65) ? towards : -towards;
+                if (f == 0) target = typical[b] + rng.range(-1, 1);
+                else if (r >= 98) target = rng.range(0, cap[b]);
+                else if (r >= 90) target += 2 * sign;
+                else if (r >= 70) target += sign;
+            }
+            else if (f == 0 || r >= 70)
             {
                 if (f == 0 || r >= 98) target = rng.range(0, cap[b]);
                 else if (r < 90) target += (rng.next() & 1) ? 1 : -1;
@@ -170,7 +181,7 @@ void synth94(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
                 const int ref = 1 << (c - 1);
                 for (int i = count ; i > 0 ; )
                 {
-                    if (i >= 2 && rng.chance(P.profile == 2 ? 30 : 12))
+                    if (i >= 2 && rng.chance(P.profile == 2 ? 30 : P.profile == 5 ? 9 : 12))
                     {
                         putSample94(w, c, 0x80);        // two zeros
                         i -= 2;
@@ -178,7 +189,9 @@ void synth94(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
                     else
                     {
                         int v = clampi(rng.smallSigned(ref), -ref, ref - 1);
-                        if (P.profile >= 3) v = rng.range(-ref, ref - 1);
+                        if (P.profile == 3 || P.profile == 4) v = rng.range(-ref, ref - 1);
+                        if (P.profile == 5)             // (with the two-zeros codes a quarter of the values are zero, the others uniform)
+                            v = rng.chance(9) ? 0 : rng.range(-ref, ref - 1);
                         putSample94(w, c, v + ref);
                         --i;
                     }
@@ -189,8 +202,8 @@ void synth94(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
                 const int lim = 1 << (c - 1);
                 for (int i = 0 ; i < count ; ++i)
                 {
-                    int v = (P.profile >= 3 || rng.chance(10)) ? rng.range(-lim, lim - 1)
-                                                               : clampi(rng.smallSigned(lim), -lim, lim - 1);
+                    int v = (P.profile == 3 || P.profile == 4 || rng.chance(10)) ? rng.range(-lim, lim - 1)
+                                                                                  : clampi(rng.smallSigned(lim), -lim, lim - 1);
                     w.putSigned(v, c);
                 }
             }

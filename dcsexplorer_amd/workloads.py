@@ -5,6 +5,9 @@ derived from integer seeds so the GPU box regenerates byte-identical inputs.
   dcs93_4096     configs[1]: 4096 DCS-93 frames = 64 streams x 64 frames, OS93 Type 0
   dcs94_65536    configs[2]: 65536 1994+ ("DCS-95 format") frames = 256 streams x 256 frames,
                  80 % Type 1 sub-type 3, 10 % Type 1 sub-type 0, 10 % Type 0
+  survey3_65536  configs[2] to the letter of SURVEY.md section 8(d), Config 3: the same 256 x 256 frames and layout mix with
+                 12 populated bands, band-type deltas 0 / +-1 / +-2 / other at 70 / 20 / 8 / 2 %, a quarter of the
+                 Huffman-coded values zero, 120 bytes a frame (synth profile 5); dcs94_65536 has 16 bands at 96
   mixed_16384    configs[3]: 128 streams x 128 frames over all six unpack layouts, frames interleaved
                  so that neighbouring frames of the batch alternate formats
   realistic_65536  (not a BASELINE config) 256 x 256 frames of streams made by the reference's own encoder
@@ -43,6 +46,16 @@ def streams_dcs94_65536(n_streams=256, n_frames=256, first=0):
         fmt = D.FMT_94_T0 if m == 0 else D.FMT_94_T1_S0 if m == 1 else D.FMT_94_T1_S3
         s = D.synth_stream(fmt, n_frames, seed=0x94000003 + k, nbands=16, stride_from=16 if (k % 7) else 12,
                            profile=0)
+        out.append((D.OS95 if (k & 1) else D.OS94, s, 220, 0x64))
+    return out
+
+
+def streams_survey3_65536(n_streams=256, n_frames=256, first=0):
+    out = []
+    for k in range(first, first + n_streams):
+        m = k % 10
+        fmt = D.FMT_94_T0 if m == 0 else D.FMT_94_T1_S0 if m == 1 else D.FMT_94_T1_S3
+        s = D.synth_stream(fmt, n_frames, seed=0x94000003 + k, nbands=12, stride_from=16, profile=5)
         out.append((D.OS95 if (k & 1) else D.OS94, s, 220, 0x64))
     return out
 
@@ -184,6 +197,7 @@ WORKLOADS = {
     "layout_4": lambda **kw: streams_one_layout(4, **kw), "layout_5": lambda **kw: streams_one_layout(5, **kw),
     "dcs93_4096": streams_dcs93_4096,
     "dcs94_65536": streams_dcs94_65536,
+    "survey3_65536": streams_survey3_65536,
     "mixed_16384": streams_mixed_16384,
     "realistic_65536": streams_realistic_65536,
 }

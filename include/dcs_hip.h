@@ -581,7 +581,10 @@ typedef struct DcsSynthParams
     int32_t  profile;                  /* 0 = default mix, 1 = dense (wide codes), 2 = sparse (many zero
                                           bands), 3 = adversarial edge cases (max widths, deep codes),
                                           4 = saturated (every band at its widest code in every frame:
-                                          the largest frames the formats can express, ~500 bytes)         */
+                                          the largest frames the formats can express, ~500 bytes),
+                                          5 = SURVEY config 3 (1994+ layouts: band-type deltas 0 / +-1 / +-2 /
+                                          other at 70 / 20 / 8 / 2 %, a quarter of the Huffman-coded values
+                                          zero, ~120 bytes a frame with 12 bands; other layouts as 0)       */
     int32_t  reserved;
 } DcsSynthParams;
 

@@ -85,7 +85,7 @@ def main():
 
     # hashes of the full-size seeded workloads (each stream decoded alone by the reference)
     hashes = {}
-    for wl in ("dcs93_4096", "dcs94_65536", "mixed_16384"):
+    for wl in ("dcs93_4096", "dcs94_65536", "mixed_16384", "survey3_65536"):
         streams = workloads.WORKLOADS[wl]()
         h = 0xcbf29ce484222325
         per_stream = []

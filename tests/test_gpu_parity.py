@@ -212,7 +212,7 @@ def test_multichannel_mix(gpu_ctx, oracle):
         assert_same(pcm, arrays[case["name"] + "/pcm"], case["name"])
 
 
-@pytest.mark.parametrize("wl", ["dcs93_4096", "dcs94_65536", "mixed_16384"])
+@pytest.mark.parametrize("wl", ["dcs93_4096", "dcs94_65536", "mixed_16384", "survey3_65536"])
 def test_full_size_workloads_hash_and_sampled_oracle(gpu_ctx, oracle, wl):
     """BASELINE.json sizes: per-stream FNV-1a of the HIP PCM == the reference's committed hashes, plus
     a direct oracle comparison on a sample of streams"""

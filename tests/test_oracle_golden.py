@@ -49,7 +49,7 @@ def test_survey_appendix_d_sample_values(golden):
         assert not pcm[2, 16:].any()                # frame 2 is the taper: only the 16 overlap samples
 
 
-@pytest.mark.parametrize("wl", ["dcs93_4096", "dcs94_65536", "mixed_16384"])
+@pytest.mark.parametrize("wl", ["dcs93_4096", "dcs94_65536", "mixed_16384", "survey3_65536"])
 def test_oracle_matches_reference_hashes_of_full_workloads(oracle, golden, wl):
     """full-size seeded workloads: per-stream FNV-1a of the oracle's PCM == the reference's"""
     meta, _ = golden

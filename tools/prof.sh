@@ -2,7 +2,7 @@
 # tools/prof.sh <tag> <workload> [extra bench args]  -- run on the GPU box (via gpurun).
 # Writes rocprofv3 kernel-trace stats and PMC counter passes under gpurun_out/prof_<tag>/.
 set -u
-TAG=${1:-r1}; WL=${2:-dcs94_65536}; shift 2 || true
+TAG=${1:-r1}; WL=${2:-survey3_65536}; shift 2 || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

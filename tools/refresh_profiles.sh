@@ -5,14 +5,14 @@
 # counters in place.  Copy gpurun_out/profiles_new/* into profiles/ afterwards.
 TAG=${1:-r02}
 NEW=$PWD/gpurun_out/profiles_new; mkdir -p $NEW
-for wl in dcs94_65536 dcs93_4096 mixed_16384 realistic_65536 corpus; do
+for wl in survey3_65536 dcs94_65536 dcs93_4096 mixed_16384 realistic_65536 corpus; do
   bash tools/prof.sh ${TAG}_$wl $wl > gpurun_out/prof_${TAG}_$wl.log 2>&1 || { echo "prof $wl failed"; tail -5 gpurun_out/prof_${TAG}_$wl.log; exit 1; }
   cp gpurun_out/prof_${TAG}_$wl/summary.txt $NEW/${TAG}_${wl}_rocprofv3_summary.txt
   cp gpurun_out/prof_${TAG}_$wl/traffic.json $NEW/traffic_$wl.json
   cp gpurun_out/prof_${TAG}_$wl/traffic.json profiles/traffic_$wl.json
   echo "profiled $wl"
 done
-for wl in dcs94_65536 dcs93_4096 mixed_16384 realistic_65536 corpus; do
+for wl in survey3_65536 dcs94_65536 dcs93_4096 mixed_16384 realistic_65536 corpus; do
   python bench.py --workload $wl > $NEW/${TAG}_bench_$wl.json 2> gpurun_out/bench_${TAG}_$wl.err || { echo "bench $wl failed"; tail -5 gpurun_out/bench_${TAG}_$wl.err; exit 1; }
   echo "benched $wl"
 done
