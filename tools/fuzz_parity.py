@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Seeded fuzz of the decode path on a GPU box: lists of random streams (every layout, 1..18 bands, strided from a random
-band, five symbol profiles, some with flipped payload bits or cut short) decoded with 4, 8 and 16 frames per wavefront
+band, six symbol profiles, some with flipped payload bits or cut short) decoded with 4, 8 and 16 frames per wavefront
 and held against the oracle, the device's index pass held against the host's; every fourth seed also a multi-channel mix of 2..6 streams on one decoder, every eighth the list through dcs_pipeline.  argv[1]: seconds to run (default 120), argv[2]: first seed."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +29,7 @@ while time.time() - t0 < budget:
         stride_from = 16 if next(g) % 2 else next(g) % 16
         if fmt == D.FMT_93_T0 and stride_from < 16:
             nbands = min(nbands, 12)                  # (Type 0 strided bands span 32 slots)
-        s = make_stream(fmt, nfr, seed=(seed << 8) + k, profile=next(g) % 5, stride_from=stride_from, nbands=nbands)
+        s = make_stream(fmt, nfr, seed=(seed << 8) + k, profile=next(g) % 6, stride_from=stride_from, nbands=nbands)
         r = next(g) % 8
         if r == 0 and len(s) > 24:
             s = corrupt(s, next(g) & 0xFFFF, nflips=1 + next(g) % 4) + bytes(256)
@@ -89,7 +89,7 @@ while time.time() - t0 < budget:
             stride_from = 16 if next(g) % 2 else next(g) % 16
             if fmt == D.FMT_93_T0 and stride_from < 16:
                 nbands = min(nbands, 12)
-            chans.append(make_stream(fmt, 4 + next(g) % 40, seed=(seed << 8) + 100 + c, profile=next(g) % 5, stride_from=stride_from, nbands=nbands))
+            chans.append(make_stream(fmt, 4 + next(g) % 40, seed=(seed << 8) + 100 + c, profile=next(g) % 6, stride_from=stride_from, nbands=nbands))
             levels.append(0x20 + next(g) % 0x60)
         vol = 128 + next(g) % 128
         n_out = max((c[0] << 8) | c[1] for c in chans) + 2
