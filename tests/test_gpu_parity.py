@@ -36,12 +36,12 @@ def test_native_library_is_what_runs(gpu_ctx):
 
 
 @pytest.mark.parametrize("fmt", ALL_FORMATS, ids=[FORMAT_NAMES[f] for f in ALL_FORMATS])
-@pytest.mark.parametrize("profile", [0, 1, 2, 3])
+@pytest.mark.parametrize("profile", [0, 1, 2, 3, 4, 5])
 def test_single_stream_every_layout(gpu_ctx, oracle, fmt, profile):
     for k in range(2):
         s = make_stream(fmt, 70, seed=11000 + fmt * 32 + profile * 4 + k, profile=profile,
                         stride_from=16 if k == 0 else 7)
-        streams = [(os_for(fmt, k), s, [255, 220, 0x67, 255][profile], [0x64, 0x7F, 0x64, 0x20][profile])]
+        streams = [(os_for(fmt, k), s, [255, 220, 0x67, 255, 240, 200][profile], [0x64, 0x7F, 0x64, 0x20, 0x50, 0x70][profile])]
         pcm, err, _ = gpu_ctx.decode_streams(streams, extra_frames=2)
         assert_same(pcm, oracle_streams(oracle, streams, extra=2), FORMAT_NAMES[fmt])
         assert not err.any()
@@ -290,7 +290,7 @@ def test_gpu_index_pass_equals_host_index_pass(gpu_ctx, oracle):
     valid streams of every layout, corrupted streams, ragged lengths -- and decode to the oracle's PCM."""
     streams = []
     for i, fmt in enumerate(ALL_FORMATS * 4):
-        s = make_stream(fmt, 3 + 11 * i, seed=4000 + i, profile=i % 4)
+        s = make_stream(fmt, 3 + 11 * i, seed=4000 + i, profile=i % 6)
         if i % 6 == 5:
             s = corrupt(s, seed=i)
         streams.append((os_for(fmt, i), s, 0xE0, 0x64))

@@ -69,7 +69,7 @@ def test_fast_walk_equals_literal_walk():
     n = 0
     for fmt in ALL_FORMATS:
         for k in range(12):
-            s = make_stream(fmt, 40 + k, seed=8800 + fmt * 32 + k, profile=k % 4, stride_from=16 if k % 3 else 8)
+            s = make_stream(fmt, 40 + k, seed=8800 + fmt * 32 + k, profile=k % 6, stride_from=16 if k % 3 else 8)
             variants = [s, corrupt(s, 200 + k, nflips=4), s[:len(s) * 2 // 3], s + bytes(7)]
             for v in variants:
                 os_ = os_for(fmt, k)
@@ -92,7 +92,7 @@ def test_index_pass_error_semantics_match_oracle(oracle):
     hit = 0
     for fmt in ALL_FORMATS:
         for k in range(40):
-            s = corrupt(make_stream(fmt, 30, seed=5100 + fmt * 64 + k, profile=k % 4), seed=k, nflips=4)
+            s = corrupt(make_stream(fmt, 30, seed=5100 + fmt * 64 + k, profile=k % 6), seed=k, nflips=4)
             os_ = os_for(fmt)
             idx, info = D.index_stream(os_, s)
             _, _, _, stops = oracle.decompress(os_, s, 0x7FFF, 30)

@@ -7,7 +7,7 @@ from util import ALL_FORMATS, FORMAT_NAMES, make_stream, os_for, splitmix
 
 
 @pytest.mark.parametrize("fmt", ALL_FORMATS, ids=[FORMAT_NAMES[f] for f in ALL_FORMATS])
-@pytest.mark.parametrize("profile", [0, 1, 2, 3])
+@pytest.mark.parametrize("profile", [0, 1, 2, 3, 4, 5])
 def test_whole_decoder_pcm_and_probes(oracle, reference, fmt, profile):
     for k in range(3):
         stream = make_stream(fmt, 48, seed=7000 + 100 * fmt + 10 * profile + k, profile=profile,
@@ -94,7 +94,7 @@ def _sequence_case(os_, seed, with_error=False):
     streams, levels = [], []
     for i in range(6):
         fmt = fmts[i % len(fmts)]
-        s = make_stream(fmt, 3 + 5 * i, seed=seed + i, profile=i % 4)
+        s = make_stream(fmt, 3 + 5 * i, seed=seed + i, profile=i % 6)
         if with_error and i in (1, 4):
             s = corrupt(s, seed=seed + i)
         streams.append(s)
