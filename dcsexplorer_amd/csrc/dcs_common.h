@@ -302,6 +302,7 @@ struct DcsPlanStream
     uint8_t  volShift0, volShiftN;
     uint8_t  xform, hdrLen, format, pad_[3];
 };
+static_assert(sizeof(DcsPlanStream) == 40, "DcsPlanStream layout (uploaded by copy kernel: whole dwords)");
 #define DCS_PLAN_POOL_OVERFLOW 1u       // flag word of the device planner: some chunk's compressed bytes do not fit the bit pool
 #define DCS_PLAN_TRUNCATED     2u       // ... some stream's frames run past its buffer
 // what the index kernel writes per frame next to the full record: all the host needs for planning (8 bytes)
