@@ -11,8 +11,8 @@ variants = [base[i:] + base[:i] for i in (0, 7, 19)]              # three differ
 ctx = D.Context(0)
 want = [zlib.crc32(ctx.decode_streams(v)[0].tobytes()) for v in variants]
 refs = [D.make_refs(v) for v in variants]
-for mode, name in ((0, "host index"), (1, "device index"), (2, "device index + pack")):
-    pipe = ctx.pipeline(12, index_on_device=mode >= 1, pack_on_device=mode == 2)
+for mode, name in ((0, "host index"), (1, "device index"), (2, "device index + pack"), (3, "device index + plan + pack")):
+    pipe = ctx.pipeline(12, index_on_device=mode >= 1, pack_on_device=mode >= 2, plan_on_device=mode == 3)
     rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     t0 = time.time(); bad = 0; done = 0
     for k in range(n_lists):
