@@ -50,6 +50,7 @@ def parse_args(argv=None):
                     "per frame with the lanes of the other slots idle); 0 = every slot of the kernel variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-device-path", action="store_true", help="skip device_full_path (stream bytes in HBM -> PCM in HBM: index walk, planner, packer, decode)")
     ap.add_argument("--no-second-workload", action="store_true", help="skip the encoder-made streams reported next to the default workload")
     ap.add_argument("--clock-settle-ms", type=float, default=50.0, help="run the clock-probe kernel (not a step) this long before the "
                     "warm-up steps, so that the shader clock has left its idle state when the K steps are timed (0: do not)")
@@ -64,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--e2e-depth", type=int, default=8, help="lists in flight of end_to_end.sustained_host_index")
     ap.add_argument("--e2e-device-depth", type=int, default=48, help="lists in flight of end_to_end.sustained_device_index")
     ap.add_argument("--e2e-lists", type=int, default=96, help="lists per rank of the N-rank end_to_end measurement (at least twice the depth)")
+    ap.add_argument("--rotate", type=int, default=8, help="roofline_cold: this many distinct resident batches of the workload (the shares of "
+                    "ranks 0..N-1, together larger than the 256 MB Infinity Cache) launched round-robin, so that no launch finds its "
+                    "inputs or outputs cached (0: skip; one rank only; not for the corpus, whose one batch is larger than the cache)")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the N-rank path (gloo, no GPU, no kernel)")
     ap.add_argument("--share-gpu", action="store_true", help="testing on a one-GPU box: every rank decodes on GPU 0 and gloo carries the "
                     "barrier and the max (RCCL needs one device per rank); exercises the whole N-rank path but is no scaling measurement")
@@ -292,6 +296,183 @@ def end_to_end_ranks(ctx, streams, n_frames, world, rank, device, depth=48, list
                                      "per list times lists per second cannot exceed them, whatever the number of GPUs"}}
 
 
+def load_counters(workload, profiles_dir=None):
+    """-> (counters, note): the committed rocprofv3 --pmc counters of `workload` (profiles/traffic_<workload>.json, written
+    by tools/prof.sh) -- but ONLY when they were taken with the library build that is loaded now (dcs_build_id: a digest of
+    the library's sources and compiler flags; or the same file by sha256).  Counters of another binary say nothing about
+    the one being timed: they are withheld (None) with a note, until tools/prof.sh has been run on this build."""
+    import dcsexplorer_amd as D
+    tpath = os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "traffic_%s.json" % workload)
+    if not os.path.exists(tpath):
+        return None, None
+    t = json.load(open(tpath))
+    if t.get("lib_build_id") != D.build_id() and t.get("lib_sha256") != D.lib_sha256():
+        return None, ("%s was taken with library build %s, the library timed here is build %s: counters withheld (run "
+                      "tools/prof.sh on this build)" % (os.path.relpath(tpath, ROOT), t.get("lib_build_id"), D.build_id()))
+    return t, None
+
+
+# --------------------------------------------------------------------------------------------- the kernel on cold inputs
+def roofline_cold(ctx, args, first_batch, stream):
+    """The timed steps relaunch ONE resident batch, whose ~60 MB of packages and PCM stay in the 256 MB Infinity Cache from
+    launch to launch (and FETCH_SIZE / WRITE_SIZE count cache hits like HBM transfers).  Here `--rotate` distinct resident
+    batches of the same workload -- the shares ranks 0..N-1 would decode, so the reference's hashes of each are committed --
+    are launched round-robin: with more than 256 MB between two launches of the same batch nothing a launch reads or
+    writes is cached.  Kernel time by HIP events over the rotation (median of three runs)."""
+    import numpy as np
+    import dcsexplorer_amd as D
+    from dcsexplorer_amd import sharding, workloads
+    from oracle.dcs_oracle import Oracle
+    n = max(2, args.rotate)
+    batches, builds = [first_batch], [None]
+    for r in range(1, n):
+        streams = sharding.rank_streams(args.workload, r)
+        b = D.build_stream_batch(streams, indexer=D.index_streams)
+        if args.workload == "mixed_16384":
+            b, _ = workloads.interleave(b)
+        batches.append(ctx.batch(b["blob"], b["srcs"], b["jobs"]))
+        builds.append((b, streams))
+    pkg = {4: 2176, 8: 3072, 16: 5632}
+    resident = sum(bt.num_chunks * pkg[bt.frames_per_wave] + bt.n_jobs * (480 + 32 + 4) for bt in batches)
+    iters = max(3 * n, args.steps)
+    Batch = type(first_batch)
+    Batch.time_rotating(batches, n, stream)                                  # (every batch launched once: code and tables warm, data not)
+    kern_ms = sorted(Batch.time_rotating(batches, iters, stream) for _ in range(3))[1]
+    algo = sum(bt.algorithmic_bytes for bt in batches) / n
+    achieved = algo / (kern_ms * 1e-3) / 1e9
+    # every batch of the rotation is held against the reference's committed hashes of that rank's streams
+    ok = None
+    G = os.path.join(ROOT, "tests", "golden", "rank_golden_hashes.json")
+    rg = json.load(open(G))
+    if args.workload in rg["workloads"] and n <= rg["ranks"] and args.workload != "mixed_16384":
+        orc, ok = Oracle(), True
+        for r in range(1, n):
+            pcm, err = batches[r].download()
+            first = builds[r][0]["first_job"]
+            got = ["%016x" % orc.fnv1a64(pcm[first[k]:first[k + 1]]) for k in range(len(first) - 1)]
+            ok = ok and got == rg["workloads"][args.workload]["rank_stream_hashes"][r] and not bool(err.any())
+    for bt in batches[1:]:
+        bt.close()
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "kernel_avg_ms": kern_ms, "batches": n, "launches_timed": iters, "resident_bytes_rotated": resident,
+            "algorithmic_bytes_per_launch": algo, "bit_exact": ok,
+            "note": "%d distinct resident batches (%.0f MB of packages + PCM, Infinity Cache 256 MB) launched round-robin on one stream: "
+                    "no launch finds its inputs or its outputs' lines cached; `roofline` relaunches one batch" % (n, resident / 1e6)}
+
+
+# --------------------------------------------------------------------------------------------- the whole device path
+def device_full_path(ctx, args, streams, n_frames, rank_golden):
+    """Stream bytes resident in HBM -> PCM resident in HBM: index walk (the reference's GetStreamInfo walk,
+    DCSDecoderNative.cpp:1486-1537), chunk planner, packer and decode kernel on one HIP stream, nothing over PCIe, no host work
+    between the kernels (dcs_device_path_*).  `value` of the line times the LAST of these four kernels over a batch prepared
+    beforehand; this is the rate of all four.  Two sizes: ONE list of the workload (256 streams: latency -- 256 wavefronts walk
+    256 streams) and a SATURATED launch (32 such lists in one: 8 192 streams, 8 wavefronts per SIMD in the index kernel)."""
+    import numpy as np
+    import dcsexplorer_amd as D
+    from dcsexplorer_amd import sharding
+    from oracle.dcs_oracle import Oracle
+    from concurrent.futures import ThreadPoolExecutor
+    orc = Oracle()
+    CU, SIMDS = 256, 1024
+
+    def measure(strs, iters, gold):
+        path = ctx.device_path(strs)
+        path.run(max(2, iters // 4))                                    # warm: clocks, caches of the code
+        t = path.run(iters)
+        clock = ctx.clock_mhz()
+        pcm, err, first = path.download()
+        ok = None
+        if gold is not None:
+            n = min(len(gold), len(first) - 1)
+            with ThreadPoolExecutor(max_workers=min(16, D.host_threads())) as ex:
+                got = list(ex.map(lambda k: "%016x" % orc.fnv1a64(pcm[first[k]:first[k + 1]]), range(n)))
+            ok = got == gold[:n] and not bool(err.any())
+        frames = int(t["nFrames"])
+        path.close()
+        del pcm
+        return {"streams": len(strs), "frames": frames, "ms_per_pass": t["passMs"], "value": frames * 240 / (t["passMs"] * 1e-3), "unit": "samples/s",
+                "ns_per_frame": t["passMs"] * 1e6 / frames,
+                "kernel_ms": {"dcsIndexWaveKernel": t["indexMs"], "dcsPlanKernel (+ clearing packages, error and hand-off words)": t["planMs"],
+                              "dcsPackKernel": t["packMs"], "dcsDecodeKernel<%d>" % t["framesPerWave"]: t["decodeMs"]},
+                "index_share_of_pass": t["indexMs"] / max(t["indexMs"] + t["planMs"] + t["packMs"] + t["decodeMs"], 1e-9),
+                "index_ns_per_frame": t["indexMs"] * 1e6 / frames, "clock_mhz": clock, "passes_timed": iters,
+                "hbm": {"algorithmic_bytes_per_pass": int(t["algorithmicBytes"]), "achieved_GBps": t["algorithmicBytes"] / (t["passMs"] * 1e-3) / 1e9,
+                        "frac_of_peak": t["algorithmicBytes"] / (t["passMs"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "bit_exact": ok, "bit_exact_streams_checked": None if gold is None else min(len(gold), len(strs))}, t, clock
+
+    one, t1, clk1 = measure(streams, 20, rank_golden[0] if rank_golden else None)
+    lists = 32
+    with ThreadPoolExecutor(max_workers=min(16, D.host_threads())) as ex:
+        many = [s for part in ex.map(lambda r: sharding.rank_streams(args.workload, r), range(lists)) for s in part]
+    gold = [h for r in rank_golden for h in r] if rank_golden else None
+    sat, t2, clk2 = measure(many, 6, gold)
+    out = {"what": "stream bytes resident in HBM -> PCM resident in HBM on one HIP stream: dcsIndexWaveKernel (one wavefront per stream), dcsPlanKernel, "
+                   "dcsPackKernel, dcsDecodeKernel; no PCIe, no host work between the kernels; per-kernel times from HIP events around each",
+           "one_list": one, "saturated": dict(sat, lists_in_one_launch=lists)}
+    # the index kernel against the roofs: its scalar issue (the chain through the Huffman codes runs on the scalar unit) and HBM
+    c, note = load_counters("index_%s" % args.workload)
+    if c is not None and "SQ_INSTS_SALU" in c:
+        per_frame = {k: c[k] / c["frames"] for k in ("SQ_INSTS_SALU", "SQ_INSTS_VALU", "SQ_INSTS_LDS") if k in c}
+        def issue(run, t, clk):
+            cycles = t["indexMs"] * 1e-3 * clk * 1e6
+            return {"salu_insts_per_frame": per_frame["SQ_INSTS_SALU"], "valu_insts_per_frame": per_frame.get("SQ_INSTS_VALU"),
+                    "salu_issue_frac_of_cu_cycles": per_frame["SQ_INSTS_SALU"] * run["frames"] / (CU * cycles),
+                    "valu_issue_frac_4_cycles_per_inst": None if "SQ_INSTS_VALU" not in per_frame else per_frame["SQ_INSTS_VALU"] * run["frames"] * 4 / (SIMDS * cycles),
+                    "hbm_frac": (c.get("hbm_bytes_per_frame", 0.0) * run["frames"]) / (t["indexMs"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "insts_source": "from_profile: profiles/traffic_index_%s.json (same library build); cycles: this run's kernel time x measured clock" % args.workload,
+                    "note": "one scalar instruction per cycle per CU is the scalar unit's issue peak"}
+        out["one_list"]["index_kernel_issue"] = issue(one, t1, clk1)
+        out["saturated"]["index_kernel_issue"] = issue(sat, t2, clk2)
+    else:
+        out["index_kernel_issue_note"] = note or "no counter profile of the index kernel for this workload (tools/prof_index.sh)"
+    return out
+
+
+# --------------------------------------------------------------------------------------------- parity of what was timed
+def verify_rank(args, batch, b, streams, rank, corpus, golden_range):
+    """-> (ok, note) for THIS rank's share: per-stream FNV-1a-64 of the PCM the timed launches left in HBM against the
+    hashes of the unmodified reference decoder committed under tests/golden/ (corpus: the rank's stream range of the
+    20- or 600-streams-per-title corpus; the weak-scaling workloads: the hashes of rank r's streams, r < 8).  Where no
+    hashes are committed (another corpus size, --scale, rank >= 8) a seeded sample of the rank's streams is compared
+    with the oracle sample for sample.  The oracle library is the checker here, after the timed region."""
+    import numpy as np
+    import dcsexplorer_amd as D
+    from dcsexplorer_amd import workloads
+    from oracle.dcs_oracle import Oracle
+    from concurrent.futures import ThreadPoolExecutor
+    orc = Oracle()
+    pcm, err = batch.download()
+    first = b["first_job"]
+    gold, note = None, None
+    G = os.path.join(ROOT, "tests", "golden")
+    if corpus:
+        for name in ("corpus_golden.json", "corpus_golden_full.json"):
+            cg = json.load(open(os.path.join(G, name)))
+            if cg["corpus"] == golden_range[0]:
+                gold = cg["stream_hashes"][golden_range[1]:golden_range[2]]
+    elif args.scale == 1:
+        rg = json.load(open(os.path.join(G, "rank_golden_hashes.json")))
+        if args.workload in rg["workloads"] and rank < rg["ranks"]:
+            gold = rg["workloads"][args.workload]["rank_stream_hashes"][rank]
+        if args.workload == "mixed_16384":
+            plain = D.build_stream_batch(streams, indexer=D.index_streams)
+            _, perm = workloads.interleave(plain)
+            inv = np.empty_like(perm); inv[perm] = np.arange(perm.size)
+            pcm = pcm[inv]
+            first = plain["first_job"]
+    if gold is not None:
+        with ThreadPoolExecutor(max_workers=min(16, D.host_threads())) as ex:       # (the hash is C behind ctypes: threads scale)
+            got = list(ex.map(lambda k: "%016x" % orc.fnv1a64(pcm[first[k]:first[k + 1]]), range(len(first) - 1)))
+        return bool(got == gold) and not bool(err.any()), "%d streams of rank %d against the reference's committed hashes" % (len(got), rank)
+    pick = sorted(set(int(x) for x in np.random.default_rng(5 + rank).integers(0, len(streams), size=48)))
+    ok = not bool(err.any())
+    for k in pick:
+        os_, data, vol, lvl = streams[k]
+        want = orc.decode(os_, vol, [data], [lvl], int(first[k + 1] - first[k]))
+        ok = ok and bool(np.array_equal(pcm[first[k]:first[k + 1]], want))
+    return ok, "%d of rank %d's %d streams compared with the oracle sample for sample (no committed hashes for this range)" % (len(pick), rank, len(streams))
+
+
 # --------------------------------------------------------------------------------------------- one rank
 def run_rank(args):
     import numpy as np
@@ -418,7 +599,8 @@ def run_rank(args):
     dt = time.perf_counter() - t0           # this rank's K steps are done; the job's time is the MAX of this over the ranks
     barrier()                               # (the closing bracket; its own latency -- an RCCL all-reduce, 50-100 us against
     torch.cuda.synchronize()                #  0.7 ms of steps at the driver's K = 20 -- is no part of any rank's K steps)
-    dt = sharding.max_over_ranks(dt, device=None if (args.share_gpu or getattr(args, "gloo_fallback", False)) else "cuda")
+    red_dev = None if (args.share_gpu or getattr(args, "gloo_fallback", False)) else "cuda"     # where the small all-reduces live
+    dt = sharding.max_over_ranks(dt, device=red_dev)
 
     # kernel-only average duration by HIP events on the launch stream (roofline denominator)
     # (three runs of K launches, the median: the host now and then falls behind 8-us kernels and an average over one
@@ -427,49 +609,21 @@ def run_rank(args):
     clock_mhz = ctx.clock_mhz()             # shader clock under an integer load, measured right behind the timed launches
     algo_bytes = batch.algorithmic_bytes    # payload + stream headers + 56 B per frame + 480 B PCM
 
-    # bit-exactness of what was just timed (rank 0): per-stream hashes vs the reference's committed hashes
-    bit_exact, bit_exact_note = None, None
-    if rank == 0:
-        from oracle.dcs_oracle import Oracle
-        orc = Oracle()
-        pcm, err = batch.download()
-        gold = None
-        if corpus:
-            cg = json.load(open(os.path.join(ROOT, "tests", "golden", "corpus_golden.json")))
-            if cg["corpus"] == golden_range[0]:
-                gold = cg["stream_hashes"][golden_range[1]:golden_range[2]]
-            first = b["first_job"]
-        elif args.scale == 1:
-            g = json.load(open(os.path.join(ROOT, "tests", "golden", "dcs_golden_hashes.json")))["workloads"]
-            g.update(json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_golden.json")))["workloads"])
-            gold = g.get(args.workload, {}).get("stream_hashes")
-            if args.workload == "mixed_16384":
-                plain = D.build_stream_batch(streams, indexer=D.index_streams)
-                _, perm = workloads.interleave(plain)
-                inv = np.empty_like(perm); inv[perm] = np.arange(perm.size)
-                pcm = pcm[inv]
-                first = plain["first_job"]
-            else:
-                first = b["first_job"]
-        if gold is not None:
-            got = ["%016x" % orc.fnv1a64(pcm[first[k]:first[k + 1]]) for k in range(len(first) - 1)]
-            bit_exact = bool(got == gold) and not bool(err.any())
-        elif corpus:
-            # a corpus size without committed hashes: a seeded sample of its streams against the oracle, sample for sample
-            pick = sorted(set(int(x) for x in np.random.default_rng(5).integers(0, len(streams), size=48)))
-            ok = not bool(err.any())
-            for k in pick:
-                os_, data, vol, lvl = streams[k]
-                want = orc.decode(os_, vol, [data], [lvl], int(first[k + 1] - first[k]))
-                ok = ok and bool(np.array_equal(pcm[first[k]:first[k + 1]], want))
-            bit_exact = ok
-            bit_exact_note = "%d of this rank's %d streams compared with the oracle sample for sample (no committed hashes at this corpus size)" % (len(pick), len(streams))
+    # bit-exactness of what was just timed, on EVERY rank: per-stream hashes of this rank's PCM vs the reference's
+    # committed hashes of this rank's range; the line's bit_exact is the AND over the ranks (one all-reduce)
+    ok, bit_exact_note = verify_rank(args, batch, b, streams, rank, corpus, golden_range)
+    bit_exact_ranks = [ok]
+    if world > 1:
+        t = torch.full((world,), 0, dtype=torch.int64, device=red_dev if red_dev is not None else "cpu")
+        t[rank] = 2 if ok is None else int(bool(ok))            # 1 = every stream equal, 0 = some stream differs, 2 = nothing to compare with
+        dist.all_reduce(t)
+        bit_exact_ranks = [None if int(x) == 2 else bool(int(x)) for x in t.cpu()]
+    bit_exact = None if all(x is None for x in bit_exact_ranks) else all(x is True for x in bit_exact_ranks)
 
     # host buffers in, host buffers out on every rank at once (never `value`): what N ranks do to the node's host CPUs
     e2e_ranks = None
     if world > 1 and not args.no_end_to_end and not corpus:
-        e2e_ranks = end_to_end_ranks(ctx, streams, n_frames, world, rank,
-                                     None if (args.share_gpu or getattr(args, "gloo_fallback", False)) else "cuda",
+        e2e_ranks = end_to_end_ranks(ctx, streams, n_frames, world, rank, red_dev,
                                      depth=args.e2e_device_depth, lists=args.e2e_lists)
 
     if rank == 0:
@@ -481,14 +635,14 @@ def run_rank(args):
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         plain_run = args.scale == 1 and not args.fpw and not args.frames_per_chunk and world == 1 and args.inflight == 1 and \
             (not corpus or (args.corpus_titles, args.corpus_streams) == (29, 20))
-        if os.path.exists(tpath) and plain_run:                  # (the committed counters are those of the plain workload)
-            t = json.load(open(tpath))
+        t, traffic_note = load_counters(args.workload) if plain_run else (None, None)   # (the committed counters are those of the plain workload)
+        if t is not None:
             # the kernel's reads are 16-byte-per-lane loads of the chunk packages, for which FETCH_SIZE reports half
             # the bytes on gfx950 (MI355X_MICROARCH.md, HBM section): doubled here; WRITE_SIZE is exact
             traffic = t["traffic_bytes_fetch_x2"]
-            traffic_note = ("2 x FETCH_SIZE + WRITE_SIZE from %s (separate --pmc passes; kilobytes; the gfx950 wide-read "
-                            "correction applied to FETCH_SIZE; uncorrected sum: %d)"
-                            % (os.path.relpath(tpath, ROOT), t["traffic_bytes_fetch_raw"]))
+            traffic_note = ("2 x FETCH_SIZE + WRITE_SIZE from %s (separate --pmc passes of this library build, %s; kilobytes; the gfx950 "
+                            "wide-read correction applied to FETCH_SIZE; uncorrected sum: %d)"
+                            % (os.path.relpath(tpath, ROOT), t.get("lib_build_id"), t["traffic_bytes_fetch_raw"]))
             if "SQ_INSTS_VALU" in t:
                 # what actually bounds this integer kernel: wave64 VALU issue, 4 cycles per instruction per SIMD.  The
                 # instruction count per launch is a property of (workload, binary) and comes from the committed
@@ -528,10 +682,11 @@ def run_rank(args):
                        "scale": args.scale, "inflight": args.inflight, "clock_settle_ms": args.clock_settle_ms, "frames_per_chunk": args.frames_per_chunk or "all"},
             **({"share_gpu": "all ranks on GPU 0 (test of the N-rank path on a one-GPU box): not a scaling measurement"} if args.share_gpu else {}),
             "bit_exact": bit_exact,
+            "bit_exact_ranks": bit_exact_ranks,
             "bit_exact_note": bit_exact_note,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "dcsDecodeKernel<%d>" % batch.frames_per_wave, "kernel_avg_ms": kern_ms,
+                         "kernel": "dcsDecodeKernel<%d>" % batch.frames_per_wave, "kernel_avg_ms": kern_ms, "lib_build_id": D.build_id(),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_bytes_note": "SURVEY 8(d): exact payload + stream headers + 56 B descriptor and 480 B PCM per frame "
                                                    "(x %d frames per launch)" % n_frames,
@@ -543,6 +698,12 @@ def run_rank(args):
         if world == 1 and args.workload == DEFAULT_WORKLOAD and not args.no_second_workload and args.scale == 1:
             out["second_workload"] = second_workload(ctx, args, torch)
             out["third_workload"] = second_workload(ctx, args, torch, name=PREVIOUS_DEFAULT)
+        if world == 1 and args.rotate > 0 and not corpus and args.scale == 1 and args.inflight == 1:
+            out["roofline_cold"] = roofline_cold(ctx, args, batch, stream)
+        if world == 1 and not args.no_device_path and not corpus and args.scale == 1 and args.workload in ("survey3_65536", "dcs94_65536", "realistic_65536"):
+            rgp = os.path.join(ROOT, "tests", "golden", "rank_golden_hashes.json")
+            rg = json.load(open(rgp))["workloads"].get(args.workload, {}).get("rank_stream_hashes")
+            out["device_full_path"] = device_full_path(ctx, args, streams, n_frames, rg)
         if world == 1 and not args.no_end_to_end:
             out["end_to_end"] = end_to_end(ctx, streams, n_frames, depth=args.e2e_depth, dev_depth=args.e2e_device_depth)
         if e2e_ranks is not None:

@@ -69,6 +69,12 @@ class PipelineResult(ctypes.Structure):
                 ("hostMs", ctypes.c_float), ("deviceMs", ctypes.c_float), ("path", ctypes.c_uint32)]
 
 
+class DevicePathTimes(ctypes.Structure):
+    _fields_ = [("passMs", ctypes.c_float), ("indexMs", ctypes.c_float), ("planMs", ctypes.c_float), ("packMs", ctypes.c_float),
+                ("decodeMs", ctypes.c_float), ("planFlags", ctypes.c_uint32), ("nStreams", ctypes.c_uint32), ("nFrames", ctypes.c_uint32),
+                ("framesPerWave", ctypes.c_uint32), ("algorithmicBytes", ctypes.c_uint64)]
+
+
 class SynthParams(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("format", ctypes.c_int32), ("nFrames", ctypes.c_int32),
                 ("nBands", ctypes.c_int32), ("strideFromBand", ctypes.c_int32), ("profile", ctypes.c_int32),
@@ -93,12 +99,13 @@ class DcsError(RuntimeError):
 
 
 _LIB = None
+ABI_VERSION = 7                 # include/dcs_hip.h DCS_ABI_VERSION these bindings are written for
 
 EXPORTS = [
-    "dcs_abi_version", "dcs_index_stream", "dcs_volume_multiplier", "dcs_mixing_multiplier", "dcs_frame_scale",
+    "dcs_abi_version", "dcs_build_id", "dcs_index_stream", "dcs_volume_multiplier", "dcs_mixing_multiplier", "dcs_frame_scale",
     "dcs_stream_params", "dcs_ctx_create", "dcs_ctx_destroy", "dcs_last_error", "dcs_device_count",
-    "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_ctx_set_large_list_path", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run", "dcs_batch_run_many", "dcs_pack_chunks",
-    "dcs_batch_time", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_download_view", "dcs_batch_device_pcm",
+    "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_ctx_set_large_list_path", "dcs_ctx_set_cache_limits", "dcs_ctx_trim_cache", "dcs_ctx_cache_bytes", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run", "dcs_batch_run_many", "dcs_pack_chunks",
+    "dcs_batch_time", "dcs_batch_time_rotating", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_download_view", "dcs_batch_device_pcm",
     "dcs_batch_algorithmic_bytes", "dcs_batch_num_jobs", "dcs_decode_streams", "dcs_count_stream_frames",
     "dcs_synth_stream", "dcs_plan_chunks", "dcs_index_streams", "dcs_index_streams_gpu",
     "dcs_index_streams_gpu_time", "dcs_stream_params_from", "dcs_decode_stream_sequence", "dcs_wav_header",
@@ -115,7 +122,18 @@ EXPORTS = [
     "dcs_host_threads", "dcs_partition_streams", "dcs_decode_streams_sharded",
     "dcs_ctx_set_frames_per_chunk", "dcs_index_stream_literal", "dcs_pack_chunks_device", "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_set_test_hooks",
     "dcs_pipeline_create", "dcs_pipeline_destroy", "dcs_pipeline_submit", "dcs_pipeline_collect",
+    "dcs_device_path_create", "dcs_device_path_run", "dcs_device_path_download", "dcs_device_path_destroy",
 ]
+
+
+def build_id():
+    """the digest of sources and flags the LOADED library was built from (dcs_build_id)"""
+    return load_library().dcs_build_id().decode()
+
+
+def lib_sha256():
+    import hashlib
+    return hashlib.sha256(open(lib_path(), "rb").read()).hexdigest()
 
 
 def lib_path():
@@ -140,6 +158,12 @@ def load_library():
     L = ctypes.CDLL(path)
     vp, u32, i32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_size_t
     L.dcs_abi_version.restype = u32
+    L.dcs_build_id.restype = ctypes.c_char_p
+    if L.dcs_abi_version() != ABI_VERSION:
+        # (DCS_HIP_LIB may name another BUILD of this library, tools/ab.sh; one with other struct layouts must not be driven
+        # through these bindings: dcs_pipeline_collect writes sizeof(DcsPipelineResult) bytes into the caller's struct)
+        raise ImportError("%s has ABI version %d, these bindings are written for %d: rebuild it (make -C dcsexplorer_amd/csrc)"
+                          % (path, L.dcs_abi_version(), ABI_VERSION))
     L.dcs_index_stream.restype = i32
     L.dcs_index_stream.argtypes = [i32, vp, sz, vp, u32, ctypes.POINTER(StreamInfo)]
     L.dcs_index_stream_literal.restype = i32
@@ -165,6 +189,13 @@ def load_library():
     L.dcs_ctx_set_tail_handoff.argtypes = [vp, ctypes.c_int]
     L.dcs_ctx_set_large_list_path.restype = i32
     L.dcs_ctx_set_large_list_path.argtypes = [vp, ctypes.c_int]
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    L.dcs_ctx_set_cache_limits.restype = i32
+    L.dcs_ctx_set_cache_limits.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64]
+    L.dcs_ctx_trim_cache.restype = i32
+    L.dcs_ctx_trim_cache.argtypes = [vp, u64p, u64p]
+    L.dcs_ctx_cache_bytes.restype = i32
+    L.dcs_ctx_cache_bytes.argtypes = [vp, u64p, u64p, u64p, u64p]
     L.dcs_pack_chunks.restype = i32
     L.dcs_pack_chunks.argtypes = [vp, u32, vp, vp, sz, ctypes.c_int, vp, sz, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.dcs_plan_chunks2.restype = i32
@@ -181,6 +212,8 @@ def load_library():
     L.dcs_batch_run_many.argtypes = [vp, vp, ctypes.c_int]
     L.dcs_batch_time.restype = i32
     L.dcs_batch_time.argtypes = [vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    L.dcs_batch_time_rotating.restype = i32
+    L.dcs_batch_time_rotating.argtypes = [ctypes.POINTER(vp), u32, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
     L.dcs_batch_sync.restype = i32
     L.dcs_batch_sync.argtypes = [vp]
     L.dcs_batch_download.restype = i32
@@ -305,6 +338,14 @@ def load_library():
     L.dcs_pipeline_submit.argtypes = [vp, vp, u32, u32]
     L.dcs_pipeline_collect.restype = i32
     L.dcs_pipeline_collect.argtypes = [vp, ctypes.POINTER(PipelineResult)]
+    L.dcs_device_path_create.restype = i32
+    L.dcs_device_path_create.argtypes = [vp, vp, u32, u32, ctypes.POINTER(vp)]
+    L.dcs_device_path_run.restype = i32
+    L.dcs_device_path_run.argtypes = [vp, ctypes.c_int, ctypes.POINTER(DevicePathTimes)]
+    L.dcs_device_path_download.restype = i32
+    L.dcs_device_path_download.argtypes = [vp, vp, vp, vp]
+    L.dcs_device_path_destroy.restype = None
+    L.dcs_device_path_destroy.argtypes = [vp]
     L.dcs_host_threads.restype = ctypes.c_int
     L.dcs_host_threads.argtypes = []
     L.dcs_partition_streams.restype = i32
@@ -630,6 +671,21 @@ class Context:
         except Exception:
             pass
 
+    def set_cache_limits(self, device_bytes, pinned_bytes):
+        _check(self.L.dcs_ctx_set_cache_limits(self.h, int(device_bytes), int(pinned_bytes)), self.h)
+
+    def trim_cache(self):
+        """release every cached buffer -> (device bytes, pinned bytes) released"""
+        d, p = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _check(self.L.dcs_ctx_trim_cache(self.h, ctypes.byref(d), ctypes.byref(p)), self.h)
+        return d.value, p.value
+
+    def cache_bytes(self):
+        """-> (device bytes cached, pinned bytes cached, device limit, pinned limit)"""
+        v = [ctypes.c_uint64(0) for _ in range(4)]
+        _check(self.L.dcs_ctx_cache_bytes(self.h, *[ctypes.byref(x) for x in v]), self.h)
+        return tuple(x.value for x in v)
+
     def set_frames_per_wave(self, fpw):
         _check(self.L.dcs_ctx_set_frames_per_wave(self.h, fpw), self.h)
 
@@ -721,6 +777,9 @@ class Context:
     def set_test_hooks(self, handoff_timeout_us=0, drop_exports=False):
         _check(self.L.dcs_ctx_set_test_hooks(self.h, int(handoff_timeout_us), int(bool(drop_exports))), self.h)
 
+    def device_path(self, streams, extra_frames=0):
+        return DevicePath(self, streams, extra_frames)
+
     def pipeline(self, depth=3, index_on_device=False, pack_on_device=False, plan_on_device=False):
         return Pipeline(self, depth, index_on_device, pack_on_device, plan_on_device)
 
@@ -786,6 +845,15 @@ class Batch:
         ms = ctypes.c_float(0)
         _check(self.L.dcs_batch_time(self.h, ctypes.c_void_p(stream) if stream else None, iters, ctypes.byref(ms)),
                self.ctx.h)
+        return ms.value
+
+    @staticmethod
+    def time_rotating(batches, iters, stream=None):
+        """average kernel time of `iters` launches dealt round-robin to `batches` (dcs_batch_time_rotating)"""
+        b0 = batches[0]
+        hs = (ctypes.c_void_p * len(batches))(*[b.h for b in batches])
+        ms = ctypes.c_float(0)
+        _check(b0.L.dcs_batch_time_rotating(hs, len(batches), ctypes.c_void_p(stream) if stream else None, iters, ctypes.byref(ms)), b0.ctx.h)
         return ms.value
 
     def sync(self):
@@ -880,6 +948,48 @@ class Pipeline:
                 self.L.dcs_pipeline_destroy(self.h)
             self.h = None
             self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DevicePath:
+    """DcsDevicePath: a list of whole streams resident in HBM; index walk, planner, packer and decode kernels run back to
+    back on the device with nothing crossing PCIe (include/dcs_hip.h dcs_device_path_*)"""
+
+    def __init__(self, ctx, streams, extra_frames=0):
+        self.ctx = ctx
+        self.L = ctx.L
+        streams = list(streams)
+        refs, keep = _stream_refs(streams)
+        h = ctypes.c_void_p()
+        _check(self.L.dcs_device_path_create(ctx.h, refs, len(streams), extra_frames, ctypes.byref(h)), ctx.h)
+        self.h = h
+        self.n_streams = len(streams)
+        self.n_frames = int(sum(((int(k[0]) << 8) | int(k[1])) + extra_frames for k in keep))
+        ctx._batches.add(self)                  # closed before the context, like a batch
+
+    def run(self, iters=10):
+        """-> dict of the DcsDevicePathTimes fields: ms per pass and per kernel"""
+        t = DevicePathTimes()
+        _check(self.L.dcs_device_path_run(self.h, int(iters), ctypes.byref(t)), self.ctx.h)
+        return {f[0]: getattr(t, f[0]) for f in DevicePathTimes._fields_}
+
+    def download(self):
+        pcm = np.zeros((self.n_frames, FRAME_SAMPLES), dtype=np.int16)
+        err = np.zeros(self.n_frames, dtype=np.uint32)
+        first = np.zeros(self.n_streams + 1, dtype=np.uint32)
+        _check(self.L.dcs_device_path_download(self.h, _ptr(pcm), _ptr(err), _ptr(first)), self.ctx.h)
+        return pcm, err, first
+
+    def close(self):
+        if self.h:
+            if self.ctx.h:
+                self.L.dcs_device_path_destroy(self.h)
+            self.h = None
 
     def __del__(self):
         try:

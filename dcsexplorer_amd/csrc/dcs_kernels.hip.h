@@ -49,11 +49,13 @@ struct Stamper
 };
 #define DCS_STAMP(k) stamp(k)
 
-// default bound of the wait for a tail from another chunk: 50 ms (100 MHz ticks).  A producer publishes before it waits for
-// anything and is dispatched ahead of its consumers, so a wait is microseconds; the bound only has to outlast what can keep a
-// dispatched-ahead producer from running at all (other kernels holding the chip: the pipeline's index rounds are 3 to 15 ms),
-// and a wait that does run into it costs one more decode of the batch with re-decoded predecessors, not a wrong sample.
-constexpr uint32_t kHandoffTimeoutTicks = 5000000u;
+// default bound of the wait for a tail from another chunk: 500 ms (100 MHz ticks).  A producer publishes before it waits for
+// anything and is dispatched ahead of its consumers, so a wait is microseconds; the bound has to outlast what can keep a
+// dispatched-ahead producer from running at all -- other kernels holding the chip: one pipeline's index rounds are 3 to 15 ms,
+// but several pipelines or ranks on one GPU (48 lists in flight each) can starve a wavefront for many of those in a row, and a
+// resident batch (dcs_batch_run) that runs into the bound returns DCS_FRAME_TAIL_LOST instead of decoding again as the
+// library's one-shot paths do.  A wait that does run into it costs one more decode of the batch, not a wrong sample.
+constexpr uint32_t kHandoffTimeoutTicks = 50000000u;
 constexpr int kWavesPerBlock = 4;       // wavefronts of a workgroup share one copy of the decode tables in LDS
 #ifndef DCS_ROW_BYTES
 #define DCS_ROW_BYTES 528

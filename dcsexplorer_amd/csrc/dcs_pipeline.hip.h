@@ -251,6 +251,8 @@ static void pipelineIndexer(DcsPipeline *p, int which)
                 p->toIndex.pop_front();
             }
         }
+        if (jobs.empty())       // (the other indexer took every list while this one dropped the mutex in the gather wait)
+            continue;
         const double t0 = nowMs();
         for (const DcsPipeline::JobPtr &j : jobs) j->tIndexStart = t0;
         // stream locations with ABSOLUTE device addresses (the kernel's blob base is address 0); every list's results go to
@@ -426,28 +428,22 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     return st;
 }
 
-// Planner on the device (DCS_PIPE_PLAN_ON_DEVICE), stage B: the list's index records are on the device (an indexer's round
-// put them there); planner, packer and decode kernels and the PCM's way down are queued on the worker's stream, and the one
-// wait is for the PCM.  Returns DCS_OK with *served = false when the arithmetic plan cannot serve the list (DCS_PLAN_*):
-// the caller then takes the host-planned path.
-static DcsStatus pipelineDecodePlanned(DcsPipeline *p, DcsPipeline::Job *job, hipStream_t stream, bool *served)
+// The device planner's stream table (DcsPlanStream, 40 bytes a stream): what the host knows of every stream of a list of
+// whole streams without walking it -- where it lies in the list's blob, its layout, frame count, and the mixing parameters
+// of frame 0 and of every later frame.  Also the first output frame of every stream (n + 1 entries) and the list's totals.
+static DcsStatus planTableFor(const DcsStreamRef *streams, uint32_t n, uint32_t extraFrames, const DcsStreamLoc *locs, const uint64_t *firstRecord,
+                              std::vector<DcsPlanStream> &table, std::vector<uint32_t> &firstJob, uint64_t *nJobsOut, uint64_t *payloadOut,
+                              bool *all94Out, bool *has93aOut)
 {
-    DcsCtx *ctx = p->ctx;
-    *served = false;
-    const double t0 = nowMs();
-    DcsStatus st = DCS_OK;
-    const uint32_t n = job->nStreams;
-    // what the host knows of every stream without walking it
-    thread_local std::vector<DcsPlanStream> table;
     table.resize(n);
-    job->firstJob.resize(static_cast<size_t>(n) + 1);
+    firstJob.resize(static_cast<size_t>(n) + 1);
     uint64_t nJobs = 0, payload = 0;
     bool all94 = true, has93a = false;
     for (uint32_t k = 0 ; k < n ; ++k)
     {
-        const DcsStreamRef &sr = job->streams[k];
+        const DcsStreamRef &sr = streams[k];
         const uint8_t *d = sr.data;
-        const uint32_t len = job->locs[k].len;
+        const uint32_t len = locs[k].len;
         const uint32_t nFrames = (static_cast<uint32_t>(d[0]) << 8) | d[1];
         const bool typeBit = (d[2] & 0x80) != 0;
         const uint32_t h12 = (len > 3 ? d[3] : 0u) | (len > 4 ? d[4] : 0u);
@@ -461,21 +457,43 @@ static DcsStatus pipelineDecodePlanned(DcsPipeline *p, DcsPipeline::Job *job, hi
         t.xform = (os == DCS_OS93A || os == DCS_OS93B) ? DCS_XFORM_93 : DCS_XFORM_94;
         all94 = all94 && t.xform == DCS_XFORM_94;
         has93a = has93a || t.format == DCS_FMT_93A_T1;
-        t.streamOff = job->streamOff[k];
+        t.streamOff = locs[k].off;
         t.len = len;
-        t.firstRecord = static_cast<uint32_t>(job->firstRecord[k]);
+        t.firstRecord = static_cast<uint32_t>(firstRecord[k]);
         t.firstJob = static_cast<uint32_t>(nJobs);
         t.nFrames = nFrames;
         uint16_t mm[2]; uint8_t vs[2];
-        st = dcs_stream_params_from(os, sr.volume, sr.level, sr.channelVolume, 0x7FFF, 2, mm, vs);    // frame 0, and every later frame
+        const DcsStatus st = dcs_stream_params_from(os, sr.volume, sr.level, sr.channelVolume, 0x7FFF, 2, mm, vs);    // frame 0, and every later frame
         if (st != DCS_OK)
             return st;
         t.mixMul0 = mm[0]; t.mixMulN = mm[1]; t.volShift0 = vs[0]; t.volShiftN = vs[1];
-        job->firstJob[k] = static_cast<uint32_t>(nJobs);
-        nJobs += nFrames + job->extraFrames;
+        firstJob[k] = static_cast<uint32_t>(nJobs);
+        nJobs += nFrames + extraFrames;
         payload += len;
     }
-    job->firstJob[n] = static_cast<uint32_t>(nJobs);
+    firstJob[n] = static_cast<uint32_t>(nJobs);
+    *nJobsOut = nJobs; *payloadOut = payload; *all94Out = all94; *has93aOut = has93a;
+    return DCS_OK;
+}
+
+// Planner on the device (DCS_PIPE_PLAN_ON_DEVICE), stage B: the list's index records are on the device (an indexer's round
+// put them there); planner, packer and decode kernels and the PCM's way down are queued on the worker's stream, and the one
+// wait is for the PCM.  Returns DCS_OK with *served = false when the arithmetic plan cannot serve the list (DCS_PLAN_*):
+// the caller then takes the host-planned path.
+static DcsStatus pipelineDecodePlanned(DcsPipeline *p, DcsPipeline::Job *job, hipStream_t stream, bool *served)
+{
+    DcsCtx *ctx = p->ctx;
+    *served = false;
+    const double t0 = nowMs();
+    DcsStatus st = DCS_OK;
+    const uint32_t n = job->nStreams;
+    // what the host knows of every stream without walking it
+    thread_local std::vector<DcsPlanStream> table;
+    uint64_t nJobs = 0, payload = 0;
+    bool all94 = true, has93a = false;
+    st = planTableFor(job->streams, n, job->extraFrames, job->locs.data(), job->firstRecord.data(), table, job->firstJob, &nJobs, &payload, &all94, &has93a);
+    if (st != DCS_OK)
+        return st;
     if (nJobs > 0xFFFFFFFFull || job->totalRec > 0xFFFFFFFFull)
         return DCS_ERR_CAPACITY;
     st = createBatchPlannedOnDevice(ctx, table.data(), n, job->extraFrames, static_cast<uint32_t>(nJobs), static_cast<uint32_t>(job->totalRec), all94,
@@ -822,17 +840,23 @@ DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint
     DcsStatus st = DCS_OK;
     // the index pass over the WHOLE list in one region of the host pool (eight regions of 32 streams each would balance
     // badly over the pool's threads), then the parts go to the workers with their records
+    // (only the host-index path needs them: 148 B per frame, kept per calling thread; the device path leaves them empty)
     thread_local std::vector<DcsFrameIndex> records;
-    std::vector<DcsStreamInfo> infos(nStreams);
-    std::vector<uint64_t> firstRecord(nStreams);
-    uint64_t nRec = 0;
-    for (uint32_t k = 0 ; k < nStreams ; ++k)
+    std::vector<DcsStreamInfo> infos;
+    std::vector<uint64_t> firstRecord;
+    if (!onDevice)
     {
-        firstRecord[k] = nRec;
-        nRec += frames[k] - extraFrames;
+        infos.resize(nStreams);
+        firstRecord.resize(nStreams);
+        uint64_t nRec = 0;
+        for (uint32_t k = 0 ; k < nStreams ; ++k)
+        {
+            firstRecord[k] = nRec;
+            nRec += frames[k] - extraFrames;
+        }
+        if (records.size() < nRec)
+            records.resize(nRec);
     }
-    if (records.size() < nRec)
-        records.resize(nRec);
     const double tI0 = nowMs();
     // a part goes to the workers the moment the last of its streams has been indexed (by whichever pool thread that was):
     // planner, packer, upload and decode of the early parts run under the index pass of the late ones

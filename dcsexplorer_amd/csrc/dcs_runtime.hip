@@ -3,6 +3,7 @@
 // dcs_ctx_create fails and nothing below can run.
 #include <hip/hip_runtime.h>
 #include <time.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -48,14 +49,43 @@ struct DcsCtx
     struct Cached { void *p; size_t cap; };
     std::vector<Cached> devCache, pinCache;
     size_t cachedBytes = 0, cachedPinBytes = 0;
+    // what the cache may keep (set at dcs_ctx_create from the card's free memory and the host's RAM; dcs_ctx_set_cache_limits)
+    size_t devCacheLimit = size_t(4) << 30, pinCacheLimit = size_t(1) << 30;
     // real size of every buffer handed out by cacheAlloc (a reused buffer may be up to twice what was asked for; the
     // callers only remember what they asked for, and the cache must account for what it really holds)
     std::unordered_map<void *, size_t> liveCap;
 };
 
-// bytes kept per context.  Device: a list in flight holds ~80 MB and a pipeline keeps up to 64 of them, and giving a
+// Bytes kept per context.  Device: a list in flight holds ~80 MB and a pipeline keeps up to 64 of them, and giving a
 // buffer back with hipFree waits for the WHOLE device (milliseconds while an index round runs): the card has 288 GB.
-static const size_t kDevCacheLimit = size_t(32) << 30, kPinCacheLimit = size_t(8) << 30;
+// The ceilings are at most these, and less on a small card or host: an eighth of the card's free memory and a sixteenth
+// of the host's RAM at dcs_ctx_create (eight ranks of a node then pin at most half of it between them).
+static const size_t kDevCacheCeiling = size_t(32) << 30, kPinCacheCeiling = size_t(8) << 30;
+
+// give everything the cache holds of one kind back to the runtime (largest first, until `want` bytes could be had or all
+// of it when want == 0); returns the bytes released.  Caller does NOT hold the mutex.
+static size_t cacheTrim(DcsCtx *ctx, bool pinned, size_t want)
+{
+    std::vector<DcsCtx::Cached> victims;
+    {
+        std::lock_guard<std::mutex> lock(ctx->cacheMutex);
+        std::vector<DcsCtx::Cached> &c = pinned ? ctx->pinCache : ctx->devCache;
+        std::sort(c.begin(), c.end(), [](const DcsCtx::Cached &a, const DcsCtx::Cached &b) { return a.cap > b.cap; });
+        size_t got = 0, n = 0;
+        while (n < c.size() && (want == 0 || got < want))
+            got += c[n++].cap;
+        victims.assign(c.begin(), c.begin() + static_cast<long>(n));
+        c.erase(c.begin(), c.begin() + static_cast<long>(n));
+        (pinned ? ctx->cachedPinBytes : ctx->cachedBytes) -= got;
+    }
+    size_t released = 0;
+    for (const DcsCtx::Cached &v : victims)
+    {
+        if (pinned) (void)hipHostFree(v.p); else (void)hipFree(v.p);
+        released += v.cap;
+    }
+    return released;
+}
 
 static hipError_t cacheAlloc(DcsCtx *ctx, bool pinned, void **out, size_t bytes)
 {
@@ -74,7 +104,19 @@ static hipError_t cacheAlloc(DcsCtx *ctx, bool pinned, void **out, size_t bytes)
         return hipSuccess;
     }
     lock.unlock();
-    const hipError_t e = pinned ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+    hipError_t e = pinned ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+    if (e != hipSuccess)
+    {
+        // out of memory while the cache sits on buffers of other sizes (reuse needs cap <= 2 x bytes): give those back,
+        // largest first, and ask again; only when nothing is left to give does the error go to the caller
+        (void)hipGetLastError();
+        while (e != hipSuccess && cacheTrim(ctx, pinned, bytes) != 0)
+        {
+            e = pinned ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+            if (e != hipSuccess)
+                (void)hipGetLastError();
+        }
+    }
     if (e == hipSuccess)
     {
         lock.lock();
@@ -95,7 +137,7 @@ static void cacheFree(DcsCtx *ctx, bool pinned, void *p, size_t cap)
         ctx->liveCap.erase(live);
     }
     size_t &held = pinned ? ctx->cachedPinBytes : ctx->cachedBytes;
-    if (held + cap > (pinned ? kPinCacheLimit : kDevCacheLimit))
+    if (held + cap > (pinned ? ctx->pinCacheLimit : ctx->devCacheLimit))
     {
         if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
         return;
@@ -266,6 +308,10 @@ static const double g_hipSlowUs = getenv("DCS_HIP_SLOW") ? atof(getenv("DCS_HIP_
     } while (0)
 
 extern "C" uint32_t dcs_abi_version(void) { return DCS_ABI_VERSION; }
+#ifndef DCS_BUILD_ID
+#define DCS_BUILD_ID "unknown"
+#endif
+extern "C" const char *dcs_build_id(void) { return DCS_BUILD_ID; }
 
 extern "C" int dcs_device_count(void)
 {
@@ -328,6 +374,14 @@ extern "C" DcsStatus dcs_ctx_create(int deviceId, DcsCtx **out)
     ctx->numCUs = prop.multiProcessorCount;
     DcsStatus st = [&]() -> DcsStatus {
         HIPCHK(ctx, hipSetDevice(deviceId));
+        size_t freeB = 0, totalB = 0;
+        HIPCHK(ctx, hipMemGetInfo(&freeB, &totalB));
+        ctx->devCacheLimit = std::min(kDevCacheCeiling, freeB / 8);
+        const long pages = sysconf(_SC_PHYS_PAGES), pageSize = sysconf(_SC_PAGE_SIZE);
+        if (pages > 0 && pageSize > 0)
+            ctx->pinCacheLimit = std::min(kPinCacheCeiling, static_cast<size_t>(pages) * static_cast<size_t>(pageSize) / 16);
+        if (const char *mb = getenv("DCS_CACHE_DEV_MB")) ctx->devCacheLimit = static_cast<size_t>(atol(mb)) << 20;
+        if (const char *mb = getenv("DCS_CACHE_PIN_MB")) ctx->pinCacheLimit = static_cast<size_t>(atol(mb)) << 20;
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dTables), sizeof(DcsDevTables)));
         HIPCHK(ctx, hipMemcpy(ctx->dTables, &dcsTables(), sizeof(DcsDevTables), hipMemcpyHostToDevice));
@@ -361,6 +415,41 @@ extern "C" void dcs_ctx_destroy(DcsCtx *ctx)
     for (const DcsCtx::Cached &c : ctx->pinCache) (void)hipHostFree(c.p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+extern "C" DcsStatus dcs_ctx_set_cache_limits(DcsCtx *ctx, uint64_t deviceBytes, uint64_t pinnedBytes)
+{
+    if (ctx == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    {
+        std::lock_guard<std::mutex> lock(ctx->cacheMutex);
+        ctx->devCacheLimit = static_cast<size_t>(deviceBytes);
+        ctx->pinCacheLimit = static_cast<size_t>(pinnedBytes);
+    }
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_ctx_trim_cache(DcsCtx *ctx, uint64_t *deviceBytesReleased, uint64_t *pinnedBytesReleased)
+{
+    if (ctx == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    const size_t d = cacheTrim(ctx, false, 0), p = cacheTrim(ctx, true, 0);
+    if (deviceBytesReleased) *deviceBytesReleased = d;
+    if (pinnedBytesReleased) *pinnedBytesReleased = p;
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_ctx_cache_bytes(DcsCtx *ctx, uint64_t *deviceBytes, uint64_t *pinnedBytes, uint64_t *deviceLimit, uint64_t *pinnedLimit)
+{
+    if (ctx == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->cacheMutex);
+    if (deviceBytes) *deviceBytes = ctx->cachedBytes;
+    if (pinnedBytes) *pinnedBytes = ctx->cachedPinBytes;
+    if (deviceLimit) *deviceLimit = ctx->devCacheLimit;
+    if (pinnedLimit) *pinnedLimit = ctx->pinCacheLimit;
+    return DCS_OK;
 }
 
 extern "C" DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw)
@@ -966,6 +1055,42 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
     return DCS_OK;
 }
 
+// What a planned-on-device batch queues in front of its decode launch: packages, error words and hand-off words cleared,
+// one thread per chunk plans (dcsPlanKernel), one wavefront per chunk packs (dcsPackKernel).  `between` (optional) is
+// recorded between planner and packer (the device-path timing, dcs_device_path_run).
+static DcsStatus queuePlanAndPack(DcsBatch *b, uint32_t nStreams, uint32_t extraFrames, const DcsFrameIndex *dRecords, const DcsStreamInfo *dInfos,
+                                  const uint8_t *dBlob, uint64_t blobLen, hipEvent_t between)
+{
+    DcsCtx *ctx = b->ctx;
+    const uint32_t nJobs = b->nJobs;
+    HIPCHK(ctx, hipMemsetAsync(b->dPackages, 0, static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw), b->stream));
+    HIPCHK(ctx, hipMemsetAsync(b->dErr, 0, sizeof(uint32_t) * nJobs, b->stream));
+    HIPCHK(ctx, hipMemsetAsync(b->dHandoff, 0, b->cap[8], b->stream));      // (epoch 0 = never written; the planner's flag word lies behind the last chunk's words)
+    uint32_t *flagWord = reinterpret_cast<uint32_t *>(b->dHandoff + static_cast<size_t>(b->nChunks) * 16) + 2;
+    const uint32_t planBlocks = (b->nChunks + 63) / 64;         // (one wavefront per workgroup: a thread's work is serial, the chunks should spread over the CUs)
+    DcsSlot *dS = static_cast<DcsSlot *>(b->dPlanSlots);
+    DcsPlanSrc *dP = static_cast<DcsPlanSrc *>(b->dPlanSrcs);
+    const DcsPlanStream *dT = static_cast<const DcsPlanStream *>(b->dTable);
+    const uint32_t blocks = (b->nChunks + 3) / 4;
+    if (b->fpw == 16)
+        hipLaunchKernelGGL(dcsPlanKernel<16>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
+    else if (b->fpw == 8)
+        hipLaunchKernelGGL(dcsPlanKernel<8>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
+    else
+        hipLaunchKernelGGL(dcsPlanKernel<4>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
+    HIPCHK(ctx, hipGetLastError());
+    if (between != nullptr)
+        HIPCHK(ctx, hipEventRecord(between, b->stream));
+    if (b->fpw == 16)
+        hipLaunchKernelGGL(dcsPackKernel<16>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+    else if (b->fpw == 8)
+        hipLaunchKernelGGL(dcsPackKernel<8>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+    else
+        hipLaunchKernelGGL(dcsPackKernel<4>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+    HIPCHK(ctx, hipGetLastError());
+    return DCS_OK;
+}
+
 // Plan AND pack on the device (dcsPlanKernel above): nothing of the list's index results is needed on the host.  `table`
 // describes the streams (host memory; copied), dRecords / dInfos are what the index kernel wrote or is still writing on
 // `stream`, dBlob the streams as uploaded.  The planner's flag word (DCS_PLAN_*) is copied to *flagOut (pinned memory of the
@@ -1010,33 +1135,14 @@ static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *ta
         b->dTable = dTable;
         HIPCHK(ctx, copyByKernel(b->stream, dTable, static_cast<uint8_t *>(b->hStage) + 16, tableBytes));
         b->cap[9] = pkgBytes; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPackages), b->cap[9]));
-        HIPCHK(ctx, hipMemsetAsync(b->dPackages, 0, pkgBytes, b->stream));
         b->cap[4] = sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPcm), b->cap[4]));
         b->cap[5] = sizeof(uint32_t) * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dErr), b->cap[5]));
         b->cap[6] = sizeof(int16_t) * 16 * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsOut), b->cap[6]));
-        HIPCHK(ctx, hipMemsetAsync(b->dErr, 0, sizeof(uint32_t) * nJobs, b->stream));
         b->cap[8] = sizeof(unsigned long long) * 16 * (b->nChunks + 1); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dHandoff), b->cap[8]));
-        HIPCHK(ctx, hipMemsetAsync(b->dHandoff, 0, b->cap[8], b->stream));      // (epoch 0 = never written; the planner's flag word lies behind the last chunk's words)
-        uint32_t *flagWord = reinterpret_cast<uint32_t *>(b->dHandoff + static_cast<size_t>(b->nChunks) * 16) + 2;
-        const uint32_t planBlocks = (b->nChunks + 63) / 64;         // (one wavefront per workgroup: a thread's work is serial, the chunks should spread over the CUs)
-        DcsSlot *dS = static_cast<DcsSlot *>(b->dPlanSlots);
-        DcsPlanSrc *dP = static_cast<DcsPlanSrc *>(b->dPlanSrcs);
-        const DcsPlanStream *dT = static_cast<const DcsPlanStream *>(dTable);
-        const uint32_t blocks = (b->nChunks + 3) / 4;
-        if (b->fpw == 16)
         {
-            hipLaunchKernelGGL(dcsPlanKernel<16>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
-            hipLaunchKernelGGL(dcsPackKernel<16>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
-        }
-        else if (b->fpw == 8)
-        {
-            hipLaunchKernelGGL(dcsPlanKernel<8>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
-            hipLaunchKernelGGL(dcsPackKernel<8>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
-        }
-        else
-        {
-            hipLaunchKernelGGL(dcsPlanKernel<4>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
-            hipLaunchKernelGGL(dcsPackKernel<4>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+            const DcsStatus sq = queuePlanAndPack(b, nStreams, extraFrames, dRecords, dInfos, dBlob, blobLen, nullptr);
+            if (sq != DCS_OK)
+                return sq;
         }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipEventCreate(&b->ev0));
@@ -1230,6 +1336,40 @@ extern "C" DcsStatus dcs_batch_time(DcsBatch *b, void *hipStream, int iters, flo
     return DCS_OK;
 }
 
+// `iters` launches dealt round-robin to `n` resident batches on one stream, bracketed by HIP events: with batches whose
+// packages and PCM together exceed the 256 MB Infinity Cache no launch finds its inputs or its outputs' lines in it
+extern "C" DcsStatus dcs_batch_time_rotating(DcsBatch *const *batches, uint32_t n, void *hipStream, int iters, float *avgMs)
+{
+    if (batches == nullptr || n == 0 || iters < 1 || avgMs == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    for (uint32_t k = 0 ; k < n ; ++k)
+        if (batches[k] == nullptr || batches[k]->ctx != batches[0]->ctx)
+            return DCS_ERR_INVALID_ARG;
+    DcsBatch *b0 = batches[0];
+    DcsCtx *ctx = b0->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = hipStream ? static_cast<hipStream_t>(hipStream) : b0->stream;
+    HIPCHK(ctx, hipEventRecord(b0->ev0, stream));
+    for (int i = 0 ; i < iters ; ++i)
+    {
+        const DcsStatus st = launchOnce(batches[static_cast<uint32_t>(i) % n], stream);
+        if (st != DCS_OK)
+            return st;
+    }
+    HIPCHK(ctx, hipEventRecord(b0->ev1, stream));
+    for (uint32_t k = 0 ; k < n ; ++k)
+    {
+        const DcsStatus st = markLaunched(batches[k], stream);
+        if (st != DCS_OK)
+            return st;
+    }
+    HIPCHK(ctx, hipEventSynchronize(b0->ev1));
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, b0->ev0, b0->ev1));
+    *avgMs = ms / static_cast<float>(iters);
+    return DCS_OK;
+}
+
 extern "C" DcsStatus dcs_batch_sync(DcsBatch *b)
 {
     if (b == nullptr)
@@ -1369,6 +1509,8 @@ extern "C" DcsStatus dcs_decode_batch(DcsCtx *ctx,
 static hipError_t launchIndexWave(hipStream_t stream, uintptr_t blobBase, const DcsStreamLoc *dLocs, uint32_t nStreams, const DcsDevTables *dTables,
                                   DcsFrameIndex *dOut, DcsStreamInfo *dInfos, DcsFrameDigest *dDigest, const dcsidx::StreamOut *dOuts = nullptr)
 {
+    if (nStreams == 0)          // (an empty round is no launch: a zero-block grid is an error to some runtimes)
+        return hipSuccess;
     const uint32_t blocks = (nStreams + dcsidx::kWaves - 1) / dcsidx::kWaves;
     hipLaunchKernelGGL(dcsidx::dcsIndexWaveKernel, dim3(blocks), dim3(dcsidx::kWaves * 64), 0, stream, blobBase, dLocs, nStreams, dTables,
                        dOut, dInfos, dDigest, dOuts);
@@ -1533,3 +1675,4 @@ extern "C" DcsStatus dcs_ctx_clock_mhz(DcsCtx *ctx, float *mhzOut)
 }
 
 #include "dcs_pipeline.hip.h"
+#include "dcs_device_path.hip.h"

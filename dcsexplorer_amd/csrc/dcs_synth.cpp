@@ -240,6 +240,8 @@ void synth93(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
         wTyp[b] = P.profile == 1 ? rng.range(5, 9) : P.profile == 2 ? rng.range(1, 3) : rng.range(2, 6);
         int e = clampi(8 - wTyp[b], 1, 8);
         hdr[b] = static_cast<uint8_t>((e << 2) | rng.range(0, 3) | (b >= P.strideFromBand ? 0x40 : 0));
+        if (P.profile == 6)                                 // SURVEY 8(d) Config 2: scale codes uniform in 0x20..0x34
+            hdr[b] = static_cast<uint8_t>(rng.range(0x20, 0x34) | (b >= P.strideFromBand ? 0x40 : 0));
     }
     if (type1)
         hdr[0] |= 0x80;
@@ -263,9 +265,17 @@ void synth93(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
             const int maxCode = type1 ? 16 : 15;
 
             bool wantZero = rng.chance(P.profile == 2 ? 45 : 12) && P.profile != 4;
+            int drawn = -1;
+            if (P.profile == 6)
+            {
+                // SURVEY 8(d) Config 2: type code from {0: 15 %, 1-3: 35 %, 4-6: 40 %, 7-9: 10 %}
+                const int r = static_cast<int>(rng.below(100));
+                drawn = r < 15 ? 0 : r < 50 ? rng.range(1, 3) : r < 90 ? rng.range(4, 6) : rng.range(7, 9);
+                wantZero = drawn == 0;
+            }
             if (reuse)
             {
-                bool again = wantZero || rng.chance(30);
+                bool again = wantZero || (P.profile != 6 && rng.chance(30));
                 w.put(again ? 1 : 0, 1);
                 reuse = again;
             }
@@ -275,6 +285,7 @@ void synth93(const DcsSynthParams &P, Rng &rng, std::vector<uint8_t> &out)
                     : clampi(wTyp[b] + rng.range(-1, 1) - (type1 ? 0 : 1), 1, P.profile >= 3 ? maxCode : 11);
                 if (P.profile == 3 && rng.chance(25)) target = rng.range(0, maxCode);
                 if (P.profile == 4) target = maxCode;       // saturated: the widest samples in every band
+                if (drawn >= 0) target = drawn;
                 if (!type1)
                 {
                     if (rng.chance(20))
@@ -454,12 +465,15 @@ extern "C" DcsStatus dcs_synth_stream(const DcsSynthParams *params, uint8_t *out
     Rng rng(params->seed * 0x2545F4914F6CDD1Dull + static_cast<uint64_t>(params->format) + 1);
     std::vector<uint8_t> out;
     out.reserve(static_cast<size_t>(params->nFrames) * 160 + 64);
-    switch (params->format)
+    DcsSynthParams P = *params;
+    if (P.profile == 6 && P.format != DCS_FMT_93_T0 && P.format != DCS_FMT_93B_T1)
+        P.profile = 0;                                      // profile 6 is a recipe for the 1993 band layouts only
+    switch (P.format)
     {
     case DCS_FMT_93_T0:
-    case DCS_FMT_93B_T1: synth93(*params, rng, out); break;
-    case DCS_FMT_93A_T1: synth93a(*params, rng, out); break;
-    default:             synth94(*params, rng, out); break;
+    case DCS_FMT_93B_T1: synth93(P, rng, out); break;
+    case DCS_FMT_93A_T1: synth93a(P, rng, out); break;
+    default:             synth94(P, rng, out); break;
     }
     *lenOut = out.size();
     if (outBuf == nullptr || cap < out.size())

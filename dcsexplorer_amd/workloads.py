@@ -2,7 +2,8 @@
 stream writer (the reference ships no audio).  Used by bench.py and by the parity tests; everything is
 derived from integer seeds so the GPU box regenerates byte-identical inputs.
 
-  dcs93_4096     configs[1]: 4096 DCS-93 frames = 64 streams x 64 frames, OS93 Type 0
+  dcs93_4096     configs[1]: 4096 DCS-93 frames = 64 streams x 64 frames, OS93 Type 0, to the letter of SURVEY.md section
+                 8(d) Config 2 (12 populated bands, scale codes 0x20..0x34, the stated band-type code mix: synth profile 6)
   dcs94_65536    configs[2]: 65536 1994+ ("DCS-95 format") frames = 256 streams x 256 frames,
                  80 % Type 1 sub-type 3, 10 % Type 1 sub-type 0, 10 % Type 0
   survey3_65536  configs[2] to the letter of SURVEY.md section 8(d), Config 3: the same 256 x 256 frames and layout mix with
@@ -32,9 +33,11 @@ def _splitmix(seed):
 def streams_dcs93_4096(n_streams=64, n_frames=64, first=0):
     out = []
     for k in range(first, first + n_streams):
+        # SURVEY 8(d) Config 2: bands 0-11 populated, 12-15 empty; one stream in ten carries the stride bit on bands >= 6
+        # (a strided Type-0 band spans 32 slots, so the writer keeps as many of the twelve as fit the frame buffer: ten)
         strided = (k % 10) == 9
-        s = D.synth_stream(D.FMT_93_T0, n_frames, seed=0x93020002 + k, nbands=12 if strided else 16,
-                           stride_from=6 if strided else 16, profile=0)
+        s = D.synth_stream(D.FMT_93_T0, n_frames, seed=0x93020002 + k, nbands=12,
+                           stride_from=6 if strided else 16, profile=6)
         out.append((D.OS93A if (k & 1) else D.OS93B, s, 255, 0x64))
     return out
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DCS_ABI_VERSION 6
+#define DCS_ABI_VERSION 7              /* 7: DcsPipelineResult.path, dcs_node_*, cache control (round 4) */
 #define DCS_FRAME_SAMPLES 240          /* PCM samples per frame (DCSDecoder.h:123: 7.68 ms at 31250 Hz) */
 #define DCS_MAX_CHANNELS 8             /* DCSDecoderNative.h:305 */
 
@@ -226,6 +226,16 @@ DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable);
  * on the device (DCS_PIPE_ALL_ON_DEVICE; 3.8 ms for 256 x 256 frames, ~2 CPU-ms); 0: the index pass on the host's worker
  * pool with the parts following it (4.0-4.4 ms, ~45 CPU-ms on 16 threads).  Same PCM either way. */
 DcsStatus dcs_ctx_set_large_list_path(DcsCtx *ctx, int onDevice);
+/* The context keeps device and pinned-host buffers of finished batches and lists for the next ones (hipMalloc / hipFree
+ * cost as much as decoding thousands of frames, and hipFree waits for the whole device).  What it may keep is bounded:
+ * by default min(32 GB, an eighth of the card's free memory at dcs_ctx_create) of device memory and min(8 GB, a
+ * sixteenth of the host's RAM) of pinned memory (environment: DCS_CACHE_DEV_MB / DCS_CACHE_PIN_MB).  An allocation that
+ * fails gives cached buffers back (largest first) and is tried again before DCS_ERR_NO_MEMORY reaches the caller.
+ * dcs_ctx_trim_cache releases everything the cache holds now (a pipeline does that when it is destroyed);
+ * dcs_ctx_cache_bytes reports what it holds and the limits.  Output pointers may be NULL. */
+DcsStatus dcs_ctx_set_cache_limits(DcsCtx *ctx, uint64_t deviceBytes, uint64_t pinnedBytes);
+DcsStatus dcs_ctx_trim_cache(DcsCtx *ctx, uint64_t *deviceBytesReleased, uint64_t *pinnedBytesReleased);
+DcsStatus dcs_ctx_cache_bytes(DcsCtx *ctx, uint64_t *deviceBytes, uint64_t *pinnedBytes, uint64_t *deviceLimit, uint64_t *pinnedLimit);
 
 /* One-shot convenience: host buffers in, host buffers out (H2D, kernel, D2H on the context's
  * stream, synchronous).  pcmOut = nJobs x 240 int16; errOut (optional) = nJobs x uint32 DCS_FRAME_*.
@@ -255,7 +265,7 @@ DcsStatus dcs_batch_create(DcsCtx *ctx,
 void      dcs_batch_destroy(DcsBatch *batch);
 /* Enqueue the decode on `hipStream` (a hipStream_t passed as void*; NULL = the context's stream).
  * Asynchronous: returns after the launch.
- * A frame whose predecessor's overlap tail comes from another wavefront of the launch waits for it at most 50 ms; if it
+ * A frame whose predecessor's overlap tail comes from another wavefront of the launch waits for it at most 500 ms; if it
  * does not come (no measured case; the bound covers hardware that dispatched workgroups out of order) the frame's error
  * word carries DCS_FRAME_FATAL | DCS_FRAME_TAIL_LOST and its first 16 samples lack the overlap -- nothing else is
  * affected.  A caller of the resident-batch entries who sees that flag creates the batch again after
@@ -268,6 +278,10 @@ DcsStatus dcs_batch_run_many(DcsBatch *batch, void *hipStream, int count);
 /* Run `iters` times bracketed by HIP events on the same stream and return the average kernel
  * duration in milliseconds (what bench.py's roofline block divides by). */
 DcsStatus dcs_batch_time(DcsBatch *batch, void *hipStream, int iters, float *avgMs);
+/* The same with the `iters` launches dealt round-robin to `n` resident batches of one context: when their packages and PCM
+ * together exceed the 256 MB Infinity Cache, no launch finds its inputs (or the lines of its outputs) there -- the kernel
+ * time on COLD inputs (bench.py --rotate, roofline_cold). */
+DcsStatus dcs_batch_time_rotating(DcsBatch *const *batches, uint32_t n, void *hipStream, int iters, float *avgMs);
 DcsStatus dcs_batch_sync(DcsBatch *batch);
 DcsStatus dcs_batch_download(DcsBatch *batch, int16_t *pcmOut, uint32_t *errOut, int16_t *tailsOut);
 /* the same without the copy into caller memory: PCM (and error words) in pinned host memory owned by the batch,
@@ -287,7 +301,7 @@ int       dcs_batch_frames_per_wave(const DcsBatch *batch);     /* the kernel va
 /* shader clock (MHz) the chip holds under an integer VALU load on every SIMD (a probe kernel of a few hundred
  * microseconds; not part of the decode path): turns a kernel duration into cycles */
 DcsStatus dcs_ctx_clock_mhz(DcsCtx *ctx, float *mhzOut);
-/* test hooks: bound of a consumer's wait for a tail from another chunk in microseconds (0 = the default, 50 ms), and
+/* test hooks: bound of a consumer's wait for a tail from another chunk in microseconds (0 = the default, 500 ms), and
  * dropExports != 0: no chunk publishes its tail, so every such wait runs into the bound (DCS_FRAME_TAIL_LOST) */
 DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t handoffTimeoutUs, int dropExports);
 
@@ -374,6 +388,29 @@ DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth /* 1..64 lists in flight */
 void      dcs_pipeline_destroy(DcsPipeline *p);
 DcsStatus dcs_pipeline_submit(DcsPipeline *p, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames);
 DcsStatus dcs_pipeline_collect(DcsPipeline *p, DcsPipelineResult *out);
+
+/* The whole device path of one list of whole streams, RESIDENT: stream bytes in HBM -> PCM in HBM, nothing over PCIe.
+ * What the reference does per stream -- the GetStreamInfo walk that finds every frame (DCSDecoderNative.cpp:1486-1537), then
+ * DecompressFrame + TransformFrame per frame (:1546-1589, :272-278) -- as four kernels on one HIP stream: index walk (one
+ * wavefront per stream), chunk planner, packer, decode.  create uploads the streams once and runs one pass (same PCM as
+ * dcs_decode_streams; DCS_ERR_BAD_STREAM if the device planner cannot serve the list, see DCS_PIPE_PLAN_ON_DEVICE);
+ * run queues `iters` passes back to back and reports the average time of a pass, and of each kernel from HIP events around
+ * it (five further passes); download copies the last pass's PCM (nFrames x 240), error words and the first output frame of
+ * every stream (nStreams + 1) to the host.  A measurement and test entry (bench.py device_full_path); lists in flight with
+ * host buffers on both ends are dcs_pipeline's job. */
+typedef struct DcsDevicePath DcsDevicePath;
+typedef struct DcsDevicePathTimes
+{
+    float    passMs;                   /* index + plan + pack + decode, average over the back-to-back passes            */
+    float    indexMs, planMs, packMs, decodeMs;     /* per kernel (plan includes clearing packages, error and hand-off words) */
+    uint32_t planFlags;                /* DCS_PLAN_*: 0 = the device planner served the list                            */
+    uint32_t nStreams, nFrames, framesPerWave;
+    uint64_t algorithmicBytes;         /* SURVEY 8(d) bytes of one pass (as dcs_batch_algorithmic_bytes)                */
+} DcsDevicePathTimes;
+DcsStatus dcs_device_path_create(DcsCtx *ctx, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, DcsDevicePath **out);
+DcsStatus dcs_device_path_run(DcsDevicePath *path, int iters, DcsDevicePathTimes *times);
+DcsStatus dcs_device_path_download(DcsDevicePath *path, int16_t *pcmOut, uint32_t *errOut, uint32_t *frameOffsets);
+void      dcs_device_path_destroy(DcsDevicePath *path);
 
 /* The stream loop of `DCSExplorer --extract-streams` exactly (DCSExplorer.cpp:1628-1907): ONE decoder
  * object plays the streams one after the other -- LoadAudioStream(0, ptr, level), nFrames + extraFrames
@@ -544,8 +581,8 @@ DcsStatus   dcs_seq_decode(DcsCtx *ctx, DcsSequencer *seq, int16_t *pcmOut, size
  * frames, ClearTracks() after each of the last two.  Whatever a track leaves behind (channel state, mixing levels, a
  * deferred track, the overlap tail) is what the next one starts from, as there.  The sequencer runs all of it ahead on
  * the host and the frames of every track are decoded in ONE kernel launch.  pcmOut receives the tracks back to back,
- * frameOffsets (n + 1, optional) the first frame of each; hostBytes / nHostBytes (optional) what the decoder sent to the
- * host meanwhile, ticks counted from the first track's first frame. */
+ * frameOffsets (n + 1, optional) the first frame of each.  (What the decoder sends to the host meanwhile is not returned
+ * here: a caller that wants it drives a DcsSequencer itself and reads dcs_seq_host_bytes.) */
 DcsStatus   dcs_extract_tracks(DcsCtx *ctx, const DcsRomSet *rs, const DcsExtractTrack *items, uint32_t n,
                                int16_t *pcmOut, size_t pcmCapFrames, uint32_t *frameOffsets, uint32_t *errOut);
 
@@ -584,7 +621,11 @@ typedef struct DcsSynthParams
                                           the largest frames the formats can express, ~500 bytes),
                                           5 = SURVEY config 3 (1994+ layouts: band-type deltas 0 / +-1 / +-2 /
                                           other at 70 / 20 / 8 / 2 %, a quarter of the Huffman-coded values
-                                          zero, ~120 bytes a frame with 12 bands; other layouts as 0)       */
+                                          zero, ~120 bytes a frame with 12 bands; other layouts as 0),
+                                          6 = SURVEY config 2 (1993 band layouts: scale codes uniform in
+                                          0x20..0x34, band-type codes 0 / 1-3 / 4-6 / 7-9 at 15 / 35 / 40 /
+                                          10 %, sub-type changes with probability 0.2, samples uniform in
+                                          the signed range of their width; other layouts as 0)              */
     int32_t  reserved;
 } DcsSynthParams;
 
@@ -620,6 +661,9 @@ DcsStatus dcs_pack_chunks_device(DcsCtx *ctx, const DcsFrameJob *jobs, uint32_t 
                                  uint8_t *out, size_t cap, uint32_t *nChunksOut, uint32_t *packageBytesOut);
 
 uint32_t dcs_abi_version(void);
+/* a digest of the sources and compiler flags this library was built from (16 hex digits).  Counter profiles under
+ * profiles/ carry the id of the library they were taken with; bench.py reports them only for a library with that id. */
+const char *dcs_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,9 @@ def test_library_exports_every_declared_symbol(dcs):
 
 
 def test_abi_version_and_struct_sizes(dcs):
-    assert dcs.load_library().dcs_abi_version() == 6
+    hdr = open(os.path.join(ROOT, "include", "dcs_hip.h")).read()
+    declared = int(re.search(r"#define\s+DCS_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert dcs.load_library().dcs_abi_version() == declared == dcs.api.ABI_VERSION == 7
     assert dcs.SRC_DTYPE.itemsize == 160
     assert dcs.JOB_DTYPE.itemsize == 16
     assert dcs.INDEX_DTYPE.itemsize == 148
@@ -68,3 +70,23 @@ def test_product_reads_no_test_data():
             text = open(os.path.join(pkg, f)).read()
             assert '"tests"' not in text and "tests/golden/" not in text.replace("tests/golden/encoder_golden.npz (made", "").replace(
                 "tests/golden/make_encoder_golden.py", "").replace("with tests/golden/encoder_golden.npz", ""), f
+
+
+def test_counter_profiles_are_tied_to_the_library_build(dcs, tmp_path):
+    """bench.py reports committed PMC counters only for the library build they were taken with (dcs_build_id): counters
+    of another build -- the kernel edited, tools/prof.sh not run again -- are withheld with a note, never reported stale"""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    bid = dcs.build_id()
+    assert re.fullmatch(r"[0-9a-f]{16}", bid)
+    json.dump({"traffic_bytes_fetch_x2": 1.0, "lib_build_id": bid, "lib_sha256": "0" * 64}, open(tmp_path / "traffic_same.json", "w"))
+    json.dump({"traffic_bytes_fetch_x2": 1.0, "lib_build_id": "f" * 16, "lib_sha256": "0" * 64}, open(tmp_path / "traffic_other.json", "w"))
+    json.dump({"traffic_bytes_fetch_x2": 1.0}, open(tmp_path / "traffic_untagged.json", "w"))
+    t, note = bench.load_counters("same", str(tmp_path))
+    assert t is not None and note is None
+    for stale in ("other", "untagged"):
+        t, note = bench.load_counters(stale, str(tmp_path))
+        assert t is None and "withheld" in note
+    assert bench.load_counters("absent", str(tmp_path)) == (None, None)

@@ -328,7 +328,7 @@ def test_one_call_on_a_large_list_goes_through_the_pipeline_in_parts(gpu_ctx, or
 def test_bench_two_ranks_on_one_gpu_runs_launcher_ranks_and_kernel(tmp_path):
     """bench.py --gpus 2 --share-gpu: the launcher starts its two ranks (gloo carries barrier and max; both decode on GPU 0),
     every rank times its K launches, and every rank runs a pipeline of its own for the N-rank end_to_end figure: the line
-    says n_gpus 2, carries per-rank host figures, and rank 0's PCM equals the reference's hashes"""
+    says n_gpus 2, carries per-rank host figures, and EVERY rank's PCM equals the reference's hashes of its range"""
     import subprocess
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "1",
@@ -337,8 +337,68 @@ def test_bench_two_ranks_on_one_gpu_runs_launcher_ranks_and_kernel(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["bit_exact"] is True and "share_gpu" in out
+    assert out["bit_exact_ranks"] == [True, True]           # every rank held ITS streams' PCM against the reference's hashes
     assert out["value"] > 1e9 and out["config"]["frames_all_ranks_per_step"] == 2 * out["config"]["frames_rank0_per_step"]
     e = out["end_to_end"]
     assert e["sustained"]["ranks"] == 2 and len(e["per_rank"]) == 2 and e["usable_cpus"] >= 1
     assert all(p["worker_host_ms"] > 0 and p["cpu_ms_per_list"] > 0 for p in e["per_rank"])
     assert e["sustained"]["value"] > 1e9
+
+
+def test_full_size_corpus_through_the_pipeline_matches_reference_hashes(gpu_ctx, oracle):
+    """BASELINE configs[4] at SURVEY 8(d) Config 5's size: 29 titles x 600 streams of U[20, 2000] frames = 17 667 184 frames,
+    all six layouts.  One title per list through dcs_pipeline (index walk, planner and packer on the device, two lists in
+    flight); EVERY stream's PCM hash equals the hash of the unmodified reference's PCM (tests/golden/corpus_golden_full.json,
+    made by tests/golden/make_corpus_golden.py --full).  The reference loop is DCSExplorer.cpp:1628-1907."""
+    from concurrent.futures import ThreadPoolExecutor
+    g = json.load(open(os.path.join(GOLD, "corpus_golden_full.json")))
+    spec = g["corpus"]
+    assert (spec["titles"], spec["streams_per_title"]) == (29, 600) and g["streams"] == 17400 and g["frames"] == 17667184
+    manifest = workloads.corpus_manifest(**spec)
+    per = spec["streams_per_title"]
+    pipe = gpu_ctx.pipeline(2, index_on_device=True, pack_on_device=True, plan_on_device=True)
+    pool = ThreadPoolExecutor(max_workers=min(16, D.host_threads()))
+    frames, bad, on_device = 0, [], 0
+
+    def check(t):
+        nonlocal frames, on_device
+        pcm, err, first, _, _ = pipe.collect()
+        on_device += int(pipe.last_path == 7)
+        assert not err.any(), "title %d: error flags" % t
+        got = list(pool.map(lambda k: "%016x" % oracle.fnv1a64(pcm[first[k]:first[k + 1]]), range(per)))
+        want = g["stream_hashes"][t * per:(t + 1) * per]
+        bad.extend(t * per + k for k in range(per) if got[k] != want[k])
+        frames += int(first[-1])
+
+    for t in range(spec["titles"]):
+        pipe.submit(workloads.corpus_streams(manifest, t * per, (t + 1) * per))     # (blocks while two lists are in flight)
+        if t >= 1:
+            check(t - 1)
+    check(spec["titles"] - 1)
+    pipe.close()
+    pool.shutdown()
+    assert not bad, "%d streams differ from the reference, first %s" % (len(bad), bad[:8])
+    assert frames == g["frames"]
+    assert on_device >= spec["titles"] - 2, "only %d of %d lists took the device path" % (on_device, spec["titles"])
+
+
+@pytest.mark.parametrize("extra", [0, 2])
+def test_device_path_resident_streams_to_resident_pcm(gpu_ctx, oracle, corpus, extra):
+    """dcs_device_path: the streams uploaded once, then index walk, planner, packer and decode kernels back to back with
+    nothing crossing PCIe -- the PCM of dcs_decode_streams (and therefore the reference's), on the first pass and after
+    timed passes; per-kernel times come back positive and add up to about a pass"""
+    g, manifest, streams = corpus
+    part = streams[100:180]                     # ragged, several layouts
+    want_pcm, want_err, want_first = gpu_ctx.decode_streams(part, extra_frames=extra)
+    path = gpu_ctx.device_path(part, extra_frames=extra)
+    pcm, err, first = path.download()
+    assert np.array_equal(first, want_first) and np.array_equal(err, want_err) and np.array_equal(pcm, want_pcm)
+    t = path.run(6)
+    assert t["planFlags"] == 0 and t["nStreams"] == len(part) and t["nFrames"] == want_pcm.shape[0]
+    assert t["indexMs"] > 0 and t["planMs"] > 0 and t["packMs"] > 0 and t["decodeMs"] > 0
+    assert 0.5 * t["passMs"] < t["indexMs"] + t["planMs"] + t["packMs"] + t["decodeMs"] < 2.0 * t["passMs"]
+    pcm, err, first = path.download()
+    assert np.array_equal(pcm, want_pcm) and not err.any()
+    if extra == 0:
+        assert stream_hashes(oracle, pcm, first) == g["stream_hashes"][100:180]
+    path.close()

@@ -89,3 +89,47 @@ def test_oracle_matches_reference_hashes_of_the_realistic_workload(oracle, encod
     assert len(streams) == want["streams"]
     got = ["%016x" % oracle.fnv1a64(oracle.decode(os_, vol, [s], [lvl], (s[0] << 8) | s[1])) for os_, s, vol, lvl in streams]
     assert got == want["stream_hashes"]
+
+
+def test_rank_goldens_cover_eight_ranks_and_rank_0_is_the_workload_golden():
+    """tests/golden/rank_golden_hashes.json (make_rank_golden.py): what bench.py --gpus N holds every rank's PCM against.
+    Rank 0's streams are the workload itself, so its hashes must be the committed workload hashes; ranks differ."""
+    import json, os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rg = json.load(open(os.path.join(G, "rank_golden_hashes.json")))
+    wl = json.load(open(os.path.join(G, "dcs_golden_hashes.json")))["workloads"]
+    wl.update(json.load(open(os.path.join(G, "encoder_golden.json")))["workloads"])
+    assert rg["ranks"] == 8
+    for name in ("survey3_65536", "dcs94_65536", "dcs93_4096", "mixed_16384", "realistic_65536"):
+        per_rank = rg["workloads"][name]["rank_stream_hashes"]
+        assert len(per_rank) == 8 and per_rank[0] == wl[name]["stream_hashes"]
+        assert all(len(r) == len(per_rank[0]) for r in per_rank)
+        if name != "realistic_65536":                       # (24 recordings replicated: ranks repeat recordings at other volumes)
+            assert len({h for r in per_rank for h in r}) == 8 * len(per_rank[0])
+
+
+def test_rank_goldens_equal_the_oracle_on_a_sample_of_every_rank(oracle):
+    """the restatement reproduces the reference's hashes for streams of ranks 1..7 too (CPU, a few streams per rank)"""
+    import json, os
+    from dcsexplorer_amd import sharding
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rg = json.load(open(os.path.join(G, "rank_golden_hashes.json")))
+    for name in ("survey3_65536", "dcs93_4096", "mixed_16384"):
+        for r in (1, 4, 7):
+            streams = sharding.rank_streams(name, r)
+            for k in (0, len(streams) // 2 + 1, len(streams) - 1):
+                os_, data, vol, lvl = streams[k]
+                nf = (data[0] << 8) | data[1]
+                assert "%016x" % oracle.fnv1a64(oracle.decode(os_, vol, [data], [lvl], nf)) == rg["workloads"][name]["rank_stream_hashes"][r][k]
+
+
+def test_full_corpus_golden_is_the_reduced_corpus_grown():
+    """corpus_golden_full.json: SURVEY 8(d) Config 5 at its stated size; same recipe and seeds as the reduced corpus, so
+    stream k of title t of the reduced corpus is stream k of title t of the full one"""
+    import json, os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    full = json.load(open(os.path.join(G, "corpus_golden_full.json")))
+    small = json.load(open(os.path.join(G, "corpus_golden.json")))
+    assert full["streams"] == 29 * 600 == len(full["stream_hashes"]) and full["frames"] == 17667184
+    for t in range(29):
+        assert full["stream_hashes"][t * 600:t * 600 + 20] == small["stream_hashes"][t * 20:(t + 1) * 20]

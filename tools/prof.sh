@@ -17,8 +17,8 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
 done
 cd $OUT
 # compact summaries
-python3 - <<'PY'
-import csv, glob, collections, os
+DCS_REPO=$(dirname $(dirname $(readlink -f $0))) DCS_WL=$WL DCS_EXTRA="$*" python3 - <<'PY'
+import csv, glob, collections, os, sys
 out = open("summary.txt", "w")
 for f in glob.glob("trace/**/*kernel_stats.csv", recursive=True):
     out.write("== %s\n" % f); out.write(open(f).read())
@@ -56,5 +56,10 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             d[k] = vals[k]
     if "trace_avg_ns" in vals:
         d["trace_avg_ns"] = vals["trace_avg_ns"]; d["trace_calls"] = vals["trace_calls"]
+    # which binary and which workload these counters belong to: bench.py reports them only for a library with this id
+    sys.path.insert(0, os.environ["DCS_REPO"])
+    import dcsexplorer_amd as D
+    d["workload"] = os.environ["DCS_WL"]; d["bench_args"] = os.environ.get("DCS_EXTRA", "")
+    d["lib_build_id"] = D.build_id(); d["lib_sha256"] = D.lib_sha256()
     json.dump(d, open("traffic.json", "w"))
 PY
