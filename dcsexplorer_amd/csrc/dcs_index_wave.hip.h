@@ -44,7 +44,7 @@ struct IndexLds
     uint16_t fast94[256];
     uint16_t trie94[DCS_TRIE94_MAX];
     uint8_t multi94[6][1 << DCS_IDX_MULTI_BITS];
-    uint32_t ring[kWaves][kRingDw + 2];     // (slot 0 once more behind the end: a gather reads two neighbours with one instruction)
+    uint32_t ring[kWaves][kRingDw + 4];     // (slots 0..2 once more behind the end: a gather reads four neighbours without wrapping)
     uint32_t rec[kWaves][kRecDw];
 };
 
@@ -133,8 +133,8 @@ struct WaveBits
     {
         const uint32_t slot = d & (kRingDw - 1);
         ring[slot] = v;
-        if (slot == 0)
-            ring[kRingDw] = v;
+        if (slot < 3)
+            ring[kRingDw + slot] = v;
     }
     __device__ __forceinline__ void reload()
     {
@@ -243,6 +243,17 @@ struct WaveBits
         const uint32_t h = p[0], l = p[1];
         return static_cast<uint32_t>((((static_cast<uint64_t>(h) << 32) | l) << (a & 31)) >> 32);
     }
+    // the same for TWO positions per lane: `off` and `off` + 64 bits behind the current position (128 candidates a look)
+    __device__ __forceinline__ void gather32x2(uint32_t off, uint32_t &lo, uint32_t &hi64) const
+    {
+        const uint32_t a = payBit + pos + off;
+        const uint32_t d = a >> 5;
+        const uint32_t *p = ring + (d & (kRingDw - 1));
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
+        const uint32_t sh = a & 31;
+        lo = static_cast<uint32_t>((((static_cast<uint64_t>(w0) << 32) | w1) << sh) >> 32);
+        hi64 = static_cast<uint32_t>((((static_cast<uint64_t>(w2) << 32) | w3) << sh) >> 32);
+    }
     __device__ __forceinline__ uint32_t bitPos() const { return pos; }
     __device__ __forceinline__ uint32_t bytesFetched(uint32_t payOff) const { return any ? payOff + (hi >> 3) + 1 : payOff; }
 };
@@ -278,28 +289,34 @@ struct Walk
 
 // The chain through the candidates: state = bits walked | samples left - 1 << 16, v = per lane the length of the code
 // that starts there minus, in the upper half, the samples it stands for.  Ends when the samples run out (sign bit) or
-// the walk leaves the 64 candidates (bit 6); `se` = the last candidate taken.  Written out because the loop the
+// the walk leaves the candidates (bit 6 or 7); `se` = the last candidate taken.  Written out because the loop the
 // compiler makes of it pays a taken branch per symbol (62 cycles a symbol measured, against ~20 for this form: eight
-// steps in a row whose exits are branches NOT taken).
-__device__ __forceinline__ void chain(uint32_t v, uint32_t &state, uint32_t &se)
-{
-    uint32_t t;
-#define DCS_CHAIN_STEP                                  \
+// steps in a row whose exits are branches NOT taken).  (An exit through the CARRY of the add -- entries that leave the
+// candidates poisoned, the sample count running up to an overflow -- saves the s_and per step and was measured in round 4:
+// 2.21 against 2.16 ms for one list, nothing at 8 192 streams; the poisoning costs the look what the steps save.)
+#define DCS_CHAIN_STEP(MASK)                            \
         "v_readlane_b32 %[se], %[v], %[st]\n\t"          \
         "s_add_u32 %[st], %[st], %[se]\n\t"              \
-        "s_and_b32 %[t], %[st], 0x80000040\n\t"          \
+        "s_and_b32 %[t], %[st], " MASK "\n\t"            \
         "s_cbranch_scc1 2f\n\t"
-    asm volatile("s_nop 0\n"
-                 "1:\n\t"
-                 DCS_CHAIN_STEP DCS_CHAIN_STEP DCS_CHAIN_STEP DCS_CHAIN_STEP
-                 DCS_CHAIN_STEP DCS_CHAIN_STEP DCS_CHAIN_STEP DCS_CHAIN_STEP
-                 "s_branch 1b\n"
-                 "2:\n\t"
-                 : [st] "+s"(state), [se] "=&s"(se), [t] "=&s"(t)
-                 : [v] "v"(v)
+#define DCS_CHAIN_BODY(MASK)                                                                        \
+    uint32_t t;                                                                                     \
+    asm volatile("s_nop 0\n"                                                                        \
+                 "1:\n\t"                                                                           \
+                 DCS_CHAIN_STEP(MASK) DCS_CHAIN_STEP(MASK) DCS_CHAIN_STEP(MASK) DCS_CHAIN_STEP(MASK) \
+                 DCS_CHAIN_STEP(MASK) DCS_CHAIN_STEP(MASK) DCS_CHAIN_STEP(MASK) DCS_CHAIN_STEP(MASK) \
+                 "s_branch 1b\n"                                                                    \
+                 "2:\n\t"                                                                           \
+                 : [st] "+s"(state), [se] "=&s"(se), [t] "=&s"(t)                                   \
+                 : [v] "v"(v)                                                                       \
                  : "scc");
+// (v_readlane takes the lane from the low six bits of `state`: candidates 0..63 of the look)
+__device__ __forceinline__ void chain(uint32_t v, uint32_t &state, uint32_t &se) { DCS_CHAIN_BODY("0x80000040") }
+// the same through candidates 64..127 of a two-candidates-per-lane look (`v` = lane l: candidate 64 + l): ends when the
+// samples run out or the walk leaves the 128 candidates (bit 7)
+__device__ __forceinline__ void chainHi(uint32_t v, uint32_t &state, uint32_t &se) { DCS_CHAIN_BODY("0x80000080") }
+#undef DCS_CHAIN_BODY
 #undef DCS_CHAIN_STEP
-}
 
 // A run of Huffman-coded samples (:2186-2225): symbols from the current position until `rem` samples are accounted for
 // (a two-zeros code counts for two).  Returns what is left: 0, or -1 when the last code was a two-zeros code with one
@@ -316,29 +333,38 @@ __device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *book, uint32
     do
     {
         b.ensure();
-        // lane l: the code(s) that would start l bits from here -- length, and minus the samples in the upper half
-        const uint32_t w = b.gather32(b.lane);
-        const uint32_t e = book[w >> (32 - maxBits)];
-        const uint32_t m = multi[w >> (32 - DCS_IDX_MULTI_BITS)];
-        asm volatile("" :: "v"(e), "v"(m));         // both reads on their way before anything waits (the compiler otherwise
-                                                    // sinks the second one behind the test of `rem`: a second LDS round trip)
-        const uint32_t vSingle = ((e >> 8) & 0x1Fu) - ((e >> 13) == 2 ? 0x20000u : 0x10000u);
-        const uint32_t vMulti = (m & 15u) - ((m >> 4) << 16);
+        // lane l: the code(s) that would start l bits and 64 + l bits from here -- length, and minus the samples in the upper
+        // half.  128 candidates a look: a band of sixteen samples is 80 to 90 bits on average, so most runs need one look
+        // (with 64 candidates the second look's two LDS round trips were a quarter of a run)
+        uint32_t wLo, wHi;
+        b.gather32x2(b.lane, wLo, wHi);
+        const uint32_t eLo = book[wLo >> (32 - maxBits)], eHi = book[wHi >> (32 - maxBits)];
+        const uint32_t mLo = multi[wLo >> (32 - DCS_IDX_MULTI_BITS)], mHi = multi[wHi >> (32 - DCS_IDX_MULTI_BITS)];
+        asm volatile("" :: "v"(eLo), "v"(mLo), "v"(eHi), "v"(mHi));     // all four reads on their way before anything waits
+        const uint32_t vSingleLo = ((eLo >> 8) & 0x1Fu) - ((eLo >> 13) == 2 ? 0x20000u : 0x10000u);
+        const uint32_t vSingleHi = ((eHi >> 8) & 0x1Fu) - ((eHi >> 13) == 2 ? 0x20000u : 0x10000u);
+        const uint32_t vMultiLo = (mLo & 15u) - ((mLo >> 4) << 16);
+        const uint32_t vMultiHi = (mHi & 15u) - ((mHi >> 4) << 16);
         // state: bits walked | samples left - 1 (single) or - 1 - DCS_IDX_MULTI_SAMPLES (multi) << 16.  A chain ends when
-        // the samples run out (sign) or the walk leaves the 64 candidates (bit 6).
-        uint32_t off = 0, se;
+        // the samples run out (sign) or the walk leaves its 64 candidates (bit 6 for the first half, bit 7 for the second).
+        uint32_t off = 0, se = 0;
         IDX_T0(tChain);
         if (rem > DCS_IDX_MULTI_SAMPLES)
         {
             uint32_t state = static_cast<uint32_t>(rem - 1 - DCS_IDX_MULTI_SAMPLES) << 16;
-            chain(vMulti, state, se);
+            chain(vMultiLo, state, se);
+            if (static_cast<int32_t>(state) >= 0)           // (left the first 64 candidates with samples to go)
+                chainHi(vMultiHi, state, se);
             off = state & 0xFFFFu;
             rem = (static_cast<int32_t>(state) >> 16) + 1 + DCS_IDX_MULTI_SAMPLES;
         }
-        if (rem <= DCS_IDX_MULTI_SAMPLES && off < 64)
+        if (rem <= DCS_IDX_MULTI_SAMPLES && off < 128)
         {
             uint32_t state = off | (static_cast<uint32_t>(rem - 1) << 16);
-            chain(vSingle, state, se);
+            if (off < 64)
+                chain(vSingleLo, state, se);
+            if (static_cast<int32_t>(state) >= 0)           // (the first half left, or never entered)
+                chainHi(vSingleHi, state, se);
             off = state & 0xFFFFu;
             rem = (static_cast<int32_t>(state) >> 16) + 1;
             b.hi = umax(b.hi, b.pos + off - (se & 0xFFFFu) + maxBits);      // the last symbol's look
@@ -353,8 +379,8 @@ __device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *book, uint32
 }
 
 // The frame header of a 1994+ frame: one band-type delta code per populated band (:1780-1834), lane k < nBands
-// receives code k's payload (delta + 16).  Candidates through the first-level table; the chain takes eight codes
-// without a test (eight codes of at most eight bits stay inside the 64 candidates) and only marks where it has been;
+// receives code k's payload (delta + 16).  Candidates through the first-level table; the chain takes sixteen steps
+// without a test (it does not move on from a candidate beyond 55, so it stays inside the 64) and only marks where it has been;
 // which code is whose follows from the marks afterwards (a lane's rank among them), and the payloads travel to
 // their bands' lanes in one ds_permute.  A code longer than eight bits (rare) sends the rest of the header through the
 // trie on the scalar unit.
@@ -369,7 +395,9 @@ __device__ __forceinline__ uint32_t headerDeltas94(Walk &s)
         b.ensure();
         const uint32_t e = s.L->fast94[b.gather32(lane) >> 24];
         const bool leaf = (e & 0x8000u) != 0;
-        const uint32_t vLen = leaf ? (e >> 8) & 0xFu : 0u;      // (the chain does not get past a long code)
+        // (the chain does not get past a long code, nor past candidate 55: a code is at most eight bits, so sixteen steps that
+        // never start beyond 55 stay inside the 64 candidates without a test)
+        const uint32_t vLen = (leaf && lane < 56) ? (e >> 8) & 0xFu : 0u;
         unsigned long long marks = 0;
         uint32_t off = 0, t;
 #define DCS_HDR_STEP                                    \
@@ -378,11 +406,15 @@ __device__ __forceinline__ uint32_t headerDeltas94(Walk &s)
             "s_add_u32 %[off], %[off], %[t]\n\t"
         asm volatile("s_nop 0\n\t"
                      DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP
+                     DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP DCS_HDR_STEP
                      : [m] "+s"(marks), [off] "+s"(off), [t] "=&s"(t)
                      : [v] "v"(vLen)
                      : "scc");
 #undef DCS_HDR_STEP
-        const int n = s.nBands - band < 8 ? s.nBands - band : 8;
+        // the codes this round takes: those that start below candidate 56, as many as there are bands left
+        const int want = s.nBands - band;
+        const int low = __builtin_popcountll(marks & 0x00FFFFFFFFFFFFFFull);
+        const int n = want < low ? want : low;
         const bool marked = ((marks >> lane) & 1) != 0;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(marks >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(marks), 0u));
         const bool mine = marked && static_cast<int>(rank) < n;
@@ -398,8 +430,8 @@ __device__ __forceinline__ uint32_t headerDeltas94(Walk &s)
                                                                                  static_cast<int>(e & 0xFFu)));
         if (static_cast<int>(lane) >= band && static_cast<int>(lane) < band + n)
             vDelta = got;
-        // where the next code starts: behind the eighth, or at the mark of rank n
-        const uint32_t adv = n == 8 ? off : static_cast<uint32_t>(__builtin_ctzll(__ballot(marked && static_cast<int>(rank) == n)));
+        // where the next code starts: behind the sixteenth, or at the mark of rank n (which may be the one the chain stopped at)
+        const uint32_t adv = n == 16 ? off : static_cast<uint32_t>(__builtin_ctzll(__ballot(marked && static_cast<int>(rank) == n)));
         b.pos += adv;
         b.have = 0;
         band += n;
@@ -730,7 +762,9 @@ struct StreamOut
 };
 
 // stream k of the launch is walked by wavefront k
-__global__ __launch_bounds__(kWaves * 64) void dcsIndexWaveKernel(uintptr_t blobBase, const DcsStreamLoc *locs, uint32_t nStreams,
+// (eight wavefronts per SIMD: the walk's scalar state would otherwise take 106 SGPRs, and a gfx9 SIMD's 800 hold only seven such
+// wavefronts -- a launch of 8 192 streams, eight per SIMD, then ran in two generations; three more spilled SGPRs are cheaper)
+__global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void dcsIndexWaveKernel(uintptr_t blobBase, const DcsStreamLoc *locs, uint32_t nStreams,
                                                                   const DcsDevTables *tables, DcsFrameIndex *out, DcsStreamInfo *infos,
                                                                   DcsFrameDigest *digest, const StreamOut *outs)
 {

@@ -3,6 +3,7 @@
 # Writes rocprofv3 kernel-trace stats and PMC counter passes under gpurun_out/prof_<tag>/.
 set -u
 TAG=${1:-r1}; WL=${2:-survey3_65536}; shift 2 || true
+REPO=$PWD
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -17,7 +18,7 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
 done
 cd $OUT
 # compact summaries
-DCS_REPO=$(dirname $(dirname $(readlink -f $0))) DCS_WL=$WL DCS_EXTRA="$*" python3 - <<'PY'
+DCS_REPO=$REPO DCS_WL=$WL DCS_EXTRA="$*" python3 - <<'PY'
 import csv, glob, collections, os, sys
 out = open("summary.txt", "w")
 for f in glob.glob("trace/**/*kernel_stats.csv", recursive=True):
