@@ -68,6 +68,9 @@ def parse_args(argv=None):
     ap.add_argument("--rotate", type=int, default=8, help="roofline_cold: this many distinct resident batches of the workload (the shares of "
                     "ranks 0..N-1, together larger than the 256 MB Infinity Cache) launched round-robin, so that no launch finds its "
                     "inputs or outputs cached (0: skip; one rank only; not for the corpus, whose one batch is larger than the cache)")
+    ap.add_argument("--node", type=int, default=0, help="end_to_end.node: ONE process drives this many contexts through dcs_node (persistent "
+                    "contexts, a pipeline each, lists dealt by frames in flight, threads and pinned buffers on each GPU's NUMA node); with "
+                    "--share-gpu every context is on GPU 0 (test on a one-GPU box), else context d is on GPU d")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the N-rank path (gloo, no GPU, no kernel)")
     ap.add_argument("--share-gpu", action="store_true", help="testing on a one-GPU box: every rank decodes on GPU 0 and gloo carries the "
                     "barrier and the max (RCCL needs one device per rank); exercises the whole N-rank path but is no scaling measurement")
@@ -428,6 +431,44 @@ def device_full_path(ctx, args, streams, n_frames, rank_golden):
     return out
 
 
+# --------------------------------------------------------------------------------------------- one process, several GPUs
+def end_to_end_node(args, streams, n_frames, depth=24, lists=192):
+    """host buffers in, PCM in pinned memory out through dcs_node: one process, `--node` persistent contexts with a pipeline each
+    (index pass, planner and packer on the device), lists dealt to the device with the fewest frames in flight, collected in
+    submission order.  CPU-milliseconds per list of the whole process next to the rate (the N-process form: end_to_end of
+    `--gpus N`)."""
+    import resource
+    import dcsexplorer_amd as D
+    devs = [0] * args.node if args.share_gpu else list(range(args.node))
+    refs, keep = D.make_refs(streams)
+    node = D.Node(devs, depth=depth)
+    inflight = depth * len(devs)
+    for _ in range(inflight):
+        node.submit_refs(refs, len(streams))
+    for _ in range(inflight):
+        node.collect()
+    n_lists = max(lists, 2 * inflight)
+    r0 = resource.getrusage(resource.RUSAGE_SELF)
+    t0 = time.perf_counter()
+    done = 0
+    for k in range(n_lists):
+        node.submit_refs(refs, len(streams))
+        if k >= inflight - 1:
+            node.collect(); done += 1
+    while done < n_lists:
+        node.collect(); done += 1
+    dt = time.perf_counter() - t0
+    r1 = resource.getrusage(resource.RUSAGE_SELF)
+    info = [node.device_info(i) for i in range(len(devs))]
+    node.close()
+    cpu_ms = ((r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)) * 1e3 / n_lists
+    return {"value": n_lists * n_frames * 240 / dt, "unit": "samples/s", "ms_per_list": dt / n_lists * 1e3, "cpu_ms_per_list": cpu_ms,
+            "contexts": len(devs), "devices": devs, "depth_per_context": depth, "lists": n_lists,
+            "per_context": [{"device": d, "numa_node": nn, "lists": int(done_)} for d, nn, done_ in info],
+            "what": "dcs_node: one process, persistent contexts with a dcs_pipeline each (index pass, planner and packer on the device), lists dealt by "
+                    "frames in flight, results in submission order; worker and indexer threads and pinned buffers on each GPU's NUMA node"}
+
+
 # --------------------------------------------------------------------------------------------- parity of what was timed
 def verify_rank(args, batch, b, streams, rank, corpus, golden_range):
     """-> (ok, note) for THIS rank's share: per-stream FNV-1a-64 of the PCM the timed launches left in HBM against the
@@ -708,6 +749,8 @@ def run_rank(args):
             out["end_to_end"] = end_to_end(ctx, streams, n_frames, depth=args.e2e_depth, dev_depth=args.e2e_device_depth)
         if e2e_ranks is not None:
             out["end_to_end"] = e2e_ranks
+        if world == 1 and args.node > 0 and not corpus:
+            out.setdefault("end_to_end", {})["node"] = end_to_end_node(args, streams, n_frames, depth=max(4, args.e2e_device_depth // 2))
         if world == 1 and not args.no_cpu_baseline:
             sample = streams if not corpus else streams[:64]
             out["cpu_baseline"] = cpu_baseline(sample)

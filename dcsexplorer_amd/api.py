@@ -123,6 +123,8 @@ EXPORTS = [
     "dcs_ctx_set_frames_per_chunk", "dcs_index_stream_literal", "dcs_pack_chunks_device", "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_set_test_hooks",
     "dcs_pipeline_create", "dcs_pipeline_destroy", "dcs_pipeline_submit", "dcs_pipeline_collect",
     "dcs_device_path_create", "dcs_device_path_run", "dcs_device_path_download", "dcs_device_path_destroy",
+    "dcs_node_create", "dcs_node_destroy", "dcs_node_submit", "dcs_node_collect", "dcs_node_num_devices", "dcs_node_device_info",
+    "dcs_node_last_error", "dcs_node_cache_release", "dcs_device_numa_node",
 ]
 
 
@@ -346,6 +348,24 @@ def load_library():
     L.dcs_device_path_download.argtypes = [vp, vp, vp, vp]
     L.dcs_device_path_destroy.restype = None
     L.dcs_device_path_destroy.argtypes = [vp]
+    L.dcs_node_create.restype = i32
+    L.dcs_node_create.argtypes = [vp, u32, ctypes.c_int, u32, ctypes.POINTER(vp)]
+    L.dcs_node_destroy.restype = None
+    L.dcs_node_destroy.argtypes = [vp]
+    L.dcs_node_submit.restype = i32
+    L.dcs_node_submit.argtypes = [vp, vp, u32, u32]
+    L.dcs_node_collect.restype = i32
+    L.dcs_node_collect.argtypes = [vp, ctypes.POINTER(PipelineResult), ctypes.POINTER(ctypes.c_int)]
+    L.dcs_node_num_devices.restype = u32
+    L.dcs_node_num_devices.argtypes = [vp]
+    L.dcs_node_device_info.restype = i32
+    L.dcs_node_device_info.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]
+    L.dcs_node_last_error.restype = ctypes.c_char_p
+    L.dcs_node_last_error.argtypes = [vp]
+    L.dcs_node_cache_release.restype = None
+    L.dcs_node_cache_release.argtypes = []
+    L.dcs_device_numa_node.restype = ctypes.c_int
+    L.dcs_device_numa_node.argtypes = [ctypes.c_int]
     L.dcs_host_threads.restype = ctypes.c_int
     L.dcs_host_threads.argtypes = []
     L.dcs_partition_streams.restype = i32
@@ -996,6 +1016,73 @@ class DevicePath:
             self.close()
         except Exception:
             pass
+
+
+class Node:
+    """DcsNode: several GPUs of one node behind one object -- persistent contexts, one pipeline each, lists dealt to the
+    least-loaded device, results in submission order (include/dcs_hip.h dcs_node_*)"""
+
+    def __init__(self, device_ids, depth=8, index_on_device=True, pack_on_device=True, plan_on_device=True):
+        self.L = load_library()
+        devs = np.ascontiguousarray(device_ids, dtype=np.int32)
+        flags = (1 if index_on_device else 0) | (2 if pack_on_device else 0) | (4 if plan_on_device else 0)
+        h = ctypes.c_void_p()
+        st = self.L.dcs_node_create(_ptr(devs), devs.size, depth, flags, ctypes.byref(h))
+        if st != 0:
+            raise DcsError(st, "dcs_node_create")
+        self.h = h
+        self.n_devices = int(devs.size)
+        self._keep = []
+
+    def _check(self, st):
+        if st != 0:
+            raise DcsError(st, self.L.dcs_node_last_error(self.h).decode(errors="replace"))
+
+    def submit_refs(self, refs, n, extra_frames=0, keep=None):
+        self._keep.append((refs, keep))
+        self._check(self.L.dcs_node_submit(self.h, refs, n, extra_frames))
+
+    def submit(self, streams, extra_frames=0):
+        streams = list(streams)
+        refs, keep = _stream_refs(streams)
+        self.submit_refs(refs, len(streams), extra_frames, keep)
+
+    def collect(self):
+        """-> (pcm, err, first frame of each stream, hostMs, deviceMs, index of the device that decoded the list)"""
+        r = PipelineResult()
+        dev = ctypes.c_int(-1)
+        st = self.L.dcs_node_collect(self.h, ctypes.byref(r), ctypes.byref(dev))
+        if self._keep:
+            self._keep.pop(0)
+        self._check(st)
+        self.last_path = int(r.path)
+        pcm = _view(r.pcm, ctypes.c_int16, np.int16, (r.nFrames, FRAME_SAMPLES))
+        err = _view(r.err, ctypes.c_uint32, np.uint32, (r.nFrames,))
+        first = _view(r.frameOffsets, ctypes.c_uint32, np.uint32, (r.nStreams + 1,))
+        return pcm, err, first, r.hostMs, r.deviceMs, dev.value
+
+    def device_info(self, index):
+        """-> (HIP device id, NUMA node or -1, lists decoded so far)"""
+        d, nn, done = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_uint64(0)
+        self._check(self.L.dcs_node_device_info(self.h, index, ctypes.byref(d), ctypes.byref(nn), ctypes.byref(done)))
+        return d.value, nn.value, done.value
+
+    def close(self):
+        if self.h:
+            self.L.dcs_node_destroy(self.h)
+            self.h = None
+            self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def node_cache_release():
+    """destroy the contexts dcs_decode_streams_sharded keeps per device list"""
+    load_library().dcs_node_cache_release()
 
 
 def make_refs(streams):

@@ -1676,3 +1676,4 @@ extern "C" DcsStatus dcs_ctx_clock_mhz(DcsCtx *ctx, float *mhzOut)
 
 #include "dcs_pipeline.hip.h"
 #include "dcs_device_path.hip.h"
+#include "dcs_node.hip.h"

@@ -301,60 +301,4 @@ extern "C" DcsStatus dcs_partition_streams(const uint32_t *frameCounts, uint32_t
     return DCS_OK;
 }
 
-extern "C" DcsStatus dcs_decode_streams_sharded(const int *deviceIds, uint32_t nDevices,
-                                                const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames,
-                                                int16_t *pcmOut, size_t pcmCapFrames, uint32_t *frameOffsets,
-                                                uint32_t *errOut, uint32_t *firstStreamOfDevice)
-{
-    if (deviceIds == nullptr || nDevices == 0 || streams == nullptr || nStreams == 0 || pcmOut == nullptr)
-        return DCS_ERR_INVALID_ARG;
-    // output frames per stream, from the U16 prefix (what dcs_decode_streams will produce)
-    std::vector<uint32_t> frames(nStreams);
-    std::vector<uint64_t> firstFrame(static_cast<size_t>(nStreams) + 1, 0);
-    for (uint32_t k = 0 ; k < nStreams ; ++k)
-    {
-        if (streams[k].data == nullptr || streams[k].len < 3)
-            return DCS_ERR_INVALID_ARG;
-        frames[k] = ((static_cast<uint32_t>(streams[k].data[0]) << 8) | streams[k].data[1]) + extraFrames;
-        firstFrame[k + 1] = firstFrame[k] + frames[k];
-    }
-    if (firstFrame[nStreams] > pcmCapFrames || firstFrame[nStreams] > 0xFFFFFFFFull)
-        return DCS_ERR_CAPACITY;
-    std::vector<uint32_t> cut(static_cast<size_t>(nDevices) + 1);
-    DcsStatus st = dcs_partition_streams(frames.data(), nStreams, nDevices, cut.data());
-    if (st != DCS_OK)
-        return st;
-    if (firstStreamOfDevice != nullptr)
-        memcpy(firstStreamOfDevice, cut.data(), sizeof(uint32_t) * cut.size());
-
-    // one host thread and one context per device; every range writes its own part of the outputs
-    std::vector<DcsStatus> status(nDevices, DCS_OK);
-    std::vector<std::thread> workers;
-    for (uint32_t d = 0 ; d < nDevices ; ++d)
-    {
-        const uint32_t lo = cut[d], hi = cut[d + 1];
-        if (lo == hi)
-            continue;
-        workers.emplace_back([&, d, lo, hi]() {
-            DcsCtx *ctx = nullptr;
-            DcsStatus s = dcs_ctx_create(deviceIds[d], &ctx);
-            if (s == DCS_OK)
-            {
-                const uint64_t f0 = firstFrame[lo];
-                s = dcs_decode_streams(ctx, streams + lo, hi - lo, extraFrames, pcmOut + f0 * DCS_FRAME_SAMPLES,
-                                       static_cast<size_t>(firstFrame[hi] - f0), nullptr, errOut ? errOut + f0 : nullptr);
-                dcs_ctx_destroy(ctx);
-            }
-            status[d] = s;
-        });
-    }
-    for (std::thread &w : workers)
-        w.join();
-    if (frameOffsets != nullptr)
-        for (uint32_t k = 0 ; k <= nStreams ; ++k)
-            frameOffsets[k] = static_cast<uint32_t>(firstFrame[k]);
-    for (uint32_t d = 0 ; d < nDevices ; ++d)
-        if (status[d] != DCS_OK)
-            return status[d];
-    return DCS_OK;
-}
+// (dcs_decode_streams_sharded: csrc/dcs_node.hip.h -- on the persistent contexts of a node-level object)

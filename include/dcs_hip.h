@@ -335,15 +335,41 @@ DcsStatus dcs_count_stream_frames(const DcsStreamRef *streams, uint32_t nStreams
  * dcs_partition_streams: cut a list of nStreams streams with the given frame counts into nParts contiguous ranges
  * balanced by total frame count; range r is [firstStreamOut[r], firstStreamOut[r+1]) (nParts + 1 entries; a range
  * may be empty).  Every range's frame total lies within one (longest) stream of total / nParts.
- * dcs_decode_streams_sharded: dcs_decode_streams over the devices `deviceIds` -- one host thread and one context
- * per device, range d decoded on device d into its own part of pcmOut / errOut.  Same output layout and the same
- * PCM as dcs_decode_streams on one device.  firstStreamOfDevice (optional, nDevices + 1) receives the cut. */
+ * dcs_decode_streams_sharded: dcs_decode_streams over the devices `deviceIds` -- range d decoded on device d into its
+ * own part of pcmOut / errOut, one host thread per device (bound to the CPUs of that GPU's NUMA node).  The contexts
+ * live in a node-level object (below) that the library keeps per device list from the first call on, so a call creates
+ * no context, stream or pipeline; dcs_node_cache_release() destroys them (call it before unloading the library, or
+ * never).  Same output layout and the same PCM as dcs_decode_streams on one device.  firstStreamOfDevice (optional,
+ * nDevices + 1) receives the cut. */
 DcsStatus dcs_partition_streams(const uint32_t *frameCounts, uint32_t nStreams, uint32_t nParts,
                                 uint32_t *firstStreamOut);
 DcsStatus dcs_decode_streams_sharded(const int *deviceIds, uint32_t nDevices,
                                      const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames,
                                      int16_t *pcmOut, size_t pcmCapFrames, uint32_t *frameOffsets,
                                      uint32_t *errOut, uint32_t *firstStreamOfDevice);
+
+void      dcs_node_cache_release(void);
+
+/* Several GPUs behind one object (the loop being spread out is DCSExplorer.cpp:1628-1907).  N persistent
+ * contexts -- deviceIds may name a device more than once -- with one dcs_pipeline each (`depth` lists in flight per
+ * device, DCS_PIPE_* flags; created with the first list).  dcs_node_submit deals a list to the device with the fewest
+ * FRAMES in flight among those with room and blocks while none has room; dcs_node_collect returns the results in
+ * SUBMISSION order whatever device decoded them (pointers into that device's pinned memory, valid until the next
+ * collect; deviceIndexOut, optional, says which entry of deviceIds it was).  Streams must stay valid until collected;
+ * submit and collect from one thread each.  No data moves between the devices: no collective, no peer copies.
+ * Placement: every context, its pipeline's worker and indexer threads and the pinned buffers they allocate are created
+ * from a thread bound to the CPUs of the GPU's NUMA node (dcs_device_numa_node: /sys/bus/pci/devices/<addr>/numa_node; the
+ * default local memory policy then places the buffers there).  Where the node is unknown (-1) nothing is bound. */
+typedef struct DcsNode DcsNode;
+struct DcsPipelineResult;
+int         dcs_device_numa_node(int deviceId);
+DcsStatus   dcs_node_create(const int *deviceIds, uint32_t nDevices, int depth, uint32_t flags, DcsNode **out);
+void        dcs_node_destroy(DcsNode *node);
+DcsStatus   dcs_node_submit(DcsNode *node, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames);
+DcsStatus   dcs_node_collect(DcsNode *node, struct DcsPipelineResult *out, int *deviceIndexOut);
+uint32_t    dcs_node_num_devices(const DcsNode *node);
+DcsStatus   dcs_node_device_info(const DcsNode *node, uint32_t index, int *deviceId, int *numaNode, uint64_t *listsDone);
+const char *dcs_node_last_error(const DcsNode *node);
 
 /* Batches in flight.  A caller with many lists of streams to decode (an archive, a ROM corpus) submits them and
  * collects their PCM in submission order; `depth` host worker threads each take a list through index pass, mixing

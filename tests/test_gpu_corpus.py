@@ -402,3 +402,61 @@ def test_device_path_resident_streams_to_resident_pcm(gpu_ctx, oracle, corpus, e
     if extra == 0:
         assert stream_hashes(oracle, pcm, first) == g["stream_hashes"][100:180]
     path.close()
+
+
+def _rss_kb():
+    for line in open("/proc/self/status"):
+        if line.startswith("VmRSS:"):
+            return int(line.split()[1])
+    return 0
+
+
+def test_node_two_contexts_on_one_device_200_lists_in_submission_order_memory_flat(gpu_ctx):
+    """dcs_node with the device list [0, 0]: two persistent contexts with a pipeline each, lists dealt by frames in flight;
+    200 lists of unlike sizes come back in SUBMISSION order with the single-context PCM, both contexts take their share, and
+    the process's resident memory does not grow over the second hundred"""
+    import zlib
+    base = workloads.streams_mixed_16384(n_streams=30, n_frames=48)
+    variants = [base[:30], base[3:14], base[10:30] + base[:6], base[5:6]]
+    want = [zlib.crc32(gpu_ctx.decode_streams(v, extra_frames=1)[0].tobytes()) for v in variants]
+    refs = [D.make_refs(v) for v in variants]
+    node = D.Node([0, 0], depth=6)
+    assert node.n_devices == 2 and node.device_info(0)[0] == 0 and node.device_info(1)[0] == 0
+    n, inflight, done, bad, by_dev = 200, 10, 0, 0, [0, 0]
+    rss_mid = None
+    for k in range(n):
+        v = (k * 7 + k // 5) % 4
+        node.submit_refs(refs[v][0], len(variants[v]), extra_frames=1)
+        if k >= inflight - 1:
+            pcm, err, first, _, _, dev = node.collect()
+            w = (done * 7 + done // 5) % 4
+            bad += zlib.crc32(pcm.tobytes()) != want[w] or bool(err.any()) or len(first) != len(variants[w]) + 1
+            by_dev[dev] += 1; done += 1
+            if done == n // 2:
+                rss_mid = _rss_kb()
+    while done < n:
+        pcm, err, first, _, _, dev = node.collect()
+        w = (done * 7 + done // 5) % 4
+        bad += zlib.crc32(pcm.tobytes()) != want[w] or bool(err.any())
+        by_dev[dev] += 1; done += 1
+    rss_end = _rss_kb()
+    assert bad == 0
+    assert min(by_dev) >= n // 5, "lists per context: %s" % by_dev
+    assert [node.device_info(i)[2] for i in range(2)] == by_dev
+    assert rss_end - rss_mid < 64 * 1024, "resident memory grew by %d KB over the second hundred lists" % (rss_end - rss_mid)
+    node.close()
+
+
+def test_sharded_entry_keeps_its_contexts_between_calls(oracle, corpus):
+    """dcs_decode_streams_sharded runs on the persistent contexts of a cached node: the second call with the same device
+    list creates nothing (markedly faster than the first, which creates two contexts), same PCM both times"""
+    import time
+    g, manifest, streams = corpus
+    sub = streams[200:260]
+    D.node_cache_release()
+    t0 = time.perf_counter(); a = D.decode_streams_sharded([0, 0], sub); t1 = time.perf_counter()
+    b = D.decode_streams_sharded([0, 0], sub); t2 = time.perf_counter()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and not a[1].any()
+    assert stream_hashes(oracle, b[0], b[2]) == g["stream_hashes"][200:260]
+    assert (t2 - t1) < (t1 - t0), "second call %.1f ms, first %.1f ms" % ((t2 - t1) * 1e3, (t1 - t0) * 1e3)
+    D.node_cache_release()
