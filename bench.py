@@ -33,6 +33,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# hardware queues the HIP runtime spreads this process's streams over (read when the runtime initialises, i.e. before torch's
+# first GPU call; libdcs_hip.so sets the same default when it is loaded first -- dcs_runtime.hip): the pipelines of end_to_end
+# run a dozen streams, and with the default of 4 a list's chain of short kernels waits behind other lists' copies
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 DEFAULT_WORKLOAD = "survey3_65536"  # BASELINE.json configs[2] as SURVEY.md 8(d) specifies it (12 bands, 120 B/frame): the configuration the roofline is quoted on
@@ -157,11 +161,14 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
     def sustained(depth, on_device, pack_on_device=False, plan_on_device=False):
         pipe = ctx.pipeline(depth, index_on_device=on_device, pack_on_device=pack_on_device, plan_on_device=plan_on_device)
         host_ms, dev_ms = [], []
-        for _ in range(depth):                                  # warm: every worker has had a list
-            pipe.submit_refs(refs, len(streams))
-        for _ in range(depth):
-            pipe.collect()
-        n_lists = max(lists, 3 * depth)
+        # warm: the context's buffer cache takes about two rounds of `depth` lists until nothing is allocated any more, and every
+        # stream's first copies are slow (profiles/NOTES.md 17); the rate of a job of thousands of lists is the one behind that
+        for _ in range(2):
+            for _ in range(depth):
+                pipe.submit_refs(refs, len(streams))
+            for _ in range(depth):
+                pipe.collect()
+        n_lists = max(lists, 3 * depth) if not on_device else max(lists, 400)
         t0 = time.perf_counter()
         done = 0
         for k in range(n_lists):
@@ -180,6 +187,7 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
                 "planner": "device (dcsPlanKernel, one thread per chunk)" if plan_on_device else "host",
                 "worker_host_ms": sum(host_ms) / len(host_ms), "worker_device_ms": sum(dev_ms) / len(dev_ms)}
 
+    link_gbps = ctx.link_rate()                                # GB/s, device -> pinned host memory, measured now
     host_idx = sustained(depth, False)
     dev_idx = sustained(dev_depth, True)
     dev_pack = sustained(dev_depth, True, True)
@@ -192,7 +200,12 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
                              "kernel + D2H + copy out (a list this large goes through the context's own pipeline in eight parts, index walk, planner and "
                              "packer on the device)"},
             "sustained": dict(best, what="dcs_pipeline, the fastest of the four configurations below: lists in flight, PCM "
-                                         "returned in pinned memory, collected in submission order"),
+                                         "returned in pinned memory, collected in submission order",
+                              link={"pcm_bytes_per_list": n_frames * 480, "measured_GBps": link_gbps,
+                                    "floor_ms_per_list": n_frames * 480 / (link_gbps * 1e6) if link_gbps else None,
+                                    "frac_of_link": (n_frames * 480 / (link_gbps * 1e6)) / best["ms_per_list"] if link_gbps else None,
+                                    "note": "the PCM of a list (480 B per frame) has to cross PCIe once; measured_GBps: device to pinned host memory in this "
+                                            "run, one 64 MB copy at a time (dcs_ctx_link_rate)"}),
             "sustained_host_index": host_idx, "sustained_device_index": dev_idx, "sustained_device_index_and_pack": dev_pack,
             "sustained_device_index_plan_and_pack": dev_plan,
             "note": "worker_host_ms / worker_device_ms: wall time one worker thread spends per list in host preparation "
@@ -600,7 +613,7 @@ def run_rank(args):
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(1, args.steps) * 1e3,
                               "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int16",
                               "data": "synthetic", "rehearsal": "CPU rehearsal of the N-rank path: no GPU, no kernel, nothing measured",
-                              "config": {"workload": args.workload, "frames_per_rank": counts, "frames_total": sum(counts),
+                              "config": {"workload": args.workload, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "frames_per_rank": counts, "frames_total": sum(counts),
                                          "partition": "range over streams, balanced by frames, no collective"}}))
         if world > 1:
             dist.destroy_process_group()
@@ -712,7 +725,7 @@ def run_rank(args):
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
-            "config": {"workload": args.workload,
+            "config": {"workload": args.workload, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "workload_is": {"survey3_65536": "BASELINE configs[2] as SURVEY.md 8(d) Config 3 specifies it: 256 streams x 256 1994+ frames, 80 % Type 1 "
                                                         "sub-type 3, 10 % Type 1 sub-type 0, 10 % Type 0, 12 populated bands, 120 B/frame",
                                        "dcs94_65536": "BASELINE configs[2], the form of rounds 1 and 2: 16 populated bands, 96 B/frame"}.get(args.workload, args.workload),

@@ -112,7 +112,7 @@ EXPORTS = [
     "dcs_dcsa_header", "dcs_dcsa_parse", "dcs_write_wav", "dcs_write_dcsa", "dcs_frame_diff",
     "dcs_romset_create", "dcs_romset_destroy", "dcs_romset_last_error", "dcs_romset_add_rom", "dcs_romset_load_zip",
     "dcs_romset_load_zip_memory", "dcs_romset_check", "dcs_romset_set_version", "dcs_romset_num_tracks",
-    "dcs_romset_pointer", "dcs_romset_track_info", "dcs_romset_decompile", "dcs_romset_list_streams",
+    "dcs_romset_pointer", "dcs_romset_bytes_behind", "dcs_romset_track_info", "dcs_romset_decompile", "dcs_romset_list_streams",
     "dcs_romset_extract_plan", "dcs_romset_stream_refs", "dcs_romset_extract_tracks_plan", "dcs_extract_tracks",
     "dcs_seq_create", "dcs_seq_destroy", "dcs_seq_last_error", "dcs_seq_set_master_volume", "dcs_seq_set_reported_version",
     "dcs_seq_write_data_port", "dcs_seq_add_track_command", "dcs_seq_clear_tracks", "dcs_seq_load_audio_stream",
@@ -120,7 +120,7 @@ EXPORTS = [
     "dcs_seq_create_standalone", "dcs_seq_load_audio_stream_mem", "dcs_seq_rewind", "dcs_seq_set_rewindable",
     "dcs_seq_tick", "dcs_seq_fatal_tick", "dcs_seq_stream_playing",
     "dcs_host_threads", "dcs_partition_streams", "dcs_decode_streams_sharded",
-    "dcs_ctx_set_frames_per_chunk", "dcs_index_stream_literal", "dcs_pack_chunks_device", "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_set_test_hooks",
+    "dcs_ctx_set_frames_per_chunk", "dcs_index_stream_literal", "dcs_pack_chunks_device", "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_link_rate", "dcs_ctx_set_test_hooks",
     "dcs_pipeline_create", "dcs_pipeline_destroy", "dcs_pipeline_submit", "dcs_pipeline_collect",
     "dcs_device_path_create", "dcs_device_path_run", "dcs_device_path_download", "dcs_device_path_destroy",
     "dcs_node_create", "dcs_node_destroy", "dcs_node_submit", "dcs_node_collect", "dcs_node_num_devices", "dcs_node_device_info",
@@ -330,6 +330,8 @@ def load_library():
     L.dcs_batch_frames_per_wave.argtypes = [vp]
     L.dcs_ctx_clock_mhz.restype = i32
     L.dcs_ctx_clock_mhz.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.dcs_ctx_link_rate.restype = i32
+    L.dcs_ctx_link_rate.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.dcs_ctx_set_test_hooks.restype = i32
     L.dcs_ctx_set_test_hooks.argtypes = [vp, u32, ctypes.c_int]
     L.dcs_pipeline_create.restype = i32
@@ -690,6 +692,12 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def link_rate(self):
+        """GB/s, device memory -> pinned host memory, measured now (dcs_ctx_link_rate)"""
+        v = ctypes.c_float(0)
+        _check(self.L.dcs_ctx_link_rate(self.h, ctypes.byref(v)), self.h)
+        return float(v.value)
 
     def set_cache_limits(self, device_bytes, pinned_bytes):
         _check(self.L.dcs_ctx_set_cache_limits(self.h, int(device_bytes), int(pinned_bytes)), self.h)

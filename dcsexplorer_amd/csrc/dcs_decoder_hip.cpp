@@ -329,7 +329,23 @@ void DCSDecoderHIP::ClearTracks()
     }
 }
 
-DCSDecoderHIP::StreamInfo DCSDecoderHIP::GetStreamInfo(const ROMPointer &p, size_t maxLen)
+// what lies behind a stream pointer: the rest of the ROM image it points into (the base's, or the ROM set's copy), else 64 MB
+size_t DCSDecoderHIP::BytesBehind(const ROMPointer &p) const
+{
+    if (p.IsNull())
+        return 0;
+#ifdef DCSHIP_USE_REFERENCE_BASE
+    for (int i = 0 ; i < 8 ; ++i)
+        if (ROM[i].data != nullptr && p.p >= ROM[i].data && p.p < ROM[i].data + ROM[i].size)
+            return static_cast<size_t>(ROM[i].data + ROM[i].size - p.p);
+#endif
+    const size_t n = roms != nullptr ? dcs_romset_bytes_behind(roms, p.p) : 0;
+    return n != 0 ? n : size_t(1) << 26;
+}
+
+DCSDecoderHIP::StreamInfo DCSDecoderHIP::GetStreamInfo(const ROMPointer &p) { return GetStreamInfoBounded(p, BytesBehind(p)); }
+
+DCSDecoderHIP::StreamInfo DCSDecoderHIP::GetStreamInfoBounded(const ROMPointer &p, size_t maxLen)
 {
     StreamInfo out;
     memset(&out, 0, sizeof(out));
@@ -345,7 +361,9 @@ DCSDecoderHIP::StreamInfo DCSDecoderHIP::GetStreamInfo(const ROMPointer &p, size
     return out;
 }
 
-void DCSDecoderHIP::LoadAudioStream(int ch, const ROMPointer &p, int mixingLevel, size_t maxLen)
+void DCSDecoderHIP::LoadAudioStream(int ch, const ROMPointer &p, int mixingLevel) { LoadAudioStreamBounded(ch, p, mixingLevel, BytesBehind(p)); }
+
+void DCSDecoderHIP::LoadAudioStreamBounded(int ch, const ROMPointer &p, int mixingLevel, size_t maxLen)
 {
     if (seq == nullptr || ch < 0 || ch >= DCS_MAX_CHANNELS || p.IsNull())       // :1390
         return;

@@ -87,7 +87,7 @@ struct DcsPipeline
     JobPtr held;                                    // the list whose result the caller is reading
     std::vector<std::thread> workers;
     std::vector<std::thread> indexers;
-    int nWorkers = 0;
+    int nWorkers = 0, nUploaders = 0;               // (device index pass: the first nUploaders workers do stage A only)
     std::vector<hipStream_t> streams;               // one per worker, and one more for each indexer
     bool quit = false;
 };
@@ -551,14 +551,20 @@ static void pipelineWorker(DcsPipeline *p, int id)
         DcsPipeline::JobPtr job;
         bool stageB = false;
         {
+            // With the index pass on the device the first `nUploaders` workers take ONLY fresh lists (stage A: lay the streams
+            // out, send them up) and the others only indexed ones (stage B, which ends in a wait of milliseconds for the PCM).
+            // When every worker took whatever was there, indexed lists first, the pipeline fell into lock step: all lists in
+            // flight reached stage B together, the fresh ones behind them waited 20 ms for a worker, the indexers ran dry and
+            // then walked everything in a burst (round 4, DCS_PIPE_TRACE=2: rounds of 8 lists back to back, then 20 ms of nothing).
+            const bool takesFresh = !deviceIndex || id < p->nUploaders, takesIndexed = !deviceIndex || id >= p->nUploaders;
             std::unique_lock<std::mutex> lk(p->m);
-            p->work.wait(lk, [&] { return p->quit || !p->indexed.empty() || !p->fresh.empty(); });
-            if (!p->indexed.empty())            // lists that are further along come first
+            p->work.wait(lk, [&] { return p->quit || (takesIndexed && !p->indexed.empty()) || (takesFresh && !p->fresh.empty()); });
+            if (takesIndexed && !p->indexed.empty())            // lists that are further along come first
             {
                 job = p->indexed.front(); p->indexed.pop_front();
                 stageB = true;
             }
-            else if (!p->fresh.empty())
+            else if (takesFresh && !p->fresh.empty())
             {
                 job = p->fresh.front(); p->fresh.pop_front();
             }
@@ -656,6 +662,16 @@ static DcsStatus pipelineCreate(DcsCtx *ctx, int depth, uint32_t flags, DcsPipel
                  : (flags & DCS_PIPE_INDEX_ON_DEVICE) ? std::min(depth, dcs_host_threads() + 4) : depth;
     if (const char *w = getenv("DCS_PIPE_WORKERS"))
         nWorkers = std::max(1, std::min(64, atoi(w)));
+    int nUploaders = 0;
+    if (flags & DCS_PIPE_INDEX_ON_DEVICE)
+    {
+        // stage A costs a worker a quarter to half a millisecond per list: two of them keep up with any rate the link allows
+        nUploaders = (flags & kPipeLatency) ? std::min(depth, 4) : depth >= 4 ? 2 : 1;      // (one waiting caller: its parts go up side by side)
+        if (const char *u = getenv("DCS_PIPE_UPLOADERS"))
+            nUploaders = std::max(1, std::min(8, atoi(u)));
+        nWorkers += nUploaders;
+    }
+    p->nUploaders = nUploaders;
     int prioLeast = 0, prioGreatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest);
     p->nWorkers = nWorkers;
@@ -668,7 +684,12 @@ static DcsStatus pipelineCreate(DcsCtx *ctx, int depth, uint32_t flags, DcsPipel
         // different priorities never share a hardware queue.  Their launches run for milliseconds (a walk is serial per
         // stream, on a handful of lanes), and neither a worker's copies and 40-microsecond kernels nor the other
         // indexer's launch must queue up behind one.
-        const hipError_t e = i >= nWorkers ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, i == nWorkers ? prioLeast : prioGreatest)
+        // (DCS_PIPE_INDEXER_PRIO=ab, a / b one of l(east) g(reatest) n(ormal): the two indexers' priorities, an experiment switch)
+        static const char *prioEnv = getenv("DCS_PIPE_INDEXER_PRIO");
+        auto prioOf = [&](char c, int dflt) { return c == 'l' ? prioLeast : c == 'g' ? prioGreatest : c == 'n' ? (prioLeast + prioGreatest) / 2 : dflt; };
+        const int idxPrio = i == nWorkers ? prioOf(prioEnv && prioEnv[0] ? prioEnv[0] : 0, prioLeast)
+                                          : prioOf(prioEnv && prioEnv[0] && prioEnv[1] ? prioEnv[1] : 0, prioGreatest);
+        const hipError_t e = i >= nWorkers ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, idxPrio)
                                            : hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
         if (e != hipSuccess)
         {
@@ -732,7 +753,7 @@ static DcsStatus pipelineSubmit(DcsPipeline *p, const DcsStreamRef *streams, uin
         p->fresh.push_back(job);
         p->order.push_back(job);
     }
-    p->work.notify_one();
+    p->work.notify_all();           // (workers have roles: the one woken must be one that takes fresh lists)
     return DCS_OK;
 }
 

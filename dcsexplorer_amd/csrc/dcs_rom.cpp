@@ -271,6 +271,20 @@ extern "C" DcsStatus dcs_romset_pointer(const DcsRomSet *rs, uint32_t linear, co
     return DCS_OK;
 }
 
+// bytes from `p` to the end of the ROM image of this set that contains it (0: p points into none of them)
+extern "C" size_t dcs_romset_bytes_behind(const DcsRomSet *rs, const uint8_t *p)
+{
+    if (rs == nullptr || p == nullptr)
+        return 0;
+    for (int c = 0 ; c < 8 ; ++c)
+    {
+        const std::vector<uint8_t> &img = rs->image(c);
+        if (!img.empty() && p >= img.data() && p < img.data() + img.size())
+            return static_cast<size_t>(img.data() + img.size() - p);
+    }
+    return 0;
+}
+
 extern "C" uint32_t dcs_romset_num_tracks(const DcsRomSet *rs) { return rs != nullptr ? rs->nTracks : 0; }
 
 extern "C" DcsStatus dcs_romset_track_info(const DcsRomSet *rs, uint32_t track, DcsTrackInfo *ti)

@@ -269,6 +269,7 @@ struct DcsBatch
     bool launched = false;
     bool downByKernel = false;  // the PCM's way down by dcsCopyKernel instead of the copy engines (the context's own pipeline: one waiting caller)
     bool settled = false;       // a wait has covered everything enqueued for this batch and nothing was enqueued since
+    bool errJoined = false;     // dErr lies behind dPcm in ONE allocation (and hErr behind hPcm): the two come down in one copy
 };
 
 // the device work of the batch's last launch has finished (host-side wait)
@@ -306,6 +307,17 @@ static const double g_hipSlowUs = getenv("DCS_HIP_SLOW") ? atof(getenv("DCS_HIP_
             return DCS_ERR_HIP;                                                                  \
         }                                                                                        \
     } while (0)
+
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and packets of
+// different streams that share a queue run one behind the other.  A pipeline has a dozen streams with chains of short kernels
+// and half-millisecond copies; with eight queues a list's chain stops waiting behind another list's copy (0.75 -> 0.70 ms per
+// list sustained, round 4; sixteen queues showed stalls of seconds).  The variable is read when the runtime initialises, so it
+// is set when this library is loaded -- before any HIP call of a program that links it -- and only if the user has not set it.
+// A host that initialises HIP before loading the library (python: torch first) sets it itself (bench.py does).
+__attribute__((constructor)) static void dcsSetRuntimeDefaults()
+{
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
 
 extern "C" uint32_t dcs_abi_version(void) { return DCS_ABI_VERSION; }
 #ifndef DCS_BUILD_ID
@@ -525,14 +537,15 @@ extern "C" void dcs_batch_destroy(DcsBatch *b)
         if (b->evDone) (void)waitLaunched(b);
         (void)streamWait(b->ctx, b->stream);
     }
-    void *ptrs[] = { b->dBlob, b->dSrcs, b->dTable, b->dTailsIn, b->dPcm, b->dErr, b->dTailsOut, b->dDebug, b->dHandoff, b->dPackages };
+    void *ptrs[] = { b->dBlob, b->dSrcs, b->dTable, b->dTailsIn, b->dPcm, b->errJoined ? nullptr : b->dErr, b->dTailsOut, b->dDebug, b->dHandoff, b->dPackages };
     for (int i = 0 ; i < 10 ; ++i)
         cacheFree(b->ctx, false, ptrs[i], b->cap[i]);
     cacheFree(b->ctx, false, b->dPlanSlots, b->planSlotsCap);
     cacheFree(b->ctx, false, b->dPlanSrcs, b->planSrcsCap);
     cacheFree(b->ctx, true, b->hStage, b->hStageCap);
     cacheFree(b->ctx, true, b->hPcm, b->hCap[0]);
-    cacheFree(b->ctx, true, b->hErr, b->hCap[1]);
+    if (!b->errJoined || b->hCap[1] != 0)
+        cacheFree(b->ctx, true, b->hErr, b->hCap[1]);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->evDone) (void)hipEventDestroy(b->evDone);
@@ -862,7 +875,7 @@ namespace {
 template <int FPW>
 __global__ __launch_bounds__(256) void dcsPlanKernel(const DcsPlanStream *streams, uint32_t nStreams, uint32_t extraFrames, uint32_t nJobs,
                                                       const DcsFrameIndex *records, const DcsStreamInfo *infos,
-                                                      DcsSlot *slots, DcsPlanSrc *srcs, uint32_t *flagWord)
+                                                      DcsSlot *slots, DcsPlanSrc *srcs, uint32_t *flagWord, uint32_t *hostFlag)
 {
     const uint32_t nChunks = (nJobs + FPW - 1) / FPW;
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -959,7 +972,13 @@ __global__ __launch_bounds__(256) void dcsPlanKernel(const DcsPlanStream *stream
     for (int p = 0 ; p < FPW ; ++p)
         slots[static_cast<size_t>(c) * FPW + p] = out[p];
     if (flags != 0)
+    {
         atomicOr(flagWord, flags);
+        // ... and straight into the batch's pinned staging word, so that no copy kernel has to bring it down behind the decode
+        // launch (a plain store: concurrent writers all write non-zero values, and non-zero is all the host asks)
+        if (hostFlag != nullptr)
+            __hip_atomic_store(hostFlag, flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 }   // namespace
 
@@ -1055,6 +1074,18 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
     return DCS_OK;
 }
 
+namespace {
+// three ranges cleared by one launch: a (16-byte units), b (dwords), c (16-byte units)
+__global__ __launch_bounds__(256) void dcsClear3Kernel(uint4 *a, size_t nA16, uint32_t *b, size_t nB4, uint4 *c, size_t nC16)
+{
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x, t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (size_t i = t ; i < nA16 ; i += stride) a[i] = z;
+    for (size_t i = t ; i < nB4 ; i += stride) b[i] = 0;
+    for (size_t i = t ; i < nC16 ; i += stride) c[i] = z;
+}
+}   // namespace
+
 // What a planned-on-device batch queues in front of its decode launch: packages, error words and hand-off words cleared,
 // one thread per chunk plans (dcsPlanKernel), one wavefront per chunk packs (dcsPackKernel).  `between` (optional) is
 // recorded between planner and packer (the device-path timing, dcs_device_path_run).
@@ -1063,9 +1094,16 @@ static DcsStatus queuePlanAndPack(DcsBatch *b, uint32_t nStreams, uint32_t extra
 {
     DcsCtx *ctx = b->ctx;
     const uint32_t nJobs = b->nJobs;
-    HIPCHK(ctx, hipMemsetAsync(b->dPackages, 0, static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw), b->stream));
-    HIPCHK(ctx, hipMemsetAsync(b->dErr, 0, sizeof(uint32_t) * nJobs, b->stream));
-    HIPCHK(ctx, hipMemsetAsync(b->dHandoff, 0, b->cap[8], b->stream));      // (epoch 0 = never written; the planner's flag word lies behind the last chunk's words)
+    // packages, error words and hand-off words cleared by ONE kernel (three hipMemsetAsync were three dispatches in a chain of
+    // ten per list; epoch 0 = never written; the planner's flag word lies behind the last chunk's hand-off words)
+    {
+        const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw), errBytes = sizeof(uint32_t) * nJobs, hoBytes = b->cap[8];
+        const size_t total16 = pkgBytes / 16 + (errBytes + 15) / 16 + hoBytes / 16;
+        const unsigned blocks = static_cast<unsigned>(std::min<size_t>((total16 + 255) / 256, 2048));
+        hipLaunchKernelGGL(dcsClear3Kernel, dim3(blocks), dim3(256), 0, b->stream, reinterpret_cast<uint4 *>(b->dPackages), pkgBytes / 16,
+                           reinterpret_cast<uint32_t *>(b->dErr), errBytes / 4, reinterpret_cast<uint4 *>(b->dHandoff), hoBytes / 16);
+        HIPCHK(ctx, hipGetLastError());
+    }
     uint32_t *flagWord = reinterpret_cast<uint32_t *>(b->dHandoff + static_cast<size_t>(b->nChunks) * 16) + 2;
     const uint32_t planBlocks = (b->nChunks + 63) / 64;         // (one wavefront per workgroup: a thread's work is serial, the chunks should spread over the CUs)
     DcsSlot *dS = static_cast<DcsSlot *>(b->dPlanSlots);
@@ -1073,11 +1111,11 @@ static DcsStatus queuePlanAndPack(DcsBatch *b, uint32_t nStreams, uint32_t extra
     const DcsPlanStream *dT = static_cast<const DcsPlanStream *>(b->dTable);
     const uint32_t blocks = (b->nChunks + 3) / 4;
     if (b->fpw == 16)
-        hipLaunchKernelGGL(dcsPlanKernel<16>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
+        hipLaunchKernelGGL(dcsPlanKernel<16>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord, static_cast<uint32_t *>(b->hStage));
     else if (b->fpw == 8)
-        hipLaunchKernelGGL(dcsPlanKernel<8>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
+        hipLaunchKernelGGL(dcsPlanKernel<8>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord, static_cast<uint32_t *>(b->hStage));
     else
-        hipLaunchKernelGGL(dcsPlanKernel<4>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord);
+        hipLaunchKernelGGL(dcsPlanKernel<4>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord, static_cast<uint32_t *>(b->hStage));
     HIPCHK(ctx, hipGetLastError());
     if (between != nullptr)
         HIPCHK(ctx, hipEventRecord(between, b->stream));
@@ -1135,8 +1173,11 @@ static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *ta
         b->dTable = dTable;
         HIPCHK(ctx, copyByKernel(b->stream, dTable, static_cast<uint8_t *>(b->hStage) + 16, tableBytes));
         b->cap[9] = pkgBytes; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPackages), b->cap[9]));
-        b->cap[4] = sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPcm), b->cap[4]));
-        b->cap[5] = sizeof(uint32_t) * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dErr), b->cap[5]));
+        // (PCM and error words in one allocation: one copy brings both down)
+        b->errJoined = true;
+        b->cap[4] = sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs + sizeof(uint32_t) * nJobs; b->cap[5] = 0;
+        HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPcm), b->cap[4]));
+        b->dErr = reinterpret_cast<uint32_t *>(b->dPcm + static_cast<size_t>(DCS_FRAME_SAMPLES) * nJobs);
         b->cap[6] = sizeof(int16_t) * 16 * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsOut), b->cap[6]));
         b->cap[8] = sizeof(unsigned long long) * 16 * (b->nChunks + 1); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dHandoff), b->cap[8]));
         {
@@ -1164,9 +1205,8 @@ static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *ta
 // read it with batchPlanFlag once the stream has been waited for
 static DcsStatus batchQueuePlanFlag(DcsBatch *b)
 {
-    const uint32_t *flagWord = reinterpret_cast<const uint32_t *>(b->dHandoff + static_cast<size_t>(b->nChunks) * 16) + 2;
-    b->settled = false;
-    HIPCHK(b->ctx, copyByKernel(b->stream, b->hStage, flagWord, sizeof(uint32_t)));
+    // (nothing to queue since round 4: the planner stores a non-zero flag into the pinned word itself)
+    (void)b;
     return DCS_OK;
 }
 static uint32_t batchPlanFlag(const DcsBatch *b) { return *static_cast<const volatile uint32_t *>(b->hStage); }
@@ -1408,10 +1448,19 @@ extern "C" DcsStatus dcs_batch_download_view(DcsBatch *b, const int16_t **pcmOut
     DcsCtx *ctx = b->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t pcmBytes = sizeof(int16_t) * DCS_FRAME_SAMPLES * b->nJobs, errBytes = sizeof(uint32_t) * b->nJobs;
+    // (the error words lie behind the PCM on the device: mirror that in pinned memory and bring both down in one copy -- unless
+    // dcs_batch_download has given this batch separate host buffers before)
+    const bool joined = b->errJoined && (b->hPcm == nullptr
+                                         || b->hErr == reinterpret_cast<uint32_t *>(b->hPcm + static_cast<size_t>(DCS_FRAME_SAMPLES) * b->nJobs));
     if (b->hPcm == nullptr)
     {
-        b->hCap[0] = pcmBytes;
-        HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&b->hPcm), pcmBytes));
+        b->hCap[0] = joined ? pcmBytes + errBytes : pcmBytes;
+        HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&b->hPcm), b->hCap[0]));
+        if (joined)
+        {
+            b->hErr = reinterpret_cast<uint32_t *>(b->hPcm + static_cast<size_t>(DCS_FRAME_SAMPLES) * b->nJobs);
+            b->hCap[1] = 0;
+        }
     }
     if (b->hErr == nullptr && errOut != nullptr)
     {
@@ -1420,16 +1469,17 @@ extern "C" DcsStatus dcs_batch_download_view(DcsBatch *b, const int16_t **pcmOut
     }
     if (b->launched)
         HIPCHK(ctx, hipStreamWaitEvent(b->stream, b->evDone, 0));      // the copies follow the last launch, whatever stream it ran on
+    const size_t firstBytes = joined ? pcmBytes + errBytes : pcmBytes;
     if (b->downByKernel)
     {
-        HIPCHK(ctx, copyByKernel(b->stream, b->hPcm, b->dPcm, pcmBytes));
-        if (errOut != nullptr)
+        HIPCHK(ctx, copyByKernel(b->stream, b->hPcm, b->dPcm, firstBytes));
+        if (errOut != nullptr && !joined)
             HIPCHK(ctx, copyByKernel(b->stream, b->hErr, b->dErr, errBytes));
     }
     else
     {
-        HIPCHK(ctx, hipMemcpyAsync(b->hPcm, b->dPcm, pcmBytes, hipMemcpyDeviceToHost, b->stream));
-        if (errOut != nullptr)
+        HIPCHK(ctx, hipMemcpyAsync(b->hPcm, b->dPcm, firstBytes, hipMemcpyDeviceToHost, b->stream));
+        if (errOut != nullptr && !joined)
             HIPCHK(ctx, hipMemcpyAsync(b->hErr, b->dErr, errBytes, hipMemcpyDeviceToHost, b->stream));
     }
     HIPCHK(ctx, streamWait(b->ctx, b->stream));
@@ -1672,6 +1722,43 @@ extern "C" DcsStatus dcs_ctx_clock_mhz(DcsCtx *ctx, float *mhzOut)
     std::nth_element(ratio.begin(), ratio.begin() + static_cast<long>(ratio.size() / 2), ratio.end());
     *mhzOut = static_cast<float>(ratio[ratio.size() / 2] * 100.0);
     return DCS_OK;
+}
+
+// device memory -> pinned host memory, the way the pipelines bring PCM down (hipMemcpyAsync on a stream, one copy of 64 MB at
+// a time, five of them timed by HIP events): GB/s.  Not part of the decode path: what the link allows, to hold a sustained
+// end-to-end rate against (480 bytes of PCM per frame have to cross it).
+extern "C" DcsStatus dcs_ctx_link_rate(DcsCtx *ctx, float *gbpsOut)
+{
+    if (ctx == nullptr || gbpsOut == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = size_t(64) << 20;
+    void *d = nullptr, *h = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    DcsStatus st = [&]() -> DcsStatus {
+        HIPCHK(ctx, cacheAlloc(ctx, false, &d, bytes));
+        HIPCHK(ctx, cacheAlloc(ctx, true, &h, bytes));
+        HIPCHK(ctx, hipEventCreate(&e0));
+        HIPCHK(ctx, hipEventCreate(&e1));
+        HIPCHK(ctx, hipMemsetAsync(d, 0x5A, bytes, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));       // (first use of the path)
+        HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+        for (int i = 0 ; i < 5 ; ++i)
+            HIPCHK(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+        HIPCHK(ctx, hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+        *gbpsOut = static_cast<float>(5.0 * static_cast<double>(bytes) / (static_cast<double>(ms) * 1e6));
+        return DCS_OK;
+    }();
+    if (st != DCS_OK)
+        (void)hipStreamSynchronize(ctx->stream);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d) cacheFree(ctx, false, d, bytes);
+    if (h) cacheFree(ctx, true, h, bytes);
+    return st;
 }
 
 #include "dcs_pipeline.hip.h"

@@ -161,9 +161,12 @@ public:
     void AddTrackCommand(uint16_t trackNum);                    // DCSDecoderNative.cpp:1475
     void ClearTracks();                                         // DCSDecoderNative.h:126
 
-    // DCSDecoderNative.h:98.  The reference takes a bare pointer and trusts the stream to end; pass
-    // maxLen when the size of the buffer behind streamPtr is known (bytes past it read as zero).
-    void LoadAudioStream(int channel, const ROMPointer &streamPtr, int mixingLevel, size_t maxLen = size_t(1) << 26);
+    // DCSDecoderNative.h:98, the reference's signature.  The reference takes a bare pointer and trusts the stream to end: so
+    // does this member, except that a pointer into one of the decoder's ROM images is bounded by that image's end, and any
+    // other pointer by 64 MB (the stream's own frame count and codes end it long before; bytes past a bound read as zero).
+    void LoadAudioStream(int channel, const ROMPointer &streamPtr, int mixingLevel);
+    // the same for a caller that knows the size of the buffer behind streamPtr (not in the reference)
+    void LoadAudioStreamBounded(int channel, const ROMPointer &streamPtr, int mixingLevel, size_t maxLen);
     bool IsStreamPlaying(int channel);                          // DCSDecoderNative.h:101
 
     struct StreamInfo                                           // DCSDecoderNative.h:106-122
@@ -174,7 +177,8 @@ public:
         int formatSubType;
         uint8_t header[16];
     };
-    StreamInfo GetStreamInfo(const ROMPointer &streamPtr, size_t maxLen = size_t(1) << 26);
+    StreamInfo GetStreamInfo(const ROMPointer &streamPtr);                      // DCSDecoderNative.h:123, the reference's signature
+    StreamInfo GetStreamInfoBounded(const ROMPointer &streamPtr, size_t maxLen);    // (buffer size known; not in the reference)
 
     // ---- the batch-submit path (new): decode whole streams, each played alone from a fresh decoder at
     // (volume, mixingLevel), extraFrames taper frames appended per stream; one kernel launch for all.
@@ -203,6 +207,7 @@ protected:
 
 private:
     void Sync();                                // back to the state after the last frame handed out
+    size_t BytesBehind(const ROMPointer &p) const;     // to the end of the ROM image p points into, else 64 MB
     DcsOsVersion AbiOs() const;
     bool EnsureRoms();
 

@@ -301,6 +301,9 @@ int       dcs_batch_frames_per_wave(const DcsBatch *batch);     /* the kernel va
 /* shader clock (MHz) the chip holds under an integer VALU load on every SIMD (a probe kernel of a few hundred
  * microseconds; not part of the decode path): turns a kernel duration into cycles */
 DcsStatus dcs_ctx_clock_mhz(DcsCtx *ctx, float *mhzOut);
+/* device memory -> pinned host memory in GB/s, measured now (five 64 MB copies on the context's stream): what the link allows
+ * a sustained end-to-end rate (480 bytes of PCM per frame cross it).  Not part of the decode path. */
+DcsStatus dcs_ctx_link_rate(DcsCtx *ctx, float *gbpsOut);
 /* test hooks: bound of a consumer's wait for a tail from another chunk in microseconds (0 = the default, 500 ms), and
  * dropExports != 0: no chunk publishes its tail, so every such wait runs into the bound (DCS_FRAME_TAIL_LOST) */
 DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t handoffTimeoutUs, int dropExports);
@@ -542,6 +545,8 @@ DcsStatus   dcs_romset_check(DcsRomSet *rs, DcsRomCheck *out);           /* also
 DcsStatus   dcs_romset_set_version(DcsRomSet *rs, int hw, int os);       /* explicit override (no ADSP code in U2) */
 uint32_t    dcs_romset_num_tracks(const DcsRomSet *rs);
 DcsStatus   dcs_romset_pointer(const DcsRomSet *rs, uint32_t linear, const uint8_t **p, size_t *avail, int *chip);
+/* bytes from p to the end of the ROM image of this set that contains p; 0 when p points into none of them */
+size_t      dcs_romset_bytes_behind(const DcsRomSet *rs, const uint8_t *p);
 DcsStatus   dcs_romset_track_info(const DcsRomSet *rs, uint32_t track, DcsTrackInfo *ti);   /* BAD_STREAM: no such track */
 DcsStatus   dcs_romset_decompile(const DcsRomSet *rs, uint32_t track, DcsTrackOp *ops, uint32_t cap, uint32_t *nOut);
 DcsStatus   dcs_romset_list_streams(const DcsRomSet *rs, uint32_t *addrs, uint32_t cap, uint32_t *nOut);

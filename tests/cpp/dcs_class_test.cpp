@@ -69,9 +69,9 @@ int main(int argc, char **argv)
         for (int i = 7 ; i + 1 < argc ; i += 2, ++ch)
         {
             keep.push_back(readFile(argv[i + 1]));
-            dec->LoadAudioStream(ch, DCSDecoder::ROMPointer(0, keep.back().data()), atoi(argv[i]), keep.back().size());
+            dec->LoadAudioStreamBounded(ch, DCSDecoder::ROMPointer(0, keep.back().data()), atoi(argv[i]), keep.back().size());
         }
-        auto info = dec->GetStreamInfo(DCSDecoder::ROMPointer(0, keep[0].data()), keep[0].size());
+        auto info = dec->GetStreamInfoBounded(DCSDecoder::ROMPointer(0, keep[0].data()), keep[0].size());
         fprintf(stderr, "stream 0: %d frames, %d bytes, type %d/%d\n", info.nFrames, info.nBytes, info.formatType, info.formatSubType);
         for (int f = 0 ; f < nFramesOut ; ++f)
             for (int i = 0 ; i < 240 ; ++i)
@@ -150,7 +150,7 @@ int main(int argc, char **argv)
         {
             keep.push_back(readFile(argv[i + 1]));
             const std::vector<uint8_t> &data = keep.back();
-            dec->LoadAudioStream(0, DCSDecoder::ROMPointer(0, data.data()), atoi(argv[i]), data.size());
+            dec->LoadAudioStreamBounded(0, DCSDecoder::ROMPointer(0, data.data()), atoi(argv[i]), data.size());
             const int nFrames = ((data[0] << 8) | data[1]) + 2;
             const size_t first = pcm.size();
             for (int frame = 0 ; frame < nFrames ; ++frame)

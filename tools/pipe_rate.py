@@ -1,0 +1,30 @@
+"""sustained rate of dcs_pipeline (index pass, planner and packer on the device) over a long run, per block of 100 lists:
+argv[1] depth, argv[2] lists, [argv[3] workload]; environment: DCS_PIPE_ROUND_STREAMS, DCS_PIPE_WORKERS"""
+import sys, time, os, resource
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import dcsexplorer_amd as D
+from dcsexplorer_amd import workloads as W
+depth = int(sys.argv[1]); n = int(sys.argv[2]); wl = sys.argv[3] if len(sys.argv) > 3 else "survey3_65536"
+streams = W.WORKLOADS[wl]()
+ctx = D.Context(0)
+refs, keep = D.make_refs(streams)
+pipe = ctx.pipeline(depth, index_on_device=True, pack_on_device=True, plan_on_device=True)
+for _ in range(depth): pipe.submit_refs(refs, len(streams))
+for _ in range(depth): pipe.collect()
+r0 = resource.getrusage(resource.RUSAGE_SELF)
+t0 = time.perf_counter(); done = 0; marks = [t0]
+for k in range(n):
+    pipe.submit_refs(refs, len(streams))
+    if k >= depth - 1:
+        pipe.collect(); done += 1
+        if done % 100 == 0: marks.append(time.perf_counter())
+while done < n:
+    pipe.collect(); done += 1
+    if done % 100 == 0: marks.append(time.perf_counter())
+dt = time.perf_counter() - t0
+r1 = resource.getrusage(resource.RUSAGE_SELF)
+print("depth %d lists %d round_streams %s workers %s: %.3f ms/list overall, cpu %.2f ms/list; per 100 lists: %s" % (
+    depth, n, os.environ.get("DCS_PIPE_ROUND_STREAMS", "-"), os.environ.get("DCS_PIPE_WORKERS", "-"), dt / n * 1e3,
+    ((r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)) / n * 1e3, " ".join("%.3f" % ((b - a) * 10) for a, b in zip(marks, marks[1:]))))
+pipe.close(); ctx.close()
