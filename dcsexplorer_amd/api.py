@@ -122,7 +122,7 @@ EXPORTS = [
     "dcs_host_threads", "dcs_partition_streams", "dcs_decode_streams_sharded",
     "dcs_ctx_set_frames_per_chunk", "dcs_index_stream_literal", "dcs_pack_chunks_device", "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_link_rate", "dcs_ctx_set_test_hooks",
     "dcs_pipeline_create", "dcs_pipeline_destroy", "dcs_pipeline_submit", "dcs_pipeline_collect",
-    "dcs_device_path_create", "dcs_device_path_run", "dcs_device_path_download", "dcs_device_path_destroy",
+    "dcs_device_path_create", "dcs_device_path_run", "dcs_device_path_run_many", "dcs_device_path_download", "dcs_device_path_destroy",
     "dcs_node_create", "dcs_node_destroy", "dcs_node_submit", "dcs_node_collect", "dcs_node_num_devices", "dcs_node_device_info",
     "dcs_node_last_error", "dcs_node_cache_release", "dcs_device_numa_node",
 ]
@@ -346,6 +346,8 @@ def load_library():
     L.dcs_device_path_create.argtypes = [vp, vp, u32, u32, ctypes.POINTER(vp)]
     L.dcs_device_path_run.restype = i32
     L.dcs_device_path_run.argtypes = [vp, ctypes.c_int, ctypes.POINTER(DevicePathTimes)]
+    L.dcs_device_path_run_many.restype = i32
+    L.dcs_device_path_run_many.argtypes = [vp, ctypes.c_int]
     L.dcs_device_path_download.restype = i32
     L.dcs_device_path_download.argtypes = [vp, vp, vp, vp]
     L.dcs_device_path_destroy.restype = None
@@ -678,6 +680,7 @@ class Context:
             msg = self.L.dcs_last_error(None)
             raise DcsError(st, msg.decode() if msg else "")
         self.h = h
+        self.device = int(device)
         self._batches = weakref.WeakSet()       # a DcsBatch must be destroyed before its DcsCtx (dcs_hip.h)
 
     def close(self):
@@ -1005,6 +1008,10 @@ class DevicePath:
         t = DevicePathTimes()
         _check(self.L.dcs_device_path_run(self.h, int(iters), ctypes.byref(t)), self.ctx.h)
         return {f[0]: getattr(t, f[0]) for f in DevicePathTimes._fields_}
+
+    def run_many(self, iters):
+        """`iters` passes back to back and a wait; nothing timed"""
+        _check(self.L.dcs_device_path_run_many(self.h, int(iters)), self.ctx.h)
 
     def download(self):
         pcm = np.zeros((self.n_frames, FRAME_SAMPLES), dtype=np.int16)

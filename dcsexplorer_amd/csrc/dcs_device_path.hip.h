@@ -208,6 +208,24 @@ extern "C" DcsStatus dcs_device_path_run(DcsDevicePath *d, int iters, DcsDeviceP
     return DCS_OK;
 }
 
+// `iters` passes back to back and a wait for the last: nothing is timed here (a caller with several paths in flight, each driven
+// by a thread of its own, takes the wall clock around all of them)
+extern "C" DcsStatus dcs_device_path_run_many(DcsDevicePath *d, int iters)
+{
+    if (d == nullptr || iters < 1)
+        return DCS_ERR_INVALID_ARG;
+    DcsCtx *ctx = d->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int i = 0 ; i < iters ; ++i)
+    {
+        const DcsStatus st = devicePathPass(d, nullptr);
+        if (st != DCS_OK)
+            return st;
+    }
+    const DcsStatus st = markLaunched(d->batch, ctx->stream);
+    return st != DCS_OK ? st : dcs_batch_sync(d->batch);
+}
+
 extern "C" DcsStatus dcs_device_path_download(DcsDevicePath *d, int16_t *pcmOut, uint32_t *errOut, uint32_t *frameOffsets)
 {
     if (d == nullptr)

@@ -438,6 +438,7 @@ typedef struct DcsDevicePathTimes
 } DcsDevicePathTimes;
 DcsStatus dcs_device_path_create(DcsCtx *ctx, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, DcsDevicePath **out);
 DcsStatus dcs_device_path_run(DcsDevicePath *path, int iters, DcsDevicePathTimes *times);
+DcsStatus dcs_device_path_run_many(DcsDevicePath *path, int iters);    /* `iters` passes back to back, a wait, nothing timed */
 DcsStatus dcs_device_path_download(DcsDevicePath *path, int16_t *pcmOut, uint32_t *errOut, uint32_t *frameOffsets);
 void      dcs_device_path_destroy(DcsDevicePath *path);
 

@@ -13,7 +13,7 @@ esac
 N=$1; shift
 for i in $(seq $N); do for lib in "$@"; do for spec in $WLS; do
   wl=${spec%%:*}; sc=1; [ "$spec" != "$wl" ] && sc=${spec##*:}
-  DCS_HIP_LIB=$PWD/$lib python bench.py --workload $wl --scale $sc --steps $STEPS --no-cpu-baseline --no-end-to-end 2>/dev/null | python -c "
+  DCS_HIP_LIB=$PWD/$lib python bench.py --workload $wl --scale $sc --steps $STEPS --no-cpu-baseline --no-end-to-end --no-device-path --no-second-workload --rotate 0 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$lib %-18s %.2f us %s' % ('$spec', d['roofline']['kernel_avg_ms']*1e3, d['bit_exact']))"
 done; done; done | sort | awk '{k=$1" "$2; s[k]+=$3; n[k]++; if(!(k in m)||$3<m[k])m[k]=$3; if($5!="True")bad[k]=1} END{for(k in s) printf "%s mean %.2f min %.2f us%s\n", k, s[k]/n[k], m[k], (k in bad)?"  NOT BIT-EXACT":""}' | sort -k2,2 -k1,1
