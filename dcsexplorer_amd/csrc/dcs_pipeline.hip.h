@@ -205,7 +205,12 @@ static DcsStatus pipelineUpload(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     }
     const double tu2 = nowMs();
     HIPCHK(ctx, hipEventCreateWithFlags(&job->uploaded, hipEventDisableTiming));
-    HIPCHK(ctx, copyByKernel(stream, job->dBlob, job->hBlob, job->hBlobCap));
+    // The streams go up through EIGHT workgroups (DCS_PIPE_UP_BLOCKS).  A copy kernel that reads pinned host memory with hundreds of
+    // workgroups -- 2.4 MB a list: 586 of them -- keeps that many wavefronts stalled on PCIe reads whose completions travel the
+    // direction the PCM's writes need: the PCM of the lists further along came down at 70-75 % of the link's rate.  With 4 to 20
+    // workgroups (an upload then takes 0.15 ms instead of 0.05) the link runs at 93-97 %: 0.74 -> 0.58 ms per list sustained (round 4).
+    static const unsigned upBlocks = getenv("DCS_PIPE_UP_BLOCKS") != nullptr ? static_cast<unsigned>(std::max(1, atoi(getenv("DCS_PIPE_UP_BLOCKS")))) : 8u;
+    HIPCHK(ctx, copyByKernel(stream, job->dBlob, job->hBlob, job->hBlobCap, (p->flags & kPipeLatency) ? 1024u : upBlocks));
     HIPCHK(ctx, hipEventRecord(job->uploaded, stream));
     if (getenv("DCS_PIPE_TRACE"))
         fprintf(stderr, "pipe upload: allocs %.2f, memcpy %.2f, hip calls %.2f\n", tu1 - tu0, tu2 - tu1, nowMs() - tu2);
@@ -320,6 +325,18 @@ static void pipelineIndexer(DcsPipeline *p, int which)
     }
 }
 
+// How a list's PCM comes down: by the runtime's copy (hipMemcpyAsync into pinned memory, which this runtime does with a blit
+// kernel of its own), or -- DCS_PIPE_DOWN_BLOCKS=n, and always for a pipeline with ONE waiting caller (the context's own), where
+// hipMemcpyAsync now and then holds the calling thread for 7 ms (profiles/NOTES.md 17) -- by dcsCopyKernel with at most n workgroups.
+// Measured in round 4 (NOTES 24): with the uploads throttled (pipelineUpload) both ways down run at 93-97 % of the link.
+static void pipelineDownPolicy(const DcsPipeline *p, DcsBatch *b)
+{
+    static const int downBlocksEnv = getenv("DCS_PIPE_DOWN_BLOCKS") != nullptr ? atoi(getenv("DCS_PIPE_DOWN_BLOCKS")) : 0;
+    const bool latency = (p->flags & kPipeLatency) != 0;
+    b->downByKernel = latency || downBlocksEnv > 0;
+    b->downBlocks = latency ? 1024u : static_cast<unsigned>(std::max(1, downBlocksEnv));
+}
+
 // stage B: from index records (device path) or from scratch (host pool) to PCM in pinned memory
 static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream_t stream)
 {
@@ -390,7 +407,7 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
         static const bool splitWait = getenv("DCS_PIPE_TRACE") != nullptr && atoi(getenv("DCS_PIPE_TRACE")) >= 3;
         if (st == DCS_OK && splitWait) st = dcs_batch_sync(job->batch);
         const double tk1 = nowMs();
-        if (st == DCS_OK) job->batch->downByKernel = (p->flags & kPipeLatency) != 0;
+        if (st == DCS_OK) pipelineDownPolicy(p, job->batch);
         if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
         pipeLog("worker", 0, "kernels", tk0, tk1);
         pipeLog("worker", 0, "download", tk1, nowMs());
@@ -505,7 +522,7 @@ static DcsStatus pipelineDecodePlanned(DcsPipeline *p, DcsPipeline::Job *job, hi
     if (st == DCS_OK) st = batchQueuePlanFlag(job->batch);
     const double t2 = nowMs();
     pipeLog("worker", 0, "run-queue", t1, t2);
-    if (st == DCS_OK) job->batch->downByKernel = (p->flags & kPipeLatency) != 0;
+    if (st == DCS_OK) pipelineDownPolicy(p, job->batch);
     if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
     pipeLog("worker", 0, "download", t2, nowMs());
     bool lost = false;

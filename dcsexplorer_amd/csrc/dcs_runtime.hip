@@ -219,14 +219,14 @@ __global__ __launch_bounds__(256) void dcsCopyKernel(uint32_t *dst, const uint32
             dst[i] = src[i];
 }
 }   // namespace
-static hipError_t copyByKernel(hipStream_t stream, void *dst, const void *src, size_t bytes)
+static hipError_t copyByKernel(hipStream_t stream, void *dst, const void *src, size_t bytes, unsigned blockCap = 1024)
 {
     if (bytes == 0)
         return hipSuccess;
     if ((bytes & 3u) != 0 || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 3u) != 0)
         return hipErrorInvalidValue;
     const size_t nDw = bytes / 4;
-    const unsigned blocks = static_cast<unsigned>(std::min<size_t>((nDw / 4 + 255) / 256 + 1, 1024));
+    const unsigned blocks = static_cast<unsigned>(std::min<size_t>((nDw / 4 + 255) / 256 + 1, blockCap));
     hipLaunchKernelGGL(dcsCopyKernel, dim3(blocks), dim3(256), 0, stream, static_cast<uint32_t *>(dst), static_cast<const uint32_t *>(src), nDw);
     return hipGetLastError();
 }
@@ -267,7 +267,8 @@ struct DcsBatch
     // against the context's non-blocking one): sync, download, download_view and destroy wait for it
     hipEvent_t evDone = nullptr;
     bool launched = false;
-    bool downByKernel = false;  // the PCM's way down by dcsCopyKernel instead of the copy engines (the context's own pipeline: one waiting caller)
+    bool downByKernel = false;  // the PCM's way down by dcsCopyKernel instead of the runtime's copy (the pipelines)
+    unsigned downBlocks = 1024; // ... with at most this many workgroups
     bool settled = false;       // a wait has covered everything enqueued for this batch and nothing was enqueued since
     bool errJoined = false;     // dErr lies behind dPcm in ONE allocation (and hErr behind hPcm): the two come down in one copy
 };
@@ -1472,9 +1473,9 @@ extern "C" DcsStatus dcs_batch_download_view(DcsBatch *b, const int16_t **pcmOut
     const size_t firstBytes = joined ? pcmBytes + errBytes : pcmBytes;
     if (b->downByKernel)
     {
-        HIPCHK(ctx, copyByKernel(b->stream, b->hPcm, b->dPcm, firstBytes));
+        HIPCHK(ctx, copyByKernel(b->stream, b->hPcm, b->dPcm, firstBytes, b->downBlocks));
         if (errOut != nullptr && !joined)
-            HIPCHK(ctx, copyByKernel(b->stream, b->hErr, b->dErr, errBytes));
+            HIPCHK(ctx, copyByKernel(b->stream, b->hErr, b->dErr, errBytes, b->downBlocks));
     }
     else
     {
