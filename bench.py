@@ -676,7 +676,7 @@ def run_rank(args):
     # The shader clock of an idle MI355X sits at 2.14 GHz and takes about 20 ms of load to reach its 2.4 GHz (the set-up
     # above is seconds of host work with the GPU idle, and W + K steps of this workload are under a millisecond): the
     # clock-probe kernel, which is no step, is run for --clock-settle-ms first, so that the K steps are timed at the clock
-    # a job of any length runs at (tools/step_overhead.py: 38.1 us per step without, 35.0 with, 33.9 when K = 200)
+    # a job of any length runs at (round 2: 38.1 us per step without, 35.0 with, 33.9 when K = 200)
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.clock_settle_ms:
         ctx.clock_mhz()

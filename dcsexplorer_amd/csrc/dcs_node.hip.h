@@ -172,7 +172,16 @@ extern "C" DcsStatus dcs_node_device_info(const DcsNode *n, uint32_t index, int 
     return DCS_OK;
 }
 
-extern "C" const char *dcs_node_last_error(const DcsNode *n) { return n ? n->lastError.c_str() : ""; }
+extern "C" const char *dcs_node_last_error(const DcsNode *n)
+{
+    // a copy owned by the calling thread: submit and collect (two threads) both write the string
+    thread_local std::string copy;
+    if (n == nullptr)
+        return "";
+    std::lock_guard<std::mutex> lk(const_cast<DcsNode *>(n)->m);
+    copy = n->lastError;
+    return copy.c_str();
+}
 
 extern "C" DcsStatus dcs_node_submit(DcsNode *n, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames)
 {
@@ -344,6 +353,7 @@ extern "C" DcsStatus dcs_decode_streams_sharded(const int *deviceIds, uint32_t n
     for (uint32_t d = 0 ; d < nDevices ; ++d)
         if (status[d] != DCS_OK)
         {
+            std::lock_guard<std::mutex> lk(node->m);
             node->lastError = std::string("device ") + std::to_string(node->devs[d].id) + ": " + dcs_last_error(node->devs[d].ctx);
             return status[d];
         }

@@ -201,7 +201,7 @@ static hipError_t streamWait(DcsCtx *ctx, hipStream_t stream)
 // A copy between pinned host memory and device memory done by a kernel on `stream` (both sides are device-visible
 // addresses; 4-byte granularity).  The pipeline's small uploads go this way: hipMemcpyAsync from pinned memory now and then
 // holds the CALLING thread for ~7 ms -- several threads at once, released together -- which a launch has not been seen to
-// do (DCS_HIP_SLOW, tools/cold_trace.py; profiles/NOTES.md item 17).  The PCM's way down stays with the copy engines.
+// do (DCS_HIP_SLOW; profiles/NOTES.md item 17).  The PCM's way down stays with the copy engines.
 namespace {
 __global__ __launch_bounds__(256) void dcsCopyKernel(uint32_t *dst, const uint32_t *src, size_t nDw)
 {
@@ -512,7 +512,7 @@ extern "C" DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t handoffTimeout
     return DCS_OK;
 }
 
-// Frames per wavefront, from measurement (tools/sweep_fpw.sh, tools/fpw_sweep.py): 4 (16 lanes unpack a frame: the
+// Frames per wavefront, from measurement (bench.py --fpw over batch sizes, rounds 2 and 3): 4 (16 lanes unpack a frame: the
 // shortest serial path per wavefront) while the batch is small, 8 (four wavefronts per SIMD, full rounds) beyond.  The
 // crossover depends on what is decoded: a batch of 1994+ frames only -- the longer symbol loops -- gains from 8 lanes per
 // frame from about 10 frames per SIMD, 1993 and mixed batches from about 32.  The 16-frames variant (fewest instructions

@@ -460,3 +460,30 @@ def test_sharded_entry_keeps_its_contexts_between_calls(oracle, corpus):
     assert stream_hashes(oracle, b[0], b[2]) == g["stream_hashes"][200:260]
     assert (t2 - t1) < (t1 - t0), "second call %.1f ms, first %.1f ms" % ((t2 - t1) * 1e3, (t1 - t0) * 1e3)
     D.node_cache_release()
+
+
+def test_buffer_cache_is_bounded_and_can_be_trimmed(dcs, corpus):
+    """the context's buffer cache: limits derived from the card and the host, never exceeded, changeable; a trim
+    gives everything back; decoding goes on afterwards with the same PCM"""
+    g, manifest, streams = corpus
+    ctx = dcs.Context(0)
+    dev, pin, dev_lim, pin_lim = ctx.cache_bytes()
+    assert dev == 0 and pin == 0 and 0 < dev_lim <= 32 << 30 and 0 < pin_lim <= 8 << 30
+    want = ctx.decode_streams(streams[:30])
+    pipe = ctx.pipeline(4, index_on_device=True, pack_on_device=True, plan_on_device=True)
+    for _ in range(4):
+        pipe.submit(streams[:30])
+    for _ in range(4):
+        pcm, err, first, _, _ = pipe.collect()
+        assert np.array_equal(pcm, want[0])
+    pipe.close()
+    dev, pin, _, _ = ctx.cache_bytes()
+    assert dev > 0 and pin > 0 and dev <= dev_lim and pin <= pin_lim
+    released = ctx.trim_cache()
+    assert released == (dev, pin) and ctx.cache_bytes()[:2] == (0, 0)
+    ctx.set_cache_limits(1 << 20, 1 << 20)          # next to nothing may be kept: every buffer goes back to the runtime at once
+    got = ctx.decode_streams(streams[:30])
+    assert np.array_equal(got[0], want[0])
+    dev, pin, dev_lim, pin_lim = ctx.cache_bytes()
+    assert (dev_lim, pin_lim) == (1 << 20, 1 << 20) and dev <= 1 << 20 and pin <= 1 << 20
+    ctx.close()
