@@ -168,7 +168,7 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
                 pipe.submit_refs(refs, len(streams))
             for _ in range(depth):
                 pipe.collect()
-        n_lists = max(lists, 3 * depth) if not on_device else max(lists, 400)
+        n_lists = max(lists, 3 * depth) if not on_device else max(3 * depth, int(400 / lists_scale))
         t0 = time.perf_counter()
         done = 0
         for k in range(n_lists):
@@ -188,6 +188,11 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
                 "worker_host_ms": sum(host_ms) / len(host_ms), "worker_device_ms": sum(dev_ms) / len(dev_ms)}
 
     link_gbps = ctx.link_rate()                                # GB/s, device -> pinned host memory, measured now
+    # lists far larger than the 65 536 frames the defaults are made for (the corpus: 608 011): fewer of them in flight and timed, so
+    # that pinned memory (480 B per frame and list in flight) and the run time stay what they are for the default workload
+    big = max(1.0, n_frames / 65536.0)
+    depth, dev_depth = max(2, int(depth / big)), max(4, int(dev_depth / big))
+    lists_scale = big
     host_idx = sustained(depth, False)
     dev_idx = sustained(dev_depth, True)
     dev_pack = sustained(dev_depth, True, True)

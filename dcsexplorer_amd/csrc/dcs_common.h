@@ -276,6 +276,13 @@ struct DcsKernelArgs
     uint32_t            timeoutTicks;   // bound of the wait for a tail from another chunk, 100 MHz ticks
 };
 #define DCS_BATCH_HAS_93A_T1 1u         // some source is an OS93a Type-1 frame: workgroups stage the pair table in LDS
+// The chunks are in CHAIN order (a chunk takes its tail from the chunk before it) and the launch maps them to workgroups in XCD
+// RANGES: workgroup i of a launch runs on XCD i % 8 (measured: tools/xcd_map.hip), so with logical workgroup
+// L = (i % 8) * R + i / 8, R = workgroups / 8, XCD j decodes logical workgroups [j R, (j + 1) R) in order, and the producer of a tail
+// sits in the same workgroup or in the one dispatched just before it ON THE SAME XCD.  Every wait is then for a wavefront that is
+// resident or through whatever else runs on the chip -- other decode kernels included (dcs_pipeline.hip.h: why that matters); only
+// the first workgroup of a range may wait for the last one of the range before, i.e. until that XCD is through.
+#define DCS_BATCH_XCD_RANGES 2u
 
 // A source as the planner and the DEVICE packer need it when the index records stay on the device (the pipeline's
 // device path): 24 bytes instead of the 160 of DcsSrcDesc.  `record` = index of the frame's DcsFrameIndex in the
@@ -361,10 +368,11 @@ struct DcsBuiltPlan
 };
 DcsStatus dcsBuildPlanFromDigest(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, const DcsDigested &in,
                                  DcsBuiltPlan &P);
+// (depthOrder = false: the chunks stay in chain order, for launches in XCD ranges -- DCS_BATCH_XCD_RANGES)
 uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true,
-                       int framesPerChunk = 0);
+                       int framesPerChunk = 0, bool depthOrder = true);
 uint32_t dcsPlanChunksLite(const DcsFrameJob *jobs, uint32_t nJobs, const DcsPlanSrc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true,
-                           int framesPerChunk = 0);
+                           int framesPerChunk = 0, bool depthOrder = true);
 // packer: out = nChunks x dcsPkgBytes(fpw) bytes (the chunk packages described above)
 void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const DcsSrcDesc *srcs,
                       const uint8_t *blob, size_t blobLen, uint8_t *out);

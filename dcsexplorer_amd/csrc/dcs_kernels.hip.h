@@ -1426,7 +1426,11 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     static_assert(kPoolBytes % 16 == 0 && kWavesPerBlock * kTileBytes >= 8192, "LDS layout");
     const Lds<FPW> L{ smem, smem + DCS_LDS_DECODE_BYTES + kWavesPerBlock * kPoolBytes + wave * kTileBytes,
                       smem + DCS_LDS_DECODE_BYTES + wave * kPoolBytes };
-    const uint32_t chunk = blockIdx.x * kWavesPerBlock + static_cast<uint32_t>(wave);
+    // (DCS_BATCH_XCD_RANGES, dcs_common.h: workgroup i runs on XCD i % 8; XCD j takes the logical workgroups [j R, (j + 1) R) in order)
+    uint32_t blk = blockIdx.x;
+    if (a.flags & DCS_BATCH_XCD_RANGES)
+        blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
+    const uint32_t chunk = blk * kWavesPerBlock + static_cast<uint32_t>(wave);
 #ifdef DCS_STAMPS
     const Stamper stamp{ (lane == 0 && a.debug != nullptr && chunk < a.nChunks) ? a.debug + static_cast<size_t>(chunk) * 16 : nullptr };
 #else

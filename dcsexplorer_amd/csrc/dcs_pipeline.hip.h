@@ -205,11 +205,13 @@ static DcsStatus pipelineUpload(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     }
     const double tu2 = nowMs();
     HIPCHK(ctx, hipEventCreateWithFlags(&job->uploaded, hipEventDisableTiming));
-    // The streams go up through EIGHT workgroups (DCS_PIPE_UP_BLOCKS).  A copy kernel that reads pinned host memory with hundreds of
+    // The streams go up through EIGHT workgroups (DCS_PIPE_UP_BLOCKS overrides).  A copy kernel that reads pinned host memory with hundreds of
     // workgroups -- 2.4 MB a list: 586 of them -- keeps that many wavefronts stalled on PCIe reads whose completions travel the
     // direction the PCM's writes need: the PCM of the lists further along came down at 70-75 % of the link's rate.  With 4 to 20
     // workgroups (an upload then takes 0.15 ms instead of 0.05) the link runs at 93-97 %: 0.74 -> 0.58 ms per list sustained (round 4).
-    static const unsigned upBlocks = getenv("DCS_PIPE_UP_BLOCKS") != nullptr ? static_cast<unsigned>(std::max(1, atoi(getenv("DCS_PIPE_UP_BLOCKS")))) : 8u;
+    // (a list far larger than those measured gets more of them, one per 300 KB up to 32, so that its upload stays shorter than its PCM's way down)
+    static const unsigned upBlocksEnv = getenv("DCS_PIPE_UP_BLOCKS") != nullptr ? static_cast<unsigned>(std::max(1, atoi(getenv("DCS_PIPE_UP_BLOCKS")))) : 0u;
+    const unsigned upBlocks = upBlocksEnv != 0 ? upBlocksEnv : static_cast<unsigned>(std::min<size_t>(32, std::max<size_t>(8, job->hBlobCap / (300u << 10))));
     HIPCHK(ctx, copyByKernel(stream, job->dBlob, job->hBlob, job->hBlobCap, (p->flags & kPipeLatency) ? 1024u : upBlocks));
     HIPCHK(ctx, hipEventRecord(job->uploaded, stream));
     if (getenv("DCS_PIPE_TRACE"))
@@ -324,6 +326,18 @@ static void pipelineIndexer(DcsPipeline *p, int which)
         p->work.notify_all();
     }
 }
+
+// Why a pipeline's batches are launched in XCD ranges (DCS_BATCH_XCD_RANGES, dcs_common.h).  A decode kernel's wavefronts may wait
+// for a tail another of ITS wavefronts publishes (dcs_kernels.hip.h: hand-off).  Workgroups are dispatched in index order and a
+// producer lies in a lower-numbered chunk, so within ONE kernel that has the chip to itself every wait is for a wavefront that is
+// resident or through.  Two such kernels side by side break that: workgroups go round-robin to the eight XCDs, each XCD fills its
+// places on its own, and an XCD can be full of kernel B's waiting consumers whose producers sit undispatched on another XCD that is
+// full of kernel A's waiting consumers -- whose producers wait for a place on the first.  Nothing moves until the bound of the wait
+// (500 ms) flags the frames and the lists are decoded again: seen in round 4 as two lists in a hundred of 608 011 frames (76 000
+// chunks each) and once in 400 lists of 65 536; short of that, the kernels of lists in flight held each other up for most of a
+// millisecond (0.94 ms per decode kernel in the pipeline against 0.05 alone).  With chain order and XCD ranges a consumer's producer
+// is dispatched before it on the consumer's own XCD, so no wait depends on a place becoming free.  (ONE decode stream per device,
+// which also rules the circle out, was measured first: 0.92 ms per list instead of 0.60 -- lists waiting behind each other's packers.)
 
 // How a list's PCM comes down: by the runtime's copy (hipMemcpyAsync into pinned memory, which this runtime does with a blit
 // kernel of its own), or -- DCS_PIPE_DOWN_BLOCKS=n, and always for a pipeline with ONE waiting caller (the context's own), where
@@ -559,6 +573,8 @@ static DcsStatus pipelineDecodePlanned(DcsPipeline *p, DcsPipeline::Job *job, hi
 static void pipelineWorker(DcsPipeline *p, int id)
 {
     pthread_setname_np(pthread_self(), "dcs-worker");
+    static const bool xcdRanges = getenv("DCS_PIPE_XCD_RANGES") == nullptr || atoi(getenv("DCS_PIPE_XCD_RANGES")) != 0;     // (0: an experiment switch)
+    tlsXcdRanges = xcdRanges;                               // (this thread's batches: chain order, launched in XCD ranges; see above)
     tlsBlockingWaits = (p->flags & kPipeLatency) == 0;      // (the context's own pipeline serves ONE waiting caller: its threads poll)
     (void)hipSetDevice(p->ctx->device);
     const hipStream_t stream = p->streams[id];

@@ -52,7 +52,7 @@ static DcsSlot makeSlot(const DcsFrameJob &jb, uint32_t job, uint8_t prevSlot, u
 
 template <class Src>
 static uint32_t planChunks(const DcsFrameJob *jobs, uint32_t nJobs, const Src *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
-                           int framesPerChunk)
+                           int framesPerChunk, bool depthOrder)
 {
     // (diagnostic: fewer frames per chunk than the kernel variant has slots, the rest of the wavefront idles)
     const uint32_t limit = static_cast<uint32_t>(framesPerChunk >= 1 && framesPerChunk < fpw ? framesPerChunk : fpw);
@@ -241,7 +241,7 @@ static uint32_t planChunks(const DcsFrameJob *jobs, uint32_t nJobs, const Src *s
     // A batch of unlike streams keeps the chain order: it makes the four wavefronts of a workgroup decode the same stream,
     // and a workgroup whose wavefronts finish together gives its LDS back sooner (measured: depth order costs such a
     // batch 8 % once it is larger than one round of workgroups).
-    bool alike = srcs != nullptr;
+    bool alike = srcs != nullptr && depthOrder;
     if (alike)
     {
         auto family = [](uint8_t format) { return format >= DCS_FMT_94_T0 ? 3 : static_cast<int>(format); };
@@ -294,15 +294,15 @@ static uint32_t planChunks(const DcsFrameJob *jobs, uint32_t nJobs, const Src *s
 }
 
 uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
-                       int framesPerChunk)
+                       int framesPerChunk, bool depthOrder)
 {
-    return planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk);
+    return planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk, depthOrder);
 }
 
 uint32_t dcsPlanChunksLite(const DcsFrameJob *jobs, uint32_t nJobs, const DcsPlanSrc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
-                           int framesPerChunk)
+                           int framesPerChunk, bool depthOrder)
 {
-    return planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk);
+    return planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk, depthOrder);
 }
 
 extern "C" DcsStatus dcs_plan_chunks2(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, int handoff,

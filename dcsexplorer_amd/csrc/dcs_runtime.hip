@@ -155,6 +155,9 @@ static double hipchkNow() { return std::chrono::duration<double, std::micro>(std
 // short look first (the kernels of a small list are done in microseconds), then naps of 50 us, which the kernel's timer slack
 // makes ~110.  DCS_WAIT_RUNTIME=1 restores hipEventSynchronize.  Everybody else polls inside the runtime (shortest latency).
 static thread_local bool tlsBlockingWaits = false;
+// Batches made by THIS thread keep their chunks in chain order and are launched in XCD ranges (DCS_BATCH_XCD_RANGES): set by the
+// pipelines' workers, whose decode kernels run next to each other's.
+static thread_local bool tlsXcdRanges = false;
 
 // wait for everything enqueued on `stream`
 static hipError_t streamWait(DcsCtx *ctx, hipStream_t stream)
@@ -668,7 +671,11 @@ static DcsStatus createBatch(DcsCtx *ctx,
     thread_local std::vector<DcsSlot> slots;    // (kept from batch to batch: see the pipeline's scratch)
     uint8_t *hPackages = nullptr;           // pinned staging for the chunk packages
     size_t pkgBytes = 0;
-    b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk);
+    static const bool forceRanges = getenv("DCS_BATCH_XCD_RANGES") != nullptr && atoi(getenv("DCS_BATCH_XCD_RANGES")) != 0;     // (experiment switch)
+    const bool ranges = tlsXcdRanges || forceRanges;
+    b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges);
+    if (ranges && handoff)
+        b->flags |= DCS_BATCH_XCD_RANGES;
     if (ctx->dropExports)
         for (DcsSlot &sl : slots)
             sl.flags &= static_cast<uint8_t>(~DCS_SLOT_EXPORT);      // test hook: imports without a producer
@@ -1018,7 +1025,9 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
     b->abiBytes = payload + static_cast<uint64_t>(nSrcs) * sizeof(DcsSrcDesc) + static_cast<uint64_t>(nJobs) * sizeof(DcsFrameJob) + pcm;
 
     thread_local std::vector<DcsSlot> slots;
-    b->nChunks = dcsPlanChunksLite(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk);
+    b->nChunks = dcsPlanChunksLite(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !tlsXcdRanges);
+    if (tlsXcdRanges && handoff)
+        b->flags |= DCS_BATCH_XCD_RANGES;
     if (ctx->dropExports)
         for (DcsSlot &sl : slots)
             sl.flags &= static_cast<uint8_t>(~DCS_SLOT_EXPORT);
@@ -1150,6 +1159,9 @@ static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *ta
     b->fpw = chooseFpw(ctx, nJobs, all94);
     if (has93aT1)
         b->flags |= DCS_BATCH_HAS_93A_T1;
+    static const bool xcdRanges = getenv("DCS_PIPE_XCD_RANGES") == nullptr || atoi(getenv("DCS_PIPE_XCD_RANGES")) != 0;
+    if (xcdRanges)
+        b->flags |= DCS_BATCH_XCD_RANGES;       // (the arithmetic plan IS chain order: chunk c takes its tail from chunk c - 1)
     const uint64_t pcm = static_cast<uint64_t>(nJobs) * DCS_FRAME_SAMPLES * 2;
     b->algoBytes = payloadBytes + static_cast<uint64_t>(nRecords) * 56u + pcm;
     b->abiBytes = payloadBytes + static_cast<uint64_t>(nRecords) * sizeof(DcsSrcDesc) + static_cast<uint64_t>(nJobs) * sizeof(DcsFrameJob) + pcm;
@@ -1288,7 +1300,9 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
 template <int FPW>
 static hipError_t launch(const DcsKernelArgs &args, hipStream_t stream)
 {
-    const uint32_t blocks = (args.nChunks + dcsk::kWavesPerBlock - 1) / dcsk::kWavesPerBlock;
+    uint32_t blocks = (args.nChunks + dcsk::kWavesPerBlock - 1) / dcsk::kWavesPerBlock;
+    if (args.flags & DCS_BATCH_XCD_RANGES)
+        blocks = (blocks + 7u) / 8u * 8u;           // eight ranges of equal length; the padding workgroups find no chunk and leave
     dcsk::dcsDecodeKernel<FPW><<<dim3(blocks), dim3(64 * dcsk::kWavesPerBlock), dcsk::ldsBytes(FPW), stream>>>(
         args.packages, args.tables, args.nChunks, args.flags, args.epoch, args.nJobs, args.pcm, args.handoff, args.err, args.tailsOut,
         args.blob, args.blobLen, args.srcs, args.tailsIn, args.debug, args.timeoutTicks);

@@ -7,14 +7,16 @@ REPO=$PWD
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --workload $WL --steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end --no-second-workload $*"
+BENCH="python3 $PWD/bench.py --workload $WL --steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end --no-second-workload --no-device-path --rotate 0 $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.log
+echo "prof $TAG: kernel trace done"
 for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
             "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
             "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_THREAD_CYCLES_VALU"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -- $BENCH > /dev/null 2> $OUT/pmc_$name.log
+  echo "prof $TAG: pass $name done"
 done
 cd $OUT
 # compact summaries

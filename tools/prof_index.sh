@@ -16,6 +16,7 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
             "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -- $RUN > /dev/null 2> $OUT/pmc_$name.log
+  echo "prof_index $TAG: pass $name done"
 done
 cd $OUT
 DCS_REPO=$REPO DCS_WL=$WL DCS_MULT=$MULT python3 - <<'PY'
