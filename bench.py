@@ -666,6 +666,8 @@ def run_rank(args):
         return
 
     ctx = D.Context(local_rank)
+    if args.share_gpu or args.inflight > 1:
+        ctx.set_concurrent_batches(True)        # several decode launches on one GPU at once: chain order, XCD ranges (include/dcs_hip.h)
     if args.fpw:
         ctx.set_frames_per_wave(args.fpw)
     if args.frames_per_chunk:

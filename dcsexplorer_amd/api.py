@@ -104,7 +104,7 @@ ABI_VERSION = 7                 # include/dcs_hip.h DCS_ABI_VERSION these bindin
 EXPORTS = [
     "dcs_abi_version", "dcs_build_id", "dcs_index_stream", "dcs_volume_multiplier", "dcs_mixing_multiplier", "dcs_frame_scale",
     "dcs_stream_params", "dcs_ctx_create", "dcs_ctx_destroy", "dcs_last_error", "dcs_device_count",
-    "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_ctx_set_large_list_path", "dcs_ctx_set_cache_limits", "dcs_ctx_trim_cache", "dcs_ctx_cache_bytes", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run", "dcs_batch_run_many", "dcs_pack_chunks",
+    "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_ctx_set_large_list_path", "dcs_ctx_set_concurrent_batches", "dcs_ctx_set_cache_limits", "dcs_ctx_trim_cache", "dcs_ctx_cache_bytes", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run", "dcs_batch_run_many", "dcs_pack_chunks",
     "dcs_batch_time", "dcs_batch_time_rotating", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_download_view", "dcs_batch_device_pcm",
     "dcs_batch_algorithmic_bytes", "dcs_batch_num_jobs", "dcs_decode_streams", "dcs_count_stream_frames",
     "dcs_synth_stream", "dcs_plan_chunks", "dcs_index_streams", "dcs_index_streams_gpu",
@@ -191,6 +191,8 @@ def load_library():
     L.dcs_ctx_set_tail_handoff.argtypes = [vp, ctypes.c_int]
     L.dcs_ctx_set_large_list_path.restype = i32
     L.dcs_ctx_set_large_list_path.argtypes = [vp, ctypes.c_int]
+    L.dcs_ctx_set_concurrent_batches.restype = i32
+    L.dcs_ctx_set_concurrent_batches.argtypes = [vp, ctypes.c_int]
     u64p = ctypes.POINTER(ctypes.c_uint64)
     L.dcs_ctx_set_cache_limits.restype = i32
     L.dcs_ctx_set_cache_limits.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64]
@@ -701,6 +703,10 @@ class Context:
         v = ctypes.c_float(0)
         _check(self.L.dcs_ctx_link_rate(self.h, ctypes.byref(v)), self.h)
         return float(v.value)
+
+    def set_concurrent_batches(self, enable=True):
+        """batches created afterwards may run next to other decode launches on the GPU (dcs_ctx_set_concurrent_batches)"""
+        _check(self.L.dcs_ctx_set_concurrent_batches(self.h, int(bool(enable))), self.h)
 
     def set_cache_limits(self, device_bytes, pinned_bytes):
         _check(self.L.dcs_ctx_set_cache_limits(self.h, int(device_bytes), int(pinned_bytes)), self.h)

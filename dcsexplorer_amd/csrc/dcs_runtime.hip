@@ -30,6 +30,7 @@ struct DcsCtx
     uint32_t handoffTimeoutTicks = dcsk::kHandoffTimeoutTicks;     // 100 MHz ticks (dcs_ctx_set_test_hooks)
     bool dropExports = false;           // test hook: no chunk publishes its tail (dcs_ctx_set_test_hooks)
     int framesPerChunk = 0;             // diagnostic: frames a wavefront decodes (0 = as many as the kernel variant has slots)
+    bool xcdRanges = false;             // batches of this context: chain order, launched in XCD ranges (dcs_ctx_set_concurrent_batches)
     bool largeListOnDevice = true;      // dcs_decode_streams on a large list: index walk, planner and packer on the device (dcs_ctx_set_large_list_path)
     std::mutex cacheMutex;              // the buffer cache is shared by the pipeline's worker threads
     struct DcsPipeline *internalPipe = nullptr;     // dcs_decode_streams takes large lists through it in parts (dcs_pipeline.hip.h)
@@ -468,6 +469,14 @@ extern "C" DcsStatus dcs_ctx_cache_bytes(DcsCtx *ctx, uint64_t *deviceBytes, uin
     return DCS_OK;
 }
 
+extern "C" DcsStatus dcs_ctx_set_concurrent_batches(DcsCtx *ctx, int enable)
+{
+    if (ctx == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    ctx->xcdRanges = enable != 0;
+    return DCS_OK;
+}
+
 extern "C" DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw)
 {
     if (ctx == nullptr || !(fpw == 0 || fpw == 4 || fpw == 8 || fpw == 16))
@@ -672,7 +681,7 @@ static DcsStatus createBatch(DcsCtx *ctx,
     uint8_t *hPackages = nullptr;           // pinned staging for the chunk packages
     size_t pkgBytes = 0;
     static const bool forceRanges = getenv("DCS_BATCH_XCD_RANGES") != nullptr && atoi(getenv("DCS_BATCH_XCD_RANGES")) != 0;     // (experiment switch)
-    const bool ranges = tlsXcdRanges || forceRanges;
+    const bool ranges = tlsXcdRanges || ctx->xcdRanges || forceRanges;
     b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges);
     if (ranges && handoff)
         b->flags |= DCS_BATCH_XCD_RANGES;
@@ -1025,8 +1034,9 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
     b->abiBytes = payload + static_cast<uint64_t>(nSrcs) * sizeof(DcsSrcDesc) + static_cast<uint64_t>(nJobs) * sizeof(DcsFrameJob) + pcm;
 
     thread_local std::vector<DcsSlot> slots;
-    b->nChunks = dcsPlanChunksLite(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !tlsXcdRanges);
-    if (tlsXcdRanges && handoff)
+    const bool ranges = tlsXcdRanges || ctx->xcdRanges;
+    b->nChunks = dcsPlanChunksLite(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges);
+    if (ranges && handoff)
         b->flags |= DCS_BATCH_XCD_RANGES;
     if (ctx->dropExports)
         for (DcsSlot &sl : slots)

@@ -226,6 +226,14 @@ DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable);
  * on the device (DCS_PIPE_ALL_ON_DEVICE; 3.8 ms for 256 x 256 frames, ~2 CPU-ms); 0: the index pass on the host's worker
  * pool with the parts following it (4.0-4.4 ms, ~45 CPU-ms on 16 threads).  Same PCM either way. */
 DcsStatus dcs_ctx_set_large_list_path(DcsCtx *ctx, int onDevice);
+/* For a caller that runs SEVERAL resident batches on one GPU at once (batches on different streams, or several processes on one
+ * card).  A decode kernel's wavefronts wait for tails other wavefronts of the same launch publish; one launch that has the chip to
+ * itself cannot wait in vain, two side by side can wait for each other's places across the chip's eight XCDs until the bound
+ * (DCS_FRAME_TAIL_LOST).  enable = 1: batches created afterwards keep their chunks in chain order and are launched in XCD ranges --
+ * workgroup i runs on XCD i % 8, XCD j decodes a contiguous range of chunks in order, a tail's producer is dispatched before its
+ * consumer on the consumer's own XCD -- so no wait depends on another launch.  About 1 % slower for a batch alone on the chip, which is
+ * why it is not the default; dcs_pipeline, dcs_node and dcs_decode_streams always work this way.  Same PCM either way. */
+DcsStatus dcs_ctx_set_concurrent_batches(DcsCtx *ctx, int enable);
 /* The context keeps device and pinned-host buffers of finished batches and lists for the next ones (hipMalloc / hipFree
  * cost as much as decoding thousands of frames, and hipFree waits for the whole device).  What it may keep is bounded:
  * by default min(32 GB, an eighth of the card's free memory at dcs_ctx_create) of device memory and min(8 GB, a

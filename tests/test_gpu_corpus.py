@@ -487,3 +487,47 @@ def test_buffer_cache_is_bounded_and_can_be_trimmed(dcs, corpus):
     dev, pin, dev_lim, pin_lim = ctx.cache_bytes()
     assert (dev_lim, pin_lim) == (1 << 20, 1 << 20) and dev <= 1 << 20 and pin <= 1 << 20
     ctx.close()
+
+
+@pytest.mark.parametrize("fpw", [4, 8, 16])
+def test_xcd_range_launches_give_the_same_pcm(dcs, corpus, fpw):
+    """dcs_ctx_set_concurrent_batches: chunks in chain order, logical workgroups mapped to the XCDs in ranges -- the PCM of the
+    default plan (depth order, index order), for every kernel variant, on ragged streams of all six layouts"""
+    g, manifest, streams = corpus
+    part = streams[300:380]
+    ctx = dcs.Context(0)
+    ctx.set_frames_per_wave(fpw)
+    want = ctx.decode_streams(part, extra_frames=1)
+    ctx.set_concurrent_batches(True)
+    got = ctx.decode_streams(part, extra_frames=1)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    ctx.close()
+
+
+def test_two_contexts_launching_side_by_side_lose_no_tail(dcs, oracle):
+    """two contexts on one GPU, each relaunching a resident 65 536-frame batch from a thread of its own (decode kernels of different
+    launches side by side, as several ranks or pipelines on one card make them): with dcs_ctx_set_concurrent_batches no frame is
+    flagged DCS_FRAME_TAIL_LOST and both PCMs equal the reference's hashes"""
+    import threading
+    gold = json.load(open(os.path.join(GOLD, "dcs_golden_hashes.json")))["workloads"]["survey3_65536"]["stream_hashes"]
+    streams = workloads.streams_survey3_65536()
+    b = D.build_stream_batch(streams, indexer=D.index_streams)
+    ctxs = [dcs.Context(0), dcs.Context(0)]
+    batches = []
+    for c in ctxs:
+        c.set_concurrent_batches(True)
+        batches.append(c.batch(b["blob"], b["srcs"], b["jobs"]))
+    def drive(bt):
+        for _ in range(10):
+            bt.run_many(100)
+            bt.sync()
+    th = [threading.Thread(target=drive, args=(bt,)) for bt in batches]
+    for t in th: t.start()
+    for t in th: t.join()
+    for bt in batches:
+        pcm, err = bt.download()
+        assert not (err & D.FRAME_TAIL_LOST).any() and not err.any()
+        assert stream_hashes(oracle, pcm, b["first_job"]) == gold
+        bt.close()
+    for c in ctxs:
+        c.close()
