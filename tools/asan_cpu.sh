@@ -10,7 +10,7 @@ CL=/opt/rocm/lib/llvm/bin/clang++
 for f in dcs_tables dcs_index dcs_params dcs_synth dcs_plan dcs_streams dcs_files dcs_rom dcs_sequencer dcs_decoder_hip; do
   $CL -x c++ -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -c $ROOT/dcsexplorer_amd/csrc/$f.cpp -o $OUT/$f.o
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -std=c++17 -fPIC -fsanitize=address -fno-gpu-sanitize -c $ROOT/dcsexplorer_amd/csrc/dcs_runtime.hip -o $OUT/dcs_runtime.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -std=c++17 -fPIC -fsanitize=address -fno-gpu-sanitize -include $ROOT/dcsexplorer_amd/csrc/build/dcs_build_id.h -c $ROOT/dcsexplorer_amd/csrc/dcs_runtime.hip -o $OUT/dcs_runtime.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -o $OUT/libdcs_hip.so $OUT/*.o -lz -Wl,-rpath,/opt/rocm/lib
 cp $ROOT/dcsexplorer_amd/libdcs_hip.so $OUT/libdcs_hip_orig.so
 trap 'cp $OUT/libdcs_hip_orig.so $ROOT/dcsexplorer_amd/libdcs_hip.so' EXIT
