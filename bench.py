@@ -594,6 +594,13 @@ def run_rank(args):
                 torch.cuda.set_device(0)
         else:
             torch.cuda.set_device(local_rank)
+            # one process per GPU: its threads (the pipeline's workers and indexers) and the buffers they pin belong on the
+            # GPU's NUMA node; dcs_node does the same per context for one process with several GPUs
+            try:
+                args.numa_node = D.bind_process_to_device_numa(local_rank)
+            except Exception as e:              # (placement is an optimisation: never a reason for a rank to die)
+                sys.stderr.write("bench.py: NUMA placement skipped (%s)\n" % e)
+                args.numa_node = None
             try:
                 dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
                 # (one collective now, so that a broken RCCL set-up shows here and not inside the timed region)
@@ -659,7 +666,7 @@ def run_rank(args):
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(1, args.steps) * 1e3,
                               "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int16",
                               "data": "synthetic", "rehearsal": "CPU rehearsal of the N-rank path: no GPU, no kernel, nothing measured",
-                              "config": {"workload": args.workload, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "frames_per_rank": counts, "frames_total": sum(counts),
+                              "config": {"workload": args.workload, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "rank0_bound_to_numa_node": getattr(args, "numa_node", None), "frames_per_rank": counts, "frames_total": sum(counts),
                                          "partition": "range over streams, balanced by frames, no collective"}}))
         if world > 1:
             dist.destroy_process_group()
@@ -773,7 +780,7 @@ def run_rank(args):
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
-            "config": {"workload": args.workload, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+            "config": {"workload": args.workload, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "rank0_bound_to_numa_node": getattr(args, "numa_node", None),
                        "workload_is": {"survey3_65536": "BASELINE configs[2] as SURVEY.md 8(d) Config 3 specifies it: 256 streams x 256 1994+ frames, 80 % Type 1 "
                                                         "sub-type 3, 10 % Type 1 sub-type 0, 10 % Type 0, 12 populated bands, 120 B/frame",
                                        "dcs94_65536": "BASELINE configs[2], the form of rounds 1 and 2: 16 populated bands, 96 B/frame"}.get(args.workload, args.workload),

@@ -13,5 +13,5 @@ from .api import (  # noqa: F401
     index_stream, index_streams, pack_streams, stream_params, volume_multiplier, mixing_multiplier, frame_scale,
     synth_stream, wav_header, dcsa_header, dcsa_parse, frame_diff, build_stream_batch, device_count, plan_chunks, pack_chunks, format_os,
     Context, Batch, RomSet, Sequencer, HW_DCS93, HW_DCS95,
-    host_threads, partition_streams, decode_streams_sharded, Pipeline, make_refs, FRAME_TAIL_LOST, Node, DevicePath, node_cache_release,
+    host_threads, partition_streams, decode_streams_sharded, Pipeline, make_refs, FRAME_TAIL_LOST, Node, DevicePath, node_cache_release, device_numa_node, bind_process_to_device_numa,
 )

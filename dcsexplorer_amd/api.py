@@ -1101,6 +1101,34 @@ class Node:
             pass
 
 
+def device_numa_node(device):
+    """NUMA node of a HIP device (dcs_device_numa_node: from its PCI address), or -1"""
+    return int(load_library().dcs_device_numa_node(int(device)))
+
+
+def bind_process_to_device_numa(device):
+    """bind the calling process (the threads it starts later inherit the mask, and the memory they pin or first touch is taken
+    from that node under the default local policy) to the CPUs of the GPU's NUMA node; -> the node, or None when it is unknown
+    or none of its CPUs may be used.  What dcs_node does per context, for a process that owns ONE GPU (a rank of bench.py)."""
+    node = device_numa_node(device)
+    if node < 0:
+        return None
+    try:
+        text = open("/sys/devices/system/node/node%d/cpulist" % node).read().strip()
+    except OSError:
+        return None
+    cpus = set()
+    for part in text.split(","):
+        if part:
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+    allowed = cpus & os.sched_getaffinity(0)
+    if not allowed:
+        return None
+    os.sched_setaffinity(0, allowed)
+    return node
+
+
 def node_cache_release():
     """destroy the contexts dcs_decode_streams_sharded keeps per device list"""
     load_library().dcs_node_cache_release()

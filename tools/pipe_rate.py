@@ -7,7 +7,10 @@ import dcsexplorer_amd as D
 from dcsexplorer_amd import workloads as W
 depth = int(sys.argv[1]); n = int(sys.argv[2]); wl = sys.argv[3] if len(sys.argv) > 3 else "survey3_65536"
 streams = W.corpus_streams(W.corpus_manifest(29, 20, 2000, 5)) if wl == "corpus" else W.WORKLOADS[wl]()
+if os.environ.get("BIND"):
+    print("bound to NUMA node", D.bind_process_to_device_numa(0))
 ctx = D.Context(0)
+print("link %.1f GB/s" % ctx.link_rate())
 refs, keep = D.make_refs(streams)
 pipe = ctx.pipeline(depth, index_on_device=True, pack_on_device=True, plan_on_device=True)
 for _ in range(int(os.environ.get("WARM_ROUNDS", "1"))):
