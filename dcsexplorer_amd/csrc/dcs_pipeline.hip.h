@@ -527,25 +527,39 @@ static DcsStatus pipelineDecodePlanned(DcsPipeline *p, DcsPipeline::Job *job, hi
         return st;
     if (nJobs > 0xFFFFFFFFull || job->totalRec > 0xFFFFFFFFull)
         return DCS_ERR_CAPACITY;
-    st = createBatchPlannedOnDevice(ctx, table.data(), n, job->extraFrames, static_cast<uint32_t>(nJobs), static_cast<uint32_t>(job->totalRec), all94,
-                                    has93a, payload, static_cast<const DcsFrameIndex *>(job->dRec), static_cast<const DcsStreamInfo *>(job->dInfo),
-                                    static_cast<const uint8_t *>(job->dBlob), job->hBlobLen, stream, &job->batch);
-    const double t1 = nowMs();
-    pipeLog("worker", 0, "plan-queue", t0, t1);
-    if (st == DCS_OK) st = dcs_batch_run(job->batch, nullptr);
-    if (st == DCS_OK) st = batchQueuePlanFlag(job->batch);
-    const double t2 = nowMs();
-    pipeLog("worker", 0, "run-queue", t1, t2);
-    if (st == DCS_OK) pipelineDownPolicy(p, job->batch);
-    if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
-    pipeLog("worker", 0, "download", t2, nowMs());
+    // A chunk whose frames' compressed bytes overflow the kernel's bit pool (224 bytes per slot) is what the arithmetic plan cannot
+    // close early as the host planner does: the list is planned again with fewer frames per chunk -- three quarters, then half of the
+    // slots -- before the host path gets it (one stream of large frames among 600 would otherwise cost the whole list the device).
+    double t1 = t0, t2 = t0;
     bool lost = false;
     uint32_t flag = 0;
-    if (st == DCS_OK)
+    const int fullFpw = chooseFpw(ctx, static_cast<uint32_t>(nJobs), all94);
+    const int tries[3] = { 0, fullFpw * 3 / 4, fullFpw / 2 };
+    for (int attempt = 0 ; attempt < 3 ; ++attempt)
     {
-        flag = batchPlanFlag(job->batch);
-        for (size_t j = 0 ; j < nJobs && !lost && flag == 0 ; ++j)
-            lost = (job->err[j] & DCS_FRAME_TAIL_LOST) != 0;
+        if (job->batch != nullptr) { dcs_batch_destroy(job->batch); job->batch = nullptr; }
+        st = createBatchPlannedOnDevice(ctx, table.data(), n, job->extraFrames, static_cast<uint32_t>(nJobs), static_cast<uint32_t>(job->totalRec), all94,
+                                        has93a, payload, static_cast<const DcsFrameIndex *>(job->dRec), static_cast<const DcsStreamInfo *>(job->dInfo),
+                                        static_cast<const uint8_t *>(job->dBlob), job->hBlobLen, stream, &job->batch, tries[attempt]);
+        t1 = nowMs();
+        pipeLog("worker", 0, "plan-queue", t0, t1);
+        if (st == DCS_OK) st = dcs_batch_run(job->batch, nullptr);
+        if (st == DCS_OK) st = batchQueuePlanFlag(job->batch);
+        t2 = nowMs();
+        pipeLog("worker", 0, "run-queue", t1, t2);
+        if (st == DCS_OK) pipelineDownPolicy(p, job->batch);
+        if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
+        pipeLog("worker", 0, "download", t2, nowMs());
+        lost = false;
+        flag = 0;
+        if (st == DCS_OK)
+        {
+            flag = batchPlanFlag(job->batch);
+            for (size_t j = 0 ; j < nJobs && !lost && flag == 0 ; ++j)
+                lost = (job->err[j] & DCS_FRAME_TAIL_LOST) != 0;
+        }
+        if (st != DCS_OK || flag != DCS_PLAN_POOL_OVERFLOW)
+            break;
     }
     job->hostMs += t1 - t0;
     job->deviceMs += nowMs() - t1;

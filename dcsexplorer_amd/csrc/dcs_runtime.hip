@@ -274,6 +274,7 @@ struct DcsBatch
     bool downByKernel = false;  // the PCM's way down by dcsCopyKernel instead of the runtime's copy (the pipelines)
     unsigned downBlocks = 1024; // ... with at most this many workgroups
     bool settled = false;       // a wait has covered everything enqueued for this batch and nothing was enqueued since
+    uint32_t planFpc = 0;       // frames per chunk of a plan made on the device (dcsPlanKernel)
     bool errJoined = false;     // dErr lies behind dPcm in ONE allocation (and hErr behind hPcm): the two come down in one copy
 };
 
@@ -892,15 +893,17 @@ namespace {
 template <int FPW>
 __global__ __launch_bounds__(256) void dcsPlanKernel(const DcsPlanStream *streams, uint32_t nStreams, uint32_t extraFrames, uint32_t nJobs,
                                                       const DcsFrameIndex *records, const DcsStreamInfo *infos,
-                                                      DcsSlot *slots, DcsPlanSrc *srcs, uint32_t *flagWord, uint32_t *hostFlag)
+                                                      DcsSlot *slots, DcsPlanSrc *srcs, uint32_t *flagWord, uint32_t *hostFlag, uint32_t fpc)
 {
-    const uint32_t nChunks = (nJobs + FPW - 1) / FPW;
+    // fpc: frames a chunk holds, FPW or -- for a list whose frames are too large for FPW of them to share the bit pool -- fewer (the
+    // chunk's other slots stay empty): chunk c holds jobs c * fpc .. c * fpc + fpc - 1
+    const uint32_t nChunks = (nJobs + fpc - 1) / fpc;
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nChunks)
         return;
     // the stream of the chunk's first job: the last stream whose first job is not behind it
     uint32_t lo = 0, hi = nStreams - 1;
-    const uint32_t j0 = c * FPW;
+    const uint32_t j0 = c * fpc;
     while (lo < hi)
     {
         const uint32_t mid = (lo + hi + 1) / 2;
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(256) void dcsPlanKernel(const DcsPlanStream *stream
     for (int p = 0 ; p < FPW ; ++p)
     {
         const uint32_t j = j0 + static_cast<uint32_t>(p);
-        if (j >= nJobs) { out[p] = empty; continue; }
+        if (j >= nJobs || static_cast<uint32_t>(p) >= fpc) { out[p] = empty; continue; }
         while (k + 1 < nStreams && j >= streams[k + 1].firstJob)
         {
             ++k;
@@ -946,7 +949,7 @@ __global__ __launch_bounds__(256) void dcsPlanKernel(const DcsPlanStream *stream
                 sl.prevJob = c - 1;
             }
         }
-        if ((p == FPW - 1 || j + 1 == nJobs) && f + 1 < framesOut && j + 1 < nJobs)
+        if ((static_cast<uint32_t>(p) == fpc - 1 || j + 1 == nJobs) && f + 1 < framesOut && j + 1 < nJobs)
             sl.flags |= DCS_SLOT_EXPORT;
         if (has)
         {
@@ -1131,11 +1134,11 @@ static DcsStatus queuePlanAndPack(DcsBatch *b, uint32_t nStreams, uint32_t extra
     const DcsPlanStream *dT = static_cast<const DcsPlanStream *>(b->dTable);
     const uint32_t blocks = (b->nChunks + 3) / 4;
     if (b->fpw == 16)
-        hipLaunchKernelGGL(dcsPlanKernel<16>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord, static_cast<uint32_t *>(b->hStage));
+        hipLaunchKernelGGL(dcsPlanKernel<16>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord, static_cast<uint32_t *>(b->hStage), b->planFpc);
     else if (b->fpw == 8)
-        hipLaunchKernelGGL(dcsPlanKernel<8>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord, static_cast<uint32_t *>(b->hStage));
+        hipLaunchKernelGGL(dcsPlanKernel<8>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord, static_cast<uint32_t *>(b->hStage), b->planFpc);
     else
-        hipLaunchKernelGGL(dcsPlanKernel<4>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord, static_cast<uint32_t *>(b->hStage));
+        hipLaunchKernelGGL(dcsPlanKernel<4>, dim3(planBlocks), dim3(64), 0, b->stream, dT, nStreams, extraFrames, nJobs, dRecords, dInfos, dS, dP, flagWord, static_cast<uint32_t *>(b->hStage), b->planFpc);
     HIPCHK(ctx, hipGetLastError());
     if (between != nullptr)
         HIPCHK(ctx, hipEventRecord(between, b->stream));
@@ -1155,7 +1158,8 @@ static DcsStatus queuePlanAndPack(DcsBatch *b, uint32_t nStreams, uint32_t extra
 // batch) behind the decode launch by batchQueuePlanFlag; a non-zero flag means the PCM of this batch is not to be used.
 static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *table, uint32_t nStreams, uint32_t extraFrames, uint32_t nJobs,
                                             uint32_t nRecords, bool all94, bool has93aT1, uint64_t payloadBytes, const DcsFrameIndex *dRecords,
-                                            const DcsStreamInfo *dInfos, const uint8_t *dBlob, uint64_t blobLen, hipStream_t stream, DcsBatch **out)
+                                            const DcsStreamInfo *dInfos, const uint8_t *dBlob, uint64_t blobLen, hipStream_t stream, DcsBatch **out,
+                                            int framesPerChunk = 0)
 {
     *out = nullptr;
     if (nStreams == 0 || nJobs == 0)
@@ -1175,7 +1179,13 @@ static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *ta
     const uint64_t pcm = static_cast<uint64_t>(nJobs) * DCS_FRAME_SAMPLES * 2;
     b->algoBytes = payloadBytes + static_cast<uint64_t>(nRecords) * 56u + pcm;
     b->abiBytes = payloadBytes + static_cast<uint64_t>(nRecords) * sizeof(DcsSrcDesc) + static_cast<uint64_t>(nJobs) * sizeof(DcsFrameJob) + pcm;
-    b->nChunks = (nJobs + static_cast<uint32_t>(b->fpw) - 1) / static_cast<uint32_t>(b->fpw);
+    // (framesPerChunk: fewer frames per chunk than the kernel variant has slots -- the pipeline's second attempt for a list whose
+    // frames are too large for a full chunk's bit pool; the context's diagnostic setting applies as well)
+    {
+        int fpc = framesPerChunk > 0 ? framesPerChunk : ctx->framesPerChunk;
+        b->planFpc = static_cast<uint32_t>(fpc >= 1 && fpc < b->fpw ? fpc : b->fpw);
+    }
+    b->nChunks = (nJobs + b->planFpc - 1) / b->planFpc;
     const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw);
     void *dTable = nullptr;
     const size_t tableBytes = sizeof(DcsPlanStream) * nStreams;

@@ -210,7 +210,7 @@ def test_pipeline_device_index_stream_that_announces_far_more_than_it_holds(gpu_
     assert recs_d.tobytes() == recs_h.tobytes()
 
 
-def test_saturated_frames_fill_the_bit_pool_and_the_device_planner_hands_the_list_back(gpu_ctx, oracle):
+def test_saturated_frames_fill_the_bit_pool_and_the_device_planner_plans_again_or_hands_the_list_back(gpu_ctx, oracle):
     """synth profile 4: every band at its widest code in every frame, ~500 bytes a frame where the workloads have ~100.  The
     chunks' compressed bytes then no longer fit the kernel's bit pool: the host planner closes such chunks early, the
     device planner (arithmetic chunks) flags the list and the pipeline decodes it through the host planner -- same PCM as
@@ -236,7 +236,32 @@ def test_saturated_frames_fill_the_bit_pool_and_the_device_planner_hands_the_lis
                 pipe.close()
                 assert easy_path == (0, 1, 3, 7)[mode]
                 if mode == 3:
-                    assert hard_path == 0          # handed back: host index pass, host planner, host packer
+                    # planned again on the device with three quarters, then half of the slots per chunk; where even that overflows
+                    # the pool (8 and 16 frames per wavefront: 448 bytes per frame) the list is handed back: host index pass, planner, packer
+                    assert hard_path == (7 if fpw == 4 else 0)
+    finally:
+        gpu_ctx.set_frames_per_wave(0)
+
+
+def test_large_frames_are_planned_again_on_the_device_with_fewer_frames_per_chunk(gpu_ctx, oracle):
+    """frames of 260 to 330 bytes (ten of sixteen bands at their widest codes): eight of them overflow a chunk's bit pool (224 bytes
+    per slot), so the arithmetic plan of the device planner flags the list -- and the pipeline plans it AGAIN on the device with six,
+    then four frames per chunk instead of handing it to the host (round 4: one such stream among 600 used to cost a 600 000-frame list
+    the device path).  DcsPipelineResult.path says 7; the PCM is the oracle's."""
+    lst = [(os_for(f, f & 1), make_stream(f, 60 + f, seed=67000 + f, profile=4, nbands=10), 255, 0x64) for f in (0, 1, 3)]
+    lst += [(os_for(f, 1), make_stream(f, 40, seed=67100 + f), 255, 0x64) for f in ALL_FORMATS]
+    assert 280 < max(len(s) / (((s[0] << 8) | s[1]) + 0.0) for _, s, _, _ in lst) < 340
+    want = np.concatenate([oracle.decode(o, v, [s], [l], ((s[0] << 8) | s[1]) + 2) for o, s, v, l in lst])
+    try:
+        for fpw in (8, 16):
+            gpu_ctx.set_frames_per_wave(fpw)
+            pipe = gpu_ctx.pipeline(2, index_on_device=True, pack_on_device=True, plan_on_device=True)
+            pipe.submit(lst, extra_frames=2)
+            pcm, err, _, _, _ = pipe.collect()
+            path = pipe.last_path
+            pipe.close()
+            assert np.array_equal(pcm, want) and not err.any(), "fpw %d" % fpw
+            assert path == 7, "fpw %d: path %d" % (fpw, path)
     finally:
         gpu_ctx.set_frames_per_wave(0)
 
