@@ -546,7 +546,7 @@ def corpus_by_title(ctx, args, streams, manifest, lo, golden):
             titles.append((start, k)); start = k
     lists = [D.make_refs(streams[a:b]) for a, b in titles]
     frames = sum(((s[1][0] << 8) | s[1][1]) for s in streams)
-    depth = 4
+    depth = int(os.environ.get("DCS_BENCH_TITLES_IN_FLIGHT", "4"))
     pipe = ctx.pipeline(depth, index_on_device=True, pack_on_device=True, plan_on_device=True)
     pool = ThreadPoolExecutor(max_workers=min(16, D.host_threads()))
     result = {}
