@@ -544,6 +544,14 @@ def corpus_by_title(ctx, args, streams, manifest, lo, golden):
     for k in range(1, len(streams) + 1):
         if k == len(streams) or manifest[lo + k]["title"] != manifest[lo + start]["title"]:
             titles.append((start, k)); start = k
+    # (DCS_BENCH_TITLE_PARTS=n: every title as n lists of consecutive streams -- smaller lists, more of them in flight)
+    parts = int(os.environ.get("DCS_BENCH_TITLE_PARTS", "1"))
+    if parts > 1:
+        cut = []
+        for a, b in titles:
+            step = max(1, (b - a + parts - 1) // parts)
+            cut += [(x, min(b, x + step)) for x in range(a, b, step)]
+        titles = cut
     lists = [D.make_refs(streams[a:b]) for a, b in titles]
     frames = sum(((s[1][0] << 8) | s[1][1]) for s in streams)
     depth = int(os.environ.get("DCS_BENCH_TITLES_IN_FLIGHT", "4"))
@@ -581,7 +589,7 @@ def corpus_by_title(ctx, args, streams, manifest, lo, golden):
                                "errors_flagged": not ok}
     pipe.close(); pool.shutdown()
     link = ctx.link_rate()
-    result.update({"titles": len(titles), "streams": len(streams), "frames": frames, "titles_in_flight": depth,
+    result.update({"lists": len(titles), "lists_per_title": parts, "streams": len(streams), "frames": frames, "titles_in_flight": depth,
                    "link_floor_seconds": frames * 480 / (link * 1e9), "link_GBps": link,
                    "note": "first_pass allocates the context's buffers (291 MB of pinned memory per title in flight), second_pass finds them in its "
                            "cache; a third, untimed pass hashes every stream's PCM against the reference's committed hashes (bit_exact)"})

@@ -7,6 +7,8 @@ import dcsexplorer_amd as D
 from dcsexplorer_amd import workloads as W
 depth = int(sys.argv[1]); n = int(sys.argv[2]); wl = sys.argv[3] if len(sys.argv) > 3 else "survey3_65536"
 streams = W.corpus_streams(W.corpus_manifest(29, 20, 2000, 5)) if wl == "corpus" else W.WORKLOADS[wl]()
+if os.environ.get("STREAMS"):                       # e.g. STREAMS=0:150: a slice of the workload's streams as the list
+    a, b = os.environ["STREAMS"].split(":"); streams = streams[int(a):int(b)]
 if os.environ.get("BIND"):
     print("bound to NUMA node", D.bind_process_to_device_numa(0))
 ctx = D.Context(0)
