@@ -344,3 +344,47 @@ def test_batch_built_from_threaded_indexer_is_identical():
     assert a["blob"] == b["blob"]
     assert a["srcs"].tobytes() == b["srcs"].tobytes()
     assert a["jobs"].tobytes() == b["jobs"].tobytes()
+
+
+def test_dcs93_4096_follows_survey_config_2_to_the_letter():
+    """SURVEY 8(d) Config 2: 64 streams x 64 frames of OS93 Type 0; header bands 0-11 populated with scale codes uniform in 0x20..0x34,
+    bands 12-15 empty (0xFF / 0x7F); one stream in ten carries the 0x40 stride bit on bands >= 6 (a strided Type-0 band spans 32 slots,
+    so such a stream keeps the ten bands that fit the 255-slot frame); band-type codes 0 / 1-3 / 4-6 / 7-9 at 15 / 35 / 40 / 10 %"""
+    from dcsexplorer_amd import workloads
+    import dcsexplorer_amd as D
+    streams = workloads.streams_dcs93_4096()
+    assert len(streams) == 64
+    codes = []
+    for k, (os_, s, vol, lvl) in enumerate(streams):
+        assert ((s[0] << 8) | s[1]) == 64 and not (s[2] & 0x80)                # 64 frames, Type 0
+        hdr = s[2:18]
+        strided = (k % 10) == 9
+        populated = [b for b in range(16) if (hdr[b] & 0x7F) != 0x7F]
+        assert populated == list(range(10 if strided else 12))
+        for b in populated:
+            assert 0x20 <= (hdr[b] & 0x3F) <= 0x34
+            assert bool(hdr[b] & 0x40) == (strided and b >= 6)
+        recs, info = D.index_stream(os_, s)
+        assert info.nValidFrames == 64
+        codes.append(len(s) / 64.0)
+    assert 80 < sum(codes) / len(codes) < 140                                   # bytes per frame
+
+
+def test_several_gpu_entries_fail_loudly_without_a_gpu(dcs):
+    """dcs_node_create / dcs_decode_streams_sharded / dcs_device_numa_node on a box without a GPU: an error, no crash, no fallback"""
+    if dcs.device_count() > 0:
+        return
+    assert dcs.device_numa_node(0) == -1 and dcs.bind_process_to_device_numa(0) is None
+    try:
+        dcs.Node([0, 0], depth=2)
+    except dcs.DcsError as e:
+        assert e.status == -2
+    else:
+        raise AssertionError("Node() succeeded without a GPU")
+    s = dcs.synth_stream(dcs.FMT_94_T1_S3, 8, seed=1)
+    try:
+        dcs.decode_streams_sharded([0], [(dcs.OS95, s, 255, 0x64)])
+    except dcs.DcsError as e:
+        assert e.status == -2
+    else:
+        raise AssertionError("dcs_decode_streams_sharded succeeded without a GPU")
