@@ -116,6 +116,7 @@ struct DcsNode
     struct Pending { uint32_t dev; uint64_t frames; };
     std::deque<Pending> order;                  // submitted, not yet collected
     std::string lastError;
+    std::mutex submitMutex;                     // dcs_node_submit: pipeline creation and the hand-over to a pipeline, one at a time
     std::mutex callMutex;                       // dcs_decode_streams_sharded: one call at a time per node
 };
 
@@ -211,31 +212,32 @@ extern "C" DcsStatus dcs_node_submit(DcsNode *n, const DcsStreamRef *streams, ui
                 break;
             n->room.wait(lk);
         }
-        n->devs[pick].listsInFlight += 1;
+        n->devs[pick].listsInFlight += 1;           // (the place is taken; the list joins `order` once its pipeline has it)
         n->devs[pick].framesInFlight += frames;
-        n->order.push_back(DcsNode::Pending{ pick, frames });
     }
     DcsNode::Dev &dev = n->devs[pick];
     DcsStatus st = DCS_OK;
-    if (dev.pipe == nullptr)
-        st = onNumaNode(dev.numa, [&] { return dcs_pipeline_create(dev.ctx, n->depth, n->flags, &dev.pipe); });
-    if (st == DCS_OK)
-        st = dcs_pipeline_submit(dev.pipe, streams, nStreams, extraFrames);
-    if (st != DCS_OK)
     {
+        // one submission at a time from here on: a device's pipeline is made once, and `order` is the order in which the
+        // pipelines received their lists (dcs_node_collect may run on another thread and must find every list it is
+        // told about already in its pipeline)
+        std::lock_guard<std::mutex> sub(n->submitMutex);
+        if (dev.pipe == nullptr)
+            st = onNumaNode(dev.numa, [&] { return dcs_pipeline_create(dev.ctx, n->depth, n->flags, &dev.pipe); });
+        if (st == DCS_OK)
+            st = dcs_pipeline_submit(dev.pipe, streams, nStreams, extraFrames);
         std::lock_guard<std::mutex> lk(n->m);
-        n->lastError = std::string("device ") + std::to_string(dev.id) + ": " + dcs_last_error(dev.ctx);
-        dev.listsInFlight -= 1;
-        dev.framesInFlight -= frames;
-        // (the submission this call queued is the newest one of its device)
-        for (size_t i = n->order.size() ; i-- > 0 ; )
-            if (n->order[i].dev == pick)
-            {
-                n->order.erase(n->order.begin() + static_cast<long>(i));
-                break;
-            }
-        n->room.notify_all();
+        if (st == DCS_OK)
+            n->order.push_back(DcsNode::Pending{ pick, frames });
+        else
+        {
+            n->lastError = std::string("device ") + std::to_string(dev.id) + ": " + dcs_last_error(dev.ctx);
+            dev.listsInFlight -= 1;
+            dev.framesInFlight -= frames;
+        }
     }
+    if (st != DCS_OK)
+        n->room.notify_all();
     return st;
 }
 

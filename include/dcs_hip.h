@@ -366,8 +366,9 @@ void      dcs_node_cache_release(void);
  * device, DCS_PIPE_* flags; created with the first list).  dcs_node_submit deals a list to the device with the fewest
  * FRAMES in flight among those with room and blocks while none has room; dcs_node_collect returns the results in
  * SUBMISSION order whatever device decoded them (pointers into that device's pinned memory, valid until the next
- * collect; deviceIndexOut, optional, says which entry of deviceIds it was).  Streams must stay valid until collected;
- * submit and collect from one thread each.  No data moves between the devices: no collective, no peer copies.
+ * collect; deviceIndexOut, optional, says which entry of deviceIds it was; DCS_ERR_INVALID_ARG when no submitted list is
+ * outstanding).  Streams must stay valid until collected; submit and collect may run on different threads (a list counts as
+ * submitted once dcs_node_submit has returned; concurrent submits are taken one at a time).  No data moves between the devices: no collective, no peer copies.
  * Placement: every context, its pipeline's worker and indexer threads and the pinned buffers they allocate are created
  * from a thread bound to the CPUs of the GPU's NUMA node (dcs_device_numa_node: /sys/bus/pci/devices/<addr>/numa_node; the
  * default local memory policy then places the buffers there).  Where the node is unknown (-1) nothing is bound. */
