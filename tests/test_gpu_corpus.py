@@ -472,6 +472,38 @@ def test_node_two_contexts_on_one_device_200_lists_in_submission_order_memory_fl
     node.close()
 
 
+def test_node_submit_and_collect_on_two_threads(gpu_ctx):
+    """dcs_node_submit on one thread, dcs_node_collect on another, from the very first list on (a device's pipeline is created
+    by its first submit): a list counts as submitted once submit has returned, every list comes back in submission order"""
+    import threading, zlib
+    base = workloads.streams_mixed_16384(n_streams=24, n_frames=40)
+    variants = [base[:24], base[2:9], base[8:24] + base[:3]]
+    want = [zlib.crc32(gpu_ctx.decode_streams(v)[0].tobytes()) for v in variants]
+    refs = [D.make_refs(v) for v in variants]
+    node = D.Node([0, 0], depth=4)
+    n, submitted, got, errors = 60, threading.Semaphore(0), [], []
+
+    def collector():
+        try:
+            for _ in range(n):
+                submitted.acquire()
+                pcm, err, first, _, _, dev = node.collect()
+                got.append((zlib.crc32(pcm.tobytes()), bool(err.any()), len(first) - 1))
+        except Exception as e:          # (reported by the main thread)
+            errors.append(e)
+
+    t = threading.Thread(target=collector)
+    t.start()
+    for k in range(n):
+        v = (k * 5 + k // 7) % 3
+        node.submit_refs(refs[v][0], len(variants[v]))
+        submitted.release()
+    t.join(120)
+    assert not t.is_alive() and not errors, errors
+    assert got == [(want[(k * 5 + k // 7) % 3], False, len(variants[(k * 5 + k // 7) % 3])) for k in range(n)]
+    node.close()
+
+
 def test_sharded_entry_keeps_its_contexts_between_calls(oracle, corpus):
     """dcs_decode_streams_sharded runs on the persistent contexts of a cached node: the second call with the same device
     list creates nothing (markedly faster than the first, which creates two contexts), same PCM both times"""
