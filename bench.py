@@ -554,7 +554,7 @@ def corpus_by_title(ctx, args, streams, manifest, lo, golden):
         titles = cut
     lists = [D.make_refs(streams[a:b]) for a, b in titles]
     frames = sum(((s[1][0] << 8) | s[1][1]) for s in streams)
-    depth = int(os.environ.get("DCS_BENCH_TITLES_IN_FLIGHT", "8"))
+    depth = int(os.environ.get("DCS_BENCH_TITLES_IN_FLIGHT", "12"))
     ctx.trim_cache()            # (what the measurements before this one left in the context's buffer cache: multi-gigabyte buffers of the resident batch)
     pipe = ctx.pipeline(depth, index_on_device=True, pack_on_device=True, plan_on_device=True)
     pool = ThreadPoolExecutor(max_workers=min(16, D.host_threads()))

@@ -238,8 +238,9 @@ DcsStatus dcs_ctx_set_concurrent_batches(DcsCtx *ctx, int enable);
  * cost as much as decoding thousands of frames, and hipFree waits for the whole device).  What it may keep is bounded:
  * by default min(32 GB, an eighth of the card's free memory at dcs_ctx_create) of device memory and min(8 GB, a
  * sixteenth of the host's RAM) of pinned memory (environment: DCS_CACHE_DEV_MB / DCS_CACHE_PIN_MB).  An allocation that
- * fails gives cached buffers back (largest first) and is tried again before DCS_ERR_NO_MEMORY reaches the caller.
- * dcs_ctx_trim_cache releases everything the cache holds now (a pipeline does that when it is destroyed);
+ * fails gives cached buffers back (largest first) and is tried again before DCS_ERR_NO_MEMORY reaches the caller.  A buffer
+ * that comes back to a full cache stays and the OLDEST cached buffers go (the next list is most likely of the size of the last).
+ * dcs_ctx_trim_cache releases everything the cache holds now (e.g. between jobs of very different list sizes);
  * dcs_ctx_cache_bytes reports what it holds and the limits.  Output pointers may be NULL. */
 DcsStatus dcs_ctx_set_cache_limits(DcsCtx *ctx, uint64_t deviceBytes, uint64_t pinnedBytes);
 DcsStatus dcs_ctx_trim_cache(DcsCtx *ctx, uint64_t *deviceBytesReleased, uint64_t *pinnedBytesReleased);
@@ -417,9 +418,9 @@ typedef struct DcsPipelineResult
  * whole streams has a regular job list, so its plan is arithmetic, one thread per chunk.  Nothing of the index results
  * comes back to the host; a worker lays the list's streams out and uploads them, and once the walk is done queues planner,
  * packer, decode kernel and the copy down on one stream and sleeps until the PCM is there.  A list the arithmetic plan
- * cannot serve (a chunk whose compressed bytes overflow the kernel's bit pool, where the host planner closes the chunk
- * early; a stream that runs past its buffer) is decoded by the host-planned path instead, same PCM
- * (DcsPipelineResult.path tells). */
+ * cannot serve (a stream that runs past its buffer; a chunk whose compressed bytes overflow the kernel's bit pool, where the
+ * host planner closes the chunk early -- such a list is first planned again on the device with three quarters, then half of
+ * the frames per chunk) is decoded by the host-planned path instead, same PCM (DcsPipelineResult.path tells). */
 #define DCS_PIPE_PLAN_ON_DEVICE  4u
 #define DCS_PIPE_ALL_ON_DEVICE   7u      /* the three together: what a caller with many lists in flight wants */
 DcsStatus dcs_pipeline_create(DcsCtx *ctx, int depth /* 1..64 lists in flight */, uint32_t flags, DcsPipeline **out);
