@@ -37,6 +37,8 @@ sys.path.insert(0, ROOT)
 # first GPU call; libdcs_hip.so sets the same default when it is loaded first -- dcs_runtime.hip): the pipelines of end_to_end
 # run a dozen streams, and with the default of 4 a list's chain of short kernels waits behind other lists' copies
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (this pool's host driver supports dmabuf IPC only: RCCL between the ranks of a node needs it, whoever launched them)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 DEFAULT_WORKLOAD = "survey3_65536"  # BASELINE.json configs[2] as SURVEY.md 8(d) specifies it (12 bands, 120 B/frame): the configuration the roofline is quoted on

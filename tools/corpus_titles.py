@@ -1,5 +1,5 @@
 """BASELINE configs[4] at SURVEY's size (29 titles x 600 streams) through dcs_pipeline, one title per list: seconds per pass for several
-numbers of titles in flight, and where a title's time goes (DCS_PIPE_TRACE=1 on the last pass: the pipeline's "pipe life" lines, averaged).
+numbers of titles in flight, and where a title's time goes (DCS_PIPE_TRACE=1 on the last pass, or on pass TRACE_PASS: the pipeline's "pipe life" lines, averaged).
 argv[1:]: titles in flight to try (default 4 8)"""
 import sys, os, time, re, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,8 +19,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     ctx = D.Context(0)
     pipe = ctx.pipeline(depth, index_on_device=True, pack_on_device=True, plan_on_device=True)
     for p in range(3):
-        if p == 2:
+        if p == int(os.environ.get("TRACE_PASS", "2")):
             os.environ["DCS_PIPE_TRACE"] = "1"
+        else:
+            os.environ.pop("DCS_PIPE_TRACE", None)
         done = 0; t0 = time.perf_counter(); lat = []; sub = []
         for i, (refs, keep) in enumerate(lists):
             sub.append(time.perf_counter()); pipe.submit_refs(refs, titles[i][1] - titles[i][0])
