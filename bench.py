@@ -78,6 +78,10 @@ def parse_args(argv=None):
                     "contexts, a pipeline each, lists dealt by frames in flight, threads and pinned buffers on each GPU's NUMA node); with "
                     "--share-gpu every context is on GPU 0 (test on a one-GPU box), else context d is on GPU d")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the N-rank path (gloo, no GPU, no kernel)")
+    ap.add_argument("--force-dist", action="store_true", help="ONE rank (RANK=0 WORLD_SIZE=1) through the N-rank code: process group over RCCL with "
+                    "device_id, NUMA bind, the exchanges on the device, end_to_end over the ranks -- what a one-GPU box can run of --gpus N")
+    ap.add_argument("--dist-timeout", type=float, default=120.0, help="seconds the ranks' rendezvous, init_process_group and every later exchange may take")
+    ap.add_argument("--sections-budget", type=float, default=300.0, help="seconds all optional sections of the line may take together (each has a budget of its own)")
     ap.add_argument("--share-gpu", action="store_true", help="testing on a one-GPU box: every rank decodes on GPU 0 and gloo carries the "
                     "barrier and the max (RCCL needs one device per rank); exercises the whole N-rank path but is no scaling measurement")
     return ap.parse_args(argv)
@@ -264,59 +268,99 @@ def second_workload(ctx, args, torch, name="realistic_65536"):
     return out
 
 
-def end_to_end_ranks(ctx, streams, n_frames, world, rank, device, depth=48, lists=96):
+def end_to_end_ranks(ctx, streams, n_frames, comm, depth=48, lists=96, budget_s=90.0):
     """N ranks on one node, each with a pipeline of its own (index pass, planner and packer on the device) over its own lists, all
     sharing the box's host CPUs: value = the samples all ranks delivered / the slowest rank's time (barrier before the
-    clock starts).  Per rank: ms per list, the worker threads' wall time per list, CPU-milliseconds per list."""
+    clock starts).  Per rank: ms per list, the worker threads' wall time per list, CPU-milliseconds per list.
+    A rank whose pipeline fails or does not come back within `budget_s` still reaches every exchange and contributes a row of
+    NaNs: the other ranks' figures are reported, the failed rank is named."""
+    import math
     import resource
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+    import threading
     import dcsexplorer_amd as D
-    refs, keep = D.make_refs(streams)
-    pipe = ctx.pipeline(depth, index_on_device=True, pack_on_device=True, plan_on_device=True)
-    for _ in range(depth):
-        pipe.submit_refs(refs, len(streams))
-    for _ in range(depth):
-        pipe.collect()
-    n_lists = max(lists, 2 * depth)
-    host_ms, dev_ms = [], []
-    dist.barrier()
-    r0 = resource.getrusage(resource.RUSAGE_SELF)
-    t0 = time.perf_counter()
-    done = 0
-    for k in range(n_lists):
-        pipe.submit_refs(refs, len(streams))
-        if k >= depth - 1:
+    world, rank = comm.world, comm.rank
+    box = {}
+
+    def warm():
+        inject("end_to_end_ranks")
+        refs, keep = D.make_refs(streams)
+        pipe = ctx.pipeline(depth, index_on_device=True, pack_on_device=True, plan_on_device=True)
+        for _ in range(depth):
+            pipe.submit_refs(refs, len(streams))
+        for _ in range(depth):
+            pipe.collect()
+        box.update(refs=refs, keep=keep, pipe=pipe)
+
+    def timed():
+        refs, pipe = box["refs"], box["pipe"]
+        n_lists = max(lists, 2 * depth)
+        host_ms, dev_ms = [], []
+        r0 = resource.getrusage(resource.RUSAGE_SELF)
+        t0 = time.perf_counter()
+        done = 0
+        for k in range(n_lists):
+            pipe.submit_refs(refs, len(streams))
+            if k >= depth - 1:
+                r = pipe.collect(); done += 1
+                host_ms.append(r[3]); dev_ms.append(r[4])
+        while done < n_lists:
             r = pipe.collect(); done += 1
             host_ms.append(r[3]); dev_ms.append(r[4])
-    while done < n_lists:
-        r = pipe.collect(); done += 1
-        host_ms.append(r[3]); dev_ms.append(r[4])
-    dt = time.perf_counter() - t0
-    r1 = resource.getrusage(resource.RUSAGE_SELF)
-    pipe.close()
-    dist.barrier()
-    cpu_ms = ((r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)) * 1e3 / n_lists
-    mine = torch.zeros(world, 5, dtype=torch.float64, device=device if device is not None else "cpu")
-    mine[rank] = torch.tensor([dt, n_lists, sum(host_ms) / len(host_ms), sum(dev_ms) / len(dev_ms), cpu_ms], dtype=torch.float64)
-    dist.all_reduce(mine)
-    rows = mine.cpu().numpy()
-    slowest = float(rows[:, 0].max())
-    total_lists = float(rows[:, 1].sum())
+        dt = time.perf_counter() - t0
+        r1 = resource.getrusage(resource.RUSAGE_SELF)
+        pipe.close()
+        cpu_ms = ((r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)) * 1e3 / n_lists
+        box["row"] = [dt, n_lists, sum(host_ms) / len(host_ms), sum(dev_ms) / len(dev_ms), cpu_ms]
+
+    def bounded(fn, what):
+        """run fn in a thread, wait at most what is left of budget_s -> None or the reason it has no result"""
+        if "error" in box:
+            return
+        def work():
+            try:
+                fn()
+            except BaseException as e:
+                box["error"] = "%s: %s: %s" % (what, type(e).__name__, e)
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(max(1.0, t_end - time.perf_counter()))
+        if th.is_alive():
+            box["error"] = "%s: no result after %.0f s" % (what, budget_s)
+            box["abandoned"] = True
+
+    t_end = time.perf_counter() + budget_s
+    bounded(warm, "warm-up lists")
+    comm.barrier()
+    bounded(timed, "timed lists")
+    comm.barrier()
+    nan = float("nan")
+    rows = comm.gather_rows(box.get("row", [nan] * 5) if "error" not in box else [nan] * 5)
+    good = [r for r in range(world) if not math.isnan(rows[r][0])]
+    failed = [r for r in range(world) if r not in good]
     usable = D.host_threads()
-    return {"unit": "samples/s", "frames_per_list": n_frames,
+    out = {"unit": "samples/s", "frames_per_list": n_frames, "ranks_failed": failed, "abandoned": bool(box.get("abandoned"))}
+    if "error" in box:
+        out["error_rank%d" % rank] = box["error"]
+        sys.stderr.write("bench.py: rank %d: end_to_end: %s\n" % (rank, box["error"]))
+    if not good:
+        out["error"] = "no rank finished its lists" + (": " + box["error"] if "error" in box else "")
+        return out
+    slowest = max(rows[r][0] for r in good)
+    total_lists = sum(rows[r][1] for r in good)
+    cpu_mean = sum(rows[r][4] for r in good) / len(good)
+    out.update({
             "sustained": {"value": total_lists * n_frames * 240 / slowest, "ms_per_list": slowest / total_lists * 1e3, "depth_per_rank": depth,
-                          "lists_per_rank": n_lists, "ranks": world,
+                          "lists_per_rank": int(rows[good[0]][1]), "ranks": len(good),
                           "what": "every rank its own dcs_pipeline (index pass, planner and packer on the device), lists in flight, PCM returned in "
                                   "pinned memory; all ranks' samples over the slowest rank's time"},
-            "per_rank": [{"rank": r, "ms_per_list": float(rows[r, 0] / rows[r, 1] * 1e3), "worker_host_ms": float(rows[r, 2]),
-                          "worker_device_ms": float(rows[r, 3]), "cpu_ms_per_list": float(rows[r, 4])} for r in range(world)],
+            "per_rank": [{"rank": r, "ms_per_list": rows[r][0] / rows[r][1] * 1e3, "worker_host_ms": rows[r][2],
+                          "worker_device_ms": rows[r][3], "cpu_ms_per_list": rows[r][4]} for r in good],
             "usable_cpus": usable,
-            "host_ceiling": {"cpu_ms_per_list": float(rows[:, 4].mean()), "lists_per_s_the_cpus_allow": usable * 1e3 / max(float(rows[:, 4].mean()), 1e-9),
-                             "samples_per_s_the_cpus_allow": usable * 1e3 / max(float(rows[:, 4].mean()), 1e-9) * n_frames * 240,
+            "host_ceiling": {"cpu_ms_per_list": cpu_mean, "lists_per_s_the_cpus_allow": usable * 1e3 / max(cpu_mean, 1e-9),
+                             "samples_per_s_the_cpus_allow": usable * 1e3 / max(cpu_mean, 1e-9) * n_frames * 240,
                              "note": "the ranks of a node share its host CPUs (usable_cpus: affinity mask and cgroup quota): CPU-milliseconds "
-                                     "per list times lists per second cannot exceed them, whatever the number of GPUs"}}
+                                     "per list times lists per second cannot exceed them, whatever the number of GPUs"}})
+    return out
 
 
 def load_counters(workload, profiles_dir=None):
@@ -644,11 +688,85 @@ def verify_rank(args, batch, b, streams, rank, corpus, golden_range):
     return ok, "%d of rank %d's %d streams compared with the oracle sample for sample (no committed hashes for this range)" % (len(pick), rank, len(streams))
 
 
+# --------------------------------------------------------------------------------------------- sections that may fail
+def inject(name):
+    """test hooks (tests/test_gpu_bench.py, tests/test_multirank_gloo.py): DCS_BENCH_INJECT_FAIL=<section>[@rank][,...] raises inside
+    that section (on that rank only), DCS_BENCH_INJECT_HANG=<section>[@rank] never returns from it"""
+    me = os.environ.get("RANK", "0")
+    def named(var):
+        for item in filter(None, os.environ.get(var, "").split(",")):
+            sec, _, only = item.partition("@")
+            if sec == name and (not only or only == me):
+                return True
+        return False
+    if named("DCS_BENCH_INJECT_FAIL"):
+        raise RuntimeError("injected failure in %s" % name)
+    if named("DCS_BENCH_INJECT_HANG"):
+        while True:
+            time.sleep(1.0)
+
+
+class Sections:
+    """The optional sections of the line (other workloads, cold inputs, the whole device path, end to end, the CPU baseline) run
+    AFTER everything `value`, `roofline` and `bit_exact` need has been gathered, each in a thread with a wall budget: an exception
+    or a section that does not come back leaves {"error": ...} in its place and the line is still printed.  A section that was
+    abandoned may still hold the GPU, so the ones behind it are skipped and the process leaves through os._exit once the line is out."""
+
+    def __init__(self, total_s):
+        self.left, self.abandoned = float(total_s), None
+
+    def run(self, name, fn, budget_s):
+        import threading
+        import traceback
+        budget_s = float(os.environ.get("DCS_BENCH_SECTION_BUDGET_S", budget_s))
+        if self.abandoned is not None:
+            return {"error": "skipped: section %s did not come back and may still hold the GPU" % self.abandoned}
+        budget = min(budget_s, self.left)
+        if budget < 1.0:
+            return {"error": "skipped: the optional sections' time budget is spent"}
+        box = {}
+
+        def work():
+            try:
+                inject(name)
+                box["value"] = fn()
+            except BaseException as e:
+                box["error"] = "%s: %s" % (type(e).__name__, e)
+                sys.stderr.write("bench.py: section %s failed:\n%s" % (name, traceback.format_exc()))
+
+        t0 = time.perf_counter()
+        th = threading.Thread(target=work, daemon=True, name="bench-" + name)
+        th.start()
+        th.join(budget)
+        self.left -= time.perf_counter() - t0
+        if th.is_alive():
+            self.abandoned = name
+            sys.stderr.write("bench.py: section %s: no result after %.0f s, abandoned\n" % (name, budget))
+            return {"error": "timeout: no result after %.0f s" % budget}
+        if "error" in box:
+            return {"error": box["error"]}
+        return box["value"]
+
+
+def emit(line, hard_exit=False, code=0):
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
+    if hard_exit:                       # (a thread that never came back would keep the interpreter's shutdown waiting)
+        sys.stderr.flush()
+        os._exit(code)
+
+
+def error_line(args, world, msg, **extra):
+    """the line of a run that could not measure: the contract's keys, value null, the reason"""
+    return dict({"metric": "bit_exact_int16_pcm_samples_per_sec", "value": None, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+                 "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if args.workload == "corpus" else "weak",
+                 "vs_baseline": None, "dtype": "int16", "data": "synthetic", "config": {"workload": args.workload}, "error": msg}, **extra)
+
+
 # --------------------------------------------------------------------------------------------- one rank
 def run_rank(args):
     import numpy as np
     import torch
-    import torch.distributed as dist
     import dcsexplorer_amd as D
     from dcsexplorer_amd import sharding, workloads
     # (the encoder-made recordings behind realistic_65536 are test data: the package is handed them, it reads no files)
@@ -656,105 +774,119 @@ def run_rank(args):
 
     rank, local_rank, world = sharding.rank_info()
     rehearse = args.rehearse
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse or args.share_gpu:
-            dist.init_process_group(backend="gloo")
-            if args.share_gpu:
-                local_rank = 0
-                torch.cuda.set_device(0)
-        else:
-            torch.cuda.set_device(local_rank)
-            # one process per GPU: its threads (the pipeline's workers and indexers) and the buffers they pin belong on the
-            # GPU's NUMA node; dcs_node does the same per context for one process with several GPUs
-            try:
-                args.numa_node = D.bind_process_to_device_numa(local_rank)
-            except Exception as e:              # (placement is an optimisation: never a reason for a rank to die)
-                sys.stderr.write("bench.py: NUMA placement skipped (%s)\n" % e)
-                args.numa_node = None
-            try:
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-                # (one collective now, so that a broken RCCL set-up shows here and not inside the timed region)
-                probe = torch.zeros(1, device="cuda")
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-            except Exception as e:          # the data path has no collective: gloo can carry the barrier and the max
-                sys.stderr.write("bench.py: RCCL unavailable (%s); barrier and max over gloo\n" % e)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group(backend="gloo")
-                args.share_gpu = False
-                args.gloo_fallback = True
-    elif not rehearse:
+    log = lambda m: sys.stderr.write("bench.py: rank %d: %s\n" % (rank, m))
+    distributed = world > 1 or args.force_dist          # --force-dist: ONE rank through the N-rank code (RCCL group of one, NUMA bind, device-side rows)
+    args.numa_node = None
+    if args.share_gpu:
+        local_rank = 0
+    if not rehearse:
         torch.cuda.set_device(local_rank)
+    if distributed and not rehearse and not args.share_gpu:
+        # one process per GPU: its threads (the pipeline's workers and indexers) and the buffers they pin belong on the
+        # GPU's NUMA node; dcs_node does the same per context for one process with several GPUs
+        try:
+            args.numa_node = D.bind_process_to_device_numa(local_rank)
+        except Exception as e:                  # (placement is an optimisation: never a reason for a rank to die)
+            log("NUMA placement skipped (%s)" % e)
+    if distributed:
+        want = "gloo" if (rehearse or args.share_gpu) else "nccl"       # (RCCL needs one device per rank)
+        try:
+            comm = sharding.open_comm(rank, world, want, device=None if want == "gloo" else torch.device("cuda", local_rank),
+                                      init_timeout_s=args.dist_timeout, log=log)
+        except sharding.CommError as e:
+            log(str(e))
+            if rank == 0:
+                emit(error_line(args, world, "the ranks could not be brought together: %s" % e), hard_exit=True, code=1)
+            os._exit(1)
+    else:
+        comm = sharding.Comm("single", 0, 1)
+    dist_info = {"backend": comm.backend, "attempts": [{"backend": bk, "votes": v} for bk, v in comm.attempts]}
 
     # ---- this rank's share of the work ------------------------------------------------------------------------
     corpus = args.workload == "corpus"
-    golden_range = None
-    if corpus:
-        spec = dict(titles=args.corpus_titles, streams_per_title=args.corpus_streams, max_frames=2000, seed=0x0005)
-        manifest = workloads.corpus_manifest(**spec)
-        lo, hi = sharding.rank_corpus(manifest, world, rank)           # contiguous stream range, balanced by frames
-        streams = workloads.corpus_streams(manifest, lo, hi)
-        total_frames = int(workloads.corpus_frames(manifest).sum())    # of ALL ranks: the same corpus cut N ways
-        golden_range = (spec, lo, hi)
-        scaling = "strong"
-    else:
-        streams = sharding.rank_streams(args.workload, rank)           # same shape on every rank, different seeds
-        if args.scale > 1:
-            import inspect
-            fn = workloads.WORKLOADS[args.workload]
-            n = inspect.signature(fn).parameters["n_streams"].default
-            streams = fn(n_streams=n * args.scale, first=rank * n * args.scale)
-        total_frames = None
-        scaling = "weak"
-    b = D.build_stream_batch(streams, indexer=D.index_streams)
-    if args.workload == "mixed_16384":
-        b, _ = workloads.interleave(b)
-    n_frames = int(b["jobs"].size)
-    if total_frames is None:
-        total_frames = n_frames * world
+    golden_range, manifest, ctx, batch, extra = None, None, None, None, []
+    scaling = "strong" if corpus else "weak"
+    setup_error = None
+    try:
+        inject("setup_rank%d" % rank)
+        if corpus:
+            spec = dict(titles=args.corpus_titles, streams_per_title=args.corpus_streams, max_frames=2000, seed=0x0005)
+            manifest = workloads.corpus_manifest(**spec)
+            lo, hi = sharding.rank_corpus(manifest, world, rank)           # contiguous stream range, balanced by frames
+            streams = workloads.corpus_streams(manifest, lo, hi)
+            total_frames = int(workloads.corpus_frames(manifest).sum())    # of ALL ranks: the same corpus cut N ways
+            golden_range = (spec, lo, hi)
+        else:
+            streams = sharding.rank_streams(args.workload, rank)           # same shape on every rank, different seeds
+            if args.scale > 1:
+                import inspect
+                fn = workloads.WORKLOADS[args.workload]
+                n = inspect.signature(fn).parameters["n_streams"].default
+                streams = fn(n_streams=n * args.scale, first=rank * n * args.scale)
+            total_frames = None
+        b = D.build_stream_batch(streams, indexer=D.index_streams)
+        if args.workload == "mixed_16384":
+            b, _ = workloads.interleave(b)
+        n_frames = int(b["jobs"].size)
+        if total_frames is None:
+            total_frames = n_frames * world
+        if not rehearse:
+            ctx = D.Context(local_rank)
+            if args.share_gpu or args.inflight > 1:
+                ctx.set_concurrent_batches(True)        # several decode launches on one GPU at once: chain order, XCD ranges (include/dcs_hip.h)
+            if args.fpw:
+                ctx.set_frames_per_wave(args.fpw)
+            if args.frames_per_chunk:
+                ctx.set_frames_per_chunk(args.frames_per_chunk)
+            batch = ctx.batch(b["blob"], b["srcs"], b["jobs"])
+            stream = torch.cuda.current_stream().cuda_stream
+            # further batches of the same workload on streams of their own (--inflight): a step is still one launch over one batch
+            extra = [(ctx.batch(b["blob"], b["srcs"], b["jobs"]), torch.cuda.Stream()) for _ in range(max(0, args.inflight - 1))]
+    except BaseException as e:
+        import traceback
+        setup_error = "%s: %s" % (type(e).__name__, e)
+        log("set-up failed:\n" + traceback.format_exc())
+        comm.post("setup_r%d" % rank, setup_error)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    # every rank learns whether every rank is ready: a rank that cannot take part must not leave the others in a barrier
+    try:
+        ready = comm.gather_rows([0.0 if setup_error else 1.0])
+    except Exception as e:
+        log("exchange failed: %s" % e)
+        if rank == 0:
+            emit(error_line(args, world, "the ranks lost each other before the timed region: %s" % e, dist=dist_info), hard_exit=True, code=1)
+        os._exit(1)
+    not_ready = [r for r in range(world) if ready[r][0] != 1.0]
+    if not_ready:
+        if rank == 0:
+            why = {"rank%d" % r: (setup_error if r == rank else comm.read("setup_r%d" % r)) for r in not_ready}
+            emit(error_line(args, world, "set-up failed on rank(s) %s; nothing was timed" % not_ready, ranks_failed=why, dist=dist_info))
+        try:
+            comm.barrier()                  # (rank 0's line is out before any rank's exit code makes the launcher stop the others)
+        except Exception:
+            pass
+        os._exit(1)
 
     if rehearse:
         # no kernel: the step is the host half of dcs_batch_create (planner + packer) for this rank's share
         t0 = time.perf_counter()
         for _ in range(max(1, args.steps)):
             D.pack_chunks(b["blob"], b["srcs"], b["jobs"], 8)
-        barrier()
-        dt = sharding.max_over_ranks(time.perf_counter() - t0)
-        counts = [0] * world
-        if world > 1:
-            t = torch.zeros(world, dtype=torch.int64); t[rank] = n_frames
-            dist.all_reduce(t); counts = [int(x) for x in t]
-        else:
-            counts = [n_frames]
+        comm.barrier()
+        dt = comm.max(time.perf_counter() - t0)
+        counts = [int(r[0]) for r in comm.gather_rows([n_frames])]
         if rank == 0:
-            print(json.dumps({"metric": "bit_exact_int16_pcm_samples_per_sec", "value": None, "unit": "samples/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(1, args.steps) * 1e3,
-                              "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int16",
-                              "data": "synthetic", "rehearsal": "CPU rehearsal of the N-rank path: no GPU, no kernel, nothing measured",
-                              "config": {"workload": args.workload, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "rank0_bound_to_numa_node": getattr(args, "numa_node", None), "frames_per_rank": counts, "frames_total": sum(counts),
-                                         "partition": "range over streams, balanced by frames, no collective"}}))
-        if world > 1:
-            dist.destroy_process_group()
+            emit({"metric": "bit_exact_int16_pcm_samples_per_sec", "value": None, "unit": "samples/s",
+                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(1, args.steps) * 1e3,
+                  "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int16",
+                  "data": "synthetic", "rehearsal": "CPU rehearsal of the N-rank path: no GPU, no kernel, nothing measured",
+                  "dist": dist_info,
+                  "config": {"workload": args.workload, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "rank0_bound_to_numa_node": args.numa_node,
+                             "frames_per_rank": counts, "frames_total": sum(counts),
+                             "partition": "range over streams, balanced by frames, no collective"}})
+        comm.close()
         return
 
-    ctx = D.Context(local_rank)
-    if args.share_gpu or args.inflight > 1:
-        ctx.set_concurrent_batches(True)        # several decode launches on one GPU at once: chain order, XCD ranges (include/dcs_hip.h)
-    if args.fpw:
-        ctx.set_frames_per_wave(args.fpw)
-    if args.frames_per_chunk:
-        ctx.set_frames_per_chunk(args.frames_per_chunk)
-    batch = ctx.batch(b["blob"], b["srcs"], b["jobs"])
-    stream = torch.cuda.current_stream().cuda_stream
-
-    # further batches of the same workload on streams of their own (--inflight): a step is still one launch over one batch
-    extra = [(ctx.batch(b["blob"], b["srcs"], b["jobs"]), torch.cuda.Stream()) for _ in range(max(0, args.inflight - 1))]
     lanes = [(batch, stream)] + [(bt, st.cuda_stream) for bt, st in extra]
     share = [args.steps // len(lanes) + (1 if k < args.steps % len(lanes) else 0) for k in range(len(lanes))]
 
@@ -769,7 +901,7 @@ def run_rank(args):
         for bt, st in lanes:
             bt.run(st)
     torch.cuda.synchronize()
-    barrier()
+    comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for (bt, st), k in zip(lanes, share):
@@ -777,46 +909,62 @@ def run_rank(args):
             bt.run_many(k, st)              # K launches back to back (one step = one launch), issued from C
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0           # this rank's K steps are done; the job's time is the MAX of this over the ranks
-    barrier()                               # (the closing bracket; its own latency -- an RCCL all-reduce, 50-100 us against
+    comm.barrier()                          # (the closing bracket; its own latency -- an RCCL all-reduce, 50-100 us against
     torch.cuda.synchronize()                #  0.7 ms of steps at the driver's K = 20 -- is no part of any rank's K steps)
-    red_dev = None if (args.share_gpu or getattr(args, "gloo_fallback", False)) else "cuda"     # where the small all-reduces live
-    dt = sharding.max_over_ranks(dt, device=red_dev)
+    dt = comm.max(dt)
 
+    # From here on nothing may take the line away: everything below is guarded, and every rank reaches every exchange.
     # kernel-only average duration by HIP events on the launch stream (roofline denominator)
     # (three runs of K launches, the median: the host now and then falls behind 8-us kernels and an average over one
     # run then includes the gaps)
-    kern_ms = sorted(batch.time(max(10, args.steps), stream) for _ in range(3))[1]
-    clock_mhz = ctx.clock_mhz()             # shader clock under an integer load, measured right behind the timed launches
-    algo_bytes = batch.algorithmic_bytes    # payload + stream headers + 56 B per frame + 480 B PCM
+    kern_ms, clock_mhz, algo_bytes, core_notes = None, None, None, []
+    try:
+        inject("kernel_time")
+        kern_ms = sorted(batch.time(max(10, args.steps), stream) for _ in range(3))[1]
+        clock_mhz = ctx.clock_mhz()             # shader clock under an integer load, measured right behind the timed launches
+        algo_bytes = batch.algorithmic_bytes    # payload + stream headers + 56 B per frame + 480 B PCM
+    except Exception as e:
+        core_notes.append("kernel time by HIP events failed: %s: %s" % (type(e).__name__, e))
 
     # bit-exactness of what was just timed, on EVERY rank: per-stream hashes of this rank's PCM vs the reference's
-    # committed hashes of this rank's range; the line's bit_exact is the AND over the ranks (one all-reduce)
-    ok, bit_exact_note = verify_rank(args, batch, b, streams, rank, corpus, golden_range)
-    bit_exact_ranks = [ok]
-    if world > 1:
-        t = torch.full((world,), 0, dtype=torch.int64, device=red_dev if red_dev is not None else "cpu")
-        t[rank] = 2 if ok is None else int(bool(ok))            # 1 = every stream equal, 0 = some stream differs, 2 = nothing to compare with
-        dist.all_reduce(t)
-        bit_exact_ranks = [None if int(x) == 2 else bool(int(x)) for x in t.cpu()]
+    # committed hashes of this rank's range; the line's bit_exact is the AND over the ranks (one exchange)
+    try:
+        inject("verify")
+        ok, bit_exact_note = verify_rank(args, batch, b, streams, rank, corpus, golden_range)
+    except Exception as e:
+        ok, bit_exact_note = None, "rank %d could not verify its PCM: %s: %s" % (rank, type(e).__name__, e)
+        log(bit_exact_note)
+    try:
+        rows = comm.gather_rows([2.0 if ok is None else float(bool(ok))])       # 1 = every stream equal, 0 = some stream differs, 2 = nothing to compare with
+        bit_exact_ranks = [None if int(r[0]) == 2 else bool(int(r[0])) for r in rows]
+    except Exception as e:
+        bit_exact_ranks = [ok if r == rank else None for r in range(world)]
+        core_notes.append("the ranks' bit_exact flags could not be exchanged: %s" % e)
     bit_exact = None if all(x is None for x in bit_exact_ranks) else all(x is True for x in bit_exact_ranks)
 
     # host buffers in, host buffers out on every rank at once (never `value`): what N ranks do to the node's host CPUs
     e2e_ranks = None
-    if world > 1 and not args.no_end_to_end and not corpus:
-        e2e_ranks = end_to_end_ranks(ctx, streams, n_frames, world, rank, red_dev,
-                                     depth=args.e2e_device_depth, lists=args.e2e_lists)
+    if distributed and not args.no_end_to_end and not corpus:
+        try:
+            e2e_ranks = end_to_end_ranks(ctx, streams, n_frames, comm, depth=args.e2e_device_depth, lists=args.e2e_lists)
+        except Exception as e:
+            e2e_ranks = {"error": "%s: %s" % (type(e).__name__, e)}
+    hard_exit = bool(e2e_ranks and e2e_ranks.get("abandoned"))
 
     if rank == 0:
         samples = total_frames * 240 * args.steps
-        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        achieved = None if kern_ms is None else algo_bytes / (kern_ms * 1e-3) / 1e9
         # HBM traffic per launch: FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes of this same command
         # (tools/prof.sh), committed under profiles/; null when no profile of this workload exists
         traffic, traffic_note, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         plain_run = args.scale == 1 and not args.fpw and not args.frames_per_chunk and world == 1 and args.inflight == 1 and \
             (not corpus or (args.corpus_titles, args.corpus_streams) == (29, 20))
-        t, traffic_note = load_counters(args.workload) if plain_run else (None, None)   # (the committed counters are those of the plain workload)
-        if t is not None:
+        try:
+            t, traffic_note = load_counters(args.workload) if plain_run else (None, None)   # (the committed counters are those of the plain workload)
+        except Exception as e:
+            t, traffic_note = None, "profiles/traffic_%s.json could not be read: %s" % (args.workload, e)
+        if t is not None and kern_ms is not None:
             # the kernel's reads are 16-byte-per-lane loads of the chunk packages, for which FETCH_SIZE reports half
             # the bytes on gfx950 (MI355X_MICROARCH.md, HBM section): doubled here; WRITE_SIZE is exact
             traffic = t["traffic_bytes_fetch_x2"]
@@ -851,7 +999,7 @@ def run_rank(args):
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
-            "config": {"workload": args.workload, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "rank0_bound_to_numa_node": getattr(args, "numa_node", None),
+            "config": {"workload": args.workload, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "rank0_bound_to_numa_node": args.numa_node,
                        "workload_is": {"survey3_65536": "BASELINE configs[2] as SURVEY.md 8(d) Config 3 specifies it: 256 streams x 256 1994+ frames, 80 % Type 1 "
                                                         "sub-type 3, 10 % Type 1 sub-type 0, 10 % Type 0, 12 populated bands, 120 B/frame",
                                        "dcs94_65536": "BASELINE configs[2], the form of rounds 1 and 2: 16 populated bands, 96 B/frame"}.get(args.workload, args.workload),
@@ -861,57 +1009,88 @@ def run_rank(args):
                        "partition": "range over streams%s, no collective" % (", balanced by frames" if corpus else ""),
                        "scale": args.scale, "inflight": args.inflight, "clock_settle_ms": args.clock_settle_ms, "frames_per_chunk": args.frames_per_chunk or "all"},
             **({"share_gpu": "all ranks on GPU 0 (test of the N-rank path on a one-GPU box): not a scaling measurement"} if args.share_gpu else {}),
+            **({"force_dist": "one rank through the N-rank code: process group of one, NUMA bind, the exchanges on the device"} if args.force_dist else {}),
+            "dist": dist_info,
             "bit_exact": bit_exact,
             "bit_exact_ranks": bit_exact_ranks,
             "bit_exact_note": bit_exact_note,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "frac": None if achieved is None else achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "dcsDecodeKernel<%d>" % batch.frames_per_wave, "kernel_avg_ms": kern_ms, "lib_build_id": D.build_id(),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_bytes_note": "SURVEY 8(d): exact payload + stream headers + 56 B descriptor and 480 B PCM per frame "
                                                    "(x %d frames per launch)" % n_frames,
                          "abi_bytes_per_launch": batch.abi_bytes, "valu_issue": valu},
         }
+        if core_notes:
+            out["notes"] = core_notes
         if corpus:
             out["config"]["corpus"] = golden_range[0]
             out["config"]["rank0_stream_range"] = [golden_range[1], golden_range[2]]
-        if world == 1 and args.workload == DEFAULT_WORKLOAD and not args.no_second_workload and args.scale == 1:
-            out["second_workload"] = second_workload(ctx, args, torch)
-            out["third_workload"] = second_workload(ctx, args, torch, name=PREVIOUS_DEFAULT)
-        if world == 1 and args.rotate > 0 and not corpus and args.scale == 1 and args.inflight == 1:
-            out["roofline_cold"] = roofline_cold(ctx, args, batch, stream)
-        if world == 1 and not args.no_device_path and not corpus and args.scale == 1 and args.workload in ("survey3_65536", "dcs94_65536", "realistic_65536"):
-            rgp = os.path.join(ROOT, "tests", "golden", "rank_golden_hashes.json")
-            rg = json.load(open(rgp))["workloads"].get(args.workload, {}).get("rank_stream_hashes")
-            out["device_full_path"] = device_full_path(ctx, args, streams, n_frames, rg)
-        if world == 1 and not args.no_end_to_end and n_frames <= (1 << 20):
-            out["end_to_end"] = end_to_end(ctx, streams, n_frames, depth=args.e2e_depth, dev_depth=args.e2e_device_depth)
-        elif world == 1 and not args.no_end_to_end:
-            out["end_to_end"] = {"note": "one list of %d frames (%.1f GB of PCM) is no list to keep several of in flight: see corpus_by_title" % (n_frames, n_frames * 480 / 1e9)}
         if e2e_ranks is not None:
             out["end_to_end"] = e2e_ranks
-        if world == 1 and corpus and not args.no_end_to_end:
-            gold = None
-            for name in ("corpus_golden.json", "corpus_golden_full.json"):
-                cg = json.load(open(os.path.join(ROOT, "tests", "golden", name)))
-                if cg["corpus"] == golden_range[0]:
-                    gold = cg["stream_hashes"][golden_range[1]:golden_range[2]]
-            out["end_to_end"]["corpus_by_title"] = corpus_by_title(ctx, args, streams, manifest, golden_range[1], gold)
-        if world == 1 and args.node > 0 and not corpus:
-            out.setdefault("end_to_end", {})["node"] = end_to_end_node(args, streams, n_frames, depth=max(4, args.e2e_device_depth // 2))
-        if world == 1 and not args.no_cpu_baseline:
-            sample = streams if not corpus else streams[:64]
-            out["cpu_baseline"] = cpu_baseline(sample)
-            if "sustained" in out.get("end_to_end", {}):
-                out["end_to_end"]["sustained_vs_cpu_baseline"] = out["end_to_end"]["sustained"]["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
 
+        # ---- the optional sections: the line above is complete without them --------------------------------------------
+        sec = Sections(args.sections_budget)
+        if hard_exit:
+            sec.abandoned = "end_to_end (ranks)"
+        alone = world == 1 and not args.force_dist
+        if alone and args.workload == DEFAULT_WORKLOAD and not args.no_second_workload and args.scale == 1:
+            out["second_workload"] = sec.run("second_workload", lambda: second_workload(ctx, args, torch), 40)
+            out["third_workload"] = sec.run("third_workload", lambda: second_workload(ctx, args, torch, name=PREVIOUS_DEFAULT), 40)
+        if alone and args.rotate > 0 and not corpus and args.scale == 1 and args.inflight == 1:
+            out["roofline_cold"] = sec.run("roofline_cold", lambda: roofline_cold(ctx, args, batch, stream), 60)
+        if alone and not args.no_device_path and not corpus and args.scale == 1 and args.workload in ("survey3_65536", "dcs94_65536", "realistic_65536"):
+            def full_path():
+                rgp = os.path.join(ROOT, "tests", "golden", "rank_golden_hashes.json")
+                rg = json.load(open(rgp))["workloads"].get(args.workload, {}).get("rank_stream_hashes")
+                return device_full_path(ctx, args, streams, n_frames, rg)
+            out["device_full_path"] = sec.run("device_full_path", full_path, 120)
+        if alone and not args.no_end_to_end and n_frames <= (1 << 20):
+            out["end_to_end"] = sec.run("end_to_end", lambda: end_to_end(ctx, streams, n_frames, depth=args.e2e_depth, dev_depth=args.e2e_device_depth), 120)
+        elif alone and not args.no_end_to_end:
+            out["end_to_end"] = {"note": "one list of %d frames (%.1f GB of PCM) is no list to keep several of in flight: see corpus_by_title" % (n_frames, n_frames * 480 / 1e9)}
+        if alone and corpus and not args.no_end_to_end:
+            def by_title():
+                gold = None
+                for name in ("corpus_golden.json", "corpus_golden_full.json"):
+                    cg = json.load(open(os.path.join(ROOT, "tests", "golden", name)))
+                    if cg["corpus"] == golden_range[0]:
+                        gold = cg["stream_hashes"][golden_range[1]:golden_range[2]]
+                return corpus_by_title(ctx, args, streams, manifest, golden_range[1], gold)
+            out["end_to_end"]["corpus_by_title"] = sec.run("corpus_by_title", by_title, 240)
+        if alone and args.node > 0 and not corpus:
+            if not isinstance(out.get("end_to_end"), dict):
+                out["end_to_end"] = {}
+            out["end_to_end"]["node"] = sec.run("node", lambda: end_to_end_node(args, streams, n_frames, depth=max(4, args.e2e_device_depth // 2)), 90)
+        if alone and not args.no_cpu_baseline:
+            sample = streams if not corpus else streams[:64]
+            out["cpu_baseline"] = sec.run("cpu_baseline", lambda: cpu_baseline(sample), 60)
+            try:
+                out["end_to_end"]["sustained_vs_cpu_baseline"] = out["end_to_end"]["sustained"]["value"] / out["cpu_baseline"]["value"]
+            except (KeyError, TypeError):
+                pass
+        hard_exit = hard_exit or sec.abandoned is not None
+        emit(out, hard_exit=hard_exit and world == 1)
+
+    if hard_exit:
+        # some thread of this process never came back (it may be inside a HIP call): no orderly tear-down.  The other ranks
+        # are let go first, so that this rank's exit cannot make the launcher stop one that has not printed yet.
+        try:
+            comm.barrier()
+        except Exception:
+            pass
+        sys.stderr.flush()
+        os._exit(0)
     for bt, _ in extra:
         bt.close()
     batch.close()
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    try:
+        comm.barrier()                      # (rank 0 has printed before any rank leaves)
+    except Exception:
+        pass
+    comm.close()
 
 
 def main():

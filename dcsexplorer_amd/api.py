@@ -103,7 +103,7 @@ ABI_VERSION = 7                 # include/dcs_hip.h DCS_ABI_VERSION these bindin
 
 EXPORTS = [
     "dcs_abi_version", "dcs_build_id", "dcs_index_stream", "dcs_volume_multiplier", "dcs_mixing_multiplier", "dcs_frame_scale",
-    "dcs_stream_params", "dcs_ctx_create", "dcs_ctx_destroy", "dcs_last_error", "dcs_device_count",
+    "dcs_stream_params", "dcs_ctx_create", "dcs_ctx_destroy", "dcs_last_error", "dcs_device_count", "dcs_runtime_defaults",
     "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_ctx_set_large_list_path", "dcs_ctx_set_concurrent_batches", "dcs_ctx_set_cache_limits", "dcs_ctx_trim_cache", "dcs_ctx_cache_bytes", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run", "dcs_batch_run_many", "dcs_pack_chunks",
     "dcs_batch_time", "dcs_batch_time_rotating", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_download_view", "dcs_batch_device_pcm",
     "dcs_batch_algorithmic_bytes", "dcs_batch_num_jobs", "dcs_decode_streams", "dcs_count_stream_frames",

@@ -10,6 +10,7 @@
 #pragma once
 #include <sched.h>
 #include <map>
+#include <memory>
 
 // NUMA node of a HIP device (from its PCI address, /sys/bus/pci/devices/<addr>/numa_node), or -1
 extern "C" int dcs_device_numa_node(int deviceId)
@@ -277,15 +278,24 @@ extern "C" DcsStatus dcs_node_collect(DcsNode *n, DcsPipelineResult *out, int *d
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 static std::mutex g_nodeCacheMutex;
-static std::map<std::vector<int>, DcsNode *> g_nodeCache;
+// key: the device ids SORTED ([0, 1] and [1, 0] are one node; a device named twice is two contexts).  shared_ptr: a call holds
+// its node while it runs, so dcs_node_cache_release() from another thread only drops the cache's reference and the contexts
+// go when the last call that uses them returns (the raw pointer was used after the cache's mutex was dropped).
+static std::map<std::vector<int>, std::shared_ptr<DcsNode>> g_nodeCache;
+// What a cached node's contexts may keep between calls: buffers of a couple of parts in flight, not the eighth of every card
+// an occasional caller would otherwise lose for the life of the process (a context's default: min(32 GB, free / 8)).
+static const uint64_t kShardedDevCache = uint64_t(2) << 30, kShardedPinCache = uint64_t(1) << 30;
 }
 
 extern "C" void dcs_node_cache_release(void)
 {
-    std::lock_guard<std::mutex> lk(g_nodeCacheMutex);
-    for (auto &kv : g_nodeCache)
-        dcs_node_destroy(kv.second);
-    g_nodeCache.clear();
+    std::map<std::vector<int>, std::shared_ptr<DcsNode>> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_nodeCacheMutex);
+        drop.swap(g_nodeCache);
+    }
+    // (outside the mutex: a node whose last reference this was destroys its contexts here; one that a running call still holds
+    // is destroyed by that call's thread when it returns)
 }
 
 extern "C" DcsStatus dcs_decode_streams_sharded(const int *deviceIds, uint32_t nDevices,
@@ -314,16 +324,31 @@ extern "C" DcsStatus dcs_decode_streams_sharded(const int *deviceIds, uint32_t n
     if (firstStreamOfDevice != nullptr)
         memcpy(firstStreamOfDevice, cut.data(), sizeof(uint32_t) * cut.size());
 
-    DcsNode *node = nullptr;
+    // the caller's d-th device is context slot[d] of the node of the sorted list
+    std::vector<uint32_t> byId(nDevices);
+    for (uint32_t d = 0 ; d < nDevices ; ++d)
+        byId[d] = d;
+    std::stable_sort(byId.begin(), byId.end(), [&](uint32_t a, uint32_t b) { return deviceIds[a] < deviceIds[b]; });
+    std::vector<int> key(nDevices);
+    std::vector<uint32_t> slot(nDevices);
+    for (uint32_t i = 0 ; i < nDevices ; ++i)
+    {
+        key[i] = deviceIds[byId[i]];
+        slot[byId[i]] = i;
+    }
+    std::shared_ptr<DcsNode> node;
     {
         std::lock_guard<std::mutex> lk(g_nodeCacheMutex);
-        const std::vector<int> key(deviceIds, deviceIds + nDevices);
         auto it = g_nodeCache.find(key);
         if (it == g_nodeCache.end())
         {
-            st = dcs_node_create(deviceIds, nDevices, 8, DCS_PIPE_ALL_ON_DEVICE, &node);
+            DcsNode *made = nullptr;
+            st = dcs_node_create(key.data(), nDevices, 8, DCS_PIPE_ALL_ON_DEVICE, &made);
             if (st != DCS_OK)
                 return st;
+            node.reset(made, [](DcsNode *n) { dcs_node_destroy(n); });
+            for (DcsNode::Dev &dev : node->devs)
+                (void)dcs_ctx_set_cache_limits(dev.ctx, kShardedDevCache, kShardedPinCache);
             g_nodeCache[key] = node;
         }
         else
@@ -339,7 +364,7 @@ extern "C" DcsStatus dcs_decode_streams_sharded(const int *deviceIds, uint32_t n
         if (lo == hi)
             continue;
         workers.emplace_back([&, d, lo, hi]() {
-            DcsNode::Dev &dev = node->devs[d];
+            DcsNode::Dev &dev = node->devs[slot[d]];
             const uint64_t f0 = firstFrame[lo];
             status[d] = onNumaNode(dev.numa, [&] {
                 return dcs_decode_streams(dev.ctx, streams + lo, hi - lo, extraFrames, pcmOut + f0 * DCS_FRAME_SAMPLES,
@@ -356,7 +381,7 @@ extern "C" DcsStatus dcs_decode_streams_sharded(const int *deviceIds, uint32_t n
         if (status[d] != DCS_OK)
         {
             std::lock_guard<std::mutex> lk(node->m);
-            node->lastError = std::string("device ") + std::to_string(node->devs[d].id) + ": " + dcs_last_error(node->devs[d].ctx);
+            node->lastError = std::string("device ") + std::to_string(node->devs[slot[d]].id) + ": " + dcs_last_error(node->devs[slot[d]].ctx);
             return status[d];
         }
     return DCS_OK;

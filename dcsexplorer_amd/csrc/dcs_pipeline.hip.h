@@ -558,7 +558,8 @@ static DcsStatus pipelineDecodePlanned(DcsPipeline *p, DcsPipeline::Job *job, hi
             for (size_t j = 0 ; j < nJobs && !lost && flag == 0 ; ++j)
                 lost = (job->err[j] & DCS_FRAME_TAIL_LOST) != 0;
         }
-        if (st != DCS_OK || flag != DCS_PLAN_POOL_OVERFLOW)
+        // again with fewer slots only for an overflow, and not when the list is (also) truncated: that one is the host's whatever the plan
+        if (st != DCS_OK || (flag & DCS_PLAN_POOL_OVERFLOW) == 0 || (flag & DCS_PLAN_TRUNCATED) != 0)
             break;
     }
     job->hostMs += t1 - t0;

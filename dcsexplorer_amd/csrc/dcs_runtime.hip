@@ -71,12 +71,25 @@ static size_t cacheTrim(DcsCtx *ctx, bool pinned, size_t want)
     {
         std::lock_guard<std::mutex> lock(ctx->cacheMutex);
         std::vector<DcsCtx::Cached> &c = pinned ? ctx->pinCache : ctx->devCache;
-        std::sort(c.begin(), c.end(), [](const DcsCtx::Cached &a, const DcsCtx::Cached &b) { return a.cap > b.cap; });
+        // victims by size, picked through an index copy: the vector itself stays in the order the buffers came back
+        // (cacheFree drops from its FRONT, the oldest, when a buffer returns to a full cache -- ADVICE r4)
+        std::vector<size_t> bySize(c.size());
+        for (size_t i = 0 ; i < c.size() ; ++i)
+            bySize[i] = i;
+        std::sort(bySize.begin(), bySize.end(), [&c](size_t a, size_t b) { return c[a].cap > c[b].cap; });
         size_t got = 0, n = 0;
-        while (n < c.size() && (want == 0 || got < want))
-            got += c[n++].cap;
-        victims.assign(c.begin(), c.begin() + static_cast<long>(n));
-        c.erase(c.begin(), c.begin() + static_cast<long>(n));
+        std::vector<char> gone(c.size(), 0);
+        while (n < bySize.size() && (want == 0 || got < want))
+        {
+            got += c[bySize[n]].cap;
+            victims.push_back(c[bySize[n]]);
+            gone[bySize[n++]] = 1;
+        }
+        size_t keep = 0;
+        for (size_t i = 0 ; i < c.size() ; ++i)
+            if (!gone[i])
+                c[keep++] = c[i];
+        c.resize(keep);
         (pinned ? ctx->cachedPinBytes : ctx->cachedBytes) -= got;
     }
     size_t released = 0;
@@ -336,12 +349,25 @@ static const double g_hipSlowUs = getenv("DCS_HIP_SLOW") ? atof(getenv("DCS_HIP_
 // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and packets of
 // different streams that share a queue run one behind the other.  A pipeline has a dozen streams with chains of short kernels
 // and half-millisecond copies; with eight queues a list's chain stops waiting behind another list's copy (0.75 -> 0.70 ms per
-// list sustained, round 4; sixteen queues showed stalls of seconds).  The variable is read when the runtime initialises, so it
-// is set when this library is loaded -- before any HIP call of a program that links it -- and only if the user has not set it.
-// A host that initialises HIP before loading the library (python: torch first) sets it itself (bench.py does).
-__attribute__((constructor)) static void dcsSetRuntimeDefaults()
+// list sustained, round 4; sixteen queues showed stalls of seconds).  The variable is read when the runtime initialises.
+// Loading this library changes NOTHING in the host's environment (round 5; a constructor used to): dcs_runtime_defaults() is an
+// explicit call, and the library's own first calls into HIP (dcs_device_count, dcs_ctx_create) make it once unless
+// DCS_NO_RUNTIME_DEFAULTS is set -- effective only if HIP has not been initialised by the host before, harmless otherwise, and a
+// variable the user has set is never overwritten.  INTEGRATION.md, "Runtime settings".
+extern "C" int dcs_runtime_defaults(void)
 {
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    if (getenv("GPU_MAX_HW_QUEUES") != nullptr)
+        return 0;
+    return setenv("GPU_MAX_HW_QUEUES", "8", 0) == 0 ? 1 : 0;
+}
+
+static void runtimeDefaultsOnce()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (getenv("DCS_NO_RUNTIME_DEFAULTS") == nullptr)
+            (void)dcs_runtime_defaults();
+    });
 }
 
 extern "C" uint32_t dcs_abi_version(void) { return DCS_ABI_VERSION; }
@@ -352,6 +378,7 @@ extern "C" const char *dcs_build_id(void) { return DCS_BUILD_ID; }
 
 extern "C" int dcs_device_count(void)
 {
+    runtimeDefaultsOnce();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess)
         return 0;
@@ -380,6 +407,7 @@ extern "C" DcsStatus dcs_ctx_create(int deviceId, DcsCtx **out)
     if (out == nullptr)
         return DCS_ERR_INVALID_ARG;
     *out = nullptr;
+    runtimeDefaultsOnce();
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -1012,11 +1040,13 @@ __global__ __launch_bounds__(256) void dcsPlanKernel(const DcsPlanStream *stream
         slots[static_cast<size_t>(c) * FPW + p] = out[p];
     if (flags != 0)
     {
-        atomicOr(flagWord, flags);
+        const uint32_t seen = atomicOr(flagWord, flags);
         // ... and straight into the batch's pinned staging word, so that no copy kernel has to bring it down behind the decode
-        // launch (a plain store: concurrent writers all write non-zero values, and non-zero is all the host asks)
+        // launch.  A plain store of everything this thread knows raised (its own bits and those the device word held before):
+        // non-zero is all the host needs for the PCM to be safe; concurrent writers can still hide each other's bits, which
+        // is why the host retries only on "overflow and NOT truncated" and treats the word as "at least these" 
         if (hostFlag != nullptr)
-            __hip_atomic_store(hostFlag, flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(hostFlag, seen | flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 }   // namespace
@@ -1576,6 +1606,9 @@ extern "C" DcsStatus dcs_decode_batch(DcsCtx *ctx,
     // dispatched when its consumer waits for it: chunks are dispatched in index order on this hardware, but nothing
     // promises it.  A consumer that waited in vain flags its frame DCS_FRAME_TAIL_LOST; the batch is then decoded again
     // with every such predecessor re-decoded next to its successor (no dependence between wavefronts at all).
+    // One-shot calls launch in XCD ranges like the pipelines' batches do (include/dcs_hip.h says "always", and two processes or threads
+    // making small one-shot calls on one card are launches side by side like any other; ~1 % of a kernel that is a fraction of the call).
+    struct Ranges { bool old; Ranges() : old(tlsXcdRanges) { tlsXcdRanges = true; } ~Ranges() { tlsXcdRanges = old; } } ranges;
     for (int attempt = 0 ; attempt < 2 ; ++attempt)
     {
         const bool handoff = ctx->handoff && attempt == 0;

@@ -210,6 +210,13 @@ DcsStatus dcs_ctx_create(int deviceId, DcsCtx **ctx);
 void      dcs_ctx_destroy(DcsCtx *ctx);
 const char *dcs_last_error(const DcsCtx *ctx);     /* ctx may be NULL: last error of ctx_create */
 int       dcs_device_count(void);                  /* does not initialise the GPU runtime further than counting */
+/* Runtime settings the pipelines want, made explicitly: GPU_MAX_HW_QUEUES=8 if the variable is not set (the HIP runtime reads it
+ * when it initialises; its default of four hardware queues serialises the chains of a pipeline's dozen streams).  Returns 1 if it
+ * set the variable, 0 if the variable was already there.  LOADING the library changes nothing in the process's environment; the
+ * library's own first calls into HIP (dcs_device_count, dcs_ctx_create) make this call once unless DCS_NO_RUNTIME_DEFAULTS is in
+ * the environment.  It has an effect only before HIP is initialised and it calls setenv: a host with threads that read the
+ * environment concurrently sets the variable itself at start-up and exports DCS_NO_RUNTIME_DEFAULTS. */
+int       dcs_runtime_defaults(void);
 
 /* tuning: frames handled per wavefront in the kernel (4, 8 or 16); 0 = choose from batch size */
 DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw);
@@ -232,7 +239,7 @@ DcsStatus dcs_ctx_set_large_list_path(DcsCtx *ctx, int onDevice);
  * (DCS_FRAME_TAIL_LOST).  enable = 1: batches created afterwards keep their chunks in chain order and are launched in XCD ranges --
  * workgroup i runs on XCD i % 8, XCD j decodes a contiguous range of chunks in order, a tail's producer is dispatched before its
  * consumer on the consumer's own XCD -- so no wait depends on another launch.  About 1 % slower for a batch alone on the chip, which is
- * why it is not the default; dcs_pipeline, dcs_node and dcs_decode_streams always work this way.  Same PCM either way. */
+ * why it is not the default for resident batches (dcs_batch_create); dcs_pipeline, dcs_node, dcs_decode_batch and dcs_decode_streams always work this way.  Same PCM either way. */
 DcsStatus dcs_ctx_set_concurrent_batches(DcsCtx *ctx, int enable);
 /* The context keeps device and pinned-host buffers of finished batches and lists for the next ones (hipMalloc / hipFree
  * cost as much as decoding thousands of frames, and hipFree waits for the whole device).  What it may keep is bounded:

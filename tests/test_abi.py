@@ -33,6 +33,47 @@ def test_abi_version_and_struct_sizes(dcs):
     assert dcs.INDEX_DTYPE.itemsize == 148
 
 
+def test_loading_the_library_leaves_the_environment_untouched():
+    """no load-time constructor edits the host's environment.  A fresh process loads libdcs_hip.so with
+    GPU_MAX_HW_QUEUES unset and compares os.environ / the C environ before and after; the explicit dcs_runtime_defaults() then
+    sets the variable, never overwrites one, and DCS_NO_RUNTIME_DEFAULTS keeps the library's first HIP call from making it"""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, os, sys
+libc = ctypes.CDLL(None)
+libc.getenv.restype = ctypes.c_char_p
+def c_environ():
+    env = ctypes.POINTER(ctypes.c_char_p).in_dll(libc, "environ")
+    out, i = [], 0
+    while env[i]:
+        out.append(env[i]); i += 1
+    # (GLOG_*: exported by librocprofiler-register when ANY library that carries a HIP code object registers it with the runtime
+    #  at load -- the HIP runtime's doing for every HIP program, not this library's)
+    return sorted(e for e in out if not e.startswith(b"GLOG_"))
+before = c_environ()
+L = ctypes.CDLL(sys.argv[1])
+assert c_environ() == before, "loading the library changed environ"
+assert libc.getenv(b"GPU_MAX_HW_QUEUES") is None
+if os.environ.get("DCS_NO_RUNTIME_DEFAULTS"):
+    L.dcs_device_count()                                   # the library's first call into HIP
+    assert libc.getenv(b"GPU_MAX_HW_QUEUES") is None, "opt-out ignored"
+    print("optout-ok")
+else:
+    L.dcs_runtime_defaults.restype = ctypes.c_int
+    assert L.dcs_runtime_defaults() == 1 and libc.getenv(b"GPU_MAX_HW_QUEUES") == b"8"
+    libc.setenv(b"GPU_MAX_HW_QUEUES", b"4", 1)
+    assert L.dcs_runtime_defaults() == 0 and libc.getenv(b"GPU_MAX_HW_QUEUES") == b"4"    # never overwritten
+    print("explicit-ok")
+'''
+    lib = os.path.join(ROOT, "dcsexplorer_amd", "libdcs_hip.so")
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "DCS_NO_RUNTIME_DEFAULTS")}
+    r = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "explicit-ok" in r.stdout, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True, env=dict(env, DCS_NO_RUNTIME_DEFAULTS="1"), timeout=300)
+    assert r.returncode == 0 and "optout-ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_no_gpu_means_loud_failure_not_fallback(dcs):
     """without a gfx950 device the context constructor must raise; nothing decodes on the CPU"""
     if dcs.device_count() > 0:

@@ -145,3 +145,69 @@ def test_bench_launches_its_own_ranks():
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] is None and "rehearsal" in d
         assert len(d["config"]["frames_per_rank"]) == 2 and all(f > 0 for f in d["config"]["frames_per_rank"])
+
+
+def _bench(extra_args, extra_env=None, timeout=900):
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(extra_env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, (json.loads(lines[-1]) if lines else None), len(lines)
+
+
+def test_bench_rehearses_eight_ranks():
+    """the driver's --gpus 8 shape on CPU: launcher, eight ranks, rendezvous store, the vote on the process group, every rank's
+    share, barrier, max over ranks, ONE line from rank 0"""
+    out, d, n = _bench(["--gpus", "8", "--rehearse", "--steps", "1", "--workload", "dcs93_4096"])
+    assert out.returncode == 0 and n == 1, out.stderr[-2000:]
+    assert d["n_gpus"] == 8 and d["config"]["frames_per_rank"] == [4096] * 8
+    assert d["dist"]["backend"] == "gloo" and d["dist"]["attempts"][0]["votes"] == ["ok"] * 8
+
+
+def test_bench_ranks_fall_back_to_the_rendezvous_store():
+    """no process group on every rank (here: gloo sabotaged on rank 1 only, so rank 0's attempt runs into its timeout) -> all
+    ranks agree on the store as carrier of barrier and max, the line is printed, the attempts are in it"""
+    out, d, n = _bench(["--gpus", "2", "--rehearse", "--steps", "1", "--workload", "dcs93_4096", "--dist-timeout", "10"],
+                       {"DCS_COMM_SABOTAGE": "gloo@1"})
+    assert out.returncode == 0 and n == 1, out.stderr[-2000:]
+    assert d["dist"]["backend"] == "store" and d["n_gpus"] == 2 and d["config"]["frames_per_rank"] == [4096, 4096]
+    votes = d["dist"]["attempts"][0]["votes"]
+    assert votes[1].startswith("error: sabotaged") and votes[0].startswith("error")
+
+
+def test_bench_a_rank_stuck_in_init_does_not_hang_the_job():
+    """init_process_group never returns on rank 1: both ranks see "hung" in the vote, make no second attempt and carry on over
+    the store (no silent hang)"""
+    out, d, n = _bench(["--gpus", "2", "--rehearse", "--steps", "1", "--workload", "dcs93_4096", "--dist-timeout", "5"],
+                       {"DCS_COMM_SABOTAGE": "gloo:hang@1"}, timeout=300)
+    assert out.returncode == 0 and n == 1, out.stderr[-2000:]
+    assert d["dist"]["backend"] == "store" and d["dist"]["attempts"][0]["votes"][1] == "hung" and len(d["dist"]["attempts"]) == 1
+
+
+def test_bench_a_rank_that_fails_in_setup_yields_an_error_line_not_a_hang():
+    out, d, n = _bench(["--gpus", "2", "--rehearse", "--steps", "1", "--workload", "dcs93_4096", "--dist-timeout", "20"],
+                       {"DCS_BENCH_INJECT_FAIL": "setup_rank1"}, timeout=300)
+    assert out.returncode != 0 and n == 1
+    assert d["value"] is None and d["n_gpus"] == 2 and "rank(s) [1]" in d["error"]
+    assert "injected failure in setup_rank1" in d["ranks_failed"]["rank1"]
+
+
+def test_sections_guard_exceptions_and_timeouts(monkeypatch):
+    """bench.Sections: an exception or a section that never returns leaves {"error": ...}; what follows an abandoned section is
+    skipped (it may still hold the GPU); the total budget is kept"""
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    sec = bench.Sections(30.0)
+    assert sec.run("a", lambda: {"x": 1}, 5) == {"x": 1}
+    r = sec.run("b", lambda: 1 / 0, 5)
+    assert r["error"].startswith("ZeroDivisionError")
+    monkeypatch.setenv("DCS_BENCH_INJECT_FAIL", "c")
+    assert "injected failure in c" in sec.run("c", lambda: 1, 5)["error"]
+    t0 = time.perf_counter()
+    r = sec.run("d", lambda: time.sleep(60), 1.5)
+    assert r["error"].startswith("timeout") and time.perf_counter() - t0 < 5 and sec.abandoned == "d"
+    assert "skipped" in sec.run("e", lambda: 1, 5)["error"]
+    sec2 = bench.Sections(0.5)
+    assert "budget is spent" in sec2.run("f", lambda: 1, 5)["error"]

@@ -6,7 +6,12 @@
 TAG=${1:-r02}
 NEW=$PWD/gpurun_out/profiles_new; mkdir -p $NEW
 for wl in survey3_65536 dcs94_65536 dcs93_4096 mixed_16384 realistic_65536 corpus; do
-  bash tools/prof.sh ${TAG}_$wl $wl 2>&1 | tee gpurun_out/prof_${TAG}_$wl.log | grep '^prof ' || { echo "prof $wl failed"; tail -5 gpurun_out/prof_${TAG}_$wl.log; exit 1; }
+  # (the status is prof.sh's, not grep's: a prof.sh that dies after its first pass must not go unnoticed -- ADVICE r4)
+  bash tools/prof.sh ${TAG}_$wl $wl > gpurun_out/prof_${TAG}_$wl.log 2>&1; rc=$?
+  grep '^prof ' gpurun_out/prof_${TAG}_$wl.log
+  if [ $rc -ne 0 ] || [ ! -s gpurun_out/prof_${TAG}_$wl/traffic.json ] || [ ! -s gpurun_out/prof_${TAG}_$wl/summary.txt ]; then
+    echo "prof $wl failed (rc $rc)"; tail -5 gpurun_out/prof_${TAG}_$wl.log; exit 1
+  fi
   cp gpurun_out/prof_${TAG}_$wl/summary.txt $NEW/${TAG}_${wl}_rocprofv3_summary.txt
   cp gpurun_out/prof_${TAG}_$wl/traffic.json $NEW/traffic_$wl.json
   cp gpurun_out/prof_${TAG}_$wl/traffic.json profiles/traffic_$wl.json
