@@ -105,6 +105,7 @@ struct WaveBits
     uint32_t hi = 0;            // max over looks of pos + n
     bool any = false;
     uint32_t B = 0;
+    uint32_t posLim = 0;        // the position's dword lies in W0 while pos < posLim (= ((B + 64) << 5) - payBit: one compare per look)
     uint32_t W0 = 0, W1 = 0, W2 = 0;
     uint32_t *ring;
     uint32_t lane;
@@ -139,6 +140,7 @@ struct WaveBits
     __device__ __forceinline__ void reload()
     {
         B = (payBit + pos) >> 5;
+        posLim = ((B + 64) << 5) - payBit;
         W0 = load(B + lane);
         W1 = load(B + 64 + lane);
         W2 = load(B + 128 + lane);
@@ -156,6 +158,8 @@ struct WaveBits
     // the dword of the current position lies in W0
     __device__ __forceinline__ void ensure()
     {
+        if (pos < posLim)
+            return;
         uint32_t j = ((payBit + pos) >> 5) - B;
         while (j >= 64)
         {
@@ -166,6 +170,7 @@ struct WaveBits
                 return;
             }
             W0 = W1; W1 = W2; B += 64; j -= 64;
+            posLim += 64 * 32;
             waveSync();
             ringPut(B + 64 + lane, W1);
             waveSync();
@@ -318,18 +323,24 @@ __device__ __forceinline__ void chainHi(uint32_t v, uint32_t &state, uint32_t &s
 #undef DCS_CHAIN_BODY
 #undef DCS_CHAIN_STEP
 
-// A run of Huffman-coded samples (:2186-2225): symbols from the current position until `rem` samples are accounted for
-// (a two-zeros code counts for two).  Returns what is left: 0, or -1 when the last code was a two-zeros code with one
-// sample to go.  `book` = the codebook's direct look-up table on the next `maxBits` bits, `multi` = its several-codes
-// table (DcsDevTables::multi94): while more than DCS_IDX_MULTI_SAMPLES samples are to go a step of the chain takes
-// all the codes of such an entry, the band's last codes go one by one (so the two-zeros rule and the run's last look,
+// A run of Huffman-coded samples (:2186-2225): symbols from the current position until the samples are accounted for (a
+// two-zeros code counts for two).  `book` = the codebook's direct look-up table on the next 32 - `shift` bits, `multi` = its
+// several-codes table (DcsDevTables::multi94): while more than DCS_IDX_MULTI_SAMPLES samples are to go a step of the chain
+// takes all the codes of such an entry, the band's last codes go one by one (so the two-zeros rule and the run's last look,
 // the one that can decide nBytes, are the reference's).
-__device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *book, uint32_t maxBits, const uint8_t *multi, int rem)
+// The run's state is ONE word from its first look to its last (round 5: the bookkeeping between the chains was 2/3 of the
+// walk's scalar instructions): S = bits walked in this look | (samples to go - 1) << 16 -- the single-code chains' state as
+// it is, the several-codes chains' after subtracting DCS_IDX_MULTI_SAMPLES << 16.  In goes (samples - 1) << 16; out comes
+// 0xFFFF0000 (all samples accounted for) or 0xFFFE0000 (the last code was a two-zeros code with one sample to go).
+__device__ __forceinline__ uint32_t huffRunS(WaveBits &b, const uint16_t *book, uint32_t shift, const uint8_t *multi, uint32_t S)
 {
+    constexpr uint32_t kM = static_cast<uint32_t>(DCS_IDX_MULTI_SAMPLES) << 16;
+    static_assert((DCS_IDX_MULTI_SAMPLES & (DCS_IDX_MULTI_SAMPLES - 1)) == 0, "the test below masks samples-to-go with a power of two");
+    const uint32_t maxBits = 32u - shift;
     b.any = true;
     IDX_T0(tRun);
     IDX_CNT(b, 6, 1);
-    IDX_CNT(b, 7, rem);
+    IDX_CNT(b, 7, (S >> 16) + 1);
     do
     {
         b.ensure();
@@ -338,44 +349,47 @@ __device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *book, uint32
         // (with 64 candidates the second look's two LDS round trips were a quarter of a run)
         uint32_t wLo, wHi;
         b.gather32x2(b.lane, wLo, wHi);
-        const uint32_t eLo = book[wLo >> (32 - maxBits)], eHi = book[wHi >> (32 - maxBits)];
+        const uint32_t eLo = book[wLo >> shift], eHi = book[wHi >> shift];
         const uint32_t mLo = multi[wLo >> (32 - DCS_IDX_MULTI_BITS)], mHi = multi[wHi >> (32 - DCS_IDX_MULTI_BITS)];
         asm volatile("" :: "v"(eLo), "v"(mLo), "v"(eHi), "v"(mHi));     // all four reads on their way before anything waits
         const uint32_t vSingleLo = ((eLo >> 8) & 0x1Fu) - ((eLo >> 13) == 2 ? 0x20000u : 0x10000u);
         const uint32_t vSingleHi = ((eHi >> 8) & 0x1Fu) - ((eHi >> 13) == 2 ? 0x20000u : 0x10000u);
         const uint32_t vMultiLo = (mLo & 15u) - ((mLo >> 4) << 16);
         const uint32_t vMultiHi = (mHi & 15u) - ((mHi >> 4) << 16);
-        // state: bits walked | samples left - 1 (single) or - 1 - DCS_IDX_MULTI_SAMPLES (multi) << 16.  A chain ends when
-        // the samples run out (sign) or the walk leaves its 64 candidates (bit 6 for the first half, bit 7 for the second).
-        uint32_t off = 0, se = 0;
+        // A chain ends when the samples run out (sign) or the walk leaves its 64 candidates (bit 6 for the first half, bit 7
+        // for the second).
+        uint32_t se = 0;
         IDX_T0(tChain);
-        if (rem > DCS_IDX_MULTI_SAMPLES)
+        if (S >= kM)                                        // more than DCS_IDX_MULTI_SAMPLES samples to go
         {
-            uint32_t state = static_cast<uint32_t>(rem - 1 - DCS_IDX_MULTI_SAMPLES) << 16;
-            chain(vMultiLo, state, se);
-            if (static_cast<int32_t>(state) >= 0)           // (left the first 64 candidates with samples to go)
-                chainHi(vMultiHi, state, se);
-            off = state & 0xFFFFu;
-            rem = (static_cast<int32_t>(state) >> 16) + 1 + DCS_IDX_MULTI_SAMPLES;
+            S -= kM;
+            chain(vMultiLo, S, se);
+            if (static_cast<int32_t>(S) >= 0)               // (left the first 64 candidates with samples to go)
+                chainHi(vMultiHi, S, se);
+            S += kM;
         }
-        if (rem <= DCS_IDX_MULTI_SAMPLES && off < 128)
+        if ((S & ((0xFFFF0000u & ~(kM - 0x10000u)) | 0xFF80u)) == 0)     // at most DCS_IDX_MULTI_SAMPLES to go, and inside the 128 candidates
         {
-            uint32_t state = off | (static_cast<uint32_t>(rem - 1) << 16);
-            if (off < 64)
-                chain(vSingleLo, state, se);
-            if (static_cast<int32_t>(state) >= 0)           // (the first half left, or never entered)
-                chainHi(vSingleHi, state, se);
-            off = state & 0xFFFFu;
-            rem = (static_cast<int32_t>(state) >> 16) + 1;
-            b.hi = umax(b.hi, b.pos + off - (se & 0xFFFFu) + maxBits);      // the last symbol's look
+            if ((S & 64u) == 0)
+                chain(vSingleLo, S, se);
+            if (static_cast<int32_t>(S) >= 0)               // (the first half left, or never entered)
+                chainHi(vSingleHi, S, se);
+            b.hi = umax(b.hi, b.pos + maxBits + (S & 0xFFFFu) - (se & 0xFFFFu));       // the last symbol's look
         }
         IDX_ACC(b, 3, tChain);
+        const uint32_t off = S & 0xFFFFu;
         b.pos += off;
+        S -= off;
     }
-    while (rem > 0);
+    while (static_cast<int32_t>(S) >= 0);
     b.have = 0;
     IDX_ACC(b, 2, tRun);
-    return rem;
+    return S;
+}
+// the form band 15's two halves use: `rem` samples -> what is left: 0, or -1 when the last code was a two-zeros code with one sample to go
+__device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *book, uint32_t maxBits, const uint8_t *multi, int rem)
+{
+    return (static_cast<int32_t>(huffRunS(b, book, 32u - maxBits, multi, static_cast<uint32_t>(rem - 1) << 16)) >> 16) + 1;
 }
 
 // The frame header of a 1994+ frame: one band-type delta code per populated band (:1780-1834), lane k < nBands
@@ -492,48 +506,67 @@ __device__ void scan94(Walk &s)
     const uint32_t outIdxB = 1u + advIncl - adv;                // output index at the band's start
     const uint32_t fixedBefore = fixedIncl - fixedBits;         // bits of the fixed-width bands before it
 
-    // what a Huffman-coded band's walk needs, in two words: bits of the fixed-width bands before it | samples << 16, and
-    // codebook (byte offset in the tables) | its several-codes table (of the six: look-aheads 2, 3, 5, 7, 8, 9, :2005) << 12
-    // | look-ahead << 25
-    const uint32_t vRunA = fixedBefore | (s.vCount << 16);
-    const uint32_t vRunB = ((d & 0x7FFu) * 2u) | ((width <= 3u ? width - 2u : width == 5u ? 2u : width - 4u) << 22) | (width << 25);
+    // What a Huffman-coded band's walk needs, a word each (the scalar unit is the walk's busiest at saturation, the vector unit is
+    // not: five v_readlane a run instead of two and six scalar instructions that took their fields apart): the bits of the
+    // fixed-width bands before it, its state word (samples - 1 << 16), its codebook (byte offset in the tables), its several-codes
+    // table (of the six: look-aheads 2, 3, 5, 7, 8, 9, :2005) and 32 - its look-ahead
+    const uint32_t vRunS = (s.vCount - 1u) << 16;
+    const uint32_t vRunBook = (d & 0x7FFu) * 2u;
+    const uint32_t vRunMulti = (width <= 3u ? width - 2u : width == 5u ? 2u : width - 4u) << DCS_IDX_MULTI_BITS;
+    const uint32_t vRunShift = 32u - width;
 
-    // the Huffman-coded bands, one after the other
-    uint32_t vHuffBefore = 0;                                   // lane b: bits of the Huffman-coded bands before band b
-    uint32_t huffBits = 0, midBit = 0, midIdx = 0;
+    // The Huffman-coded bands, one after the other.  The walk carries q = position - bits of the fixed-width bands before it
+    // (the runs are contiguous but for those), lane h keeps q behind band h's run; where every band begins follows from
+    // that afterwards (a maximum over the lanes below: q only grows).
     const uint32_t base = frameStart + hdrBits;
+    uint32_t q = base, vQ = 0, runEnds = 0xFFFFFFFFu;
+    uint32_t midBit = 0, midIdx = 0;
     IDX_ACC(b, 9, tSetup);
     IDX_T0(tLoop);
-    for (uint32_t left = static_cast<uint32_t>(__ballot(huffBand)) ; left != 0 ; left &= left - 1)
+    const uint32_t huffMask = static_cast<uint32_t>(__ballot(huffBand));
+    for (uint32_t left = huffMask & 0x7FFFu ; left != 0 ; left &= left - 1)
     {
         const uint32_t h = static_cast<uint32_t>(__builtin_ctz(left));
-        const uint32_t runA = rl(vRunA, h), runB = rl(vRunB, h);
-        const uint32_t start = base + (runA & 0xFFFFu) + huffBits;
-        b.pos = start;
-        const uint16_t *book = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(&T) + (runB & 0xFFFu));
-        const uint8_t *multi = &s.L->multi94[0][0] + ((runB >> 12) & 0x1FFFu);
-        const uint32_t maxBits = runB >> 25;
-        const int count = static_cast<int>(runA >> 16);
-        if (h != 15)
-        {
-            if (huffRun(b, book, maxBits, multi, count) < 0)
-                s.err |= DCS_FRAME_STOP;                        // two zeros with one slot left (:2213-2218)
-        }
-        else
-        {
-            // band 15 in two halves; where the second one starts is recorded (dcsPutMid15, dcs_scan.h)
-            const int lim = count / 2;
-            const int inc = static_cast<int>(rl(s.vInc, 15));
-            int i = lim + huffRun(b, book, maxBits, multi, count - lim);
-            midBit = (b.pos - frameStart) & 0xFFFFu;
-            midIdx = ((rl(outIdxB, 15) + static_cast<uint32_t>((count - i) * inc)) & 0x1FFu) | (i < lim ? DCS_MID15_STRADDLE : 0u);
-            if (i > 0 && huffRun(b, book, maxBits, multi, i) < 0)
-                s.err |= DCS_FRAME_STOP;
-        }
-        const uint32_t len = b.pos - start;
-        huffBits += len;
-        vHuffBefore += lane > h ? len : 0u;
+        const uint32_t G = rl(fixedBefore, h);
+        const uint16_t *book = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(&T) + rl(vRunBook, h));
+        const uint8_t *multi = &s.L->multi94[0][0] + rl(vRunMulti, h);
+        b.pos = q + G;
+        runEnds &= huffRunS(b, book, rl(vRunShift, h), multi, rl(vRunS, h));
+        q = b.pos - G;
+        vQ = lane == h ? q : vQ;
     }
+    if ((runEnds >> 16) != 0xFFFFu)
+        s.err |= DCS_FRAME_STOP;                                // two zeros with one slot left (:2213-2218)
+    if ((huffMask & 0x8000u) != 0)
+    {
+        // band 15 in two halves; where the second one starts is recorded (dcsPutMid15, dcs_scan.h)
+        const uint32_t G = rl(fixedBefore, 15);
+        const uint16_t *book = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(&T) + rl(vRunBook, 15));
+        const uint8_t *multi = &s.L->multi94[0][0] + rl(vRunMulti, 15);
+        const uint32_t maxBits = 32u - rl(vRunShift, 15);
+        const int count = static_cast<int>(rl(s.vCount, 15));
+        b.pos = q + G;
+        const int lim = count / 2;
+        const int inc = static_cast<int>(rl(s.vInc, 15));
+        int i = lim + huffRun(b, book, maxBits, multi, count - lim);
+        midBit = (b.pos - frameStart) & 0xFFFFu;
+        midIdx = ((rl(outIdxB, 15) + static_cast<uint32_t>((count - i) * inc)) & 0x1FFu) | (i < lim ? DCS_MID15_STRADDLE : 0u);
+        if (i > 0 && huffRun(b, book, maxBits, multi, i) < 0)
+            s.err |= DCS_FRAME_STOP;
+        q = b.pos - G;
+    }
+    // lane b: bits of the Huffman-coded bands before band b = the largest q among the lanes below, from `base`
+    uint32_t vHuffBefore;
+    {
+        uint32_t m = vQ;
+        m = umax(m, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(m), 0x111, 0xF, 0xF, true)));     // row_shr:1
+        m = umax(m, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(m), 0x112, 0xF, 0xF, true)));     // row_shr:2
+        m = umax(m, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(m), 0x114, 0xF, 0xF, true)));     // row_shr:4
+        m = umax(m, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(m), 0x118, 0xF, 0xF, true)));     // row_shr:8
+        m = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(m), 0x111, 0xF, 0xF, true));             // exclusive
+        vHuffBefore = umax(m, base) - base;
+    }
+    const uint32_t huffBits = q - base;
     IDX_ACC(b, 10, tLoop);
     IDX_T0(tTail);
     b.pos = base + rl(fixedIncl, 15) + huffBits;
@@ -752,6 +785,53 @@ __device__ void scan93a(Walk &s)
     }
 }
 
+// the frames of one stream, one after the other: KIND 0 = 1993 Type 0 / OS93b Type 1, 1 = OS93a Type 1, 2 = 1994+
+template <int KIND>
+__device__ __forceinline__ void walkFrames(Walk &s, uint32_t nFrames, DcsFrameIndex *outRec, DcsFrameDigest *outDigest, uint32_t &valid, uint32_t &payloadBits)
+{
+    const uint32_t lane = s.lane;
+    for (uint32_t f = 0 ; f < nFrames ; ++f)
+    {
+        const uint32_t frameBit = s.b.pos;
+        IDX_T0(tWalk);
+        IDX_CNT(s.b, 8, 1);
+        s.err = 0;
+        s.vSplitLo = 0; s.vSplitHi = 0; s.vRecBT = 0; s.hdrBits = 0; s.preAdj = 0;
+        if (KIND == 0) scan93(s);
+        else if (KIND == 1) scan93a(s);
+        else scan94(s);
+        IDX_ACC(s.b, 0, tWalk);
+        IDX_T0(tOut);
+        const uint32_t nBits = (s.b.pos - frameBit) & 0xFFFFu;
+        const uint32_t flags = ((s.err << 4) | (s.err != 0 ? DCS_IDX_SERIAL : 0u)) & 0xFFu;
+        // the record, every lane its part (nothing waits for these stores)
+        {
+            uint8_t *const r8 = reinterpret_cast<uint8_t *>(outRec + valid);
+            uint32_t *const r32 = reinterpret_cast<uint32_t *>(r8);
+            if (lane < 16)
+                r8[8 + lane] = static_cast<uint8_t>(s.vRecBT);
+            if (lane < 15)
+            {
+                r32[7 + 2 * lane] = s.vSplitLo;
+                r32[8 + 2 * lane] = s.vSplitHi;
+            }
+            if (lane == 0)
+            {
+                r32[0] = frameBit;
+                r32[1] = nBits | (s.hdrBits << 16);
+                r32[6] = (s.preAdj & 0xFFFFu) | (static_cast<uint32_t>(s.nBands) << 16) | (flags << 24);
+            }
+        }
+        if (outDigest != nullptr && lane == 0)
+            outDigest[valid] = DcsFrameDigest{ frameBit, static_cast<uint16_t>(nBits), static_cast<uint8_t>(s.nBands), static_cast<uint8_t>(flags) };
+        ++valid;
+        IDX_ACC(s.b, 4, tOut);
+        payloadBits = s.b.pos;
+        if (s.err != 0)
+            break;                  // the reference stops the channel on the next tick (:95-116)
+    }
+}
+
 // where a stream's results go when the streams of one launch belong to different owners (the pipeline's lists, each
 // with buffers of its own)
 struct StreamOut
@@ -859,50 +939,14 @@ __global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 
         outDigest = digest != nullptr ? digest + loc.firstRecord : nullptr;
         outInfo = infos + k;
     }
+    // (the layout is the stream's: one frame loop per family, so that no frame pays for joining three walks' registers)
     uint32_t valid = 0, payloadBits = 0;
-    for (uint32_t f = 0 ; f < nFrames ; ++f)
+    switch (format)
     {
-        const uint32_t frameBit = s.b.pos;
-        IDX_T0(tWalk);
-        IDX_CNT(s.b, 8, 1);
-        s.err = 0;
-        s.vSplitLo = 0; s.vSplitHi = 0; s.vRecBT = 0; s.hdrBits = 0; s.preAdj = 0;
-        switch (format)
-        {
-        case DCS_FMT_93_T0:
-        case DCS_FMT_93B_T1: scan93(s); break;
-        case DCS_FMT_93A_T1: scan93a(s); break;
-        default:             scan94(s); break;
-        }
-        IDX_ACC(s.b, 0, tWalk);
-        IDX_T0(tOut);
-        const uint32_t nBits = (s.b.pos - frameBit) & 0xFFFFu;
-        const uint32_t flags = ((s.err << 4) | (s.err != 0 ? DCS_IDX_SERIAL : 0u)) & 0xFFu;
-        // the record, every lane its part (nothing waits for these stores)
-        {
-            uint8_t *const r8 = reinterpret_cast<uint8_t *>(outRec + valid);
-            uint32_t *const r32 = reinterpret_cast<uint32_t *>(r8);
-            if (lane < 16)
-                r8[8 + lane] = static_cast<uint8_t>(s.vRecBT);
-            if (lane < 15)
-            {
-                r32[7 + 2 * lane] = s.vSplitLo;
-                r32[8 + 2 * lane] = s.vSplitHi;
-            }
-            if (lane == 0)
-            {
-                r32[0] = frameBit;
-                r32[1] = nBits | (s.hdrBits << 16);
-                r32[6] = (s.preAdj & 0xFFFFu) | (static_cast<uint32_t>(s.nBands) << 16) | (flags << 24);
-            }
-        }
-        if (outDigest != nullptr && lane == 0)
-            outDigest[valid] = DcsFrameDigest{ frameBit, static_cast<uint16_t>(nBits), static_cast<uint8_t>(s.nBands), static_cast<uint8_t>(flags) };
-        ++valid;
-        IDX_ACC(s.b, 4, tOut);
-        payloadBits = s.b.pos;
-        if (s.err != 0)
-            break;                  // the reference stops the channel on the next tick (:95-116)
+    case DCS_FMT_93_T0:
+    case DCS_FMT_93B_T1: walkFrames<0>(s, nFrames, outRec, outDigest, valid, payloadBits); break;
+    case DCS_FMT_93A_T1: walkFrames<1>(s, nFrames, outRec, outDigest, valid, payloadBits); break;
+    default:             walkFrames<2>(s, nFrames, outRec, outDigest, valid, payloadBits); break;
     }
 
     // the stream's summary (GetStreamInfo :1486-1537)
