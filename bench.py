@@ -399,8 +399,7 @@ def roofline_cold(ctx, args, first_batch, stream):
             b, _ = workloads.interleave(b)
         batches.append(ctx.batch(b["blob"], b["srcs"], b["jobs"]))
         builds.append((b, streams))
-    pkg = {4: 2176, 8: 3072, 16: 5632}
-    resident = sum(bt.num_chunks * pkg[bt.frames_per_wave] + bt.n_jobs * (480 + 32 + 4) for bt in batches)
+    resident = sum(bt.num_chunks * bt.package_bytes + bt.n_jobs * (480 + 4) for bt in batches)
     iters = max(3 * n, args.steps)
     Batch = type(first_batch)
     Batch.time_rotating(batches, n, stream)                                  # (every batch launched once: code and tables warm, data not)

@@ -99,11 +99,11 @@ class DcsError(RuntimeError):
 
 
 _LIB = None
-ABI_VERSION = 7                 # include/dcs_hip.h DCS_ABI_VERSION these bindings are written for
+ABI_VERSION = 8                 # include/dcs_hip.h DCS_ABI_VERSION these bindings are written for
 
 EXPORTS = [
     "dcs_abi_version", "dcs_build_id", "dcs_index_stream", "dcs_volume_multiplier", "dcs_mixing_multiplier", "dcs_frame_scale",
-    "dcs_stream_params", "dcs_ctx_create", "dcs_ctx_destroy", "dcs_last_error", "dcs_device_count", "dcs_runtime_defaults",
+    "dcs_stream_params", "dcs_ctx_create", "dcs_ctx_destroy", "dcs_last_error", "dcs_device_count", "dcs_runtime_defaults", "dcs_ctx_set_batch_tails", "dcs_batch_package_bytes",
     "dcs_ctx_set_frames_per_wave", "dcs_ctx_set_tail_handoff", "dcs_ctx_set_large_list_path", "dcs_ctx_set_concurrent_batches", "dcs_ctx_set_cache_limits", "dcs_ctx_trim_cache", "dcs_ctx_cache_bytes", "dcs_plan_chunks2", "dcs_decode_batch", "dcs_batch_create", "dcs_batch_destroy", "dcs_batch_run", "dcs_batch_run_many", "dcs_pack_chunks",
     "dcs_batch_time", "dcs_batch_time_rotating", "dcs_batch_sync", "dcs_batch_download", "dcs_batch_download_view", "dcs_batch_device_pcm",
     "dcs_batch_algorithmic_bytes", "dcs_batch_num_jobs", "dcs_decode_streams", "dcs_count_stream_frames",
@@ -328,6 +328,12 @@ def load_library():
     L.dcs_batch_abi_bytes.argtypes = [vp]
     L.dcs_batch_num_chunks.restype = u32
     L.dcs_batch_num_chunks.argtypes = [vp]
+    L.dcs_batch_package_bytes.restype = u32
+    L.dcs_batch_package_bytes.argtypes = [vp]
+    L.dcs_ctx_set_batch_tails.restype = i32
+    L.dcs_ctx_set_batch_tails.argtypes = [vp, ctypes.c_int]
+    L.dcs_runtime_defaults.restype = ctypes.c_int
+    L.dcs_runtime_defaults.argtypes = []
     L.dcs_batch_frames_per_wave.restype = ctypes.c_int
     L.dcs_batch_frames_per_wave.argtypes = [vp]
     L.dcs_ctx_clock_mhz.restype = i32
@@ -708,6 +714,10 @@ class Context:
         """batches created afterwards may run next to other decode launches on the GPU (dcs_ctx_set_concurrent_batches)"""
         _check(self.L.dcs_ctx_set_concurrent_batches(self.h, int(bool(enable))), self.h)
 
+    def set_batch_tails(self, all_frames=True):
+        """resident batches created afterwards store every frame's tail (True) or the last frame's of every chain (False, default)"""
+        _check(self.L.dcs_ctx_set_batch_tails(self.h, int(bool(all_frames))), self.h)
+
     def set_cache_limits(self, device_bytes, pinned_bytes):
         _check(self.L.dcs_ctx_set_cache_limits(self.h, int(device_bytes), int(pinned_bytes)), self.h)
 
@@ -923,6 +933,11 @@ class Batch:
     @property
     def num_chunks(self):
         return int(self.L.dcs_batch_num_chunks(self.h))
+
+    @property
+    def package_bytes(self):
+        """bytes of one chunk package of this batch (the kernel reads num_chunks of them)"""
+        return int(self.L.dcs_batch_package_bytes(self.h))
 
     @property
     def frames_per_wave(self):

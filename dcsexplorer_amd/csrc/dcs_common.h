@@ -139,6 +139,8 @@ constexpr uint32_t dcsPoolCapacity(int fpw)
 #define DCS_SLOT_EXT_TAIL  0x02u        // overlap tail comes from tailsIn[job.prev & 0x7FFFFFFF]
 #define DCS_SLOT_EXPORT    0x04u        // publish this frame's tail in handoff[chunk] for a frame of a later chunk
 #define DCS_SLOT_IMPORT    0x08u        // overlap tail comes from handoff[prevJob] (prevJob = the publishing chunk)
+#define DCS_SLOT_KEEP_TAIL 0x10u        // store this frame's tail in tailsOut: the last frame of its chain in the batch (what a caller
+                                        // needs to carry a stream into its next batch), or every frame when the batch keeps all tails
 #define DCS_SLOT_EMPTY     0x80u        // padding
 #define DCS_NO_PREV_SLOT   0xFFu
 
@@ -252,6 +254,16 @@ static inline
 __host__ __device__
 #endif
 constexpr uint32_t dcsPkgBytes(int fpw) { return dcsPkgOffPool(fpw) + dcsPoolCapacity(fpw) * 4u; }
+// Round 5: the pool image of a HOST-planned batch is only as long as the batch's fullest chunk needs (imgDw dwords, a multiple
+// of 32 = 128 bytes, so that every package still starts on a cache line): the typical chunk fills little more than half of the
+// pool's capacity, and a wavefront reads its whole package.  The packages then lie at dcsPkgStride(fpw, imgDw); the kernel gets
+// imgDw in its flags word (DCS_BATCH_IMG_SHIFT) and clears the rest of the LDS pool itself.  Batches planned on the device keep the
+// full image (the stride would have to come out of device memory: a dependent load in front of the package loads).
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr uint32_t dcsPkgStride(int fpw, uint32_t imgDw) { return dcsPkgOffPool(fpw) + imgDw * 4u; }
 #endif
 
 struct DcsKernelArgs
@@ -283,6 +295,8 @@ struct DcsKernelArgs
 // resident or through whatever else runs on the chip -- other decode kernels included (dcs_pipeline.hip.h: why that matters); only
 // the first workgroup of a range may wait for the last one of the range before, i.e. until that XCD is through.
 #define DCS_BATCH_XCD_RANGES 2u
+#define DCS_BATCH_IMG_SHIFT 16          // bits 16..25: dwords of pool image in every package (dcsPkgStride)
+#define DCS_BATCH_IMG_MASK  0x3FFu
 
 // A source as the planner and the DEVICE packer need it when the index records stay on the device (the pipeline's
 // device path): 24 bytes instead of the 160 of DcsSrcDesc.  `record` = index of the frame's DcsFrameIndex in the
@@ -369,11 +383,20 @@ struct DcsBuiltPlan
 DcsStatus dcsBuildPlanFromDigest(const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames, const DcsDigested &in,
                                  DcsBuiltPlan &P);
 // (depthOrder = false: the chunks stay in chain order, for launches in XCD ranges -- DCS_BATCH_XCD_RANGES)
+// dwords of pool image the packages of a plan need: the fullest chunk's runs, rounded up to 32 dwords, at most the pool's capacity
+uint32_t dcsImageDwords(const DcsSlot *slots, uint32_t nChunks, int fpw);
+// (keepAllTails: every frame's slot gets DCS_SLOT_KEEP_TAIL, else only the last frame of every chain)
 uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true,
-                       int framesPerChunk = 0, bool depthOrder = true);
+                       int framesPerChunk = 0, bool depthOrder = true, bool keepAllTails = false);
+// (places: wavefronts of the decode kernel the chip runs at a time -- CUs x 16 -- or 0; the diagnostic entries assume an MI355X)
+#define DCS_MI355X_WAVE_PLACES 4096u
+uint32_t dcsPlanChunksCapped(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
+                             int framesPerChunk, bool depthOrder, bool keepAllTails, uint32_t *imgDwOut, uint32_t places);
+uint32_t dcsPlanChunksCappedLite(const DcsFrameJob *jobs, uint32_t nJobs, const DcsPlanSrc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
+                                 int framesPerChunk, bool depthOrder, bool keepAllTails, uint32_t *imgDwOut, uint32_t places);
 uint32_t dcsPlanChunksLite(const DcsFrameJob *jobs, uint32_t nJobs, const DcsPlanSrc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true,
-                           int framesPerChunk = 0, bool depthOrder = true);
-// packer: out = nChunks x dcsPkgBytes(fpw) bytes (the chunk packages described above)
+                           int framesPerChunk = 0, bool depthOrder = true, bool keepAllTails = false);
+// packer: out = nChunks x dcsPkgStride(fpw, imgDw) bytes (the chunk packages described above)
 void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const DcsSrcDesc *srcs,
-                      const uint8_t *blob, size_t blobLen, uint8_t *out);
+                      const uint8_t *blob, size_t blobLen, uint8_t *out, uint32_t imgDw);
 #endif

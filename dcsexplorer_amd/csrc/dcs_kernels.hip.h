@@ -1454,7 +1454,9 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     // ---- everything unpack round 0 needs comes from the chunk's package (dcs_common.h): slot, descriptor head, stream
     // header, this lane's split record, the pool image.  All of it is requested here, before anything else, in one
     // go; the padding wavefronts of the last workgroup read package 0 and drop out after the barrier.
-    const uint8_t *pkg = a.packages + (chunk < a.nChunks ? static_cast<size_t>(chunk) * dcsPkgBytes(FPW) : 0);
+    // (the packages' pool image is imgDw dwords long, as much as the batch's fullest chunk needs: flags bits 16..25, dcs_common.h)
+    const int imgDw = static_cast<int>((a.flags >> DCS_BATCH_IMG_SHIFT) & DCS_BATCH_IMG_MASK);
+    const uint8_t *pkg = a.packages + (chunk < a.nChunks ? static_cast<size_t>(chunk) * (dcsPkgOffPool(FPW) + static_cast<uint32_t>(imgDw) * 4u) : 0);
     // The head of the package (slots, descriptor heads, headers: FPW x 96 contiguous bytes) is per-slot data: it is
     // fetched ONCE per wavefront, 16 bytes per lane, and handed to the lanes through LDS below (fewer vector-memory
     // instructions in the burst at the start of a kernel, where every wavefront of the chip issues its loads at once).
@@ -1475,7 +1477,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
         {
             // (unconditional: a predicated load would make the compiler wait for every load above before the tables
             // are even requested; lanes past the image re-read its last 16 bytes and store nothing)
-            const int i = min(lane * 4 + 256 * t, poolDwords(FPW) - 4);
+            const int i = min(lane * 4 + 256 * t, imgDw - 4);
             pimg[t] = *reinterpret_cast<const uint4 *>(pkg + dcsPkgOffPool(FPW) + i * 4);
         }
     }
@@ -1555,8 +1557,9 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     for (int t = 0 ; t < kPoolPieces ; ++t)
     {
         const int i = lane * 4 + 256 * t;
+        const bool in = i < imgDw;                  // (behind the image the pool is zero, as it was when the image had the pool's length)
         if (i < poolDwords(FPW))
-            ldsWrite4(L.pool() + i, pimg[t].x, pimg[t].y, pimg[t].z, pimg[t].w);
+            ldsWrite4(L.pool() + i, in ? pimg[t].x : 0u, in ? pimg[t].y : 0u, in ? pimg[t].z : 0u, in ? pimg[t].w : 0u);
     }
 
     // ---- job of this lane's slot ---------------------------------------------------------------------------
@@ -2008,7 +2011,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
 #pragma unroll
                 for (int r = 1 ; r < 15 ; ++r)
                     out[8 * bitrevN(r, 4)] = x[r];                      // pair 8*bitrev4(r) + bitrev3(l)
-                if (a.tailsOut != nullptr)
+                if (a.tailsOut != nullptr && (myFlags & DCS_SLOT_KEEP_TAIL))
                     reinterpret_cast<uint32_t *>(a.tailsOut)[static_cast<size_t>(myJob) * 8 + lr] = x[15];
             }
         }
@@ -2027,7 +2030,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
 #pragma unroll
                 for (int r = 1 ; r < 15 ; ++r)
                     out[16 * bitrevN(r, 4)] = static_cast<int16_t>(x[r]);          // sample 16*bitrev4(r) + bitrev4(l)
-                if (a.tailsOut != nullptr)
+                if (a.tailsOut != nullptr && (myFlags & DCS_SLOT_KEEP_TAIL))
                     a.tailsOut[static_cast<size_t>(myJob) * 16 + lr] = static_cast<int16_t>(x[15]);
             }
         }

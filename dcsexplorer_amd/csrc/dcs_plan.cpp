@@ -52,7 +52,7 @@ static DcsSlot makeSlot(const DcsFrameJob &jb, uint32_t job, uint8_t prevSlot, u
 
 template <class Src>
 static uint32_t planChunks(const DcsFrameJob *jobs, uint32_t nJobs, const Src *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
-                           int framesPerChunk, bool depthOrder)
+                           int framesPerChunk, bool depthOrder, bool keepAllTails, uint32_t imgCap)
 {
     // (diagnostic: fewer frames per chunk than the kernel variant has slots, the rest of the wavefront idles)
     const uint32_t limit = static_cast<uint32_t>(framesPerChunk >= 1 && framesPerChunk < fpw ? framesPerChunk : fpw);
@@ -122,6 +122,22 @@ static uint32_t planChunks(const DcsFrameJob *jobs, uint32_t nJobs, const Src *s
         }
         sl.poolOff = static_cast<uint16_t>(runs.back().poolOff + (st - runs.back().start));
     };
+    // pool dwords the chunk's runs would take with job jb's first source added (what placeFrame will do)
+    auto runUseWith = [&](const DcsFrameJob &jb, uint32_t from) -> uint32_t {
+        if (srcs == nullptr || jb.nSrc == 0)
+            return from;
+        const Src &sd = srcs[jb.firstSrc];
+        const uint64_t bitPos = (srcStreamOff(sd) + 2 + srcHdrLen(sd)) * 8 + srcBitOff(sd);
+        const uint32_t st = static_cast<uint32_t>(bitPos >> 5);
+        const uint32_t n = dcsPoolDwords(srcStreamOff(sd), srcHdrLen(sd), srcBitOff(sd), srcNBits(sd));
+        if (!runs.empty() && from == runUse && st >= runs.back().start && st <= runs.back().start + runs.back().n)
+        {
+            const Run &r = runs.back();
+            const uint32_t len = st + n > r.start + r.n ? st + n - r.start : r.n;
+            return r.poolOff + ((len + 3) & ~3u);
+        }
+        return from + ((n + 3) & ~3u);
+    };
     const DcsSlot empty{ 0xFFFFFFFFu, DCS_NO_PREV_SLOT, DCS_SLOT_EMPTY, 0, 0, 0, DCS_PREV_NONE, 0, 0, 0, 0, 0, 0, 0 };
     auto closeChunk = [&]() {
         lastLive.push_back(slots.size() - 1);
@@ -188,7 +204,11 @@ static uint32_t planChunks(const DcsFrameJob *jobs, uint32_t nJobs, const Src *s
             return handoff && homeChunk[p] != 0xFFFFFFFFu && homeChunk[p] < chunk && lastLive[homeChunk[p]] == homePos[p];
         };
         uint32_t need = (link && !inChunk(prev) && !canImport(prev)) ? 2u : 1u;
-        if (used + need > (need == 2 && limit < 2 ? 2u : limit) || (used != 0 && !poolFits(j, prev, need == 2)))
+        // imgCap (resident batches, dcsPlanChunksCapped): a chunk whose runs would outgrow the batch's pool image is closed early
+        // as well -- a few per cent of the chunks then hold a frame less, and every package is that much shorter
+        const bool imgFull = imgCap != 0 && used != 0
+                             && runUseWith(jobs[j], need == 2 ? runUseWith(jobs[prev], runUse) : runUse) > imgCap;
+        if (used + need > (need == 2 && limit < 2 ? 2u : limit) || (used != 0 && !poolFits(j, prev, need == 2)) || imgFull)
         {
             closeChunk();
             need = (link && !canImport(prev)) ? 2u : 1u;      // nothing of the new chunk exists yet
@@ -196,6 +216,9 @@ static uint32_t planChunks(const DcsFrameJob *jobs, uint32_t nJobs, const Src *s
 
         uint8_t prevSlot = DCS_NO_PREV_SLOT;
         uint8_t flags = static_cast<uint8_t>(ext ? DCS_SLOT_EXT_TAIL : 0);
+        // whose tail goes to tailsOut: the last frame of a chain (nothing in the batch follows it), or every frame on request
+        if (keepAllTails || succ[j] == 0xFFFFFFFFu)
+            flags |= DCS_SLOT_KEEP_TAIL;
         uint32_t importFrom = 0;
         if (link)
         {
@@ -294,15 +317,99 @@ static uint32_t planChunks(const DcsFrameJob *jobs, uint32_t nJobs, const Src *s
 }
 
 uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
-                       int framesPerChunk, bool depthOrder)
+                       int framesPerChunk, bool depthOrder, bool keepAllTails)
 {
-    return planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk, depthOrder);
+    return planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk, depthOrder, keepAllTails, 0);
+}
+
+// A resident batch is planned for the shortest packages that cost it next to nothing: the plan above, then -- when its fullest
+// chunks are outliers -- once more with the pool image capped at what 97 % of the chunks need (rounded up to 32 dwords).  The
+// chunks that would have been fuller close a frame early.  *imgDwOut = dcsImageDwords of the plan returned.
+template <class Src>
+static uint32_t planChunksCapped(const DcsFrameJob *jobs, uint32_t nJobs, const Src *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
+                                 int framesPerChunk, bool depthOrder, bool keepAllTails, uint32_t *imgDwOut, uint32_t places)
+{
+    uint32_t nChunks = planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk, depthOrder, keepAllTails, 0);
+    uint32_t imgDw = dcsImageDwords(slots.data(), nChunks, fpw);
+    if (nChunks >= 64 && srcs != nullptr)
+    {
+        std::vector<uint32_t> hist(dcsPoolCapacity(fpw) / 32 + 2, 0);
+        for (uint32_t c = 0 ; c < nChunks ; ++c)
+        {
+            uint32_t use = 0;
+            for (int k = 0 ; k < fpw ; ++k)
+            {
+                const DcsSlot &sl = slots[static_cast<size_t>(c) * static_cast<size_t>(fpw) + static_cast<size_t>(k)];
+                if (sl.runNDw != 0 && static_cast<uint32_t>(sl.runPoolOff) + sl.runNDw > use)
+                    use = static_cast<uint32_t>(sl.runPoolOff) + sl.runNDw;
+            }
+            ++hist[(use + 31) / 32 < hist.size() ? (use + 31) / 32 : hist.size() - 1];
+        }
+        uint32_t seen = 0, cap = imgDw;
+        for (size_t b = 0 ; b < hist.size() ; ++b)
+        {
+            seen += hist[b];
+            if (static_cast<uint64_t>(seen) * 100 >= static_cast<uint64_t>(nChunks) * 97)
+            {
+                cap = static_cast<uint32_t>(b) * 32;
+                break;
+            }
+        }
+        // (the cap is a target, not a limit: an empty chunk takes its first frame -- and a halo with its successor -- whatever
+        // their size, and the image is sized by what the plan really holds, dcsImageDwords)
+        if (cap >= 32 && cap + 32 <= imgDw)
+        {
+            std::vector<DcsSlot> again;
+            const uint32_t n2 = planChunks(jobs, nJobs, srcs, fpw, again, handoff, framesPerChunk, depthOrder, keepAllTails, cap);
+            const uint32_t img2 = dcsImageDwords(again.data(), n2, fpw);
+            // Taken when the packages really get shorter in total -- and the launch no longer: `places` wavefronts run at a time
+            // (0: unknown), a launch lasts as many generations of them as it has chunks, and the chunks closed early must not
+            // open another one (measured, round 5: 65 536 frames = 8 192 chunks = exactly two generations, 33.4 us; the same
+            // frames in 8 216 chunks 36.2)
+            const bool sameGenerations = places == 0 || (n2 + places - 1) / places == (nChunks + places - 1) / places;
+            if (sameGenerations && static_cast<uint64_t>(n2) * dcsPkgStride(fpw, img2) < static_cast<uint64_t>(nChunks) * dcsPkgStride(fpw, imgDw))
+            {
+                slots.swap(again);
+                nChunks = n2;
+                imgDw = img2;
+            }
+        }
+    }
+    if (imgDwOut != nullptr)
+        *imgDwOut = imgDw;
+    return nChunks;
+}
+uint32_t dcsPlanChunksCapped(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
+                             int framesPerChunk, bool depthOrder, bool keepAllTails, uint32_t *imgDwOut, uint32_t places)
+{
+    return planChunksCapped(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk, depthOrder, keepAllTails, imgDwOut, places);
+}
+uint32_t dcsPlanChunksCappedLite(const DcsFrameJob *jobs, uint32_t nJobs, const DcsPlanSrc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
+                                 int framesPerChunk, bool depthOrder, bool keepAllTails, uint32_t *imgDwOut, uint32_t places)
+{
+    return planChunksCapped(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk, depthOrder, keepAllTails, imgDwOut, places);
 }
 
 uint32_t dcsPlanChunksLite(const DcsFrameJob *jobs, uint32_t nJobs, const DcsPlanSrc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
-                           int framesPerChunk, bool depthOrder)
+                           int framesPerChunk, bool depthOrder, bool keepAllTails)
 {
-    return planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk, depthOrder);
+    return planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk, depthOrder, keepAllTails, 0);
+}
+
+uint32_t dcsImageDwords(const DcsSlot *slots, uint32_t nChunks, int fpw)
+{
+    uint32_t use = 0;
+    for (size_t i = 0, n = static_cast<size_t>(nChunks) * static_cast<size_t>(fpw) ; i < n ; ++i)
+        if (slots[i].runNDw != 0)
+        {
+            const uint32_t end = static_cast<uint32_t>(slots[i].runPoolOff) + slots[i].runNDw;
+            if (end > use)
+                use = end;
+        }
+    const uint32_t cap = dcsPoolCapacity(fpw);
+    use = (use + 31u) & ~31u;
+    if (use < 32u) use = 32u;           // (the kernel's image loads clamp to imgDw - 4)
+    return use < cap ? use : cap;
 }
 
 extern "C" DcsStatus dcs_plan_chunks2(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, int handoff,
@@ -311,7 +418,8 @@ extern "C" DcsStatus dcs_plan_chunks2(const DcsFrameJob *jobs, uint32_t nJobs, c
     if (jobs == nullptr || nChunksOut == nullptr || fpw < 4 || fpw > 64)
         return DCS_ERR_INVALID_ARG;
     std::vector<DcsSlot> slots;
-    *nChunksOut = dcsPlanChunks(jobs, nJobs, srcs, fpw, slots, handoff != 0);
+    // (the plan of a RESIDENT batch, dcs_batch_create: planned for the shortest packages)
+    *nChunksOut = dcsPlanChunksCapped(jobs, nJobs, srcs, fpw, slots, handoff != 0, 0, true, false, nullptr, DCS_MI355X_WAVE_PLACES);
     if (slotsOut != nullptr)
     {
         if (cap < slots.size())
@@ -336,10 +444,10 @@ extern "C" DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, co
 // (big-endian).  A layout change only; nothing is decoded.  The device then reads nothing else in round 0.
 // ---------------------------------------------------------------------------------------------------------
 static void packChunks(const DcsSlot *slots, uint32_t c0, uint32_t c1, int fpw, const DcsSrcDesc *srcs,
-                       const uint8_t *blob, size_t blobLen, uint8_t *out)
+                       const uint8_t *blob, size_t blobLen, uint8_t *out, uint32_t imgDw)
 {
-    const uint32_t pkgBytes = dcsPkgBytes(fpw);
-    const uint32_t poolCap = dcsPoolCapacity(fpw);
+    const uint32_t pkgBytes = dcsPkgStride(fpw, imgDw);
+    const uint32_t poolCap = imgDw;
     const int sub = 64 / fpw;
     for (uint32_t c = c0 ; c < c1 ; ++c)
     {
@@ -403,7 +511,7 @@ static void packChunks(const DcsSlot *slots, uint32_t c0, uint32_t c1, int fpw, 
             if (n == 0)
                 break;
             if (o + n > poolCap)
-                continue;                                   // cannot happen with the planner above
+                continue;                                   // cannot happen: imgDw covers every run of the plan (dcsImageDwords)
             // dword w of the blob in bit order = its four bytes as they come; bytes past the blob read as zero
             const size_t b0 = static_cast<size_t>(st) * 4, bytes = static_cast<size_t>(n) * 4;
             uint8_t *dst = img + static_cast<size_t>(o) * 4;
@@ -423,7 +531,7 @@ static void packChunks(const DcsSlot *slots, uint32_t c0, uint32_t c1, int fpw, 
 }
 
 void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const DcsSrcDesc *srcs,
-                      const uint8_t *blob, size_t blobLen, uint8_t *out)
+                      const uint8_t *blob, size_t blobLen, uint8_t *out, uint32_t imgDw)
 {
     // (measured on the 2 x EPYC host of an MI355X box, 65 536 frames: 1 thread 2.5 ms, 4 threads 1.2 ms, 8 and 16
     // threads no faster -- the work is memory traffic -- and they slow the single-threaded planner of the next batch down)
@@ -431,7 +539,7 @@ void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const Dcs
     if (nt > 4) nt = 4;
     if (nt <= 1)
     {
-        packChunks(slots, 0, nChunks, fpw, srcs, blob, blobLen, out);
+        packChunks(slots, 0, nChunks, fpw, srcs, blob, blobLen, out, imgDw);
         return;
     }
     std::vector<std::thread> th;
@@ -440,7 +548,7 @@ void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const Dcs
     {
         const uint32_t c0 = t * per, c1 = c0 + per < nChunks ? c0 + per : nChunks;
         if (c0 < c1)
-            th.emplace_back(packChunks, slots, c0, c1, fpw, srcs, blob, blobLen, out);
+            th.emplace_back(packChunks, slots, c0, c1, fpw, srcs, blob, blobLen, out, imgDw);
     }
     for (std::thread &t : th)
         t.join();
@@ -454,14 +562,15 @@ extern "C" DcsStatus dcs_pack_chunks(const DcsFrameJob *jobs, uint32_t nJobs, co
     if (jobs == nullptr || srcs == nullptr || nChunksOut == nullptr || !(fpw == 4 || fpw == 8 || fpw == 16))
         return DCS_ERR_INVALID_ARG;
     std::vector<DcsSlot> slots;
-    const uint32_t nChunks = dcsPlanChunks(jobs, nJobs, srcs, fpw, slots, true);
+    uint32_t imgDw = 0;
+    const uint32_t nChunks = dcsPlanChunksCapped(jobs, nJobs, srcs, fpw, slots, true, 0, true, false, &imgDw, DCS_MI355X_WAVE_PLACES);
     *nChunksOut = nChunks;
     if (packageBytesOut != nullptr)
-        *packageBytesOut = dcsPkgBytes(fpw);
+        *packageBytesOut = dcsPkgStride(fpw, imgDw);
     if (out == nullptr)
         return DCS_OK;
-    if (cap < static_cast<size_t>(nChunks) * dcsPkgBytes(fpw))
+    if (cap < static_cast<size_t>(nChunks) * dcsPkgStride(fpw, imgDw))
         return DCS_ERR_CAPACITY;
-    dcsBuildPackages(slots.data(), nChunks, fpw, srcs, blob, blobLen, out);
+    dcsBuildPackages(slots.data(), nChunks, fpw, srcs, blob, blobLen, out, imgDw);
     return DCS_OK;
 }

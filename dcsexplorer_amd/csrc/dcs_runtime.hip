@@ -31,6 +31,7 @@ struct DcsCtx
     bool dropExports = false;           // test hook: no chunk publishes its tail (dcs_ctx_set_test_hooks)
     int framesPerChunk = 0;             // diagnostic: frames a wavefront decodes (0 = as many as the kernel variant has slots)
     bool xcdRanges = false;             // batches of this context: chain order, launched in XCD ranges (dcs_ctx_set_concurrent_batches)
+    bool keepAllTails = false;          // resident batches store EVERY frame's tail (dcs_ctx_set_batch_tails); default: the last frame of every chain
     bool largeListOnDevice = true;      // dcs_decode_streams on a large list: index walk, planner and packer on the device (dcs_ctx_set_large_list_path)
     std::mutex cacheMutex;              // the buffer cache is shared by the pipeline's worker threads
     struct DcsPipeline *internalPipe = nullptr;     // dcs_decode_streams takes large lists through it in parts (dcs_pipeline.hip.h)
@@ -191,6 +192,8 @@ static thread_local bool tlsBlockingWaits = false;
 // Batches made by THIS thread keep their chunks in chain order and are launched in XCD ranges (DCS_BATCH_XCD_RANGES): set by the
 // pipelines' workers, whose decode kernels run next to each other's.
 static thread_local bool tlsXcdRanges = false;
+static thread_local bool tlsResidentBatch = false;   // dcs_batch_create: a batch that is run many times is planned twice for the shortest packages (dcsPlanChunksCapped)
+static thread_local bool tlsKeepAllTails = false;   // dcs_decode_batch with a tailsOut array: every frame's tail (the sequencer resumes from any tick)
 
 // wait for everything enqueued on `stream`
 static hipError_t streamWait(DcsCtx *ctx, hipStream_t stream)
@@ -290,6 +293,7 @@ struct DcsBatch
     uint8_t *dPackages = nullptr;           // nChunks x dcsPkgBytes(fpw) (DcsKernelArgs.packages)
     uint32_t epoch = 0;                     // launches of this batch so far
     uint32_t flags = 0;                     // DCS_BATCH_*
+    uint32_t imgDw = 0;                     // dwords of pool image per package (0: the pool's capacity); packages at dcsPkgStride(fpw, imgDw)
     size_t cap[10] = { 0 };                 // allocated bytes of the buffers above, in that order
     // packages assembled on the device: the plan and the source digests as uploaded for the pack kernel
     void *dPlanSlots = nullptr, *dPlanSrcs = nullptr, *hStage = nullptr, *dTable = nullptr;      // (dTable: the stream table of the device planner; cap[2])
@@ -562,6 +566,19 @@ extern "C" DcsStatus dcs_ctx_set_large_list_path(DcsCtx *ctx, int onDevice)
     return DCS_OK;
 }
 
+extern "C" DcsStatus dcs_ctx_set_batch_tails(DcsCtx *ctx, int allFrames)
+{
+    if (ctx == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    ctx->keepAllTails = allFrames != 0;
+    return DCS_OK;
+}
+
+extern "C" uint32_t dcs_batch_package_bytes(const DcsBatch *b)
+{
+    return b ? dcsPkgStride(b->fpw, b->imgDw != 0 ? b->imgDw : dcsPoolCapacity(b->fpw)) : 0;
+}
+
 extern "C" DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t handoffTimeoutUs, int dropExports)
 {
     if (ctx == nullptr)
@@ -630,7 +647,7 @@ static DcsKernelArgs kernelArgs(const DcsBatch *b)
     args.debug = b->dDebug;
     args.handoff = b->dHandoff;
     args.epoch = b->epoch;
-    args.flags = b->flags;
+    args.flags = b->flags | ((b->imgDw != 0 ? b->imgDw : dcsPoolCapacity(b->fpw)) << DCS_BATCH_IMG_SHIFT);
     args.timeoutTicks = b->ctx->handoffTimeoutTicks;
     return args;
 }
@@ -730,7 +747,17 @@ static DcsStatus createBatch(DcsCtx *ctx,
     size_t pkgBytes = 0;
     static const bool forceRanges = getenv("DCS_BATCH_XCD_RANGES") != nullptr && atoi(getenv("DCS_BATCH_XCD_RANGES")) != 0;     // (experiment switch)
     const bool ranges = tlsXcdRanges || ctx->xcdRanges || forceRanges;
-    b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges);
+    // (experiment switch, for A/B runs on one binary: round 4's packages -- the full pool image, every frame's tail stored)
+    static const bool fullImage = getenv("DCS_EXP_FULL_IMAGE") != nullptr && atoi(getenv("DCS_EXP_FULL_IMAGE")) != 0;
+    const bool allTails = ctx->keepAllTails || tlsKeepAllTails || fullImage;
+    if (tlsResidentBatch && !fullImage)
+        b->nChunks = dcsPlanChunksCapped(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges, allTails, &b->imgDw,
+                                          static_cast<uint32_t>(ctx->numCUs) * 16u);
+    else
+    {
+        b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges, allTails);
+        b->imgDw = fullImage ? dcsPoolCapacity(b->fpw) : dcsImageDwords(slots.data(), b->nChunks, b->fpw);
+    }
     if (ranges && handoff)
         b->flags |= DCS_BATCH_XCD_RANGES;
     if (ctx->dropExports)
@@ -778,9 +805,9 @@ static DcsStatus createBatch(DcsCtx *ctx,
             HIPCHK(ctx, hipMemcpyAsync(b->dSrcs, srcs, sizeof(DcsSrcDesc) * nSrcs, hipMemcpyHostToDevice, b->stream));
         }
         // built in pinned host memory (recycled by the context like the device buffers): the upload runs at link speed
-        pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw);
+        pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgStride(b->fpw, b->imgDw);
         HIPCHK(ctx, cacheAlloc(ctx, true, reinterpret_cast<void **>(&hPackages), pkgBytes));
-        dcsBuildPackages(slots.data(), b->nChunks, b->fpw, srcs, blob, blobLen, hPackages);
+        dcsBuildPackages(slots.data(), b->nChunks, b->fpw, srcs, blob, blobLen, hPackages, b->imgDw);
         b->cap[9] = pkgBytes; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPackages), b->cap[9]));
         HIPCHK(ctx, hipMemcpyAsync(b->dPackages, hPackages, pkgBytes, hipMemcpyHostToDevice, b->stream));
         if (nTailsIn)
@@ -791,6 +818,7 @@ static DcsStatus createBatch(DcsCtx *ctx,
         b->cap[4] = sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPcm), b->cap[4]));
         b->cap[5] = sizeof(uint32_t) * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dErr), b->cap[5]));
         b->cap[6] = sizeof(int16_t) * 16 * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsOut), b->cap[6]));
+        HIPCHK(ctx, hipMemsetAsync(b->dTailsOut, 0, b->cap[6], b->stream));   // (rows of frames whose tail is not kept read as zero)
         HIPCHK(ctx, hipMemsetAsync(b->dErr, 0, sizeof(uint32_t) * nJobs, b->stream));
         b->cap[8] = sizeof(unsigned long long) * 16 * (b->nChunks + 1); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dHandoff), b->cap[8]));
         HIPCHK(ctx, hipMemsetAsync(b->dHandoff, 0, b->cap[8], b->stream));     // epoch 0 = never written
@@ -826,13 +854,13 @@ namespace {
 template <int FPW>
 __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint32_t nChunks, const DcsPlanSrc *srcs,
                                                       const DcsFrameIndex *records, const uint8_t *blob, uint64_t blobLen,
-                                                      uint8_t *packages)
+                                                      uint8_t *packages, uint32_t imgDw)
 {
     const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = static_cast<int>(threadIdx.x & 63);
     if (chunk >= nChunks)
         return;
-    uint8_t *pkg = packages + static_cast<size_t>(chunk) * dcsPkgBytes(FPW);
+    uint8_t *pkg = packages + static_cast<size_t>(chunk) * dcsPkgStride(FPW, imgDw);
     const DcsSlot *cs = slots + static_cast<size_t>(chunk) * FPW;
     // the slots, 16 bytes per lane
     if (lane < FPW * 2)
@@ -907,7 +935,7 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
         const uint32_t n = cs[k].runNDw, st = cs[k].runStartDw, o = cs[k].runPoolOff;
         if (n == 0)
             break;
-        if (o + n > dcsPoolCapacity(FPW))
+        if (o + n > imgDw)
             continue;
         for (uint32_t i = static_cast<uint32_t>(lane) ; i < n ; i += 64)
         {
@@ -998,6 +1026,8 @@ __global__ __launch_bounds__(256) void dcsPlanKernel(const DcsPlanStream *stream
         }
         if ((static_cast<uint32_t>(p) == fpc - 1 || j + 1 == nJobs) && f + 1 < framesOut && j + 1 < nJobs)
             sl.flags |= DCS_SLOT_EXPORT;
+        if (f + 1 == framesOut)
+            sl.flags |= DCS_SLOT_KEEP_TAIL;         // the last frame of its chain (dcs_plan.cpp)
         if (has)
         {
             const uint32_t *rec = reinterpret_cast<const uint32_t *>(&records[st.firstRecord + f]);
@@ -1088,12 +1118,13 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
     thread_local std::vector<DcsSlot> slots;
     const bool ranges = tlsXcdRanges || ctx->xcdRanges;
     b->nChunks = dcsPlanChunksLite(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges);
+    b->imgDw = dcsImageDwords(slots.data(), b->nChunks, b->fpw);
     if (ranges && handoff)
         b->flags |= DCS_BATCH_XCD_RANGES;
     if (ctx->dropExports)
         for (DcsSlot &sl : slots)
             sl.flags &= static_cast<uint8_t>(~DCS_SLOT_EXPORT);
-    const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw);
+    const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgStride(b->fpw, b->imgDw);
     void *stage = nullptr;
     size_t stageBytes = 0;
     DcsStatus st = [&]() -> DcsStatus {
@@ -1117,11 +1148,11 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
         const DcsSlot *dS = static_cast<const DcsSlot *>(b->dPlanSlots);
         const DcsPlanSrc *dP = static_cast<const DcsPlanSrc *>(b->dPlanSrcs);
         if (b->fpw == 16)
-            hipLaunchKernelGGL(dcsPackKernel<16>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+            hipLaunchKernelGGL(dcsPackKernel<16>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages, b->imgDw);
         else if (b->fpw == 8)
-            hipLaunchKernelGGL(dcsPackKernel<8>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+            hipLaunchKernelGGL(dcsPackKernel<8>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages, b->imgDw);
         else
-            hipLaunchKernelGGL(dcsPackKernel<4>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+            hipLaunchKernelGGL(dcsPackKernel<4>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages, b->imgDw);
         HIPCHK(ctx, hipGetLastError());
         b->cap[4] = sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPcm), b->cap[4]));
         b->cap[5] = sizeof(uint32_t) * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dErr), b->cap[5]));
@@ -1192,11 +1223,11 @@ static DcsStatus queuePlanAndPack(DcsBatch *b, uint32_t nStreams, uint32_t extra
     if (between != nullptr)
         HIPCHK(ctx, hipEventRecord(between, b->stream));
     if (b->fpw == 16)
-        hipLaunchKernelGGL(dcsPackKernel<16>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+        hipLaunchKernelGGL(dcsPackKernel<16>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages, b->imgDw);
     else if (b->fpw == 8)
-        hipLaunchKernelGGL(dcsPackKernel<8>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+        hipLaunchKernelGGL(dcsPackKernel<8>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages, b->imgDw);
     else
-        hipLaunchKernelGGL(dcsPackKernel<4>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages);
+        hipLaunchKernelGGL(dcsPackKernel<4>, dim3(blocks), dim3(256), 0, b->stream, dS, b->nChunks, dP, dRecords, dBlob, blobLen, b->dPackages, b->imgDw);
     HIPCHK(ctx, hipGetLastError());
     return DCS_OK;
 }
@@ -1235,6 +1266,7 @@ static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *ta
         b->planFpc = static_cast<uint32_t>(fpc >= 1 && fpc < b->fpw ? fpc : b->fpw);
     }
     b->nChunks = (nJobs + b->planFpc - 1) / b->planFpc;
+    b->imgDw = dcsPoolCapacity(b->fpw);         // (a plan made on the device: the full image, dcs_common.h)
     const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw);
     void *dTable = nullptr;
     const size_t tableBytes = sizeof(DcsPlanStream) * nStreams;
@@ -1310,13 +1342,14 @@ extern "C" DcsStatus dcs_pack_chunks_device(DcsCtx *ctx, const DcsFrameJob *jobs
         recs[k] = sd.idx;
     }
     std::vector<DcsSlot> slots;
-    const uint32_t nChunks = dcsPlanChunksLite(jobs, nJobs, ps.data(), fpw, slots, true, 0);
+    uint32_t imgDw = 0;
+    const uint32_t nChunks = dcsPlanChunksCappedLite(jobs, nJobs, ps.data(), fpw, slots, true, 0, true, false, &imgDw, DCS_MI355X_WAVE_PLACES);
     *nChunksOut = nChunks;
     if (packageBytesOut != nullptr)
-        *packageBytesOut = dcsPkgBytes(fpw);
+        *packageBytesOut = dcsPkgStride(fpw, imgDw);
     if (out == nullptr)
         return DCS_OK;
-    const size_t pkgBytes = static_cast<size_t>(nChunks) * dcsPkgBytes(fpw);
+    const size_t pkgBytes = static_cast<size_t>(nChunks) * dcsPkgStride(fpw, imgDw);
     if (cap < pkgBytes)
         return DCS_ERR_CAPACITY;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1340,9 +1373,9 @@ extern "C" DcsStatus dcs_pack_chunks_device(DcsCtx *ctx, const DcsFrameJob *jobs
         const DcsFrameIndex *dR = static_cast<const DcsFrameIndex *>(dRecs);
         const uint8_t *dB = static_cast<const uint8_t *>(dBlob);
         uint8_t *dO = static_cast<uint8_t *>(dPkg);
-        if (fpw == 16)     hipLaunchKernelGGL(dcsPackKernel<16>, dim3(blocks), dim3(256), 0, ctx->stream, dS, nChunks, dP, dR, dB, blobLen, dO);
-        else if (fpw == 8) hipLaunchKernelGGL(dcsPackKernel<8>, dim3(blocks), dim3(256), 0, ctx->stream, dS, nChunks, dP, dR, dB, blobLen, dO);
-        else               hipLaunchKernelGGL(dcsPackKernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, dS, nChunks, dP, dR, dB, blobLen, dO);
+        if (fpw == 16)     hipLaunchKernelGGL(dcsPackKernel<16>, dim3(blocks), dim3(256), 0, ctx->stream, dS, nChunks, dP, dR, dB, blobLen, dO, imgDw);
+        else if (fpw == 8) hipLaunchKernelGGL(dcsPackKernel<8>, dim3(blocks), dim3(256), 0, ctx->stream, dS, nChunks, dP, dR, dB, blobLen, dO, imgDw);
+        else               hipLaunchKernelGGL(dcsPackKernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, dS, nChunks, dP, dR, dB, blobLen, dO, imgDw);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(out, dPkg, pkgBytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1363,6 +1396,7 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
 {
     if (ctx == nullptr)
         return DCS_ERR_INVALID_ARG;
+    struct Resident { bool old; Resident() : old(tlsResidentBatch) { tlsResidentBatch = true; } ~Resident() { tlsResidentBatch = old; } } resident;
     return createBatch(ctx, blob, blobLen, srcs, nSrcs, jobs, nJobs, tailsIn, nTailsIn, nullptr, ctx->handoff, out);
 }
 
@@ -1609,6 +1643,8 @@ extern "C" DcsStatus dcs_decode_batch(DcsCtx *ctx,
     // One-shot calls launch in XCD ranges like the pipelines' batches do (include/dcs_hip.h says "always", and two processes or threads
     // making small one-shot calls on one card are launches side by side like any other; ~1 % of a kernel that is a fraction of the call).
     struct Ranges { bool old; Ranges() : old(tlsXcdRanges) { tlsXcdRanges = true; } ~Ranges() { tlsXcdRanges = old; } } ranges;
+    // a caller that asks for tailsOut gets the tail EVERY frame leaves (the sequencer resumes from any tick of a batch)
+    struct Tails { bool old; explicit Tails(bool all) : old(tlsKeepAllTails) { tlsKeepAllTails = all; } ~Tails() { tlsKeepAllTails = old; } } tails(tailsOut != nullptr);
     for (int attempt = 0 ; attempt < 2 ; ++attempt)
     {
         const bool handoff = ctx->handoff && attempt == 0;

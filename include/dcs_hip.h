@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DCS_ABI_VERSION 7              /* 7: DcsPipelineResult.path, dcs_node_*, cache control (round 4) */
+#define DCS_ABI_VERSION 8              /* 8: dcs_ctx_set_batch_tails (resident batches keep chain-end tails by default), dcs_batch_package_bytes, dcs_runtime_defaults (round 5) */
 #define DCS_FRAME_SAMPLES 240          /* PCM samples per frame (DCSDecoder.h:123: 7.68 ms at 31250 Hz) */
 #define DCS_MAX_CHANNELS 8             /* DCSDecoderNative.h:305 */
 
@@ -241,6 +241,12 @@ DcsStatus dcs_ctx_set_large_list_path(DcsCtx *ctx, int onDevice);
  * consumer on the consumer's own XCD -- so no wait depends on another launch.  About 1 % slower for a batch alone on the chip, which is
  * why it is not the default for resident batches (dcs_batch_create); dcs_pipeline, dcs_node, dcs_decode_batch and dcs_decode_streams always work this way.  Same PCM either way. */
 DcsStatus dcs_ctx_set_concurrent_batches(DcsCtx *ctx, int enable);
+/* Which frames' 16-sample tails a RESIDENT batch (dcs_batch_create) stores for dcs_batch_download's tailsOut.  0 (default): the last
+ * frame of every chain of the batch -- a frame no other frame of the batch names as its predecessor -- which is what a caller needs
+ * to carry a stream into its next batch (DCS_PREV_EXT); the other rows read as zero.  1: every frame (32 bytes of HBM writes per
+ * frame more), for a caller that may resume behind ANY frame of the batch.  Applies to batches created afterwards.  dcs_decode_batch
+ * stores every frame's tail whenever it is given a tailsOut array (DCSDecoderHIP's sequencer rewinds to any tick of its look-ahead). */
+DcsStatus dcs_ctx_set_batch_tails(DcsCtx *ctx, int allFrames);
 /* The context keeps device and pinned-host buffers of finished batches and lists for the next ones (hipMalloc / hipFree
  * cost as much as decoding thousands of frames, and hipFree waits for the whole device).  What it may keep is bounded:
  * by default min(32 GB, an eighth of the card's free memory at dcs_ctx_create) of device memory and min(8 GB, a
@@ -256,7 +262,7 @@ DcsStatus dcs_ctx_cache_bytes(DcsCtx *ctx, uint64_t *deviceBytes, uint64_t *pinn
 /* One-shot convenience: host buffers in, host buffers out (H2D, kernel, D2H on the context's
  * stream, synchronous).  pcmOut = nJobs x 240 int16; errOut (optional) = nJobs x uint32 DCS_FRAME_*.
  * tailsIn (optional) = 16-sample overlap tails referenced by DCS_PREV_EXT; tailsOut (optional) =
- * nJobs x 16 samples, the tail each frame leaves for its successor. */
+ * nJobs x 16 samples, the tail each frame leaves for its successor (every frame's). */
 DcsStatus dcs_decode_batch(DcsCtx *ctx,
                            const uint8_t *blob, size_t blobLen,
                            const DcsSrcDesc *srcs, uint32_t nSrcs,
@@ -299,7 +305,11 @@ DcsStatus dcs_batch_time(DcsBatch *batch, void *hipStream, int iters, float *avg
  * time on COLD inputs (bench.py --rotate, roofline_cold). */
 DcsStatus dcs_batch_time_rotating(DcsBatch *const *batches, uint32_t n, void *hipStream, int iters, float *avgMs);
 DcsStatus dcs_batch_sync(DcsBatch *batch);
+/* (tailsOut: nJobs x 16 samples; which rows are filled is the context's dcs_ctx_set_batch_tails setting at dcs_batch_create) */
 DcsStatus dcs_batch_download(DcsBatch *batch, int16_t *pcmOut, uint32_t *errOut, int16_t *tailsOut);
+/* bytes of one chunk package of this batch: the kernel's input is dcs_batch_num_chunks() packages of this size.  A batch planned
+ * on the host sizes the packages' image of the LDS bit pool by its fullest chunk (a multiple of 128 bytes). */
+uint32_t dcs_batch_package_bytes(const DcsBatch *batch);
 /* the same without the copy into caller memory: PCM (and error words) in pinned host memory owned by the batch,
  * valid until the batch is run again or destroyed; the device-to-host copy then runs at link speed */
 DcsStatus dcs_batch_download_view(DcsBatch *b, const int16_t **pcmOut, const uint32_t **errOut);

@@ -198,6 +198,36 @@ def test_external_tails_and_tails_out(gpu_ctx, oracle):
         assert_same(np.concatenate([pcm_a, pcm_b]), want, "two-call streaming")
 
 
+def test_resident_batch_keeps_chain_end_tails_unless_asked_for_all(gpu_ctx):
+    """dcs_ctx_set_batch_tails: by default a resident batch stores the tail of the LAST frame of every chain (what carries a
+    stream into its next batch), the other rows read as zero; with all_frames every row is what dcs_decode_batch returns.
+    Three streams of unlike lengths and layouts, so that chain ends fall inside chunks."""
+    streams = [(os_for(f), make_stream(f, n, seed=15000 + f), 255, 0x64) for f, n in ((D.FMT_94_T1_S3, 21), (D.FMT_93_T0, 9), (D.FMT_94_T0, 14))]
+    b = D.build_stream_batch(streams)
+    _, _, want = gpu_ctx.decode_batch(b["blob"], b["srcs"], b["jobs"], want_tails=True)
+    ends = np.asarray(b["first_job"][1:], dtype=np.int64) - 1
+    assert want[ends].any()
+    for fpw in (4, 8, 16):
+        gpu_ctx.set_frames_per_wave(fpw)
+        try:
+            bt = gpu_ctx.batch(b["blob"], b["srcs"], b["jobs"])
+            bt.run(); bt.run()
+            _, _, got = bt.download(want_tails=True)
+            bt.close()
+            assert np.array_equal(got[ends], want[ends]), fpw
+            rest = np.ones(got.shape[0], bool); rest[ends] = False
+            assert not got[rest].any(), fpw
+            gpu_ctx.set_batch_tails(True)
+            bt = gpu_ctx.batch(b["blob"], b["srcs"], b["jobs"])
+            bt.run()
+            _, _, got = bt.download(want_tails=True)
+            bt.close()
+            assert np.array_equal(got, want), fpw
+        finally:
+            gpu_ctx.set_batch_tails(False)
+            gpu_ctx.set_frames_per_wave(0)
+
+
 def test_multichannel_mix(gpu_ctx, oracle):
     """several sources mixed into one output frame (MainLoop's per-channel DecodeStream loop, :272-273)"""
     meta = json.load(open(os.path.join(GOLD, "dcs_golden_hashes.json")))

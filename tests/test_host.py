@@ -213,8 +213,11 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
     assert pk.shape[0] == plan.shape[0]
     sub = 64 // fpw
     off_desc, off_hdr, off_split, off_pool = fpw * 32, fpw * 80, fpw * 96, fpw * 96 + 512
-    pool_dw = max(fpw * 56, 320)
-    assert pk.shape[1] == off_pool + pool_dw * 4
+    # the image of the bit pool is as long as the plan's fullest chunk needs (a multiple of 128 bytes, at most the pool)
+    pool_cap = max(fpw * 56, 320)
+    img_dw = (pk.shape[1] - off_pool) // 4
+    assert pk.shape[1] == off_pool + img_dw * 4 and img_dw % 32 == 0 and 32 <= img_dw <= pool_cap
+    fullest = 0
     src_bytes = srcs.view(np.uint8).reshape(srcs.size, -1)
     seen = 0
     n_shared, n_93a = [0], [0]
@@ -222,6 +225,9 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
         slots = pk[c, :off_desc].view("<u4").reshape(fpw, 8)
         pool = pk[c, off_pool:].view("<u4")
         for s in range(fpw):
+            # (run s of the chunk rides in slot s: runNDw = low half of dword 5, runPoolOff = high half of dword 7)
+            if int(slots[s, 5]) & 0xFFFF:
+                fullest = max(fullest, (int(slots[s, 7]) >> 16) + (int(slots[s, 5]) & 0xFFFF))
             flags = (int(slots[s, 1]) >> 8) & 0xFF
             assert int(slots[s, 0]) == int(plan[c, s]["job"]) and flags == int(plan[c, s]["flags"])
             if flags & 0x80:
@@ -304,6 +310,7 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
                 assert got == (byte >> (7 - ((bit0 + k) & 7))) & 1
             seen += 1
     assert seen >= jobs.size
+    assert img_dw == min(pool_cap, max(32, (fullest + 31) // 32 * 32))      # exactly the fullest chunk's runs, rounded up
     assert (n_shared[0] > 0) == (fpw == 4)          # one band per lane: band 15 of the 1994+ frames goes to two lanes
     assert n_93a[0] > 0
 
