@@ -141,7 +141,8 @@ def cpu_baseline(streams, budget_s=10.0):
 # --------------------------------------------------------------------------------------------- end to end
 def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
     """host buffers in, host buffers out (never `value`): index pass + parameters + plan + pack + H2D + kernel + D2H.
-    cold: one synchronous dcs_decode_streams call per list (which takes a large list through an internal pipeline in parts).  sustained: the same lists through dcs_pipeline with
+    cold: one synchronous dcs_decode_streams call per list (which takes a large list through an internal pipeline in parts, the index walk
+    shared between the host pool and the device).  sustained: the same lists through dcs_pipeline with
     `depth` lists in flight (host preparation of list k+1 while the GPU decodes k and k-1 comes back into pinned memory)."""
     import numpy as np
     import dcsexplorer_amd as D
@@ -208,8 +209,9 @@ def end_to_end(ctx, streams, n_frames, depth=8, dev_depth=32, lists=24):
     return {"unit": "samples/s", "frames_per_list": n_frames,
             "cold": {"value": samples / cold_s, "ms_per_list": cold_s * 1e3,
                      "what": "dcs_decode_streams, one synchronous call per list into pageable memory (median of nine calls): H2D + index + plan + pack + "
-                             "kernel + D2H + copy out (a list this large goes through the context's own pipeline in eight parts, index walk, planner and "
-                             "packer on the device)"},
+                             "kernel + D2H + copy out (a list this large goes through the context's own pipeline in eight parts, planner and packer on "
+                             "the device, the index walk shared: the host pool walks the first parts while dcsIndexWaveKernel walks the last, "
+                             "dcs_ctx_set_large_list_path 2)"},
             "sustained": dict(best, what="dcs_pipeline, the fastest of the four configurations below: lists in flight, PCM "
                                          "returned in pinned memory, collected in submission order",
                               link={"pcm_bytes_per_list": n_frames * 480, "measured_GBps": link_gbps,

@@ -742,9 +742,12 @@ class Context:
     def set_tail_handoff(self, enable):
         _check(self.L.dcs_ctx_set_tail_handoff(self.h, int(bool(enable))), self.h)
 
-    def set_large_list_path(self, on_device):
-        """dcs_decode_streams on a large list: index walk, planner and packer on the device (default) or the host's pool"""
-        _check(self.L.dcs_ctx_set_large_list_path(self.h, int(bool(on_device))), self.h)
+    def set_large_list_path(self, on_device, shared=True):
+        """dcs_decode_streams on a large list: 0 = index pass on the host's pool; 1 = index walk, planner and packer on the device;
+        2 (default) = the device path with the host pool walking the list's first parts next to the index kernel.
+        on_device may also be the mode itself (0, 1, 2)."""
+        mode = int(on_device) if on_device in (0, 1, 2) and not isinstance(on_device, bool) else (0 if not on_device else (2 if shared else 1))
+        _check(self.L.dcs_ctx_set_large_list_path(self.h, mode), self.h)
 
     def decode_batch(self, blob, srcs, jobs, tails_in=None, want_tails=False):
         blob_a = np.frombuffer(bytes(blob), dtype=np.uint8)

@@ -1483,6 +1483,9 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     }
     TwA W;
     loadTwA(a.tables, W);
+#ifdef DCS_EXP_PREFETCH
+    uint32_t pfWord = 0;
+#endif
 
     // ---- stage the shared tables (whole workgroup), clear this wavefront's tile ------------------------
     {
@@ -1496,6 +1499,17 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
         uint4 pairPiece = make_uint4(0, 0, 0, 0);
         if (stagePairs)
             pairPiece = reinterpret_cast<const uint4 *>(a.tables->pair93a)[threadIdx.x];
+#ifdef DCS_EXP_PREFETCH
+        // experiment: touch the package of the chunk that will take this wavefront's place (DCS_EXP_PREFETCH chunks on: the
+        // chip holds that many wavefronts of this kernel, and workgroup w + 1024 runs on the XCD of workgroup w), one dword in
+        // every 128-byte line, so that the next generation finds its package in this XCD's L2.  The result is never used.
+        {
+            const uint32_t ahead = min(chunk + static_cast<uint32_t>(DCS_EXP_PREFETCH), a.nChunks - 1u);
+            const uint32_t stride = dcsPkgOffPool(FPW) + static_cast<uint32_t>(imgDw) * 4u;
+            const uint8_t *nx = a.packages + static_cast<size_t>(ahead) * stride + min(static_cast<uint32_t>(lane) * 128u, stride - 4u);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pfWord) : "v"(nx) : "memory");
+        }
+#endif
         uint4 *tile = reinterpret_cast<uint4 *>(L.base);
 #ifndef DCS_CLEAR_FIRST_MAX_FPW
 #define DCS_CLEAR_FIRST_MAX_FPW 8
@@ -1515,6 +1529,9 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
                 tile[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();                                // the only workgroup barrier: tables are in place
+#ifdef DCS_EXP_PREFETCH
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(pfWord) : "memory");      // (the youngest load; its register is free from here on)
+#endif
     if (chunk >= a.nChunks)
         return;                                     // padding wavefront of the last workgroup
 

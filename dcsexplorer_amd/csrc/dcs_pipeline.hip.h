@@ -90,6 +90,8 @@ struct DcsPipeline
     int nWorkers = 0, nUploaders = 0;               // (device index pass: the first nUploaders workers do stage A only)
     std::vector<hipStream_t> streams;               // one per worker, and one more for each indexer
     bool quit = false;
+    // dcsDecodeStreamsInParts with the walk shared between host and device: when the last list of either kind was finished
+    double lastHostWalkedDone = 0, lastDeviceWalkedDone = 0;
 };
 
 static double nowMs()
@@ -142,6 +144,7 @@ static void pipelineFinish(DcsPipeline *p, const DcsPipeline::JobPtr &job, DcsSt
         std::lock_guard<std::mutex> lk(p->m);
         job->status = st;
         job->done = true;
+        (job->preRecords != nullptr ? p->lastHostWalkedDone : p->lastDeviceWalkedDone) = nowMs();
     }
     p->finished.notify_all();
 }
@@ -632,6 +635,30 @@ static void pipelineWorker(DcsPipeline *p, int id)
                 pipelineFinish(p, job, st);
                 continue;
             }
+            if (job->preRecords != nullptr && (p->flags & DCS_PIPE_PLAN_ON_DEVICE))
+            {
+                // The host pool has walked this list already (dcsDecodeStreamsInParts, the walk shared with the device): its
+                // records and stream summaries -- the very bytes the index kernel would have written -- go up behind the streams
+                // and the list joins the indexed ones.  (Pinned memory of the caller's; this worker's stream is waited for, as an
+                // indexer waits for its round, because stage B runs on another stream.)
+                DcsStatus s2 = [&]() -> DcsStatus {
+                    DcsCtx *ctx = p->ctx;
+                    HIPCHK(ctx, copyByKernel(stream, job->dRec, job->preRecords + job->preFirstRecord[0], sizeof(DcsFrameIndex) * job->totalRec, 64u));
+                    HIPCHK(ctx, copyByKernel(stream, job->dInfo, job->preInfos, job->infoBytes, 1u));
+                    HIPCHK(ctx, streamWait(ctx, stream));
+                    return DCS_OK;
+                }();
+                const double t1 = nowMs();
+                {
+                    std::lock_guard<std::mutex> lk(p->m);
+                    job->dRecords = static_cast<const DcsFrameIndex *>(job->dRec);
+                    job->status = s2;
+                    job->tQueuedForIndex = job->tIndexStart = job->tIndexed = t1;
+                    p->indexed.push_back(job);
+                }
+                p->work.notify_all();
+                continue;
+            }
             {
                 std::lock_guard<std::mutex> lk(p->m);
                 job->tQueuedForIndex = nowMs();
@@ -704,8 +731,13 @@ static DcsStatus pipelineCreate(DcsCtx *ctx, int depth, uint32_t flags, DcsPipel
     // inside the HIP runtime: measured with 32 lists in flight on 16 CPUs, 4 to 6 workers 1.65-1.95 ms per list at 7-9 CPU-ms,
     // 10 workers 1.8-2.4, 20 workers 2.1-2.5 at 18-22 CPU-ms (tools/pipe_trace.py, round 2).  Planner on the device too: a
     // worker spends a third of a millisecond on a list and then sleeps until its PCM is down; 0.70-0.77 ms per list with 6,
-    // 8, 12, 16 or 24 of them (round 3: the link is what bounds it)
-    int nWorkers = (flags & DCS_PIPE_PLAN_ON_DEVICE)  ? std::min(depth, 8)
+    // 8, 12, 16 or 24 of them (round 3: the link is what bounds it).  Round 5 (tools/thread_cpu.py, three interleaved rounds of 1 500
+    // lists): TWO of them 0.59-0.63 ms per list at 0.43-0.55 CPU-ms, three 0.65 / 0.67, eight 0.63-0.66 / 0.74-0.87 -- every worker has a
+    // HIP stream of its own, the runtime spreads a process's streams over GPU_MAX_HW_QUEUES (8) hardware queues per device, and once
+    // streams share queues a thread of the RUNTIME orders them on the host: two pipelines with twelve streams each on one device (two
+    // contexts of a node, or two ranks, sharing a card) kept that thread 65 % busy, 0.45 CPU-ms per list; with two stage-B workers a
+    // pipeline has six streams.  (The context's own pipeline, which serves one waiting caller's parts side by side, keeps eight.)
+    int nWorkers = (flags & DCS_PIPE_PLAN_ON_DEVICE)  ? std::min(depth, (flags & kPipeLatency) ? 8 : 2)
                  : (flags & DCS_PIPE_PACK_ON_DEVICE)  ? std::min(depth, std::max(4, dcs_host_threads() / 3))
                  : (flags & DCS_PIPE_INDEX_ON_DEVICE) ? std::min(depth, dcs_host_threads() + 4) : depth;
     if (const char *w = getenv("DCS_PIPE_WORKERS"))
@@ -758,6 +790,7 @@ static DcsStatus pipelineCreate(DcsCtx *ctx, int depth, uint32_t flags, DcsPipel
 
 extern "C" void dcs_pipeline_destroy(DcsPipeline *p)
 {
+    printWaitStats("dcs_pipeline_destroy");
     if (p == nullptr)
         return;
     {
@@ -957,16 +990,83 @@ DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint
         }
     };
     const int idxThreads = 0;        // (all of the pool: leaving a quarter of the CPUs to the workers was measured, 6.8 against 5.8 ms)
+    void *sharedPinned = nullptr;
+    size_t sharedPinnedBytes = 0;
+    uint32_t hostParts = 0;
+    double tCall0 = nowMs();
     if (onDevice)
     {
-        // every part at once: index walk, planner, packer and decode on the device, the workers copy the PCM out
-        for (uint32_t r = 0 ; r < kParts && st == DCS_OK ; ++r)
+        // The walk SHARED between host and device (dcs_ctx_set_large_list_path 2, the default; round 5).  The index kernel takes as
+        // long as its longest stream whatever the number of streams (a lone wavefront per stream: 1.9 ms for 256 frames), and until
+        // it is through nothing of the list can be decoded; the host pool walks a stream fourteen times faster and delivers the
+        // list's FIRST parts while the device walks the last ones: their planner, packer, decode and -- what counts -- their PCM's
+        // way down run under the index kernel.  The host's records are the index kernel's, byte for byte (tests/test_gpu_parity.py),
+        // so they go up and take its place (pipelineWorker).  How many parts the host takes follows what was measured: the side
+        // that finished later in the last call gets less in the next.
+        hostParts = ctx->largeListShared ? static_cast<uint32_t>(std::max(0, std::min(static_cast<int>(kParts) - 1, ctx->sharedHostParts))) : 0u;
+        const uint32_t hostStreams = cut[hostParts];
+        const uint64_t hostRecs = first[hostStreams] - static_cast<uint64_t>(hostStreams) * extraFrames;
+        DcsFrameIndex *hRecs = nullptr;
+        DcsStreamInfo *hInfos = nullptr;
+        if (hostParts != 0)
+        {
+            sharedPinnedBytes = sizeof(DcsFrameIndex) * hostRecs + sizeof(DcsStreamInfo) * hostStreams + 64;
+            if (cacheAlloc(ctx, true, &sharedPinned, sharedPinnedBytes) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                sharedPinned = nullptr;
+                hostParts = 0;
+            }
+            else
+            {
+                hRecs = static_cast<DcsFrameIndex *>(sharedPinned);
+                hInfos = reinterpret_cast<DcsStreamInfo *>(static_cast<uint8_t *>(sharedPinned) + ((sizeof(DcsFrameIndex) * hostRecs + 15) & ~size_t(15)));
+                firstRecord.resize(hostStreams);
+                uint64_t nRec = 0;
+                for (uint32_t k = 0 ; k < hostStreams ; ++k)
+                {
+                    firstRecord[k] = nRec;
+                    nRec += frames[k] - extraFrames;
+                }
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(ctx->internalPipe->m);
+            ctx->internalPipe->roundGather = kParts - hostParts;           // (the index round waits until its parts are all there)
+            ctx->internalPipe->lastHostWalkedDone = ctx->internalPipe->lastDeviceWalkedDone = 0;
+        }
+        tCall0 = nowMs();
+        // the device's parts first: index walk, planner, packer and decode on the device, the workers copy the PCM out
+        for (uint32_t r = hostParts ; r < kParts && st == DCS_OK ; ++r)
         {
             const uint64_t f0 = first[cut[r]];
             st = pipelineSubmit(ctx->internalPipe, streams + cut[r], cut[r + 1] - cut[r], extraFrames,
                                 pcmOut + f0 * DCS_FRAME_SAMPLES, errOut ? errOut + f0 : nullptr);
             if (st == DCS_OK)
                 submitted.fetch_add(1);
+        }
+        if (hostParts != 0 && st == DCS_OK)
+        {
+            // ... and the host's: a part goes to the pipeline the moment the pool has walked the last of its streams
+            const std::function<void(uint32_t)> walked = [&, hRecs, hInfos](uint32_t k) {
+                const uint32_t r = partOf[k];
+                if (left[r].fetch_sub(1) != 1)
+                    return;
+                const uint64_t f0 = first[cut[r]];
+                const DcsStatus s1 = pipelineSubmit(ctx->internalPipe, streams + cut[r], cut[r + 1] - cut[r], extraFrames,
+                                                    pcmOut + f0 * DCS_FRAME_SAMPLES, errOut ? errOut + f0 : nullptr,
+                                                    hRecs, firstRecord.data() + cut[r], hInfos + cut[r]);
+                if (s1 == DCS_OK)
+                    submitted.fetch_add(1);
+                else
+                {
+                    int expected = DCS_OK;
+                    submitError.compare_exchange_strong(expected, s1);
+                }
+            };
+            st = dcsIndexStreamsNotify(streams, hostStreams, idxThreads, hRecs, firstRecord.data(), hInfos, &walked);
+            if (st == DCS_OK)
+                st = static_cast<DcsStatus>(submitError.load());
         }
     }
     else
@@ -983,6 +1083,28 @@ DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint
         if (st == DCS_OK)
             st = s1;
     }
+    if (onDevice && hostParts != 0)
+    {
+        // who finished later?  (the pool's parts are submitted as they are walked, so both times are of lists of this call)
+        double tHost, tDev;
+        {
+            std::lock_guard<std::mutex> lk(ctx->internalPipe->m);
+            tHost = ctx->internalPipe->lastHostWalkedDone - tCall0;
+            tDev = ctx->internalPipe->lastDeviceWalkedDone - tCall0;
+        }
+        if (st == DCS_OK && tHost > 0 && tDev > 0)
+        {
+            if (tHost > tDev + 0.15 && ctx->sharedHostParts > 1)
+                ctx->sharedHostParts -= 1;
+            else if (tDev > tHost + 0.15 && ctx->sharedHostParts < static_cast<int>(kParts) - 1)
+                ctx->sharedHostParts += 1;
+        }
+        if (getenv("DCS_PIPE_TRACE"))
+            fprintf(stderr, "decode in parts: %u of %u parts walked by the host pool, done at %.2f ms; the device's at %.2f ms; next call %d\n",
+                    hostParts, kParts, tHost, tDev, ctx->sharedHostParts);
+    }
+    if (sharedPinned != nullptr)
+        cacheFree(ctx, true, sharedPinned, sharedPinnedBytes);
     if (getenv("DCS_PIPE_TRACE"))
         fprintf(stderr, "decode in parts: index %.2f ms, parts %.2f ms\n", tI1 - tI0, nowMs() - tI1);
     if (frameOffsets != nullptr)

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <algorithm>
 #include <mutex>
+#include <atomic>
 #include <unordered_set>
 #include <unordered_map>
 #include "dcs_common.h"
@@ -33,6 +34,8 @@ struct DcsCtx
     bool xcdRanges = false;             // batches of this context: chain order, launched in XCD ranges (dcs_ctx_set_concurrent_batches)
     bool keepAllTails = false;          // resident batches store EVERY frame's tail (dcs_ctx_set_batch_tails); default: the last frame of every chain
     bool largeListOnDevice = true;      // dcs_decode_streams on a large list: index walk, planner and packer on the device (dcs_ctx_set_large_list_path)
+    bool largeListShared = true;        // ... with the host pool walking the first parts of the list next to the device (mode 2, the default)
+    int sharedHostParts = 5;            // how many of the eight parts the host walks; follows the measured finish times from call to call
     std::mutex cacheMutex;              // the buffer cache is shared by the pipeline's worker threads
     struct DcsPipeline *internalPipe = nullptr;     // dcs_decode_streams takes large lists through it in parts (dcs_pipeline.hip.h)
     int numCUs = 256;
@@ -195,6 +198,23 @@ static thread_local bool tlsXcdRanges = false;
 static thread_local bool tlsResidentBatch = false;   // dcs_batch_create: a batch that is run many times is planned twice for the shortest packages (dcsPlanChunksCapped)
 static thread_local bool tlsKeepAllTails = false;   // dcs_decode_batch with a tailsOut array: every frame's tail (the sequencer resumes from any tick)
 
+// DCS_WAIT_STATS=1: what the host's waits cost, summed over all threads, printed when a pipeline is destroyed
+static std::atomic<uint64_t> g_waitCalls{0}, g_waitPolls{0}, g_waitCpuNs{0}, g_waitWallNs{0};
+static const bool g_waitStats = getenv("DCS_WAIT_STATS") != nullptr && atoi(getenv("DCS_WAIT_STATS")) != 0;
+static uint64_t threadCpuNs()
+{
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return static_cast<uint64_t>(ts.tv_sec) * 1000000000ull + static_cast<uint64_t>(ts.tv_nsec);
+}
+static void printWaitStats(const char *who)
+{
+    if (g_waitStats)
+        fprintf(stderr, "wait stats (%s): %llu waits, %llu polls, %.1f ms of thread CPU, %.1f ms of wall time in them\n", who,
+                static_cast<unsigned long long>(g_waitCalls.load()), static_cast<unsigned long long>(g_waitPolls.load()),
+                g_waitCpuNs.load() * 1e-6, g_waitWallNs.load() * 1e-6);
+}
+
 // wait for everything enqueued on `stream`
 static hipError_t streamWait(DcsCtx *ctx, hipStream_t stream)
 {
@@ -224,14 +244,25 @@ static hipError_t streamWait(DcsCtx *ctx, hipStream_t stream)
     if (runtimeWait)
         return hipEventSynchronize(te.ev);
     const double t0 = hipchkNow();
+    const uint64_t c0 = g_waitStats ? threadCpuNs() : 0;
+    uint64_t polls = 0;
     for (;;)
     {
         e = hipEventQuery(te.ev);
+        ++polls;
         if (e != hipErrorNotReady)
+        {
+            if (g_waitStats)
+            {
+                g_waitCalls += 1; g_waitPolls += polls; g_waitCpuNs += threadCpuNs() - c0;
+                g_waitWallNs += static_cast<uint64_t>((hipchkNow() - t0) * 1000.0);
+            }
             return e;
+        }
         if (hipchkNow() - t0 > 30.0)
         {
-            timespec nap{ 0, 50000 };
+            static const long napNs = getenv("DCS_WAIT_NAP_US") != nullptr ? std::max(1, atoi(getenv("DCS_WAIT_NAP_US"))) * 1000L : 50000L;
+            timespec nap{ 0, napNs };
             nanosleep(&nap, nullptr);
         }
     }
@@ -553,16 +584,18 @@ extern "C" DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable)
     return DCS_OK;
 }
 
-extern "C" DcsStatus dcs_ctx_set_large_list_path(DcsCtx *ctx, int onDevice)
+extern "C" DcsStatus dcs_ctx_set_large_list_path(DcsCtx *ctx, int mode)
 {
-    if (ctx == nullptr)
+    if (ctx == nullptr || mode < 0 || mode > 2)
         return DCS_ERR_INVALID_ARG;
-    if (ctx->largeListOnDevice != (onDevice != 0) && ctx->internalPipe != nullptr)
+    const bool onDevice = mode != 0;
+    if (ctx->largeListOnDevice != onDevice && ctx->internalPipe != nullptr)
     {
         dcs_pipeline_destroy(ctx->internalPipe);        // (made for the other path; the next large list makes its own)
         ctx->internalPipe = nullptr;
     }
-    ctx->largeListOnDevice = onDevice != 0;
+    ctx->largeListOnDevice = onDevice;
+    ctx->largeListShared = mode == 2;
     return DCS_OK;
 }
 

@@ -229,10 +229,14 @@ DcsStatus dcs_ctx_set_frames_per_chunk(DcsCtx *ctx, int frames);
  * Same PCM either way.  Applies to batches created afterwards. */
 DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable);
 /* tuning: how dcs_decode_streams takes a LARGE list (32 768 frames and more, 32 streams and more), which it cuts into
- * eight parts that go through a pipeline of the context's own.  1 (default): index walk, planner and packer of every part
- * on the device (DCS_PIPE_ALL_ON_DEVICE; 3.8 ms for 256 x 256 frames, ~2 CPU-ms); 0: the index pass on the host's worker
- * pool with the parts following it (4.0-4.4 ms, ~45 CPU-ms on 16 threads).  Same PCM either way. */
-DcsStatus dcs_ctx_set_large_list_path(DcsCtx *ctx, int onDevice);
+ * eight parts that go through a pipeline of the context's own.  mode 1: index walk, planner and packer of every part on the
+ * device (DCS_PIPE_ALL_ON_DEVICE; 3.3 ms for 256 x 256 frames, ~2 CPU-ms).  mode 2 (default, round 5): the same, with the host's
+ * worker pool walking the list's first parts while the index kernel walks the last ones -- the kernel takes as long as its longest
+ * stream however few streams it has, the pool delivers a part every third of a millisecond, and the early parts' PCM comes
+ * down under the kernel; the records are the same bytes either way.  How many parts the pool takes follows the finish times
+ * measured in the previous call.  Costs the pool's threads for the length of the call (~20 CPU-ms).  mode 0: the whole index
+ * pass on the pool with the parts following it (4.0-4.4 ms, ~45 CPU-ms on 16 threads).  Same PCM in every mode. */
+DcsStatus dcs_ctx_set_large_list_path(DcsCtx *ctx, int mode);
 /* For a caller that runs SEVERAL resident batches on one GPU at once (batches on different streams, or several processes on one
  * card).  A decode kernel's wavefronts wait for tails other wavefronts of the same launch publish; one launch that has the chip to
  * itself cannot wait in vain, two side by side can wait for each other's places across the chip's eight XCDs until the bound

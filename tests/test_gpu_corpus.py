@@ -322,10 +322,11 @@ def test_pipeline_soak(gpu_ctx, mode):
     assert bad == 0
 
 
-@pytest.mark.parametrize("on_device", [True, False], ids=["parts-on-device", "parts-behind-host-index"])
+@pytest.mark.parametrize("on_device", [2, 1, 0], ids=["walk-shared-by-host-and-device", "parts-on-device", "parts-behind-host-index"])
 def test_one_call_on_a_large_list_goes_through_the_pipeline_in_parts(gpu_ctx, oracle, corpus, on_device):
     """dcs_decode_streams cuts a large list into eight parts that go through the context's own pipeline -- index walk,
-    planner and packer on the device (the default), or behind the host pool's index pass (dcs_ctx_set_large_list_path);
+    planner and packer on the device with the host pool walking the first parts next to the index kernel (the default),
+    everything on the device, or behind the host pool's index pass (dcs_ctx_set_large_list_path 2, 1, 0);
     same PCM, error words and frame offsets as the one-batch path, including taper frames, a damaged stream in the middle
     and a truncated one (whose part the device stages hand back to the host's)"""
     from util import corrupt
@@ -337,10 +338,17 @@ def test_one_call_on_a_large_list_goes_through_the_pipeline_in_parts(gpu_ctx, or
     streams[k] = (streams[k][0], streams[k][1][:len(streams[k][1]) // 2], streams[k][2], streams[k][3])
     gpu_ctx.set_large_list_path(on_device)
     try:
-        for _ in range(2):                                                       # (the second call finds the pipeline made)
+        # (the second call finds the pipeline made; with the walk shared, the number of parts the host takes moves from call to
+        # call -- every split must give the same PCM)
+        for _ in range(2 if on_device != 2 else 6):
             pcm, err, first = gpu_ctx.decode_streams(streams, extra_frames=2)    # > 32 768 frames: in parts
+            if on_device == 2:
+                if _ == 0:
+                    first_pcm, first_err = pcm.copy(), err.copy()
+                else:
+                    assert np.array_equal(pcm, first_pcm) and np.array_equal(err, first_err)
     finally:
-        gpu_ctx.set_large_list_path(True)
+        gpu_ctx.set_large_list_path(2)
     b = D.build_stream_batch(streams, extra_frames=2, indexer=D.index_streams)
     want, werr = gpu_ctx.decode_batch(b["blob"], b["srcs"], b["jobs"])           # one batch, one launch
     assert np.array_equal(first, b["first_job"])

@@ -123,12 +123,12 @@ while time.time() - t0 < budget:
         except Exception as e:
             bwant = None
         if bwant is not None:
-            for on_device in (True, False):
+            for on_device in (2, 1, 0):
                 ctx.set_large_list_path(on_device)
                 pcm, err, _ = ctx.decode_streams(big, extra_frames=2)
                 if pcm.shape != bwant.shape or not np.array_equal(pcm, bwant):
-                    print("MISMATCH (large list, parts %s) seed %d" % ("on the device" if on_device else "behind the host index", seed)); sys.exit(1)
-            ctx.set_large_list_path(True)
+                    print("MISMATCH (large list, parts %s) seed %d" % (("behind the host index", "on the device", "walk shared by host and device")[on_device], seed)); sys.exit(1)
+            ctx.set_large_list_path(2)
             large += 1
     seed += 1
     if time.time() - t_said > 30:               # (a line now and then: a silent command is taken to be hung)
@@ -136,5 +136,5 @@ while time.time() - t0 < budget:
         print("  ... %d lists, %d mixes, %.0f s" % (lists, mixes, t_said - t0), flush=True)
 for pipe in pipes:
     pipe.close()
-print("fuzz: %d lists (%d of them also through the pipeline's four modes), %d large lists through dcs_decode_streams' two paths and %d multi-channel mixes (%d frames x 3 kernel variants) in %.0f s, seeds %d..%d, all bit-exact; streams by layout: %s" %
+print("fuzz: %d lists (%d of them also through the pipeline's four modes), %d large lists through dcs_decode_streams' three paths and %d multi-channel mixes (%d frames x 3 kernel variants) in %.0f s, seeds %d..%d, all bit-exact; streams by layout: %s" %
       (lists, piped, large, mixes, frames, time.time() - t0, seed0, seed - 1, {FORMAT_NAMES[f]: n for f, n in by_fmt.items()}))
