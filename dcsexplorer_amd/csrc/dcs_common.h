@@ -223,47 +223,36 @@ constexpr bool dcsMid15(int format, int bpl, int nb16, uint32_t midBits)
 #endif
 
 // Chunk packages.  Everything unpack round 0 of a chunk needs, gathered once per batch by the host packer
-// (dcsBuildPackages, dcs_plan.cpp) into one block at a fixed stride, so that a wavefront requests ALL of it at its first instruction (no load depends on
-// another load):  slots [fpw] (32 B) | descriptor heads [fpw] (first 40 bytes of DcsSrcDesc, padded to 48) |
-// stream headers [fpw] (16 B, already aligned; a 1-byte header zero-extended) | the split record of every lane [64]
-// (8 B; zero for a frame's first lane; the lane's first band in bits 12..15 of its state word, bit 15 of bitDelta: no
-// bands) | the image of the bit pool (runs placed, dwords in bit order).
+// (dcsBuildPackages, dcs_plan.cpp) or the device packer (dcsPackKernel) into one block at a fixed stride, so that a wavefront
+// requests ALL of it at its first instruction (no load depends on another load).  Round 5 layout (a wavefront reads its whole
+// package, so every byte of it counts as HBM traffic):
+//   [0, fpw x 80)   per slot five 16-byte pieces: the slot (DcsSlot bytes 0..15: job, prevSlot | flags | nSrc | shiftXform,
+//                   firstSrc, prevJob) | descriptor head bytes 0..15 | 16..31 | 32..39 followed by poolOff (u16), bpl (u8)
+//                   and five spare bytes | the stream header (16 B, a 1-byte header zero-extended)
+//   [fpw x 80, ..)  the split record of every lane [64]: 8 bytes (zero for a frame's first lane; the lane's first band in bits
+//                   12..15 of its state word, bit 15 of bitDelta: no bands) -- or, when every source of the batch is a 1994+
+//                   frame, 4 bytes: bitDelta | state << 16 (those layouts carry nothing in prv / prvDelta but band 15's middle,
+//                   which the packers fold into the two halves)
+//   [dcsPkgOffPool, + imgDw x 4)  the image of the bit pool (runs placed, dwords in bit order), as long as the batch's fullest
+//                   chunk needs, a multiple of 128 bytes (a HOST-planned batch; one planned on the device has the pool's capacity:
+//                   its stride would have to come out of device memory, a dependent load in front of the package loads)
+// The layout word: image dwords | DCS_PKG_SPLIT4; it travels to the kernel in bits 16..31 of its flags.
 #ifdef __cplusplus
-static inline
+#define DCS_PKG_SLOT_BYTES 80u
+#define DCS_PKG_SPLIT4     0x8000u
 #ifdef __HIPCC__
-__host__ __device__
+#define DCS_HD __host__ __device__
+#else
+#define DCS_HD
 #endif
-constexpr uint32_t dcsPkgOffDesc(int fpw) { return static_cast<uint32_t>(fpw) * 32u; }
-static inline
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-constexpr uint32_t dcsPkgOffHdr(int fpw) { return static_cast<uint32_t>(fpw) * 80u; }
-static inline
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-constexpr uint32_t dcsPkgOffSplit(int fpw) { return static_cast<uint32_t>(fpw) * 96u; }
-static inline
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-constexpr uint32_t dcsPkgOffPool(int fpw) { return static_cast<uint32_t>(fpw) * 96u + 512u; }
-static inline
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-constexpr uint32_t dcsPkgBytes(int fpw) { return dcsPkgOffPool(fpw) + dcsPoolCapacity(fpw) * 4u; }
-// Round 5: the pool image of a HOST-planned batch is only as long as the batch's fullest chunk needs (imgDw dwords, a multiple
-// of 32 = 128 bytes, so that every package still starts on a cache line): the typical chunk fills little more than half of the
-// pool's capacity, and a wavefront reads its whole package.  The packages then lie at dcsPkgStride(fpw, imgDw); the kernel gets
-// imgDw in its flags word (DCS_BATCH_IMG_SHIFT) and clears the rest of the LDS pool itself.  Batches planned on the device keep the
-// full image (the stride would have to come out of device memory: a dependent load in front of the package loads).
-static inline
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-constexpr uint32_t dcsPkgStride(int fpw, uint32_t imgDw) { return dcsPkgOffPool(fpw) + imgDw * 4u; }
+static inline DCS_HD constexpr uint32_t dcsPkgImgDw(uint32_t layout) { return layout & 0x7FFFu; }
+static inline DCS_HD constexpr uint32_t dcsPkgSplitBytes(uint32_t layout) { return (layout & DCS_PKG_SPLIT4) ? 4u : 8u; }
+static inline DCS_HD constexpr uint32_t dcsPkgOffSplit(int fpw) { return static_cast<uint32_t>(fpw) * DCS_PKG_SLOT_BYTES; }
+static inline DCS_HD constexpr uint32_t dcsPkgOffPool(int fpw, uint32_t layout)
+{
+    return (static_cast<uint32_t>(fpw) * DCS_PKG_SLOT_BYTES + 64u * dcsPkgSplitBytes(layout) + 127u) & ~127u;
+}
+static inline DCS_HD constexpr uint32_t dcsPkgStride(int fpw, uint32_t layout) { return dcsPkgOffPool(fpw, layout) + dcsPkgImgDw(layout) * 4u; }
 #endif
 
 struct DcsKernelArgs
@@ -271,7 +260,7 @@ struct DcsKernelArgs
     const uint8_t      *blob;
     uint64_t            blobLen;        // bytes that may be read (allocation is padded beyond this)
     const DcsSrcDesc   *srcs;
-    uint8_t            *packages;       // nChunks x dcsPkgBytes(fpw), see above
+    uint8_t            *packages;       // nChunks x dcsPkgStride(fpw, layout), see above
     uint32_t            nChunks;
     uint32_t            nJobs;
     int16_t            *pcm;            // nJobs x 240
@@ -295,8 +284,8 @@ struct DcsKernelArgs
 // resident or through whatever else runs on the chip -- other decode kernels included (dcs_pipeline.hip.h: why that matters); only
 // the first workgroup of a range may wait for the last one of the range before, i.e. until that XCD is through.
 #define DCS_BATCH_XCD_RANGES 2u
-#define DCS_BATCH_IMG_SHIFT 16          // bits 16..25: dwords of pool image in every package (dcsPkgStride)
-#define DCS_BATCH_IMG_MASK  0x3FFu
+#define DCS_BATCH_IMG_SHIFT 16          // bits 16..31: the packages' layout word (image dwords | DCS_PKG_SPLIT4; dcsPkgStride)
+#define DCS_BATCH_IMG_MASK  0xFFFFu
 
 // A source as the planner and the DEVICE packer need it when the index records stay on the device (the pipeline's
 // device path): 24 bytes instead of the 160 of DcsSrcDesc.  `record` = index of the frame's DcsFrameIndex in the
@@ -385,6 +374,7 @@ DcsStatus dcsBuildPlanFromDigest(const DcsStreamRef *streams, uint32_t nStreams,
 // (depthOrder = false: the chunks stay in chain order, for launches in XCD ranges -- DCS_BATCH_XCD_RANGES)
 // dwords of pool image the packages of a plan need: the fullest chunk's runs, rounded up to 32 dwords, at most the pool's capacity
 uint32_t dcsImageDwords(const DcsSlot *slots, uint32_t nChunks, int fpw);
+bool dcsAllSources94(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs);
 // (keepAllTails: every frame's slot gets DCS_SLOT_KEEP_TAIL, else only the last frame of every chain)
 uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true,
                        int framesPerChunk = 0, bool depthOrder = true, bool keepAllTails = false);
@@ -396,7 +386,7 @@ uint32_t dcsPlanChunksCappedLite(const DcsFrameJob *jobs, uint32_t nJobs, const 
                                  int framesPerChunk, bool depthOrder, bool keepAllTails, uint32_t *imgDwOut, uint32_t places);
 uint32_t dcsPlanChunksLite(const DcsFrameJob *jobs, uint32_t nJobs, const DcsPlanSrc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true,
                            int framesPerChunk = 0, bool depthOrder = true, bool keepAllTails = false);
-// packer: out = nChunks x dcsPkgStride(fpw, imgDw) bytes (the chunk packages described above)
+// packer: out = nChunks x dcsPkgStride(fpw, layout) bytes (the chunk packages described above); layout = image dwords | DCS_PKG_SPLIT4
 void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const DcsSrcDesc *srcs,
-                      const uint8_t *blob, size_t blobLen, uint8_t *out, uint32_t imgDw);
+                      const uint8_t *blob, size_t blobLen, uint8_t *out, uint32_t layout);
 #endif

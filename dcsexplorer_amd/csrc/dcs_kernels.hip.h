@@ -1455,37 +1455,42 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     // header, this lane's split record, the pool image.  All of it is requested here, before anything else, in one
     // go; the padding wavefronts of the last workgroup read package 0 and drop out after the barrier.
     // (the packages' pool image is imgDw dwords long, as much as the batch's fullest chunk needs: flags bits 16..25, dcs_common.h)
-    const int imgDw = static_cast<int>((a.flags >> DCS_BATCH_IMG_SHIFT) & DCS_BATCH_IMG_MASK);
-    const uint8_t *pkg = a.packages + (chunk < a.nChunks ? static_cast<size_t>(chunk) * (dcsPkgOffPool(FPW) + static_cast<uint32_t>(imgDw) * 4u) : 0);
-    // The head of the package (slots, descriptor heads, headers: FPW x 96 contiguous bytes) is per-slot data: it is
+    const uint32_t layout = (a.flags >> DCS_BATCH_IMG_SHIFT) & DCS_BATCH_IMG_MASK;
+    const int imgDw = static_cast<int>(dcsPkgImgDw(layout));
+    const bool split4 = (layout & DCS_PKG_SPLIT4) != 0;     // every source a 1994+ frame: 4-byte split records
+    const uint32_t offPool = split4 ? dcsPkgOffPool(FPW, DCS_PKG_SPLIT4) : dcsPkgOffPool(FPW, 0);
+    const uint8_t *pkg = a.packages + (chunk < a.nChunks ? static_cast<size_t>(chunk) * (offPool + static_cast<uint32_t>(imgDw) * 4u) : 0);
+    // The head of the package (per slot 80 bytes: slot, descriptor head, header) is per-slot data: it is
     // fetched ONCE per wavefront, 16 bytes per lane, and handed to the lanes through LDS below (fewer vector-memory
     // instructions in the burst at the start of a kernel, where every wavefront of the chip issues its loads at once).
-    constexpr int kHeadVec = FPW * 6, kHeadLoads = (kHeadVec + 63) / 64;
+    constexpr int kHeadVec = FPW * 5, kHeadLoads = (kHeadVec + 63) / 64;
     static_assert(kHeadLoads <= 2, "package head: two 16-byte loads per lane at most");
     uint4 phead0, phead1 = make_uint4(0, 0, 0, 0);      // (named registers: an array of two ended up in scratch memory)
     uint2 psplit;
     constexpr int kPoolPieces = (poolDwords(FPW) + 255) / 256;
     uint4 pimg[kPoolPieces];
     {
-        static_assert(sizeof(DcsSlot) == 32 && offsetof(DcsSlot, runStartDw) == 16 && offsetof(DcsSlot, hdrDw) == 24, "DcsSlot layout");
+        static_assert(sizeof(DcsSlot) == 32 && offsetof(DcsSlot, runStartDw) == 16 && offsetof(DcsSlot, hdrDw) == 24 && DCS_PKG_SLOT_BYTES == 80, "DcsSlot / package layout");
         phead0 = reinterpret_cast<const uint4 *>(pkg)[min(lane, kHeadVec - 1)];
         if (kHeadLoads > 1)
             phead1 = reinterpret_cast<const uint4 *>(pkg)[min(lane + 64, kHeadVec - 1)];
-        psplit = reinterpret_cast<const uint2 *>(pkg + dcsPkgOffSplit(FPW))[lane];
+        {
+            // (one 8-byte load either way: lane l's record lies at l x 8, or -- 4-byte records -- at l x 4, and then only its
+            // first dword is the lane's)
+            const uint2 raw = *reinterpret_cast<const uint2 *>(pkg + dcsPkgOffSplit(FPW) + static_cast<uint32_t>(lane) * (split4 ? 4u : 8u));
+            psplit = split4 ? make_uint2(raw.x & 0xFFFFu, raw.x & 0xFFFF0000u) : raw;
+        }
 #pragma unroll
         for (int t = 0 ; t < kPoolPieces ; ++t)
         {
             // (unconditional: a predicated load would make the compiler wait for every load above before the tables
             // are even requested; lanes past the image re-read its last 16 bytes and store nothing)
             const int i = min(lane * 4 + 256 * t, imgDw - 4);
-            pimg[t] = *reinterpret_cast<const uint4 *>(pkg + dcsPkgOffPool(FPW) + i * 4);
+            pimg[t] = *reinterpret_cast<const uint4 *>(pkg + offPool + i * 4);
         }
     }
     TwA W;
     loadTwA(a.tables, W);
-#ifdef DCS_EXP_PREFETCH
-    uint32_t pfWord = 0;
-#endif
 
     // ---- stage the shared tables (whole workgroup), clear this wavefront's tile ------------------------
     {
@@ -1499,17 +1504,6 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
         uint4 pairPiece = make_uint4(0, 0, 0, 0);
         if (stagePairs)
             pairPiece = reinterpret_cast<const uint4 *>(a.tables->pair93a)[threadIdx.x];
-#ifdef DCS_EXP_PREFETCH
-        // experiment: touch the package of the chunk that will take this wavefront's place (DCS_EXP_PREFETCH chunks on: the
-        // chip holds that many wavefronts of this kernel, and workgroup w + 1024 runs on the XCD of workgroup w), one dword in
-        // every 128-byte line, so that the next generation finds its package in this XCD's L2.  The result is never used.
-        {
-            const uint32_t ahead = min(chunk + static_cast<uint32_t>(DCS_EXP_PREFETCH), a.nChunks - 1u);
-            const uint32_t stride = dcsPkgOffPool(FPW) + static_cast<uint32_t>(imgDw) * 4u;
-            const uint8_t *nx = a.packages + static_cast<size_t>(ahead) * stride + min(static_cast<uint32_t>(lane) * 128u, stride - 4u);
-            asm volatile("global_load_dword %0, %1, off" : "=v"(pfWord) : "v"(nx) : "memory");
-        }
-#endif
         uint4 *tile = reinterpret_cast<uint4 *>(L.base);
 #ifndef DCS_CLEAR_FIRST_MAX_FPW
 #define DCS_CLEAR_FIRST_MAX_FPW 8
@@ -1529,9 +1523,6 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
                 tile[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();                                // the only workgroup barrier: tables are in place
-#ifdef DCS_EXP_PREFETCH
-    asm volatile("s_waitcnt vmcnt(0)" :: "v"(pfWord) : "memory");      // (the youngest load; its register is free from here on)
-#endif
     if (chunk >= a.nChunks)
         return;                                     // padding wavefront of the last workgroup
 
@@ -1549,18 +1540,18 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
         if (kHeadLoads > 1 && lane + 64 < kHeadVec)
             scratch[lane + 64] = phead1;
         waveSync();
-        const uint4 s0 = scratch[2 * s], s1 = scratch[2 * s + 1];
-        const uint4 *dp = scratch + FPW * 2 + 3 * s;
-        pd0 = dp[0]; pd1 = dp[1];
-        const uint4 d2v = dp[2];
+        const uint4 *sp5 = scratch + 5 * s;             // (dcs_common.h: five pieces per slot)
+        const uint4 s0 = sp5[0];
+        pd0 = sp5[1]; pd1 = sp5[2];
+        const uint4 d2v = sp5[3];
         pd2 = make_uint2(d2v.x, d2v.y);
-        phdr = scratch[FPW * 5 + s];
+        phdr = sp5[4];
         waveSync();
         slot.job = s0.x;
         slot.prevSlot = s0.y & 0xFFu; slot.flags = (s0.y >> 8) & 0xFFu; slot.nSrc = (s0.y >> 16) & 0xFFu; slot.shiftXform = s0.y >> 24;
         slot.firstSrc = s0.z; slot.prevJob = s0.w;
-        slot.poolOff = s1.y >> 16;
-        slot.bpl = (s1.w >> 8) & 0xFFu;
+        slot.poolOff = d2v.z & 0xFFFFu;
+        slot.bpl = (d2v.z >> 16) & 0xFFu;
     }
 
     // the lane's transform constants for the chunk's first frame (the whole chunk, normally): requested now, needed in

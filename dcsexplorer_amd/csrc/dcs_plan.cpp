@@ -396,6 +396,18 @@ uint32_t dcsPlanChunksLite(const DcsFrameJob *jobs, uint32_t nJobs, const DcsPla
     return planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk, depthOrder, keepAllTails, 0);
 }
 
+// every source the jobs draw on is a 1994+ frame (the packages then carry 4-byte split records, dcs_common.h)
+bool dcsAllSources94(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs)
+{
+    if (srcs == nullptr)
+        return false;
+    for (uint32_t j = 0 ; j < nJobs ; ++j)
+        for (uint32_t r = 0 ; r < jobs[j].nSrc ; ++r)
+            if (srcs[jobs[j].firstSrc + r].format < DCS_FMT_94_T0)
+                return false;
+    return true;
+}
+
 uint32_t dcsImageDwords(const DcsSlot *slots, uint32_t nChunks, int fpw)
 {
     uint32_t use = 0;
@@ -444,25 +456,29 @@ extern "C" DcsStatus dcs_plan_chunks(const DcsFrameJob *jobs, uint32_t nJobs, co
 // (big-endian).  A layout change only; nothing is decoded.  The device then reads nothing else in round 0.
 // ---------------------------------------------------------------------------------------------------------
 static void packChunks(const DcsSlot *slots, uint32_t c0, uint32_t c1, int fpw, const DcsSrcDesc *srcs,
-                       const uint8_t *blob, size_t blobLen, uint8_t *out, uint32_t imgDw)
+                       const uint8_t *blob, size_t blobLen, uint8_t *out, uint32_t layout)
 {
-    const uint32_t pkgBytes = dcsPkgStride(fpw, imgDw);
-    const uint32_t poolCap = imgDw;
+    const uint32_t pkgBytes = dcsPkgStride(fpw, layout);
+    const uint32_t poolCap = dcsPkgImgDw(layout);
+    const bool split4 = (layout & DCS_PKG_SPLIT4) != 0;
     const int sub = 64 / fpw;
     for (uint32_t c = c0 ; c < c1 ; ++c)
     {
         uint8_t *pkg = out + static_cast<size_t>(c) * pkgBytes;
         const DcsSlot *cs = slots + static_cast<size_t>(c) * static_cast<size_t>(fpw);
         memset(pkg, 0, pkgBytes);
-        memcpy(pkg, cs, static_cast<size_t>(fpw) * sizeof(DcsSlot));
         for (int s = 0 ; s < fpw ; ++s)
         {
             const DcsSlot &sl = cs[s];
+            uint8_t *ps = pkg + static_cast<size_t>(s) * DCS_PKG_SLOT_BYTES;
+            memcpy(ps, &sl, 16);                            // job, prevSlot | flags | nSrc | shiftXform, firstSrc, prevJob
+            memcpy(ps + 56, &sl.poolOff, 2);
+            ps[58] = sl.bpl;
             if ((sl.flags & DCS_SLOT_EMPTY) || sl.nSrc == 0 || srcs == nullptr)
                 continue;
             const DcsSrcDesc &sd = srcs[sl.firstSrc];
-            memcpy(pkg + dcsPkgOffDesc(fpw) + static_cast<size_t>(s) * 48, &sd, 40);
-            uint8_t *hd = pkg + dcsPkgOffHdr(fpw) + static_cast<size_t>(s) * 16;
+            memcpy(ps + 16, &sd, 40);
+            uint8_t *hd = ps + 64;
             const size_t hOff = static_cast<size_t>(sd.streamOff) + 2;
             const size_t hLen = sd.hdrLen == 1 ? 1 : 16;
             for (size_t i = 0 ; i < hLen ; ++i)
@@ -501,10 +517,16 @@ static void packChunks(const DcsSlot *slots, uint32_t c0, uint32_t c1, int fpw, 
                     rec = sd.idx.split[base[q] - 1];
                     rec.state = static_cast<uint16_t>((rec.state & 0x0FFFu) | (static_cast<unsigned>(base[q]) << 12));
                 }
-                memcpy(pkg + dcsPkgOffSplit(fpw) + static_cast<size_t>(s + q * fpw) * 8, &rec, 8);
+                if (split4)
+                {
+                    const uint32_t w = static_cast<uint32_t>(rec.bitDelta) | (static_cast<uint32_t>(rec.state) << 16);
+                    memcpy(pkg + dcsPkgOffSplit(fpw) + static_cast<size_t>(s + q * fpw) * 4, &w, 4);
+                }
+                else
+                    memcpy(pkg + dcsPkgOffSplit(fpw) + static_cast<size_t>(s + q * fpw) * 8, &rec, 8);
             }
         }
-        uint8_t *img = pkg + dcsPkgOffPool(fpw);
+        uint8_t *img = pkg + dcsPkgOffPool(fpw, layout);
         for (int k = 0 ; k < fpw ; ++k)
         {
             const uint32_t n = cs[k].runNDw, st = cs[k].runStartDw, o = cs[k].runPoolOff;
@@ -531,7 +553,7 @@ static void packChunks(const DcsSlot *slots, uint32_t c0, uint32_t c1, int fpw, 
 }
 
 void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const DcsSrcDesc *srcs,
-                      const uint8_t *blob, size_t blobLen, uint8_t *out, uint32_t imgDw)
+                      const uint8_t *blob, size_t blobLen, uint8_t *out, uint32_t layout)
 {
     // (measured on the 2 x EPYC host of an MI355X box, 65 536 frames: 1 thread 2.5 ms, 4 threads 1.2 ms, 8 and 16
     // threads no faster -- the work is memory traffic -- and they slow the single-threaded planner of the next batch down)
@@ -539,7 +561,7 @@ void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const Dcs
     if (nt > 4) nt = 4;
     if (nt <= 1)
     {
-        packChunks(slots, 0, nChunks, fpw, srcs, blob, blobLen, out, imgDw);
+        packChunks(slots, 0, nChunks, fpw, srcs, blob, blobLen, out, layout);
         return;
     }
     std::vector<std::thread> th;
@@ -548,7 +570,7 @@ void dcsBuildPackages(const DcsSlot *slots, uint32_t nChunks, int fpw, const Dcs
     {
         const uint32_t c0 = t * per, c1 = c0 + per < nChunks ? c0 + per : nChunks;
         if (c0 < c1)
-            th.emplace_back(packChunks, slots, c0, c1, fpw, srcs, blob, blobLen, out, imgDw);
+            th.emplace_back(packChunks, slots, c0, c1, fpw, srcs, blob, blobLen, out, layout);
     }
     for (std::thread &t : th)
         t.join();
@@ -565,12 +587,13 @@ extern "C" DcsStatus dcs_pack_chunks(const DcsFrameJob *jobs, uint32_t nJobs, co
     uint32_t imgDw = 0;
     const uint32_t nChunks = dcsPlanChunksCapped(jobs, nJobs, srcs, fpw, slots, true, 0, true, false, &imgDw, DCS_MI355X_WAVE_PLACES);
     *nChunksOut = nChunks;
+    const uint32_t layout = imgDw | (dcsAllSources94(jobs, nJobs, srcs) ? DCS_PKG_SPLIT4 : 0u);
     if (packageBytesOut != nullptr)
-        *packageBytesOut = dcsPkgStride(fpw, imgDw);
+        *packageBytesOut = dcsPkgStride(fpw, layout);
     if (out == nullptr)
         return DCS_OK;
-    if (cap < static_cast<size_t>(nChunks) * dcsPkgStride(fpw, imgDw))
+    if (cap < static_cast<size_t>(nChunks) * dcsPkgStride(fpw, layout))
         return DCS_ERR_CAPACITY;
-    dcsBuildPackages(slots.data(), nChunks, fpw, srcs, blob, blobLen, out, imgDw);
+    dcsBuildPackages(slots.data(), nChunks, fpw, srcs, blob, blobLen, out, layout);
     return DCS_OK;
 }

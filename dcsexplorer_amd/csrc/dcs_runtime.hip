@@ -324,7 +324,7 @@ struct DcsBatch
     uint8_t *dPackages = nullptr;           // nChunks x dcsPkgBytes(fpw) (DcsKernelArgs.packages)
     uint32_t epoch = 0;                     // launches of this batch so far
     uint32_t flags = 0;                     // DCS_BATCH_*
-    uint32_t imgDw = 0;                     // dwords of pool image per package (0: the pool's capacity); packages at dcsPkgStride(fpw, imgDw)
+    uint32_t imgDw = 0;                     // the packages' LAYOUT word (dcs_common.h): dwords of pool image | DCS_PKG_SPLIT4; packages at dcsPkgStride(fpw, imgDw)
     size_t cap[10] = { 0 };                 // allocated bytes of the buffers above, in that order
     // packages assembled on the device: the plan and the source digests as uploaded for the pack kernel
     void *dPlanSlots = nullptr, *dPlanSrcs = nullptr, *hStage = nullptr, *dTable = nullptr;      // (dTable: the stream table of the device planner; cap[2])
@@ -609,7 +609,7 @@ extern "C" DcsStatus dcs_ctx_set_batch_tails(DcsCtx *ctx, int allFrames)
 
 extern "C" uint32_t dcs_batch_package_bytes(const DcsBatch *b)
 {
-    return b ? dcsPkgStride(b->fpw, b->imgDw != 0 ? b->imgDw : dcsPoolCapacity(b->fpw)) : 0;
+    return b ? dcsPkgStride(b->fpw, dcsPkgImgDw(b->imgDw) != 0 ? b->imgDw : (b->imgDw | dcsPoolCapacity(b->fpw))) : 0;
 }
 
 extern "C" DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t handoffTimeoutUs, int dropExports)
@@ -680,7 +680,7 @@ static DcsKernelArgs kernelArgs(const DcsBatch *b)
     args.debug = b->dDebug;
     args.handoff = b->dHandoff;
     args.epoch = b->epoch;
-    args.flags = b->flags | ((b->imgDw != 0 ? b->imgDw : dcsPoolCapacity(b->fpw)) << DCS_BATCH_IMG_SHIFT);
+    args.flags = b->flags | ((dcsPkgImgDw(b->imgDw) != 0 ? b->imgDw : (b->imgDw | dcsPoolCapacity(b->fpw))) << DCS_BATCH_IMG_SHIFT);
     args.timeoutTicks = b->ctx->handoffTimeoutTicks;
     return args;
 }
@@ -791,6 +791,8 @@ static DcsStatus createBatch(DcsCtx *ctx,
         b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges, allTails);
         b->imgDw = fullImage ? dcsPoolCapacity(b->fpw) : dcsImageDwords(slots.data(), b->nChunks, b->fpw);
     }
+    if (!fullImage && dcsAllSources94(jobs, nJobs, srcs))
+        b->imgDw |= DCS_PKG_SPLIT4;             // (the layout word: every source a 1994+ frame -> 4-byte split records)
     if (ranges && handoff)
         b->flags |= DCS_BATCH_XCD_RANGES;
     if (ctx->dropExports)
@@ -887,26 +889,29 @@ namespace {
 template <int FPW>
 __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint32_t nChunks, const DcsPlanSrc *srcs,
                                                       const DcsFrameIndex *records, const uint8_t *blob, uint64_t blobLen,
-                                                      uint8_t *packages, uint32_t imgDw)
+                                                      uint8_t *packages, uint32_t layout)
 {
     const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = static_cast<int>(threadIdx.x & 63);
     if (chunk >= nChunks)
         return;
-    uint8_t *pkg = packages + static_cast<size_t>(chunk) * dcsPkgStride(FPW, imgDw);
+    uint8_t *pkg = packages + static_cast<size_t>(chunk) * dcsPkgStride(FPW, layout);
     const DcsSlot *cs = slots + static_cast<size_t>(chunk) * FPW;
-    // the slots, 16 bytes per lane
-    if (lane < FPW * 2)
-        reinterpret_cast<uint4 *>(pkg)[lane] = reinterpret_cast<const uint4 *>(cs)[lane];
-    // descriptor head (the first 40 bytes of what DcsSrcDesc would be) and stream header of slot `lane`
+    const uint32_t imgDw = dcsPkgImgDw(layout);
+    const bool split4 = (layout & DCS_PKG_SPLIT4) != 0;
+    // slot `lane`: its first 16 bytes, the descriptor head (the first 40 bytes of what DcsSrcDesc would be) with poolOff and bpl
+    // behind it, the stream header (dcs_common.h: five 16-byte pieces per slot)
     if (lane < FPW)
     {
         const DcsSlot sl = cs[lane];
+        uint8_t *ps = pkg + static_cast<size_t>(lane) * DCS_PKG_SLOT_BYTES;
+        reinterpret_cast<uint4 *>(ps)[0] = reinterpret_cast<const uint4 *>(&cs[lane])[0];
+        reinterpret_cast<uint32_t *>(ps)[14] = static_cast<uint32_t>(sl.poolOff) | (static_cast<uint32_t>(sl.bpl) << 16);
         if (!(sl.flags & DCS_SLOT_EMPTY) && sl.nSrc != 0)
         {
             const DcsPlanSrc sd = srcs[sl.firstSrc];
             const uint32_t *rec = reinterpret_cast<const uint32_t *>(&records[sd.record]);
-            uint32_t *d = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffDesc(FPW) + static_cast<size_t>(lane) * 48);
+            uint32_t *d = reinterpret_cast<uint32_t *>(ps + 16);
             d[0] = static_cast<uint32_t>(sd.streamOff);
             d[1] = static_cast<uint32_t>(sd.streamOff >> 32);
             d[2] = static_cast<uint32_t>(sd.mixMul) | (static_cast<uint32_t>(sd.format) << 16) | (static_cast<uint32_t>(sd.hdrLen) << 24);
@@ -918,7 +923,7 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
             for (uint32_t i = 0 ; i < hLen ; ++i)
                 if (hOff + i < blobLen)
                     h[i >> 2] |= static_cast<uint32_t>(blob[hOff + i]) << (8 * (i & 3));
-            uint32_t *hd = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffHdr(FPW) + static_cast<size_t>(lane) * 16);
+            uint32_t *hd = reinterpret_cast<uint32_t *>(ps + 64);
             hd[0] = h[0]; hd[1] = h[1]; hd[2] = h[2]; hd[3] = h[3];
         }
     }
@@ -957,12 +962,17 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
                 r0 = sp[0];
                 r1 = (sp[1] & 0x0FFFFFFFu) | (static_cast<uint32_t>(base) << 28);
             }
-            uint32_t *dst = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffSplit(FPW) + static_cast<size_t>(lane) * 8);
-            dst[0] = r0; dst[1] = r1;
+            if (split4)
+                reinterpret_cast<uint32_t *>(pkg + dcsPkgOffSplit(FPW))[lane] = (r0 & 0xFFFFu) | (r1 & 0xFFFF0000u);
+            else
+            {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffSplit(FPW) + static_cast<size_t>(lane) * 8);
+                dst[0] = r0; dst[1] = r1;
+            }
         }
     }
     // the image of the bit pool: the chunk's runs of stream dwords, in bit order
-    uint32_t *img = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffPool(FPW));
+    uint32_t *img = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffPool(FPW, layout));
     for (int k = 0 ; k < FPW ; ++k)
     {
         const uint32_t n = cs[k].runNDw, st = cs[k].runStartDw, o = cs[k].runPoolOff;
@@ -1152,6 +1162,13 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
     const bool ranges = tlsXcdRanges || ctx->xcdRanges;
     b->nChunks = dcsPlanChunksLite(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges);
     b->imgDw = dcsImageDwords(slots.data(), b->nChunks, b->fpw);
+    {
+        bool all94 = nSrcs != 0;
+        for (uint32_t k = 0 ; k < nSrcs && all94 ; ++k)
+            all94 = srcs[k].format >= DCS_FMT_94_T0;
+        if (all94)
+            b->imgDw |= DCS_PKG_SPLIT4;
+    }
     if (ranges && handoff)
         b->flags |= DCS_BATCH_XCD_RANGES;
     if (ctx->dropExports)
@@ -1233,7 +1250,7 @@ static DcsStatus queuePlanAndPack(DcsBatch *b, uint32_t nStreams, uint32_t extra
     // packages, error words and hand-off words cleared by ONE kernel (three hipMemsetAsync were three dispatches in a chain of
     // ten per list; epoch 0 = never written; the planner's flag word lies behind the last chunk's hand-off words)
     {
-        const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw), errBytes = sizeof(uint32_t) * nJobs, hoBytes = b->cap[8];
+        const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgStride(b->fpw, b->imgDw), errBytes = sizeof(uint32_t) * nJobs, hoBytes = b->cap[8];
         const size_t total16 = pkgBytes / 16 + (errBytes + 15) / 16 + hoBytes / 16;
         const unsigned blocks = static_cast<unsigned>(std::min<size_t>((total16 + 255) / 256, 2048));
         hipLaunchKernelGGL(dcsClear3Kernel, dim3(blocks), dim3(256), 0, b->stream, reinterpret_cast<uint4 *>(b->dPackages), pkgBytes / 16,
@@ -1299,8 +1316,8 @@ static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *ta
         b->planFpc = static_cast<uint32_t>(fpc >= 1 && fpc < b->fpw ? fpc : b->fpw);
     }
     b->nChunks = (nJobs + b->planFpc - 1) / b->planFpc;
-    b->imgDw = dcsPoolCapacity(b->fpw);         // (a plan made on the device: the full image, dcs_common.h)
-    const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgBytes(b->fpw);
+    b->imgDw = dcsPoolCapacity(b->fpw) | (all94 ? DCS_PKG_SPLIT4 : 0u);     // (a plan made on the device: the full image, dcs_common.h)
+    const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgStride(b->fpw, b->imgDw);
     void *dTable = nullptr;
     const size_t tableBytes = sizeof(DcsPlanStream) * nStreams;
     DcsStatus st = [&]() -> DcsStatus {
@@ -1378,6 +1395,8 @@ extern "C" DcsStatus dcs_pack_chunks_device(DcsCtx *ctx, const DcsFrameJob *jobs
     uint32_t imgDw = 0;
     const uint32_t nChunks = dcsPlanChunksCappedLite(jobs, nJobs, ps.data(), fpw, slots, true, 0, true, false, &imgDw, DCS_MI355X_WAVE_PLACES);
     *nChunksOut = nChunks;
+    if (dcsAllSources94(jobs, nJobs, srcs))
+        imgDw |= DCS_PKG_SPLIT4;
     if (packageBytesOut != nullptr)
         *packageBytesOut = dcsPkgStride(fpw, imgDw);
     if (out == nullptr)

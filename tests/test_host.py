@@ -202,17 +202,23 @@ def test_chunk_plan_properties(fpw, handoff):
         assert 0 < halos_interleaved <= plan.shape[0]
 
 
+@pytest.mark.parametrize("workload", ["mixed_16384", "dcs94_65536"], ids=["mixed-layouts", "all-1994+"])
 @pytest.mark.parametrize("fpw", [4, 8, 16])
-def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
-    """the host packer (what a batch uploads): slots, descriptor heads, aligned headers, per-lane split records and
-    a bit-pool image from which every frame's bits can be read back at the position its slot names"""
-    b = workloads.build("mixed_16384", n_streams=18, n_frames=29)
+def test_chunk_packages_hold_exactly_what_round_0_needs(fpw, workload):
+    """the host packer (what a batch uploads): per slot the slot word, descriptor head, pool offset and aligned header; per-lane
+    split records (4 bytes each when every source is a 1994+ frame, else 8) and a bit-pool image from which every frame's bits
+    can be read back at the position its slot names"""
+    b = workloads.build(workload, n_streams=18, n_frames=29)
     blob, srcs, jobs = bytes(b["blob"]), b["srcs"], b["jobs"]
     pk = D.pack_chunks(blob, srcs, jobs, fpw)
     plan = D.plan_chunks(jobs, fpw, srcs)
     assert pk.shape[0] == plan.shape[0]
     sub = 64 // fpw
-    off_desc, off_hdr, off_split, off_pool = fpw * 32, fpw * 80, fpw * 96, fpw * 96 + 512
+    split4 = bool((srcs["format"] >= D.FMT_94_T0).all())
+    assert split4 == (workload == "dcs94_65536")
+    sb = 4 if split4 else 8
+    off_split = fpw * 80
+    off_pool = (fpw * 80 + 64 * sb + 127) // 128 * 128
     # the image of the bit pool is as long as the plan's fullest chunk needs (a multiple of 128 bytes, at most the pool)
     pool_cap = max(fpw * 56, 320)
     img_dw = (pk.shape[1] - off_pool) // 4
@@ -221,34 +227,36 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
     src_bytes = srcs.view(np.uint8).reshape(srcs.size, -1)
     seen = 0
     n_shared, n_93a = [0], [0]
+    flat_plan = {}
     for c in range(pk.shape[0]):
-        slots = pk[c, :off_desc].view("<u4").reshape(fpw, 8)
         pool = pk[c, off_pool:].view("<u4")
         for s in range(fpw):
-            # (run s of the chunk rides in slot s: runNDw = low half of dword 5, runPoolOff = high half of dword 7)
-            if int(slots[s, 5]) & 0xFFFF:
-                fullest = max(fullest, (int(slots[s, 7]) >> 16) + (int(slots[s, 5]) & 0xFFFF))
-            flags = (int(slots[s, 1]) >> 8) & 0xFF
-            assert int(slots[s, 0]) == int(plan[c, s]["job"]) and flags == int(plan[c, s]["flags"])
+            blk = pk[c, 80 * s: 80 * s + 80]
+            slot = blk[:16].view("<u4")
+            flags = (int(slot[1]) >> 8) & 0xFF
+            assert int(slot[0]) == int(plan[c, s]["job"]) and flags == int(plan[c, s]["flags"])
             if flags & 0x80:
+                assert not blk[16:56].any() and not blk[64:].any()
                 continue
-            job = jobs[int(slots[s, 0])]
-            assert int(slots[s, 2]) == int(job["firstSrc"]) and ((int(slots[s, 1]) >> 16) & 0xFF) == int(job["nSrc"])
+            job = jobs[int(slot[0])]
+            assert int(slot[2]) == int(job["firstSrc"]) and ((int(slot[1]) >> 16) & 0xFF) == int(job["nSrc"])
             if job["nSrc"] == 0:
                 continue
             sd = srcs[int(job["firstSrc"])]
             # descriptor head: the first 40 bytes of the DcsSrcDesc
-            assert np.array_equal(pk[c, off_desc + 48 * s: off_desc + 48 * s + 40], src_bytes[int(job["firstSrc"]), :40])
+            assert np.array_equal(blk[16:56], src_bytes[int(job["firstSrc"]), :40])
+            pool_off = int(blk[56:58].view("<u2")[0])
+            bpl = int(blk[58])
+            assert not blk[59:64].any()
             # header: the bytes behind the U16 frame count
             so, hl = int(sd["streamOff"]), int(sd["hdrLen"])
             want_hdr = np.zeros(16, np.uint8); want_hdr[:hl] = np.frombuffer(blob[so + 2: so + 2 + hl], np.uint8)
-            assert np.array_equal(pk[c, off_hdr + 16 * s: off_hdr + 16 * s + 16], want_hdr)
+            assert np.array_equal(blk[64:80], want_hdr)
             # per-lane records: lane q's first band (bits 12..15 of the state word; bit 15 of bitDelta = no bands) with
             # the split record of that band's start.  The lanes cover the bands contiguously, in order: bpl bands each for
             # the 1993 layouts; in a 1994+ frame (bands of 7, 8, 13 x 16 and 32 samples) bands 0 and 1 count as one and
             # band 15 as two, so every lane after the first starts one band later; with one band per lane the last lane
             # takes the second half of band 15.
-            bpl = (int(slots[s, 7]) >> 8) & 0xFF
             nb16 = min(int(sd["idx"]["nBands"]), 16)
             is94 = int(sd["format"]) >= D.FMT_94_T0
             is93a = int(sd["format"]) == D.FMT_93A_T1
@@ -257,7 +265,13 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
             shared15 = is94 and bpl == 1 and nb16 == 16 and int(mid["prv"]) != 0
             bases = [0]
             for q in range(1, sub):
-                rec = pk[c, off_split + 8 * (s + q * fpw): off_split + 8 * (s + q * fpw) + 8].copy()
+                lane = s + q * fpw
+                raw = pk[c, off_split + sb * lane: off_split + sb * lane + sb].copy()
+                if split4:
+                    # bitDelta | state << 16: the 8-byte record without its prv / prvDelta words
+                    rec = np.zeros(8, np.uint8); rec[0:2] = raw[0:2]; rec[6:8] = raw[2:4]
+                else:
+                    rec = raw
                 if bpl == 0:
                     assert not rec.any()
                     continue
@@ -280,17 +294,15 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
                     assert np.array_equal(rec[:6], np.asarray(sd["idx"]["bandType"][(base - 16) * 8:(base - 16) * 8 + 6], np.uint8))
                     assert int(r16[3]) == (int(sd["idx"]["bandType"][(base - 16) * 8 + 6]) | int(sd["idx"]["bandType"][(base - 16) * 8 + 7]) << 8) & 0x0DFF
                 else:
-                    r16[3] &= 0x0FFF
-                    assert np.array_equal(rec, np.frombuffer(sd["idx"]["split"][base - 1].tobytes(), np.uint8))
-                assert 0 < base < nb_end and base >= bases[-1]
+                    sp = sd["idx"]["split"][base - 1]
+                    want16 = [int(sp["bitDelta"]), 0 if split4 else int(sp["prv"]), 0 if split4 else int(sp["prvDelta"]),
+                              (int(sp["state"]) & 0x0FFF) | (base << 12)]
+                    assert list(r16) == want16
                 bases.append(base)
-            if bpl != 0:
-                bases.append(nb_end)
-                assert all(bases[i] <= bases[i + 1] for i in range(sub))
+            if bpl:
                 if is93a:
-                    # eighteen bands of 2, 2, 2, 2, 3, 4, 5, 6, 5, 6, 7, 9, 11, 14, 12, 12, 12, 13 sample pairs, dealt so that the
-                    # lanes' k-th bands are of a size
-                    start = {1: lambda q: 2 * q if q < 2 else q + 2, 2: lambda q: 3 * q if q < 2 else 2 * q + 2}.get(bpl, lambda q: (0, 7, 11, 14)[q])
+                    def start(q):
+                        return (2 * q if q < 2 else q + 2) if bpl == 1 else (3 * q if q < 2 else 2 * q + 2) if bpl == 2 else (0, 7, 11, 14)[q]
                     want = [min(start(q), nb_end) for q in range(sub)]
                     n_93a[0] += 1
                 else:
@@ -300,9 +312,9 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
                     n_shared[0] += 1
                 assert bases[:sub] == want
             # the frame's bits, read MSB-first from the pool image at the slot's position, are the stream's
-            pool_off = int(slots[s, 5]) >> 16
             bit0 = (so + 2 + hl) * 8 + int(sd["idx"]["bitOff"])
             nbits = int(sd["idx"]["nBits"])
+            fullest = max(fullest, pool_off + ((bit0 & 31) + nbits + 31) // 32 + 3)
             for k in (0, nbits // 2, max(nbits - 1, 0)):
                 pos = (bit0 & 31) + k
                 got = (int(pool[pool_off + (pos >> 5)]) >> (31 - (pos & 31))) & 1
@@ -312,7 +324,7 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw):
     assert seen >= jobs.size
     assert img_dw == min(pool_cap, max(32, (fullest + 31) // 32 * 32))      # exactly the fullest chunk's runs, rounded up
     assert (n_shared[0] > 0) == (fpw == 4)          # one band per lane: band 15 of the 1994+ frames goes to two lanes
-    assert n_93a[0] > 0
+    assert (n_93a[0] > 0) == (workload == "mixed_16384")
 
 
 def test_workload_builders_shape():
