@@ -70,7 +70,7 @@ def parse_args(argv=None):
                     "stand-in is 600; 20 is the size whose per-stream reference hashes are committed)")
     ap.add_argument("--e2e-depth", type=int, default=8, help="lists in flight of end_to_end.sustained_host_index")
     ap.add_argument("--e2e-device-depth", type=int, default=48, help="lists in flight of end_to_end.sustained_device_index")
-    ap.add_argument("--e2e-lists", type=int, default=96, help="lists per rank of the N-rank end_to_end measurement (at least twice the depth)")
+    ap.add_argument("--e2e-lists", type=int, default=400, help="lists per rank of the N-rank end_to_end measurement (at least twice the depth)")
     ap.add_argument("--rotate", type=int, default=8, help="roofline_cold: this many distinct resident batches of the workload (the shares of "
                     "ranks 0..N-1, together larger than the 256 MB Infinity Cache) launched round-robin, so that no launch finds its "
                     "inputs or outputs cached (0: skip; one rank only; not for the corpus, whose one batch is larger than the cache)")
@@ -309,7 +309,7 @@ def end_to_end_ranks(ctx, streams, n_frames, comm, depth=48, lists=96, budget_s=
             r = pipe.collect(); done += 1
             host_ms.append(r[3]); dev_ms.append(r[4])
         dt = time.perf_counter() - t0
-        r1 = resource.getrusage(resource.RUSAGE_SELF)
+        r1 = resource.getrusage(resource.RUSAGE_SELF)           # (before the pipeline's tear-down: joins, stream and buffer releases are no list's cost)
         pipe.close()
         cpu_ms = ((r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)) * 1e3 / n_lists
         box["row"] = [dt, n_lists, sum(host_ms) / len(host_ms), sum(dev_ms) / len(dev_ms), cpu_ms]
@@ -749,9 +749,26 @@ class Sections:
         return box["value"]
 
 
+_LINE_FD = None
+
+
+def keep_stdout_for_the_line():
+    """ONE JSON line on stdout is the contract -- but libraries write there too (gloo announces its peers on stdout, a runtime
+    may print a warning): from here on file descriptor 1 is the process's stderr, and only emit() holds the real stdout."""
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
 def emit(line, hard_exit=False, code=0):
-    sys.stdout.write(json.dumps(line) + "\n")
-    sys.stdout.flush()
+    text = (json.dumps(line) + "\n").encode()
+    if _LINE_FD is not None:
+        os.write(_LINE_FD, text)
+    else:
+        sys.stdout.write(text.decode())
+        sys.stdout.flush()
     if hard_exit:                       # (a thread that never came back would keep the interpreter's shutdown waiting)
         sys.stderr.flush()
         os._exit(code)
@@ -1098,6 +1115,7 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))
+    keep_stdout_for_the_line()
     run_rank(args)
 
 
