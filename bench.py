@@ -538,7 +538,7 @@ def device_full_path(ctx, args, streams, n_frames, rank_golden):
 
 
 # --------------------------------------------------------------------------------------------- one process, several GPUs
-def end_to_end_node(args, streams, n_frames, depth=24, lists=192):
+def end_to_end_node(args, streams, n_frames, depth=24, lists=600):
     """host buffers in, PCM in pinned memory out through dcs_node: one process, `--node` persistent contexts with a pipeline each
     (index pass, planner and packer on the device), lists dealt to the device with the fewest frames in flight, collected in
     submission order.  CPU-milliseconds per list of the whole process next to the rate (the N-process form: end_to_end of
@@ -549,10 +549,11 @@ def end_to_end_node(args, streams, n_frames, depth=24, lists=192):
     refs, keep = D.make_refs(streams)
     node = D.Node(devs, depth=depth)
     inflight = depth * len(devs)
-    for _ in range(inflight):
-        node.submit_refs(refs, len(streams))
-    for _ in range(inflight):
-        node.collect()
+    for _ in range(2):                  # (as the single pipeline's measurement: two rounds until nothing is allocated any more)
+        for _ in range(inflight):
+            node.submit_refs(refs, len(streams))
+        for _ in range(inflight):
+            node.collect()
     n_lists = max(lists, 2 * inflight)
     r0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
