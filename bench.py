@@ -460,7 +460,7 @@ def device_full_path(ctx, args, streams, n_frames, rank_golden):
         del pcm
         return {"streams": len(strs), "frames": frames, "ms_per_pass": t["passMs"], "value": frames * 240 / (t["passMs"] * 1e-3), "unit": "samples/s",
                 "ns_per_frame": t["passMs"] * 1e6 / frames,
-                "kernel_ms": {"dcsIndexWaveKernel": t["indexMs"], "dcsPlanKernel (+ clearing packages, error and hand-off words)": t["planMs"],
+                "kernel_ms": {"dcsIndexWaveKernel": t["indexMs"], "dcsPlanKernel (+ clearing error and hand-off words)": t["planMs"],
                               "dcsPackKernel": t["packMs"], "dcsDecodeKernel<%d>" % t["framesPerWave"]: t["decodeMs"]},
                 "index_share_of_pass": t["indexMs"] / max(t["indexMs"] + t["planMs"] + t["packMs"] + t["decodeMs"], 1e-9),
                 "index_ns_per_frame": t["indexMs"] * 1e6 / frames, "clock_mhz": clock, "passes_timed": iters,

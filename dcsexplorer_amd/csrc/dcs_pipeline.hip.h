@@ -919,8 +919,11 @@ DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint
     // The parts taper: the call ends one part's latency (build, create, upload, kernel, download) after the index pass
     // has reached the list's last stream, so the last parts are small -- 4 4 4 4 3 2 2 1 twenty-fourths of the frames
     // (equal parts: 4.6 ms for 65 536 frames, of which 1.45 behind the index pass).
-    static const uint32_t kWeightHost[kParts] = { 4, 4, 4, 4, 3, 2, 2, 1 }, kWeightDevice[kParts] = { 3, 3, 3, 3, 3, 3, 3, 3 };
-    const uint32_t *kWeight = onDevice ? kWeightDevice : kWeightHost;
+    // (the walk shared with the device: the device walks the LAST part(s), and what it does behind its walk -- planner, packer,
+    // decode, the PCM's way down -- is the call's tail: those parts are the small ones)
+    static const uint32_t kWeightHost[kParts] = { 4, 4, 4, 4, 3, 2, 2, 1 }, kWeightDevice[kParts] = { 3, 3, 3, 3, 3, 3, 3, 3 },
+                          kWeightShared[kParts] = { 4, 4, 4, 3, 3, 3, 2, 1 };
+    const uint32_t *kWeight = !onDevice ? kWeightHost : ctx->largeListShared ? kWeightShared : kWeightDevice;
     uint32_t cut[kParts + 1];
     {
         uint32_t wSum = 0, wAcc = 0;

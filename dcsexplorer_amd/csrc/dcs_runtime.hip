@@ -35,7 +35,7 @@ struct DcsCtx
     bool keepAllTails = false;          // resident batches store EVERY frame's tail (dcs_ctx_set_batch_tails); default: the last frame of every chain
     bool largeListOnDevice = true;      // dcs_decode_streams on a large list: index walk, planner and packer on the device (dcs_ctx_set_large_list_path)
     bool largeListShared = true;        // ... with the host pool walking the first parts of the list next to the device (mode 2, the default)
-    int sharedHostParts = 5;            // how many of the eight parts the host walks; follows the measured finish times from call to call
+    int sharedHostParts = 7;            // how many of the eight parts the host walks (where 16 pool threads settle); follows the measured finish times from call to call
     std::mutex cacheMutex;              // the buffer cache is shared by the pipeline's worker threads
     struct DcsPipeline *internalPipe = nullptr;     // dcs_decode_streams takes large lists through it in parts (dcs_pipeline.hip.h)
     int numCUs = 256;
@@ -899,46 +899,51 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
     const DcsSlot *cs = slots + static_cast<size_t>(chunk) * FPW;
     const uint32_t imgDw = dcsPkgImgDw(layout);
     const bool split4 = (layout & DCS_PKG_SPLIT4) != 0;
+    // EVERY byte of the package is written here, once (round 5: the buffer used to be cleared first, 700 MB of writes in front of
+    // the packer for 2 M frames): what does not apply is written as zero, as the host packer's memset leaves it.
     // slot `lane`: its first 16 bytes, the descriptor head (the first 40 bytes of what DcsSrcDesc would be) with poolOff and bpl
     // behind it, the stream header (dcs_common.h: five 16-byte pieces per slot)
     if (lane < FPW)
     {
         const DcsSlot sl = cs[lane];
-        uint8_t *ps = pkg + static_cast<size_t>(lane) * DCS_PKG_SLOT_BYTES;
-        reinterpret_cast<uint4 *>(ps)[0] = reinterpret_cast<const uint4 *>(&cs[lane])[0];
-        reinterpret_cast<uint32_t *>(ps)[14] = static_cast<uint32_t>(sl.poolOff) | (static_cast<uint32_t>(sl.bpl) << 16);
+        uint4 *ps = reinterpret_cast<uint4 *>(pkg + static_cast<size_t>(lane) * DCS_PKG_SLOT_BYTES);
+        uint32_t d[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, h[4] = { 0, 0, 0, 0 };
         if (!(sl.flags & DCS_SLOT_EMPTY) && sl.nSrc != 0)
         {
             const DcsPlanSrc sd = srcs[sl.firstSrc];
             const uint32_t *rec = reinterpret_cast<const uint32_t *>(&records[sd.record]);
-            uint32_t *d = reinterpret_cast<uint32_t *>(ps + 16);
             d[0] = static_cast<uint32_t>(sd.streamOff);
             d[1] = static_cast<uint32_t>(sd.streamOff >> 32);
             d[2] = static_cast<uint32_t>(sd.mixMul) | (static_cast<uint32_t>(sd.format) << 16) | (static_cast<uint32_t>(sd.hdrLen) << 24);
+#pragma unroll
             for (int i = 0 ; i < 7 ; ++i)
                 d[3 + i] = rec[i];              // bitOff, nBits | hdrBits, bandType[16], preAdj | nBands | flags
             const uint64_t hOff = sd.streamOff + 2;
             const uint32_t hLen = sd.hdrLen == 1 ? 1u : 16u;
-            uint32_t h[4] = { 0, 0, 0, 0 };
-            for (uint32_t i = 0 ; i < hLen ; ++i)
-                if (hOff + i < blobLen)
+#pragma unroll
+            for (uint32_t i = 0 ; i < 16 ; ++i)
+                if (i < hLen && hOff + i < blobLen)
                     h[i >> 2] |= static_cast<uint32_t>(blob[hOff + i]) << (8 * (i & 3));
-            uint32_t *hd = reinterpret_cast<uint32_t *>(ps + 64);
-            hd[0] = h[0]; hd[1] = h[1]; hd[2] = h[2]; hd[3] = h[3];
         }
+        ps[0] = reinterpret_cast<const uint4 *>(&cs[lane])[0];
+        ps[1] = make_uint4(d[0], d[1], d[2], d[3]);
+        ps[2] = make_uint4(d[4], d[5], d[6], d[7]);
+        ps[3] = make_uint4(d[8], d[9], static_cast<uint32_t>(sl.poolOff) | (static_cast<uint32_t>(sl.bpl) << 16), 0u);
+        ps[4] = make_uint4(h[0], h[1], h[2], h[3]);
     }
-    // the lane's own record: first band and split record of the frame's q-th unpack lane
+    // the lane's own record: first band and split record of the frame's q-th unpack lane (zero where there is none)
     {
         constexpr int SUB = 64 / FPW;
         const int sI = lane % FPW, q = lane / FPW;
         const DcsSlot sl = cs[sI];
+        uint32_t r0 = 0, r1 = 0;
         if (q >= 1 && q < SUB && !(sl.flags & DCS_SLOT_EMPTY) && sl.nSrc != 0 && sl.bpl != 0)
         {
             const DcsPlanSrc sd = srcs[sl.firstSrc];
             const int nb16 = sd.nBands < 16 ? sd.nBands : 16;
             const int nbEnd = dcsDealEnd(sd.format, sd.nBands);
             const int base = dcsLaneFirstBand(sd.format, q, sl.bpl, nbEnd);
-            uint32_t r0 = 0x8000u, r1 = 0;      // bitDelta bit 15: no bands for this lane
+            r0 = 0x8000u;                       // bitDelta bit 15: no bands for this lane
             const uint32_t *mid = reinterpret_cast<const uint32_t *>(&records[sd.record].split[14]);
             if (q == SUB - 1 && dcsMid15(sd.format, sl.bpl, nb16, mid[0] >> 16))
             {
@@ -962,24 +967,31 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
                 r0 = sp[0];
                 r1 = (sp[1] & 0x0FFFFFFFu) | (static_cast<uint32_t>(base) << 28);
             }
-            if (split4)
-                reinterpret_cast<uint32_t *>(pkg + dcsPkgOffSplit(FPW))[lane] = (r0 & 0xFFFFu) | (r1 & 0xFFFF0000u);
-            else
-            {
-                uint32_t *dst = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffSplit(FPW) + static_cast<size_t>(lane) * 8);
-                dst[0] = r0; dst[1] = r1;
-            }
         }
+        if (split4)
+            reinterpret_cast<uint32_t *>(pkg + dcsPkgOffSplit(FPW))[lane] = (r0 & 0xFFFFu) | (r1 & 0xFFFF0000u);
+        else
+            reinterpret_cast<uint2 *>(pkg + dcsPkgOffSplit(FPW))[lane] = make_uint2(r0, r1);
     }
-    // the image of the bit pool: the chunk's runs of stream dwords, in bit order
+    // (the bytes between the split records and the image's 128-byte boundary)
+    {
+        const uint32_t padFrom = dcsPkgOffSplit(FPW) + 64u * dcsPkgSplitBytes(layout), padTo = dcsPkgOffPool(FPW, layout);
+        for (uint32_t i = padFrom / 4 + static_cast<uint32_t>(lane) ; i < padTo / 4 ; i += 64)
+            reinterpret_cast<uint32_t *>(pkg)[i] = 0;
+    }
+    // the image of the bit pool: the chunk's runs of stream dwords, in bit order; zero between them (the runs lie one behind the
+    // other, each on a 16-byte boundary: gaps of at most three dwords) and behind the last one
     uint32_t *img = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffPool(FPW, layout));
+    uint32_t end = 0;
     for (int k = 0 ; k < FPW ; ++k)
     {
         const uint32_t n = cs[k].runNDw, st = cs[k].runStartDw, o = cs[k].runPoolOff;
         if (n == 0)
             break;
-        if (o + n > imgDw)
-            continue;
+        if (o + n > imgDw || o < end)
+            continue;                           // (cannot happen: the image covers every run of the plan, in order)
+        for (uint32_t i = end + static_cast<uint32_t>(lane) ; i < o ; i += 64)
+            img[i] = 0;
         for (uint32_t i = static_cast<uint32_t>(lane) ; i < n ; i += 64)
         {
             const uint64_t b0 = (static_cast<uint64_t>(st) + i) * 4;
@@ -992,7 +1004,10 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
                         w |= static_cast<uint32_t>(blob[b0 + j]) << (24 - 8 * j);
             img[o + i] = w;
         }
+        end = o + n;
     }
+    for (uint32_t i = end + static_cast<uint32_t>(lane) ; i < imgDw ; i += 64)
+        img[i] = 0;
 }
 }   // namespace
 
@@ -1193,8 +1208,7 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
         if (nSrcs)
             HIPCHK(ctx, copyByKernel(b->stream, b->dPlanSrcs, static_cast<uint8_t *>(stage) + b->planSlotsCap, sizeof(DcsPlanSrc) * nSrcs));
         b->cap[9] = pkgBytes; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPackages), b->cap[9]));
-        HIPCHK(ctx, hipMemsetAsync(b->dPackages, 0, pkgBytes, b->stream));
-        const uint32_t blocks = (b->nChunks + 3) / 4;
+        const uint32_t blocks = (b->nChunks + 3) / 4;       // (the pack kernel writes every byte of the packages: nothing to clear)
         const DcsSlot *dS = static_cast<const DcsSlot *>(b->dPlanSlots);
         const DcsPlanSrc *dP = static_cast<const DcsPlanSrc *>(b->dPlanSrcs);
         if (b->fpw == 16)
@@ -1239,7 +1253,7 @@ __global__ __launch_bounds__(256) void dcsClear3Kernel(uint4 *a, size_t nA16, ui
 }
 }   // namespace
 
-// What a planned-on-device batch queues in front of its decode launch: packages, error words and hand-off words cleared,
+// What a planned-on-device batch queues in front of its decode launch: error words and hand-off words cleared,
 // one thread per chunk plans (dcsPlanKernel), one wavefront per chunk packs (dcsPackKernel).  `between` (optional) is
 // recorded between planner and packer (the device-path timing, dcs_device_path_run).
 static DcsStatus queuePlanAndPack(DcsBatch *b, uint32_t nStreams, uint32_t extraFrames, const DcsFrameIndex *dRecords, const DcsStreamInfo *dInfos,
@@ -1247,13 +1261,14 @@ static DcsStatus queuePlanAndPack(DcsBatch *b, uint32_t nStreams, uint32_t extra
 {
     DcsCtx *ctx = b->ctx;
     const uint32_t nJobs = b->nJobs;
-    // packages, error words and hand-off words cleared by ONE kernel (three hipMemsetAsync were three dispatches in a chain of
+    // error words and hand-off words cleared by ONE kernel (three hipMemsetAsync were three dispatches in a chain of
     // ten per list; epoch 0 = never written; the planner's flag word lies behind the last chunk's hand-off words)
     {
-        const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgStride(b->fpw, b->imgDw), errBytes = sizeof(uint32_t) * nJobs, hoBytes = b->cap[8];
-        const size_t total16 = pkgBytes / 16 + (errBytes + 15) / 16 + hoBytes / 16;
+        // (the packages are no longer among them: the pack kernel writes every byte of a package itself)
+        const size_t errBytes = sizeof(uint32_t) * nJobs, hoBytes = b->cap[8];
+        const size_t total16 = (errBytes + 15) / 16 + hoBytes / 16;
         const unsigned blocks = static_cast<unsigned>(std::min<size_t>((total16 + 255) / 256, 2048));
-        hipLaunchKernelGGL(dcsClear3Kernel, dim3(blocks), dim3(256), 0, b->stream, reinterpret_cast<uint4 *>(b->dPackages), pkgBytes / 16,
+        hipLaunchKernelGGL(dcsClear3Kernel, dim3(blocks), dim3(256), 0, b->stream, static_cast<uint4 *>(nullptr), static_cast<size_t>(0),
                            reinterpret_cast<uint32_t *>(b->dErr), errBytes / 4, reinterpret_cast<uint4 *>(b->dHandoff), hoBytes / 16);
         HIPCHK(ctx, hipGetLastError());
     }
@@ -1414,7 +1429,7 @@ extern "C" DcsStatus dcs_pack_chunks_device(DcsCtx *ctx, const DcsFrameJob *jobs
         HIPCHK(ctx, hipMalloc(&dBlob, blobAlloc));
         HIPCHK(ctx, hipMalloc(&dPkg, pkgBytes));
         HIPCHK(ctx, hipMemsetAsync(dBlob, 0, blobAlloc, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(dPkg, 0, pkgBytes, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(dPkg, 0xA5, pkgBytes, ctx->stream));     // (the pack kernel writes every byte: a pattern it must leave nothing of)
         HIPCHK(ctx, hipMemcpyAsync(dSlots, slots.data(), sizeof(DcsSlot) * slots.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(dPs, ps.data(), sizeof(DcsPlanSrc) * nSrcs, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(dRecs, recs.data(), sizeof(DcsFrameIndex) * nSrcs, hipMemcpyHostToDevice, ctx->stream));

@@ -462,7 +462,7 @@ typedef struct DcsDevicePath DcsDevicePath;
 typedef struct DcsDevicePathTimes
 {
     float    passMs;                   /* index + plan + pack + decode, average over the back-to-back passes            */
-    float    indexMs, planMs, packMs, decodeMs;     /* per kernel (plan includes clearing packages, error and hand-off words) */
+    float    indexMs, planMs, packMs, decodeMs;     /* per kernel (plan includes clearing error and hand-off words) */
     uint32_t planFlags;                /* DCS_PLAN_*: 0 = the device planner served the list                            */
     uint32_t nStreams, nFrames, framesPerWave;
     uint64_t algorithmicBytes;         /* SURVEY 8(d) bytes of one pass (as dcs_batch_algorithmic_bytes)                */
@@ -709,9 +709,10 @@ DcsStatus dcs_plan_chunks2(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrc
                            uint64_t *slotsOut, size_t cap, uint32_t *nChunksOut);
 
 /* Diagnostic: the chunk packages dcs_batch_create uploads for `jobs` at `fpw` frames per wavefront (4, 8 or 16): per
- * chunk, at a fixed stride of *packageBytesOut bytes, the slots (32 B each), the first 40 bytes of each slot's first
- * DcsSrcDesc (at a 48-byte pitch), the 16 stream-header bytes of each slot, one 8-byte split record per lane, and the
- * image of the kernel's bit pool (the chunk's compressed dwords in bit order).  out = NULL to size. */
+ * chunk, at a fixed stride of *packageBytesOut bytes, 80 bytes per slot (the slot's first 16 bytes, the first 40 bytes of
+ * its first DcsSrcDesc, its pool offset and bands per lane, its 16 stream-header bytes), one split record per lane (8 bytes;
+ * 4 when every source is a 1994+ frame) and -- from the next 128-byte boundary -- the image of the kernel's bit pool (the
+ * chunk's compressed dwords in bit order), as long as the plan's fullest chunk needs.  out = NULL to size. */
 DcsStatus dcs_pack_chunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs,
                           const uint8_t *blob, size_t blobLen, int fpw,
                           uint8_t *out, size_t cap, uint32_t *nChunksOut, uint32_t *packageBytesOut);
