@@ -327,6 +327,27 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw, workload):
     assert (n_93a[0] > 0) == (workload == "mixed_16384")
 
 
+def test_resident_plan_shortens_packages_but_opens_no_further_generation():
+    """dcsPlanChunksCapped (what dcs_batch_create plans with): the default workload's 65 536 frames stay 8 192 chunks -- exactly two
+    generations of an MI355X's 4 096 wavefront places; a plan capped at what 97 % of the chunks need would make 8 216 of them and a
+    third generation (measured: 36.2 us against 33.4) -- with the image sized by the fullest chunk and 4-byte split records; a batch
+    that is well inside one generation takes the capped plan: more chunks than frames / 8, shorter packages, fewer bytes in all"""
+    b = workloads.build("survey3_65536")
+    pk = D.pack_chunks(bytes(b["blob"]), b["srcs"], b["jobs"], 8)
+    assert pk.shape[0] == 8192
+    img_dw = (pk.shape[1] - 896) // 4
+    assert pk.shape[1] == 896 + img_dw * 4 and img_dw % 32 == 0 and 256 <= img_dw < 448
+    small = workloads.build("survey3_65536", n_streams=40)                 # 10 240 frames: 1 280 chunks, a third of a generation
+    pk2 = D.pack_chunks(bytes(small["blob"]), small["srcs"], small["jobs"], 8)
+    n_min = small["jobs"].size // 8
+    assert n_min <= pk2.shape[0] <= n_min + n_min // 16
+    if pk2.shape[0] > n_min:                                               # the cap was taken: it must have paid
+        assert pk2.shape[1] < pk.shape[1] and pk2.size < n_min * pk.shape[1]
+    jobs_seen = np.sort(np.concatenate([pk2[c, 80 * s: 80 * s + 4].view("<u4") for c in range(pk2.shape[0]) for s in range(8)]))
+    jobs_seen = jobs_seen[jobs_seen != 0xFFFFFFFF]
+    assert np.array_equal(jobs_seen, np.arange(small["jobs"].size, dtype=np.uint32))      # every frame once, halo-free
+
+
 def test_workload_builders_shape():
     b = workloads.build("dcs93_4096")
     assert b["jobs"].size == 4096 and b["srcs"].size == 4096
