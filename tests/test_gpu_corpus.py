@@ -76,6 +76,35 @@ def test_sharded_entry_two_contexts_one_device(oracle, corpus):
     assert "%016x" % oracle.fnv1a64(pcm[first[k]:first[k] + nf]) == g["stream_hashes"][k]
 
 
+def test_sharded_entry_survives_a_concurrent_cache_release(corpus):
+    """the node a sharded call runs on is held while the call uses it (it used to be a raw pointer looked up under a
+    mutex that was dropped before the call): one thread decodes the same list over [0, 0] and [0, 0, 0] again and again while another
+    releases the node cache all the time -- every call returns the same PCM and nothing crashes"""
+    import threading
+    g, manifest, streams = corpus
+    sub = streams[40:72]
+    want, werr, wfirst, _ = D.decode_streams_sharded([0, 0], sub, extra_frames=1)
+    stop, bad = threading.Event(), []
+
+    def releaser():
+        while not stop.is_set():
+            D.node_cache_release()
+
+    th = threading.Thread(target=releaser)
+    th.start()
+    try:
+        for k in range(12):
+            devs = [0, 0] if k % 2 == 0 else [0, 0, 0]
+            pcm, err, first, cut = D.decode_streams_sharded(devs, sub, extra_frames=1)
+            if not (np.array_equal(pcm, want) and np.array_equal(err, werr) and np.array_equal(first, wfirst)):
+                bad.append(k)
+    finally:
+        stop.set()
+        th.join()
+        D.node_cache_release()
+    assert not bad
+
+
 @pytest.mark.parametrize("fpw", [4, 8, 16])
 def test_device_packer_lays_out_the_same_packages_as_the_host_packer(gpu_ctx, fpw):
     """the packer on the device (DCS_PIPE_PACK_ON_DEVICE) against the host packer: byte for byte the same packages,
