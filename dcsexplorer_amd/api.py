@@ -99,7 +99,7 @@ class DcsError(RuntimeError):
 
 
 _LIB = None
-ABI_VERSION = 8                 # include/dcs_hip.h DCS_ABI_VERSION these bindings are written for
+ABI_VERSION = 9                 # include/dcs_hip.h DCS_ABI_VERSION these bindings are written for
 
 EXPORTS = [
     "dcs_abi_version", "dcs_build_id", "dcs_index_stream", "dcs_volume_multiplier", "dcs_mixing_multiplier", "dcs_frame_scale",
@@ -119,6 +119,7 @@ EXPORTS = [
     "dcs_seq_plan", "dcs_seq_pending_ticks", "dcs_seq_is_fatal", "dcs_seq_host_bytes", "dcs_seq_decode",
     "dcs_seq_create_standalone", "dcs_seq_load_audio_stream_mem", "dcs_seq_rewind", "dcs_seq_set_rewindable",
     "dcs_seq_tick", "dcs_seq_fatal_tick", "dcs_seq_stream_playing",
+    "dcs_decode_batch_live", "dcs_seq_decode_view", "dcs_seq_plan_ahead", "dcs_seq_stream_playing_at",
     "dcs_host_threads", "dcs_partition_streams", "dcs_decode_streams_sharded",
     "dcs_ctx_set_frames_per_chunk", "dcs_index_stream_literal", "dcs_pack_chunks_device", "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_link_rate", "dcs_ctx_set_test_hooks",
     "dcs_pipeline_create", "dcs_pipeline_destroy", "dcs_pipeline_submit", "dcs_pipeline_collect",
@@ -306,6 +307,16 @@ def load_library():
     L.dcs_seq_load_audio_stream_mem.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, sz, ctypes.c_int]
     L.dcs_seq_rewind.restype = i32
     L.dcs_seq_rewind.argtypes = [vp, u32]
+    L.dcs_seq_plan_ahead.restype = i32
+    L.dcs_seq_plan_ahead.argtypes = [vp, u32, u32, ctypes.POINTER(u32)]
+    L.dcs_seq_decode_view.restype = i32
+    L.dcs_seq_decode_view.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(u32), ctypes.POINTER(vp)]
+    L.dcs_seq_stream_playing_at.restype = ctypes.c_int
+    L.dcs_seq_stream_playing_at.argtypes = [vp, u32, ctypes.c_int]
+    L.dcs_seq_stream_playing.restype = ctypes.c_int
+    L.dcs_seq_stream_playing.argtypes = [vp, ctypes.c_int]
+    L.dcs_decode_batch_live.restype = i32
+    L.dcs_decode_batch_live.argtypes = [vp, vp, sz, ctypes.c_uint64, vp, u32, vp, u32, vp, u32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.dcs_seq_set_rewindable.restype = i32
     L.dcs_seq_set_rewindable.argtypes = [vp, ctypes.c_int]
     L.dcs_seq_pending_ticks.restype = u32
@@ -762,6 +773,23 @@ class Context:
                                        _ptr(tin), 0 if tin is None else tin.shape[0], _ptr(pcm), _ptr(err),
                                        _ptr(tails)), self.h)
         return (pcm, err, tails) if want_tails else (pcm, err)
+
+    def decode_batch_live(self, blob, srcs, jobs, tails_in=None, blob_id=0):
+        """dcs_decode_batch_live: the context's persistent small-batch decoder -> (pcm, err, tails), copies of what lies in the
+        context's pinned memory until its next decode call"""
+        blob_a = np.frombuffer(bytes(blob), dtype=np.uint8)
+        srcs = np.ascontiguousarray(srcs, dtype=SRC_DTYPE)
+        jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+        n = jobs.size
+        tin = None if tails_in is None else np.ascontiguousarray(tails_in, dtype=np.int16)
+        pcm, err, tails = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _check(self.L.dcs_decode_batch_live(self.h, _ptr(blob_a), ctypes.c_size_t(blob_a.size), ctypes.c_uint64(blob_id), _ptr(srcs), srcs.size,
+                                            _ptr(jobs), n, _ptr(tin), 0 if tin is None else tin.shape[0],
+                                            ctypes.byref(pcm), ctypes.byref(err), ctypes.byref(tails)), self.h)
+        def view(p, dtype, shape):
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return np.frombuffer(ctypes.string_at(p.value, nbytes), dtype=dtype).reshape(shape).copy()
+        return view(pcm, np.int16, (n, FRAME_SAMPLES)), view(err, np.uint32, (n,)), view(tails, np.int16, (n, 16))
 
     def decode_streams(self, streams, extra_frames=0):
         """streams: iterable of (os, bytes, volume, level) -> (pcm [frames,240], err, first_job)"""
@@ -1343,6 +1371,35 @@ class Sequencer:
             st = self.L.dcs_seq_plan(self.h, 1)
             if st != 0:
                 raise DcsError(st, self.L.dcs_seq_last_error(self.h).decode())
+
+    def plan(self, n_ticks):
+        st = self.L.dcs_seq_plan(self.h, n_ticks)
+        if st != 0:
+            raise DcsError(st, self.L.dcs_seq_last_error(self.h).decode())
+
+    def plan_ahead(self, max_ticks, idle_ticks=2):
+        """dcs_seq_plan_ahead -> ticks planned"""
+        n = ctypes.c_uint32()
+        st = self.L.dcs_seq_plan_ahead(self.h, max_ticks, idle_ticks, ctypes.byref(n))
+        if st != 0:
+            raise DcsError(st, self.L.dcs_seq_last_error(self.h).decode())
+        return n.value
+
+    def stream_playing_at(self, ticks, channel):
+        return bool(self.L.dcs_seq_stream_playing_at(self.h, ticks, channel))
+
+    def stream_playing(self, channel):
+        return bool(self.L.dcs_seq_stream_playing(self.h, channel))
+
+    def decode_view(self, ctx):
+        """dcs_seq_decode_view: (pcm, err) copied out of the context's pinned memory"""
+        pcm, err, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32()
+        _check(self.L.dcs_seq_decode_view(ctx.h, self.h, ctypes.byref(pcm), ctypes.byref(n), ctypes.byref(err)), ctx.h)
+        if n.value == 0:
+            return np.zeros((0, FRAME_SAMPLES), dtype=np.int16), np.zeros(0, dtype=np.uint32)
+        p = np.frombuffer(ctypes.string_at(pcm.value, n.value * FRAME_SAMPLES * 2), dtype=np.int16).reshape(n.value, FRAME_SAMPLES).copy()
+        e = np.frombuffer(ctypes.string_at(err.value, n.value * 4), dtype=np.uint32).copy()
+        return p, e
 
     @property
     def pending_ticks(self):

@@ -4,6 +4,7 @@
 // :1546-1589); the frame decode itself is dcs_decode_batch -> HIP kernels.
 #include "../../include/DCSDecoderHIP.h"
 #include <string.h>
+#include <mutex>
 
 DCSHIP_NAMESPACE_BEGIN
 
@@ -30,7 +31,7 @@ void DCSDecoder::SoftBoot()
     state = Initialize() ? State::Running : State::InitializationError;
 }
 
-int16_t DCSDecoder::GetNextSample()
+int16_t DCSDecoder::RefillAndGetSample()
 {
     if (state != State::Running)
         return 0;                                               // halted or not booted: silence (DCSDecoder.cpp:1680-1689)
@@ -50,14 +51,70 @@ int16_t DCSDecoder::GetNextSample()
 static DCSDecoder::Registration registration("hip", "MI355X HIP batch decoder",
     [](DCSDecoder::Host *host) -> DCSDecoder * { return new DCSDecoderHIP(host); });
 
+// ---- contexts ------------------------------------------------------------------------------------------------
+// The reference's callers make a decoder per file (DCSEncoder.cpp:522-540) or per run and expect that to cost nothing.  A
+// DcsCtx is a HIP stream, the decode tables on the device and the live decoder's pinned arenas: 8 ms to make, as long as the
+// reference takes to decode 2 000 frames.  So a decoder that goes away leaves its context here, and the next decoder on that
+// device takes it over (a context serves one decoder at a time, like the decoder object itself serves one thread).  At most
+// kIdleContexts wait here; they are destroyed when the library is unloaded.
+namespace {
+struct ContextPool
+{
+    static const size_t kIdleContexts = 4;
+    std::mutex m;
+    std::vector<std::pair<int, DcsCtx *>> idle;
+    ~ContextPool()
+    {
+        for (auto &c : idle)
+            dcs_ctx_destroy(c.second);
+    }
+    DcsCtx *take(int device)
+    {
+        std::lock_guard<std::mutex> lock(m);
+        for (size_t i = 0 ; i < idle.size() ; ++i)
+            if (idle[i].first == device)
+            {
+                DcsCtx *c = idle[i].second;
+                idle.erase(idle.begin() + static_cast<long>(i));
+                return c;
+            }
+        return nullptr;
+    }
+    void give(int device, DcsCtx *c)
+    {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            if (idle.size() < kIdleContexts)
+            {
+                idle.emplace_back(device, c);
+                return;
+            }
+        }
+        dcs_ctx_destroy(c);
+    }
+};
+ContextPool &contextPool()
+{
+    static ContextPool pool;
+    return pool;
+}
+}   // namespace
+
 // ---- DCSDecoderHIP -----------------------------------------------------------------------------------------
 DCSDecoderHIP::DCSDecoderHIP(Host *host, int deviceId) : DCSDecoder(host), deviceId(deviceId) { }
+
+void DCSDecoderHIP::ReleaseContext()
+{
+    if (ctx != nullptr)
+        contextPool().give(deviceId, ctx);
+    ctx = nullptr;
+}
 
 DCSDecoderHIP::~DCSDecoderHIP()
 {
     if (seq != nullptr) dcs_seq_destroy(seq);
     if (roms != nullptr) dcs_romset_destroy(roms);
-    if (ctx != nullptr) dcs_ctx_destroy(ctx);
+    ReleaseContext();
 }
 
 void DCSDecoderHIP::InitStandalone(OSVersion v)
@@ -189,6 +246,8 @@ DCSDecoder::ROMPointer DCSDecoderHIP::MakeROMPointer(uint32_t linearAddress) con
 bool DCSDecoderHIP::Initialize()
 {
     if (ctx == nullptr)
+        ctx = contextPool().take(deviceId);
+    if (ctx == nullptr)
     {
         DcsStatus st = dcs_ctx_create(deviceId, &ctx);
         if (st != DCS_OK)
@@ -202,7 +261,8 @@ bool DCSDecoderHIP::Initialize()
         dcs_seq_destroy(seq);
         seq = nullptr;
     }
-    ready.clear(); hostBytes.clear(); handedOut = 0; nextTick = 0;
+    ready = nullptr; readyCount = 0; hostBytes.clear(); hostNext = 0; handedOut = 0; nextTick = 0;
+    curLookahead = kFirstLookahead; fatalTick = ~uint64_t(0);
 #ifdef DCSHIP_USE_REFERENCE_BASE
     // The base class owns the ROM images (AddROM / LoadROMFromZipFile put them in ROM[], CheckROMs has identified them
     // or the caller has named the versions): hand them to the C ABI's ROM set, with the versions the base holds.
@@ -254,11 +314,12 @@ bool DCSDecoderHIP::Initialize()
 // sequencer did for them.
 void DCSDecoderHIP::Sync()
 {
-    if (seq == nullptr || ready.empty())
+    curLookahead = kFirstLookahead;             // a command: whoever sends one may send another soon
+    if (seq == nullptr || handedOut == readyCount)
         return;
     dcs_seq_rewind(seq, handedOut);
-    ready.clear();
-    while (!hostBytes.empty() && hostBytes.back().tick >= nextTick)
+    readyCount = handedOut;
+    while (hostBytes.size() > hostNext && hostBytes.back().tick >= nextTick)
         hostBytes.pop_back();
 }
 
@@ -373,10 +434,41 @@ void DCSDecoderHIP::LoadAudioStreamBounded(int ch, const ROMPointer &p, int mixi
 
 bool DCSDecoderHIP::IsStreamPlaying(int ch)
 {
-    if (seq == nullptr)
+    // (a question, not a command: callers ask it between every two buffers, EncoderTester.cpp:106 -- answered for the last frame
+    // handed out, the look-ahead stays)
+    return seq != nullptr && dcs_seq_stream_playing_at(seq, handedOut, ch) != 0;
+}
+
+// run the sequencer ahead and decode what it planned in one launch
+bool DCSDecoderHIP::Refill()
+{
+    handedOut = 0;
+    readyCount = 0;
+    ready = nullptr;
+    DcsStatus st;
+    if (lookahead >= 1)
+        st = dcs_seq_plan(seq, static_cast<uint32_t>(lookahead));
+    else
+    {
+        st = dcs_seq_plan_ahead(seq, static_cast<uint32_t>(curLookahead), 2, nullptr);
+        curLookahead = curLookahead * 8 > kMaxLookahead ? kMaxLookahead : curLookahead * 8;     // (Sync() takes it back to the start)
+    }
+    if (st == DCS_OK)
+        st = dcs_seq_decode_view(ctx, seq, &ready, &readyCount, nullptr);
+    if (st != DCS_OK || readyCount == 0)
+    {
+        readyCount = 0;
         return false;
-    Sync();
-    return dcs_seq_stream_playing(seq, ch) != 0;
+    }
+    const uint32_t nb = dcs_seq_host_bytes(seq, nullptr, 0);
+    if (nb != 0)
+    {
+        const size_t at = hostBytes.size();
+        hostBytes.resize(at + nb);
+        dcs_seq_host_bytes(seq, &hostBytes[at], nb);
+    }
+    fatalTick = dcs_seq_fatal_tick(seq);
+    return true;
 }
 
 void DCSDecoderHIP::MainLoop()
@@ -387,37 +479,22 @@ void DCSDecoderHIP::MainLoop()
         errorMessage = "decoder not initialised";
         return;
     }
-    if (ready.empty())
+    if (handedOut == readyCount && !Refill())
     {
-        // run the sequencer `lookahead` ticks ahead and decode them in one launch
-        handedOut = 0;
-        std::vector<int16_t> pcm(static_cast<size_t>(lookahead) * DCS_FRAME_SAMPLES);
-        if (dcs_seq_plan(seq, static_cast<uint32_t>(lookahead)) != DCS_OK
-            || dcs_seq_decode(ctx, seq, pcm.data(), static_cast<size_t>(lookahead), nullptr) != DCS_OK)
-        {
-            memset(outputBuffer, 0, sizeof(outputBuffer));
-            state = State::DecoderFatalError;
-            errorMessage = std::string("HIP decode failed: ") + dcs_last_error(ctx);
-            return;
-        }
-        for (int t = 0 ; t < lookahead ; ++t)
-            ready.emplace_back(pcm.begin() + static_cast<size_t>(t) * DCS_FRAME_SAMPLES,
-                               pcm.begin() + static_cast<size_t>(t + 1) * DCS_FRAME_SAMPLES);
-        const uint32_t nb = dcs_seq_host_bytes(seq, nullptr, 0);
-        if (nb != 0)
-        {
-            std::vector<DcsHostByte> b(nb);
-            dcs_seq_host_bytes(seq, b.data(), nb);
-            hostBytes.insert(hostBytes.end(), b.begin(), b.end());
-        }
+        memset(outputBuffer, 0, sizeof(outputBuffer));
+        state = State::DecoderFatalError;
+        errorMessage = std::string("HIP decode failed: ") + dcs_last_error(ctx);
+        return;
     }
     // this tick's bytes go to the host now, its frame to the output buffer
-    while (!hostBytes.empty() && hostBytes.front().tick <= nextTick)
+    while (hostNext < hostBytes.size() && hostBytes[hostNext].tick <= nextTick)
+        host->ReceiveDataPort(static_cast<uint8_t>(hostBytes[hostNext++].byte));
+    if (hostNext == hostBytes.size() && hostNext != 0)
     {
-        host->ReceiveDataPort(static_cast<uint8_t>(hostBytes.front().byte));
-        hostBytes.pop_front();
+        hostBytes.clear();
+        hostNext = 0;
     }
-    if (dcs_seq_fatal_tick(seq) <= nextTick)
+    if (fatalTick <= nextTick)
     {
         // the reference gives up after four failed passes in a row (DCSDecoder.cpp:1637-1645) and answers THIS call with
         // silence (:1661); the base class, which sees this MainLoop return normally, hands out the buffer's first sample
@@ -429,8 +506,7 @@ void DCSDecoderHIP::MainLoop()
                        "that the ROM image is invalid or corrupted.";
         return;
     }
-    memcpy(outputBuffer, ready.front().data(), sizeof(int16_t) * DCS_FRAME_SAMPLES);
-    ready.pop_front();
+    memcpy(outputBuffer, ready + static_cast<size_t>(handedOut) * DCS_FRAME_SAMPLES, sizeof(int16_t) * DCS_FRAME_SAMPLES);
     ++handedOut;
     ++nextTick;
 }

@@ -38,6 +38,7 @@ struct DcsCtx
     int sharedHostParts = 7;            // how many of the eight parts the host walks (where 16 pool threads settle); follows the measured finish times from call to call
     std::mutex cacheMutex;              // the buffer cache is shared by the pipeline's worker threads
     struct DcsPipeline *internalPipe = nullptr;     // dcs_decode_streams takes large lists through it in parts (dcs_pipeline.hip.h)
+    struct DcsLive *live = nullptr;     // the context's persistent small-batch decoder (dcs_decode_batch_live)
     int numCUs = 256;
     std::string lastError;              // written through setError only (the pipeline's threads fail concurrently)
     std::mutex errMutex;
@@ -353,6 +354,7 @@ static hipError_t waitLaunched(DcsBatch *b)
 
 static std::string g_createError;
 static std::mutex g_createErrorMutex;
+static void liveDestroy(DcsCtx *ctx);
 
 static void setError(DcsCtx *ctx, const std::string &text)
 {
@@ -506,6 +508,7 @@ extern "C" void dcs_ctx_destroy(DcsCtx *ctx)
         return;
     (void)hipSetDevice(ctx->device);
     if (ctx->internalPipe) dcs_pipeline_destroy(ctx->internalPipe);
+    liveDestroy(ctx);
     if (ctx->dTables) (void)hipFree(ctx->dTables);
     if (ctx->dIdxBlob) (void)hipFree(ctx->dIdxBlob);
     if (ctx->dIdxLocs) (void)hipFree(ctx->dIdxLocs);
@@ -685,20 +688,11 @@ static DcsKernelArgs kernelArgs(const DcsBatch *b)
     return args;
 }
 
-// stream: where the batch's uploads, default launches and downloads run (nullptr: the context's); handoff: how tails
-// cross chunk boundaries (DcsCtx::handoff, or forced off for the second attempt after a lost tail)
-static DcsStatus createBatch(DcsCtx *ctx,
-                             const uint8_t *blob, size_t blobLen,
-                             const DcsSrcDesc *srcs, uint32_t nSrcs,
-                             const DcsFrameJob *jobs, uint32_t nJobs,
-                             const int16_t *tailsIn, uint32_t nTailsIn,
-                             hipStream_t stream, bool handoff, DcsBatch **out)
+// The description of a batch is checked on the host: the kernel trusts indices and formats.  *payloadBits = the bits the batch's
+// sources occupy, *batchFlags = DCS_BATCH_HAS_93A_T1 where it applies.
+static DcsStatus validateBatch(DcsCtx *ctx, size_t blobLen, const DcsSrcDesc *srcs, uint32_t nSrcs, const DcsFrameJob *jobs, uint32_t nJobs,
+                               const int16_t *tailsIn, uint32_t nTailsIn, uint64_t *payloadBitsOut, uint32_t *batchFlagsOut)
 {
-    if (ctx == nullptr || out == nullptr || jobs == nullptr || nJobs == 0 || (nSrcs != 0 && (srcs == nullptr || blob == nullptr)))
-        return DCS_ERR_INVALID_ARG;
-    *out = nullptr;
-
-    // validate the description on the host: the kernel trusts indices and formats
     uint64_t payloadBits = 0;
     uint32_t batchFlags = 0;
     for (uint32_t j = 0 ; j < nJobs ; ++j)
@@ -759,6 +753,32 @@ static DcsStatus createBatch(DcsCtx *ctx,
         payloadBits += sd.idx.nBits;
         if (sd.format == DCS_FMT_93A_T1)
             batchFlags |= DCS_BATCH_HAS_93A_T1;
+    }
+
+    *payloadBitsOut = payloadBits;
+    *batchFlagsOut = batchFlags;
+    return DCS_OK;
+}
+
+// stream: where the batch's uploads, default launches and downloads run (nullptr: the context's); handoff: how tails
+// cross chunk boundaries (DcsCtx::handoff, or forced off for the second attempt after a lost tail)
+static DcsStatus createBatch(DcsCtx *ctx,
+                             const uint8_t *blob, size_t blobLen,
+                             const DcsSrcDesc *srcs, uint32_t nSrcs,
+                             const DcsFrameJob *jobs, uint32_t nJobs,
+                             const int16_t *tailsIn, uint32_t nTailsIn,
+                             hipStream_t stream, bool handoff, DcsBatch **out)
+{
+    if (ctx == nullptr || out == nullptr || jobs == nullptr || nJobs == 0 || (nSrcs != 0 && (srcs == nullptr || blob == nullptr)))
+        return DCS_ERR_INVALID_ARG;
+    *out = nullptr;
+
+    uint64_t payloadBits = 0;
+    uint32_t batchFlags = 0;
+    {
+        const DcsStatus vst = validateBatch(ctx, blobLen, srcs, nSrcs, jobs, nJobs, tailsIn, nTailsIn, &payloadBits, &batchFlags);
+        if (vst != DCS_OK)
+            return vst;
     }
 
     DcsBatch *b = new (std::nothrow) DcsBatch;
@@ -1694,6 +1714,250 @@ extern "C" uint32_t dcs_batch_num_chunks(const DcsBatch *b) { return b ? b->nChu
 extern "C" int dcs_batch_frames_per_wave(const DcsBatch *b) { return b ? b->fpw : 0; }
 extern "C" uint32_t dcs_batch_num_jobs(const DcsBatch *b) { return b ? b->nJobs : 0; }
 
+// ---------------------------------------------------------------------------------------------------------
+// The context's LIVE decoder: dcs_decode_batch for a caller that comes back every few frames (DCSDecoderHIP's sample pump, the
+// sequencer, small one-shot calls).  Round 5's one-shot call made a batch object per call: a planner and packer run into freshly
+// borrowed buffers, three events, three memsets, an upload, the launch and two synchronous downloads -- 80 us for ONE frame, when
+// the reference's whole pump takes 4 us a frame.  Here everything that can outlive a call does:
+//   * one pinned arena for what goes up (the external tails, the descriptors of multi-channel frames, the chunk packages) and one
+//     for what comes down (PCM, error words, every frame's tail), grown geometrically, never given back before the context goes;
+//   * small batches are not copied at all: the kernel reads its packages from the pinned arena and writes its PCM into the
+//     pinned arena over the link (a package is read once, 16 bytes per lane; the PCM of a few dozen frames is a few kilobytes),
+//     so a call is ONE launch and ONE wait.  Larger ones get one copy up, one copy down (PCM, error words and tails are one
+//     block), queued with the launch and waited for once;
+//   * the hand-off words live as long as the context and are told apart by a launch counter (epoch) that only grows, so nothing
+//     is cleared per call; the kernel writes every error word itself;
+//   * the streams behind the SECOND and later sources of multi-channel frames stay resident: a caller that names its blob
+//     (blobId != 0, append-only under that name) has every byte of it uploaded once, when it first appears.
+// Results are handed out as pointers into the pinned arena, valid until the context's next live call.
+// ---------------------------------------------------------------------------------------------------------
+struct DcsLive
+{
+    uint8_t *hUp = nullptr, *dUp = nullptr, *hDown = nullptr, *dDown = nullptr, *dBlob = nullptr;
+    size_t hUpCap = 0, dUpCap = 0, hDownCap = 0, dDownCap = 0, blobCap = 0;
+    unsigned long long *dHandoff = nullptr;
+    size_t handoffChunks = 0;
+    uint32_t epoch = 0;
+    size_t blobResident = 0;            // bytes of the named blob that are on the device
+    size_t blobDirty = 0;               // bytes of the device blob written since it was last cleared
+    uint64_t blobId = 0;
+    std::vector<DcsSlot> slots;
+    // what a call may leave to the link instead of a copy (bytes up, frames down); DCS_LIVE_ZC_UP_KB / DCS_LIVE_ZC_DOWN_FRAMES
+    size_t zcUpBytes = size_t(256) << 10;
+    uint32_t zcDownFrames = 64;
+};
+
+static void liveDestroy(DcsCtx *ctx)
+{
+    DcsLive *l = ctx->live;
+    if (l == nullptr)
+        return;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (l->hUp) (void)hipHostFree(l->hUp);
+    if (l->hDown) (void)hipHostFree(l->hDown);
+    for (void *p : { static_cast<void *>(l->dUp), static_cast<void *>(l->dDown), static_cast<void *>(l->dBlob), static_cast<void *>(l->dHandoff) })
+        if (p) (void)hipFree(p);
+    delete l;
+    ctx->live = nullptr;
+}
+
+// room for `bytes` in one of the live arenas (pinned or device); what it held is not kept
+static hipError_t liveRoom(uint8_t **buf, size_t *cap, size_t bytes, bool pinned)
+{
+    if (bytes <= *cap)
+        return hipSuccess;
+    if (*buf != nullptr)
+    {
+        (void)(pinned ? hipHostFree(*buf) : hipFree(*buf));
+        *buf = nullptr;
+        *cap = 0;
+    }
+    const size_t want = std::max((bytes + 65535) & ~size_t(65535), *cap * 2);
+    void *p = nullptr;
+    hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+    if (e != hipSuccess && want != ((bytes + 65535) & ~size_t(65535)))
+    {
+        (void)hipGetLastError();
+        e = pinned ? hipHostMalloc(&p, (bytes + 65535) & ~size_t(65535), hipHostMallocDefault) : hipMalloc(&p, (bytes + 65535) & ~size_t(65535));
+    }
+    if (e != hipSuccess)
+        return e;
+    *buf = static_cast<uint8_t *>(p);
+    *cap = want;
+    return hipSuccess;
+}
+
+// batches beyond this go the resident-batch way (buffers from the context's bounded cache): the live arenas never shrink
+static const uint32_t kLiveMaxJobs = 1u << 17;
+
+static DcsStatus decodeLive(DcsCtx *ctx, const uint8_t *blob, size_t blobLen, uint64_t blobId,
+                            const DcsSrcDesc *srcs, uint32_t nSrcs, const DcsFrameJob *jobs, uint32_t nJobs,
+                            const int16_t *tailsIn, uint32_t nTailsIn,
+                            const int16_t **pcmOut, const uint32_t **errOut, const int16_t **tailsOut)
+{
+    uint64_t payloadBits = 0;
+    uint32_t batchFlags = 0;
+    {
+        const DcsStatus vst = validateBatch(ctx, blobLen, srcs, nSrcs, jobs, nJobs, tailsIn, nTailsIn, &payloadBits, &batchFlags);
+        if (vst != DCS_OK)
+            return vst;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->live == nullptr)
+    {
+        ctx->live = new (std::nothrow) DcsLive;
+        if (ctx->live == nullptr)
+            return DCS_ERR_NO_MEMORY;
+        if (const char *v = getenv("DCS_LIVE_ZC_UP_KB")) ctx->live->zcUpBytes = static_cast<size_t>(atol(v)) << 10;
+        if (const char *v = getenv("DCS_LIVE_ZC_DOWN_FRAMES")) ctx->live->zcDownFrames = static_cast<uint32_t>(atol(v));
+    }
+    DcsLive *l = ctx->live;
+    bool all94 = true, multi = false;
+    for (uint32_t j = 0 ; j < nJobs ; ++j)
+    {
+        all94 = all94 && jobs[j].xform == DCS_XFORM_94;
+        multi = multi || jobs[j].nSrc > 1;
+    }
+    const int fpw = chooseFpw(ctx, nJobs, all94);
+    const bool split4 = dcsAllSources94(jobs, nJobs, srcs);
+
+    // the streams behind further sources: resident under the caller's name for the blob, else uploaded for this call
+    if (multi)
+    {
+        const size_t need = ((blobLen + 3) & ~size_t(3)) + 64;          // zero tail: the bit reader looks past the end
+        const bool reuse = blobId != 0 && blobId == l->blobId && blobLen >= l->blobResident && need <= l->blobCap;
+        if (!reuse)
+        {
+            if (need > l->blobCap)
+            {
+                HIPCHK(ctx, liveRoom(&l->dBlob, &l->blobCap, blobId != 0 ? need * 2 : need, false));
+                HIPCHK(ctx, hipMemsetAsync(l->dBlob, 0, l->blobCap, ctx->stream));
+            }
+            else if (l->blobDirty != 0)                                 // (what another blob left there must not show behind this one's end)
+                HIPCHK(ctx, hipMemsetAsync(l->dBlob, 0, std::min(l->blobCap, ((l->blobDirty + 3) & ~size_t(3)) + 64), ctx->stream));
+            l->blobDirty = 0;
+            l->blobResident = 0;
+            l->blobId = blobId;
+        }
+        if (blobLen > l->blobResident)
+        {
+            HIPCHK(ctx, hipMemcpyAsync(l->dBlob + l->blobResident, blob + l->blobResident, blobLen - l->blobResident, hipMemcpyHostToDevice, ctx->stream));
+            l->blobDirty = std::max(l->blobDirty, blobLen);
+            if (blobId != 0)
+                l->blobResident = blobLen;                              // (an unnamed blob is nobody's next time)
+        }
+    }
+
+    const size_t pcmBytes = static_cast<size_t>(nJobs) * DCS_FRAME_SAMPLES * sizeof(int16_t), errBytes = static_cast<size_t>(nJobs) * sizeof(uint32_t);
+    const size_t downBytes = pcmBytes + errBytes + static_cast<size_t>(nJobs) * 16 * sizeof(int16_t);
+    const bool zcDown = nJobs <= l->zcDownFrames;
+    HIPCHK(ctx, liveRoom(&l->hDown, &l->hDownCap, downBytes, true));
+    if (!zcDown)
+        HIPCHK(ctx, liveRoom(&l->dDown, &l->dDownCap, downBytes, false));
+
+    static const bool forceNoRanges = getenv("DCS_BATCH_XCD_RANGES") != nullptr && atoi(getenv("DCS_BATCH_XCD_RANGES")) == 0;
+    for (int attempt = 0 ; attempt < 2 ; ++attempt)
+    {
+        // (the second attempt, after a lost tail: every predecessor decoded again next to its successor -- see dcs_decode_batch)
+        const bool handoff = ctx->handoff && attempt == 0;
+        const uint32_t nChunks = dcsPlanChunks(jobs, nJobs, srcs, fpw, l->slots, handoff, ctx->framesPerChunk, false, true);
+        const uint32_t layout = dcsImageDwords(l->slots.data(), nChunks, fpw) | (split4 ? DCS_PKG_SPLIT4 : 0u);
+        if (ctx->dropExports)
+            for (DcsSlot &sl : l->slots)
+                sl.flags &= static_cast<uint8_t>(~DCS_SLOT_EXPORT);      // test hook: imports without a producer
+
+        // what goes up, in one block: external tails | descriptors (only multi-channel frames read them) | chunk packages
+        const size_t tailBytes = static_cast<size_t>(nTailsIn) * 16 * sizeof(int16_t);
+        const size_t offSrcs = (tailBytes + 255) & ~size_t(255);
+        const size_t srcBytes = multi ? static_cast<size_t>(nSrcs) * sizeof(DcsSrcDesc) : 0;
+        const size_t offPkg = (offSrcs + srcBytes + 255) & ~size_t(255);
+        const size_t pkgBytes = static_cast<size_t>(nChunks) * dcsPkgStride(fpw, layout);
+        const size_t upBytes = offPkg + pkgBytes;
+        HIPCHK(ctx, liveRoom(&l->hUp, &l->hUpCap, upBytes, true));
+        if (tailBytes)
+            memcpy(l->hUp, tailsIn, tailBytes);
+        if (srcBytes)
+            memcpy(l->hUp + offSrcs, srcs, srcBytes);
+        dcsBuildPackages(l->slots.data(), nChunks, fpw, srcs, blob, blobLen, l->hUp + offPkg, layout);
+        const bool zcUp = upBytes <= l->zcUpBytes;
+        if (!zcUp)
+        {
+            HIPCHK(ctx, liveRoom(&l->dUp, &l->dUpCap, upBytes, false));
+            HIPCHK(ctx, hipMemcpyAsync(l->dUp, l->hUp, upBytes, hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (nChunks + 1 > l->handoffChunks)
+        {
+            if (l->dHandoff) (void)hipFree(l->dHandoff);
+            l->dHandoff = nullptr;
+            l->handoffChunks = std::max<size_t>(size_t(nChunks) + 1, std::max<size_t>(l->handoffChunks * 2, 1024));
+            HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&l->dHandoff), l->handoffChunks * 16 * sizeof(unsigned long long)));
+            HIPCHK(ctx, hipMemsetAsync(l->dHandoff, 0, l->handoffChunks * 16 * sizeof(unsigned long long), ctx->stream));
+        }
+        if (++l->epoch == 0)
+        {
+            // the launch counter has come round: words of 2^32 launches ago must not pass for this launch's
+            HIPCHK(ctx, hipMemsetAsync(l->dHandoff, 0, l->handoffChunks * 16 * sizeof(unsigned long long), ctx->stream));
+            l->epoch = 1;
+        }
+        uint8_t *up = zcUp ? l->hUp : l->dUp, *down = zcDown ? l->hDown : l->dDown;
+        DcsKernelArgs args;
+        args.blob = multi ? l->dBlob : nullptr;
+        args.blobLen = multi ? blobLen : 0;
+        args.srcs = multi ? reinterpret_cast<const DcsSrcDesc *>(up + offSrcs) : nullptr;
+        args.packages = up + offPkg;
+        args.nChunks = nChunks;
+        args.nJobs = nJobs;
+        args.pcm = reinterpret_cast<int16_t *>(down);
+        args.err = reinterpret_cast<uint32_t *>(down + pcmBytes);
+        args.tailsIn = nTailsIn ? reinterpret_cast<const int16_t *>(up) : nullptr;
+        args.tailsOut = reinterpret_cast<int16_t *>(down + pcmBytes + errBytes);
+        args.tables = ctx->dTables;
+        args.debug = nullptr;
+        args.handoff = l->dHandoff;
+        args.epoch = l->epoch;
+        args.flags = batchFlags | ((handoff && !forceNoRanges) ? DCS_BATCH_XCD_RANGES : 0u) | (layout << DCS_BATCH_IMG_SHIFT);
+        args.timeoutTicks = ctx->handoffTimeoutTicks;
+        const hipError_t e = fpw == 16 ? launch<16>(args, ctx->stream) : fpw == 8 ? launch<8>(args, ctx->stream) : launch<4>(args, ctx->stream);
+        if (e != hipSuccess)
+        {
+            setError(ctx, std::string("kernel launch failed: ") + hipGetErrorString(e));
+            (void)streamWait(ctx, ctx->stream);
+            return DCS_ERR_HIP;
+        }
+        if (!zcDown)
+            HIPCHK(ctx, hipMemcpyAsync(l->hDown, l->dDown, downBytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, streamWait(ctx, ctx->stream));
+        bool lost = false;
+        if (handoff)
+        {
+            const uint32_t *ew = reinterpret_cast<const uint32_t *>(l->hDown + pcmBytes);
+            for (uint32_t j = 0 ; j < nJobs && !lost ; ++j)
+                lost = (ew[j] & DCS_FRAME_TAIL_LOST) != 0;
+        }
+        if (!lost)
+            break;
+    }
+    if (pcmOut) *pcmOut = reinterpret_cast<const int16_t *>(l->hDown);
+    if (errOut) *errOut = reinterpret_cast<const uint32_t *>(l->hDown + pcmBytes);
+    if (tailsOut) *tailsOut = reinterpret_cast<const int16_t *>(l->hDown + pcmBytes + errBytes);
+    return DCS_OK;
+}
+
+extern "C" DcsStatus dcs_decode_batch_live(DcsCtx *ctx, const uint8_t *blob, size_t blobLen, uint64_t blobId,
+                                           const DcsSrcDesc *srcs, uint32_t nSrcs, const DcsFrameJob *jobs, uint32_t nJobs,
+                                           const int16_t *tailsIn, uint32_t nTailsIn,
+                                           const int16_t **pcmOut, const uint32_t **errOut, const int16_t **tailsOut)
+{
+    if (ctx == nullptr || jobs == nullptr || nJobs == 0 || (nSrcs != 0 && (srcs == nullptr || blob == nullptr)))
+        return DCS_ERR_INVALID_ARG;
+    if (nJobs > kLiveMaxJobs)
+    {
+        setError(ctx, "dcs_decode_batch_live: more than 131 072 frames in one call (use dcs_decode_batch or a resident batch)");
+        return DCS_ERR_CAPACITY;
+    }
+    return decodeLive(ctx, blob, blobLen, blobId, srcs, nSrcs, jobs, nJobs, tailsIn, nTailsIn, pcmOut, errOut, tailsOut);
+}
+
 extern "C" DcsStatus dcs_decode_batch(DcsCtx *ctx,
                                       const uint8_t *blob, size_t blobLen,
                                       const DcsSrcDesc *srcs, uint32_t nSrcs,
@@ -1703,6 +1967,19 @@ extern "C" DcsStatus dcs_decode_batch(DcsCtx *ctx,
 {
     if (ctx == nullptr)
         return DCS_ERR_INVALID_ARG;
+    if (jobs != nullptr && nJobs != 0 && nJobs <= kLiveMaxJobs && !(nSrcs != 0 && (srcs == nullptr || blob == nullptr)))
+    {
+        // the context's live decoder: no batch object, nothing allocated, one launch, one wait; the results are copied out
+        const int16_t *pcm = nullptr, *tails = nullptr;
+        const uint32_t *err = nullptr;
+        const DcsStatus st = decodeLive(ctx, blob, blobLen, 0, srcs, nSrcs, jobs, nJobs, tailsIn, nTailsIn, &pcm, &err, &tails);
+        if (st != DCS_OK)
+            return st;
+        if (pcmOut) memcpy(pcmOut, pcm, static_cast<size_t>(nJobs) * DCS_FRAME_SAMPLES * sizeof(int16_t));
+        if (errOut) memcpy(errOut, err, static_cast<size_t>(nJobs) * sizeof(uint32_t));
+        if (tailsOut) memcpy(tailsOut, tails, static_cast<size_t>(nJobs) * 16 * sizeof(int16_t));
+        return DCS_OK;
+    }
     // Tails cross chunk boundaries through the hand-off buffer, which rests on the producing wavefront having been
     // dispatched when its consumer waits for it: chunks are dispatched in index order on this hardware, but nothing
     // promises it.  A consumer that waited in vain flags its frame DCS_FRAME_TAIL_LOST; the batch is then decoded again

@@ -15,6 +15,7 @@
 // reference's ResetException path; a zero-frame stream is not played.
 #include "dcs_rom.h"
 #include <string.h>
+#include <atomic>
 #include <deque>
 #include <map>
 #include <memory>
@@ -75,6 +76,7 @@ struct VmState
     bool fatal = false;
     uint64_t fatalTick = 0;                 // the first tick that produced silence because of it
     uint64_t tick = 0;
+    uint32_t idleRun = 0;                   // ticks in a row that began and ended with nothing playing, nothing queued, no program, no timer
 };
 
 }   // namespace
@@ -94,16 +96,77 @@ struct DcsSequencer : VmState
     std::vector<DcsSrcDesc> srcs;
     std::vector<DcsFrameJob> jobs;
     std::vector<DcsHostByte> hostBytes;
-    std::vector<VmState> history;           // history[k] = state after k ticks of the current batch ([0] = before it)
-    std::vector<size_t> srcsAfter;          // srcs.size() after each tick of the current batch
+    // Going back inside the current batch (dcs_seq_rewind).  A snapshot of the machine costs a microsecond (two queues, eight loop
+    // stacks), a tick a tenth of that, and the machine is deterministic: so a snapshot is kept every kSnapStride ticks only, and
+    // going back to tick k means restoring the last snapshot at or before k and running the ticks in between again, with the bytes
+    // for the host (which were already handed out) suppressed.  (Round 5 kept one per tick: 2 KB and a microsecond a frame.)
+    struct Snapshot { uint32_t ticks; size_t nSrcs; VmState st; };
+    static const uint32_t kSnapStride = 64;
+    std::vector<Snapshot> history;          // ascending by ticks; history[0].ticks == 0: the state the batch started from
+    std::vector<uint8_t> playingAfter;      // per tick of the current batch: which channels have a stream loaded after it (IsStreamPlaying)
     std::vector<int16_t> batchTails;        // after a decode: the 16-sample tail each tick of the batch left
     int16_t batchTail0[16] = { 0 };         // ... and the tail the batch started from
     bool batchDecoded = false;
-    bool keepHistory = false;               // dcs_seq_set_rewindable: a snapshot per tick (about 2 KB each)
+    bool keepHistory = false;               // dcs_seq_set_rewindable
+    bool replaying = false;                 // ticks run again by dcs_seq_rewind: nothing goes to the host twice
     int16_t tail[16] = { 0 };
+    uint64_t blobId = 0;                    // names the blob for the context's live decoder: append-only under one name (dcs_decode_batch_live)
     std::string lastError;
 
-    void toHost(uint8_t b) { hostBytes.push_back(DcsHostByte{ static_cast<uint32_t>(tick), static_cast<uint32_t>(b) }); }
+    void toHost(uint8_t b)
+    {
+        if (!replaying)
+            hostBytes.push_back(DcsHostByte{ static_cast<uint32_t>(tick), static_cast<uint32_t>(b) });
+    }
+    uint32_t batchTicks() const { return static_cast<uint32_t>(playingAfter.size()); }
+    bool quiescent() const
+    {
+        if (!commandQueue.empty() || !dataPortQueue.empty())
+            return false;
+        for (const Chan &c : ch)
+            if (c.st != nullptr || !c.track.isNull() || c.timer.interval != 0 || c.stop)
+                return false;
+        return true;
+    }
+    uint8_t playingMask() const
+    {
+        uint8_t m = 0;
+        for (int c = 0 ; c < DCS_MAX_CHANNELS ; ++c)
+            if (ch[c].st != nullptr)
+                m |= static_cast<uint8_t>(1u << c);
+        return m;
+    }
+    void startBatch()
+    {
+        batchDecoded = false;
+        history.clear();
+        history.push_back(Snapshot{ 0, srcs.size(), static_cast<const VmState &>(*this) });
+        playingAfter.clear();
+        batchTails.clear();
+    }
+    // A command from outside (data port, track command, volume, a stream loaded, tracks cleared) changes the machine where it
+    // stands, behind the batch's last tick: going back to any LATER tick must run from a state that has the command in it, so the
+    // state right behind the command becomes the snapshot of that tick.
+    void noteCommand()
+    {
+        if (history.empty())
+            return;
+        if (history.back().ticks == batchTicks())
+        {
+            history.back().st = static_cast<const VmState &>(*this);
+            history.back().nSrcs = srcs.size();
+        }
+        else if (keepHistory)
+            history.push_back(Snapshot{ batchTicks(), srcs.size(), static_cast<const VmState &>(*this) });
+    }
+    void tickDone(bool wasQuiet)            // bookkeeping behind every tick of a batch (wasQuiet: quiescent when the tick began)
+    {
+        idleRun = wasQuiet && quiescent() ? idleRun + 1 : 0;
+        playingAfter.push_back(playingMask());
+        if (keepHistory && batchTicks() % kSnapStride == 0 && history.back().ticks != batchTicks())
+            history.push_back(Snapshot{ batchTicks(), srcs.size(), static_cast<const VmState &>(*this) });
+    }
+    void advance(uint32_t nTicks, uint32_t stopWhenIdleFor, uint32_t *ran);
     Chan &chan(uint32_t c)
     {
         if (c >= DCS_MAX_CHANNELS)
@@ -119,6 +182,7 @@ struct DcsSequencer : VmState
     const StreamEntry *streamAt(DcsRomCursor p);
     const StreamEntry *addStream(const uint8_t *data, size_t avail, std::pair<const void *, size_t> key, bool cache);
     void compact();
+    static uint64_t newBlobId();
     void loadAudioStream(uint32_t streamChannel, int sourceChannel, uint32_t loopCounter, DcsRomCursor p);
     void loadStreamEntry(uint32_t streamChannel, int sourceChannel, uint32_t loopCounter, const StreamEntry *e);
     void loadTrack(uint32_t c, DcsRomCursor p);
@@ -167,6 +231,12 @@ const StreamEntry *DcsSequencer::addStream(const uint8_t *data, size_t avail, st
     return r;
 }
 
+uint64_t DcsSequencer::newBlobId()
+{
+    static std::atomic<uint64_t> next{1};
+    return next.fetch_add(1);
+}
+
 // Between batches: when the blob has grown large (a long-running decoder keeps loading streams), keep only the
 // streams a channel is still playing.
 void DcsSequencer::compact()
@@ -195,6 +265,7 @@ void DcsSequencer::compact()
         if (playing(it->get())) { keep(it->get()); ++it; }
         else it = uncached.erase(it);
     blob.swap(fresh);
+    blobId = newBlobId();                   // (what the live decoder keeps resident under the old name is no longer this blob)
 }
 
 // LoadAudioStream (:1408-1431) + InitChannelStream (:1433-1463)
@@ -628,7 +699,8 @@ extern "C" DcsSequencer *dcs_seq_create_standalone(DcsOsVersion os)
     s->emptyRoms.os = os;
     s->rs = &s->emptyRoms;
     s->os = os;
-    s->history.push_back(*s);
+    s->blobId = DcsSequencer::newBlobId();
+    s->startBatch();
     return s;
 }
 
@@ -650,7 +722,8 @@ extern "C" DcsSequencer *dcs_seq_create(const DcsRomSet *rs)
         while (k < sizeof(key) - 1 && (u2[i + k] | 0x20) == key[k]) ++k;
         if (k == sizeof(key) - 1) { s->totan = true; break; }
     }
-    s->history.push_back(*s);
+    s->blobId = DcsSequencer::newBlobId();
+    s->startBatch();
     return s;
 }
 
@@ -661,6 +734,7 @@ extern "C" DcsStatus dcs_seq_set_master_volume(DcsSequencer *s, int vol)
 {
     if (s == nullptr) return DCS_ERR_INVALID_ARG;
     s->volumeMultiplier = dcs_volume_multiplier(vol);
+    s->noteCommand();
     return DCS_OK;
 }
 
@@ -675,6 +749,7 @@ extern "C" DcsStatus dcs_seq_write_data_port(DcsSequencer *s, uint8_t byte)
 {
     if (s == nullptr) return DCS_ERR_INVALID_ARG;
     s->dataPortQueue.push_back(byte);
+    s->noteCommand();
     return DCS_OK;
 }
 
@@ -682,6 +757,7 @@ extern "C" DcsStatus dcs_seq_add_track_command(DcsSequencer *s, uint16_t track)
 {
     if (s == nullptr) return DCS_ERR_INVALID_ARG;
     s->commandQueue.push_back(track);
+    s->noteCommand();
     return DCS_OK;
 }
 
@@ -693,6 +769,7 @@ extern "C" DcsStatus dcs_seq_clear_tracks(DcsSequencer *s)       // :1466-1473
         c.track.clear();
         c.st = nullptr;
     }
+    s->noteCommand();
     return DCS_OK;
 }
 
@@ -705,6 +782,7 @@ extern "C" DcsStatus dcs_seq_load_audio_stream(DcsSequencer *s, int channel, uin
     Mixer &m = c.mixer[channel];
     m.reset();
     m.cur = m.target = mixingLevel * 64;
+    s->noteCommand();
     return DCS_OK;
 }
 
@@ -720,6 +798,7 @@ extern "C" DcsStatus dcs_seq_load_audio_stream_mem(DcsSequencer *s, int channel,
     Mixer &m = c.mixer[channel];
     m.reset();
     m.cur = m.target = mixingLevel * 64;
+    s->noteCommand();
     return DCS_OK;
 }
 
@@ -732,52 +811,21 @@ extern "C" DcsStatus dcs_seq_set_rewindable(DcsSequencer *s, int on)
     if (s == nullptr || !s->jobs.empty())
         return DCS_ERR_INVALID_ARG;             // only between batches
     s->keepHistory = on != 0;
-    s->batchDecoded = false;
-    s->history.assign(1, static_cast<const VmState &>(*s));
-    s->srcsAfter.clear();
-    s->batchTails.clear();
+    s->startBatch();
     return DCS_OK;
 }
 
-extern "C" DcsStatus dcs_seq_rewind(DcsSequencer *s, uint32_t keepTicks)
+// `nTicks` ticks further (or fewer: once the machine has been quiescent for `stopWhenIdleFor` ticks in a row, 0 = never stop);
+// every tick appends one frame job to the pending plan.  Bytes written to the data port since the last tick are handled first, as
+// the sample pump does (DCSDecoder.cpp:1617).
+void DcsSequencer::advance(uint32_t nTicks, uint32_t stopWhenIdleFor, uint32_t *ran)
 {
-    if (s == nullptr || !s->keepHistory || keepTicks + 1 > s->history.size())
-        return DCS_ERR_INVALID_ARG;
-    const uint64_t firstTick = s->history[0].tick;
-    static_cast<VmState &>(*s) = s->history[keepTicks];
-    s->history.resize(keepTicks + 1);
-    while (!s->hostBytes.empty() && s->hostBytes.back().tick >= firstTick + keepTicks)
-        s->hostBytes.pop_back();
-    if (s->batchDecoded)
-    {
-        memcpy(s->tail, keepTicks == 0 ? s->batchTail0 : &s->batchTails[(keepTicks - 1) * 16], sizeof(s->tail));
-        s->batchTails.resize(static_cast<size_t>(keepTicks) * 16);
-    }
-    else
-    {
-        s->jobs.resize(keepTicks);
-        s->srcs.resize(keepTicks == 0 ? 0 : s->srcsAfter[keepTicks - 1]);
-        s->srcsAfter.resize(keepTicks);
-    }
-    return DCS_OK;
-}
-
-// Run the sequencer `nTicks` ticks further; every tick appends one frame job to the pending plan.  Bytes
-// written to the data port since the last tick are handled first, as the sample pump does (DCSDecoder.cpp:1617).
-extern "C" DcsStatus dcs_seq_plan(DcsSequencer *s, uint32_t nTicks)
-{
-    if (s == nullptr) return DCS_ERR_INVALID_ARG;
-    if (s->batchDecoded)
-    {
-        // a new batch starts: the previous one can no longer be rewound into
-        s->batchDecoded = false;
-        s->history.assign(1, static_cast<const VmState &>(*s));
-        s->srcsAfter.clear();
-        s->batchTails.clear();
-        s->compact();
-    }
+    DcsSequencer *s = this;
+    uint32_t done = 0;
     for (uint32_t t = 0 ; t < nTicks ; ++t)
     {
+        if (stopWhenIdleFor != 0 && done != 0 && s->idleRun >= stopWhenIdleFor)
+            break;
         if (s->fatal)
         {
             // DecoderFatalError: silence from here on (DCSDecoder.cpp:1672-1675)
@@ -789,9 +837,11 @@ extern "C" DcsStatus dcs_seq_plan(DcsSequencer *s, uint32_t nTicks)
             jb.flags = 0;
             s->jobs.push_back(jb);
             ++s->tick;
-            if (s->keepHistory) { s->srcsAfter.push_back(s->srcs.size()); s->history.push_back(*s); }
+            ++done;
+            s->tickDone(true);
             continue;
         }
+        const bool wasQuiet = s->quiescent();
         while (!s->dataPortQueue.empty())
         {
             s->lastDataPortByte = s->dataPortQueue.front();
@@ -826,8 +876,85 @@ extern "C" DcsStatus dcs_seq_plan(DcsSequencer *s, uint32_t nTicks)
             continue;
         }
         ++s->tick;
-        if (s->keepHistory) { s->srcsAfter.push_back(s->srcs.size()); s->history.push_back(*s); }
+        ++done;
+        s->tickDone(wasQuiet);
     }
+    if (ran != nullptr)
+        *ran = done;
+}
+
+extern "C" DcsStatus dcs_seq_rewind(DcsSequencer *s, uint32_t keepTicks)
+{
+    if (s == nullptr || !s->keepHistory || keepTicks > s->batchTicks())
+        return DCS_ERR_INVALID_ARG;
+    if (keepTicks == s->batchTicks() && !s->history.empty())
+        return DCS_OK;                          // nothing behind it to drop
+    const uint64_t firstTick = s->history[0].st.tick;
+    // the last snapshot at or before the tick asked for, then the ticks in between once more
+    size_t k = s->history.size() - 1;
+    while (s->history[k].ticks > keepTicks)
+        --k;
+    s->history.resize(k + 1);
+    const DcsSequencer::Snapshot &snap = s->history[k];
+    static_cast<VmState &>(*s) = snap.st;
+    const uint32_t from = snap.ticks;
+    s->playingAfter.resize(from);
+    while (!s->hostBytes.empty() && s->hostBytes.back().tick >= firstTick + keepTicks)
+        s->hostBytes.pop_back();
+    if (s->batchDecoded)
+    {
+        memcpy(s->tail, keepTicks == 0 ? s->batchTail0 : &s->batchTails[(keepTicks - 1) * 16], sizeof(s->tail));
+        s->batchTails.resize(static_cast<size_t>(keepTicks) * 16);
+    }
+    else
+    {
+        s->jobs.resize(from);
+        s->srcs.resize(snap.nSrcs);
+    }
+    if (keepTicks > from)
+    {
+        s->replaying = true;
+        s->advance(keepTicks - from, 0, nullptr);
+        s->replaying = false;
+        if (s->batchDecoded)
+        {
+            s->jobs.clear();                    // (these frames have been decoded already)
+            s->srcs.clear();
+        }
+    }
+    return DCS_OK;
+}
+
+// Run the sequencer `nTicks` ticks further; every tick appends one frame job to the pending plan.
+extern "C" DcsStatus dcs_seq_plan(DcsSequencer *s, uint32_t nTicks)
+{
+    if (s == nullptr) return DCS_ERR_INVALID_ARG;
+    if (s->batchDecoded)
+    {
+        // a new batch starts: the previous one can no longer be rewound into
+        s->startBatch();
+        s->compact();
+    }
+    s->advance(nTicks, 0, nullptr);
+    return DCS_OK;
+}
+
+// The same for a caller that decodes AHEAD of what it has been asked for (DCSDecoderHIP's sample pump): at most maxTicks, at least
+// one, and no further than idleTicks ticks into silence -- once nothing plays, no program runs, no timer is set and nothing is
+// queued, every further frame is digital silence until the next command, and a command takes the caller back (dcs_seq_rewind)
+// anyway.  idleTicks = 2 covers the frame that carries the last overlap tail out and one of silence (DCSExplorer.cpp:1674).
+extern "C" DcsStatus dcs_seq_plan_ahead(DcsSequencer *s, uint32_t maxTicks, uint32_t idleTicks, uint32_t *plannedOut)
+{
+    if (s == nullptr || maxTicks == 0) return DCS_ERR_INVALID_ARG;
+    if (s->batchDecoded)
+    {
+        s->startBatch();
+        s->compact();
+    }
+    uint32_t ran = 0;
+    s->advance(maxTicks, idleTicks, &ran);
+    if (plannedOut != nullptr)
+        *plannedOut = ran;
     return DCS_OK;
 }
 
@@ -838,6 +965,16 @@ extern "C" uint64_t dcs_seq_fatal_tick(const DcsSequencer *s) { return s != null
 extern "C" int dcs_seq_stream_playing(const DcsSequencer *s, int channel)
 {
     return s != nullptr && channel >= 0 && channel < DCS_MAX_CHANNELS && s->ch[channel].st != nullptr ? 1 : 0;
+}
+
+// ... as it was after the first `ticks` ticks of the current batch (planned or just decoded), without going back there
+extern "C" int dcs_seq_stream_playing_at(const DcsSequencer *s, uint32_t ticks, int channel)
+{
+    if (s == nullptr || channel < 0 || channel >= DCS_MAX_CHANNELS || ticks > s->batchTicks() || s->history.empty())
+        return 0;
+    if (ticks == 0)
+        return s->history[0].st.ch[channel].st != nullptr ? 1 : 0;
+    return (s->playingAfter[ticks - 1] >> channel) & 1;
 }
 
 extern "C" uint32_t dcs_seq_host_bytes(DcsSequencer *s, DcsHostByte *out, uint32_t cap)
@@ -853,7 +990,39 @@ extern "C" uint32_t dcs_seq_host_bytes(DcsSequencer *s, DcsHostByte *out, uint32
     return n;
 }
 
-// Decode everything planned since the last call in ONE launch; the overlap tail carries over to the next call.
+// Decode everything planned since the last call in ONE launch; the overlap tail carries over to the next call.  The PCM (and
+// error words) stay where the context's live decoder put them -- pinned memory, valid until the context decodes again.
+extern "C" DcsStatus dcs_seq_decode_view(DcsCtx *ctx, DcsSequencer *s, const int16_t **pcmOut, uint32_t *nFramesOut, const uint32_t **errOut)
+{
+    if (ctx == nullptr || s == nullptr || pcmOut == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    const size_t n = s->jobs.size();
+    *pcmOut = nullptr;
+    if (nFramesOut != nullptr)
+        *nFramesOut = static_cast<uint32_t>(n);
+    if (n == 0)
+        return DCS_OK;
+    if (s->blob.empty())
+        s->blob.assign(16, 0);
+    const int16_t *tails = nullptr;
+    const DcsStatus st = dcs_decode_batch_live(ctx, s->blob.data(), s->blob.size(), s->blobId, s->srcs.empty() ? nullptr : s->srcs.data(),
+                                               static_cast<uint32_t>(s->srcs.size()), s->jobs.data(), static_cast<uint32_t>(n),
+                                               s->tail, 1, pcmOut, errOut, &tails);
+    if (st != DCS_OK)
+    {
+        s->lastError = dcs_last_error(ctx);
+        return st;
+    }
+    memcpy(s->batchTail0, s->tail, sizeof(s->tail));
+    memcpy(s->tail, tails + (n - 1) * 16, sizeof(s->tail));
+    s->batchTails.assign(tails, tails + n * 16);
+    s->batchDecoded = true;
+    s->jobs.clear();
+    s->srcs.clear();
+    // the blob and the stream cache stay: streams already copied are reused by later plans
+    return DCS_OK;
+}
+
 extern "C" DcsStatus dcs_seq_decode(DcsCtx *ctx, DcsSequencer *s, int16_t *pcmOut, size_t pcmCapFrames, uint32_t *errOut)
 {
     if (ctx == nullptr || s == nullptr || pcmOut == nullptr)
@@ -863,25 +1032,36 @@ extern "C" DcsStatus dcs_seq_decode(DcsCtx *ctx, DcsSequencer *s, int16_t *pcmOu
         return DCS_OK;
     if (n > pcmCapFrames)
         return DCS_ERR_CAPACITY;
-    if (s->blob.empty())
-        s->blob.assign(16, 0);
-    std::vector<int16_t> tails(n * 16);
-    const DcsStatus st = dcs_decode_batch(ctx, s->blob.data(), s->blob.size(), s->srcs.empty() ? nullptr : s->srcs.data(),
-                                          static_cast<uint32_t>(s->srcs.size()), s->jobs.data(), static_cast<uint32_t>(n),
-                                          s->tail, 1, pcmOut, errOut, tails.data());
-    if (st != DCS_OK)
+    if (n > (1u << 17))
     {
-        s->lastError = dcs_last_error(ctx);
-        return st;
+        // more than the live decoder takes in one call (a whole ROM's tracks planned ahead, dcs_extract_tracks): the one-shot way
+        if (s->blob.empty())
+            s->blob.assign(16, 0);
+        std::vector<int16_t> tails(n * 16);
+        const DcsStatus st = dcs_decode_batch(ctx, s->blob.data(), s->blob.size(), s->srcs.empty() ? nullptr : s->srcs.data(),
+                                              static_cast<uint32_t>(s->srcs.size()), s->jobs.data(), static_cast<uint32_t>(n),
+                                              s->tail, 1, pcmOut, errOut, tails.data());
+        if (st != DCS_OK)
+        {
+            s->lastError = dcs_last_error(ctx);
+            return st;
+        }
+        memcpy(s->batchTail0, s->tail, sizeof(s->tail));
+        memcpy(s->tail, &tails[(n - 1) * 16], sizeof(s->tail));
+        s->batchTails.swap(tails);
+        s->batchDecoded = true;
+        s->jobs.clear();
+        s->srcs.clear();
+        return DCS_OK;
     }
-    memcpy(s->batchTail0, s->tail, sizeof(s->tail));
-    memcpy(s->tail, &tails[(n - 1) * 16], sizeof(s->tail));
-    s->batchTails.swap(tails);
-    s->batchDecoded = true;
-    s->jobs.clear();
-    s->srcs.clear();
-    s->srcsAfter.clear();
-    // the blob and the stream cache stay: streams already copied are reused by later plans
+    const int16_t *pcm = nullptr;
+    const uint32_t *err = nullptr;
+    const DcsStatus st = dcs_seq_decode_view(ctx, s, &pcm, nullptr, &err);
+    if (st != DCS_OK)
+        return st;
+    memcpy(pcmOut, pcm, n * DCS_FRAME_SAMPLES * sizeof(int16_t));
+    if (errOut != nullptr)
+        memcpy(errOut, err, n * sizeof(uint32_t));
     return DCS_OK;
 }
 

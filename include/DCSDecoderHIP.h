@@ -85,8 +85,14 @@ public:
 
     // DCSDecoder.cpp:1518-1540: initialise the subclass and enter the Running state
     void SoftBoot();
-    // DCSDecoder.cpp:1579-1690: one PCM sample; refills 240 samples through MainLoop() when empty
-    int16_t GetNextSample();
+    // DCSDecoder.cpp:1579-1690: one PCM sample; refills 240 samples through MainLoop() when empty.  Inline: callers pull samples
+    // one at a time in a bare loop, 240 calls a frame (DCSEncoder.cpp:565-567, DCSExplorer.cpp:1709-1711).
+    int16_t GetNextSample()
+    {
+        if (sampleCounter < DCS_FRAME_SAMPLES && state == State::Running)
+            return outputBuffer[sampleCounter++];
+        return RefillAndGetSample();
+    }
 
     bool IsOK() const { return state != State::DecoderFatalError && state != State::InitializationError; }
     bool IsRunning() const { return state == State::Running; }
@@ -103,6 +109,7 @@ public:
     static const std::map<std::string, const Registration &> &GetRegistrationMap();
 
 protected:
+    int16_t RefillAndGetSample();                               // the rest of GetNextSample: state check, MainLoop()
     virtual bool Initialize() = 0;                              // DCSDecoder.h:1137
     virtual void IRQ2Handler() = 0;                             // DCSDecoder.h:1140
     virtual void MainLoop() = 0;                                // DCSDecoder.h:1143
@@ -192,11 +199,16 @@ public:
     bool DecodeStreamsBatch(const std::vector<BatchStream> &streams, unsigned extraFrames,
                             std::vector<int16_t> &pcm, std::vector<uint32_t> *firstFrameOfStream = nullptr);
 
-    // Live playback decodes `frames` MainLoop ticks per kernel launch (default 1 = tick by tick).  The
-    // sequencer simply runs that far ahead; anything that can change what it does -- WriteDataPort,
-    // AddTrackCommand, LoadAudioStream, SetMasterVolume, ClearTracks -- first takes it back to the last
-    // frame handed out, so the result does not depend on the look-ahead.
-    void SetLookahead(int frames) { lookahead = frames < 1 ? 1 : frames > 4096 ? 4096 : frames; }
+    // Live playback decodes several MainLoop ticks per kernel launch.  The sequencer simply runs that far ahead; anything that
+    // can change what it does -- WriteDataPort, AddTrackCommand, LoadAudioStream, SetMasterVolume, ClearTracks -- first takes it
+    // back to the last frame handed out, so the result does not depend on the look-ahead.  By DEFAULT the look-ahead is the
+    // decoder's own business ("N frames of look-ahead when no commands are pending"): kFirstLookahead ticks behind a
+    // command, eight times as many with every refill that no command preceded, up to kMaxLookahead, and never further than two
+    // ticks into silence (nothing playing, no track program, nothing queued).  A caller that pulls samples in a bare loop and has
+    // never heard of look-ahead gets this.  SetLookahead(n), n >= 1, fixes it at n ticks per launch (1 = tick by tick, as the
+    // reference works; for measurements and tests); SetLookahead(0) gives it back to the decoder.
+    void SetLookahead(int frames) { lookahead = frames < 0 ? 0 : frames > kMaxLookahead ? kMaxLookahead : frames; }
+    static const int kFirstLookahead = 64, kMaxLookahead = 4096;
 
 protected:
     bool Initialize() override;
@@ -207,6 +219,8 @@ protected:
 
 private:
     void Sync();                                // back to the state after the last frame handed out
+    bool Refill();                              // plan ahead and decode: one launch
+    void ReleaseContext();
     size_t BytesBehind(const ROMPointer &p) const;     // to the end of the ROM image p points into, else 64 MB
     DcsOsVersion AbiOs() const;
     bool EnsureRoms();
@@ -223,10 +237,14 @@ private:
 #endif
     uint16_t reportedVersion = 0x0106;
     int masterVolume = -1;                      // last SetMasterVolume before the sequencer existed
-    int lookahead = 1;
-    std::deque<std::vector<int16_t>> ready;     // frames decoded ahead
+    int lookahead = 0;                          // 0 = the decoder's own (see SetLookahead)
+    int curLookahead = kFirstLookahead;         // ... which is this many ticks for the next refill
+    const int16_t *ready = nullptr;             // frames decoded ahead: readyCount x 240 samples in the context's pinned memory
+    uint32_t readyCount = 0;
     uint32_t handedOut = 0;                     // frames of the current batch already handed out
-    std::deque<DcsHostByte> hostBytes;          // bytes for the host, by tick, not delivered yet
+    uint64_t fatalTick = ~uint64_t(0);          // first tick the sequencer answers with silence (DecoderFatalError), as of the last refill
+    std::vector<DcsHostByte> hostBytes;         // bytes for the host, by tick; [hostNext, end) not delivered yet
+    size_t hostNext = 0;
     uint64_t nextTick = 0;                      // tick of the next frame to hand out
     std::string zipError;
 };

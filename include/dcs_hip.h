@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DCS_ABI_VERSION 8              /* 8: dcs_ctx_set_batch_tails (resident batches keep chain-end tails by default), dcs_batch_package_bytes, dcs_runtime_defaults (round 5) */
+#define DCS_ABI_VERSION 9              /* 9: dcs_decode_batch_live, dcs_seq_decode_view, dcs_seq_plan_ahead, dcs_seq_stream_playing_at (round 6) */
 #define DCS_FRAME_SAMPLES 240          /* PCM samples per frame (DCSDecoder.h:123: 7.68 ms at 31250 Hz) */
 #define DCS_MAX_CHANNELS 8             /* DCSDecoderNative.h:305 */
 
@@ -273,6 +273,22 @@ DcsStatus dcs_decode_batch(DcsCtx *ctx,
                            const DcsFrameJob *jobs, uint32_t nJobs,
                            const int16_t *tailsIn, uint32_t nTailsIn,
                            int16_t *pcmOut, uint32_t *errOut, int16_t *tailsOut);
+
+/* The same for a caller that comes back every few frames (DCSDecoderHIP's sample pump, DCSDecoder.cpp:1579-1690; the sequencer):
+ * the context's LIVE decoder.  Nothing is allocated, created or cleared per call: the packages are built in a pinned arena the
+ * context keeps, small batches are read and written by the kernel straight over the link (one launch, one wait), larger ones get
+ * one copy up and one copy down (PCM, error words and EVERY frame's tail are one block).  The results are handed out as pointers
+ * into the context's pinned arena (any of the three may be NULL), valid until the context's next decode call.
+ * blobId names the blob: a caller whose blob only ever GROWS under one non-zero name (bytes already passed never change) has the
+ * streams that multi-channel frames read on the device uploaded once, when they first appear; 0 = no such promise, the blob is
+ * uploaded per call when some frame has more than one source (frames with one source never read it: their bytes travel in the
+ * packages).  At most 131 072 frames a call (DCS_ERR_CAPACITY beyond).  dcs_decode_batch itself takes this way up to that size. */
+DcsStatus dcs_decode_batch_live(DcsCtx *ctx,
+                                const uint8_t *blob, size_t blobLen, uint64_t blobId,
+                                const DcsSrcDesc *srcs, uint32_t nSrcs,
+                                const DcsFrameJob *jobs, uint32_t nJobs,
+                                const int16_t *tailsIn, uint32_t nTailsIn,
+                                const int16_t **pcmOut, const uint32_t **errOut, const int16_t **tailsOut);
 
 /* Resident batches: upload once, run many times, download when wanted.  This is the path bench.py
  * times (inputs already in HBM when the clock starts).
@@ -624,20 +640,33 @@ DcsStatus   dcs_seq_load_audio_stream(DcsSequencer *seq, int channel, uint32_t l
 /* LoadAudioStream for a stream in caller memory (copied), the ROM-less recipe of DCSEncoder.cpp:522-571 */
 DcsStatus   dcs_seq_load_audio_stream_mem(DcsSequencer *seq, int channel, const uint8_t *data, size_t len, int mixingLevel);
 DcsStatus   dcs_seq_plan(DcsSequencer *seq, uint32_t nTicks);        /* run nTicks ticks, extend the pending plan  */
+/* the same for a caller that decodes ahead of what it has been asked for: at most maxTicks, at least one, and no further than
+ * idleTicks ticks into silence (nothing playing, no program, no timer, nothing queued: digital silence until the next command);
+ * *plannedOut = ticks run */
+DcsStatus   dcs_seq_plan_ahead(DcsSequencer *seq, uint32_t maxTicks, uint32_t idleTicks, uint32_t *plannedOut);
 /* go back inside the current batch (pending, or just decoded): state, overlap tail and host bytes as they were
  * after its first keepTicks ticks; how a caller that decodes ahead stays exact when a command arrives */
 DcsStatus   dcs_seq_rewind(DcsSequencer *seq, uint32_t keepTicks);
-DcsStatus   dcs_seq_set_rewindable(DcsSequencer *seq, int on);      /* keep a snapshot per tick (off by default)  */
+/* make dcs_seq_rewind possible (off by default): a snapshot of the machine every 64 ticks; going back runs the ticks between the
+ * snapshot and the tick asked for again (the machine is deterministic; bytes for the host are not sent twice) */
+DcsStatus   dcs_seq_set_rewindable(DcsSequencer *seq, int on);
 uint32_t    dcs_seq_pending_ticks(const DcsSequencer *seq);
 int         dcs_seq_is_fatal(const DcsSequencer *seq);               /* DecoderFatalError after 4 failed passes    */
 uint64_t    dcs_seq_tick(const DcsSequencer *seq);                   /* ticks run so far                           */
 uint64_t    dcs_seq_fatal_tick(const DcsSequencer *seq);             /* first silent tick of a fatal error, or ~0  */
 int         dcs_seq_stream_playing(const DcsSequencer *seq, int channel);   /* IsStreamPlaying (:101)              */
+/* ... as it was after the first `ticks` ticks of the current batch, without going back there (a caller that has handed out
+ * `ticks` frames of its look-ahead answers IsStreamPlaying from this and keeps the rest) */
+int         dcs_seq_stream_playing_at(const DcsSequencer *seq, uint32_t ticks, int channel);
 /* bytes sent to the host since the last successful call; returns their number (call with out = NULL to size) */
 uint32_t    dcs_seq_host_bytes(DcsSequencer *seq, DcsHostByte *out, uint32_t cap);
 /* decode the pending plan (pcmOut = pending ticks x 240 samples) in one launch and clear it; the overlap
  * tail carries into the next plan */
 DcsStatus   dcs_seq_decode(DcsCtx *ctx, DcsSequencer *seq, int16_t *pcmOut, size_t pcmCapFrames, uint32_t *errOut);
+/* the same without the copy: *pcmOut (and *errOut, optional) point into the context's pinned memory (dcs_decode_batch_live),
+ * *nFramesOut frames, valid until the context decodes again.  The streams the sequencer has loaded stay resident on the device:
+ * each is uploaded once.  At most 131 072 pending ticks. */
+DcsStatus   dcs_seq_decode_view(DcsCtx *ctx, DcsSequencer *seq, const int16_t **pcmOut, uint32_t *nFramesOut, const uint32_t **errOut);
 
 /* The track loop of `DCSExplorer --extract-tracks` exactly (DCSExplorer.cpp:1628-1721, :1905-1925): ONE decoder --
  * SoftBoot, SetMasterVolume(255) -- plays the tracks one after the other: ClearTracks(), AddTrackCommand(track), nFrames

@@ -73,10 +73,19 @@ int main(int argc, char **argv)
         }
         auto info = dec->GetStreamInfoBounded(DCSDecoder::ROMPointer(0, keep[0].data()), keep[0].size());
         fprintf(stderr, "stream 0: %d frames, %d bytes, type %d/%d\n", info.nFrames, info.nBytes, info.formatType, info.formatSubType);
+        // (IsStreamPlaying between every two frames, as EncoderTester.cpp:94-106 asks it: <OUT>.playing, one digit per frame and channel)
+        std::string playing;
         for (int f = 0 ; f < nFramesOut ; ++f)
+        {
             for (int i = 0 ; i < 240 ; ++i)
                 pcm.push_back(dec->GetNextSample());
+            for (int c = 0 ; c < ch ; ++c)
+                playing += dec->IsStreamPlaying(c) ? '1' : '0';
+            playing += '\n';
+        }
         if (!dec->IsOK()) { fprintf(stderr, "decoder failed: %s\n", dec->GetErrorMessage().c_str()); return 5; }
+        FILE *pf = fopen((std::string(argv[5]) + ".playing").c_str(), "w");
+        if (pf != nullptr) { fputs(playing.c_str(), pf); fclose(pf); }
     }
     else if (mode == "script")
     {

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(dcs):
 def test_abi_version_and_struct_sizes(dcs):
     hdr = open(os.path.join(ROOT, "include", "dcs_hip.h")).read()
     declared = int(re.search(r"#define\s+DCS_ABI_VERSION\s+(\d+)", hdr).group(1))
-    assert dcs.load_library().dcs_abi_version() == declared == dcs.api.ABI_VERSION == 8
+    assert dcs.load_library().dcs_abi_version() == declared == dcs.api.ABI_VERSION == 9
     assert dcs.SRC_DTYPE.itemsize == 160
     assert dcs.JOB_DTYPE.itemsize == 16
     assert dcs.INDEX_DTYPE.itemsize == 148

@@ -37,8 +37,9 @@ def test_class_fails_loudly_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lookahead", [1, 7])
+@pytest.mark.parametrize("lookahead", [0, 1, 7])
 def test_live_playback_matches_oracle(tmp_path, oracle, lookahead):
+    """look-ahead 0 = the decoder's own (what a caller gets who never calls SetLookahead), 1 = tick by tick, 7 = fixed"""
     for fmt in (D.FMT_94_T1_S3, D.FMT_93_T0, D.FMT_93A_T1):
         data = make_stream(fmt, 23, seed=21000 + fmt)
         os_ = os_for(fmt)
@@ -48,6 +49,27 @@ def test_live_playback_matches_oracle(tmp_path, oracle, lookahead):
         got = np.fromfile(out, dtype=np.int16).reshape(26, 240)
         want = oracle.decode(os_, 230, [data], [0x66], 26)
         assert np.array_equal(got, want), "fmt %d" % fmt
+        # IsStreamPlaying after every frame is the state behind THAT frame, however far the decoder has run ahead: the
+        # stream's last frame ends it (DCSDecoderNative.cpp:1377, :1575-1589)
+        assert open(out + ".playing").read().split() == ["1"] * 22 + ["0"] * 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [D.FMT_94_T1_S3, D.FMT_93B_T1])
+def test_long_stream_at_the_default_lookahead(tmp_path, oracle, fmt):
+    """a caller that pulls samples in a bare loop and never heard of SetLookahead (DCSEncoder.cpp:565-567): the decoder runs
+    64, 512, 4 096 ticks ahead on its own and stops two ticks behind the stream's end; 700 frames cross every snapshot and
+    refill boundary"""
+    data = make_stream(fmt, 700, seed=21500 + fmt, profile=5)
+    os_ = os_for(fmt)
+    s = write_stream(tmp_path, "long%d.bin" % fmt, data)
+    p, out = run(["live", str(os_), "255", "0", "OUT", "705", str(0x64), s], tmp_path)
+    assert p.returncode == 0, p.stderr
+    got = np.fromfile(out, dtype=np.int16).reshape(705, 240)
+    want = oracle.decode(os_, 255, [data], [0x64], 705)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "first differing frames: %s" % bad[:8]
+    assert open(out + ".playing").read().split() == ["1"] * 699 + ["0"] * 6
 
 
 @pytest.mark.gpu
@@ -55,13 +77,18 @@ def test_live_multichannel_matches_oracle(tmp_path, oracle):
     datas = [make_stream(f, 9 + 6 * i, seed=22000 + i, profile=i % 3) for i, f in
              enumerate((D.FMT_94_T0, D.FMT_94_T1_S0, D.FMT_94_T1_S3, D.FMT_94_T1_S3))]
     levels = [0x68, 0x60, 0x64, 0x5C]
-    args = ["live", "2", "255", "5", "OUT", "40"]
-    for i, d in enumerate(datas):
-        args += [str(levels[i]), write_stream(tmp_path, "m%d.bin" % i, d)]
-    p, out = run(args, tmp_path)
-    assert p.returncode == 0, p.stderr
-    got = np.fromfile(out, dtype=np.int16).reshape(40, 240)
-    assert np.array_equal(got, oracle.decode(2, 255, datas, levels, 40))
+    want = oracle.decode(2, 255, datas, levels, 40)
+    for lookahead in (5, 0, 1):
+        args = ["live", "2", "255", str(lookahead), "OUT", "40"]
+        for i, d in enumerate(datas):
+            args += [str(levels[i]), write_stream(tmp_path, "m%d.bin" % i, d)]
+        p, out = run(args, tmp_path)
+        assert p.returncode == 0, p.stderr
+        got = np.fromfile(out, dtype=np.int16).reshape(40, 240)
+        assert np.array_equal(got, want), "look-ahead %d" % lookahead
+        # channel c plays 9 + 6 c frames
+        rows = open(out + ".playing").read().split()
+        assert rows == ["".join("1" if f + 1 < 9 + 6 * c else "0" for c in range(4)) for f in range(40)]
 
 
 @pytest.mark.gpu
@@ -76,7 +103,7 @@ def test_batch_submit_matches_oracle(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lookahead", [1, 16])
+@pytest.mark.parametrize("lookahead", [0, 1, 16])
 def test_extract_streams_loop_matches_oracle(tmp_path, oracle, lookahead):
     """the --extract-streams loop on ONE DCSDecoderHIP object: decoder state carries over between streams
     (incl. a stream stopped by an error, whose mixer level is reset), WAV files as ExtractToWAV writes them"""
@@ -104,7 +131,7 @@ def test_extract_streams_loop_matches_oracle(tmp_path, oracle, lookahead):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lookahead", [1, 9])
+@pytest.mark.parametrize("lookahead", [0, 1, 9, 100])
 @pytest.mark.parametrize("script", ["main", "fatal-opcode", "volume-and-clear"])
 def test_rom_mode_script_through_the_class(tmp_path, lookahead, script):
     """DCSDecoderHIP driven like DCSExplorer drives a decoder: AddROM, CheckROMs, SoftBoot, WriteDataPort /

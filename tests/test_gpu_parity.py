@@ -414,3 +414,75 @@ def test_caller_made_index_records_cannot_break_the_launch(gpu_ctx):
     gpu_ctx.set_frames_per_wave(0)
     good, _ = gpu_ctx.decode_batch(batch["blob"], srcs, batch["jobs"])
     assert good.any()
+
+
+def _slice_batch(b, lo, hi, first_prev):
+    """frames [lo, hi) of a one-stream batch as a batch of their own: the first takes its tail from outside"""
+    jobs = b["jobs"][lo:hi].copy()
+    s0 = int(jobs["firstSrc"][jobs["nSrc"] > 0].min()) if (jobs["nSrc"] > 0).any() else 0
+    s1 = int((jobs["firstSrc"] + jobs["nSrc"])[jobs["nSrc"] > 0].max()) if (jobs["nSrc"] > 0).any() else 0
+    jobs["firstSrc"] = np.where(jobs["nSrc"] > 0, jobs["firstSrc"] - s0, 0)
+    jobs["prev"] = np.arange(hi - lo, dtype=np.int64) - 1
+    jobs["prev"][0] = first_prev
+    return b["srcs"][s0:s1], jobs
+
+
+@pytest.mark.parametrize("zc", ["default", "always-copy", "never-copy"])
+def test_live_decoder_call_after_call(dcs, oracle, zc, monkeypatch):
+    """dcs_decode_batch_live, the path DCSDecoderHIP's pump takes: ONE context, call after call of 1, 2, 5, 64, 65 and 163 frames
+    of one stream per layout, every call's first frame taking the tail the call before left (DCS_PREV_EXT) -- nothing allocated,
+    cleared or created per call, hand-off words told apart by a launch counter that only grows.  With the packages read and the
+    PCM written over the link (small calls by default), with copies both ways, and with neither."""
+    if zc == "always-copy":
+        monkeypatch.setenv("DCS_LIVE_ZC_UP_KB", "0"); monkeypatch.setenv("DCS_LIVE_ZC_DOWN_FRAMES", "0")
+    elif zc == "never-copy":
+        monkeypatch.setenv("DCS_LIVE_ZC_UP_KB", "1000000"); monkeypatch.setenv("DCS_LIVE_ZC_DOWN_FRAMES", "1000000")
+    ctx = dcs.Context(0)
+    try:
+        for fmt in ALL_FORMATS:
+            s = make_stream(fmt, 300, seed=31000 + fmt, profile=fmt % 4)
+            streams = [(os_for(fmt), s, 255, 0x64)]
+            b = D.build_stream_batch(streams, extra_frames=2)
+            want = oracle_streams(oracle, streams, extra=2)
+            got, tail, lo = [], None, 0
+            for n in (1, 2, 5, 64, 65, 163, 2):
+                srcs, jobs = _slice_batch(b, lo, lo + n, D.PREV_NONE if tail is None else (D.PREV_EXT | 0))
+                pcm, err, tails = ctx.decode_batch_live(b["blob"], srcs, jobs, tails_in=tail)
+                assert not err.any()
+                got.append(pcm)
+                tail = tails[-1:].copy()
+                lo += n
+            assert_same(np.concatenate(got), want, "%s %s" % (FORMAT_NAMES[fmt], zc))
+    finally:
+        ctx.close()
+
+
+def test_live_decoder_keeps_named_blobs_resident(dcs, oracle):
+    """multi-channel frames read their second and later sources from the blob on the device: under a name (blobId) the blob is
+    uploaded once and only what is appended later goes up; another name, or none, replaces it; the PCM is the same"""
+    meta = json.load(open(os.path.join(GOLD, "dcs_golden_hashes.json")))
+    arrays = np.load(os.path.join(GOLD, "dcs_golden.npz"))
+    from mixer_ref import build_mix_batch
+    cases = [c for c in meta["cases"] if c["streams"] > 1]
+    ctx = dcs.Context(0)
+    try:
+        for rep, case in enumerate(cases + cases[:1]):
+            streams = [arrays["%s/stream%d" % (case["name"], c)].tobytes() for c in range(case["streams"])]
+            b = build_mix_batch(case["os"], case["volume"], streams, case["levels"], case["frames_out"])
+            want = arrays[case["name"] + "/pcm"]
+            n = len(b["jobs"])
+            half = n // 2
+            # first half under the blob's name, second half with the blob grown (appended bytes only go up), tail carried
+            srcs, jobs = _slice_batch(b, 0, half, D.PREV_NONE)
+            pcm_a, err, tails = ctx.decode_batch_live(b["blob"], srcs, jobs, blob_id=100 + rep)
+            grown = b["blob"] + bytes(range(256)) * 3
+            srcs, jobs = _slice_batch(b, half, n, D.PREV_EXT | 0)
+            pcm_b, err, _ = ctx.decode_batch_live(grown, srcs, jobs, tails_in=tails[-1:], blob_id=100 + rep)
+            assert_same(np.concatenate([pcm_a, pcm_b]), want, case["name"] + " named")
+            # the same without a name, and through the one-shot call
+            pcm, err, _ = ctx.decode_batch_live(b["blob"], b["srcs"], b["jobs"])
+            assert_same(pcm, want, case["name"] + " unnamed")
+            pcm, err = ctx.decode_batch(b["blob"], b["srcs"], b["jobs"])
+            assert_same(pcm, want, case["name"] + " one-shot")
+    finally:
+        ctx.close()

@@ -78,7 +78,7 @@ ENC = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_golden.json"
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lookahead", [1, 64])
+@pytest.mark.parametrize("lookahead", [0, 1, 64])
 @pytest.mark.parametrize("case", ENC, ids=[c["name"] for c in ENC])
 def test_rom_less_recipe_behind_the_real_base(tmp_path, case, lookahead):
     """InitStandalone / SetDefaultVolume / SoftBoot / LoadAudioStream(0, ROMPointer(0, p), level) / GetNextSample, as

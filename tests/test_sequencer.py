@@ -78,3 +78,53 @@ def test_script_pcm_equals_reference(gpu_ctx, case, script):
         bad = np.nonzero((pcm != want).any(axis=1))[0]
         assert bad.size == 0, "first differing ticks: %s" % bad[:8]
     assert "%016x" % fnv1a64(pcm.tobytes()) == gold["pcm_fnv1a64"]
+
+
+@pytest.mark.parametrize("case,script", PAIRS, ids=IDS)
+def test_going_back_inside_a_plan_replays_to_the_same_state(case, script):
+    """dcs_seq_rewind keeps a snapshot every 64 ticks and runs the ticks between the snapshot and the tick asked for again.
+    A caller that plans 97 ticks ahead and is taken back by every event (the way DCSDecoderHIP's pump is) ends up with the
+    same bytes for the host at the same ticks, none of them twice, and the same fatal state as the tick-by-tick run --
+    which equal the reference's (seq_golden.json)."""
+    n, ev = romkit.SCRIPTS[script]
+    ev = sorted(ev, key=lambda x: x[0])
+    rs, seq = make_sequencer(case)
+    seq.set_rewindable(True)
+    planned, e = 0, 0
+    while planned < n:
+        while e < len(ev) and ev[e][0] <= planned:
+            seq.event(ev[e][1], ev[e][2])
+            e += 1
+        seq.plan(min(97, n - planned))
+        planned = min(n, planned + 97)
+        if e < len(ev) and ev[e][0] < planned:
+            seq.rewind(ev[e][0])
+            planned = ev[e][0]
+            assert seq.pending_ticks == planned
+    gold = GOLD["%s/%s" % (case[0], script)]
+    assert seq.pending_ticks == n
+    assert [list(x) for x in seq.host_bytes()] == gold["host_bytes"]
+    assert seq.fatal == gold["fatal"]
+
+
+def test_plan_ahead_stops_two_ticks_into_silence():
+    """dcs_seq_plan_ahead: a stream of 30 frames on a stand-alone sequencer; asked for 500 ticks it plans the 30, the tick that
+    carries the last overlap tail out and one of silence; asked again it plans one tick at a time; IsStreamPlaying is
+    answered for any tick of the plan without going back"""
+    from util import make_stream
+    L = D.load_library()
+    s = make_stream(D.FMT_94_T1_S3, 30, seed=77)
+    h = L.dcs_seq_create_standalone(D.OS94)
+    try:
+        seq = D.Sequencer.__new__(D.Sequencer)
+        seq.L, seq.rs, seq.h = L, None, h
+        assert L.dcs_seq_load_audio_stream_mem(h, 0, s, len(s), 0x64) == 0
+        assert seq.plan_ahead(500) == 32
+        assert [seq.stream_playing_at(k, 0) for k in (0, 1, 29, 30, 32)] == [True, True, True, False, False]
+        assert seq.plan_ahead(500) == 1 and seq.pending_ticks == 33
+        assert L.dcs_seq_load_audio_stream_mem(h, 1, s, len(s), 0x60) == 0
+        assert seq.plan_ahead(7) == 7 and seq.plan_ahead(500) == 25
+        assert seq.stream_playing_at(33 + 29, 1) and not seq.stream_playing_at(33 + 30, 1)
+    finally:
+        seq.h = None
+        L.dcs_seq_destroy(h)
