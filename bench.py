@@ -55,6 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames-per-chunk", type=int, default=0, help="diagnostic: frames a wavefront decodes (1 = one wavefront "
                     "per frame with the lanes of the other slots idle); 0 = every slot of the kernel variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-class-surface", action="store_true", help="skip the section that times DCSDecoderHIP::GetNextSample() (and the reference pump beside it)")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-device-path", action="store_true", help="skip device_full_path (stream bytes in HBM -> PCM in HBM: index walk, planner, packer, decode)")
     ap.add_argument("--no-second-workload", action="store_true", help="skip the encoder-made streams reported next to the default workload")
@@ -136,6 +137,45 @@ def cpu_baseline(streams, budget_s=10.0):
                 sample="%d streams (%d frames) of the workload: decoded %d times in %.1f s on 1 thread and %d times in "
                        "%.1f s on %d threads, one decoder object per thread" % (len(streams), frames_per_pass, rep1, dt1,
                                                                                rept, dtt, threads))
+
+
+def cpu_pump(budget_s=25.0):
+    """the reference's own sample pump (DCSDecoderNative behind GetNextSample, one thread, as every caller of the reference runs
+    it) on the scenarios of class_surface, same caller code: tests/cpp/dcs_pump_bench.cpp built over the unmodified reference
+    (oracle/_ref/dcs_pump_bench_native).  Part of the CPU baseline; its PCM hashes are what class_surface's are held against."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pump_bench
+    return pump_bench.run_all(builds=("native",), lookaheads=(-1,), reps=3, budget_s=budget_s)
+
+
+# --------------------------------------------------------------------------------------------- the class surface
+def class_surface(budget_s=60.0):
+    """samples/s through DCSDecoderHIP::GetNextSample() -- what a caller of the reference gets who switches decoder and changes
+    nothing else: the ROM-less recipe (DCSEncoder.cpp:522-571; one 2 000-frame stream per layout, a NEW decoder
+    per stream), the --extract-streams loop (DCSExplorer.cpp:1670-1721, :1900-1907; 64 streams on one decoder), a ROM-mode
+    multi-channel script through the data port; at the decoder's default look-ahead and tick by tick (SetLookahead(1)).  The caller is
+    tests/cpp/dcs_pump_bench.cpp, a child process per run; median repetition, the first (which creates the context) left out.
+    one_shot: microseconds per dcs_decode_batch call underneath, next to the box's floor for a synchronous call."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pump_bench
+    res = pump_bench.run_all(builds=("hip-mirror",), lookaheads=(-1, 1), reps=5, budget_s=budget_s)
+    res.pop("bit_exact", None)              # (nothing to compare with yet: the reference's hashes come with cpu_baseline.pump)
+    res["caller"] = "tests/cpp/dcs_pump_bench.cpp: GetNextSample() in a bare loop, 240 calls a frame; look-ahead never mentioned (default) or SetLookahead(1)"
+    return res
+
+
+def compare_pump_hashes(surface, pump):
+    """class_surface's PCM hashes against the reference pump's, scenario by scenario"""
+    out = {}
+    def one(mine, theirs):
+        want = (theirs or {}).get("native", {}).get("fnv1a64")
+        got = {k: v.get("fnv1a64") for k, v in (mine or {}).items() if isinstance(v, dict) and "fnv1a64" in v}
+        return None if want is None or not got else all(h == want for h in got.values())
+    for name in (surface.get("recipe") or {}):
+        out["recipe " + name] = one(surface["recipe"][name], (pump.get("recipe") or {}).get(name))
+    out["extract"] = one(surface.get("extract"), pump.get("extract"))
+    out["script"] = one(surface.get("script"), pump.get("script"))
+    return out
 
 
 # --------------------------------------------------------------------------------------------- end to end
@@ -1082,9 +1122,23 @@ def run_rank(args):
             if not isinstance(out.get("end_to_end"), dict):
                 out["end_to_end"] = {}
             out["end_to_end"]["node"] = sec.run("node", lambda: end_to_end_node(args, streams, n_frames, depth=max(4, args.e2e_device_depth // 2)), 90)
+        if alone and not args.no_class_surface:
+            out["class_surface"] = sec.run("class_surface", lambda: class_surface(), 90)
         if alone and not args.no_cpu_baseline:
             sample = streams if not corpus else streams[:64]
             out["cpu_baseline"] = sec.run("cpu_baseline", lambda: cpu_baseline(sample), 60)
+            if not args.no_class_surface and isinstance(out.get("cpu_baseline"), dict) and "error" not in out["cpu_baseline"]:
+                out["cpu_baseline"]["pump"] = sec.run("cpu_pump", lambda: cpu_pump(), 45)
+                try:
+                    out["class_surface"]["bit_exact"] = compare_pump_hashes(out["class_surface"], out["cpu_baseline"]["pump"])
+                    ref = out["cpu_baseline"]["pump"]
+                    cs = out["class_surface"]
+                    cs["vs_reference_pump"] = {
+                        **{"recipe " + n: cs["recipe"][n]["hip-mirror"]["samples_per_s"] / ref["recipe"][n]["native"]["samples_per_s"] for n in cs["recipe"]},
+                        "extract": cs["extract"]["hip-mirror"]["samples_per_s"] / ref["extract"]["native"]["samples_per_s"],
+                        "script": cs["script"]["hip-mirror"]["samples_per_s"] / ref["script"]["native"]["samples_per_s"]}
+                except (KeyError, TypeError, ZeroDivisionError):
+                    pass
             try:
                 out["end_to_end"]["sustained_vs_cpu_baseline"] = out["end_to_end"]["sustained"]["value"] / out["cpu_baseline"]["value"]
             except (KeyError, TypeError):

@@ -119,7 +119,7 @@ EXPORTS = [
     "dcs_seq_plan", "dcs_seq_pending_ticks", "dcs_seq_is_fatal", "dcs_seq_host_bytes", "dcs_seq_decode",
     "dcs_seq_create_standalone", "dcs_seq_load_audio_stream_mem", "dcs_seq_rewind", "dcs_seq_set_rewindable",
     "dcs_seq_tick", "dcs_seq_fatal_tick", "dcs_seq_stream_playing",
-    "dcs_decode_batch_live", "dcs_seq_decode_view", "dcs_seq_plan_ahead", "dcs_seq_stream_playing_at",
+    "dcs_decode_batch_live", "dcs_seq_decode_view", "dcs_seq_plan_ahead", "dcs_seq_stream_playing_at", "dcs_seq_tracks_active_at", "dcs_ctx_call_floor",
     "dcs_host_threads", "dcs_partition_streams", "dcs_decode_streams_sharded",
     "dcs_ctx_set_frames_per_chunk", "dcs_index_stream_literal", "dcs_pack_chunks_device", "dcs_batch_abi_bytes", "dcs_batch_num_chunks", "dcs_batch_frames_per_wave", "dcs_ctx_clock_mhz", "dcs_ctx_link_rate", "dcs_ctx_set_test_hooks",
     "dcs_pipeline_create", "dcs_pipeline_destroy", "dcs_pipeline_submit", "dcs_pipeline_collect",
@@ -315,6 +315,10 @@ def load_library():
     L.dcs_seq_stream_playing_at.argtypes = [vp, u32, ctypes.c_int]
     L.dcs_seq_stream_playing.restype = ctypes.c_int
     L.dcs_seq_stream_playing.argtypes = [vp, ctypes.c_int]
+    L.dcs_seq_tracks_active_at.restype = ctypes.c_int
+    L.dcs_seq_tracks_active_at.argtypes = [vp, u32]
+    L.dcs_ctx_call_floor.restype = i32
+    L.dcs_ctx_call_floor.argtypes = [vp, u32, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.dcs_decode_batch_live.restype = i32
     L.dcs_decode_batch_live.argtypes = [vp, vp, sz, ctypes.c_uint64, vp, u32, vp, u32, vp, u32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.dcs_seq_set_rewindable.restype = i32
@@ -773,6 +777,12 @@ class Context:
                                        _ptr(tin), 0 if tin is None else tin.shape[0], _ptr(pcm), _ptr(err),
                                        _ptr(tails)), self.h)
         return (pcm, err, tails) if want_tails else (pcm, err)
+
+    def call_floor(self, n_frames, iters=200):
+        """dcs_ctx_call_floor -> (launch + wait, launch + copy of n_frames x 516 B + wait) in microseconds"""
+        a, b = ctypes.c_float(), ctypes.c_float()
+        _check(self.L.dcs_ctx_call_floor(self.h, n_frames, iters, ctypes.byref(a), ctypes.byref(b)), self.h)
+        return a.value, b.value
 
     def decode_batch_live(self, blob, srcs, jobs, tails_in=None, blob_id=0):
         """dcs_decode_batch_live: the context's persistent small-batch decoder -> (pcm, err, tails), copies of what lies in the
@@ -1387,6 +1397,9 @@ class Sequencer:
 
     def stream_playing_at(self, ticks, channel):
         return bool(self.L.dcs_seq_stream_playing_at(self.h, ticks, channel))
+
+    def tracks_active_at(self, ticks):
+        return bool(self.L.dcs_seq_tracks_active_at(self.h, ticks))
 
     def stream_playing(self, channel):
         return bool(self.L.dcs_seq_stream_playing(self.h, channel))

@@ -4,6 +4,9 @@
 // :1546-1589); the frame decode itself is dcs_decode_batch -> HIP kernels.
 #include "../../include/DCSDecoderHIP.h"
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <chrono>
 #include <mutex>
 
 DCSHIP_NAMESPACE_BEGIN
@@ -100,6 +103,11 @@ ContextPool &contextPool()
 }
 }   // namespace
 
+// DCS_CLASS_STATS=1: where a decoder object's time went (loading streams = the index walk, planning ahead, decoding), printed when
+// it goes away
+static const bool g_classStats = getenv("DCS_CLASS_STATS") != nullptr && atoi(getenv("DCS_CLASS_STATS")) != 0;
+static double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // ---- DCSDecoderHIP -----------------------------------------------------------------------------------------
 DCSDecoderHIP::DCSDecoderHIP(Host *host, int deviceId) : DCSDecoder(host), deviceId(deviceId) { }
 
@@ -112,6 +120,9 @@ void DCSDecoderHIP::ReleaseContext()
 
 DCSDecoderHIP::~DCSDecoderHIP()
 {
+    if (g_classStats)
+        fprintf(stderr, "DCSDecoderHIP %p: %llu ticks handed out, %u refills; load %.1f us, plan %.1f us, decode %.1f us, going back %.1f us (%u times)\n",
+                static_cast<void *>(this), static_cast<unsigned long long>(nextTick), stats.refills, stats.loadUs, stats.planUs, stats.decodeUs, stats.syncUs, stats.syncs);
     if (seq != nullptr) dcs_seq_destroy(seq);
     if (roms != nullptr) dcs_romset_destroy(roms);
     ReleaseContext();
@@ -262,7 +273,7 @@ bool DCSDecoderHIP::Initialize()
         seq = nullptr;
     }
     ready = nullptr; readyCount = 0; hostBytes.clear(); hostNext = 0; handedOut = 0; nextTick = 0;
-    curLookahead = kFirstLookahead; fatalTick = ~uint64_t(0);
+    curLookahead = kFirstLookahead; fatalTick = ~uint64_t(0); lastCommandTick = 0; lastQuiet = 0;
 #ifdef DCSHIP_USE_REFERENCE_BASE
     // The base class owns the ROM images (AddROM / LoadROMFromZipFile put them in ROM[], CheckROMs has identified them
     // or the caller has named the versions): hand them to the C ABI's ROM set, with the versions the base holds.
@@ -314,10 +325,21 @@ bool DCSDecoderHIP::Initialize()
 // sequencer did for them.
 void DCSDecoderHIP::Sync()
 {
-    curLookahead = kFirstLookahead;             // a command: whoever sends one may send another soon
+    // a command: whoever sends one may send another soon -- but a caller that let the decoder run for N frames since its last
+    // command (a stream loop, DCSExplorer.cpp:1900-1907) will most likely do so again
+    // (several commands between two frames -- the bytes of one data-port message -- count as one)
+    if (nextTick != lastCommandTick)
+    {
+        lastQuiet = nextTick - lastCommandTick;
+        lastCommandTick = nextTick;
+    }
+    curLookahead = lastQuiet <= static_cast<uint64_t>(kFirstLookahead) ? kFirstLookahead
+                 : lastQuiet >= static_cast<uint64_t>(kMaxLookahead) ? kMaxLookahead : static_cast<int>(lastQuiet);
     if (seq == nullptr || handedOut == readyCount)
         return;
+    const double t0 = g_classStats ? nowUs() : 0.0;
     dcs_seq_rewind(seq, handedOut);
+    if (g_classStats) { stats.syncUs += nowUs() - t0; ++stats.syncs; }
     readyCount = handedOut;
     while (hostBytes.size() > hostNext && hostBytes.back().tick >= nextTick)
         hostBytes.pop_back();
@@ -383,11 +405,14 @@ void DCSDecoderHIP::AddTrackCommand(uint16_t trackNum)
 
 void DCSDecoderHIP::ClearTracks()
 {
-    if (seq != nullptr)
-    {
-        Sync();
-        dcs_seq_clear_tracks(seq);
-    }
+    if (seq == nullptr)
+        return;
+    // Behind the last frame handed out no channel has a program or a stream (the end of ExtractToWAV, DCSExplorer.cpp:1716-1718,
+    // clears a decoder that has run out twice per stream): nothing to clear, and what was decoded ahead stands.
+    if (!dcs_seq_tracks_active_at(seq, handedOut))
+        return;
+    Sync();
+    dcs_seq_clear_tracks(seq);
 }
 
 // what lies behind a stream pointer: the rest of the ROM image it points into (the base's, or the ROM set's copy), else 64 MB
@@ -429,7 +454,9 @@ void DCSDecoderHIP::LoadAudioStreamBounded(int ch, const ROMPointer &p, int mixi
     if (seq == nullptr || ch < 0 || ch >= DCS_MAX_CHANNELS || p.IsNull())       // :1390
         return;
     Sync();
+    const double t0 = g_classStats ? nowUs() : 0.0;
     dcs_seq_load_audio_stream_mem(seq, ch, p.p, maxLen, mixingLevel);
+    if (g_classStats) stats.loadUs += nowUs() - t0;
 }
 
 bool DCSDecoderHIP::IsStreamPlaying(int ch)
@@ -446,6 +473,7 @@ bool DCSDecoderHIP::Refill()
     readyCount = 0;
     ready = nullptr;
     DcsStatus st;
+    const double t0 = g_classStats ? nowUs() : 0.0;
     if (lookahead >= 1)
         st = dcs_seq_plan(seq, static_cast<uint32_t>(lookahead));
     else
@@ -453,8 +481,10 @@ bool DCSDecoderHIP::Refill()
         st = dcs_seq_plan_ahead(seq, static_cast<uint32_t>(curLookahead), 2, nullptr);
         curLookahead = curLookahead * 8 > kMaxLookahead ? kMaxLookahead : curLookahead * 8;     // (Sync() takes it back to the start)
     }
+    const double t1 = g_classStats ? nowUs() : 0.0;
     if (st == DCS_OK)
         st = dcs_seq_decode_view(ctx, seq, &ready, &readyCount, nullptr);
+    if (g_classStats) { stats.planUs += t1 - t0; stats.decodeUs += nowUs() - t1; ++stats.refills; }
     if (st != DCS_OK || readyCount == 0)
     {
         readyCount = 0;

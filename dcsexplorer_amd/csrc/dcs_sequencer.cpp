@@ -104,6 +104,7 @@ struct DcsSequencer : VmState
     static const uint32_t kSnapStride = 64;
     std::vector<Snapshot> history;          // ascending by ticks; history[0].ticks == 0: the state the batch started from
     std::vector<uint8_t> playingAfter;      // per tick of the current batch: which channels have a stream loaded after it (IsStreamPlaying)
+    std::vector<uint8_t> tracksAfter;       // ... and which have a track program (ClearTracks changes nothing where both are zero)
     std::vector<int16_t> batchTails;        // after a decode: the 16-sample tail each tick of the batch left
     int16_t batchTail0[16] = { 0 };         // ... and the tail the batch started from
     bool batchDecoded = false;
@@ -128,6 +129,14 @@ struct DcsSequencer : VmState
                 return false;
         return true;
     }
+    uint8_t trackMask() const
+    {
+        uint8_t m = 0;
+        for (int c = 0 ; c < DCS_MAX_CHANNELS ; ++c)
+            if (!ch[c].track.isNull())
+                m |= static_cast<uint8_t>(1u << c);
+        return m;
+    }
     uint8_t playingMask() const
     {
         uint8_t m = 0;
@@ -142,6 +151,7 @@ struct DcsSequencer : VmState
         history.clear();
         history.push_back(Snapshot{ 0, srcs.size(), static_cast<const VmState &>(*this) });
         playingAfter.clear();
+        tracksAfter.clear();
         batchTails.clear();
     }
     // A command from outside (data port, track command, volume, a stream loaded, tracks cleared) changes the machine where it
@@ -163,6 +173,7 @@ struct DcsSequencer : VmState
     {
         idleRun = wasQuiet && quiescent() ? idleRun + 1 : 0;
         playingAfter.push_back(playingMask());
+        tracksAfter.push_back(trackMask());
         if (keepHistory && batchTicks() % kSnapStride == 0 && history.back().ticks != batchTicks())
             history.push_back(Snapshot{ batchTicks(), srcs.size(), static_cast<const VmState &>(*this) });
     }
@@ -899,6 +910,7 @@ extern "C" DcsStatus dcs_seq_rewind(DcsSequencer *s, uint32_t keepTicks)
     static_cast<VmState &>(*s) = snap.st;
     const uint32_t from = snap.ticks;
     s->playingAfter.resize(from);
+    s->tracksAfter.resize(from);
     while (!s->hostBytes.empty() && s->hostBytes.back().tick >= firstTick + keepTicks)
         s->hostBytes.pop_back();
     if (s->batchDecoded)
@@ -975,6 +987,22 @@ extern "C" int dcs_seq_stream_playing_at(const DcsSequencer *s, uint32_t ticks, 
     if (ticks == 0)
         return s->history[0].st.ch[channel].st != nullptr ? 1 : 0;
     return (s->playingAfter[ticks - 1] >> channel) & 1;
+}
+
+// whether ClearTracks (:1466-1473: every channel's program and stream dropped) would have changed anything after the first `ticks`
+// ticks of the current batch: 0 = no channel had a program or a stream then
+extern "C" int dcs_seq_tracks_active_at(const DcsSequencer *s, uint32_t ticks)
+{
+    if (s == nullptr || ticks > s->batchTicks() || s->history.empty())
+        return 1;
+    if (ticks == 0)
+    {
+        for (const Chan &c : s->history[0].st.ch)
+            if (c.st != nullptr || !c.track.isNull())
+                return 1;
+        return 0;
+    }
+    return (s->playingAfter[ticks - 1] | s->tracksAfter[ticks - 1]) != 0 ? 1 : 0;
 }
 
 extern "C" uint32_t dcs_seq_host_bytes(DcsSequencer *s, DcsHostByte *out, uint32_t cap)

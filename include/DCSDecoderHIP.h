@@ -202,9 +202,10 @@ public:
     // Live playback decodes several MainLoop ticks per kernel launch.  The sequencer simply runs that far ahead; anything that
     // can change what it does -- WriteDataPort, AddTrackCommand, LoadAudioStream, SetMasterVolume, ClearTracks -- first takes it
     // back to the last frame handed out, so the result does not depend on the look-ahead.  By DEFAULT the look-ahead is the
-    // decoder's own business ("N frames of look-ahead when no commands are pending"): kFirstLookahead ticks behind a
-    // command, eight times as many with every refill that no command preceded, up to kMaxLookahead, and never further than two
-    // ticks into silence (nothing playing, no track program, nothing queued).  A caller that pulls samples in a bare loop and has
+    // decoder's own business ("N frames of look-ahead when no commands are pending"): behind a command as many ticks as
+    // the caller pulled between its last two commands (at least kFirstLookahead), eight times as many with every refill that no
+    // command preceded, up to kMaxLookahead, and never further than two ticks into silence (nothing playing, no track program,
+    // nothing queued).  A caller that pulls samples in a bare loop and has
     // never heard of look-ahead gets this.  SetLookahead(n), n >= 1, fixes it at n ticks per launch (1 = tick by tick, as the
     // reference works; for measurements and tests); SetLookahead(0) gives it back to the decoder.
     void SetLookahead(int frames) { lookahead = frames < 0 ? 0 : frames > kMaxLookahead ? kMaxLookahead : frames; }
@@ -246,7 +247,10 @@ private:
     std::vector<DcsHostByte> hostBytes;         // bytes for the host, by tick; [hostNext, end) not delivered yet
     size_t hostNext = 0;
     uint64_t nextTick = 0;                      // tick of the next frame to hand out
+    uint64_t lastCommandTick = 0;               // ... and what it was when the last command arrived
+    uint64_t lastQuiet = 0;                     // frames handed out between the last two commands
     std::string zipError;
+    struct { double loadUs = 0, planUs = 0, decodeUs = 0, syncUs = 0; unsigned refills = 0, syncs = 0; } stats;    // DCS_CLASS_STATS=1
 };
 
 DCSHIP_NAMESPACE_END

@@ -350,6 +350,10 @@ DcsStatus dcs_ctx_clock_mhz(DcsCtx *ctx, float *mhzOut);
 /* device memory -> pinned host memory in GB/s, measured now (five 64 MB copies on the context's stream): what the link allows
  * a sustained end-to-end rate (480 bytes of PCM per frame cross it).  Not part of the decode path. */
 DcsStatus dcs_ctx_link_rate(DcsCtx *ctx, float *gbpsOut);
+/* what a synchronous call on this box cannot get under, to hold the one-shot calls against: an empty kernel launched on the context's
+ * stream and waited for (launchWaitUs), and the same with a copy of nFrames x 516 bytes (PCM, error word, tail) into pinned memory
+ * behind it (launchCopyWaitUs); medians of `iters` rounds, microseconds of host time.  Not part of the decode path. */
+DcsStatus dcs_ctx_call_floor(DcsCtx *ctx, uint32_t nFrames, int iters, float *launchWaitUs, float *launchCopyWaitUs);
 /* test hooks: bound of a consumer's wait for a tail from another chunk in microseconds (0 = the default, 500 ms), and
  * dropExports != 0: no chunk publishes its tail, so every such wait runs into the bound (DCS_FRAME_TAIL_LOST) */
 DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t handoffTimeoutUs, int dropExports);
@@ -658,6 +662,9 @@ int         dcs_seq_stream_playing(const DcsSequencer *seq, int channel);   /* I
 /* ... as it was after the first `ticks` ticks of the current batch, without going back there (a caller that has handed out
  * `ticks` frames of its look-ahead answers IsStreamPlaying from this and keeps the rest) */
 int         dcs_seq_stream_playing_at(const DcsSequencer *seq, uint32_t ticks, int channel);
+/* whether any channel had a track program or a stream after the first `ticks` ticks of the current batch, i.e. whether ClearTracks
+ * (DCSDecoderNative.cpp:1466-1473) would change anything there; 0 = no (a caller that decodes ahead then need not go back) */
+int         dcs_seq_tracks_active_at(const DcsSequencer *seq, uint32_t ticks);
 /* bytes sent to the host since the last successful call; returns their number (call with out = NULL to size) */
 uint32_t    dcs_seq_host_bytes(DcsSequencer *seq, DcsHostByte *out, uint32_t cap);
 /* decode the pending plan (pcmOut = pending ticks x 240 samples) in one launch and clear it; the overlap

@@ -18,11 +18,16 @@
 //       ROM mode (DCSExplorer.cpp:457-488): AddROM per chip, CheckROMs, SoftBoot, SetMasterVolume, then per tick the events
 //       of that tick ("<tick> <kind> <value>": 0 WriteDataPort, 2 SetMasterVolume) and 240 GetNextSample
 //
+//   dcs_pump_bench oneshot <os 0..3> <volume> <level> <iters> <stream.bin> <nFrames> [<nFrames> ...]        (HIP builds only)
+//       the one-shot C ABI underneath the class: dcs_decode_batch over the stream's first nFrames frames, `iters` calls, host
+//       microseconds per call (median), next to what a synchronous call on the box cannot get under (dcs_ctx_call_floor)
+//
 // Prints one JSON object per run on stdout: the decoder's name, frames, per-repetition milliseconds (boot = construction
 // to SoftBoot, play = first command to last sample), the FNV-1a-64 of the last repetition's PCM.  Test infrastructure.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <chrono>
 #include <memory>
 #include <string>
@@ -257,12 +262,69 @@ static int script(int argc, char **argv)
     return 0;
 }
 
+#ifndef PUMP_NATIVE
+static int oneshot(int argc, char **argv)
+{
+    if (argc < 8) return 2;
+    const int os = atoi(argv[2]), volume = atoi(argv[3]), level = atoi(argv[4]), iters = atoi(argv[5]);
+    const std::vector<uint8_t> stream = readFile(argv[6]);
+    const uint32_t total = (static_cast<uint32_t>(stream[0]) << 8) | stream[1];
+    std::vector<DcsFrameIndex> index(total);
+    DcsStreamInfo info;
+    if (dcs_index_stream(static_cast<DcsOsVersion>(os), stream.data(), stream.size(), index.data(), total, &info) != DCS_OK) return 3;
+    std::vector<uint16_t> mm(total);
+    std::vector<uint8_t> vs(total);
+    if (dcs_stream_params(static_cast<DcsOsVersion>(os), volume, level, 255, total, mm.data(), vs.data()) != DCS_OK) return 3;
+    DcsCtx *ctx = nullptr;
+    if (dcs_ctx_create(0, &ctx) != DCS_OK) { fprintf(stderr, "no context: %s\n", dcs_last_error(nullptr)); return 4; }
+    printf("{\"scenario\": \"oneshot\", \"build\": \"%s\", \"iters\": %d, \"calls\": [", kBuild, iters);
+    for (int a = 7 ; a < argc ; ++a)
+    {
+        const uint32_t n = static_cast<uint32_t>(atoi(argv[a]));
+        if (n == 0 || n > static_cast<uint32_t>(info.nValidFrames)) return 2;
+        std::vector<DcsSrcDesc> srcs(n);
+        std::vector<DcsFrameJob> jobs(n);
+        for (uint32_t f = 0 ; f < n ; ++f)
+        {
+            memset(&srcs[f], 0, sizeof(DcsSrcDesc));
+            srcs[f].streamOff = 0; srcs[f].mixMul = mm[f]; srcs[f].format = static_cast<uint8_t>(info.format);
+            srcs[f].hdrLen = static_cast<uint8_t>(info.hdrLen); srcs[f].idx = index[f];
+            memset(&jobs[f], 0, sizeof(DcsFrameJob));
+            jobs[f].firstSrc = f; jobs[f].nSrc = 1; jobs[f].volShift = vs[f];
+            jobs[f].xform = os <= 1 ? DCS_XFORM_93 : DCS_XFORM_94;
+            jobs[f].prev = f == 0 ? DCS_PREV_NONE : f - 1;
+        }
+        std::vector<int16_t> pcm(static_cast<size_t>(n) * 240);
+        std::vector<uint32_t> err(n);
+        std::vector<double> us;
+        for (int i = 0 ; i < iters + 5 ; ++i)
+        {
+            const double t0 = nowMs();
+            if (dcs_decode_batch(ctx, stream.data(), stream.size(), srcs.data(), n, jobs.data(), n, nullptr, 0, pcm.data(), err.data(), nullptr) != DCS_OK)
+            { fprintf(stderr, "dcs_decode_batch: %s\n", dcs_last_error(ctx)); return 5; }
+            if (i >= 5) us.push_back((nowMs() - t0) * 1e3);
+        }
+        std::sort(us.begin(), us.end());
+        float fl = 0, fc = 0;
+        dcs_ctx_call_floor(ctx, n, iters, &fl, &fc);
+        printf("%s{\"frames\": %u, \"us_per_call\": %.2f, \"us_min\": %.2f, \"floor_launch_wait_us\": %.2f, \"floor_launch_copy_wait_us\": %.2f, \"fnv1a64\": \"%016llx\"}",
+               a > 7 ? ", " : "", n, us[us.size() / 2], us[0], fl, fc, static_cast<unsigned long long>(fnv(pcm)));
+    }
+    printf("]}\n");
+    dcs_ctx_destroy(ctx);
+    return 0;
+}
+#endif
+
 int main(int argc, char **argv)
 {
     int rc = 2;
     if (argc > 1 && strcmp(argv[1], "recipe") == 0) rc = recipe(argc, argv);
     else if (argc > 1 && strcmp(argv[1], "extract") == 0) rc = extract(argc, argv);
     else if (argc > 1 && strcmp(argv[1], "script") == 0) rc = script(argc, argv);
+#ifndef PUMP_NATIVE
+    else if (argc > 1 && strcmp(argv[1], "oneshot") == 0) rc = oneshot(argc, argv);
+#endif
     if (rc == 2)
         fprintf(stderr, "usage: see the comment at the top of dcs_pump_bench.cpp\n");
     return rc;

@@ -90,7 +90,7 @@ def run_all(builds=("hip-mirror", "hip-refbase", "native"), lookaheads=(-1, 1), 
     """{scenario: {build[@lookahead]: rate}}; lookahead -1 = the decoder's default, 1 = tick by tick (HIP builds only)"""
     import time
     t_end = time.time() + budget_s
-    out = {"recipe": {}, "extract": {}, "script": {}, "notes": []}
+    out = {"recipe": {}, "extract": {}, "script": {}, "one_shot": None, "notes": []}
     with tempfile.TemporaryDirectory(prefix="dcs_pump_") as tmp:
         inp = make_inputs(tmp)
         for b in builds:
@@ -116,6 +116,12 @@ def run_all(builds=("hip-mirror", "hip-refbase", "native"), lookaheads=(-1, 1), 
                 res = _rate(_run(exe, ["script", s["volume"], la, r, "-", s["ticks"], s["events"]] + s["roms"], left()))
                 out["script"][key] = res
                 if log: log("script %s: %s" % (key, res.get("samples_per_s", res)))
+            if b == "hip-mirror" and time.time() < t_end:
+                # the one-shot C ABI underneath the class: microseconds per dcs_decode_batch call, next to the box's floor
+                name, os_, path = inp["recipe"][-1]
+                res = _run(exe, ["oneshot", os_, 255, 0x64, 300, path, 1, 8, 64, 512], max(5.0, t_end - time.time()))
+                out["one_shot"] = res.get("calls", res)
+                if log: log("one_shot: %s" % (out["one_shot"],))
     # the reference's PCM is the native build's: every other build and look-ahead must hash the same
     def check(d):
         want = d.get("native", {}).get("fnv1a64")
@@ -148,6 +154,9 @@ if __name__ == "__main__":
         row("recipe " + n, d)
     row("extract (64 streams)", res["extract"])
     row("script (2000 ticks, ROM mode)", res["script"])
+    for c in (res.get("one_shot") or []) if isinstance(res.get("one_shot"), list) else []:
+        print("one-shot dcs_decode_batch, %4d frames: %7.2f us per call (min %.2f); floor on this box: launch + wait %.2f us, with the copy down %.2f us"
+              % (c["frames"], c["us_per_call"], c["us_min"], c["floor_launch_wait_us"], c["floor_launch_copy_wait_us"]))
     print(json.dumps(res["bit_exact"]))
     for n in res["notes"]:
         print("note:", n)
