@@ -479,7 +479,10 @@ bool DCSDecoderHIP::Refill()
     else
     {
         st = dcs_seq_plan_ahead(seq, static_cast<uint32_t>(curLookahead), 2, nullptr);
-        curLookahead = curLookahead * 8 > kMaxLookahead ? kMaxLookahead : curLookahead * 8;     // (Sync() takes it back to the start)
+        // (Sync() takes it back to the start.)  What was planned beyond a command is thrown away, half of the last refill on
+        // average: a caller that has been sending commands gets refills that double, one that never has, eightfold ones.
+        const int grown = curLookahead * (lastQuiet != 0 ? 2 : 8);
+        curLookahead = grown > kMaxLookahead ? kMaxLookahead : grown;
     }
     const double t1 = g_classStats ? nowUs() : 0.0;
     if (st == DCS_OK)

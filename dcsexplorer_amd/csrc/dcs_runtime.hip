@@ -1742,9 +1742,11 @@ struct DcsLive
     size_t blobDirty = 0;               // bytes of the device blob written since it was last cleared
     uint64_t blobId = 0;
     std::vector<DcsSlot> slots;
-    // what a call may leave to the link instead of a copy (bytes up, frames down); DCS_LIVE_ZC_UP_KB / DCS_LIVE_ZC_DOWN_FRAMES
-    size_t zcUpBytes = size_t(256) << 10;
-    uint32_t zcDownFrames = 64;
+    // what a call may leave to the link instead of a copy (bytes up, frames down); DCS_LIVE_ZC_UP_KB / DCS_LIVE_ZC_DOWN_FRAMES.
+    // Measured (tools/live_sweep.py, profiles/r06_live_sweep.txt): up to 2 000 frames a call no copy pays in either direction
+    // (1 frame 21 us, 64 frames 26.5 against 36-39 with copies, 2 000 frames 176 against 187); beyond a megabyte the copy engines take over.
+    size_t zcUpBytes = size_t(1) << 20;
+    uint32_t zcDownFrames = 2048;
     // DCS_LIVE_STATS=1: where the calls' time went, printed when the context goes
     struct { double validateUs = 0, planUs = 0, packUs = 0, queueUs = 0, waitUs = 0; unsigned long long calls = 0, frames = 0; } stats;
 };

@@ -203,8 +203,8 @@ public:
     // can change what it does -- WriteDataPort, AddTrackCommand, LoadAudioStream, SetMasterVolume, ClearTracks -- first takes it
     // back to the last frame handed out, so the result does not depend on the look-ahead.  By DEFAULT the look-ahead is the
     // decoder's own business ("N frames of look-ahead when no commands are pending"): behind a command as many ticks as
-    // the caller pulled between its last two commands (at least kFirstLookahead), eight times as many with every refill that no
-    // command preceded, up to kMaxLookahead, and never further than two ticks into silence (nothing playing, no track program,
+    // the caller pulled between its last two commands (at least kFirstLookahead), twice as many with every refill that no command
+    // preceded (eight times for a caller that has not sent a command since its first frame), up to kMaxLookahead, and never further than two ticks into silence (nothing playing, no track program,
     // nothing queued).  A caller that pulls samples in a bare loop and has
     // never heard of look-ahead gets this.  SetLookahead(n), n >= 1, fixes it at n ticks per launch (1 = tick by tick, as the
     // reference works; for measurements and tests); SetLookahead(0) gives it back to the decoder.
