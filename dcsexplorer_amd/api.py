@@ -862,8 +862,9 @@ class Context:
         _check(self.L.dcs_ctx_clock_mhz(self.h, ctypes.byref(mhz)), self.h)
         return mhz.value
 
-    def set_test_hooks(self, handoff_timeout_us=0, drop_exports=False):
-        _check(self.L.dcs_ctx_set_test_hooks(self.h, int(handoff_timeout_us), int(bool(drop_exports))), self.h)
+    def set_test_hooks(self, chunk_order_seed=0, no_xcd_ranges=False):
+        """test hooks: host-planned batches get their chunks in a seeded random order; no batch is launched in XCD ranges"""
+        _check(self.L.dcs_ctx_set_test_hooks(self.h, int(chunk_order_seed), int(bool(no_xcd_ranges))), self.h)
 
     def device_path(self, streams, extra_frames=0):
         return DevicePath(self, streams, extra_frames)

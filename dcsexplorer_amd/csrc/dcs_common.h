@@ -137,8 +137,8 @@ constexpr uint32_t dcsPoolCapacity(int fpw)
 
 #define DCS_SLOT_HALO      0x01u        // do not write PCM / err for this slot
 #define DCS_SLOT_EXT_TAIL  0x02u        // overlap tail comes from tailsIn[job.prev & 0x7FFFFFFF]
-#define DCS_SLOT_EXPORT    0x04u        // publish this frame's tail in handoff[chunk] for a frame of a later chunk
-#define DCS_SLOT_IMPORT    0x08u        // overlap tail comes from handoff[prevJob] (prevJob = the publishing chunk)
+#define DCS_SLOT_EXPORT    0x04u        // this frame's tail meets a frame of another chunk (job nextJob) at handoff[this chunk]
+#define DCS_SLOT_IMPORT    0x08u        // overlap tail meets this frame at handoff[prevJob] (prevJob = the chunk of its predecessor)
 #define DCS_SLOT_KEEP_TAIL 0x10u        // store this frame's tail in tailsOut: the last frame of its chain in the batch (what a caller
                                         // needs to carry a stream into its next batch), or every frame when the batch keeps all tails
 #define DCS_SLOT_EMPTY     0x80u        // padding
@@ -160,10 +160,9 @@ struct DcsSlot                          // 32 bytes: everything the kernel needs
     uint32_t runStartDw;                // first blob dword of run k
     uint16_t runNDw;                    // its length in dwords (whole frames + 3 dwords of window look-ahead)
     uint16_t poolOff;                   // THIS slot's frame: pool dword that holds its first bit
-    // likewise for the first source's stream header and split records: with these the header bytes and the lane's
-    // split record are requested together with the descriptor instead of one memory round trip after it
-    uint32_t hdrDw;                     // blob dword that holds the first header byte (streamOff + 2)
-    uint8_t  hdrSh;                     // byte position of that byte in the dword
+    uint32_t nextJob;                   // DCS_SLOT_EXPORT: the job whose first 16 samples this frame's tail overlaps into (round 6; the
+                                        // field held the blob dword of the stream header, which both packers take from the source)
+    uint8_t  pad_;
     uint8_t  bpl;                       // header bands per unpack lane, ceil(min(nBands, 16) / (64 / fpw)); 0: one lane
                                         // unpacks the whole frame (DCS_IDX_SERIAL)
     uint16_t runPoolOff;                // pool dword where run k goes (a multiple of 4)
@@ -227,8 +226,8 @@ constexpr bool dcsMid15(int format, int bpl, int nb16, uint32_t midBits)
 // requests ALL of it at its first instruction (no load depends on another load).  Round 5 layout (a wavefront reads its whole
 // package, so every byte of it counts as HBM traffic):
 //   [0, fpw x 80)   per slot five 16-byte pieces: the slot (DcsSlot bytes 0..15: job, prevSlot | flags | nSrc | shiftXform,
-//                   firstSrc, prevJob) | descriptor head bytes 0..15 | 16..31 | 32..39 followed by poolOff (u16), bpl (u8)
-//                   and five spare bytes | the stream header (16 B, a 1-byte header zero-extended)
+//                   firstSrc, prevJob) | descriptor head bytes 0..15 | 16..31 | 32..39 followed by poolOff (u16), bpl (u8),
+//                   a spare byte and nextJob (u32) | the stream header (16 B, a 1-byte header zero-extended)
 //   [fpw x 80, ..)  the split record of every lane [64]: 8 bytes (zero for a frame's first lane; the lane's first band in bits
 //                   12..15 of its state word, bit 15 of bitDelta: no bands) -- or, when every source of the batch is a 1994+
 //                   frame, 4 bytes: bitDelta | state << 16 (those layouts carry nothing in prv / prvDelta but band 15's middle,
@@ -269,13 +268,13 @@ struct DcsKernelArgs
     int16_t            *tailsOut;       // nJobs x 16 (may be null)
     const DcsDevTables *tables;
     unsigned long long *debug;          // diagnostic builds only (DCS_STAMPS); null otherwise
-    // tail hand-off between chunks: nChunks x 16 words of (epoch << 32 | payload); a word is valid for this launch
-    // when its epoch equals `epoch` (the batch's launch counter, never 0), so the buffer is never cleared
+    // tails between chunks (the rendezvous, dcs_kernels.hip.h): nChunks x 16 words of epoch << 33 | who << 32 | payload; a word
+    // belongs to this launch when its epoch equals `epoch` (the launch counter, 1 .. 2^31 - 1), so the buffer is never cleared
     unsigned long long *handoff;
     uint32_t            epoch;
     uint32_t            flags;          // DCS_BATCH_*
-    uint32_t            timeoutTicks;   // bound of the wait for a tail from another chunk, 100 MHz ticks
 };
+#define DCS_EPOCH_MAX 0x7FFFFFFFu
 #define DCS_BATCH_HAS_93A_T1 1u         // some source is an OS93a Type-1 frame: workgroups stage the pair table in LDS
 // The chunks are in CHAIN order (a chunk takes its tail from the chunk before it) and the launch maps them to workgroups in XCD
 // RANGES: workgroup i of a launch runs on XCD i % 8 (measured: tools/xcd_map.hip), so with logical workgroup
@@ -376,8 +375,10 @@ DcsStatus dcsBuildPlanFromDigest(const DcsStreamRef *streams, uint32_t nStreams,
 uint32_t dcsImageDwords(const DcsSlot *slots, uint32_t nChunks, int fpw);
 bool dcsAllSources94(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs);
 // (keepAllTails: every frame's slot gets DCS_SLOT_KEEP_TAIL, else only the last frame of every chain)
+// (shuffleSeed != 0, a test hook: the chunks in a seeded random order -- the rendezvous between chunks must not care)
 uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff = true,
-                       int framesPerChunk = 0, bool depthOrder = true, bool keepAllTails = false);
+                       int framesPerChunk = 0, bool depthOrder = true, bool keepAllTails = false, uint32_t shuffleSeed = 0);
+void dcsShuffleChunks(std::vector<DcsSlot> &slots, uint32_t nChunks, int fpw, uint32_t seed);
 // (places: wavefronts of the decode kernel the chip runs at a time -- CUs x 16 -- or 0; the diagnostic entries assume an MI355X)
 #define DCS_MI355X_WAVE_PLACES 4096u
 uint32_t dcsPlanChunksCapped(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,

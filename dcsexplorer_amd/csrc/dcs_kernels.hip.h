@@ -49,13 +49,25 @@ struct Stamper
 };
 #define DCS_STAMP(k) stamp(k)
 
-// default bound of the wait for a tail from another chunk: 500 ms (100 MHz ticks).  A producer publishes before it waits for
-// anything and is dispatched ahead of its consumers, so a wait is microseconds; the bound has to outlast what can keep a
-// dispatched-ahead producer from running at all -- other kernels holding the chip: one pipeline's index rounds are 3 to 15 ms,
-// but several pipelines or ranks on one GPU (48 lists in flight each) can starve a wavefront for many of those in a row, and a
-// resident batch (dcs_batch_run) that runs into the bound returns DCS_FRAME_TAIL_LOST instead of decoding again as the
-// library's one-shot paths do.  A wait that does run into it costs one more decode of the batch, not a wrong sample.
-constexpr uint32_t kHandoffTimeoutTicks = 50000000u;
+// Tails between chunks: a RENDEZVOUS, nobody waits (round 6; rounds 2-5 had the consumer poll for up to 500 ms, which rested on
+// workgroups being dispatched in index order).  The last frame of a chunk whose successor lies in another chunk (the producer,
+// DCS_SLOT_EXPORT) and that successor (the consumer, DCS_SLOT_IMPORT) each do ONE 64-bit atomic exchange per tail word on the
+// producing chunk's row of the hand-off buffer: the producer offers  epoch | 0 | its tail sample (pair),  the consumer
+// epoch | 1 | its own first output sample (pair) before the overlap.  Whoever finds the other's word of THIS launch in what the
+// exchange returns is the second to arrive, holds both halves, computes the overlap (DCSDecoderNative.cpp:538-555, :789-802) and
+// stores the sample into the consumer's PCM row; whoever finds anything else was first and is finished for.  Both sides hold the
+// overlap window (one transform per chain), the producer knows the consumer's job from its slot (DcsSlot::nextJob).  No order of
+// dispatch, no residency and no other launch on the chip matters, and nothing can be lost.
+//   word = epoch (31 bits) << 33 | who << 32 | payload (32 bits; 1993 transform: one 16-bit sample)
+__device__ __forceinline__ unsigned long long handoffWord(uint32_t epoch, uint32_t who, uint32_t payload)
+{
+    return (static_cast<unsigned long long>(epoch) << 33) | (static_cast<unsigned long long>(who) << 32) | payload;
+}
+// the other side's word of this launch?
+__device__ __forceinline__ bool handoffMeets(unsigned long long old, uint32_t epoch, uint32_t whoWanted)
+{
+    return static_cast<uint32_t>(old >> 32) == ((epoch << 1) | whoWanted);
+}
 constexpr int kWavesPerBlock = 4;       // wavefronts of a workgroup share one copy of the decode tables in LDS
 #ifndef DCS_ROW_BYTES
 #define DCS_ROW_BYTES 528
@@ -1412,13 +1424,12 @@ template <int FPW>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, DCS_MIN_WAVES)
 dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChunks, uint32_t kFlags, uint32_t kEpoch, uint32_t kNJobs,
                 int16_t *kPcm, unsigned long long *kHandoff, uint32_t *kErr, int16_t *kTailsOut,
-                const uint8_t *kBlob, uint64_t kBlobLen, const DcsSrcDesc *kSrcs, const int16_t *kTailsIn, unsigned long long *kDebug,
-                uint32_t kTimeoutTicks)
+                const uint8_t *kBlob, uint64_t kBlobLen, const DcsSrcDesc *kSrcs, const int16_t *kTailsIn, unsigned long long *kDebug)
 {
     DcsKernelArgs a;
     a.blob = kBlob; a.blobLen = kBlobLen; a.srcs = kSrcs; a.packages = kPackages; a.nChunks = kNChunks; a.nJobs = kNJobs;
     a.pcm = kPcm; a.err = kErr; a.tailsIn = kTailsIn; a.tailsOut = kTailsOut; a.tables = kTables; a.debug = kDebug;
-    a.handoff = kHandoff; a.epoch = kEpoch; a.flags = kFlags; a.timeoutTicks = kTimeoutTicks;
+    a.handoff = kHandoff; a.epoch = kEpoch; a.flags = kFlags;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = static_cast<int>(threadIdx.x) >> 6;
     const int lane = static_cast<int>(threadIdx.x) & 63;
@@ -1470,7 +1481,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     constexpr int kPoolPieces = (poolDwords(FPW) + 255) / 256;
     uint4 pimg[kPoolPieces];
     {
-        static_assert(sizeof(DcsSlot) == 32 && offsetof(DcsSlot, runStartDw) == 16 && offsetof(DcsSlot, hdrDw) == 24 && DCS_PKG_SLOT_BYTES == 80, "DcsSlot / package layout");
+        static_assert(sizeof(DcsSlot) == 32 && offsetof(DcsSlot, runStartDw) == 16 && offsetof(DcsSlot, nextJob) == 24 && DCS_PKG_SLOT_BYTES == 80, "DcsSlot / package layout");
         phead0 = reinterpret_cast<const uint4 *>(pkg)[min(lane, kHeadVec - 1)];
         if (kHeadLoads > 1)
             phead1 = reinterpret_cast<const uint4 *>(pkg)[min(lane + 64, kHeadVec - 1)];
@@ -1530,6 +1541,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
 
     // hand the package head to the lanes: through this wavefront's bit pool (filled with the image right after)
     struct { uint32_t job; uint32_t prevSlot, flags, nSrc, shiftXform; uint32_t firstSrc, prevJob, poolOff, bpl; } slot;
+    uint32_t exportNext;                                // where the chunk's tail for another chunk is due (a scalar: see below)
     uint4 pd0, pd1, phdr;
     uint2 pd2;
     {
@@ -1552,6 +1564,10 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
         slot.firstSrc = s0.z; slot.prevJob = s0.w;
         slot.poolOff = d2v.z & 0xFFFFu;
         slot.bpl = (d2v.z >> 16) & 0xFFu;
+        // (DCS_SLOT_EXPORT: the job whose first samples this frame's tail overlaps into.  A chunk has at most one such frame, its
+        // last one, so this is the same for every lane: taken into a scalar register here, no vector register lives through phase 1)
+        const unsigned long long exportSlots = __ballot(lane < FPW && !(slot.flags & DCS_SLOT_EMPTY) && (slot.flags & DCS_SLOT_EXPORT) != 0);
+        exportNext = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(d2v.w), exportSlots != 0 ? static_cast<int>(__builtin_ctzll(exportSlots)) : 0));
     }
 
     // the lane's transform constants for the chunk's first frame (the whole chunk, normally): requested now, needed in
@@ -1876,24 +1892,10 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     DCS_STAMP(7);
 #endif
     const int nSlots = __popcll(__ballot(live && lane < FPW));          // padding slots are trailing
-    const int slotFlags = slot.flags, slotJob = static_cast<int>(slot.job);
+    const int slotJob = static_cast<int>(slot.job);
     const int slotWord = static_cast<int>(slot.flags | (slot.prevSlot << 8) | (static_cast<uint32_t>(job.volShift) << 16));
     const int jobXform = job.xform, jobPrev = static_cast<int>(job.prev);
 
-    // frames that take their tail from an earlier chunk are finished after the last pass (see below); the first poll for
-    // the first of them (normally the only one) is issued in the last pass just BEFORE that pass's PCM stores, so that
-    // its wait does not include those stores (loads and stores retire in issue order)
-    const unsigned long long importSlots = __ballot(live && lane < FPW && (slotFlags & DCS_SLOT_IMPORT) != 0);
-    const int firstImport = importSlots != 0 ? __builtin_ctzll(importSlots) : 0;
-    const int firstImportXf = __builtin_amdgcn_readlane(jobXform, firstImport);
-    const unsigned long long *firstImportSrc = a.handoff + static_cast<size_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(jobPrev, firstImport))) * 16
-                                             + ((firstImportXf == DCS_XFORM_94) ? bitrevN(lane & 7, 3) : bitrevN(lane & 15, 4));
-    unsigned long long earlyWord = 0;
-    auto earlyPoll = [&](bool lastPass)
-    {
-        if (lastPass && importSlots != 0 && lane < ((firstImportXf == DCS_XFORM_94) ? 8 : 16))
-            earlyWord = __hip_atomic_load(firstImportSrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
 
     const unsigned long long slots94 = __ballot(live && lane < FPW && jobXform == DCS_XFORM_94);
     const bool oneXform = slots94 == 0 || slots94 == __ballot(live && lane < FPW);
@@ -1979,48 +1981,82 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
             else
                 reinterpret_cast<uint16_t *>(tails)[ts * 16 + lr] = static_cast<uint16_t>(x[15]);
         }
-        // ... and, for the last frame of a chunk whose successor lies in a later chunk, in the hand-off buffer: the
-        // payload travels inside the same 64-bit word as the launch's epoch, so no fence or flag is needed
-        if (active && (myFlags & DCS_SLOT_EXPORT))
-        {
-            const uint32_t payload = (xf == DCS_XFORM_94) ? x[15] : (x[15] & 0xFFFFu);
-            __hip_atomic_store(a.handoff + static_cast<size_t>(chunk) * 16 + lr,
-                               (static_cast<unsigned long long>(a.epoch) << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         waveSync();
 
         if (s0 == 0) DCS_STAMP(15);
         const bool emit = active && !(myFlags & DCS_SLOT_HALO);
-        // A frame whose tail comes from an earlier chunk (DCS_SLOT_IMPORT) is finished after the last pass: its first
-        // 16 output samples, not yet overlapped, wait in its tile row (dead after the transform).  Waiting here
-        // instead would chain the chunks of a stream one behind the other (this chunk's LAST frame, which the next
-        // chunk waits for, is transformed in a later pass).
-        const bool deferred = active && (myFlags & DCS_SLOT_IMPORT) != 0;
         const bool hasPrev = myPrevSlot != DCS_NO_PREV_SLOT;
+        // Where the successor or the predecessor lies in another chunk, the frame goes to the rendezvous (see the top of this file):
+        // its tail for a successor elsewhere (DCS_SLOT_EXPORT), its own first sample (pair), NOT overlapped, for a tail from
+        // elsewhere (DCS_SLOT_IMPORT; such a frame leaves its first 16 samples to whoever arrives second).  The exchanges are issued
+        // half way through the PCM stores -- the registers their results take have just come free, and the other half of the stores
+        // covers their way to memory and back -- and looked at behind the last store.
+        const bool exporter = active && (myFlags & DCS_SLOT_EXPORT) != 0;
+        const bool deferred = active && (myFlags & DCS_SLOT_IMPORT) != 0;
+#ifndef DCS_RDV_SPLIT_FPW4
+#define DCS_RDV_SPLIT_FPW4 12
+#endif
+        // (stores issued in front of the exchanges: with 4 frames per wavefront -- sixteen lanes unpack a frame, the longest-lived
+        // register set -- the exchanges' results only fit behind twelve of them)
+        constexpr int kSplit = FPW == 4 ? DCS_RDV_SPLIT_FPW4 : 8;
+        // (the lane's output position once more, opaque to the compiler: with 4 frames per wavefront every pass runs the same transform,
+        // and the addresses behind the transform, hoisted out of the pass loop as 64-bit pairs, cost the transform its registers)
+        int lrA = lr;
+        if (FPW == 4)
+            asm volatile("" : "+v"(lrA));
+        unsigned long long metAsProducer = 0, metAsConsumer = 0;
+        auto rendezvous = [&](uint32_t mine0, uint32_t tailOut)
+        {
+            if (exporter)
+                metAsProducer = __hip_atomic_exchange(a.handoff + static_cast<size_t>(chunk) * 16 + lrA, handoffWord(a.epoch, 0u, tailOut),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (deferred)
+                metAsConsumer = __hip_atomic_exchange(a.handoff + static_cast<size_t>(myPrevJob) * 16 + lrA, handoffWord(a.epoch, 1u, mine0),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
         // (The PCM leaves as 15 two- resp. four-byte stores per lane.  Putting a frame's samples in order in its dead tile
         // row first and storing 16 bytes per lane -- 2 resp. 4 store instructions -- was measured twice: 5 % slower, the
         // extra LDS round trip is on the critical path and the narrow stores are not.  Swapping registers r and r + 8
         // with lane l ^ 8 by DPP and storing sample PAIRS, 8 stores instead of 15 for a 1993 frame: no difference.)
-        // everybody stashes (only a deferred frame's row is read again; the row is dead otherwise)
-        P.rowC[lr] = x[0];
         if (xf == DCS_XFORM_94)
         {
             // overlap-add on sample pair m = bitrev3(l) (register 0) (:538-555)
             uint32_t tailPair = tails[(hasPrev ? myPrevSlot : mySlot) * 8 + lr];
             tailPair = hasPrev ? tailPair : extTail;
-            x[0] = packC(overlapMix(reC(x[0]), C.k[DCS_K94_OVLA] & 0xFFFFu, reC(tailPair), C.k[DCS_K94_OVLB] & 0xFFFFu),
-                         overlapMix(imC(x[0]), C.k[DCS_K94_OVLA] >> 16, imC(tailPair), C.k[DCS_K94_OVLB] >> 16));
-            earlyPoll(s0 + n >= nSlots);
+            const uint32_t mixed = packC(overlapMix(reC(x[0]), C.k[DCS_K94_OVLA] & 0xFFFFu, reC(tailPair), C.k[DCS_K94_OVLB] & 0xFFFFu),
+                                         overlapMix(imC(x[0]), C.k[DCS_K94_OVLA] >> 16, imC(tailPair), C.k[DCS_K94_OVLB] >> 16));
+            x[0] = deferred ? x[0] : mixed;                             // (a deferred frame keeps the raw pair for the rendezvous)
+            uint32_t *out = reinterpret_cast<uint32_t *>(a.pcm) + static_cast<size_t>(myJob) * (DCS_FRAME_SAMPLES / 2) + lrA;
             if (emit)
             {
-                uint32_t *out = reinterpret_cast<uint32_t *>(a.pcm) + static_cast<size_t>(myJob) * (DCS_FRAME_SAMPLES / 2) + lr;
                 if (!deferred)
                     out[0] = x[0];
 #pragma unroll
-                for (int r = 1 ; r < 15 ; ++r)
+                for (int r = 1 ; r < kSplit ; ++r)
                     out[8 * bitrevN(r, 4)] = x[r];                      // pair 8*bitrev4(r) + bitrev3(l)
+            }
+            rendezvous(x[0], x[15]);
+            if (emit)
+            {
+#pragma unroll
+                for (int r = kSplit ; r < 15 ; ++r)
+                    out[8 * bitrevN(r, 4)] = x[r];
                 if (a.tailsOut != nullptr && (myFlags & DCS_SLOT_KEEP_TAIL))
-                    reinterpret_cast<uint32_t *>(a.tailsOut)[static_cast<size_t>(myJob) * 8 + lr] = x[15];
+                    reinterpret_cast<uint32_t *>(a.tailsOut)[static_cast<size_t>(myJob) * 8 + lrA] = x[15];
+            }
+            // the second to arrive finishes the consumer's first sample pair
+            if (deferred && handoffMeets(metAsConsumer, a.epoch, 0u))
+            {
+                const uint32_t theirTail = static_cast<uint32_t>(metAsConsumer);
+                out[0] = packC(overlapMix(reC(x[0]), C.k[DCS_K94_OVLA] & 0xFFFFu, reC(theirTail), C.k[DCS_K94_OVLB] & 0xFFFFu),
+                               overlapMix(imC(x[0]), C.k[DCS_K94_OVLA] >> 16, imC(theirTail), C.k[DCS_K94_OVLB] >> 16));
+            }
+            if (exporter && handoffMeets(metAsProducer, a.epoch, 1u))
+            {
+                const uint32_t theirs = static_cast<uint32_t>(metAsProducer);
+                reinterpret_cast<uint32_t *>(a.pcm)[static_cast<size_t>(exportNext) * (DCS_FRAME_SAMPLES / 2) + lrA] =
+                    packC(overlapMix(reC(theirs), C.k[DCS_K94_OVLA] & 0xFFFFu, reC(x[15]), C.k[DCS_K94_OVLB] & 0xFFFFu),
+                          overlapMix(imC(theirs), C.k[DCS_K94_OVLA] >> 16, imC(x[15]), C.k[DCS_K94_OVLB] >> 16));
             }
         }
         else
@@ -2028,74 +2064,36 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
             // overlap-add on sample i = bitrev4(l) (register 0) (:789-802)
             int tailSample = static_cast<int16_t>(reinterpret_cast<const uint16_t *>(tails)[(hasPrev ? myPrevSlot : mySlot) * 16 + lr]);
             tailSample = hasPrev ? tailSample : sx16(extTail);
-            x[0] = static_cast<uint32_t>(overlapMix(reC(x[0]), C.k[DCS_K93_OVL] & 0xFFFFu, tailSample, C.k[DCS_K93_OVL] >> 16)) & 0xFFFFu;
-            earlyPoll(s0 + n >= nSlots);
+            const uint32_t mixed = static_cast<uint32_t>(overlapMix(reC(x[0]), C.k[DCS_K93_OVL] & 0xFFFFu, tailSample, C.k[DCS_K93_OVL] >> 16)) & 0xFFFFu;
+            x[0] = deferred ? (x[0] & 0xFFFFu) : mixed;
+            int16_t *out = a.pcm + static_cast<size_t>(myJob) * DCS_FRAME_SAMPLES + lrA;
             if (emit)
             {
-                int16_t *out = a.pcm + static_cast<size_t>(myJob) * DCS_FRAME_SAMPLES + lr;
                 if (!deferred)
                     out[0] = static_cast<int16_t>(x[0]);
 #pragma unroll
-                for (int r = 1 ; r < 15 ; ++r)
+                for (int r = 1 ; r < kSplit ; ++r)
                     out[16 * bitrevN(r, 4)] = static_cast<int16_t>(x[r]);          // sample 16*bitrev4(r) + bitrev4(l)
-                if (a.tailsOut != nullptr && (myFlags & DCS_SLOT_KEEP_TAIL))
-                    a.tailsOut[static_cast<size_t>(myJob) * 16 + lr] = static_cast<int16_t>(x[15]);
             }
+            rendezvous(x[0], x[15] & 0xFFFFu);
+            if (emit)
+            {
+#pragma unroll
+                for (int r = kSplit ; r < 15 ; ++r)
+                    out[16 * bitrevN(r, 4)] = static_cast<int16_t>(x[r]);
+                if (a.tailsOut != nullptr && (myFlags & DCS_SLOT_KEEP_TAIL))
+                    a.tailsOut[static_cast<size_t>(myJob) * 16 + lrA] = static_cast<int16_t>(x[15]);
+            }
+            if (deferred && handoffMeets(metAsConsumer, a.epoch, 0u))
+                out[0] = static_cast<int16_t>(overlapMix(reC(x[0]), C.k[DCS_K93_OVL] & 0xFFFFu, sx16(static_cast<uint32_t>(metAsConsumer)), C.k[DCS_K93_OVL] >> 16));
+            if (exporter && handoffMeets(metAsProducer, a.epoch, 1u))
+                a.pcm[static_cast<size_t>(exportNext) * DCS_FRAME_SAMPLES + lrA] =
+                    static_cast<int16_t>(overlapMix(reC(static_cast<uint32_t>(metAsProducer)), C.k[DCS_K93_OVL] & 0xFFFFu, sx16(x[15]), C.k[DCS_K93_OVL] >> 16));
         }
         waveSync();
         s0 += n;
     }
 
-    // ---- frames that take their tail from an earlier chunk: every tail this chunk publishes is out by now, so
-    // waiting cannot hold anybody up.  The producer was dispatched before this chunk and waits for nothing before it
-    // publishes, so the wait is short; it is bounded all the same (a word that never arrives costs the frame an
-    // error flag, not the launch).  Lane l of the first lane group finishes sample (pair) bitrev(l), for which it
-    // holds the overlap window in its constants.
-    DCS_STAMP(13);
-    for (unsigned long long pending = importSlots ; pending != 0 ; pending &= pending - 1)
-    {
-        const int sI = __builtin_ctzll(pending);
-        const int xf = __builtin_amdgcn_readlane(jobXform, sI);
-        const uint32_t jobI = static_cast<uint32_t>(__builtin_amdgcn_readlane(slotJob, sI));
-        const uint32_t fromChunk = static_cast<uint32_t>(__builtin_amdgcn_readlane(jobPrev, sI));
-        const int lpf = (xf == DCS_XFORM_94) ? 8 : 16;
-        if (xf != constsXform)
-        {
-            constsXform = xf;                       // (the chunk's last pass ran the other transform)
-            loadLaneConsts(a.tables, lane, constsXform, C);
-        }
-        if (lane < lpf)
-        {
-            const int k = (xf == DCS_XFORM_94) ? bitrevN(lane, 3) : bitrevN(lane, 4);
-            const unsigned long long *src = a.handoff + static_cast<size_t>(fromChunk) * 16 + k;
-            // (Tried without gain: a second poll half way through the PCM stores; scalar loads (s_load_dwordx16 glc) of the
-            // producer's sixteen words, which do not queue behind this wavefront's stores; polling at workgroup scope first
-            // -- the XCD's L2, with the chunks dealt to the XCDs in contiguous runs so that producer and consumer share
-            // one -- which never saw the producer's write-through store in time.  The polls go to memory.)
-            unsigned long long w = (sI == firstImport) ? earlyWord : 0ull;              // (epoch 0 never matches)
-            // (bounded by wall time, 100 MHz ticks)
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (static_cast<uint32_t>(w >> 32) != a.epoch && __builtin_amdgcn_s_memrealtime() - t0 < a.timeoutTicks)
-            {
-                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (static_cast<uint32_t>(w >> 32) != a.epoch)
-                    __builtin_amdgcn_s_sleep(1);
-            }
-            uint32_t tail = 0;
-            if (static_cast<uint32_t>(w >> 32) == a.epoch)
-                tail = static_cast<uint32_t>(w);
-            else if (a.err != nullptr)
-                atomicOr(&a.err[jobI], DCS_FRAME_FATAL | DCS_FRAME_TAIL_LOST);
-            const uint32_t x0 = reinterpret_cast<const uint32_t *>(L.row(sI))[k];
-            if (xf == DCS_XFORM_94)
-                reinterpret_cast<uint32_t *>(a.pcm)[static_cast<size_t>(jobI) * (DCS_FRAME_SAMPLES / 2) + k] =
-                    packC(overlapMix(reC(x0), C.k[DCS_K94_OVLA] & 0xFFFFu, reC(tail), C.k[DCS_K94_OVLB] & 0xFFFFu),
-                          overlapMix(imC(x0), C.k[DCS_K94_OVLA] >> 16, imC(tail), C.k[DCS_K94_OVLB] >> 16));
-            else
-                a.pcm[static_cast<size_t>(jobI) * DCS_FRAME_SAMPLES + k] =
-                    static_cast<int16_t>(overlapMix(reC(x0), C.k[DCS_K93_OVL] & 0xFFFFu, sx16(tail), C.k[DCS_K93_OVL] >> 16));
-        }
-    }
     DCS_STAMP(6);
 }
 

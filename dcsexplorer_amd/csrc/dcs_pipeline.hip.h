@@ -405,10 +405,9 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
     const uint8_t *blob = fromDevice ? job->hBlob : built.blob.data();
     const size_t blobLen = fromDevice ? job->hBlobLen : built.blob.size();
     double t1 = nowMs(), t2 = t1;
-    // (second attempt, tails by re-decoding the predecessor, only after a lost tail: see dcs_decode_batch)
-    for (int attempt = 0 ; st == DCS_OK && attempt < 2 ; ++attempt)
+    if (st == DCS_OK)
     {
-        const bool handoff = p->ctx->handoff && attempt == 0;
+        const bool handoff = p->ctx->handoff;
         const DcsBuiltStreams &B = built;
         if (devicePacked)
             st = createBatchOnDevice(p->ctx, planScratch.jobs.data(), static_cast<uint32_t>(planScratch.jobs.size()), planScratch.srcs.data(),
@@ -428,14 +427,6 @@ static DcsStatus pipelineDecode(DcsPipeline *p, DcsPipeline::Job *job, hipStream
         if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
         pipeLog("worker", 0, "kernels", tk0, tk1);
         pipeLog("worker", 0, "download", tk1, nowMs());
-        bool lost = false;
-        if (st == DCS_OK && handoff)
-            for (size_t j = 0 ; j < nJobsBuilt && !lost ; ++j)
-                lost = (job->err[j] & DCS_FRAME_TAIL_LOST) != 0;
-        if (!lost)
-            break;
-        dcs_batch_destroy(job->batch);
-        job->batch = nullptr;
     }
     // A failed list may have left its pack kernel (which reads dBlob and the round's records) in flight: nothing of it
     // runs any more when those buffers go back to the cache, which knows nothing of streams.  (A list that succeeded has
@@ -534,7 +525,6 @@ static DcsStatus pipelineDecodePlanned(DcsPipeline *p, DcsPipeline::Job *job, hi
     // close early as the host planner does: the list is planned again with fewer frames per chunk -- three quarters, then half of the
     // slots -- before the host path gets it (one stream of large frames among 600 would otherwise cost the whole list the device).
     double t1 = t0, t2 = t0;
-    bool lost = false;
     uint32_t flag = 0;
     const int fullFpw = chooseFpw(ctx, static_cast<uint32_t>(nJobs), all94);
     const int tries[3] = { 0, fullFpw * 3 / 4, fullFpw / 2 };
@@ -553,23 +543,18 @@ static DcsStatus pipelineDecodePlanned(DcsPipeline *p, DcsPipeline::Job *job, hi
         if (st == DCS_OK) pipelineDownPolicy(p, job->batch);
         if (st == DCS_OK) st = dcs_batch_download_view(job->batch, &job->pcm, &job->err);
         pipeLog("worker", 0, "download", t2, nowMs());
-        lost = false;
         flag = 0;
         if (st == DCS_OK)
-        {
             flag = batchPlanFlag(job->batch);
-            for (size_t j = 0 ; j < nJobs && !lost && flag == 0 ; ++j)
-                lost = (job->err[j] & DCS_FRAME_TAIL_LOST) != 0;
-        }
         // again with fewer slots only for an overflow, and not when the list is (also) truncated: that one is the host's whatever the plan
         if (st != DCS_OK || (flag & DCS_PLAN_POOL_OVERFLOW) == 0 || (flag & DCS_PLAN_TRUNCATED) != 0)
             break;
     }
     job->hostMs += t1 - t0;
     job->deviceMs += nowMs() - t1;
-    if (st != DCS_OK || flag != 0 || lost)
+    if (st != DCS_OK || flag != 0)
     {
-        // not served (or failed): nothing of this attempt stays; (a lost tail -- see dcs_decode_batch -- also goes to the other path)
+        // not served (or failed): nothing of this attempt stays
         if (job->batch != nullptr) { dcs_batch_destroy(job->batch); job->batch = nullptr; }
         (void)streamWait(ctx, stream);
         pipelineFreeIndexBuffers(p, job, false);

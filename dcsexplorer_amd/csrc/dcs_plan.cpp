@@ -12,6 +12,7 @@
 // index.
 #include "dcs_common.h"
 #include <string.h>
+#include <algorithm>
 #include <thread>
 #include <vector>
 
@@ -40,8 +41,6 @@ static DcsSlot makeSlot(const DcsFrameJob &jb, uint32_t job, uint8_t prevSlot, u
     if (srcs != nullptr && jb.nSrc != 0)
     {
         const Src &sd = srcs[jb.firstSrc];
-        sl.hdrDw = static_cast<uint32_t>((srcStreamOff(sd) + 2) >> 2);
-        sl.hdrSh = static_cast<uint8_t>((srcStreamOff(sd) + 2) & 3);
         const int sub = 64 / fpw;
         const int nb16 = srcNBands(sd) < 16 ? srcNBands(sd) : 16;
         const int bpl = (nb16 + sub - 1) / sub;
@@ -227,6 +226,7 @@ static uint32_t planChunks(const DcsFrameJob *jobs, uint32_t nJobs, const Src *s
             else if (canImport(prev))
             {
                 slots[homePos[prev]].flags |= DCS_SLOT_EXPORT;
+                slots[homePos[prev]].nextJob = j;           // (whoever arrives second at the rendezvous finishes job j's first samples)
                 flags |= DCS_SLOT_IMPORT;
                 importFrom = homeChunk[prev];
             }
@@ -316,10 +316,39 @@ static uint32_t planChunks(const DcsFrameJob *jobs, uint32_t nJobs, const Src *s
     return chunk;
 }
 
-uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
-                       int framesPerChunk, bool depthOrder, bool keepAllTails)
+// test hook: the chunks of a plan in a seeded random order (a chunk that takes a tail names its predecessor's chunk: renumbered)
+void dcsShuffleChunks(std::vector<DcsSlot> &slots, uint32_t nChunks, int fpw, uint32_t seed)
 {
-    return planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk, depthOrder, keepAllTails, 0);
+    if (seed == 0 || nChunks < 2)
+        return;
+    const size_t F = static_cast<size_t>(fpw);
+    std::vector<uint32_t> newIndex(nChunks);
+    for (uint32_t c = 0 ; c < nChunks ; ++c)
+        newIndex[c] = c;
+    uint64_t x = seed;
+    for (uint32_t c = nChunks - 1 ; c > 0 ; --c)
+    {
+        x = x * 6364136223846793005ull + 1442695040888963407ull;
+        std::swap(newIndex[c], newIndex[static_cast<uint32_t>((x >> 33) % (c + 1))]);
+    }
+    std::vector<DcsSlot> moved(slots.size());
+    for (uint32_t c = 0 ; c < nChunks ; ++c)
+        for (size_t k = 0 ; k < F ; ++k)
+        {
+            DcsSlot sl = slots[c * F + k];
+            if (!(sl.flags & DCS_SLOT_EMPTY) && (sl.flags & DCS_SLOT_IMPORT))
+                sl.prevJob = newIndex[sl.prevJob];
+            moved[static_cast<size_t>(newIndex[c]) * F + k] = sl;
+        }
+    slots.swap(moved);
+}
+
+uint32_t dcsPlanChunks(const DcsFrameJob *jobs, uint32_t nJobs, const DcsSrcDesc *srcs, int fpw, std::vector<DcsSlot> &slots, bool handoff,
+                       int framesPerChunk, bool depthOrder, bool keepAllTails, uint32_t shuffleSeed)
+{
+    const uint32_t n = planChunks(jobs, nJobs, srcs, fpw, slots, handoff, framesPerChunk, depthOrder, keepAllTails, 0);
+    dcsShuffleChunks(slots, n, fpw, shuffleSeed);
+    return n;
 }
 
 // A resident batch is planned for the shortest packages that cost it next to nothing: the plan above, then -- when its fullest
@@ -474,6 +503,7 @@ static void packChunks(const DcsSlot *slots, uint32_t c0, uint32_t c1, int fpw, 
             memcpy(ps, &sl, 16);                            // job, prevSlot | flags | nSrc | shiftXform, firstSrc, prevJob
             memcpy(ps + 56, &sl.poolOff, 2);
             ps[58] = sl.bpl;
+            memcpy(ps + 60, &sl.nextJob, 4);
             if ((sl.flags & DCS_SLOT_EMPTY) || sl.nSrc == 0 || srcs == nullptr)
                 continue;
             const DcsSrcDesc &sd = srcs[sl.firstSrc];

@@ -28,8 +28,8 @@ struct DcsCtx
     DcsDevTables *dTables = nullptr;
     int fpwOverride = 0;
     bool handoff = true;                // tails cross chunk boundaries through the hand-off buffer (else: halo re-decode)
-    uint32_t handoffTimeoutTicks = dcsk::kHandoffTimeoutTicks;     // 100 MHz ticks (dcs_ctx_set_test_hooks)
-    bool dropExports = false;           // test hook: no chunk publishes its tail (dcs_ctx_set_test_hooks)
+    uint32_t shuffleSeed = 0;           // test hook: host-planned batches get their chunks in a seeded random order (dcs_ctx_set_test_hooks)
+    bool noXcdRanges = false;           // test hook: no batch of this context is launched in XCD ranges
     int framesPerChunk = 0;             // diagnostic: frames a wavefront decodes (0 = as many as the kernel variant has slots)
     bool xcdRanges = false;             // batches of this context: chain order, launched in XCD ranges (dcs_ctx_set_concurrent_batches)
     bool keepAllTails = false;          // resident batches store EVERY frame's tail (dcs_ctx_set_batch_tails); default: the last frame of every chain
@@ -615,13 +615,12 @@ extern "C" uint32_t dcs_batch_package_bytes(const DcsBatch *b)
     return b ? dcsPkgStride(b->fpw, dcsPkgImgDw(b->imgDw) != 0 ? b->imgDw : (b->imgDw | dcsPoolCapacity(b->fpw))) : 0;
 }
 
-extern "C" DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t handoffTimeoutUs, int dropExports)
+extern "C" DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t chunkOrderSeed, int noXcdRanges)
 {
     if (ctx == nullptr)
         return DCS_ERR_INVALID_ARG;
-    ctx->handoffTimeoutTicks = handoffTimeoutUs == 0 ? dcsk::kHandoffTimeoutTicks
-                             : handoffTimeoutUs > 40000000u ? 4000000000u : handoffTimeoutUs * 100u;
-    ctx->dropExports = dropExports != 0;
+    ctx->shuffleSeed = chunkOrderSeed;
+    ctx->noXcdRanges = noXcdRanges != 0;
     return DCS_OK;
 }
 
@@ -684,7 +683,6 @@ static DcsKernelArgs kernelArgs(const DcsBatch *b)
     args.handoff = b->dHandoff;
     args.epoch = b->epoch;
     args.flags = b->flags | ((dcsPkgImgDw(b->imgDw) != 0 ? b->imgDw : (b->imgDw | dcsPoolCapacity(b->fpw))) << DCS_BATCH_IMG_SHIFT);
-    args.timeoutTicks = b->ctx->handoffTimeoutTicks;
     return args;
 }
 
@@ -799,7 +797,7 @@ static DcsStatus createBatch(DcsCtx *ctx,
     uint8_t *hPackages = nullptr;           // pinned staging for the chunk packages
     size_t pkgBytes = 0;
     static const bool forceRanges = getenv("DCS_BATCH_XCD_RANGES") != nullptr && atoi(getenv("DCS_BATCH_XCD_RANGES")) != 0;     // (experiment switch)
-    const bool ranges = tlsXcdRanges || ctx->xcdRanges || forceRanges;
+    const bool ranges = (tlsXcdRanges || ctx->xcdRanges || forceRanges) && !ctx->noXcdRanges;
     // (experiment switch, for A/B runs on one binary: round 4's packages -- the full pool image, every frame's tail stored)
     static const bool fullImage = getenv("DCS_EXP_FULL_IMAGE") != nullptr && atoi(getenv("DCS_EXP_FULL_IMAGE")) != 0;
     const bool allTails = ctx->keepAllTails || tlsKeepAllTails || fullImage;
@@ -811,13 +809,11 @@ static DcsStatus createBatch(DcsCtx *ctx,
         b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges, allTails);
         b->imgDw = fullImage ? dcsPoolCapacity(b->fpw) : dcsImageDwords(slots.data(), b->nChunks, b->fpw);
     }
+    dcsShuffleChunks(slots, b->nChunks, b->fpw, ctx->shuffleSeed);          // (test hook)
     if (!fullImage && dcsAllSources94(jobs, nJobs, srcs))
         b->imgDw |= DCS_PKG_SPLIT4;             // (the layout word: every source a 1994+ frame -> 4-byte split records)
     if (ranges && handoff)
         b->flags |= DCS_BATCH_XCD_RANGES;
-    if (ctx->dropExports)
-        for (DcsSlot &sl : slots)
-            sl.flags &= static_cast<uint8_t>(~DCS_SLOT_EXPORT);      // test hook: imports without a producer
 
     // algorithmic bytes per launch: the exact compressed payload, the header (and U16 frame count) of every
     // stream the batch draws on, a 56-byte frame descriptor per source, 480 bytes of PCM per output frame.  abiBytes
@@ -948,7 +944,7 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
         ps[0] = reinterpret_cast<const uint4 *>(&cs[lane])[0];
         ps[1] = make_uint4(d[0], d[1], d[2], d[3]);
         ps[2] = make_uint4(d[4], d[5], d[6], d[7]);
-        ps[3] = make_uint4(d[8], d[9], static_cast<uint32_t>(sl.poolOff) | (static_cast<uint32_t>(sl.bpl) << 16), 0u);
+        ps[3] = make_uint4(d[8], d[9], static_cast<uint32_t>(sl.poolOff) | (static_cast<uint32_t>(sl.bpl) << 16), sl.nextJob);
         ps[4] = make_uint4(h[0], h[1], h[2], h[3]);
     }
     // the lane's own record: first band and split record of the frame's q-th unpack lane (zero where there is none)
@@ -1103,15 +1099,16 @@ __global__ __launch_bounds__(256) void dcsPlanKernel(const DcsPlanStream *stream
             }
         }
         if ((static_cast<uint32_t>(p) == fpc - 1 || j + 1 == nJobs) && f + 1 < framesOut && j + 1 < nJobs)
+        {
             sl.flags |= DCS_SLOT_EXPORT;
+            sl.nextJob = j + 1;                     // (the stream's next frame: the first job of the next chunk)
+        }
         if (f + 1 == framesOut)
             sl.flags |= DCS_SLOT_KEEP_TAIL;         // the last frame of its chain (dcs_plan.cpp)
         if (has)
         {
             const uint32_t *rec = reinterpret_cast<const uint32_t *>(&records[st.firstRecord + f]);
             const uint32_t bitOff = rec[0], nBits = rec[1] & 0xFFFFu, nBands = (rec[6] >> 16) & 0xFFu, fl = rec[6] >> 24;
-            sl.hdrDw = static_cast<uint32_t>((st.streamOff + 2) >> 2);
-            sl.hdrSh = static_cast<uint8_t>((st.streamOff + 2) & 3);
             const uint32_t sub = 64 / FPW, nb16 = nBands < 16 ? nBands : 16;
             const uint32_t bpl = (nb16 + sub - 1) / sub;
             sl.bpl = (fl & DCS_IDX_SERIAL) ? 0 : static_cast<uint8_t>(bpl < 1 ? 1 : bpl);
@@ -1194,7 +1191,7 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
     b->abiBytes = payload + static_cast<uint64_t>(nSrcs) * sizeof(DcsSrcDesc) + static_cast<uint64_t>(nJobs) * sizeof(DcsFrameJob) + pcm;
 
     thread_local std::vector<DcsSlot> slots;
-    const bool ranges = tlsXcdRanges || ctx->xcdRanges;
+    const bool ranges = (tlsXcdRanges || ctx->xcdRanges) && !ctx->noXcdRanges;
     b->nChunks = dcsPlanChunksLite(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges);
     b->imgDw = dcsImageDwords(slots.data(), b->nChunks, b->fpw);
     {
@@ -1206,9 +1203,7 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
     }
     if (ranges && handoff)
         b->flags |= DCS_BATCH_XCD_RANGES;
-    if (ctx->dropExports)
-        for (DcsSlot &sl : slots)
-            sl.flags &= static_cast<uint8_t>(~DCS_SLOT_EXPORT);
+    dcsShuffleChunks(slots, b->nChunks, b->fpw, ctx->shuffleSeed);          // (test hook)
     const size_t pkgBytes = static_cast<size_t>(b->nChunks) * dcsPkgStride(b->fpw, b->imgDw);
     void *stage = nullptr;
     size_t stageBytes = 0;
@@ -1339,7 +1334,7 @@ static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *ta
     if (has93aT1)
         b->flags |= DCS_BATCH_HAS_93A_T1;
     static const bool xcdRanges = getenv("DCS_PIPE_XCD_RANGES") == nullptr || atoi(getenv("DCS_PIPE_XCD_RANGES")) != 0;
-    if (xcdRanges)
+    if (xcdRanges && !ctx->noXcdRanges)
         b->flags |= DCS_BATCH_XCD_RANGES;       // (the arithmetic plan IS chain order: chunk c takes its tail from chunk c - 1)
     const uint64_t pcm = static_cast<uint64_t>(nJobs) * DCS_FRAME_SAMPLES * 2;
     b->algoBytes = payloadBytes + static_cast<uint64_t>(nRecords) * 56u + pcm;
@@ -1495,7 +1490,7 @@ static hipError_t launch(const DcsKernelArgs &args, hipStream_t stream)
         blocks = (blocks + 7u) / 8u * 8u;           // eight ranges of equal length; the padding workgroups find no chunk and leave
     dcsk::dcsDecodeKernel<FPW><<<dim3(blocks), dim3(64 * dcsk::kWavesPerBlock), dcsk::ldsBytes(FPW), stream>>>(
         args.packages, args.tables, args.nChunks, args.flags, args.epoch, args.nJobs, args.pcm, args.handoff, args.err, args.tailsOut,
-        args.blob, args.blobLen, args.srcs, args.tailsIn, args.debug, args.timeoutTicks);
+        args.blob, args.blobLen, args.srcs, args.tailsIn, args.debug);
     return hipGetLastError();
 }
 
@@ -1504,8 +1499,8 @@ static DcsStatus launchOnce(DcsBatch *b, hipStream_t stream)
 {
     DcsCtx *ctx = b->ctx;
     b->settled = false;
-    if (++b->epoch == 0)
-        b->epoch = 1;                   // 0 marks words no launch has written
+    if (++b->epoch > DCS_EPOCH_MAX)
+        b->epoch = 1;                   // (0 marks words no launch has written; after 2^31 launches of ONE batch the count starts over)
     const DcsKernelArgs args = kernelArgs(b);
     hipError_t e;
     e = (b->fpw == 16) ? launch<16>(args, stream) : (b->fpw == 8) ? launch<8>(args, stream) : launch<4>(args, stream);
@@ -1865,18 +1860,12 @@ static DcsStatus decodeLive(DcsCtx *ctx, const uint8_t *blob, size_t blobLen, ui
     if (!zcDown)
         HIPCHK(ctx, liveRoom(&l->dDown, &l->dDownCap, downBytes, false));
 
-    static const bool forceNoRanges = getenv("DCS_BATCH_XCD_RANGES") != nullptr && atoi(getenv("DCS_BATCH_XCD_RANGES")) == 0;
-    for (int attempt = 0 ; attempt < 2 ; ++attempt)
     {
-        // (the second attempt, after a lost tail: every predecessor decoded again next to its successor -- see dcs_decode_batch)
-        const bool handoff = ctx->handoff && attempt == 0;
+        const bool handoff = ctx->handoff;
         const double tp0 = g_liveStats ? hipchkNow() : 0.0;
-        const uint32_t nChunks = dcsPlanChunks(jobs, nJobs, srcs, fpw, l->slots, handoff, ctx->framesPerChunk, false, true);
+        const uint32_t nChunks = dcsPlanChunks(jobs, nJobs, srcs, fpw, l->slots, handoff, ctx->framesPerChunk, false, true, ctx->shuffleSeed);
         const double tp1 = g_liveStats ? hipchkNow() : 0.0;
         const uint32_t layout = dcsImageDwords(l->slots.data(), nChunks, fpw) | (split4 ? DCS_PKG_SPLIT4 : 0u);
-        if (ctx->dropExports)
-            for (DcsSlot &sl : l->slots)
-                sl.flags &= static_cast<uint8_t>(~DCS_SLOT_EXPORT);      // test hook: imports without a producer
 
         // what goes up, in one block: external tails | descriptors (only multi-channel frames read them) | chunk packages
         const size_t tailBytes = static_cast<size_t>(nTailsIn) * 16 * sizeof(int16_t);
@@ -1906,7 +1895,7 @@ static DcsStatus decodeLive(DcsCtx *ctx, const uint8_t *blob, size_t blobLen, ui
             HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&l->dHandoff), l->handoffChunks * 16 * sizeof(unsigned long long)));
             HIPCHK(ctx, hipMemsetAsync(l->dHandoff, 0, l->handoffChunks * 16 * sizeof(unsigned long long), ctx->stream));
         }
-        if (++l->epoch == 0)
+        if (++l->epoch > DCS_EPOCH_MAX)
         {
             // the launch counter has come round: words of 2^32 launches ago must not pass for this launch's
             HIPCHK(ctx, hipMemsetAsync(l->dHandoff, 0, l->handoffChunks * 16 * sizeof(unsigned long long), ctx->stream));
@@ -1928,8 +1917,7 @@ static DcsStatus decodeLive(DcsCtx *ctx, const uint8_t *blob, size_t blobLen, ui
         args.debug = nullptr;
         args.handoff = l->dHandoff;
         args.epoch = l->epoch;
-        args.flags = batchFlags | ((handoff && !forceNoRanges) ? DCS_BATCH_XCD_RANGES : 0u) | (layout << DCS_BATCH_IMG_SHIFT);
-        args.timeoutTicks = ctx->handoffTimeoutTicks;
+        args.flags = batchFlags | (layout << DCS_BATCH_IMG_SHIFT);
         const hipError_t e = fpw == 16 ? launch<16>(args, ctx->stream) : fpw == 8 ? launch<8>(args, ctx->stream) : launch<4>(args, ctx->stream);
         if (e != hipSuccess)
         {
@@ -1946,15 +1934,6 @@ static DcsStatus decodeLive(DcsCtx *ctx, const uint8_t *blob, size_t blobLen, ui
             l->stats.planUs += tp1 - tp0; l->stats.packUs += tp2 - tp1; l->stats.queueUs += tp3 - tp2; l->stats.waitUs += hipchkNow() - tp3;
             l->stats.validateUs += tv1 - tv0; l->stats.calls += 1; l->stats.frames += nJobs;
         }
-        bool lost = false;
-        if (handoff)
-        {
-            const uint32_t *ew = reinterpret_cast<const uint32_t *>(l->hDown + pcmBytes);
-            for (uint32_t j = 0 ; j < nJobs && !lost ; ++j)
-                lost = (ew[j] & DCS_FRAME_TAIL_LOST) != 0;
-        }
-        if (!lost)
-            break;
     }
     if (pcmOut) *pcmOut = reinterpret_cast<const int16_t *>(l->hDown);
     if (errOut) *errOut = reinterpret_cast<const uint32_t *>(l->hDown + pcmBytes);
@@ -1999,42 +1978,18 @@ extern "C" DcsStatus dcs_decode_batch(DcsCtx *ctx,
         if (tailsOut) memcpy(tailsOut, tails, static_cast<size_t>(nJobs) * 16 * sizeof(int16_t));
         return DCS_OK;
     }
-    // Tails cross chunk boundaries through the hand-off buffer, which rests on the producing wavefront having been
-    // dispatched when its consumer waits for it: chunks are dispatched in index order on this hardware, but nothing
-    // promises it.  A consumer that waited in vain flags its frame DCS_FRAME_TAIL_LOST; the batch is then decoded again
-    // with every such predecessor re-decoded next to its successor (no dependence between wavefronts at all).
-    // One-shot calls launch in XCD ranges like the pipelines' batches do (include/dcs_hip.h says "always", and two processes or threads
-    // making small one-shot calls on one card are launches side by side like any other; ~1 % of a kernel that is a fraction of the call).
-    struct Ranges { bool old; Ranges() : old(tlsXcdRanges) { tlsXcdRanges = true; } ~Ranges() { tlsXcdRanges = old; } } ranges;
+    // more than the live decoder takes: a batch object with buffers from the context's bounded cache, run once
     // a caller that asks for tailsOut gets the tail EVERY frame leaves (the sequencer resumes from any tick of a batch)
     struct Tails { bool old; explicit Tails(bool all) : old(tlsKeepAllTails) { tlsKeepAllTails = all; } ~Tails() { tlsKeepAllTails = old; } } tails(tailsOut != nullptr);
-    for (int attempt = 0 ; attempt < 2 ; ++attempt)
-    {
-        const bool handoff = ctx->handoff && attempt == 0;
-        DcsBatch *b = nullptr;
-        DcsStatus st = createBatch(ctx, blob, blobLen, srcs, nSrcs, jobs, nJobs, tailsIn, nTailsIn, nullptr, handoff, &b);
-        if (st != DCS_OK)
-            return st;
-        st = dcs_batch_run(b, nullptr);
-        bool lost = false;
-        if (st == DCS_OK && handoff)
-        {
-            // the error words first (4 bytes per frame): they say whether the PCM is worth fetching
-            std::vector<uint32_t> errTmp(errOut ? 0 : nJobs);
-            uint32_t *errWords = errOut ? errOut : errTmp.data();
-            st = dcs_batch_download(b, nullptr, errWords, nullptr);
-            for (uint32_t j = 0 ; st == DCS_OK && j < nJobs && !lost ; ++j)
-                lost = (errWords[j] & DCS_FRAME_TAIL_LOST) != 0;
-            if (st == DCS_OK && !lost)
-                st = dcs_batch_download(b, pcmOut, nullptr, tailsOut);
-        }
-        else if (st == DCS_OK)
-            st = dcs_batch_download(b, pcmOut, errOut, tailsOut);
-        dcs_batch_destroy(b);
-        if (st != DCS_OK || !lost)
-            return st;
-    }
-    return DCS_OK;
+    DcsBatch *b = nullptr;
+    DcsStatus st = createBatch(ctx, blob, blobLen, srcs, nSrcs, jobs, nJobs, tailsIn, nTailsIn, nullptr, ctx->handoff, &b);
+    if (st != DCS_OK)
+        return st;
+    st = dcs_batch_run(b, nullptr);
+    if (st == DCS_OK)
+        st = dcs_batch_download(b, pcmOut, errOut, tailsOut);
+    dcs_batch_destroy(b);
+    return st;
 }
 
 

@@ -67,12 +67,9 @@ typedef enum DcsFormat
 #define DCS_FRAME_STOP   1u            /* the reference's channel.stop: corrupt band, zeroed (:1989, :2216) */
 #define DCS_FRAME_FATAL  2u            /* malformed beyond what the reference defines (it has UB there):
                                           decode of the frame stops at that point; STOP is raised too    */
-#define DCS_FRAME_TAIL_LOST 4u         /* (with FATAL) not a property of the stream: the overlap tail of the frame's
-                                          predecessor, decoded by another wavefront of the same launch, did not arrive
-                                          within the wait bound, so the frame's first 16 samples lack the overlap.
-                                          dcs_decode_batch and everything built on it decode such a batch again with
-                                          the predecessor re-decoded next to its successor and never return this bit;
-                                          a caller of dcs_batch_run sees it in the error words */
+#define DCS_FRAME_TAIL_LOST 4u         /* never set since ABI 9.  (Rounds 2-5: the overlap tail of the frame's predecessor, decoded
+                                          by another wavefront of the launch, had not arrived within a wait bound.  Tails between
+                                          wavefronts are a rendezvous now: nobody waits and nothing can be lost.) */
 
 /* ------------------------------------------------------------------------------------------------
  * Index pass: the carried state that makes a frame independently decodable.
@@ -224,8 +221,9 @@ DcsStatus dcs_ctx_set_frames_per_wave(DcsCtx *ctx, int fpw);
  * slots idle): 1 = one wavefront per frame.  0 (default) = every slot is used.  Same PCM at every setting. */
 DcsStatus dcs_ctx_set_frames_per_chunk(DcsCtx *ctx, int frames);
 /* tuning: how a frame gets the 16-sample tail of a predecessor that lies in another wavefront's chunk.  1 (default):
- * the wavefront that decodes the predecessor publishes the tail in a device buffer and the successor picks it up
- * after its own transform; 0: the predecessor is decoded a second time next to the successor (a "halo" slot).
+ * the two wavefronts meet in a device buffer -- each exchanges one word per tail sample there, and whichever of them arrives second
+ * finishes the successor's first sixteen samples; nobody waits (round 6); 0: the predecessor is decoded a second time next to the
+ * successor (a "halo" slot).
  * Same PCM either way.  Applies to batches created afterwards. */
 DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable);
 /* tuning: how dcs_decode_streams takes a LARGE list (32 768 frames and more, 32 streams and more), which it cuts into
@@ -238,12 +236,11 @@ DcsStatus dcs_ctx_set_tail_handoff(DcsCtx *ctx, int enable);
  * pass on the pool with the parts following it (4.0-4.4 ms, ~45 CPU-ms on 16 threads).  Same PCM in every mode. */
 DcsStatus dcs_ctx_set_large_list_path(DcsCtx *ctx, int mode);
 /* For a caller that runs SEVERAL resident batches on one GPU at once (batches on different streams, or several processes on one
- * card).  A decode kernel's wavefronts wait for tails other wavefronts of the same launch publish; one launch that has the chip to
- * itself cannot wait in vain, two side by side can wait for each other's places across the chip's eight XCDs until the bound
- * (DCS_FRAME_TAIL_LOST).  enable = 1: batches created afterwards keep their chunks in chain order and are launched in XCD ranges --
- * workgroup i runs on XCD i % 8, XCD j decodes a contiguous range of chunks in order, a tail's producer is dispatched before its
- * consumer on the consumer's own XCD -- so no wait depends on another launch.  About 1 % slower for a batch alone on the chip, which is
- * why it is not the default for resident batches (dcs_batch_create); dcs_pipeline, dcs_node, dcs_decode_batch and dcs_decode_streams always work this way.  Same PCM either way. */
+ * card).  enable = 1: batches created afterwards keep their chunks in chain order and are launched in XCD ranges -- workgroup i runs on
+ * XCD i % 8, XCD j decodes a contiguous range of chunks in order.  Rounds 4 and 5 NEEDED this when launches ran side by side (a
+ * wavefront waited for the tail another wavefront published, and two launches could fill each other's places); since round 6 no
+ * wavefront waits for another and the setting is a placement choice only (neighbouring chunks of a stream share an XCD's L2).
+ * dcs_pipeline and dcs_node work this way.  Same PCM either way. */
 DcsStatus dcs_ctx_set_concurrent_batches(DcsCtx *ctx, int enable);
 /* Which frames' 16-sample tails a RESIDENT batch (dcs_batch_create) stores for dcs_batch_download's tailsOut.  0 (default): the last
  * frame of every chain of the batch -- a frame no other frame of the batch names as its predecessor -- which is what a caller needs
@@ -306,14 +303,9 @@ DcsStatus dcs_batch_create(DcsCtx *ctx,
                            DcsBatch **batch);
 void      dcs_batch_destroy(DcsBatch *batch);
 /* Enqueue the decode on `hipStream` (a hipStream_t passed as void*; NULL = the context's stream).
- * Asynchronous: returns after the launch.
- * A frame whose predecessor's overlap tail comes from another wavefront of the launch waits for it at most 500 ms; if it
- * does not come (no measured case; the bound covers hardware that dispatched workgroups out of order) the frame's error
- * word carries DCS_FRAME_FATAL | DCS_FRAME_TAIL_LOST and its first 16 samples lack the overlap -- nothing else is
- * affected.  A caller of the resident-batch entries who sees that flag creates the batch again after
- * dcs_ctx_set_tail_handoff(ctx, 0) (predecessors re-decoded next to their successors: no wavefront waits for another)
- * and runs it once more; dcs_decode_batch, dcs_decode_streams, the sequencer, the class and the pipeline do exactly that
- * by themselves and never return the flag. */
+ * Asynchronous: returns after the launch.  No wavefront of the launch waits for another (a frame whose predecessor is decoded by
+ * another wavefront meets it in the hand-off buffer, and the later of the two finishes the frame's first samples), so a launch
+ * depends on nothing but itself, whatever else runs on the chip. */
 DcsStatus dcs_batch_run(DcsBatch *batch, void *hipStream);
 /* The same `count` times back to back (one call from the host language for many launches). */
 DcsStatus dcs_batch_run_many(DcsBatch *batch, void *hipStream, int count);
@@ -354,9 +346,10 @@ DcsStatus dcs_ctx_link_rate(DcsCtx *ctx, float *gbpsOut);
  * stream and waited for (launchWaitUs), and the same with a copy of nFrames x 516 bytes (PCM, error word, tail) into pinned memory
  * behind it (launchCopyWaitUs); medians of `iters` rounds, microseconds of host time.  Not part of the decode path. */
 DcsStatus dcs_ctx_call_floor(DcsCtx *ctx, uint32_t nFrames, int iters, float *launchWaitUs, float *launchCopyWaitUs);
-/* test hooks: bound of a consumer's wait for a tail from another chunk in microseconds (0 = the default, 500 ms), and
- * dropExports != 0: no chunk publishes its tail, so every such wait runs into the bound (DCS_FRAME_TAIL_LOST) */
-DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t handoffTimeoutUs, int dropExports);
+/* test hooks: chunkOrderSeed != 0 -- batches planned on the host get their chunks (the units wavefronts decode) in a seeded random
+ * order, so that frames are decoded long before or long after the frames whose tails they take; noXcdRanges != 0 -- no batch of the
+ * context is launched in XCD ranges.  Same PCM either way: tails between chunks are a rendezvous, nobody waits (csrc/dcs_kernels.hip.h) */
+DcsStatus dcs_ctx_set_test_hooks(DcsCtx *ctx, uint32_t chunkOrderSeed, int noXcdRanges);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole-stream convenience (the reference's --extract-streams shape, DCSExplorer.cpp:1628-1907):

@@ -226,7 +226,7 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw, workload):
     fullest = 0
     src_bytes = srcs.view(np.uint8).reshape(srcs.size, -1)
     seen = 0
-    n_shared, n_93a = [0], [0]
+    n_shared, n_93a, n_export = [0], [0], [0]
     flat_plan = {}
     for c in range(pk.shape[0]):
         pool = pk[c, off_pool:].view("<u4")
@@ -247,7 +247,14 @@ def test_chunk_packages_hold_exactly_what_round_0_needs(fpw, workload):
             assert np.array_equal(blk[16:56], src_bytes[int(job["firstSrc"]), :40])
             pool_off = int(blk[56:58].view("<u2")[0])
             bpl = int(blk[58])
-            assert not blk[59:64].any()
+            assert blk[59] == 0
+            # bytes 60..63: the job this frame's tail is due at, where the frame hands its tail to another chunk (DCS_SLOT_EXPORT)
+            next_job = int(blk[60:64].view("<u4")[0])
+            if flags & 0x04:
+                assert int(jobs[next_job]["prev"]) == int(slot[0]), "the exporter's nextJob names the frame that follows it"
+                n_export[0] += 1
+            else:
+                assert next_job == 0
             # header: the bytes behind the U16 frame count
             so, hl = int(sd["streamOff"]), int(sd["hdrLen"])
             want_hdr = np.zeros(16, np.uint8); want_hdr[:hl] = np.frombuffer(blob[so + 2: so + 2 + hl], np.uint8)
