@@ -798,15 +798,16 @@ static DcsStatus createBatch(DcsCtx *ctx,
     size_t pkgBytes = 0;
     static const bool forceRanges = getenv("DCS_BATCH_XCD_RANGES") != nullptr && atoi(getenv("DCS_BATCH_XCD_RANGES")) != 0;     // (experiment switch)
     const bool ranges = (tlsXcdRanges || ctx->xcdRanges || forceRanges) && !ctx->noXcdRanges;
+    static const bool chainOrder = getenv("DCS_EXP_CHAIN_ORDER") != nullptr && atoi(getenv("DCS_EXP_CHAIN_ORDER")) != 0;      // (experiment switch)
     // (experiment switch, for A/B runs on one binary: round 4's packages -- the full pool image, every frame's tail stored)
     static const bool fullImage = getenv("DCS_EXP_FULL_IMAGE") != nullptr && atoi(getenv("DCS_EXP_FULL_IMAGE")) != 0;
     const bool allTails = ctx->keepAllTails || tlsKeepAllTails || fullImage;
     if (tlsResidentBatch && !fullImage)
-        b->nChunks = dcsPlanChunksCapped(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges, allTails, &b->imgDw,
+        b->nChunks = dcsPlanChunksCapped(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges && !chainOrder, allTails, &b->imgDw,
                                           static_cast<uint32_t>(ctx->numCUs) * 16u);
     else
     {
-        b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges, allTails);
+        b->nChunks = dcsPlanChunks(jobs, nJobs, srcs, b->fpw, slots, handoff, ctx->framesPerChunk, !ranges && !chainOrder, allTails);
         b->imgDw = fullImage ? dcsPoolCapacity(b->fpw) : dcsImageDwords(slots.data(), b->nChunks, b->fpw);
     }
     dcsShuffleChunks(slots, b->nChunks, b->fpw, ctx->shuffleSeed);          // (test hook)
