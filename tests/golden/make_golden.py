@@ -69,6 +69,14 @@ def main():
             arrays[name + "/pcm"] = pcm
             meta.append(dict(name=name, os=os_, volume=vol, levels=[lvl], streams=1, frames_out=nf + 2))
 
+    # BASELINE.json config 1 as SURVEY.md 8(d) words it: ONE OS93a Type-0 stream, 64 frames, seed 0x93010001, volume 255, level 0x64,
+    # all of its PCM from the compiled reference (the "bit-exact vs DCSDecoderEmu" half of that config needs ROM images: SURVEY 8c)
+    s = make_stream(D.FMT_93_T0, 64, seed=0x93010001, profile=6, nbands=12)
+    pcm = ref.decode(D.OS93A, 255, [s], [0x64], 64 + 2)
+    arrays["CONFIG-1/stream"] = np.frombuffer(s, dtype=np.uint8)
+    arrays["CONFIG-1/pcm"] = pcm
+    meta.append(dict(name="CONFIG-1", os=D.OS93A, volume=255, levels=[0x64], streams=1, frames_out=66))
+
     # multi-channel mixes (frequency-domain mixing of several streams before one transform)
     for fam, fmts, nch in ((2, [3, 4, 5, 5], 4), (1, [0, 1, 0], 3), (0, [0, 2], 2), (3, [5] * 8, 8)):
         streams = [make_stream(fmts[c], 12 + 4 * c, seed=0x3C0000 + fam * 64 + c, profile=c % 3) for c in range(nch)]

@@ -257,3 +257,51 @@ SCRIPTS = {
                   + port_cmd(95, 16) + port_cmd(100, 15) + [(105, 2, 0x60)] + port_cmd(110, 17) + port_cmd(120, 0)
                   + port_cmd(125, 9999) + [(126, 0, 0x81), (126, 0, 0x00)] + port_cmd(130, 1) + [(135, 2, 0xE0)]),
 }
+
+
+def zip_recognition_archive(seed):
+    """a seeded archive of made-up members for the zip member recognition tests: names with several digits, version numbers,
+    upper and lower case; images that start with well-formed, malformed or missing signatures, a JUMP or not.
+    -> (members [(name, bytes)], zip base name, zip bytes), or None when the draw gave two members one name"""
+    g = splitmix(0x21F0 + seed)
+    likely = seed >= 400            # seeds 400..: sets that mostly DO load -- a JUMP image named for chip 2 first, signatures that
+    n_members = 2 + next(g) % 9     # mostly carry a digit of their member's name -- so that the U3..U9 rules are what decides
+    members = []
+    for k in range(n_members):
+        stem = ["snd", "s", "u", "rom", "cc", "afm_s", "ng_u", "v1_", "l"][next(g) % 9]
+        d1, d2 = next(g) % 10, next(g) % 10
+        if likely and k == 0:
+            d1 = 2
+        name = "%s%d%s%d.%s" % (stem, d1, ["", "_", "v", "S", "-u"][next(g) % 5], d2, ["rom", "bin", "l1", "1_0"][next(g) % 4])
+        if next(g) % 4 == 0:
+            name = name.upper()
+        # (a power of two, as AddROM demands; distinct sizes tell the members apart; 0x2000 is what an absent chip reads as)
+        size = [0x100, 0x200, 0x400, 0x800, 0x1000, 0x4000, 0x8000, 0x10000, 0x20000, 0x40000, 0x80000][len(members)]
+        img = bytearray(b"\xFF" * size)
+        kind = next(g) % 8
+        d = next(g) % 10
+        if likely:
+            kind = 0 if k == 0 else (1 if next(g) % 4 else kind)
+            if next(g) % 3:
+                d = (d1, d2)[next(g) % 2]
+        if kind == 0:
+            img[0:4] = bytes([0x18 + next(g) % 4, next(g) % 256, 0x0F | (next(g) % 16) << 4, 0])     # a JUMP
+        elif kind in (1, 2, 3):
+            text = "%s%s%d %s %02d/%02d/%02d" % ("SU"[next(g) % 2], ["", "ND ", "-"][next(g) % 3], d, ["Sound", "v1.0 L-%d" % (next(g) % 10), ""][next(g) % 3],
+                                                  next(g) % 13, next(g) % 32, next(g) % 100)
+            img[0:len(text) + 1] = text.encode() + b"\0"
+        elif kind == 4:
+            text = "S%d no date here" % d
+            img[0:len(text) + 1] = text.encode() + b"\0"
+        elif kind == 5:
+            text = "X%d Sound 01/02/94" % d
+            img[0:len(text) + 1] = text.encode() + b"\0"
+        members.append((name, bytes(img)))
+    if len({len(m[1]) for m in members}) != len(members) or len({m[0].lower() for m in members}) != len(members):
+        return None
+    zip_base = ["cc_13.zip", "CC_1x.zip", "afm_113b.zip", "sttng_l7.zip", "ccx.zip"][next(g) % 5]
+    buf = io.BytesIO()
+    with zipfile.ZipFile(buf, "w", zipfile.ZIP_DEFLATED) as z:
+        for name, data in members:
+            z.writestr(name, data)
+    return members, zip_base, buf.getvalue()

@@ -136,7 +136,7 @@ def test_golden_vectors(gpu_ctx):
                                              extra_frames=case["frames_out"] - nf)
         assert_same(pcm, arrays[case["name"] + "/pcm"], case["name"])
         n += 1
-    assert n >= 31
+    assert n >= 32 and any(c["name"] == "CONFIG-1" for c in meta["cases"])      # (BASELINE configs[0] as SURVEY 8(d) words it is among them)
 
 
 def test_streams_made_by_the_reference_encoder(gpu_ctx, oracle):

@@ -29,10 +29,29 @@ def case_streams(case, arrays):
 
 def test_oracle_reproduces_every_golden_case(oracle, golden):
     meta, arrays = golden
-    assert len(meta["cases"]) >= 35
+    assert len(meta["cases"]) >= 36
     for case in meta["cases"]:
         pcm = oracle.decode(case["os"], case["volume"], case_streams(case, arrays), case["levels"], case["frames_out"])
         assert np.array_equal(pcm, arrays[case["name"] + "/pcm"]), case["name"]
+
+
+def test_config_1_as_the_survey_words_it(oracle, golden):
+    """BASELINE.json configs[0] / SURVEY.md 8(d) Config 1: ONE OS93a Type-0 stream, 64 frames, seed 0x93010001, volume 255, level
+    0x64 -- the plumbing case, no GPU: the CPU restatement against the PCM the compiled reference produced for it (committed by
+    tests/golden/make_golden.py; the stream itself is regenerated from the seed here and must be the committed one)"""
+    import dcsexplorer_amd as D
+    from util import make_stream
+    meta, arrays = golden
+    case = [c for c in meta["cases"] if c["name"] == "CONFIG-1"][0]
+    assert (case["os"], case["volume"], case["levels"], case["frames_out"]) == (D.OS93A, 255, [0x64], 66)
+    s = make_stream(D.FMT_93_T0, 64, seed=0x93010001, profile=6, nbands=12)
+    assert s == arrays["CONFIG-1/stream"].tobytes() and ((s[0] << 8) | s[1]) == 64
+    idx, info = D.index_stream(D.OS93A, s)
+    assert info.format == D.FMT_93_T0 and info.nValidFrames == 64
+    pcm = oracle.decode(D.OS93A, 255, [s], [0x64], 66)
+    want = arrays["CONFIG-1/pcm"]
+    assert np.array_equal(pcm, want)
+    assert want[:64].any(axis=1).all() and want[64].any() and not want[65].any()     # 64 frames of sound, the taper frame, silence
 
 
 def test_survey_appendix_d_sample_values(golden):

@@ -128,67 +128,68 @@ def zip_rules_twin(members, zip_base, explicit_u2=None):
     return chip_of
 
 
+def _chips_by_size(rs, members):
+    """which member the library took for which chip, read back through the size of the image behind each chip -> {chip: size}"""
+    L = rs.L
+    sizes = {len(m[1]) for m in members}
+    got = {}
+    for chip in range(2, 10):
+        p, avail, c = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_int()
+        # (linear address with the DCS-95 bank layout: chip select from bit 21)
+        L.dcs_romset_set_version(rs.h, D.api.HW_DCS95 if hasattr(D.api, "HW_DCS95") else 3, D.OS95)
+        L.dcs_romset_pointer(rs.h, (chip - 2) << 21, ctypes.byref(p), ctypes.byref(avail), ctypes.byref(c))
+        if avail.value in sizes:
+            got[chip] = avail.value
+    return got
+
+
 def test_zip_member_recognition_against_a_second_reading_of_the_rules():
-    """400 seeded archives of made-up members -- names with several digits, version numbers, upper and lower case; images that
-    start with well-formed, malformed or missing signatures, a JUMP or not -- : which member the library takes for which chip
-    (read back through the size of the image behind each chip) equals what the twin above says, Cactus Canyon's zip name
-    included.  (No table of the 29 titles' real member names is committed: the reference tree names the sets,
-    Tests/test-all.bat:27-57, but not their members, and a list from memory would be no fixture.)"""
-    import io
-    import zipfile
-    from util import splitmix
-    for seed in range(400):
-        g = splitmix(0x21F0 + seed)
-        n_members = 2 + next(g) % 9
-        members = []
-        for k in range(n_members):
-            stem = ["snd", "s", "u", "rom", "cc", "afm_s", "ng_u", "v1_", "l"][next(g) % 9]
-            name = "%s%d%s%d.%s" % (stem, next(g) % 10, ["", "_", "v", "S", "-u"][next(g) % 5], next(g) % 10, ["rom", "bin", "l1", "1_0"][next(g) % 4])
-            if next(g) % 4 == 0:
-                name = name.upper()
-            # (a power of two, as AddROM demands; distinct sizes tell the members apart; 0x2000 is what an absent chip reads as)
-            size = [0x100, 0x200, 0x400, 0x800, 0x1000, 0x4000, 0x8000, 0x10000, 0x20000, 0x40000, 0x80000][len(members)]
-            img = bytearray(b"\xFF" * size)
-            kind = next(g) % 8
-            d = next(g) % 10
-            if kind == 0:
-                img[0:4] = bytes([0x18 + next(g) % 4, next(g) % 256, 0x0F | (next(g) % 16) << 4, 0])     # a JUMP
-            elif kind in (1, 2, 3):
-                text = "%s%s%d %s %02d/%02d/%02d" % ("SU"[next(g) % 2], ["", "ND ", "-"][next(g) % 3], d, ["Sound", "v1.0 L-%d" % (next(g) % 10), ""][next(g) % 3],
-                                                      next(g) % 13, next(g) % 32, next(g) % 100)
-                img[0:len(text) + 1] = text.encode() + b"\0"
-            elif kind == 4:
-                text = "S%d no date here" % d
-                img[0:len(text) + 1] = text.encode() + b"\0"
-            elif kind == 5:
-                text = "X%d Sound 01/02/94" % d
-                img[0:len(text) + 1] = text.encode() + b"\0"
-            members.append((name, bytes(img)))
-        if len({len(m[1]) for m in members}) != len(members) or len({m[0].lower() for m in members}) != len(members):
+    """800 seeded archives of made-up members (romkit.zip_recognition_archive) -- names with several digits, version numbers, upper
+    and lower case; images that start with well-formed, malformed or missing signatures, a JUMP or not -- : which member the library
+    takes for which chip equals what the twin above says, Cactus Canyon's zip name included.  (No table of the 29 titles' real
+    member names is committed: the reference tree names the sets, Tests/test-all.bat:27-57, but not their members, and a list
+    from memory would be no fixture.)"""
+    for seed in range(800):
+        arch = romkit.zip_recognition_archive(seed)
+        if arch is None:
             continue
-        zip_base = ["cc_13.zip", "CC_1x.zip", "afm_113b.zip", "sttng_l7.zip", "ccx.zip"][next(g) % 5]
-        buf = io.BytesIO()
-        with zipfile.ZipFile(buf, "w", zipfile.ZIP_DEFLATED) as z:
-            for name, data in members:
-                z.writestr(name, data)
+        members, zip_base, zip_bytes = arch
         want = zip_rules_twin(members, zip_base)
         if want is None:
             with pytest.raises(D.DcsError):
-                D.RomSet(zip_bytes=buf.getvalue(), zip_name=zip_base)
+                D.RomSet(zip_bytes=zip_bytes, zip_name=zip_base)
             continue
-        rs = D.RomSet(zip_bytes=buf.getvalue(), zip_name=zip_base)
-        L = rs.L
-        for chip in range(2, 10):
-            p, avail, c = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_int()
-            # (linear address with the DCS-95 bank layout: chip select from bit 21)
-            L.dcs_romset_set_version(rs.h, D.api.HW_DCS95 if hasattr(D.api, "HW_DCS95") else 3, D.OS95)
-            L.dcs_romset_pointer(rs.h, (chip - 2) << 21, ctypes.byref(p), ctypes.byref(avail), ctypes.byref(c))
-            got = avail.value
-            exp = len(members[want[chip]][1]) if chip in want else None
-            if exp is None:
-                assert got not in {len(m[1]) for m in members}, "seed %d: chip %d taken from a member the rules reject" % (seed, chip)
-            else:
-                assert got == exp, "seed %d: chip %d is %d bytes, the rules say member %r (%d bytes)" % (seed, chip, got, members[want[chip]][0], exp)
+        got = _chips_by_size(D.RomSet(zip_bytes=zip_bytes, zip_name=zip_base), members)
+        assert got == {chip: len(members[i][1]) for chip, i in want.items()}, "seed %d" % seed
+
+
+def test_zip_member_recognition_against_the_reference_text():
+    """tests/golden/zip_golden.json (tests/golden/make_zip_golden.py, build container): the expected chip of every member of the same
+    800 archives, computed from the recognition literals READ OUT OF the reference's source as data -- the three regular
+    expressions, the digit and JUMP tests of DCSDecoderZipLoader.cpp:60-207 (the file cannot be compiled here: <Windows.h>) --
+    not from a copy of them in this repository.  This pins the TEXT of the rules; their execution by the reference stays unpinned
+    (DESIGN.md section 4).  The literals the library and the twin above carry are held against the recorded ones as well."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "zip_golden.json")))
+    lit = gold["literals"]
+    src = open(os.path.join(ROOT, "dcsexplorer_amd", "csrc", "dcs_rom.cpp")).read()
+    for key in ("signature_regex", "cactus_canyon_regex"):
+        assert ('"%s"' % lit[key + "_c_literal"]) in src, "dcs_rom.cpp does not carry the reference's %s" % key
+    assert lit["jump_test"].replace(" ", "") in "return (p[0] & 0xFC) == 0x18 && (p[2] & 0x0F) == 0x0F;".replace(" ", "")
+    n = 0
+    for rec in gold["archives"]:
+        arch = romkit.zip_recognition_archive(rec["seed"])
+        assert arch is not None
+        members, zip_base, zip_bytes = arch
+        assert [m[0] for m in members] == rec["members"] and zip_base == rec["zip_base"]
+        if rec["chips"] is None:
+            with pytest.raises(D.DcsError):
+                D.RomSet(zip_bytes=zip_bytes, zip_name=zip_base)
+        else:
+            got = _chips_by_size(D.RomSet(zip_bytes=zip_bytes, zip_name=zip_base), members)
+            assert got == {int(chip): len(members[i][1]) for chip, i in rec["chips"].items()}, "seed %d" % rec["seed"]
+        n += 1
+    assert n == len(gold["archives"]) >= 700
 
 
 @pytest.mark.gpu
