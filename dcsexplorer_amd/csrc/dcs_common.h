@@ -359,6 +359,7 @@ struct DcsDigested
 DcsStatus dcsIndexStreamsNotify(const DcsStreamRef *streams, uint32_t nStreams, int nThreads,
                                 DcsFrameIndex *out, const uint64_t *firstRecord, DcsStreamInfo *infos,
                                 const std::function<void(uint32_t)> *done);
+bool dcsIndexPoolBusy();
 // large lists through the context's own pipeline, in parts (dcs_pipeline.hip.h); *handled = false: take the direct path
 DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames,
                                   int16_t *pcmOut, size_t pcmCapFrames, uint32_t *frameOffsets, uint32_t *errOut, bool *handled);

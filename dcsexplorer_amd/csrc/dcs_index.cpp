@@ -221,6 +221,7 @@ public:
     // run fn(k) for k in [0, n) on up to `threads` threads (the caller is one of them)
     void run(uint32_t n, int threads, const std::function<void(uint32_t)> &fn)
     {
+        struct Count { std::atomic<int> &c; explicit Count(std::atomic<int> &c) : c(c) { ++c; } ~Count() { --c; } } count(regions);
         std::lock_guard<std::mutex> serial(runMutex);           // one parallel region at a time
         const int helpers = threads - 1;
         grow(helpers);
@@ -240,7 +241,11 @@ public:
         job = nullptr;
     }
 
+    // parallel regions running or waiting for their turn right now (a caller that would only queue up behind them can do without)
+    int busy() const { return regions.load(); }
+
 private:
+    std::atomic<int> regions{ 0 };
     void drain(const std::function<void(uint32_t)> &fn, uint32_t n)
     {
         for (uint32_t k = next.fetch_add(1) ; k < n ; k = next.fetch_add(1))
@@ -291,6 +296,10 @@ private:
 };
 
 }   // namespace
+
+// whether the process-wide index pool is serving (or queueing) a parallel region: several contexts decoding large lists at once
+// (dcs_node, dcs_decode_streams_sharded: a thread per device) would otherwise walk their lists one after the other on it
+bool dcsIndexPoolBusy() { return IndexPool::get().busy() > 0; }
 
 // Host threads this process may actually run at once: the CPUs of its affinity mask, further limited by a cgroup
 // CPU quota when there is one (a container given 16 CPUs of a 256-thread host reports 256 hardware threads).

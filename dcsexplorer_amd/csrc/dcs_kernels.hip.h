@@ -1485,12 +1485,15 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
         phead0 = reinterpret_cast<const uint4 *>(pkg)[min(lane, kHeadVec - 1)];
         if (kHeadLoads > 1)
             phead1 = reinterpret_cast<const uint4 *>(pkg)[min(lane + 64, kHeadVec - 1)];
+        if (split4)
         {
-            // (one 8-byte load either way: lane l's record lies at l x 8, or -- 4-byte records -- at l x 4, and then only its
-            // first dword is the lane's)
-            const uint2 raw = *reinterpret_cast<const uint2 *>(pkg + dcsPkgOffSplit(FPW) + static_cast<uint32_t>(lane) * (split4 ? 4u : 8u));
-            psplit = split4 ? make_uint2(raw.x & 0xFFFFu, raw.x & 0xFFFF0000u) : raw;
+            // (4-byte records, lane l's at l x 4: one dword -- ADVICE r5: an 8-byte load there was 4-byte aligned on odd lanes and
+            // read past the split area on the last one; a uniform branch, the layout word comes with the kernel's arguments)
+            const uint32_t raw = *reinterpret_cast<const uint32_t *>(pkg + dcsPkgOffSplit(FPW) + static_cast<uint32_t>(lane) * 4u);
+            psplit = make_uint2(raw & 0xFFFFu, raw & 0xFFFF0000u);
         }
+        else
+            psplit = *reinterpret_cast<const uint2 *>(pkg + dcsPkgOffSplit(FPW) + static_cast<uint32_t>(lane) * 8u);
 #pragma unroll
         for (int t = 0 ; t < kPoolPieces ; ++t)
         {

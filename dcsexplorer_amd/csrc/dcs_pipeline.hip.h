@@ -992,6 +992,15 @@ DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint
         // so they go up and take its place (pipelineWorker).  How many parts the host takes follows what was measured: the side
         // that finished later in the last call gets less in the next.
         hostParts = ctx->largeListShared ? static_cast<uint32_t>(std::max(0, std::min(static_cast<int>(kParts) - 1, ctx->sharedHostParts))) : 0u;
+        //  The pool runs ONE parallel region at a time: with several contexts decoding large lists at once (dcs_node,
+        // dcs_decode_streams_sharded: a thread per device) the shared walks would queue up one behind the other, the last device
+        // waiting (N - 1) host walks before its first part is even submitted.  A context that finds the pool taken walks its whole
+        // list on its own device (mode 1's 3.3 ms, whatever the others do).  A share that has fallen to nothing is tried again
+        // with one part every sixteenth call.
+        if (hostParts != 0 && dcsIndexPoolBusy())
+            hostParts = 0;
+        if (ctx->largeListShared && ctx->sharedHostParts == 0 && (++ctx->sharedProbe & 15) == 0 && !dcsIndexPoolBusy())
+            hostParts = 1;
         const uint32_t hostStreams = cut[hostParts];
         const uint64_t hostRecs = first[hostStreams] - static_cast<uint64_t>(hostStreams) * extraFrames;
         DcsFrameIndex *hRecs = nullptr;
@@ -1082,7 +1091,7 @@ DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint
         }
         if (st == DCS_OK && tHost > 0 && tDev > 0)
         {
-            if (tHost > tDev + 0.15 && ctx->sharedHostParts > 1)
+            if (tHost > tDev + 0.15 && ctx->sharedHostParts > 0)
                 ctx->sharedHostParts -= 1;
             else if (tDev > tHost + 0.15 && ctx->sharedHostParts < static_cast<int>(kParts) - 1)
                 ctx->sharedHostParts += 1;

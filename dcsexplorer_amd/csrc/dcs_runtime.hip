@@ -35,6 +35,7 @@ struct DcsCtx
     bool keepAllTails = false;          // resident batches store EVERY frame's tail (dcs_ctx_set_batch_tails); default: the last frame of every chain
     bool largeListOnDevice = true;      // dcs_decode_streams on a large list: index walk, planner and packer on the device (dcs_ctx_set_large_list_path)
     bool largeListShared = true;        // ... with the host pool walking the first parts of the list next to the device (mode 2, the default)
+    uint32_t sharedProbe = 0;           // calls made with a host share of nothing (every sixteenth tries one part again)
     int sharedHostParts = 7;            // how many of the eight parts the host walks (where 16 pool threads settle); follows the measured finish times from call to call
     std::mutex cacheMutex;              // the buffer cache is shared by the pipeline's worker threads
     struct DcsPipeline *internalPipe = nullptr;     // dcs_decode_streams takes large lists through it in parts (dcs_pipeline.hip.h)
@@ -1236,7 +1237,7 @@ static DcsStatus createBatchOnDevice(DcsCtx *ctx, const DcsFrameJob *jobs, uint3
         HIPCHK(ctx, hipGetLastError());
         b->cap[4] = sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPcm), b->cap[4]));
         b->cap[5] = sizeof(uint32_t) * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dErr), b->cap[5]));
-        b->cap[6] = sizeof(int16_t) * 16 * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsOut), b->cap[6]));
+        // (no tails kept: nothing reads them on this path, and a buffer from the recycling cache would carry another list's -- ADVICE r5)
         HIPCHK(ctx, hipMemsetAsync(b->dErr, 0, sizeof(uint32_t) * nJobs, b->stream));
         b->cap[8] = sizeof(unsigned long long) * 16 * (b->nChunks + 1); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dHandoff), b->cap[8]));
         HIPCHK(ctx, hipMemsetAsync(b->dHandoff, 0, b->cap[8], b->stream));
@@ -1373,7 +1374,7 @@ static DcsStatus createBatchPlannedOnDevice(DcsCtx *ctx, const DcsPlanStream *ta
         b->cap[4] = sizeof(int16_t) * DCS_FRAME_SAMPLES * nJobs + sizeof(uint32_t) * nJobs; b->cap[5] = 0;
         HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dPcm), b->cap[4]));
         b->dErr = reinterpret_cast<uint32_t *>(b->dPcm + static_cast<size_t>(DCS_FRAME_SAMPLES) * nJobs);
-        b->cap[6] = sizeof(int16_t) * 16 * nJobs; HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dTailsOut), b->cap[6]));
+        // (no tails kept: nothing reads them on this path, and a buffer from the recycling cache would carry another list's -- ADVICE r5)
         b->cap[8] = sizeof(unsigned long long) * 16 * (b->nChunks + 1); HIPCHK(ctx, cacheAlloc(ctx, false, reinterpret_cast<void **>(&b->dHandoff), b->cap[8]));
         {
             const DcsStatus sq = queuePlanAndPack(b, nStreams, extraFrames, dRecords, dInfos, dBlob, blobLen, nullptr);
@@ -1635,7 +1636,7 @@ extern "C" DcsStatus dcs_batch_download(DcsBatch *b, int16_t *pcmOut, uint32_t *
         HIPCHK(ctx, hipMemcpy(pcmOut, b->dPcm, sizeof(int16_t) * DCS_FRAME_SAMPLES * b->nJobs, hipMemcpyDeviceToHost));
     if (errOut)
         HIPCHK(ctx, hipMemcpy(errOut, b->dErr, sizeof(uint32_t) * b->nJobs, hipMemcpyDeviceToHost));
-    if (tailsOut)
+    if (tailsOut && b->dTailsOut)
         HIPCHK(ctx, hipMemcpy(tailsOut, b->dTailsOut, sizeof(int16_t) * 16 * b->nJobs, hipMemcpyDeviceToHost));
     return DCS_OK;
 }

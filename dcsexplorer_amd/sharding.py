@@ -208,11 +208,13 @@ def open_comm(rank, world, want, device=None, init_timeout_s=120.0, log=None):
         if all(v == "ok" for v in votes):
             return Comm(backend, rank, world, device=device, store=ctl, timeout_s=init_timeout_s, attempts=attempts)
         log("process group over %s not formed on every rank: %s" % (backend, votes))
-        if mine == "ok":
-            try:
+        # (whenever a group came to exist on this rank -- also when its probe all-reduce then failed: a group left behind would
+        # make the next backend's init_process_group fail here and keep the other ranks waiting for this one's vote)
+        try:
+            if mine == "ok" or dist.is_initialized():
                 dist.destroy_process_group()
-            except Exception:
-                pass
+        except Exception:
+            pass
         if any(v == "hung" for v in votes):
             break                       # a thread is stuck inside init_process_group somewhere: no second attempt
     log("barrier and max over the rendezvous store")
