@@ -1143,6 +1143,32 @@ def run_rank(args):
                 out["end_to_end"]["sustained_vs_cpu_baseline"] = out["end_to_end"]["sustained"]["value"] / out["cpu_baseline"]["value"]
             except (KeyError, TypeError):
                 pass
+        # ---- what the device does with STREAMS (not with a batch prepared beforehand) next to `value`, at the top of the line ----
+        # `value` times the last of four kernels over descriptors the index pass produced earlier ("descriptors +
+        # compressed bytes resident in HBM").  The whole path from stream bytes in HBM to PCM in HBM -- index walk, planner,
+        # packer, decode -- is value_full_path (saturated: 8 192 streams in one launch) / value_full_path_one_list (the config's
+        # own 256 streams); roofline_full_path prices it by the same SURVEY 8(d) bytes.
+        try:
+            dfp = out.get("device_full_path") or {}
+            sat, one = dfp.get("saturated"), dfp.get("one_list")
+            if sat:
+                out["value_full_path"] = sat["value"]
+                out["roofline_full_path"] = {"bound": "hbm", "achieved": sat["hbm"]["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": sat["hbm"]["frac_of_peak"], "traffic": None, "ms_per_pass": sat["ms_per_pass"],
+                                             "kernels": sat["kernel_ms"], "bound_in_fact": "issue of dcsIndexWaveKernel (scalar + vector), %d %% of the pass"
+                                                                                            % round(100 * sat["index_share_of_pass"]),
+                                             "bit_exact": sat["bit_exact"]}
+            if one:
+                out["value_full_path_one_list"] = one["value"]
+            cs = out.get("class_surface") or {}
+            if isinstance(cs.get("recipe"), dict) and cs["recipe"]:
+                rates = [v["hip-mirror"]["samples_per_s"] for v in cs["recipe"].values() if "samples_per_s" in v.get("hip-mirror", {})]
+                if rates:
+                    out["value_class_surface"] = {"min_over_layouts": min(rates), "max_over_layouts": max(rates), "unit": "samples/s",
+                                                  "what": "DCSDecoderHIP::GetNextSample() in a bare loop, default settings, one 2 000-frame stream per layout "
+                                                          "(class_surface.recipe); beside it cpu_baseline.pump, the reference's pump on this box"}
+        except (KeyError, TypeError):
+            pass
         hard_exit = hard_exit or sec.abandoned is not None
         emit(out, hard_exit=hard_exit and world == 1)
 

@@ -360,6 +360,10 @@ DcsStatus dcsIndexStreamsNotify(const DcsStreamRef *streams, uint32_t nStreams, 
                                 DcsFrameIndex *out, const uint64_t *firstRecord, DcsStreamInfo *infos,
                                 const std::function<void(uint32_t)> *done);
 bool dcsIndexPoolBusy();
+// the host walk with its records handed over frame by frame, and the container part of it alone (dcs_index.cpp)
+DcsStatus dcsIndexStreamProgressive(DcsOsVersion os, const uint8_t *stream, size_t len, DcsStreamInfo *info,
+                                    const std::function<void(uint32_t, const DcsFrameIndex &)> &onFrame);
+DcsStatus dcsStreamContainer(DcsOsVersion os, const uint8_t *stream, size_t len, DcsStreamInfo *info);
 // large lists through the context's own pipeline, in parts (dcs_pipeline.hip.h); *handled = false: take the direct path
 DcsStatus dcsDecodeStreamsInParts(DcsCtx *ctx, const DcsStreamRef *streams, uint32_t nStreams, uint32_t extraFrames,
                                   int16_t *pcmOut, size_t pcmCapFrames, uint32_t *frameOffsets, uint32_t *errOut, bool *handled);

@@ -182,6 +182,58 @@ extern "C" DcsStatus dcs_index_stream(DcsOsVersion os, const uint8_t *stream, si
     return sink.overflow ? DCS_ERR_CAPACITY : DCS_OK;
 }
 
+// The same walk for a caller that uses the records as they come (the sequencer's background walker, dcs_sequencer.cpp): onFrame(f,
+// record) is called for every frame, in order, on the calling thread.  Same records, same summary as dcs_index_stream.
+namespace {
+struct CallbackSink
+{
+    const std::function<void(uint32_t, const DcsFrameIndex &)> &fn;
+    void operator()(uint32_t f, const DcsFrameIndex &fi) { fn(f, fi); }
+};
+}   // namespace
+DcsStatus dcsIndexStreamProgressive(DcsOsVersion os, const uint8_t *stream, size_t len, DcsStreamInfo *info,
+                                    const std::function<void(uint32_t, const DcsFrameIndex &)> &onFrame)
+{
+    if (stream == nullptr || len < 3 || os < DCS_OS93A || os > DCS_OS95)
+        return DCS_ERR_INVALID_ARG;
+    WinBits reader{ stream, len };
+    const DcsScanTables tabs{ &dcsTables().lds, dcsTables().trie94, multi94Table(), dcsTables().fast94 };
+    CallbackSink sink{ onFrame };
+    DcsScanMem mem;
+    const DcsStreamInfo si = dcsScanStream(static_cast<int>(os), reader, tabs, &mem, sink);
+    if (info != nullptr)
+        *info = si;
+    return si.nFrames == 0 ? DCS_ERR_BAD_STREAM : DCS_OK;
+}
+
+// What a stream says about itself before any frame is walked: frame count, header, layout (the container part of the walk,
+// InitChannelStream / InitStreamPlayback, DCSDecoderNative.cpp:1433-1463, :1595-1641).  nBytes, nValidFrames and payloadBits are 0.
+DcsStatus dcsStreamContainer(DcsOsVersion os, const uint8_t *stream, size_t len, DcsStreamInfo *info)
+{
+    if (stream == nullptr || len < 3 || os < DCS_OS93A || os > DCS_OS95 || info == nullptr)
+        return DCS_ERR_INVALID_ARG;
+    auto byteAt = [&](size_t i) -> uint32_t { return i < len ? stream[i] : 0u; };
+    DcsStreamInfo si = {};
+    si.nFrames = static_cast<int32_t>((byteAt(0) << 8) | byteAt(1));
+    const bool typeBit = (byteAt(2) & 0x80) != 0;
+    si.hdrLen = (os == DCS_OS93A && typeBit) ? 1 : 16;
+    for (int i = 0 ; i < 16 ; ++i)
+        si.header[i] = i < si.hdrLen ? static_cast<uint8_t>(byteAt(2 + static_cast<size_t>(i))) : static_cast<uint8_t>(0);
+    si.formatType = typeBit ? 1 : 0;
+    if (os == DCS_OS94 || os == DCS_OS95)
+        si.formatSubType = ((si.header[1] & 0x80) >> 6) | ((si.header[1] & 0x80) >> 7);
+    if (os == DCS_OS93A)
+        si.format = typeBit ? DCS_FMT_93A_T1 : DCS_FMT_93_T0;
+    else if (os == DCS_OS93B)
+        si.format = typeBit ? DCS_FMT_93B_T1 : DCS_FMT_93_T0;
+    else if (!typeBit)
+        si.format = DCS_FMT_94_T0;
+    else
+        si.format = (((si.header[1] | si.header[2]) & 0x80) == 0) ? DCS_FMT_94_T1_S0 : DCS_FMT_94_T1_S3;
+    *info = si;
+    return si.nFrames == 0 ? DCS_ERR_BAD_STREAM : DCS_OK;
+}
+
 // Diagnostic: the same walk with the reader that keeps the reference's byte pointer LITERALLY (DcsBits, dcs_scan.h:
 // Peek pulls whole bytes while nBits <= n) and without the multi-code table.  The tests hold dcs_index_stream against it:
 // same records, same nBytes.

@@ -16,7 +16,15 @@
 #include "dcs_rom.h"
 #include <string.h>
 #include <atomic>
+#include <condition_variable>
 #include <deque>
+#include <mutex>
+#include <thread>
+#include <chrono>
+#include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <map>
 #include <memory>
 #include <vector>
@@ -25,11 +33,21 @@ namespace {
 
 struct ResetException { };
 
+// A stream as the sequencer plays it: the index pass's record of every frame and where its bytes lie in the blob.  A long stream is
+// walked by the sequencer's BACKGROUND WALKER while its first frames are already being planned, decoded and handed out (round 6):
+// then `index` has its full size from the start, its first `ready` entries are valid (published by the walker, release / acquire),
+// and nBytes / nValidFrames / payloadBits of `info` are only final once `done` is set.
 struct StreamEntry
 {
-    std::vector<DcsFrameIndex> index;
+    std::vector<DcsFrameIndex> index;       // (an unusable stream -- no frames, no header -- has none)
     DcsStreamInfo info;
     uint64_t blobOff = 0;
+    std::atomic<uint32_t> ready{ 0 };
+    std::atomic<bool> done{ true };
+    std::atomic<size_t> stableBytes{ 0 };   // bytes of the stream in the blob that no longer change (while it is being walked)
+    // frames that can be planned now
+    uint32_t frames() const { return done.load(std::memory_order_acquire) ? static_cast<uint32_t>(info.nValidFrames) : ready.load(std::memory_order_acquire); }
+    bool usable() const { return !index.empty(); }
 };
 
 struct Mixer
@@ -190,6 +208,23 @@ struct DcsSequencer : VmState
             x.mixer[c].reset();
     }
 
+    // ---- the background walker: a thread per long stream; one stream at a time, always the last one in the blob (its bytes are
+    // copied in as the walk reaches them); anything else that wants to append to the blob, a caller's command after which the
+    // stream's memory may go away (ClearTracks, another LoadAudioStream) and the destructor wait for it to finish.  (A NEW thread
+    // per walk, not one kept waiting for work: a thread woken through a futex is put on the waker's core, where it then waits for
+    // the very thread that waits for its records -- measured: the whole walk went by before the first record was seen; a new
+    // thread starts on an idle core.)
+    static const uint32_t kWalkInlineFrames = 512;      // shorter streams are walked where they are loaded (a thread costs ~50 us)
+    struct Walk { StreamEntry *e = nullptr; const uint8_t *src = nullptr; size_t avail = 0; size_t reserved = 0; };
+    std::thread walker;
+    StreamEntry *walking = nullptr;         // (sequencer thread only) the entry whose walk has not been taken in yet
+    size_t walkReserved = 0;
+    void runWalk(const Walk &w);
+    void finishWalk();                      // wait for the walker, shrink the blob to what the stream really takes
+    size_t blobStableLen() const { return walking != nullptr ? static_cast<size_t>(walking->blobOff) + walking->stableBytes.load(std::memory_order_acquire) : blob.size(); }
+    uint32_t plannableTicks() const;        // ticks the channels' streams have records for right now (UINT32_MAX: no limit)
+    ~DcsSequencer();
+
     const StreamEntry *streamAt(DcsRomCursor p);
     const StreamEntry *addStream(const uint8_t *data, size_t avail, std::pair<const void *, size_t> key, bool cache);
     void compact();
@@ -215,24 +250,58 @@ const StreamEntry *DcsSequencer::streamAt(DcsRomCursor p)
 
 const StreamEntry *DcsSequencer::addStream(const uint8_t *data, size_t avail, std::pair<const void *, size_t> key, bool cache)
 {
+    finishWalk();                           // (the blob grows at its end: only one stream at a time can be filling in there)
     std::unique_ptr<StreamEntry> e(new StreamEntry);
     const uint32_t nFrames = avail >= 2 ? (static_cast<uint32_t>(data[0]) << 8) | data[1] : 0;
-    if (nFrames != 0 && avail >= 3)
+    static const bool noWalker = getenv("DCS_SEQ_NO_WALKER") != nullptr && atoi(getenv("DCS_SEQ_NO_WALKER")) != 0;
+    const bool background = nFrames > kWalkInlineFrames && avail >= 3 && !noWalker;
+    if (nFrames != 0 && avail >= 3 && !background)
     {
         e->index.resize(nFrames);
         if (dcs_index_stream(static_cast<DcsOsVersion>(os), data, avail, e->index.data(), nFrames, &e->info) != DCS_OK)
             e->index.clear();
         else
             e->index.resize(static_cast<size_t>(e->info.nValidFrames));
+        if (!e->index.empty())
+        {
+            while (blob.size() & 3)
+                blob.push_back(0);
+            e->blobOff = blob.size();
+            const size_t used = static_cast<size_t>(e->info.nBytes) < avail ? static_cast<size_t>(e->info.nBytes) : avail;
+            blob.insert(blob.end(), data, data + used);
+            blob.insert(blob.end(), static_cast<size_t>(e->info.nBytes) - used + 16, 0);
+        }
     }
-    if (!e->index.empty())
+    else if (background && dcsStreamContainer(static_cast<DcsOsVersion>(os), data, avail, &e->info) == DCS_OK)
     {
+        // room for the largest the stream can be (a frame is at most DCS_MAX_FRAME_BITS long), zero-filled; the walker copies the
+        // stream's bytes in as it reaches them and finishWalk() gives back what was not needed
+        e->index.resize(nFrames);
         while (blob.size() & 3)
             blob.push_back(0);
         e->blobOff = blob.size();
-        const size_t used = static_cast<size_t>(e->info.nBytes) < avail ? static_cast<size_t>(e->info.nBytes) : avail;
-        blob.insert(blob.end(), data, data + used);
-        blob.insert(blob.end(), static_cast<size_t>(e->info.nBytes) - used + 16, 0);
+        size_t bound = 2 + static_cast<size_t>(e->info.hdrLen) + static_cast<size_t>(nFrames) * (DCS_MAX_FRAME_BITS / 8) + 64;
+        if (bound > avail + 64)
+            bound = avail + 64;
+        blob.resize(blob.size() + bound);
+        e->done.store(false, std::memory_order_relaxed);
+        walking = e.get();
+        walkReserved = bound;
+        const Walk w{ e.get(), data, avail, bound };
+        walker = std::thread([this, w] { runWalk(w); });
+        // The walker belongs on another core than the thread that waits for its records.  Left to itself a new thread may start on
+        // its creator's core and stay queued there behind the creator's polling (seen in the build container: the whole walk went by
+        // first): it is told to run anywhere BUT here (a process confined to one CPU keeps it, and the walk is then simply not
+        // concurrent).
+        {
+            cpu_set_t allowed;
+            const int here = sched_getcpu();
+            if (here >= 0 && sched_getaffinity(0, sizeof(allowed), &allowed) == 0 && CPU_COUNT(&allowed) >= 2 && CPU_ISSET(here, &allowed))
+            {
+                CPU_CLR(here, &allowed);
+                (void)pthread_setaffinity_np(walker.native_handle(), sizeof(allowed), &allowed);
+            }
+        }
     }
     StreamEntry *r = e.get();
     if (cache)
@@ -240,6 +309,81 @@ const StreamEntry *DcsSequencer::addStream(const uint8_t *data, size_t avail, st
     else
         uncached.push_back(std::move(e));
     return r;
+}
+
+// the walk of one stream, on the walker's thread: every frame's record goes to its place in the entry, the stream's bytes into the
+// blob up to where the walk has read, and a frame is PUBLISHED once everything a decode of it will read lies there for good (its
+// own bytes and the sixteen the bit pool's look-ahead may take in behind them)
+void DcsSequencer::runWalk(const Walk &w)
+{
+    StreamEntry *e = w.e;
+    uint8_t *dst = blob.data() + e->blobOff;        // (stable: nothing else appends while a walk is on)
+    size_t copied = 0;
+    uint32_t published = 0;
+    const size_t hdr = 2 + static_cast<size_t>(e->info.hdrLen);
+    auto frameEnd = [&](uint32_t f) { return hdr + (static_cast<size_t>(e->index[f].bitOff) + e->index[f].nBits + 7) / 8; };
+    auto copyTo = [&](size_t upTo) {
+        upTo = std::min(std::min(upTo, w.avail), w.reserved);
+        if (upTo > copied)
+        {
+            memcpy(dst + copied, w.src + copied, upTo - copied);
+            copied = upTo;
+        }
+    };
+    DcsStreamInfo info;
+    const std::function<void(uint32_t, const DcsFrameIndex &)> onFrame = [&](uint32_t f, const DcsFrameIndex &fi) {
+        e->index[f] = fi;
+        copyTo(frameEnd(f) + 4);                    // (as far as the walk's own reader has looked: bytes the caller's buffer is sure to have)
+        while (published < f && frameEnd(published) + 16 <= copied)
+            ++published;
+        e->stableBytes.store(copied >= 16 ? copied - 16 : 0, std::memory_order_relaxed);
+        e->ready.store(published, std::memory_order_release);
+    };
+    const auto tw0 = std::chrono::steady_clock::now();
+    dcsIndexStreamProgressive(static_cast<DcsOsVersion>(os), w.src, w.avail, &info, onFrame);
+    if (getenv("DCS_SEQ_WALK_TRACE"))
+        fprintf(stderr, "walk of %d frames: %.1f us, published %u before the end\n", info.nFrames,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw0).count(), published);
+    copyTo(static_cast<size_t>(info.nBytes));
+    // (the summary's container fields are what dcsStreamContainer gave and the planner reads them meanwhile; the rest is final now)
+    e->info.nBytes = info.nBytes;
+    e->info.nValidFrames = info.nValidFrames;
+    e->info.payloadBits = info.payloadBits;
+    e->stableBytes.store(std::min(static_cast<size_t>(info.nBytes) + 16, w.reserved), std::memory_order_relaxed);
+    e->done.store(true, std::memory_order_release);
+}
+
+void DcsSequencer::finishWalk()
+{
+    if (walking == nullptr)
+        return;
+    StreamEntry *e = walking;
+    walker.join();
+    walking = nullptr;
+    // the blob ends with this stream: keep what it takes (as a stream walked at once would have got)
+    const size_t keep = std::min(static_cast<size_t>(e->info.nBytes) + 16, walkReserved);
+    blob.resize(static_cast<size_t>(e->blobOff) + keep);
+    if (e->info.nValidFrames <= 0)
+        e->index.clear();
+}
+
+DcsSequencer::~DcsSequencer()
+{
+    if (walker.joinable())
+        walker.join();                      // (a walk in progress runs to its end first: at most a few milliseconds)
+}
+
+// ticks that can be planned without running ahead of the walker: the fewest records a channel's stream has beyond its position
+uint32_t DcsSequencer::plannableTicks() const
+{
+    if (walking == nullptr || walking->done.load(std::memory_order_acquire))
+        return 0xFFFFFFFFu;
+    uint32_t n = 0xFFFFFFFFu;
+    const uint32_t have = walking->ready.load(std::memory_order_acquire);
+    for (const Chan &c : ch)
+        if (c.st == walking)
+            n = std::min(n, have > c.pos ? have - c.pos : 0u);
+    return n;
 }
 
 uint64_t DcsSequencer::newBlobId()
@@ -254,6 +398,7 @@ void DcsSequencer::compact()
 {
     if (blob.size() < (32u << 20))
         return;
+    finishWalk();
     std::vector<uint8_t> fresh;
     auto keep = [&](StreamEntry *e) {
         const size_t n = static_cast<size_t>(e->info.nBytes) + 16;
@@ -289,7 +434,7 @@ void DcsSequencer::loadAudioStream(uint32_t streamChannel, int source, uint32_t 
 void DcsSequencer::loadStreamEntry(uint32_t streamChannel, int source, uint32_t loopCounter, const StreamEntry *e)
 {
     Chan &c = chan(streamChannel);
-    if (e->index.empty())
+    if (!e->usable())
     {
         c.st = nullptr;                     // zero frames (or unusable): nothing to play
         return;
@@ -633,7 +778,7 @@ void DcsSequencer::mainLoop()
         Chan &x = ch[c];
         if (x.st == nullptr)
             continue;
-        if (x.pos < x.st->index.size())
+        if (x.pos < x.st->frames())
         {
             DcsSrcDesc sd;
             memset(&sd, 0, sizeof(sd));
@@ -775,6 +920,7 @@ extern "C" DcsStatus dcs_seq_add_track_command(DcsSequencer *s, uint16_t track)
 extern "C" DcsStatus dcs_seq_clear_tracks(DcsSequencer *s)       // :1466-1473
 {
     if (s == nullptr) return DCS_ERR_INVALID_ARG;
+    s->finishWalk();                        // (behind this call the caller may take a loaded stream's memory away)
     for (Chan &c : s->ch)
     {
         c.track.clear();
@@ -837,6 +983,22 @@ void DcsSequencer::advance(uint32_t nTicks, uint32_t stopWhenIdleFor, uint32_t *
     {
         if (stopWhenIdleFor != 0 && done != 0 && s->idleRun >= stopWhenIdleFor)
             break;
+        // a stream still being walked is planned only as far as its records go: what there is now is decoded and handed out while
+        // the walker goes on (a call that has nothing yet waits for the next record; ticks run again by a rewind had theirs)
+        if (!s->replaying && s->plannableTicks() == 0)
+        {
+            if (done != 0)
+                break;
+            // (a record comes every half microsecond: look again at once; the core is given up only when the walker seems not to
+            // be running at all -- it may be waiting for this very core)
+            for (unsigned spins = 0 ; s->plannableTicks() == 0 ; ++spins)
+            {
+                if (spins < 20000)
+                    __builtin_ia32_pause();
+                else
+                    std::this_thread::yield();
+            }
+        }
         if (s->fatal)
         {
             // DecoderFatalError: silence from here on (DCSDecoder.cpp:1672-1675)
@@ -1033,7 +1195,7 @@ extern "C" DcsStatus dcs_seq_decode_view(DcsCtx *ctx, DcsSequencer *s, const int
     if (s->blob.empty())
         s->blob.assign(16, 0);
     const int16_t *tails = nullptr;
-    const DcsStatus st = dcs_decode_batch_live(ctx, s->blob.data(), s->blob.size(), s->blobId, s->srcs.empty() ? nullptr : s->srcs.data(),
+    const DcsStatus st = dcs_decode_batch_live(ctx, s->blob.data(), s->blobStableLen(), s->blobId, s->srcs.empty() ? nullptr : s->srcs.data(),
                                                static_cast<uint32_t>(s->srcs.size()), s->jobs.data(), static_cast<uint32_t>(n),
                                                s->tail, 1, pcmOut, errOut, &tails);
     if (st != DCS_OK)
@@ -1066,6 +1228,7 @@ extern "C" DcsStatus dcs_seq_decode(DcsCtx *ctx, DcsSequencer *s, int16_t *pcmOu
         if (s->blob.empty())
             s->blob.assign(16, 0);
         std::vector<int16_t> tails(n * 16);
+        s->finishWalk();
         const DcsStatus st = dcs_decode_batch(ctx, s->blob.data(), s->blob.size(), s->srcs.empty() ? nullptr : s->srcs.data(),
                                               static_cast<uint32_t>(s->srcs.size()), s->jobs.data(), static_cast<uint32_t>(n),
                                               s->tail, 1, pcmOut, errOut, tails.data());

