@@ -18,6 +18,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <chrono>
@@ -97,6 +98,88 @@ struct VmState
     uint32_t idleRun = 0;                   // ticks in a row that began and ended with nothing playing, nothing queued, no program, no timer
 };
 
+}   // namespace
+
+// Threads for the sequencers' background walks, kept for the life of the process (a decoder object per file is how the reference's
+// callers work, DCSEncoder.cpp:522-540, and making a thread costs 100-200 us where the HIP runtime is loaded): a sequencer borrows
+// one for the length of a walk.  A thread is told, with every job, to run anywhere BUT on the core of the thread that hands the job
+// over: a thread woken through a futex is put on its waker's core, and there it would wait for the very thread that polls for its
+// records (measured in the build container: the whole walk went by before the first record was seen).  Never destroyed, like the
+// index pool's workers: nothing joins at process exit.
+namespace {
+class WalkerPool
+{
+public:
+    struct Worker
+    {
+        pthread_t handle{};
+        std::mutex m;
+        std::condition_variable cv;
+        std::function<void()> job;
+        bool has = false;
+        void main()
+        {
+            for (;;)
+            {
+                std::function<void()> fn;
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return has; });
+                    fn.swap(job);
+                    has = false;
+                }
+                fn();
+            }
+        }
+        void post(std::function<void()> fn)
+        {
+            {
+                std::lock_guard<std::mutex> lk(m);
+                // (anywhere but here; a process confined to one CPU keeps it, and the walk is then simply not concurrent)
+                cpu_set_t allowed;
+                const int here = sched_getcpu();
+                if (here >= 0 && sched_getaffinity(0, sizeof(allowed), &allowed) == 0 && CPU_COUNT(&allowed) >= 2 && CPU_ISSET(here, &allowed))
+                {
+                    CPU_CLR(here, &allowed);
+                    (void)pthread_setaffinity_np(handle, sizeof(allowed), &allowed);
+                }
+                job = std::move(fn);
+                has = true;
+            }
+            cv.notify_one();
+        }
+    };
+    static WalkerPool &get()
+    {
+        static WalkerPool *pool = new WalkerPool;
+        return *pool;
+    }
+    Worker *take()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (!idle.empty())
+            {
+                Worker *w = idle.back();
+                idle.pop_back();
+                return w;
+            }
+        }
+        Worker *w = new Worker;
+        std::thread th([w] { w->main(); });
+        w->handle = th.native_handle();
+        th.detach();                        // (the handle stays good: the thread never ends)
+        return w;
+    }
+    void give(Worker *w)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        idle.push_back(w);
+    }
+private:
+    std::mutex m;
+    std::vector<Worker *> idle;
+};
 }   // namespace
 
 struct DcsSequencer : VmState
@@ -208,15 +291,12 @@ struct DcsSequencer : VmState
             x.mixer[c].reset();
     }
 
-    // ---- the background walker: a thread per long stream; one stream at a time, always the last one in the blob (its bytes are
-    // copied in as the walk reaches them); anything else that wants to append to the blob, a caller's command after which the
-    // stream's memory may go away (ClearTracks, another LoadAudioStream) and the destructor wait for it to finish.  (A NEW thread
-    // per walk, not one kept waiting for work: a thread woken through a futex is put on the waker's core, where it then waits for
-    // the very thread that waits for its records -- measured: the whole walk went by before the first record was seen; a new
-    // thread starts on an idle core.)
-    static const uint32_t kWalkInlineFrames = 512;      // shorter streams are walked where they are loaded (a thread costs ~50 us)
+    // ---- the background walker (a thread borrowed from WalkerPool for the length of a walk): one stream at a time, always the last
+    // one in the blob (its bytes are copied in as the walk reaches them); anything else that wants to append to the blob, a caller's
+    // command after which the stream's memory may go away (ClearTracks, another LoadAudioStream) and the destructor wait for it
+    static const uint32_t kWalkInlineFrames = 384;      // shorter streams are walked where they are loaded (a hand-over costs ~30 us)
     struct Walk { StreamEntry *e = nullptr; const uint8_t *src = nullptr; size_t avail = 0; size_t reserved = 0; };
-    std::thread walker;
+    WalkerPool::Worker *walkWorker = nullptr;
     StreamEntry *walking = nullptr;         // (sequencer thread only) the entry whose walk has not been taken in yet
     size_t walkReserved = 0;
     void runWalk(const Walk &w);
@@ -288,20 +368,8 @@ const StreamEntry *DcsSequencer::addStream(const uint8_t *data, size_t avail, st
         walking = e.get();
         walkReserved = bound;
         const Walk w{ e.get(), data, avail, bound };
-        walker = std::thread([this, w] { runWalk(w); });
-        // The walker belongs on another core than the thread that waits for its records.  Left to itself a new thread may start on
-        // its creator's core and stay queued there behind the creator's polling (seen in the build container: the whole walk went by
-        // first): it is told to run anywhere BUT here (a process confined to one CPU keeps it, and the walk is then simply not
-        // concurrent).
-        {
-            cpu_set_t allowed;
-            const int here = sched_getcpu();
-            if (here >= 0 && sched_getaffinity(0, sizeof(allowed), &allowed) == 0 && CPU_COUNT(&allowed) >= 2 && CPU_ISSET(here, &allowed))
-            {
-                CPU_CLR(here, &allowed);
-                (void)pthread_setaffinity_np(walker.native_handle(), sizeof(allowed), &allowed);
-            }
-        }
+        walkWorker = WalkerPool::get().take();
+        walkWorker->post([this, w] { runWalk(w); });
     }
     StreamEntry *r = e.get();
     if (cache)
@@ -358,8 +426,17 @@ void DcsSequencer::finishWalk()
     if (walking == nullptr)
         return;
     StreamEntry *e = walking;
-    walker.join();
+    // (its last records come within microseconds of each other: look again at once)
+    for (unsigned spins = 0 ; !e->done.load(std::memory_order_acquire) ; ++spins)
+    {
+        if (spins < 20000)
+            __builtin_ia32_pause();
+        else
+            std::this_thread::yield();
+    }
     walking = nullptr;
+    WalkerPool::get().give(walkWorker);
+    walkWorker = nullptr;
     // the blob ends with this stream: keep what it takes (as a stream walked at once would have got)
     const size_t keep = std::min(static_cast<size_t>(e->info.nBytes) + 16, walkReserved);
     blob.resize(static_cast<size_t>(e->blobOff) + keep);
@@ -369,8 +446,7 @@ void DcsSequencer::finishWalk()
 
 DcsSequencer::~DcsSequencer()
 {
-    if (walker.joinable())
-        walker.join();                      // (a walk in progress runs to its end first: at most a few milliseconds)
+    finishWalk();                           // (a walk in progress runs to its end first: at most a few milliseconds)
 }
 
 // ticks that can be planned without running ahead of the walker: the fewest records a channel's stream has beyond its position
