@@ -34,6 +34,19 @@ namespace {
 
 struct ResetException { };
 
+// the blob's bytes: a vector whose resize() leaves new bytes as they are (room for a stream that is still being walked is taken
+// without touching it: a megabyte of fresh pages cost 150-180 us to zero on the thread that loads the stream)
+template <class T>
+struct LeaveAsIs : std::allocator<T>
+{
+    template <class U> struct rebind { using other = LeaveAsIs<U>; };
+    LeaveAsIs() = default;
+    template <class U> LeaveAsIs(const LeaveAsIs<U> &) { }
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&... a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+using Bytes = std::vector<uint8_t, LeaveAsIs<uint8_t>>;
+
 // A stream as the sequencer plays it: the index pass's record of every frame and where its bytes lie in the blob.  A long stream is
 // walked by the sequencer's BACKGROUND WALKER while its first frames are already being planned, decoded and handed out (round 6):
 // then `index` has its full size from the start, its first `ready` entries are valid (published by the walker, release / acquire),
@@ -140,8 +153,32 @@ public:
                 const int here = sched_getcpu();
                 if (here >= 0 && sched_getaffinity(0, sizeof(allowed), &allowed) == 0 && CPU_COUNT(&allowed) >= 2 && CPU_ISSET(here, &allowed))
                 {
+                    // (not on this core's other hardware thread either, if there is room elsewhere: the caller polls and pumps)
+                    cpu_set_t elsewhere = allowed;
+                    char path[96], text[128] = { 0 };
+                    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", here);
+                    if (FILE *f = fopen(path, "r"))
+                    {
+                        if (fgets(text, sizeof(text), f) != nullptr)
+                            for (const char *q = text ; *q != 0 ; )
+                            {
+                                char *end = nullptr;
+                                long a = strtol(q, &end, 10), b = a;
+                                if (end == q)
+                                    break;
+                                if (*end == '-')
+                                    b = strtol(end + 1, &end, 10);
+                                for (long c = a ; c <= b && c < CPU_SETSIZE ; ++c)
+                                    CPU_CLR(static_cast<int>(c), &elsewhere);
+                                q = *end == ',' ? end + 1 : end;
+                                if (*end != ',')
+                                    break;
+                            }
+                        fclose(f);
+                    }
                     CPU_CLR(here, &allowed);
-                    (void)pthread_setaffinity_np(handle, sizeof(allowed), &allowed);
+                    CPU_CLR(here, &elsewhere);
+                    (void)pthread_setaffinity_np(handle, sizeof(allowed), CPU_COUNT(&elsewhere) >= 1 ? &elsewhere : &allowed);
                 }
                 job = std::move(fn);
                 has = true;
@@ -193,7 +230,7 @@ struct DcsSequencer : VmState
     // the batch planned so far, and what is needed to go back inside it
     std::map<std::pair<const void *, size_t>, std::unique_ptr<StreamEntry>> streams;
     std::vector<std::unique_ptr<StreamEntry>> uncached;                   // streams loaded from caller memory
-    std::vector<uint8_t> blob;
+    Bytes blob;
     std::vector<DcsSrcDesc> srcs;
     std::vector<DcsFrameJob> jobs;
     std::vector<DcsHostByte> hostBytes;
@@ -354,8 +391,9 @@ const StreamEntry *DcsSequencer::addStream(const uint8_t *data, size_t avail, st
     }
     else if (background && dcsStreamContainer(static_cast<DcsOsVersion>(os), data, avail, &e->info) == DCS_OK)
     {
-        // room for the largest the stream can be (a frame is at most DCS_MAX_FRAME_BITS long), zero-filled; the walker copies the
-        // stream's bytes in as it reaches them and finishWalk() gives back what was not needed
+        // room for the largest the stream can be (a frame is at most DCS_MAX_FRAME_BITS long), left as it is: the walker copies the
+        // stream's bytes in as it reaches them (what lies behind them is never decoded, only looked ahead at) and finishWalk() gives
+        // back what was not needed
         e->index.resize(nFrames);
         while (blob.size() & 3)
             blob.push_back(0);
@@ -413,6 +451,8 @@ void DcsSequencer::runWalk(const Walk &w)
         fprintf(stderr, "walk of %d frames: %.1f us, published %u before the end\n", info.nFrames,
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw0).count(), published);
     copyTo(static_cast<size_t>(info.nBytes));
+    if (copied + 16 <= w.reserved)
+        memset(dst + copied, 0, 16);                // (what a stream walked at once has behind it)
     // (the summary's container fields are what dcsStreamContainer gave and the planner reads them meanwhile; the rest is final now)
     e->info.nBytes = info.nBytes;
     e->info.nValidFrames = info.nValidFrames;
@@ -475,7 +515,7 @@ void DcsSequencer::compact()
     if (blob.size() < (32u << 20))
         return;
     finishWalk();
-    std::vector<uint8_t> fresh;
+    Bytes fresh;
     auto keep = [&](StreamEntry *e) {
         const size_t n = static_cast<size_t>(e->info.nBytes) + 16;
         while (fresh.size() & 3)
