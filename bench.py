@@ -352,7 +352,17 @@ def end_to_end_ranks(ctx, streams, n_frames, comm, depth=48, lists=96, budget_s=
         r1 = resource.getrusage(resource.RUSAGE_SELF)           # (before the pipeline's tear-down: joins, stream and buffer releases are no list's cost)
         pipe.close()
         cpu_ms = ((r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)) * 1e3 / n_lists
-        box["row"] = [dt, n_lists, sum(host_ms) / len(host_ms), sum(dev_ms) / len(dev_ms), cpu_ms]
+        # (what this rank's link gives, measured now: 480 bytes of PCM per frame cross it; and where the rank's threads run)
+        try:
+            link = ctx.link_rate()
+        except Exception:
+            link = float("nan")
+        numa = -1
+        try:
+            numa = D.device_numa_node(ctx.device)
+        except Exception:
+            pass
+        box["row"] = [dt, n_lists, sum(host_ms) / len(host_ms), sum(dev_ms) / len(dev_ms), cpu_ms, link, float(numa), float(len(os.sched_getaffinity(0)))]
 
     def bounded(fn, what):
         """run fn in a thread, wait at most what is left of budget_s -> None or the reason it has no result"""
@@ -376,7 +386,7 @@ def end_to_end_ranks(ctx, streams, n_frames, comm, depth=48, lists=96, budget_s=
     bounded(timed, "timed lists")
     comm.barrier()
     nan = float("nan")
-    rows = comm.gather_rows(box.get("row", [nan] * 5) if "error" not in box else [nan] * 5)
+    rows = comm.gather_rows(box.get("row", [nan] * 8) if "error" not in box else [nan] * 8)
     good = [r for r in range(world) if not math.isnan(rows[r][0])]
     failed = [r for r in range(world) if r not in good]
     usable = D.host_threads()
@@ -396,7 +406,10 @@ def end_to_end_ranks(ctx, streams, n_frames, comm, depth=48, lists=96, budget_s=
                           "what": "every rank its own dcs_pipeline (index pass, planner and packer on the device), lists in flight, PCM returned in "
                                   "pinned memory; all ranks' samples over the slowest rank's time"},
             "per_rank": [{"rank": r, "ms_per_list": rows[r][0] / rows[r][1] * 1e3, "worker_host_ms": rows[r][2],
-                          "worker_device_ms": rows[r][3], "cpu_ms_per_list": rows[r][4]} for r in good],
+                          "worker_device_ms": rows[r][3], "cpu_ms_per_list": rows[r][4],
+                          "link_GBps": None if math.isnan(rows[r][5]) else rows[r][5],
+                          "link_floor_ms_per_list": None if math.isnan(rows[r][5]) or rows[r][5] <= 0 else n_frames * 480 / (rows[r][5] * 1e9) * 1e3,
+                          "gpu_numa_node": int(rows[r][6]), "cpus_in_affinity_mask": int(rows[r][7])} for r in good],
             "usable_cpus": usable,
             "host_ceiling": {"cpu_ms_per_list": cpu_mean, "lists_per_s_the_cpus_allow": usable * 1e3 / max(cpu_mean, 1e-9),
                              "samples_per_s_the_cpus_allow": usable * 1e3 / max(cpu_mean, 1e-9) * n_frames * 240,

@@ -147,7 +147,7 @@ def test_long_stream_is_planned_while_it_is_being_walked():
             assert L.dcs_seq_load_audio_stream_mem(h, 0, s, len(s), 0x64) == 0
             total, calls = 0, 0
             while total < 700:
-                n = seq.plan_ahead(64 if calls == 0 else 4096)
+                n = seq.plan_ahead(64 if calls == 0 else 200)       # (at most 899 ticks then, whatever the walker's pace)
                 assert n >= 1
                 total += n
                 calls += 1
@@ -165,7 +165,6 @@ def test_long_stream_is_planned_while_it_is_being_walked():
             # channel 0 ends behind tick 1500; channel 1, loaded at tick `at`, 900 ticks later; then two ticks of silence
             assert seq.pending_ticks == total
             assert seq.stream_playing_at(1499, 0) and not seq.stream_playing_at(1500, 0)
-            assert seq.plan_ahead(4096) in (1, 2) or True
         finally:
             seq.h = None
             L.dcs_seq_destroy(h)
