@@ -64,10 +64,10 @@ struct IndexLds
 // are walked the old way, and a stream whose exact looks do not reach behind every table-made run's bound is walked again entirely
 // the old way (tiny last frames; rare).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kGroupWaves = 16;         // wavefronts of a workgroup of dcsIndexGroupKernel
+constexpr int kGroupWaves = 4;          // wavefronts of a workgroup of dcsIndexGroupKernel: four table positions per thread
 constexpr int kGroupWin = 1024;         // bit positions behind a frame's header the tables cover
 constexpr int kGroupBooks = 4;          // codebooks a frame may use (of six) and still take the tables
-constexpr uint32_t kGroupCarry = 0x0400u, kGroupInvalid = 0x8000u;     // entry: bits advanced (0..9) | pending zero | left the window
+constexpr uint32_t kGroupCarry = 0x0400u, kGroupInvalid = 0x8000u;     // entry (16 bits): bits advanced (0..9) | pending zero | left the window
 struct GroupShared
 {
     uint32_t cmd;                       // 1 = build (the parameters below), 2 = the stream is through
@@ -75,7 +75,9 @@ struct GroupShared
     uint32_t nBooks;
     uint32_t bookOff[kGroupBooks];      // byte offset of the codebook in DcsLdsTables
     uint32_t bookShift[kGroupBooks];    // 32 - its look-ahead
-    uint16_t step[kGroupBooks][5][2][kGroupWin];        // [codebook][log2 samples][pending zero][position]
+    // [codebook][log2 samples][position]: the entry for "no zero pending" in the low half, for "the second zero of a two-zeros code
+    // is still due" in the high half (one read serves both; the LDS pipe's instruction count is what a build costs)
+    uint32_t __attribute__((aligned(16))) step[kGroupBooks][5][kGroupWin];
 };
 constexpr uint32_t kGroupCmdBuild = 1, kGroupCmdExit = 2;
 
@@ -496,60 +498,122 @@ __device__ __forceinline__ uint32_t headerDeltas94(Walk &s)
 
 // The tables of one frame, built by every thread of the workgroup (wavefront 0 comes here from its walk, the others from their
 // waiting loop: the same barriers either way).  `ring` = wavefront 0's mirror of the stream's window.
-__device__ __forceinline__ void groupBuild(GroupShared &G, const DcsLdsTables &T, const uint32_t *ring)
+template <int NB>
+__device__ __forceinline__ void groupBuildN(GroupShared &G, const DcsLdsTables &T, const uint32_t *ring)
 {
-    const uint32_t tid = threadIdx.x, nThreads = blockDim.x;
-    const uint32_t nBooks = G.nBooks, baseAbs = G.baseAbs;
-    // one sample: the code that starts at p (a two-zeros code leaves its second zero pending), or the pending zero
-    for (uint32_t i = tid ; i < nBooks * kGroupWin ; i += nThreads)
+    // A thread takes FOUR neighbouring positions: what a build costs is the LDS pipe's instruction count (the sixteen wavefronts
+    // of the first version, one position a thread, queued ~900 wavefront-wide LDS instructions a frame: 8 200 cycles), and with
+    // four positions a thread its own entries come and go sixteen bytes at a time; what is left are the scattered reads of the
+    // entries it is sent on to (two per position, codebook and level).
+    static_assert(kGroupWaves * 64 * 4 == kGroupWin, "four table positions per thread");
+    const uint32_t p0 = threadIdx.x * 4;
+    // one sample: the code that starts at p (a two-zeros code leaves its second zero pending), or the pending zero (which moves
+    // nothing: entry 0).  The stream's bits once, every codebook's entries for them (reads that do not wait for each other)
     {
-        const uint32_t bk = i / kGroupWin, p = i % kGroupWin;
-        const uint32_t a = baseAbs + p;
+        const uint32_t a = G.baseAbs + p0;
         const uint32_t *w = ring + ((a >> 5) & (kRingDw - 1));
-        const uint32_t bits = static_cast<uint32_t>((((static_cast<uint64_t>(w[0]) << 32) | w[1]) << (a & 31)) >> 32);
-        const uint16_t *book = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(&T) + G.bookOff[bk]);
-        const uint32_t e = book[bits >> G.bookShift[bk]];
-        const uint32_t len = (e >> 8) & 0x1Fu;
-        G.step[bk][0][0][p] = static_cast<uint16_t>((p + len >= kGroupWin ? kGroupInvalid : 0u) | len | ((e >> 13) == 2 ? kGroupCarry : 0u));
-        G.step[bk][0][1][p] = 0;
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        uint32_t bits[4];
+#pragma unroll
+        for (int j = 0 ; j < 4 ; ++j)
+        {
+            const uint32_t o = (a & 31) + static_cast<uint32_t>(j);                 // 0..34
+            const uint64_t pair = o < 32 ? (static_cast<uint64_t>(w0) << 32) | w1 : (static_cast<uint64_t>(w1) << 32) | w2;
+            bits[j] = static_cast<uint32_t>((pair << (o & 31)) >> 32);
+        }
+        uint32_t e[NB][4];
+#pragma unroll
+        for (int bk = 0 ; bk < NB ; ++bk)
+        {
+            const uint16_t *book = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(&T) + G.bookOff[bk]);
+            const uint32_t sh = G.bookShift[bk];
+#pragma unroll
+            for (int j = 0 ; j < 4 ; ++j)
+                e[bk][j] = book[bits[j] >> sh];
+        }
+#pragma unroll
+        for (int bk = 0 ; bk < NB ; ++bk)
+        {
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0 ; j < 4 ; ++j)
+            {
+                const uint32_t len = (e[bk][j] >> 8) & 0x1Fu;
+                o[j] = (p0 + j + len >= kGroupWin ? kGroupInvalid : 0u) | len | ((e[bk][j] >> 13) == 2 ? kGroupCarry : 0u);
+            }
+            *reinterpret_cast<uint4 *>(&G.step[bk][0][p0]) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
     }
     __syncthreads();
-    // 2, 4, 8, 16 samples: the table applied to itself
+    // 2, 4, 8, 16 samples: the table applied to itself -- all of a thread's chains side by side, so that a level costs two LDS round trips
     for (int k = 0 ; k < 4 ; ++k)
     {
-        for (uint32_t i = tid ; i < nBooks * 2 * kGroupWin ; i += nThreads)
+        uint32_t e1[NB][4], e2a[NB][4], e2b[NB][4];
+#pragma unroll
+        for (int bk = 0 ; bk < NB ; ++bk)
         {
-            const uint32_t bk = i / (2 * kGroupWin), c = (i / kGroupWin) & 1, p = i % kGroupWin;
-            const uint32_t e1 = G.step[bk][k][c][p];
-            uint32_t out = kGroupInvalid;
-            if ((e1 & kGroupInvalid) == 0)
+            const uint4 v = *reinterpret_cast<const uint4 *>(&G.step[bk][k][p0]);
+            e1[bk][0] = v.x; e1[bk][1] = v.y; e1[bk][2] = v.z; e1[bk][3] = v.w;
+        }
+#pragma unroll
+        for (int bk = 0 ; bk < NB ; ++bk)
+#pragma unroll
+            for (int j = 0 ; j < 4 ; ++j)
             {
-                const uint32_t p1 = p + (e1 & 0x3FFu), c1 = (e1 & kGroupCarry) != 0 ? 1u : 0u;
-                const uint32_t e2 = G.step[bk][k][c1][p1];          // (p1 < kGroupWin: e1 is not marked)
-                out = (e2 & (kGroupInvalid | kGroupCarry)) | ((e1 & 0x3FFu) + (e2 & 0x3FFu));
+                const uint32_t lo = e1[bk][j] & 0xFFFFu, hi = e1[bk][j] >> 16;
+                e2a[bk][j] = G.step[bk][k][(lo & kGroupInvalid) != 0 ? 0u : p0 + j + (lo & 0x3FFu)];   // (< kGroupWin where the entry is not marked)
+                e2b[bk][j] = G.step[bk][k][(hi & kGroupInvalid) != 0 ? 0u : p0 + j + (hi & 0x3FFu)];
             }
-            G.step[bk][k + 1][c][p] = static_cast<uint16_t>(out);
+#pragma unroll
+        for (int bk = 0 ; bk < NB ; ++bk)
+        {
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0 ; j < 4 ; ++j)
+            {
+                const uint32_t lo = e1[bk][j] & 0xFFFFu, hi = e1[bk][j] >> 16;
+                const uint32_t nlo = (lo & kGroupCarry) != 0 ? e2a[bk][j] >> 16 : e2a[bk][j] & 0xFFFFu;
+                const uint32_t nhi = (hi & kGroupCarry) != 0 ? e2b[bk][j] >> 16 : e2b[bk][j] & 0xFFFFu;
+                const uint32_t olo = (lo & kGroupInvalid) != 0 ? kGroupInvalid : (nlo & (kGroupInvalid | kGroupCarry)) | ((lo & 0x3FFu) + (nlo & 0x3FFu));
+                const uint32_t ohi = (hi & kGroupInvalid) != 0 ? kGroupInvalid : (nhi & (kGroupInvalid | kGroupCarry)) | ((hi & 0x3FFu) + (nhi & 0x3FFu));
+                o[j] = olo | (ohi << 16);
+            }
+            *reinterpret_cast<uint4 *>(&G.step[bk][k + 1][p0]) = make_uint4(o[0], o[1], o[2], o[3]);
         }
         __syncthreads();
     }
 }
+__device__ __forceinline__ void groupBuild(GroupShared &G, const DcsLdsTables &T, const uint32_t *ring)
+{
+    switch (G.nBooks)                   // (the same for the whole workgroup: the barriers inside are met by all)
+    {
+    case 1:  groupBuildN<1>(G, T, ring); break;
+    case 2:  groupBuildN<2>(G, T, ring); break;
+    case 3:  groupBuildN<3>(G, T, ring); break;
+    default: groupBuildN<4>(G, T, ring); break;
+    }
+}
 
-// `n` samples from table position `rel` with `carry` pending: -> false when the tables do not reach (nothing changed)
+// ONE table step: 2^level samples from position `rel` with `carry` pending -> false when the tables do not reach (nothing changed)
+__device__ __forceinline__ bool groupStep(const GroupShared &G, uint32_t bk, uint32_t level, uint32_t &rel, uint32_t &carry)
+{
+    if (rel >= static_cast<uint32_t>(kGroupWin))
+        return false;
+    const uint32_t w = uni(G.step[bk][level][rel]);
+    const uint32_t e = carry != 0 ? w >> 16 : w & 0xFFFFu;
+    if ((e & kGroupInvalid) != 0)
+        return false;
+    rel += e & 0x3FFu;
+    carry = (e & kGroupCarry) != 0 ? 1u : 0u;
+    return true;
+}
+// `n` samples (any number up to 31) from table position `rel` with `carry` pending: -> false when the tables do not reach
 __device__ __forceinline__ bool groupAdvance(const GroupShared &G, uint32_t bk, uint32_t n, uint32_t &rel, uint32_t &carry)
 {
     uint32_t r = rel, c = carry;
     for (int k = 4 ; k >= 0 ; --k)
-        while (n >= (1u << k))
-        {
-            if (r >= static_cast<uint32_t>(kGroupWin))
-                return false;
-            const uint32_t e = uni(G.step[bk][k][c][r]);
-            if ((e & kGroupInvalid) != 0)
-                return false;
-            r += e & 0x3FFu;
-            c = (e & kGroupCarry) != 0 ? 1u : 0u;
-            n -= 1u << k;
-        }
+        if ((n & (1u << k)) != 0 && !groupStep(G, bk, static_cast<uint32_t>(k), r, c))
+            return false;
     rel = r;
     carry = c;
     return true;
@@ -626,13 +690,18 @@ __device__ void scan94(Walk &s)
     bool band15Done = false;
     if (GROUP && s.useTables && huffMask != 0)
     {
+        IDX_T0(tTables);
         // which codebooks the frame's runs use (of the six: look-aheads 2, 3, 5, 7, 8, 9) and their places in the tables
         GroupShared &G = *s.G;
         const uint32_t cbId = vRunMulti >> DCS_IDX_MULTI_BITS;
-        uint32_t present = 0;
+        uint32_t present = 0, firstOf = 0;                  // firstOf: the lowest band of every codebook in use
+#pragma unroll
         for (uint32_t id = 0 ; id < 6 ; ++id)
-            if (__ballot(huffBand && cbId == id) != 0)
-                present |= 1u << id;
+        {
+            const uint32_t who = static_cast<uint32_t>(__ballot(huffBand && cbId == id));
+            present |= who != 0 ? 1u << id : 0u;
+            firstOf |= who & (0u - who);
+        }
         const uint32_t nBooks = static_cast<uint32_t>(__builtin_popcount(present));
         if (nBooks <= static_cast<uint32_t>(kGroupBooks))
         {
@@ -640,15 +709,10 @@ __device__ void scan94(Walk &s)
             b.pos = base;
             b.have = 0;
             b.ensure();                                     // (the window's dwords are in the ring's W0 / W1 part)
-            // the first band of every codebook tells the others where it is
-            for (uint32_t id = 0 ; id < 6 ; ++id)
+            if (((firstOf >> lane) & 1u) != 0)
             {
-                const unsigned long long who = __ballot(huffBand && cbId == id);
-                if (who != 0 && lane == static_cast<uint32_t>(__builtin_ctzll(who)))
-                {
-                    G.bookOff[slot] = vRunBook;
-                    G.bookShift[slot] = vRunShift;
-                }
+                G.bookOff[slot] = vRunBook;
+                G.bookShift[slot] = vRunShift;
             }
             if (lane == 0)
             {
@@ -656,47 +720,69 @@ __device__ void scan94(Walk &s)
                 G.baseAbs = b.payBit + base;
                 G.nBooks = nBooks;
             }
+            IDX_T0(tBuild);
             __syncthreads();                                // the others have been waiting for this
             groupBuild(G, T, b.ring);
-            // band after band through the tables
+            IDX_ACC(b, 3, tBuild);
+            // Band after band through the tables.  A band's parameters in one word (one v_readlane a band): the bits of the
+            // fixed-width bands before it | its codebook's place << 13 | whether it is a half-density band << 15
+            const uint32_t vParam = fixedBefore | (slot << 13) | (s.vInc == 2u ? 0x8000u : 0u);
             uint32_t bad = 0;
-            for ( ; left != 0 ; left &= left - 1)
+            // (band 0 holds 7 samples, or 3: three or two steps; band 1 holds 8 or 4, bands 2..14 hold 16 or 8: one step each)
+            if ((left & 1u) != 0)
             {
-                const uint32_t h = static_cast<uint32_t>(__builtin_ctz(left));
-                const uint32_t Gf = rl(fixedBefore, h);
+                const uint32_t pr = rl(vParam, 0), Gf = pr & 0x1FFFu;
                 uint32_t rel = q + Gf - base, carry = 0;
-                if (!groupAdvance(G, rl(slot, h), rl(s.vCount, h), rel, carry))
-                    break;                                  // (left the window: this band and the rest the old way)
-                bad |= carry;
-                q = base + rel - Gf;
-                vQ = lane == h ? q : vQ;
-                s.hiBound = umax(s.hiBound, q + Gf + 16u);
+                if (groupAdvance(G, (pr >> 13) & 3u, (pr & 0x8000u) != 0 ? 3u : 7u, rel, carry))
+                {
+                    bad |= carry;
+                    q = base + rel - Gf;
+                    vQ = lane == 0 ? q : vQ;
+                    left &= ~1u;
+                }
             }
+            if ((left & 1u) == 0)
+                for ( ; left != 0 ; left &= left - 1)
+                {
+                    const uint32_t h = static_cast<uint32_t>(__builtin_ctz(left));
+                    const uint32_t pr = rl(vParam, h), Gf = pr & 0x1FFFu;
+                    uint32_t rel = q + Gf - base, carry = 0;
+                    // (sixteen samples: level 4; eight: level 3; band 1's eight / four: levels 3 / 2)
+                    if (!groupStep(G, (pr >> 13) & 3u, (h == 1 ? 3u : 4u) - (pr >> 15), rel, carry))
+                        break;                              // (left the window: this band and the rest the old way)
+                    bad |= carry;
+                    q = base + rel - Gf;
+                    vQ = lane == h ? q : vQ;
+                }
             if (left == 0 && (huffMask & 0x8000u) != 0)
             {
-                // band 15: its first half ends where the record's split point lies (dcsPutMid15), a pending zero there = the straddle
-                const uint32_t Gf = rl(fixedBefore, 15);
+                // band 15 (32 samples, or 16): its first half ends where the record's split point lies (dcsPutMid15), a pending zero
+                // there = the straddle
+                const uint32_t pr = rl(vParam, 15), Gf = pr & 0x1FFFu, bk = (pr >> 13) & 3u, level = 4u - (pr >> 15);
                 const uint32_t count = rl(s.vCount, 15), lim = count / 2;
                 uint32_t rel = q + Gf - base, carry = 0;
-                if (groupAdvance(G, rl(slot, 15), count - lim, rel, carry))
+                if (groupStep(G, bk, level, rel, carry))
                 {
                     const uint32_t relMid = rel, carryMid = carry;
-                    if (groupAdvance(G, rl(slot, 15), lim, rel, carry))
+                    if (groupStep(G, bk, level, rel, carry))
                     {
                         const uint32_t i = lim - carryMid;
                         midBit = (base + relMid - frameStart) & 0xFFFFu;
                         midIdx = ((rl(outIdxB, 15) + (count - i) * rl(s.vInc, 15)) & 0x1FFu) | (carryMid != 0 ? DCS_MID15_STRADDLE : 0u);
                         bad |= carry;
                         q = base + rel - Gf;
-                        s.hiBound = umax(s.hiBound, q + Gf + 16u);
                         band15Done = true;
                     }
                 }
             }
+            // (the furthest a look of these runs can have reached: behind the last one's end by less than the widest look)
+            s.hiBound = umax(s.hiBound, q + rl(fixedIncl, 15) + 16u);
             if (bad != 0)
                 s.err |= DCS_FRAME_STOP;                    // two zeros with one slot left (:2213-2218)
             b.any = true;
         }
+        IDX_ACC(b, 2, tTables);
+        IDX_CNT(b, 6, 1);
     }
     for ( ; left != 0 ; left &= left - 1)
     {
@@ -1293,6 +1379,11 @@ __global__ __launch_bounds__(kGroupWaves * 64) void dcsIndexGroupKernel(uintptr_
         waveSync();
         if (lane < 12)
             reinterpret_cast<uint32_t *>(outInfo)[lane] = rec[lane];
+#ifdef DCS_IDX_STAMPS
+        if (lane == 0)
+            for (int i = 0 ; i < 12 ; ++i)
+                atomicAdd(&g_idxStamps[i], s.b.acc[i]);
+#endif
         break;
     }
     if (lane == 0)
