@@ -48,39 +48,6 @@ struct IndexLds
     uint32_t rec[kWaves][kRecDw];
 };
 
-// ---------------------------------------------------------------------------------------------------------
-// A WORKGROUP per stream (dcsIndexGroupKernel, round 6): for launches that underfill the chip.  One wavefront per stream takes as
-// long as its longest stream however few streams there are (1.9 ms for 256 frames: a lone wavefront, ~11 cycles an instruction),
-// and two thirds of that are the runs of Huffman-coded samples -- a gather, two table reads and a scalar chain per band, each
-// waiting for the band before.  Here wavefront 0 walks the stream as before (container, frame headers, per-band set-up, records)
-// and the other wavefronts of its workgroup take the runs off it: once a frame's header is read every band's codebook is known, so
-// for each codebook in use ALL wavefronts build, over the frame's window of kGroupWin bit positions, the table "from position p
-// (and whether the second zero of a two-zeros code is still due), where am I after ONE sample", and its powers by pointer doubling
-// (2, 4, 8, 16 samples); wavefront 0 then takes a band of sixteen samples with ONE dependent LDS read (seven samples: three).  The
-// state carried is (position, the pending zero): a band that ends on a pending zero is the "two zeros with one slot left" error
-// (:2213-2218), band 15's middle is where its first sixteen samples end (the record's split point, pending zero = straddle).
-// What the tables cannot give -- a frame with more than kGroupBooks codebooks, a run that leaves the window -- goes the old way,
-// band by band, inside the same frame.  The reader's byte pointer (nBytes) needs the LAST look's reach: the stream's last two frames
-// are walked the old way, and a stream whose exact looks do not reach behind every table-made run's bound is walked again entirely
-// the old way (tiny last frames; rare).
-// ---------------------------------------------------------------------------------------------------------
-constexpr int kGroupWaves = 4;          // wavefronts of a workgroup of dcsIndexGroupKernel: four table positions per thread
-constexpr int kGroupWin = 1024;         // bit positions behind a frame's header the tables cover
-constexpr int kGroupBooks = 4;          // codebooks a frame may use (of six) and still take the tables
-constexpr uint32_t kGroupCarry = 0x0400u, kGroupInvalid = 0x8000u;     // entry (16 bits): bits advanced (0..9) | pending zero | left the window
-struct GroupShared
-{
-    uint32_t cmd;                       // 1 = build (the parameters below), 2 = the stream is through
-    uint32_t baseAbs;                   // bit position of table index 0, counted like the ring's dwords (payBit + pos)
-    uint32_t nBooks;
-    uint32_t bookOff[kGroupBooks];      // byte offset of the codebook in DcsLdsTables
-    uint32_t bookShift[kGroupBooks];    // 32 - its look-ahead
-    // [codebook][log2 samples][position]: the entry for "no zero pending" in the low half, for "the second zero of a two-zeros code
-    // is still due" in the high half (one read serves both; the LDS pipe's instruction count is what a build costs)
-    uint32_t __attribute__((aligned(16))) step[kGroupBooks][5][kGroupWin];
-};
-constexpr uint32_t kGroupCmdBuild = 1, kGroupCmdExit = 2;
-
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(lane))); }
 // v_writelane: two scalar operands are one too many for gfx950's constant bus, and this compiler has no builtin that would
 // route the lane number through M0; a compare and a select do the same
@@ -314,11 +281,6 @@ struct Walk
     uint32_t vSplitLo = 0, vSplitHi = 0;        // lane k < 15: split[k] = bitDelta | prv << 16, prvDelta | state << 16
     uint32_t vRecBT = 0;                        // lane i < 16: byte i of the record's bandType field
     uint32_t hdrBits = 0, preAdj = 0;
-    // dcsIndexGroupKernel only (wavefront 0): the workgroup's tables, whether this frame may use them, and the furthest a look of a
-    // table-made run can have reached (its end + the widest look)
-    GroupShared *G = nullptr;
-    bool useTables = false;
-    uint32_t hiBound = 0;
 
     __device__ __forceinline__ void fatal() { err |= DCS_FRAME_FATAL | DCS_FRAME_STOP; }
     __device__ __forceinline__ void putSplit(int band, uint32_t bitDelta, uint32_t prv, uint32_t prvDelta, uint32_t state)
@@ -496,135 +458,11 @@ __device__ __forceinline__ uint32_t headerDeltas94(Walk &s)
     return vDelta;
 }
 
-// The tables of one frame, built by every thread of the workgroup (wavefront 0 comes here from its walk, the others from their
-// waiting loop: the same barriers either way).  `ring` = wavefront 0's mirror of the stream's window.
-template <int NB>
-__device__ __forceinline__ void groupBuildN(GroupShared &G, const DcsLdsTables &T, const uint32_t *ring)
-{
-    // A thread takes FOUR neighbouring positions: what a build costs is the LDS pipe's instruction count (the sixteen wavefronts
-    // of the first version, one position a thread, queued ~900 wavefront-wide LDS instructions a frame: 8 200 cycles), and with
-    // four positions a thread its own entries come and go sixteen bytes at a time; what is left are the scattered reads of the
-    // entries it is sent on to (two per position, codebook and level).
-    static_assert(kGroupWaves * 64 * 4 == kGroupWin, "four table positions per thread");
-    const uint32_t p0 = threadIdx.x * 4;
-    // one sample: the code that starts at p (a two-zeros code leaves its second zero pending), or the pending zero (which moves
-    // nothing: entry 0).  The stream's bits once, every codebook's entries for them (reads that do not wait for each other)
-    {
-        const uint32_t a = G.baseAbs + p0;
-        const uint32_t *w = ring + ((a >> 5) & (kRingDw - 1));
-        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-        uint32_t bits[4];
-#pragma unroll
-        for (int j = 0 ; j < 4 ; ++j)
-        {
-            const uint32_t o = (a & 31) + static_cast<uint32_t>(j);                 // 0..34
-            const uint64_t pair = o < 32 ? (static_cast<uint64_t>(w0) << 32) | w1 : (static_cast<uint64_t>(w1) << 32) | w2;
-            bits[j] = static_cast<uint32_t>((pair << (o & 31)) >> 32);
-        }
-        uint32_t e[NB][4];
-#pragma unroll
-        for (int bk = 0 ; bk < NB ; ++bk)
-        {
-            const uint16_t *book = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(&T) + G.bookOff[bk]);
-            const uint32_t sh = G.bookShift[bk];
-#pragma unroll
-            for (int j = 0 ; j < 4 ; ++j)
-                e[bk][j] = book[bits[j] >> sh];
-        }
-#pragma unroll
-        for (int bk = 0 ; bk < NB ; ++bk)
-        {
-            uint32_t o[4];
-#pragma unroll
-            for (int j = 0 ; j < 4 ; ++j)
-            {
-                const uint32_t len = (e[bk][j] >> 8) & 0x1Fu;
-                o[j] = (p0 + j + len >= kGroupWin ? kGroupInvalid : 0u) | len | ((e[bk][j] >> 13) == 2 ? kGroupCarry : 0u);
-            }
-            *reinterpret_cast<uint4 *>(&G.step[bk][0][p0]) = make_uint4(o[0], o[1], o[2], o[3]);
-        }
-    }
-    __syncthreads();
-    // 2, 4, 8, 16 samples: the table applied to itself -- all of a thread's chains side by side, so that a level costs two LDS round trips
-    for (int k = 0 ; k < 4 ; ++k)
-    {
-        uint32_t e1[NB][4], e2a[NB][4], e2b[NB][4];
-#pragma unroll
-        for (int bk = 0 ; bk < NB ; ++bk)
-        {
-            const uint4 v = *reinterpret_cast<const uint4 *>(&G.step[bk][k][p0]);
-            e1[bk][0] = v.x; e1[bk][1] = v.y; e1[bk][2] = v.z; e1[bk][3] = v.w;
-        }
-#pragma unroll
-        for (int bk = 0 ; bk < NB ; ++bk)
-#pragma unroll
-            for (int j = 0 ; j < 4 ; ++j)
-            {
-                const uint32_t lo = e1[bk][j] & 0xFFFFu, hi = e1[bk][j] >> 16;
-                e2a[bk][j] = G.step[bk][k][(lo & kGroupInvalid) != 0 ? 0u : p0 + j + (lo & 0x3FFu)];   // (< kGroupWin where the entry is not marked)
-                e2b[bk][j] = G.step[bk][k][(hi & kGroupInvalid) != 0 ? 0u : p0 + j + (hi & 0x3FFu)];
-            }
-#pragma unroll
-        for (int bk = 0 ; bk < NB ; ++bk)
-        {
-            uint32_t o[4];
-#pragma unroll
-            for (int j = 0 ; j < 4 ; ++j)
-            {
-                const uint32_t lo = e1[bk][j] & 0xFFFFu, hi = e1[bk][j] >> 16;
-                const uint32_t nlo = (lo & kGroupCarry) != 0 ? e2a[bk][j] >> 16 : e2a[bk][j] & 0xFFFFu;
-                const uint32_t nhi = (hi & kGroupCarry) != 0 ? e2b[bk][j] >> 16 : e2b[bk][j] & 0xFFFFu;
-                const uint32_t olo = (lo & kGroupInvalid) != 0 ? kGroupInvalid : (nlo & (kGroupInvalid | kGroupCarry)) | ((lo & 0x3FFu) + (nlo & 0x3FFu));
-                const uint32_t ohi = (hi & kGroupInvalid) != 0 ? kGroupInvalid : (nhi & (kGroupInvalid | kGroupCarry)) | ((hi & 0x3FFu) + (nhi & 0x3FFu));
-                o[j] = olo | (ohi << 16);
-            }
-            *reinterpret_cast<uint4 *>(&G.step[bk][k + 1][p0]) = make_uint4(o[0], o[1], o[2], o[3]);
-        }
-        __syncthreads();
-    }
-}
-__device__ __forceinline__ void groupBuild(GroupShared &G, const DcsLdsTables &T, const uint32_t *ring)
-{
-    switch (G.nBooks)                   // (the same for the whole workgroup: the barriers inside are met by all)
-    {
-    case 1:  groupBuildN<1>(G, T, ring); break;
-    case 2:  groupBuildN<2>(G, T, ring); break;
-    case 3:  groupBuildN<3>(G, T, ring); break;
-    default: groupBuildN<4>(G, T, ring); break;
-    }
-}
-
-// ONE table step: 2^level samples from position `rel` with `carry` pending -> false when the tables do not reach (nothing changed)
-__device__ __forceinline__ bool groupStep(const GroupShared &G, uint32_t bk, uint32_t level, uint32_t &rel, uint32_t &carry)
-{
-    if (rel >= static_cast<uint32_t>(kGroupWin))
-        return false;
-    const uint32_t w = uni(G.step[bk][level][rel]);
-    const uint32_t e = carry != 0 ? w >> 16 : w & 0xFFFFu;
-    if ((e & kGroupInvalid) != 0)
-        return false;
-    rel += e & 0x3FFu;
-    carry = (e & kGroupCarry) != 0 ? 1u : 0u;
-    return true;
-}
-// `n` samples (any number up to 31) from table position `rel` with `carry` pending: -> false when the tables do not reach
-__device__ __forceinline__ bool groupAdvance(const GroupShared &G, uint32_t bk, uint32_t n, uint32_t &rel, uint32_t &carry)
-{
-    uint32_t r = rel, c = carry;
-    for (int k = 4 ; k >= 0 ; --k)
-        if ((n & (1u << k)) != 0 && !groupStep(G, bk, static_cast<uint32_t>(k), r, c))
-            return false;
-    rel = r;
-    carry = c;
-    return true;
-}
-
 // --- 1994+ frame (:1679-2261; the walk of dcsScan94, dcs_scan.h) ---------------------------------------------------
 // Once the frame header is read, everything about a band but the length of its Huffman-coded samples follows from its
 // band-type code and the stream header: lane b works that out for band b (one look-up in the decode kernel's set-up
 // table, DcsLdsTables::band94), output indices and the bits of the fixed-width bands become prefix sums over the lanes,
 // and what is left to do one after the other are the Huffman-coded bands.
-template <bool GROUP>
 __device__ void scan94(Walk &s)
 {
     WaveBits &b = s.b;
@@ -686,105 +524,7 @@ __device__ void scan94(Walk &s)
     IDX_ACC(b, 9, tSetup);
     IDX_T0(tLoop);
     const uint32_t huffMask = static_cast<uint32_t>(__ballot(huffBand));
-    uint32_t left = huffMask & 0x7FFFu;
-    bool band15Done = false;
-    if (GROUP && s.useTables && huffMask != 0)
-    {
-        IDX_T0(tTables);
-        // which codebooks the frame's runs use (of the six: look-aheads 2, 3, 5, 7, 8, 9) and their places in the tables
-        GroupShared &G = *s.G;
-        const uint32_t cbId = vRunMulti >> DCS_IDX_MULTI_BITS;
-        uint32_t present = 0, firstOf = 0;                  // firstOf: the lowest band of every codebook in use
-#pragma unroll
-        for (uint32_t id = 0 ; id < 6 ; ++id)
-        {
-            const uint32_t who = static_cast<uint32_t>(__ballot(huffBand && cbId == id));
-            present |= who != 0 ? 1u << id : 0u;
-            firstOf |= who & (0u - who);
-        }
-        const uint32_t nBooks = static_cast<uint32_t>(__builtin_popcount(present));
-        if (nBooks <= static_cast<uint32_t>(kGroupBooks))
-        {
-            const uint32_t slot = static_cast<uint32_t>(__builtin_popcount(present & ((1u << cbId) - 1u)));
-            b.pos = base;
-            b.have = 0;
-            b.ensure();                                     // (the window's dwords are in the ring's W0 / W1 part)
-            if (((firstOf >> lane) & 1u) != 0)
-            {
-                G.bookOff[slot] = vRunBook;
-                G.bookShift[slot] = vRunShift;
-            }
-            if (lane == 0)
-            {
-                G.cmd = kGroupCmdBuild;
-                G.baseAbs = b.payBit + base;
-                G.nBooks = nBooks;
-            }
-            IDX_T0(tBuild);
-            __syncthreads();                                // the others have been waiting for this
-            groupBuild(G, T, b.ring);
-            IDX_ACC(b, 3, tBuild);
-            // Band after band through the tables.  A band's parameters in one word (one v_readlane a band): the bits of the
-            // fixed-width bands before it | its codebook's place << 13 | whether it is a half-density band << 15
-            const uint32_t vParam = fixedBefore | (slot << 13) | (s.vInc == 2u ? 0x8000u : 0u);
-            uint32_t bad = 0;
-            // (band 0 holds 7 samples, or 3: three or two steps; band 1 holds 8 or 4, bands 2..14 hold 16 or 8: one step each)
-            if ((left & 1u) != 0)
-            {
-                const uint32_t pr = rl(vParam, 0), Gf = pr & 0x1FFFu;
-                uint32_t rel = q + Gf - base, carry = 0;
-                if (groupAdvance(G, (pr >> 13) & 3u, (pr & 0x8000u) != 0 ? 3u : 7u, rel, carry))
-                {
-                    bad |= carry;
-                    q = base + rel - Gf;
-                    vQ = lane == 0 ? q : vQ;
-                    left &= ~1u;
-                }
-            }
-            if ((left & 1u) == 0)
-                for ( ; left != 0 ; left &= left - 1)
-                {
-                    const uint32_t h = static_cast<uint32_t>(__builtin_ctz(left));
-                    const uint32_t pr = rl(vParam, h), Gf = pr & 0x1FFFu;
-                    uint32_t rel = q + Gf - base, carry = 0;
-                    // (sixteen samples: level 4; eight: level 3; band 1's eight / four: levels 3 / 2)
-                    if (!groupStep(G, (pr >> 13) & 3u, (h == 1 ? 3u : 4u) - (pr >> 15), rel, carry))
-                        break;                              // (left the window: this band and the rest the old way)
-                    bad |= carry;
-                    q = base + rel - Gf;
-                    vQ = lane == h ? q : vQ;
-                }
-            if (left == 0 && (huffMask & 0x8000u) != 0)
-            {
-                // band 15 (32 samples, or 16): its first half ends where the record's split point lies (dcsPutMid15), a pending zero
-                // there = the straddle
-                const uint32_t pr = rl(vParam, 15), Gf = pr & 0x1FFFu, bk = (pr >> 13) & 3u, level = 4u - (pr >> 15);
-                const uint32_t count = rl(s.vCount, 15), lim = count / 2;
-                uint32_t rel = q + Gf - base, carry = 0;
-                if (groupStep(G, bk, level, rel, carry))
-                {
-                    const uint32_t relMid = rel, carryMid = carry;
-                    if (groupStep(G, bk, level, rel, carry))
-                    {
-                        const uint32_t i = lim - carryMid;
-                        midBit = (base + relMid - frameStart) & 0xFFFFu;
-                        midIdx = ((rl(outIdxB, 15) + (count - i) * rl(s.vInc, 15)) & 0x1FFu) | (carryMid != 0 ? DCS_MID15_STRADDLE : 0u);
-                        bad |= carry;
-                        q = base + rel - Gf;
-                        band15Done = true;
-                    }
-                }
-            }
-            // (the furthest a look of these runs can have reached: behind the last one's end by less than the widest look)
-            s.hiBound = umax(s.hiBound, q + rl(fixedIncl, 15) + 16u);
-            if (bad != 0)
-                s.err |= DCS_FRAME_STOP;                    // two zeros with one slot left (:2213-2218)
-            b.any = true;
-        }
-        IDX_ACC(b, 2, tTables);
-        IDX_CNT(b, 6, 1);
-    }
-    for ( ; left != 0 ; left &= left - 1)
+    for (uint32_t left = huffMask & 0x7FFFu ; left != 0 ; left &= left - 1)
     {
         const uint32_t h = static_cast<uint32_t>(__builtin_ctz(left));
         const uint32_t G = rl(fixedBefore, h);
@@ -797,7 +537,7 @@ __device__ void scan94(Walk &s)
     }
     if ((runEnds >> 16) != 0xFFFFu)
         s.err |= DCS_FRAME_STOP;                                // two zeros with one slot left (:2213-2218)
-    if ((huffMask & 0x8000u) != 0 && !band15Done)
+    if ((huffMask & 0x8000u) != 0)
     {
         // band 15 in two halves; where the second one starts is recorded (dcsPutMid15, dcs_scan.h)
         const uint32_t G = rl(fixedBefore, 15);
@@ -1046,16 +786,12 @@ __device__ void scan93a(Walk &s)
 }
 
 // the frames of one stream, one after the other: KIND 0 = 1993 Type 0 / OS93b Type 1, 1 = OS93a Type 1, 2 = 1994+
-template <int KIND, bool GROUP = false>
-__device__ __forceinline__ void walkFrames(Walk &s, uint32_t nFrames, DcsFrameIndex *outRec, DcsFrameDigest *outDigest, uint32_t &valid, uint32_t &payloadBits,
-                                           bool tables = false)
+template <int KIND>
+__device__ __forceinline__ void walkFrames(Walk &s, uint32_t nFrames, DcsFrameIndex *outRec, DcsFrameDigest *outDigest, uint32_t &valid, uint32_t &payloadBits)
 {
     const uint32_t lane = s.lane;
     for (uint32_t f = 0 ; f < nFrames ; ++f)
     {
-        // (the stream's last two frames the old way: their looks are what decides the reader's byte pointer)
-        if (GROUP)
-            s.useTables = tables && f + 2 < nFrames;
         const uint32_t frameBit = s.b.pos;
         IDX_T0(tWalk);
         IDX_CNT(s.b, 8, 1);
@@ -1063,7 +799,7 @@ __device__ __forceinline__ void walkFrames(Walk &s, uint32_t nFrames, DcsFrameIn
         s.vSplitLo = 0; s.vSplitHi = 0; s.vRecBT = 0; s.hdrBits = 0; s.preAdj = 0;
         if (KIND == 0) scan93(s);
         else if (KIND == 1) scan93a(s);
-        else scan94<GROUP>(s);
+        else scan94(s);
         IDX_ACC(s.b, 0, tWalk);
         IDX_T0(tOut);
         const uint32_t nBits = (s.b.pos - frameBit) & 0xFFFFu;
@@ -1236,159 +972,6 @@ __global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 
         for (int i = 0 ; i < 12 ; ++i)
             atomicAdd(&g_idxStamps[i], s.b.acc[i]);
 #endif
-}
-
-
-// The workgroup-per-stream kernel: workgroup k walks stream k, wavefront 0 as dcsIndexWaveKernel's wavefronts do, the others build
-// the sample-step tables of 1994+ frames on its command (see GroupShared).  Dynamic LDS: IndexLds (of which ring[0] / rec[0] are
-// used) followed by GroupShared.
-constexpr size_t kGroupLdsBytes = ((sizeof(IndexLds) + 15) & ~size_t(15)) + sizeof(GroupShared);
-__global__ __launch_bounds__(kGroupWaves * 64) void dcsIndexGroupKernel(uintptr_t blobBase, const DcsStreamLoc *locs, uint32_t nStreams,
-                                                                         const DcsDevTables *tables, DcsFrameIndex *out, DcsStreamInfo *infos,
-                                                                         DcsFrameDigest *digest, const StreamOut *outs)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char groupSmem[];
-    IndexLds &L = *reinterpret_cast<IndexLds *>(groupSmem);
-    GroupShared &G = *reinterpret_cast<GroupShared *>(groupSmem + ((sizeof(IndexLds) + 15) & ~size_t(15)));
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tables->lds);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&L.T);
-        for (uint32_t i = threadIdx.x ; i < sizeof(DcsLdsTables) / 4 ; i += blockDim.x)
-            dst[i] = src[i];
-        for (uint32_t i = threadIdx.x ; i < 256 ; i += blockDim.x)
-            L.fast94[i] = tables->fast94[i];
-        for (uint32_t i = threadIdx.x ; i < DCS_TRIE94_MAX ; i += blockDim.x)
-            L.trie94[i] = tables->trie94[i];
-        for (uint32_t i = threadIdx.x ; i < sizeof(L.multi94) / 4 ; i += blockDim.x)
-            reinterpret_cast<uint32_t *>(L.multi94)[i] = reinterpret_cast<const uint32_t *>(tables->multi94)[i];
-        if (threadIdx.x == 0)
-            G.cmd = 0;
-    }
-    __syncthreads();
-    const uint32_t wave = uni(threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t k = blockIdx.x;
-    if (wave != 0)
-    {
-        // the helpers: wait for wavefront 0's word, build, wait again -- until the stream is through
-        for (;;)
-        {
-            __syncthreads();
-            if (*const_cast<volatile uint32_t *>(&G.cmd) == kGroupCmdExit)
-                return;
-            groupBuild(G, L.T, L.ring[0]);
-        }
-    }
-    const DcsStreamLoc loc = locs[k];
-    const int os = loc.os;
-    const uint8_t *stream = reinterpret_cast<const uint8_t *>(blobBase + loc.off);
-    const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(stream) & 3);
-    const uint32_t len = loc.len;
-    uint32_t *rec = L.rec[0];
-    DcsFrameIndex *outRec;
-    DcsFrameDigest *outDigest;
-    DcsStreamInfo *outInfo;
-    if (outs != nullptr)
-    {
-        const StreamOut o = outs[k];
-        outRec = o.records; outDigest = o.digest; outInfo = o.info;
-    }
-    else
-    {
-        outRec = out + loc.firstRecord;
-        outDigest = digest != nullptr ? digest + loc.firstRecord : nullptr;
-        outInfo = infos + k;
-    }
-    // (a second pass the old way when the first one's exact looks do not reach behind every table-made run's bound: see GroupShared)
-    for (int pass = 0 ; pass < 2 ; ++pass)
-    {
-        Walk s;
-        s.L = &L;
-        s.lane = lane;
-        s.os = os;
-        s.G = &G;
-        s.b.sBase = (const uint32_t __attribute__((address_space(1))) *)(reinterpret_cast<uintptr_t>(stream) - skew);
-        s.b.endByte = skew + len;
-        s.b.nDwValid = (skew + len + 3) / 4;
-        s.b.ring = L.ring[0];
-        s.b.lane = lane;
-        const uint32_t vByte = (lane < 18 && lane < len) ? stream[lane] : 0u;
-        const uint32_t nFrames = (rl(vByte, 0) << 8) | rl(vByte, 1);
-        const bool typeBit = (rl(vByte, 2) & 0x80u) != 0;
-        const uint32_t hdrLen = (os == DCS_OS93A && typeBit) ? 1u : 16u;
-        s.vHeader = (lane < hdrLen && lane + 2 < len) ? stream[lane + 2] : 0u;
-        s.b.setPayload(skew + 2 + hdrLen);
-        const uint32_t h0 = rl(s.vHeader, 0), h1 = rl(s.vHeader, 1), h2 = rl(s.vHeader, 2);
-        if (os == DCS_OS93A && typeBit)
-            s.nBands = static_cast<int>(h0 & 0x1F);
-        else
-        {
-            const unsigned long long ends = __ballot(lane < 16 && (s.vHeader & 0x7Fu) == 0x7Fu);
-            s.nBands = ends != 0 ? static_cast<int>(__builtin_ctzll(ends)) : 16;
-        }
-        int format;
-        if (os == DCS_OS93A)
-            format = typeBit ? DCS_FMT_93A_T1 : DCS_FMT_93_T0;
-        else if (os == DCS_OS93B)
-            format = typeBit ? DCS_FMT_93B_T1 : DCS_FMT_93_T0;
-        else if (!typeBit)
-            format = DCS_FMT_94_T0;
-        else
-            format = (((h1 | h2) & 0x80u) == 0) ? DCS_FMT_94_T1_S0 : DCS_FMT_94_T1_S3;
-        s.format = format;
-        s.type1 = typeBit;
-        s.sub0 = ((h1 | h2) & 0x80u) == 0;
-        {
-            const uint32_t full = lane == 0 ? 7u : lane == 1 ? 8u : lane == 15 ? 32u : 16u;        // :1848-1850
-            const bool strided = (s.vHeader & 0x40u) != 0;                                             // :1858-1862
-            s.vCount = lane < 16 ? (strided ? full / 2 : full) : 0u;
-            s.vInc = strided ? 2u : 1u;
-        }
-        if (format == DCS_FMT_93A_T1)
-        {
-            s.vBB = L.T.bandBits93a[((h0 & 0x60u) >> 1) + (lane & 15)];
-            s.vSc1 = L.T.scaleCb93a[lane & 15];
-            s.vInputs = L.T.inputs93a[lane < 24 ? lane : 0];
-        }
-        uint32_t valid = 0, payloadBits = 0;
-        switch (format)
-        {
-        case DCS_FMT_93_T0:
-        case DCS_FMT_93B_T1: walkFrames<0>(s, nFrames, outRec, outDigest, valid, payloadBits); break;
-        case DCS_FMT_93A_T1: walkFrames<1>(s, nFrames, outRec, outDigest, valid, payloadBits); break;
-        default:             walkFrames<2, true>(s, nFrames, outRec, outDigest, valid, payloadBits, pass == 0); break;
-        }
-        if (pass == 0 && s.hiBound > s.b.hi)
-            continue;               // (some table-made run's last look may have reached furthest: once more, every run walked)
-
-        // the stream's summary (GetStreamInfo :1486-1537)
-        waveSync();
-        if (lane < 16)
-            reinterpret_cast<uint8_t *>(rec)[16 + lane] = static_cast<uint8_t>(s.vHeader);
-        if (lane == 0)
-        {
-            rec[0] = nFrames;
-            rec[1] = s.b.bytesFetched(2 + hdrLen);
-            rec[2] = typeBit ? 1u : 0u;
-            rec[3] = (os == DCS_OS94 || os == DCS_OS95) ? (((h1 & 0x80u) >> 6) | ((h1 & 0x80u) >> 7)) : 0u;     // sic (:1517)
-            rec[8] = static_cast<uint32_t>(format);
-            rec[9] = hdrLen;
-            rec[10] = valid;
-            rec[11] = payloadBits;
-        }
-        waveSync();
-        if (lane < 12)
-            reinterpret_cast<uint32_t *>(outInfo)[lane] = rec[lane];
-#ifdef DCS_IDX_STAMPS
-        if (lane == 0)
-            for (int i = 0 ; i < 12 ; ++i)
-                atomicAdd(&g_idxStamps[i], s.b.acc[i]);
-#endif
-        break;
-    }
-    if (lane == 0)
-        G.cmd = kGroupCmdExit;
-    __syncthreads();
 }
 
 }   // namespace dcsidx

@@ -491,8 +491,6 @@ extern "C" DcsStatus dcs_ctx_create(int deviceId, DcsCtx **out)
         // opt in to the LDS the largest configuration needs
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dcsk::dcsDecodeKernel<16>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, dcsk::ldsBytes(16)));
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dcsidx::dcsIndexGroupKernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dcsidx::kGroupLdsBytes)));
         return DCS_OK;
     }();
     if (st != DCS_OK)
@@ -2006,16 +2004,6 @@ static hipError_t launchIndexWave(hipStream_t stream, uintptr_t blobBase, const 
 {
     if (nStreams == 0)          // (an empty round is no launch: a zero-block grid is an error to some runtimes)
         return hipSuccess;
-    // A launch that underfills the chip -- at most one stream per CU -- gives every stream a WORKGROUP (dcsIndexGroupKernel: the runs
-    // of Huffman-coded samples through tables all its wavefronts build); beyond that a wavefront per stream fills the chip better.
-    // DCS_INDEX_GROUP=0 / a number: never / up to that many streams.
-    static const int groupMax = getenv("DCS_INDEX_GROUP") != nullptr ? atoi(getenv("DCS_INDEX_GROUP")) : 256;
-    if (static_cast<int>(nStreams) <= groupMax)
-    {
-        hipLaunchKernelGGL(dcsidx::dcsIndexGroupKernel, dim3(nStreams), dim3(dcsidx::kGroupWaves * 64), dcsidx::kGroupLdsBytes, stream, blobBase, dLocs,
-                           nStreams, dTables, dOut, dInfos, dDigest, dOuts);
-        return hipGetLastError();
-    }
     const uint32_t blocks = (nStreams + dcsidx::kWaves - 1) / dcsidx::kWaves;
     hipLaunchKernelGGL(dcsidx::dcsIndexWaveKernel, dim3(blocks), dim3(dcsidx::kWaves * 64), 0, stream, blobBase, dLocs, nStreams, dTables,
                        dOut, dInfos, dDigest, dOuts);
