@@ -101,3 +101,32 @@ def test_rom_less_recipe_behind_the_real_base(tmp_path, case, lookahead):
     assert "%016x" % Oracle().fnv1a64(pcm) == case["pcm_fnv1a64"]
     if case["name"] + "/pcm" in z:
         assert np.array_equal(pcm, z[case["name"] + "/pcm"])
+
+
+FUZZ = os.path.join(ROOT, "oracle", "_ref", "dcs_class_fuzz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("os_", [D.OS93A, D.OS93B, D.OS94, D.OS95], ids=["os93a", "os93b", "os94", "os95"])
+def test_a_random_caller_in_lock_step_with_the_reference(tmp_path, os_):
+    """tests/cpp/dcs_class_fuzz.cpp: DCSDecoderHIP behind the reference's real base class and the reference's unmodified DCSDecoderNative
+    in one process, the same seeded random calls on both -- LoadAudioStream on any channel at any level, ClearTracks, SetMasterVolume,
+    IsStreamPlaying, pulls of 0 to 2 500 frames in between -- every sample and every answer compared.  Streams of 3 to 1 800 frames
+    (the long ones are walked on a second thread while their first frames go out), two of them damaged; the caller never mentions
+    look-ahead, and the same seeds once more tick by tick."""
+    if not os.path.exists(FUZZ):
+        pytest.skip("oracle/_ref/dcs_class_fuzz not built (needs /root/reference; `make -C oracle fuzz`)")
+    from util import make_stream, corrupt, splitmix
+    fmts = [f for f in range(6) if os_ in (D.format_os(f), D.format_os(f, prefer_95=True), D.format_os(f, prefer_93a=True))]
+    g = splitmix(0xF022 + os_)
+    paths = []
+    for k, n in enumerate([3, 17, 64, 65, 200, 385, 700, 1800, 40, 500]):
+        data = make_stream(fmts[next(g) % len(fmts)], n, seed=0xF0220 + 16 * os_ + k, profile=(0, 1, 2, 5)[next(g) % 4])
+        if k >= 8:
+            data = corrupt(data, seed=70 + k)                   # (frame errors: the channel stops on the next tick)
+        path = tmp_path / ("f%d.bin" % k)
+        path.write_bytes(data)
+        paths.append(str(path))
+    for seed, n_ops, lookahead in ((1, 300, -1), (2, 300, -1), (3, 120, 1), (4, 300, 0), (5, 200, 37)):
+        r = subprocess.run([FUZZ, str(os_), str(1000 * os_ + seed), str(n_ops), str(lookahead)] + paths, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.startswith("ok:"), "seed %d look-ahead %d: %s %s" % (seed, lookahead, r.stdout[-500:], r.stderr[-500:])
