@@ -1262,6 +1262,8 @@ extern "C" int dcs_seq_stream_playing_at(const DcsSequencer *s, uint32_t ticks, 
 {
     if (s == nullptr || channel < 0 || channel >= DCS_MAX_CHANNELS || ticks > s->batchTicks() || s->history.empty())
         return 0;
+    if (ticks == s->batchTicks())
+        return s->ch[channel].st != nullptr ? 1 : 0;        // the machine as it stands, commands behind the last tick included
     if (ticks == 0)
         return s->history[0].st.ch[channel].st != nullptr ? 1 : 0;
     return (s->playingAfter[ticks - 1] >> channel) & 1;
@@ -1273,6 +1275,13 @@ extern "C" int dcs_seq_tracks_active_at(const DcsSequencer *s, uint32_t ticks)
 {
     if (s == nullptr || ticks > s->batchTicks() || s->history.empty())
         return 1;
+    if (ticks == s->batchTicks())
+    {
+        for (const Chan &c : s->ch)                          // the machine as it stands, commands behind the last tick included
+            if (c.st != nullptr || !c.track.isNull())
+                return 1;
+        return 0;
+    }
     if (ticks == 0)
     {
         for (const Chan &c : s->history[0].st.ch)

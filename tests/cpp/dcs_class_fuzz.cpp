@@ -59,9 +59,28 @@ int main(int argc, char **argv)
     for (int i = 5 ; i < argc ; ++i)
         streams.push_back(readFile(argv[i]));
 
+    // (DCS_FUZZ_REF_ONLY=1: the reference alone runs the same calls -- to tell, where the process dies, whose fault it is: the
+    // reference has undefined behaviour on some damaged streams)
+    const bool refOnly = getenv("DCS_FUZZ_REF_ONLY") != nullptr;
     DCSDecoder::MinHost hostA, hostB;
     DCSDecoderNative ref(&hostA);
-    DCSDecoderHIP hip(&hostB);
+    DCSDecoderNative second(&hostB);
+    DCSDecoderHIP hipReal(&hostB);
+    struct Both
+    {
+        bool refOnly; DCSDecoderNative &n; DCSDecoderHIP &h;
+        void SetLookahead(int v) { if (!refOnly) h.SetLookahead(v); }
+        void InitStandalone(DCSDecoder::OSVersion v) { if (refOnly) n.InitStandalone(v); else h.InitStandalone(v); }
+        void SetDefaultVolume(int v) { if (refOnly) n.SetDefaultVolume(v); else h.SetDefaultVolume(v); }
+        void SoftBoot() { if (refOnly) n.SoftBoot(); else h.SoftBoot(); }
+        bool IsOK() { return refOnly ? n.IsOK() : h.IsOK(); }
+        std::string GetErrorMessage() { return refOnly ? n.GetErrorMessage() : h.GetErrorMessage(); }
+        int16_t GetNextSample() { return refOnly ? n.GetNextSample() : h.GetNextSample(); }
+        void LoadAudioStream(int c, const DCSDecoder::ROMPointer &p, int l) { if (refOnly) n.LoadAudioStream(c, p, l); else h.LoadAudioStream(c, p, l); }
+        void ClearTracks() { if (refOnly) n.ClearTracks(); else h.ClearTracks(); }
+        void SetMasterVolume(int v) { if (refOnly) n.SetMasterVolume(v); else h.SetMasterVolume(v); }
+        bool IsStreamPlaying(int c) { return refOnly ? n.IsStreamPlaying(c) : h.IsStreamPlaying(c); }
+    } hip{ refOnly, second, hipReal };
     if (lookahead >= 0)
         hip.SetLookahead(lookahead);
     ref.InitStandalone(kOs[os]);

@@ -119,14 +119,24 @@ def test_a_random_caller_in_lock_step_with_the_reference(tmp_path, os_):
     from util import make_stream, corrupt, splitmix
     fmts = [f for f in range(6) if os_ in (D.format_os(f), D.format_os(f, prefer_95=True), D.format_os(f, prefer_93a=True))]
     g = splitmix(0xF022 + os_)
-    paths = []
+    paths, clean = [], []
     for k, n in enumerate([3, 17, 64, 65, 200, 385, 700, 1800, 40, 500]):
         data = make_stream(fmts[next(g) % len(fmts)], n, seed=0xF0220 + 16 * os_ + k, profile=(0, 1, 2, 5)[next(g) % 4])
+        path = tmp_path / ("c%d.bin" % k)
+        path.write_bytes(data)
+        clean.append(str(path))
         if k >= 8:
             data = corrupt(data, seed=70 + k)                   # (frame errors: the channel stops on the next tick)
         path = tmp_path / ("f%d.bin" % k)
         path.write_bytes(data)
         paths.append(str(path))
+    damaged_runs = 0
     for seed, n_ops, lookahead in ((1, 300, -1), (2, 300, -1), (3, 120, 1), (4, 300, 0), (5, 200, 37)):
-        r = subprocess.run([FUZZ, str(os_), str(1000 * os_ + seed), str(n_ops), str(lookahead)] + paths, capture_output=True, text=True, timeout=900)
+        args = [str(os_), str(1000 * os_ + seed), str(n_ops), str(lookahead)]
+        # the reference has undefined behaviour on some damaged streams (unchecked table indices: it may crash): a seed whose calls
+        # kill the REFERENCE ALONE runs on the undamaged streams instead
+        alone = subprocess.run([FUZZ] + args + paths, capture_output=True, text=True, timeout=900, env=dict(os.environ, DCS_FUZZ_REF_ONLY="1"))
+        use = paths if alone.returncode == 0 else clean
+        damaged_runs += use is paths
+        r = subprocess.run([FUZZ] + args + use, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and r.stdout.startswith("ok:"), "seed %d look-ahead %d: %s %s" % (seed, lookahead, r.stdout[-500:], r.stderr[-500:])
