@@ -7,7 +7,7 @@ REPO=$PWD
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --workload $WL --steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end --no-second-workload --no-device-path --rotate 0 $*"
+BENCH="python3 $PWD/bench.py --workload $WL --steps 50 --warmup 5 --no-cpu-baseline --no-class-surface --no-end-to-end --no-second-workload --no-device-path --rotate 0 $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.log
 echo "prof $TAG: kernel trace done"
