@@ -202,10 +202,20 @@ public:
                 return w;
             }
         }
-        Worker *w = new Worker;
-        std::thread th([w] { w->main(); });
-        w->handle = th.native_handle();
-        th.detach();                        // (the handle stays good: the thread never ends)
+        Worker *w = new (std::nothrow) Worker;
+        if (w == nullptr)
+            return nullptr;
+        try
+        {
+            std::thread th([w] { w->main(); });
+            w->handle = th.native_handle();
+            th.detach();                    // (the handle stays good: the thread never ends)
+        }
+        catch (...)
+        {
+            delete w;                       // (no thread to be had: the caller walks its stream itself)
+            return nullptr;
+        }
         return w;
     }
     void give(Worker *w)
@@ -371,7 +381,9 @@ const StreamEntry *DcsSequencer::addStream(const uint8_t *data, size_t avail, st
     std::unique_ptr<StreamEntry> e(new StreamEntry);
     const uint32_t nFrames = avail >= 2 ? (static_cast<uint32_t>(data[0]) << 8) | data[1] : 0;
     static const bool noWalker = getenv("DCS_SEQ_NO_WALKER") != nullptr && atoi(getenv("DCS_SEQ_NO_WALKER")) != 0;
-    const bool background = nFrames > kWalkInlineFrames && avail >= 3 && !noWalker;
+    // (a long stream goes to a walker thread -- if one is to be had: where no thread can be made the stream is walked here)
+    WalkerPool::Worker *worker = (nFrames > kWalkInlineFrames && avail >= 3 && !noWalker) ? WalkerPool::get().take() : nullptr;
+    const bool background = worker != nullptr;
     if (nFrames != 0 && avail >= 3 && !background)
     {
         e->index.resize(nFrames);
@@ -406,9 +418,11 @@ const StreamEntry *DcsSequencer::addStream(const uint8_t *data, size_t avail, st
         walking = e.get();
         walkReserved = bound;
         const Walk w{ e.get(), data, avail, bound };
-        walkWorker = WalkerPool::get().take();
+        walkWorker = worker;
         walkWorker->post([this, w] { runWalk(w); });
     }
+    else if (worker != nullptr)
+        WalkerPool::get().give(worker);         // (a stream without a usable container: nothing to walk)
     StreamEntry *r = e.get();
     if (cache)
         streams[key] = std::move(e);
