@@ -34,6 +34,29 @@ __device__ unsigned long long g_idxStamps[16];
 #endif
 
 constexpr int kWaves = 4;               // wavefronts (= streams) per workgroup; they share the tables in LDS
+
+// Fair shares of a SIMD.  A SIMD serves its OLDEST wavefront first: of eight walks on one SIMD the five oldest run at the pace of a
+// lone wavefront and leave (a lone walk uses a fifth of the vector unit), the three youngest get what is left and then finish on a
+// SIMD they cannot fill -- 8 192 streams took 3.9 ms where the instructions issued account for 2.4.  So every walk tells its XCD
+// how many frames it has left (one atomic add every kPaceFrames frames on a word in the XCD's own L2, the answer read a frame
+// later), hears the sum and the number of walks alive, and sets its priority (s_setprio) by where it stands against their mean:
+// the walks with the most left to do go first, all of a launch finish together, and streams of unequal length (a corpus) have
+// their long ones started on at once.  The words are advice only (no result depends on them) and return to zero by themselves:
+// every walk takes back exactly what it has added.  Measured (NOTES 42): 8 192 / 6 144 / 4 096 streams x 256 frames 3.96 / 3.24 /
+// 2.49 -> 3.20 / 2.65 / 2.20 ms, one list unchanged (1.89); a report every 2 to 16 frames, bands of 1 to 16 frames and two
+// levels instead of four all measure within 2 % of each other (variant builds: DCS_EXP_PACE_MODE 1 = two levels, 3 = off).
+#ifndef DCS_EXP_PACE_FRAMES
+#define DCS_EXP_PACE_FRAMES 8
+#endif
+#ifndef DCS_EXP_PACE_BAND
+#define DCS_EXP_PACE_BAND 8
+#endif
+#ifndef DCS_EXP_PACE_MODE
+#define DCS_EXP_PACE_MODE 0
+#endif
+constexpr uint32_t kPaceFrames = DCS_EXP_PACE_FRAMES;
+constexpr uint32_t kPaceBand = DCS_EXP_PACE_BAND;       // frames ahead of / behind the mean that change the priority by one step
+__device__ unsigned long long g_idxPace[8 * 16];        // per XCD (128 bytes apart): frames left | walks alive << 32
 constexpr int kRingDw = 256;            // per wavefront: LDS mirror of the register window, for per-lane gathers
 constexpr int kRecDw = 40;              // staging of one record (37 dwords) or one stream summary (12)
 static_assert(sizeof(DcsFrameIndex) == 148 && sizeof(DcsStreamInfo) == 48 && sizeof(DcsFrameDigest) == 8, "record layouts");
@@ -277,6 +300,7 @@ struct Walk
     uint32_t vBB = 0, vSc1 = 0, vInputs = 0;    // OS93a Type 1: the stream's band-bits codebook, the first level of the scale
                                                 // codebook, inputs per band -- one entry per lane
     uint32_t err = 0;
+    unsigned long long *pace = nullptr;         // this XCD's word of g_idxPace
     // the record
     uint32_t vSplitLo = 0, vSplitHi = 0;        // lane k < 15: split[k] = bitDelta | prv << 16, prvDelta | state << 16
     uint32_t vRecBT = 0;                        // lane i < 16: byte i of the record's bandType field
@@ -790,8 +814,37 @@ template <int KIND>
 __device__ __forceinline__ void walkFrames(Walk &s, uint32_t nFrames, DcsFrameIndex *outRec, DcsFrameDigest *outDigest, uint32_t &valid, uint32_t &payloadBits)
 {
     const uint32_t lane = s.lane;
+    // (the walk's place among the others of its XCD: see g_idxPace)
+    if (lane == 0)
+        __hip_atomic_fetch_add(s.pace, static_cast<unsigned long long>(nFrames) | (1ull << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long vOthers = 0;
+    uint32_t credited = 0;
     for (uint32_t f = 0 ; f < nFrames ; ++f)
     {
+        if ((f & (kPaceFrames - 1)) == 0 && f != 0)
+        {
+            if (lane == 0)
+                vOthers = __hip_atomic_fetch_add(s.pace, 0ull - kPaceFrames, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            credited = f;
+        }
+        else if ((f & (kPaceFrames - 1)) == 1 && f != 1)
+        {
+            const uint32_t sum = rl(static_cast<uint32_t>(vOthers), 0), alive = rl(static_cast<uint32_t>(vOthers >> 32), 0);
+            const int32_t ahead = static_cast<int32_t>((nFrames - f) * alive - sum);       // > 0: more left than the mean
+            const int32_t band = static_cast<int32_t>(alive * kPaceBand);
+#if DCS_EXP_PACE_MODE == 0
+            if (ahead >= band) __builtin_amdgcn_s_setprio(3);
+            else if (ahead >= 0) __builtin_amdgcn_s_setprio(2);
+            else if (ahead >= -band) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+#elif DCS_EXP_PACE_MODE == 1
+            (void)band;
+            if (ahead >= 0) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+#else
+            (void)ahead; (void)band;
+#endif
+        }
         const uint32_t frameBit = s.b.pos;
         IDX_T0(tWalk);
         IDX_CNT(s.b, 8, 1);
@@ -830,6 +883,8 @@ __device__ __forceinline__ void walkFrames(Walk &s, uint32_t nFrames, DcsFrameIn
         if (s.err != 0)
             break;                  // the reference stops the channel on the next tick (:95-116)
     }
+    if (lane == 0)
+        __hip_atomic_fetch_add(s.pace, 0ull - (static_cast<unsigned long long>(nFrames - credited) | (1ull << 32)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // where a stream's results go when the streams of one launch belong to different owners (the pipeline's lists, each
@@ -882,6 +937,7 @@ __global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 
     s.b.nDwValid = (skew + len + 3) / 4;
     s.b.ring = L.ring[wave];
     s.b.lane = lane;
+    s.pace = &g_idxPace[(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u) * 16];        // hwreg(HW_REG_XCC_ID, 0, 4)
     uint32_t *rec = L.rec[wave];
 
     // container (InitChannelStream :1433-1463, InitStreamPlayback :1595-1641): lane l looks at byte l of the stream

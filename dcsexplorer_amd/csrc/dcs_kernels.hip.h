@@ -292,6 +292,7 @@ struct Quarter
     // 1994+, sixteen lanes per frame: band 15 shared by two lanes (dcsMid15).  midEnd: this lane's band 15 ends at the
     // middle; midStart: it starts there, midStraddle: one sample later (a two-zeros code ran across)
     bool midEnd, midStart, midStraddle;
+    bool paced;             // DCS_BATCH_ONE_GENERATION (the same on every lane): the wavefront lowers its priority as it gets on
 };
 
 // byte b (0..15) of four registers; explicit selects so that nothing is indexed in memory
@@ -543,6 +544,7 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const
         // zero product leaves the accumulator as it was).  A two-zeros code with one sample left (:2213-2218)
         // drives the cell past cellEnd, which is how the error is seen at the top of the next round.
         if (round == 0) stamp(9);
+        if (FIRST && round == 2 && Q.paced) __builtin_amdgcn_s_setprio(2);
         // (the round is bounded in samples, not iterations: a symbol is at least one sample, and the loop's only test
         // stays the cell against an end)
         const uint32_t roundLen = round == 0 ? 7u : round == 1 ? 9u : 16u;
@@ -1448,6 +1450,13 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     const Stamper stamp{};
 #endif
     DCS_STAMP(0);
+    // A launch that fits the chip at once (DCS_BATCH_ONE_GENERATION): a SIMD serves its oldest wavefront first, so its four would
+    // finish one after the other and the last one alone, on a SIMD it cannot fill.  Least progress first instead: every wavefront
+    // starts at priority 3 and lowers it as it gets on (2: half way through the unpack, 1: the transform, 0: the stores), so the four
+    // stay within a phase of each other and finish together (NOTES 43: 16 384 mixed frames 15.1 -> 14.2 us).  Not for launches of
+    // several generations: there the staggered finish is what hides the next wavefront's wait for its package (+12 % measured).
+    const bool paced = (a.flags & DCS_BATCH_ONE_GENERATION) != 0;
+    if (paced) __builtin_amdgcn_s_setprio(3);
     constexpr int SUB = subLanes(FPW);              // lanes that unpack one frame together
 #ifndef DCS_DIRECT_MAX_FPW
 #define DCS_DIRECT_MAX_FPW 4
@@ -1640,6 +1649,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
             Quarter Q;
             Q.t0 = d1.y; Q.t1 = d1.z; Q.t2 = d1.w; Q.t3 = d2.x;
             Q.preAdj = d2.y & 0xFFFFu;
+            Q.paced = paced;
 
             const uint64_t bitPos = (streamOff + 2 + static_cast<uint64_t>(hdrLen)) * 8 + bitOff;
             // ---- stage the compressed bytes into the bit pool, byte-swapped so that bit 31 of a dword is the next
@@ -1888,6 +1898,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     waveSync();
 
     DCS_STAMP(5);
+    if (paced) __builtin_amdgcn_s_setprio(1);
     // ---- phase 2: transform passes (8 frames x 8 lanes, or 4 frames x 16 lanes), overlap, emit ------------
     uint32_t *tails = reinterpret_cast<uint32_t *>(L.tails());         // [slot][8] dwords = 16 samples
 #ifdef DCS_STAMPS
@@ -1974,6 +1985,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
         else
             transform93x4(P, W, C, R, x);
         if (s0 == 0) DCS_STAMP(14);
+        if (paced) __builtin_amdgcn_s_setprio(0);
 
         // tail for the successor = output samples 240..255 (:569-575, :805-812): register 15 of every lane.  Lane
         // groups without a frame write to a spare row of the tail array.

@@ -1485,13 +1485,17 @@ extern "C" DcsStatus dcs_batch_create(DcsCtx *ctx,
 }
 
 template <int FPW>
-static hipError_t launch(const DcsKernelArgs &args, hipStream_t stream)
+static hipError_t launch(const DcsKernelArgs &args, hipStream_t stream, int numCUs)
 {
     uint32_t blocks = (args.nChunks + dcsk::kWavesPerBlock - 1) / dcsk::kWavesPerBlock;
     if (args.flags & DCS_BATCH_XCD_RANGES)
         blocks = (blocks + 7u) / 8u * 8u;           // eight ranges of equal length; the padding workgroups find no chunk and leave
+    // (four wavefronts of this kernel per SIMD: a launch of at most CUs x 16 chunks is resident at once; with no more than CUs x 4
+    // every wavefront has a SIMD to itself and there is nothing to pace)
+    const uint32_t cus = static_cast<uint32_t>(numCUs);
+    const uint32_t flags = args.flags | (args.nChunks > cus * 4u && args.nChunks <= cus * 16u ? DCS_BATCH_ONE_GENERATION : 0u);
     dcsk::dcsDecodeKernel<FPW><<<dim3(blocks), dim3(64 * dcsk::kWavesPerBlock), dcsk::ldsBytes(FPW), stream>>>(
-        args.packages, args.tables, args.nChunks, args.flags, args.epoch, args.nJobs, args.pcm, args.handoff, args.err, args.tailsOut,
+        args.packages, args.tables, args.nChunks, flags, args.epoch, args.nJobs, args.pcm, args.handoff, args.err, args.tailsOut,
         args.blob, args.blobLen, args.srcs, args.tailsIn, args.debug);
     return hipGetLastError();
 }
@@ -1505,7 +1509,7 @@ static DcsStatus launchOnce(DcsBatch *b, hipStream_t stream)
         b->epoch = 1;                   // (0 marks words no launch has written; after 2^31 launches of ONE batch the count starts over)
     const DcsKernelArgs args = kernelArgs(b);
     hipError_t e;
-    e = (b->fpw == 16) ? launch<16>(args, stream) : (b->fpw == 8) ? launch<8>(args, stream) : launch<4>(args, stream);
+    e = (b->fpw == 16) ? launch<16>(args, stream, ctx->numCUs) : (b->fpw == 8) ? launch<8>(args, stream, ctx->numCUs) : launch<4>(args, stream, ctx->numCUs);
     if (e != hipSuccess)
     {
         setError(ctx, std::string("kernel launch failed: ") + hipGetErrorString(e));
@@ -1920,7 +1924,7 @@ static DcsStatus decodeLive(DcsCtx *ctx, const uint8_t *blob, size_t blobLen, ui
         args.handoff = l->dHandoff;
         args.epoch = l->epoch;
         args.flags = batchFlags | (layout << DCS_BATCH_IMG_SHIFT);
-        const hipError_t e = fpw == 16 ? launch<16>(args, ctx->stream) : fpw == 8 ? launch<8>(args, ctx->stream) : launch<4>(args, ctx->stream);
+        const hipError_t e = fpw == 16 ? launch<16>(args, ctx->stream, ctx->numCUs) : fpw == 8 ? launch<8>(args, ctx->stream, ctx->numCUs) : launch<4>(args, ctx->stream, ctx->numCUs);
         if (e != hipSuccess)
         {
             setError(ctx, std::string("kernel launch failed: ") + hipGetErrorString(e));
