@@ -286,6 +286,10 @@ struct DcsKernelArgs
 // set by the launch, not by the batch: the chunks fit the chip's wavefront places at once (CUs x 16), so the wavefronts pace
 // themselves (s_setprio by progress, dcs_kernels.hip.h)
 #define DCS_BATCH_ONE_GENERATION 4u
+// likewise set by the launch: more chunks than places, no more than twice as many; bits 8..15 then hold CUs / 8 (workgroup
+// CUs x 4 is the first of the second generation)
+#define DCS_BATCH_TWO_GENERATIONS 8u
+#define DCS_BATCH_CUS8_SHIFT 8
 #define DCS_BATCH_IMG_SHIFT 16          // bits 16..31: the packages' layout word (image dwords | DCS_PKG_SPLIT4; dcsPkgStride)
 #define DCS_BATCH_IMG_MASK  0xFFFFu
 

@@ -1457,6 +1457,14 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     // several generations: there the staggered finish is what hides the next wavefront's wait for its package (+12 % measured).
     const bool paced = (a.flags & DCS_BATCH_ONE_GENERATION) != 0;
     if (paced) __builtin_amdgcn_s_setprio(3);
+    // A launch of two generations (DCS_BATCH_TWO_GENERATIONS; the workgroups behind the first CUs x 4 are the second): the first
+    // generation's wavefronts run above the second's (3 and 2 against 1 and 0, each lowered by one for the transform and the stores), so a
+    // wavefront that starts late does not hold up the stragglers whose places the last ones are waiting for: 32.8 -> 32.2 us on
+    // survey3_65536, 32.6 -> 31.8 on dcs94_65536, nothing on realistic_65536 (NOTES 43; the timeline shows the drain at the end of
+    // the launch two microseconds shorter).
+    const bool twoGen = (a.flags & DCS_BATCH_TWO_GENERATIONS) != 0;
+    const bool secondGen = blockIdx.x >= ((a.flags >> DCS_BATCH_CUS8_SHIFT) & 0xFFu) * 32u;
+    if (twoGen) { if (secondGen) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3); }
     constexpr int SUB = subLanes(FPW);              // lanes that unpack one frame together
 #ifndef DCS_DIRECT_MAX_FPW
 #define DCS_DIRECT_MAX_FPW 4
@@ -1899,6 +1907,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
 
     DCS_STAMP(5);
     if (paced) __builtin_amdgcn_s_setprio(1);
+    if (twoGen) { if (secondGen) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
     // ---- phase 2: transform passes (8 frames x 8 lanes, or 4 frames x 16 lanes), overlap, emit ------------
     uint32_t *tails = reinterpret_cast<uint32_t *>(L.tails());         // [slot][8] dwords = 16 samples
 #ifdef DCS_STAMPS

@@ -7,7 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import dcsexplorer_amd.api as api
-api.lib_path = lambda: os.path.join(ROOT, "dcsexplorer_amd", "libdcs_hip_stamps.so")
+api.lib_path = lambda: os.environ.get("DCS_STAMPS_LIB", os.path.join(ROOT, "dcsexplorer_amd", "libdcs_hip_stamps.so"))
 import dcsexplorer_amd as D
 from dcsexplorer_amd import workloads
 wl = sys.argv[1] if len(sys.argv) > 1 else "dcs94_65536"
