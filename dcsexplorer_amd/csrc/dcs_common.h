@@ -283,12 +283,9 @@ struct DcsKernelArgs
 // resident or through whatever else runs on the chip -- other decode kernels included (dcs_pipeline.hip.h: why that matters); only
 // the first workgroup of a range may wait for the last one of the range before, i.e. until that XCD is through.
 #define DCS_BATCH_XCD_RANGES 2u
-// set by the launch, not by the batch: the chunks fit the chip's wavefront places at once (CUs x 16), so the wavefronts pace
-// themselves (s_setprio by progress, dcs_kernels.hip.h)
-#define DCS_BATCH_ONE_GENERATION 4u
-// likewise set by the launch: more chunks than places, no more than twice as many; bits 8..15 then hold CUs / 8 (workgroup
-// CUs x 4 is the first of the second generation)
-#define DCS_BATCH_TWO_GENERATIONS 8u
+// set by the launch, not by the batch: more than one wavefront per SIMD, so the wavefronts arrange their priorities (s_setprio,
+// dcs_kernels.hip.h); bits 8..15 then hold CUs / 8 (CUs x 4 workgroups are resident at once)
+#define DCS_BATCH_PACED 4u
 #define DCS_BATCH_CUS8_SHIFT 8
 #define DCS_BATCH_IMG_SHIFT 16          // bits 16..31: the packages' layout word (image dwords | DCS_PKG_SPLIT4; dcsPkgStride)
 #define DCS_BATCH_IMG_MASK  0xFFFFu

@@ -292,7 +292,7 @@ struct Quarter
     // 1994+, sixteen lanes per frame: band 15 shared by two lanes (dcsMid15).  midEnd: this lane's band 15 ends at the
     // middle; midStart: it starts there, midStraddle: one sample later (a two-zeros code ran across)
     bool midEnd, midStart, midStraddle;
-    bool paced;             // DCS_BATCH_ONE_GENERATION (the same on every lane): the wavefront lowers its priority as it gets on
+    bool paced;             // (the same on every lane) a wavefront of the launch's last generation: it lowers its priority as it gets on
 };
 
 // byte b (0..15) of four registers; explicit selects so that nothing is indexed in memory
@@ -1450,21 +1450,17 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     const Stamper stamp{};
 #endif
     DCS_STAMP(0);
-    // A launch that fits the chip at once (DCS_BATCH_ONE_GENERATION): a SIMD serves its oldest wavefront first, so its four would
-    // finish one after the other and the last one alone, on a SIMD it cannot fill.  Least progress first instead: every wavefront
-    // starts at priority 3 and lowers it as it gets on (2: half way through the unpack, 1: the transform, 0: the stores), so the four
-    // stay within a phase of each other and finish together (NOTES 43: 16 384 mixed frames 15.1 -> 14.2 us).  Not for launches of
-    // several generations: there the staggered finish is what hides the next wavefront's wait for its package (+12 % measured).
-    const bool paced = (a.flags & DCS_BATCH_ONE_GENERATION) != 0;
-    if (paced) __builtin_amdgcn_s_setprio(3);
-    // A launch of two generations (DCS_BATCH_TWO_GENERATIONS; the workgroups behind the first CUs x 4 are the second): the first
-    // generation's wavefronts run above the second's (3 and 2 against 1 and 0, each lowered by one for the transform and the stores), so a
-    // wavefront that starts late does not hold up the stragglers whose places the last ones are waiting for: 32.8 -> 32.2 us on
-    // survey3_65536, 32.6 -> 31.8 on dcs94_65536, nothing on realistic_65536 (NOTES 43; the timeline shows the drain at the end of
-    // the launch two microseconds shorter).
-    const bool twoGen = (a.flags & DCS_BATCH_TWO_GENERATIONS) != 0;
-    const bool secondGen = blockIdx.x >= ((a.flags >> DCS_BATCH_CUS8_SHIFT) & 0xFFu) * 32u;
-    if (twoGen) { if (secondGen) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3); }
+    // Priorities (DCS_BATCH_PACED, set by launches with more than one wavefront per SIMD).  A SIMD serves its OLDEST wavefront first, so
+    // the four of a SIMD finish one after the other, which is fine while fresh wavefronts keep coming (a staggered finish hides the
+    // newcomers' wait for their packages) and costs at the END of the launch: the last ones finish alone, each on a SIMD it cannot
+    // fill.  So the LAST generation -- the workgroups that find no successors, gridDim - CUs x 4 onwards -- runs least progress
+    // first: every wavefront starts at priority 3 and those lower it as they get on (2: half way through the unpack, 1: the
+    // transform, 0: the stores); among equals the older one still goes first, so earlier generations, which stay at 3, are never
+    // held up by newcomers.  A launch of one generation is all "last".  Measured (NOTES 43): 16 384 mixed frames 15.1 -> 14.3 us,
+    // survey3_65536 32.8 -> 31.9, dcs94_65536 32.6 -> 31.5, realistic_65536 36.7 -> 35.7, sixteen generations unchanged.
+    const bool pacedLaunch = (a.flags & DCS_BATCH_PACED) != 0;
+    const bool paced = pacedLaunch && blockIdx.x + ((a.flags >> DCS_BATCH_CUS8_SHIFT) & 0xFFu) * 32u >= gridDim.x;
+    if (pacedLaunch) __builtin_amdgcn_s_setprio(3);
     constexpr int SUB = subLanes(FPW);              // lanes that unpack one frame together
 #ifndef DCS_DIRECT_MAX_FPW
 #define DCS_DIRECT_MAX_FPW 4
@@ -1907,7 +1903,6 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
 
     DCS_STAMP(5);
     if (paced) __builtin_amdgcn_s_setprio(1);
-    if (twoGen) { if (secondGen) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
     // ---- phase 2: transform passes (8 frames x 8 lanes, or 4 frames x 16 lanes), overlap, emit ------------
     uint32_t *tails = reinterpret_cast<uint32_t *>(L.tails());         // [slot][8] dwords = 16 samples
 #ifdef DCS_STAMPS

@@ -1490,12 +1490,12 @@ static hipError_t launch(const DcsKernelArgs &args, hipStream_t stream, int numC
     uint32_t blocks = (args.nChunks + dcsk::kWavesPerBlock - 1) / dcsk::kWavesPerBlock;
     if (args.flags & DCS_BATCH_XCD_RANGES)
         blocks = (blocks + 7u) / 8u * 8u;           // eight ranges of equal length; the padding workgroups find no chunk and leave
-    // (four wavefronts of this kernel per SIMD: a launch of at most CUs x 16 chunks is resident at once; with no more than CUs x 4
-    // every wavefront has a SIMD to itself and there is nothing to pace)
+    // (priorities, dcs_kernels.hip.h: four wavefronts of this kernel per SIMD, CUs x 16 resident at once; with no more than CUs x 4
+    // chunks every wavefront has a SIMD to itself and there is nothing to arrange)
     const uint32_t cus = static_cast<uint32_t>(numCUs);
-    uint32_t flags = args.flags | (args.nChunks > cus * 4u && args.nChunks <= cus * 16u ? DCS_BATCH_ONE_GENERATION : 0u);
-    if (args.nChunks > cus * 16u && args.nChunks <= cus * 32u && cus % 8u == 0 && cus / 8u < 256u)
-        flags |= DCS_BATCH_TWO_GENERATIONS | ((cus / 8u) << DCS_BATCH_CUS8_SHIFT);
+    uint32_t flags = args.flags;
+    if (args.nChunks > cus * 4u && cus % 8u == 0 && cus / 8u < 256u)
+        flags |= DCS_BATCH_PACED | ((cus / 8u) << DCS_BATCH_CUS8_SHIFT);
     dcsk::dcsDecodeKernel<FPW><<<dim3(blocks), dim3(64 * dcsk::kWavesPerBlock), dcsk::ldsBytes(FPW), stream>>>(
         args.packages, args.tables, args.nChunks, flags, args.epoch, args.nJobs, args.pcm, args.handoff, args.err, args.tailsOut,
         args.blob, args.blobLen, args.srcs, args.tailsIn, args.debug);
