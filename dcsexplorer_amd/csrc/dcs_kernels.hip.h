@@ -292,7 +292,6 @@ struct Quarter
     // 1994+, sixteen lanes per frame: band 15 shared by two lanes (dcsMid15).  midEnd: this lane's band 15 ends at the
     // middle; midStart: it starts there, midStraddle: one sample later (a two-zeros code ran across)
     bool midEnd, midStart, midStraddle;
-    bool paced;             // (the same on every lane) a wavefront of the launch's last generation: it lowers its priority as it gets on
 };
 
 // byte b (0..15) of four registers; explicit selects so that nothing is indexed in memory
@@ -544,7 +543,6 @@ __device__ uint32_t unpack94(const DcsLdsTables *T, uint16_t *row, BR &br, const
         // zero product leaves the accumulator as it was).  A two-zeros code with one sample left (:2213-2218)
         // drives the cell past cellEnd, which is how the error is seen at the top of the next round.
         if (round == 0) stamp(9);
-        if (FIRST && round == 2 && Q.paced) __builtin_amdgcn_s_setprio(2);
         // (the round is bounded in samples, not iterations: a symbol is at least one sample, and the loop's only test
         // stays the cell against an end)
         const uint32_t roundLen = round == 0 ? 7u : round == 1 ? 9u : 16u;
@@ -1191,6 +1189,7 @@ struct PassLane
     uint32_t *rowC;         // the frame's spectrum row in the tile; reused as transpose scratch once it is in registers
     int l;                  // lane inside the group
     uint32_t shiftPair;     // volShift | volShift << 16
+    bool paced;             // a wavefront of the launch's last generation (see the kernel): it lowers its priority as the transform gets on
 #ifdef DCS_STAMPS_XFORM
     Stamper stamp;
 #endif
@@ -1308,6 +1307,7 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const TwA &W, c
         x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
     }
     waveSync();         // the row is reused by the second transpose
+    if (P.paced) __builtin_amdgcn_s_setprio(2);
     // ---- layout A: point p = 8r + l.  pre-pass 3 (:458-471) then stages d = 32, 16, 8 (:480-524) -------
 #pragma unroll
     for (int r = 0 ; r < 8 ; ++r)
@@ -1318,6 +1318,7 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const TwA &W, c
     stageA<true, 4, 3>(x, W, R);
     stageA<true, 2, 2>(x, W, R);
     stageA<true, 1, 1>(x, W, R);
+    if (P.paced) __builtin_amdgcn_s_setprio(1);
     // ---- transpose to layout B: point p = 16 l' + r' lives in row (p >> 4), position (p & 15) ---------------
 #pragma unroll
     for (int r = 0 ; r < 16 ; ++r)
@@ -1331,6 +1332,7 @@ __device__ __forceinline__ void transform94x8(const PassLane &P, const TwA &W, c
     }
     // ---- stages d = 4, 2, 1 ------------------------------------------------------------------------------
     stageB<true, 4, 3>(x, C.k + DCS_K94_TWB, R);
+    if (P.paced) __builtin_amdgcn_s_setprio(0);
     stageB<true, 2, 2>(x, C.k + DCS_K94_TWB + 2, R);
     stageB<true, 1, 1>(x, C.k + DCS_K94_TWB + 6, R);
     // volume shift (:532-534); at full volume there is none
@@ -1366,6 +1368,7 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const TwA &W, c
         }
     }
     DCS_XSTAMP(8);
+    if (P.paced) __builtin_amdgcn_s_setprio(2);
     // ---- stages d = 64, 32, 16 (wrapping) (:742-778) ------------------------------------------------------
     stageA<false, 4, 3>(x, W, R);
     stageA<false, 2, 2>(x, W, R);
@@ -1397,9 +1400,11 @@ __device__ __forceinline__ void transform93x4(const PassLane &P, const TwA &W, c
     for (int r = 0 ; r < 16 ; ++r)
         x[r] = y[r];
     DCS_XSTAMP(10);
+    if (P.paced) __builtin_amdgcn_s_setprio(1);
     // ---- stages d = 8, 4, 2, 1 -----------------------------------------------------------------------------
     stageB<false, 8, 4>(x, C.k + DCS_K93_TWB, R);
     stageB<false, 4, 3>(x, C.k + DCS_K93_TWB + 1, R);
+    if (P.paced) __builtin_amdgcn_s_setprio(0);
     stageB<false, 2, 2>(x, C.k + DCS_K93_TWB + 3, R);
     stageB<false, 1, 1>(x, C.k + DCS_K93_TWB + 7, R);
     DCS_XSTAMP(11);
@@ -1454,10 +1459,12 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     // the four of a SIMD finish one after the other, which is fine while fresh wavefronts keep coming (a staggered finish hides the
     // newcomers' wait for their packages) and costs at the END of the launch: the last ones finish alone, each on a SIMD it cannot
     // fill.  So the LAST generation -- the workgroups that find no successors, gridDim - CUs x 4 onwards -- runs least progress
-    // first: every wavefront starts at priority 3 and those lower it as they get on (2: half way through the unpack, 1: the
-    // transform, 0: the stores); among equals the older one still goes first, so earlier generations, which stay at 3, are never
-    // held up by newcomers.  A launch of one generation is all "last".  Measured (NOTES 43): 16 384 mixed frames 15.1 -> 14.3 us,
-    // survey3_65536 32.8 -> 31.9, dcs94_65536 32.6 -> 31.5, realistic_65536 36.7 -> 35.7, sixteen generations unchanged.
+    // first where it counts, at the end: every wavefront starts at priority 3 and those lower it as the transform gets on (2 behind
+    // the pre-passes, 1 at the second transpose, 0 for the last stages and the stores); among equals the older one still goes first,
+    // so earlier generations, which stay at 3, are never held up by newcomers.  A launch of one generation is all "last".
+    // Measured (NOTES 43): survey3_65536 32.8 -> 31.1 us, dcs94_65536 32.6 -> 30.8, realistic_65536 36.7 -> 35.4, 16 384 mixed
+    // frames 15.1 -> 14.3, sixteen generations 444 -> 442; steps earlier in the wavefront's life (the unpack rounds) or later (the
+    // stores) measured worse.
     const bool pacedLaunch = (a.flags & DCS_BATCH_PACED) != 0;
     const bool paced = pacedLaunch && blockIdx.x + ((a.flags >> DCS_BATCH_CUS8_SHIFT) & 0xFFu) * 32u >= gridDim.x;
     if (pacedLaunch) __builtin_amdgcn_s_setprio(3);
@@ -1653,7 +1660,6 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
             Quarter Q;
             Q.t0 = d1.y; Q.t1 = d1.z; Q.t2 = d1.w; Q.t3 = d2.x;
             Q.preAdj = d2.y & 0xFFFFu;
-            Q.paced = paced;
 
             const uint64_t bitPos = (streamOff + 2 + static_cast<uint64_t>(hdrLen)) * 8 + bitOff;
             // ---- stage the compressed bytes into the bit pool, byte-swapped so that bit 31 of a dword is the next
@@ -1902,7 +1908,6 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
     waveSync();
 
     DCS_STAMP(5);
-    if (paced) __builtin_amdgcn_s_setprio(1);
     // ---- phase 2: transform passes (8 frames x 8 lanes, or 4 frames x 16 lanes), overlap, emit ------------
     uint32_t *tails = reinterpret_cast<uint32_t *>(L.tails());         // [slot][8] dwords = 16 samples
 #ifdef DCS_STAMPS
@@ -1978,6 +1983,7 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
 #endif
         P.l = lane & ((1 << lpfShift) - 1);
         P.shiftPair = static_cast<uint32_t>(myShift) * 0x00010001u;
+        P.paced = paced && s0 + n >= nSlots;            // (the chunk's last pass)
 
         uint32_t x[16];
         BflyRegs R;
@@ -1989,7 +1995,6 @@ dcsDecodeKernel(uint8_t *kPackages, const DcsDevTables *kTables, uint32_t kNChun
         else
             transform93x4(P, W, C, R, x);
         if (s0 == 0) DCS_STAMP(14);
-        if (paced) __builtin_amdgcn_s_setprio(0);
 
         // tail for the successor = output samples 240..255 (:569-575, :805-812): register 15 of every lane.  Lane
         // groups without a frame write to a spare row of the tail array.
