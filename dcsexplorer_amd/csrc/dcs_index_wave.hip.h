@@ -42,7 +42,10 @@ constexpr int kWaves = 4;               // wavefronts (= streams) per workgroup;
 // later), hears the sum and the number of walks alive, and sets its priority (s_setprio) by where it stands against their mean:
 // the walks with the most left to do go first, all of a launch finish together, and streams of unequal length (a corpus) have
 // their long ones started on at once.  The words are advice only (no result depends on them) and return to zero by themselves:
-// every walk takes back exactly what it has added.  Measured (NOTES 42): 8 192 / 6 144 / 4 096 streams x 256 frames 3.96 / 3.24 /
+// every walk takes back exactly what it has added.  Every launch has words of its own (`paceSlot`): launches that overlap -- lists
+// in flight -- are NOT paced against each other, between them the older wavefront goes first as before, so the older list's walk
+// finishes first and its planner, packer and decode overlap the younger lists' walks (one set of words for all: eight lists in
+// flight 8.5 -> 7.9 x 10^10 samples/s; per launch: see NOTES 42).  Measured (NOTES 42): 8 192 / 6 144 / 4 096 streams x 256 frames 3.96 / 3.24 /
 // 2.49 -> 3.20 / 2.65 / 2.20 ms, one list unchanged (1.89); a report every 2 to 16 frames, bands of 1 to 16 frames and two
 // levels instead of four all measure within 2 % of each other (variant builds: DCS_EXP_PACE_MODE 1 = two levels, 3 = off).
 #ifndef DCS_EXP_PACE_FRAMES
@@ -56,7 +59,8 @@ constexpr int kWaves = 4;               // wavefronts (= streams) per workgroup;
 #endif
 constexpr uint32_t kPaceFrames = DCS_EXP_PACE_FRAMES;
 constexpr uint32_t kPaceBand = DCS_EXP_PACE_BAND;       // frames ahead of / behind the mean that change the priority by one step
-__device__ unsigned long long g_idxPace[8 * 16];        // per XCD (128 bytes apart): frames left | walks alive << 32
+constexpr uint32_t kPaceSlots = 16;     // launches in flight that keep words of their own (a launch's number modulo this)
+__device__ unsigned long long g_idxPace[kPaceSlots][8 * 16];    // per launch slot and XCD (128 bytes apart): frames left | walks alive << 32
 constexpr int kRingDw = 256;            // per wavefront: LDS mirror of the register window, for per-lane gathers
 constexpr int kRecDw = 40;              // staging of one record (37 dwords) or one stream summary (12)
 static_assert(sizeof(DcsFrameIndex) == 148 && sizeof(DcsStreamInfo) == 48 && sizeof(DcsFrameDigest) == 8, "record layouts");
@@ -901,7 +905,7 @@ struct StreamOut
 // wavefronts -- a launch of 8 192 streams, eight per SIMD, then ran in two generations; three more spilled SGPRs are cheaper)
 __global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void dcsIndexWaveKernel(uintptr_t blobBase, const DcsStreamLoc *locs, uint32_t nStreams,
                                                                   const DcsDevTables *tables, DcsFrameIndex *out, DcsStreamInfo *infos,
-                                                                  DcsFrameDigest *digest, const StreamOut *outs)
+                                                                  DcsFrameDigest *digest, const StreamOut *outs, uint32_t paceSlot)
 {
     __shared__ IndexLds L;
     {
@@ -937,7 +941,7 @@ __global__ __launch_bounds__(kWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 
     s.b.nDwValid = (skew + len + 3) / 4;
     s.b.ring = L.ring[wave];
     s.b.lane = lane;
-    s.pace = &g_idxPace[(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u) * 16];        // hwreg(HW_REG_XCC_ID, 0, 4)
+    s.pace = &g_idxPace[paceSlot & (kPaceSlots - 1)][(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u) * 16];        // hwreg(HW_REG_XCC_ID, 0, 4)
     uint32_t *rec = L.rec[wave];
 
     // container (InitChannelStream :1433-1463, InitStreamPlayback :1595-1641): lane l looks at byte l of the stream

@@ -2011,8 +2011,9 @@ static hipError_t launchIndexWave(hipStream_t stream, uintptr_t blobBase, const 
     if (nStreams == 0)          // (an empty round is no launch: a zero-block grid is an error to some runtimes)
         return hipSuccess;
     const uint32_t blocks = (nStreams + dcsidx::kWaves - 1) / dcsidx::kWaves;
+    static std::atomic<uint32_t> launches{ 0 };         // (the walks of a launch pace themselves against each other, not against other launches')
     hipLaunchKernelGGL(dcsidx::dcsIndexWaveKernel, dim3(blocks), dim3(dcsidx::kWaves * 64), 0, stream, blobBase, dLocs, nStreams, dTables,
-                       dOut, dInfos, dDigest, dOuts);
+                       dOut, dInfos, dDigest, dOuts, launches.fetch_add(1, std::memory_order_relaxed));
     return hipGetLastError();
 }
 
