@@ -1773,10 +1773,14 @@ static void liveDestroy(DcsCtx *ctx)
 }
 
 // room for `bytes` in one of the live arenas (pinned or device); what it held is not kept
-static hipError_t liveRoom(uint8_t **buf, size_t *cap, size_t bytes, bool pinned)
+static hipError_t liveRoom(uint8_t **buf, size_t *cap, size_t bytes, bool pinned, size_t first = 0)
 {
     if (bytes <= *cap)
         return hipSuccess;
+    // (`first`: what the arena starts with.  A decoder's look-ahead grows 64 -> 512 -> 4 096 frames within its first three calls, and
+    // every step used to free and pin the arenas again -- 0.7-1.5 ms of a new context's first stream, NOTES 44)
+    if (*buf == nullptr && bytes < first)
+        bytes = first;
     if (*buf != nullptr)
     {
         (void)(pinned ? hipHostFree(*buf) : hipFree(*buf));
@@ -1798,6 +1802,8 @@ static hipError_t liveRoom(uint8_t **buf, size_t *cap, size_t bytes, bool pinned
     return hipSuccess;
 }
 
+// the pinned arenas' first size: what a look-ahead of 4 096 frames needs (packages up ~ 340 B a frame, PCM + error word + tail down)
+static const size_t kLiveFirstUp = size_t(3) << 19, kLiveFirstDown = size_t(9) << 18;
 // batches beyond this go the resident-batch way (buffers from the context's bounded cache): the live arenas never shrink
 static const uint32_t kLiveMaxJobs = 1u << 17;
 
@@ -1864,7 +1870,7 @@ static DcsStatus decodeLive(DcsCtx *ctx, const uint8_t *blob, size_t blobLen, ui
     const size_t pcmBytes = static_cast<size_t>(nJobs) * DCS_FRAME_SAMPLES * sizeof(int16_t), errBytes = static_cast<size_t>(nJobs) * sizeof(uint32_t);
     const size_t downBytes = pcmBytes + errBytes + static_cast<size_t>(nJobs) * 16 * sizeof(int16_t);
     const bool zcDown = nJobs <= l->zcDownFrames;
-    HIPCHK(ctx, liveRoom(&l->hDown, &l->hDownCap, downBytes, true));
+    HIPCHK(ctx, liveRoom(&l->hDown, &l->hDownCap, downBytes, true, kLiveFirstDown));
     if (!zcDown)
         HIPCHK(ctx, liveRoom(&l->dDown, &l->dDownCap, downBytes, false));
 
@@ -1882,7 +1888,7 @@ static DcsStatus decodeLive(DcsCtx *ctx, const uint8_t *blob, size_t blobLen, ui
         const size_t offPkg = (offSrcs + srcBytes + 255) & ~size_t(255);
         const size_t pkgBytes = static_cast<size_t>(nChunks) * dcsPkgStride(fpw, layout);
         const size_t upBytes = offPkg + pkgBytes;
-        HIPCHK(ctx, liveRoom(&l->hUp, &l->hUpCap, upBytes, true));
+        HIPCHK(ctx, liveRoom(&l->hUp, &l->hUpCap, upBytes, true, kLiveFirstUp));
         if (tailBytes)
             memcpy(l->hUp, tailsIn, tailBytes);
         if (srcBytes)
