@@ -1183,7 +1183,7 @@ def run_rank(args):
         except (KeyError, TypeError):
             pass
         hard_exit = hard_exit or sec.abandoned is not None
-        emit(out, hard_exit=hard_exit and world == 1)
+        emit(out, hard_exit=hard_exit and world == 1, code=3 if (hard_exit and os.environ.get("DCS_BENCH_STRICT_EXIT", "0") not in ("", "0")) else 0)
 
     if hard_exit:
         # some thread of this process never came back (it may be inside a HIP call): no orderly tear-down.  The other ranks
@@ -1193,7 +1193,9 @@ def run_rank(args):
         except Exception:
             pass
         sys.stderr.flush()
-        os._exit(0)
+        # (the line is out and `value` is whole; an optional section was given up, which the line says.  Exit code 0 by default -- a
+        # harness that reads the line must not take the run for failed --, DCS_BENCH_STRICT_EXIT=1 turns it into 3 for a CI: ADVICE r5)
+        os._exit(3 if os.environ.get("DCS_BENCH_STRICT_EXIT", "0") not in ("", "0") else 0)
     for bt, _ in extra:
         bt.close()
     batch.close()
