@@ -360,21 +360,7 @@ __device__ __forceinline__ void chainHi(uint32_t v, uint32_t &state, uint32_t &s
 // walk's scalar instructions): S = bits walked in this look | (samples to go - 1) << 16 -- the single-code chains' state as
 // it is, the several-codes chains' after subtracting DCS_IDX_MULTI_SAMPLES << 16.  In goes (samples - 1) << 16; out comes
 // 0xFFFF0000 (all samples accounted for) or 0xFFFE0000 (the last code was a two-zeros code with one sample to go).
-// A look that serves SEVERAL bands (round 6): when a band's run ends inside the look's 128 candidates and the next Huffman-coded band
-// has the same codebook and starts right there (no fixed-width band in between: `cont` bit h, worked out per frame by scan94),
-// the chain carries on with that band's sample count -- no gather, no table reads.  The bands' own results go where the caller's loop
-// would have put them: the run's end flags into `runEnds`, q behind band h into lane h of `vQ`.
-struct RunCont
-{
-    uint32_t cont;          // bit h: the Huffman-coded band after band h may carry on in band h's look
-    uint32_t left;          // Huffman-coded bands still to walk (bit mask), band h already taken out
-    uint32_t h;             // the band being walked
-    uint32_t G;             // bits of the fixed-width bands before it
-    uint32_t vRunS;         // lane i: band i's state word
-    uint32_t runEnds, vQ, lane;
-};
-template <bool CONT>
-__device__ __forceinline__ uint32_t huffRunS(WaveBits &b, const uint16_t *book, uint32_t shift, const uint8_t *multi, uint32_t S, RunCont *rc = nullptr)
+__device__ __forceinline__ uint32_t huffRunS(WaveBits &b, const uint16_t *book, uint32_t shift, const uint8_t *multi, uint32_t S)
 {
     constexpr uint32_t kM = static_cast<uint32_t>(DCS_IDX_MULTI_SAMPLES) << 16;
     static_assert((DCS_IDX_MULTI_SAMPLES & (DCS_IDX_MULTI_SAMPLES - 1)) == 0, "the test below masks samples-to-go with a power of two");
@@ -402,37 +388,21 @@ __device__ __forceinline__ uint32_t huffRunS(WaveBits &b, const uint16_t *book, 
         // for the second).
         uint32_t se = 0;
         IDX_T0(tChain);
-        for (;;)
+        if (S >= kM)                                        // more than DCS_IDX_MULTI_SAMPLES samples to go
         {
-            if (S >= kM)                                        // more than DCS_IDX_MULTI_SAMPLES samples to go
-            {
-                S -= kM;
-                if (!CONT || (S & 64u) == 0)                    // (a band that carries on may start in the second half)
-                    chain(vMultiLo, S, se);
-                if (static_cast<int32_t>(S) >= 0)               // (left the first 64 candidates with samples to go)
-                    chainHi(vMultiHi, S, se);
-                S += kM;
-            }
-            if ((S & ((0xFFFF0000u & ~(kM - 0x10000u)) | 0xFF80u)) == 0)     // at most DCS_IDX_MULTI_SAMPLES to go, and inside the 128 candidates
-            {
-                if ((S & 64u) == 0)
-                    chain(vSingleLo, S, se);
-                if (static_cast<int32_t>(S) >= 0)               // (the first half left, or never entered)
-                    chainHi(vSingleHi, S, se);
-                b.hi = umax(b.hi, b.pos + maxBits + (S & 0xFFFFu) - (se & 0xFFFFu));       // the last symbol's look
-            }
-            if (!CONT)
-                break;
-            // the band is through, the next one shares its codebook and begins at a candidate of this look: carry on
-            if (static_cast<int32_t>(S) >= 0 || ((rc->cont >> rc->h) & 1u) == 0 || (S & 0xFF80u) != 0)
-                break;
-            const uint32_t at = S & 0xFFFFu;
-            rc->runEnds &= S;
-            rc->vQ = rc->lane == rc->h ? b.pos + at - rc->G : rc->vQ;
-            rc->h = static_cast<uint32_t>(__builtin_ctz(rc->left));
-            rc->left &= rc->left - 1;
-            S = at | rl(rc->vRunS, rc->h);
-            IDX_CNT(b, 6, 1);
+            S -= kM;
+            chain(vMultiLo, S, se);
+            if (static_cast<int32_t>(S) >= 0)               // (left the first 64 candidates with samples to go)
+                chainHi(vMultiHi, S, se);
+            S += kM;
+        }
+        if ((S & ((0xFFFF0000u & ~(kM - 0x10000u)) | 0xFF80u)) == 0)     // at most DCS_IDX_MULTI_SAMPLES to go, and inside the 128 candidates
+        {
+            if ((S & 64u) == 0)
+                chain(vSingleLo, S, se);
+            if (static_cast<int32_t>(S) >= 0)               // (the first half left, or never entered)
+                chainHi(vSingleHi, S, se);
+            b.hi = umax(b.hi, b.pos + maxBits + (S & 0xFFFFu) - (se & 0xFFFFu));       // the last symbol's look
         }
         IDX_ACC(b, 3, tChain);
         const uint32_t off = S & 0xFFFFu;
@@ -447,7 +417,7 @@ __device__ __forceinline__ uint32_t huffRunS(WaveBits &b, const uint16_t *book, 
 // the form band 15's two halves use: `rem` samples -> what is left: 0, or -1 when the last code was a two-zeros code with one sample to go
 __device__ __forceinline__ int huffRun(WaveBits &b, const uint16_t *book, uint32_t maxBits, const uint8_t *multi, int rem)
 {
-    return (static_cast<int32_t>(huffRunS<false>(b, book, 32u - maxBits, multi, static_cast<uint32_t>(rem - 1) << 16)) >> 16) + 1;
+    return (static_cast<int32_t>(huffRunS(b, book, 32u - maxBits, multi, static_cast<uint32_t>(rem - 1) << 16)) >> 16) + 1;
 }
 
 // The frame header of a 1994+ frame: one band-type delta code per populated band (:1780-1834), lane k < nBands
@@ -582,35 +552,6 @@ __device__ void scan94(Walk &s)
     IDX_ACC(b, 9, tSetup);
     IDX_T0(tLoop);
     const uint32_t huffMask = static_cast<uint32_t>(__ballot(huffBand));
-#ifdef DCS_EXP_CONT
-    // bit h: the next Huffman-coded band behind band h (below band 15) has band h's codebook and no fixed-width band lies between
-    // them (one key: codebook, look-ahead, fixed-width bits before), so its run may carry on in band h's look
-    uint32_t contMask;
-    {
-        const uint32_t hm = huffMask & 0x7FFFu;
-        const uint32_t above = lane < 31 ? hm >> (lane + 1) : 0u;
-        const uint32_t next = lane + 1 + static_cast<uint32_t>(__builtin_ctz(above | 0x80000000u));
-        const uint32_t key = (vRunBook >> 1) | (width << 11) | (fixedBefore << 16);
-        const uint32_t nkey = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>((next & 63u) << 2), static_cast<int>(key)));
-        contMask = static_cast<uint32_t>(__ballot(huffBand && lane < 15 && above != 0 && nkey == key));
-    }
-    RunCont rc;
-    rc.cont = contMask; rc.vRunS = vRunS; rc.lane = lane; rc.runEnds = runEnds; rc.vQ = vQ;
-    for (rc.left = huffMask & 0x7FFFu ; rc.left != 0 ; )
-    {
-        rc.h = static_cast<uint32_t>(__builtin_ctz(rc.left));
-        rc.left &= rc.left - 1;
-        const uint32_t h0 = rc.h;
-        rc.G = rl(fixedBefore, h0);
-        const uint16_t *book = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(&T) + rl(vRunBook, h0));
-        const uint8_t *multi = &s.L->multi94[0][0] + rl(vRunMulti, h0);
-        b.pos = q + rc.G;
-        rc.runEnds &= huffRunS<true>(b, book, rl(vRunShift, h0), multi, rl(vRunS, h0), &rc);
-        q = b.pos - rc.G;
-        rc.vQ = lane == rc.h ? q : rc.vQ;
-    }
-    runEnds = rc.runEnds; vQ = rc.vQ;
-#else
     for (uint32_t left = huffMask & 0x7FFFu ; left != 0 ; left &= left - 1)
     {
         const uint32_t h = static_cast<uint32_t>(__builtin_ctz(left));
@@ -618,11 +559,10 @@ __device__ void scan94(Walk &s)
         const uint16_t *book = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(&T) + rl(vRunBook, h));
         const uint8_t *multi = &s.L->multi94[0][0] + rl(vRunMulti, h);
         b.pos = q + G;
-        runEnds &= huffRunS<false>(b, book, rl(vRunShift, h), multi, rl(vRunS, h));
+        runEnds &= huffRunS(b, book, rl(vRunShift, h), multi, rl(vRunS, h));
         q = b.pos - G;
         vQ = lane == h ? q : vQ;
     }
-#endif
     if ((runEnds >> 16) != 0xFFFFu)
         s.err |= DCS_FRAME_STOP;                                // two zeros with one slot left (:2213-2218)
     if ((huffMask & 0x8000u) != 0)
