@@ -917,6 +917,55 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
     const DcsSlot *cs = slots + static_cast<size_t>(chunk) * FPW;
     const uint32_t imgDw = dcsPkgImgDw(layout);
     const bool split4 = (layout & DCS_PKG_SPLIT4) != 0;
+    // (order: the image first -- its loads need nothing but the plan's slots, and a wavefront issues its loads in program order: behind the
+    // slot -> source -> record chain of the descriptors they waited for three round trips before they were even asked for)
+    // the image of the bit pool: the chunk's runs of stream dwords, in bit order; zero between them (the runs lie one behind the
+    // other, each on a 16-byte boundary: gaps of at most three dwords) and behind the last one
+    uint32_t *img = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffPool(FPW, layout));
+    uint32_t end = 0;
+    for (int k = 0 ; k < FPW ; ++k)
+    {
+        const uint32_t n = cs[k].runNDw, st = cs[k].runStartDw, o = cs[k].runPoolOff;
+        if (n == 0)
+            break;
+        if (o + n > imgDw || o < end)
+            continue;                           // (cannot happen: the image covers every run of the plan, in order)
+        for (uint32_t i = end + static_cast<uint32_t>(lane) ; i < o ; i += 64)
+            img[i] = 0;
+        // (four dwords a lane where the run and the blob have them: the run starts on a 16-byte boundary of the image, the stream
+        // bytes on a dword boundary only)
+        const uint32_t n4 = (static_cast<uint64_t>(st) + n) * 4 <= blobLen ? n & ~3u : 0u;
+        for (uint32_t i = static_cast<uint32_t>(lane) * 4 ; i < n4 ; i += 256)
+        {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(blob + (static_cast<uint64_t>(st) + i) * 4);
+            const uint32_t w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+            *reinterpret_cast<uint4 *>(img + o + i) = make_uint4(__builtin_bswap32(w0), __builtin_bswap32(w1), __builtin_bswap32(w2), __builtin_bswap32(w3));
+        }
+        for (uint32_t i = n4 + static_cast<uint32_t>(lane) ; i < n ; i += 64)
+        {
+            const uint64_t b0 = (static_cast<uint64_t>(st) + i) * 4;
+            uint32_t w = 0;
+            if (b0 + 4 <= blobLen)
+                w = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(blob + b0));
+            else
+                for (int j = 0 ; j < 4 ; ++j)
+                    if (b0 + j < blobLen)
+                        w |= static_cast<uint32_t>(blob[b0 + j]) << (24 - 8 * j);
+            img[o + i] = w;
+        }
+        end = o + n;
+    }
+    {
+        // (behind the last run: dwords up to the next 16-byte boundary, then sixteen bytes a lane)
+        const uint32_t end4 = (end + 3u) & ~3u;
+        for (uint32_t i = end + static_cast<uint32_t>(lane) ; i < end4 && i < imgDw ; i += 64)
+            img[i] = 0;
+        for (uint32_t i = end4 + static_cast<uint32_t>(lane) * 4 ; i + 4 <= imgDw ; i += 256)
+            *reinterpret_cast<uint4 *>(img + i) = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = (imgDw & ~3u) + static_cast<uint32_t>(lane) ; i < imgDw ; i += 64)
+            if (i >= end4)
+                img[i] = 0;
+    }
     // EVERY byte of the package is written here, once (round 5: the buffer used to be cleared first, 700 MB of writes in front of
     // the packer for 2 M frames): what does not apply is written as zero, as the host packer's memset leaves it.
     // slot `lane`: its first 16 bytes, the descriptor head (the first 40 bytes of what DcsSrcDesc would be) with poolOff and bpl
@@ -997,35 +1046,6 @@ __global__ __launch_bounds__(256) void dcsPackKernel(const DcsSlot *slots, uint3
         for (uint32_t i = padFrom / 4 + static_cast<uint32_t>(lane) ; i < padTo / 4 ; i += 64)
             reinterpret_cast<uint32_t *>(pkg)[i] = 0;
     }
-    // the image of the bit pool: the chunk's runs of stream dwords, in bit order; zero between them (the runs lie one behind the
-    // other, each on a 16-byte boundary: gaps of at most three dwords) and behind the last one
-    uint32_t *img = reinterpret_cast<uint32_t *>(pkg + dcsPkgOffPool(FPW, layout));
-    uint32_t end = 0;
-    for (int k = 0 ; k < FPW ; ++k)
-    {
-        const uint32_t n = cs[k].runNDw, st = cs[k].runStartDw, o = cs[k].runPoolOff;
-        if (n == 0)
-            break;
-        if (o + n > imgDw || o < end)
-            continue;                           // (cannot happen: the image covers every run of the plan, in order)
-        for (uint32_t i = end + static_cast<uint32_t>(lane) ; i < o ; i += 64)
-            img[i] = 0;
-        for (uint32_t i = static_cast<uint32_t>(lane) ; i < n ; i += 64)
-        {
-            const uint64_t b0 = (static_cast<uint64_t>(st) + i) * 4;
-            uint32_t w = 0;
-            if (b0 + 4 <= blobLen)
-                w = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(blob + b0));
-            else
-                for (int j = 0 ; j < 4 ; ++j)
-                    if (b0 + j < blobLen)
-                        w |= static_cast<uint32_t>(blob[b0 + j]) << (24 - 8 * j);
-            img[o + i] = w;
-        }
-        end = o + n;
-    }
-    for (uint32_t i = end + static_cast<uint32_t>(lane) ; i < imgDw ; i += 64)
-        img[i] = 0;
 }
 }   // namespace
 
